@@ -1,0 +1,173 @@
+#!/usr/bin/env python3
+"""bench.py -- graphs/s of the GIN (dim 100) hot path on molhiv-shaped synthetic graphs.
+
+    python bench.py --gpus N --steps K --warmup W [--graphs G_PER_GPU]
+
+A "step" = one full batched forward of the resident batch through the C ABI (flowgnn_run):
+batched load_graph (CSR build) -> atom encoder -> 5 x (aggregation + node MLP) -> mean-pool +
+head, for G_PER_GPU graphs per GPU (weak scaling), followed for N > 1 by the RCCL all-gather that
+concatenates the per-graph results.  Inputs are resident in HBM when the timed region starts (the
+reference also times kernel execution only: run_experiments.sh:44).  Rank 0 prints ONE JSON line.
+
+The default batch is the "roofline batch" of SURVEY 8d: 2^18 graphs per GPU, so that every
+[N_tot][100] fp32 tensor (2.7 GB) is far larger than the 256 MiB Infinity Cache.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+FP32_MFMA_PEAK_TF = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 / 32x32x2_f32, dense
+FPGA_U50_GRAPHS_PER_S = 20214.0  # GIN molhiv on Alveo U50 (other hardware; informational)
+
+
+def algorithmic(n_tot: int, e_tot: int):
+    """Per-launch algorithmic work of the two per-layer kernels (DESIGN.md 'Kernels'):
+    aggregation bytes = N*D*4 (read h once) + N*D*4 (write) + E*(8 index + 12 attrs)   [SURVEY 8d]
+    node-MLP flops    = N * 2*(100*200 + 200*100)                                        [SURVEY 8d]"""
+    agg_bytes = n_tot * 100 * 4 * 2 + e_tot * 20
+    mlp_flops = n_tot * 2 * (100 * 200 + 200 * 100)
+    return agg_bytes, mlp_flops
+
+
+def cpu_baseline(batch, w, budget_s: float = 15.0):
+    """The oracle (CPU restatement of the reference, kind='port') timed on this host's cores on a
+    bounded sample of the same workload."""
+    from oracle import oracle
+    cores = os.cpu_count() or 1
+    probe = batch.slice(0, min(256, batch.num_graphs))
+    t0 = time.perf_counter()
+    oracle.gin_forward(probe, [w], nthreads=1)
+    t1 = time.perf_counter()
+    rate1 = probe.num_graphs / (t1 - t0)
+    n = int(min(batch.num_graphs, max(256, rate1 * cores * budget_s * 0.6)))
+    sample = batch.slice(0, n)
+    t0 = time.perf_counter()
+    oracle.gin_forward(sample, [w], nthreads=cores)
+    t1 = time.perf_counter()
+    return {"value": n / (t1 - t0), "unit": "graphs/s", "cores": cores, "kind": "port",
+            "sample": f"first {n} graphs of the bench batch, oracle/gin_oracle.c, OpenMP over graphs, {cores} threads",
+            "single_core_value": rate1}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--graphs", type=int, default=1 << 18, help="graphs per GPU per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    from flowgnn_amd import Engine, graphpack as gp, weights
+
+    batch = gp.synth_molhiv_batch(args.graphs, seed=1234 + rank)  # each rank its own shard of the job
+    w = weights.synth_gin_weights(seed=7)
+    eng = Engine("GIN", device=local_rank)
+    eng.set_weights(w)
+    eng.set_batch(batch)
+    G, N, E = batch.num_graphs, batch.total_nodes, batch.total_edges
+
+    out_local = torch.empty(G, dtype=torch.float32, device="cuda")
+    eng.set_results_buffer(out_local.data_ptr())
+    out_all = torch.empty(G * world, dtype=torch.float32, device="cuda") if world > 1 else out_local
+
+    def step():
+        eng.run()
+        if world > 1:
+            eng.sync()  # results complete before the collective reads them
+            dist.all_gather_into_tensor(out_all, out_local)
+
+    for _ in range(args.warmup):
+        step()
+    eng.sync()
+    eng.profile_enable(True)  # HIP events around every kernel launch, on the engine's stream
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    eng.sync()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t1 = time.perf_counter()
+    elapsed = t1 - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    prof = eng.profile_read()
+    eng.profile_enable(False)
+
+    ok = bool(torch.isfinite(out_all).all().item())
+
+    if rank == 0:
+        total_graphs = G * world * args.steps  # every rank carries the same number of graphs
+        value = total_graphs / elapsed
+        agg_bytes, mlp_flops = algorithmic(N, E)
+        kern = {k: (v["total_ms"] / max(v["launches"], 1)) for k, v in prof.items()}
+        dominant = max(prof.items(), key=lambda kv: kv[1]["total_ms"])[0] if prof else None
+        roof = None
+        if dominant == "gin_aggregate":
+            ach = agg_bytes / (kern[dominant] * 1e-3) / 1e9
+            roof = {"kernel": dominant, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": ach / HBM_PEAK_GBS, "traffic": None}
+        elif dominant is not None and dominant in kern and dominant.startswith("gin_"):
+            ach = mlp_flops / (kern[dominant] * 1e-3) / 1e12
+            roof = {"kernel": dominant, "bound": "mfma", "achieved": ach, "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s",
+                    "frac": ach / FP32_MFMA_PEAK_TF, "traffic": None}
+        agg = None
+        if "gin_aggregate" in kern:
+            ach = agg_bytes / (kern["gin_aggregate"] * 1e-3) / 1e9
+            agg = {"kernel": "gin_aggregate", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                   "frac": ach / HBM_PEAK_GBS, "avg_ms": kern["gin_aggregate"], "bytes_per_launch": agg_bytes}
+        line = {
+            "metric": "graphs/sec on ogbg-molhiv (GIN, dim=100)",
+            "value": value, "unit": "graphs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "GIN dim=100, batched ogbg-molhiv-shaped graphs on MI355X (BASELINE configs[1])",
+                       "graphs_per_gpu_per_step": G, "nodes_per_gpu": N, "edges_per_gpu": E,
+                       "parallelism": f"batch-sharded x{world}, RCCL all-gather of logits"},
+            "finite": ok,
+            "roofline": roof,
+            "aggregation_roofline": agg,
+            "kernel_avg_ms": kern,
+            "vs_fpga_u50": value / FPGA_U50_GRAPHS_PER_S,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(batch, w)
+            line["gpu_over_cpu"] = value / line["cpu_baseline"]["value"]
+        print(json.dumps(line), flush=True)
+    eng.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,71 @@
+"""ctypes binding of libflowgnn_hip.so (the C ABI of include/flowgnn.h).
+
+There is no CPU fallback: if the HIP library is missing this module raises on load.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libflowgnn_hip.so")
+
+STATUS = {
+    0: "FLOWGNN_OK", 1: "FLOWGNN_ERR_ARG", 2: "FLOWGNN_ERR_EDGE_RANGE", 3: "FLOWGNN_ERR_EDGE_ATTR",
+    4: "FLOWGNN_ERR_NODE_FEAT", 5: "FLOWGNN_ERR_HIP", 6: "FLOWGNN_ERR_STATE", 7: "FLOWGNN_ERR_IO",
+    8: "FLOWGNN_ERR_UNSUPPORTED",
+}
+
+MODEL_IDS = {"GIN": 0, "GIN-VN": 1, "GCN": 2, "GAT": 3, "PNA": 4, "DGN": 5}
+
+_lib = None
+
+p_int = C.POINTER(C.c_int)
+p_float = C.POINTER(C.c_float)
+p_void = C.c_void_p
+
+
+def _declare(lib):
+    eng = C.c_void_p
+    lib.flowgnn_create.argtypes = [C.c_int, C.c_int, C.POINTER(eng)]
+    lib.flowgnn_destroy.argtypes = [eng]
+    lib.flowgnn_last_error.argtypes = [eng]
+    lib.flowgnn_last_error.restype = C.c_char_p
+    lib.flowgnn_set_weights_gin.argtypes = [eng] + [p_float] * 8
+    lib.flowgnn_load_weights_dir.argtypes = [eng, C.c_char_p]
+    lib.flowgnn_set_batch.argtypes = [eng, C.c_int, p_int, p_int, p_int, p_int, p_int, p_float]
+    lib.flowgnn_run.argtypes = [eng]
+    lib.flowgnn_sync.argtypes = [eng]
+    lib.flowgnn_get_results.argtypes = [eng, p_float]
+    lib.flowgnn_results_device.argtypes = [eng, C.POINTER(C.c_void_p)]
+    lib.flowgnn_set_results_buffer.argtypes = [eng, C.c_void_p]
+    lib.flowgnn_stream.argtypes = [eng, C.POINTER(C.c_void_p)]
+    lib.flowgnn_batch_info.argtypes = [eng] + [C.POINTER(C.c_longlong)] * 3
+    lib.flowgnn_get_csr.argtypes = [eng, p_int, p_int, p_int, p_int]
+    lib.flowgnn_get_h.argtypes = [eng, p_float, p_int]
+    lib.flowgnn_profile_enable.argtypes = [eng, C.c_int]
+    lib.flowgnn_profile_read.argtypes = [eng, p_int, C.POINTER(C.c_char_p), C.POINTER(C.c_double),
+                                         C.POINTER(C.c_longlong)]
+    lib.flowgnn_run_aggregation_only.argtypes = [eng, C.c_int, C.c_int, p_float]
+    lib.GIN_compute_graphs.argtypes = [C.c_int, p_int, p_int, p_int, p_float, p_int, p_int, p_int] + [p_float] * 8
+    for name in ("flowgnn_create", "flowgnn_destroy", "flowgnn_set_weights_gin", "flowgnn_load_weights_dir",
+                 "flowgnn_set_batch", "flowgnn_run", "flowgnn_sync", "flowgnn_get_results",
+                 "flowgnn_results_device", "flowgnn_set_results_buffer", "flowgnn_stream", "flowgnn_batch_info", "flowgnn_get_csr",
+                 "flowgnn_get_h", "flowgnn_profile_enable", "flowgnn_profile_read",
+                 "flowgnn_run_aggregation_only", "GIN_compute_graphs"):
+        getattr(lib, name).restype = C.c_int
+
+
+def load():
+    """Load libflowgnn_hip.so (built by `python -c 'import __graft_entry__ as g; g.build()'`
+    or `make -C flowgnn_amd/csrc`).  Raises if it is missing: there is no fallback path."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} not found: the HIP extension is not built. "
+                "Run `make -C flowgnn_amd/csrc` (needs hipcc, --offload-arch=gfx950).")
+        lib = C.CDLL(LIB_PATH)
+        _declare(lib)
+        _lib = lib
+    return _lib

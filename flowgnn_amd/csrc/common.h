@@ -1,0 +1,145 @@
+// common.h -- shared declarations for the MI355X (gfx950) FlowGNN engine.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+namespace fg {
+
+// ---- model constants (GIN/src/dcl.h:16-26 of the reference) ----
+constexpr int ND_FEATURE = 9;
+constexpr int ND_FEATURE_TOTAL = 173;
+constexpr int EDGE_ATTR = 3;
+constexpr int ED_FEATURE_PER_LAYER = 13;
+constexpr int EDGE_COMBOS = 60;  // 5 * 6 * 2 distinct (attr0, attr1, attr2) triples
+constexpr int WAVE = 64;
+
+// error flag values written by validation code on the device (match flowgnn.h)
+constexpr int ERR_EDGE_RANGE = 2;
+constexpr int ERR_EDGE_ATTR = 3;
+constexpr int ERR_NODE_FEAT = 4;
+
+__host__ __device__ inline long long ceil_div_ll(long long a, long long b) { return (a + b - 1) / b; }
+
+// ---------------------------------------------------------------------------
+// Batched graph bookkeeping in HBM (all arrays int32 unless noted)
+// ---------------------------------------------------------------------------
+struct BatchView {
+    int num_graphs;
+    int n_tot;               // total nodes
+    int e_tot;               // total edges
+    const int* nums_of_nodes;  // [G]
+    const int* nums_of_edges;  // [G]
+    const int* node_off;       // [G+1]
+    const int* edge_off;       // [G+1]
+    const int* node_feature;   // [N][9]
+    const int* edge_list;      // [E][2] local ids
+    const int* edge_attr;      // [E][3] or null
+};
+
+struct CsrView {
+    int* row_ptr;    // [N+1] in-edges of destination v: [row_ptr[v], row_ptr[v+1])
+    int* src;        // [E] global source id, ascending within a row, ties in input order
+    int* eid;        // [E] input edge index
+    uint8_t* ecode;  // [E] (attr0*6 + attr1)*2 + attr2, or null
+    int* out_deg;    // [N] out-degree of each node (reference degree_table)
+    // scratch
+    int* gsrc;       // [E] global source of input edge e
+    int* gdst;       // [E] global destination of input edge e
+    int* cursor;     // [N]
+    int* tmp;        // [E]
+    int* block_sums; // scan scratch
+    int* err;        // [1] device error flag
+};
+
+// graph_build.hip
+void launch_build_csr(const BatchView& b, const CsrView& c, bool has_edge_attr, hipStream_t s);
+
+}  // namespace fg
+
+// ---------------------------------------------------------------------------
+// Engine-side plumbing shared by the per-model translation units
+// ---------------------------------------------------------------------------
+#include <string>
+#include <vector>
+
+namespace fg {
+
+#define FG_HIP_TRY(expr)                                                            \
+    do {                                                                            \
+        hipError_t _e = (expr);                                                     \
+        if (_e != hipSuccess) {                                                     \
+            fg::set_hip_error(#expr, _e, __FILE__, __LINE__);                       \
+            return 5; /* FLOWGNN_ERR_HIP */                                         \
+        }                                                                           \
+    } while (0)
+
+void set_hip_error(const char* what, hipError_t e, const char* file, int line);
+const char* last_error_text();
+
+// HIP-event profiler: brackets launches on the engine stream; read after a sync.
+class Profiler {
+public:
+    bool enabled = false;
+    int slot(const char* name);
+    void begin(int slot, hipStream_t s);
+    void end(int slot, hipStream_t s);
+    void collect();  // after stream sync: fold finished event pairs into totals
+    void reset();
+    std::vector<std::string> names;
+    std::vector<double> total_ms;
+    std::vector<long long> launches;
+    ~Profiler();
+private:
+    struct Pending { int slot; hipEvent_t a, b; };
+    std::vector<Pending> pending_;
+    std::vector<hipEvent_t> free_;
+    hipEvent_t get_event();
+};
+
+struct ProfScope {
+    Profiler& p; int slot; hipStream_t s;
+    ProfScope(Profiler& p_, const char* name, hipStream_t s_) : p(p_), slot(-1), s(s_) {
+        if (p.enabled) { slot = p.slot(name); p.begin(slot, s); }
+    }
+    ~ProfScope() { if (slot >= 0) p.end(slot, s); }
+};
+
+// Everything a model's forward needs about the resident batch.
+struct DeviceBatch {
+    BatchView b;
+    CsrView csr;
+    const float* node_eigen;  // [N][4] or null
+    float* h[2];              // ping/pong node embeddings [N][dim]
+    float* scratch;           // [N][scratch_dim] model scratch (aggregates)
+    float* out;               // [G]
+    int final_h;              // which h[] holds the last stage's output (set by forward)
+};
+
+class Model {
+public:
+    virtual ~Model() {}
+    virtual int emb_dim() const = 0;
+    virtual int scratch_dim() const = 0;          // floats per node of scratch the forward needs
+    virtual bool has_edge_attr() const = 0;
+    virtual int num_weight_tensors() const = 0;    // host tensors expected by set_weights
+    virtual int set_weights(const float* const* host_tensors) = 0;
+    virtual int load_weights_dir(const char* dir) = 0;
+    virtual bool weights_ready() const = 0;
+    virtual int forward(DeviceBatch& db, Profiler& prof, hipStream_t s) = 0;
+    virtual int aggregation_only(DeviceBatch& db, int layer, hipStream_t s) { (void)db; (void)layer; (void)s; return 8; }
+};
+
+Model* make_gin_model();
+
+// helpers
+int read_floats(const char* dir, const char* file, size_t offset_floats, size_t count, float* dst);
+template <typename T>
+int upload(T** dptr, const std::vector<T>& host) {
+    if (*dptr) { hipFree(*dptr); *dptr = nullptr; }
+    FG_HIP_TRY(hipMalloc((void**)dptr, sizeof(T) * (host.empty() ? 1 : host.size())));
+    if (!host.empty()) FG_HIP_TRY(hipMemcpy(*dptr, host.data(), sizeof(T) * host.size(), hipMemcpyHostToDevice));
+    return 0;
+}
+
+}  // namespace fg

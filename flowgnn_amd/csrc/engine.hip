@@ -1,0 +1,526 @@
+// engine.hip -- host-side engine and the C ABI declared in include/flowgnn.h.
+//
+// One engine = one GPU + one HIP stream + one model's weights + one resident batch.
+// The reference host (GIN/src/host.cc) programs an FPGA, migrates flat buffers once and
+// enqueues the kernel NUM_TRIALS times; the counterpart here is
+//   flowgnn_create -> flowgnn_set_weights_* / flowgnn_load_weights_dir -> flowgnn_set_batch
+//   -> N x flowgnn_run -> flowgnn_get_results.
+#include "common.h"
+#include "../../include/flowgnn.h"
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+
+namespace fg {
+
+// ------------------------------------------------------------------ error text
+static thread_local char g_err[512] = "";
+void set_hip_error(const char* what, hipError_t e, const char* file, int line) {
+    snprintf(g_err, sizeof(g_err), "HIP error %d (%s) at %s:%d: %s", (int)e, hipGetErrorString(e), file, line, what);
+}
+const char* last_error_text() { return g_err; }
+
+int read_floats(const char* dir, const char* file, size_t offset_floats, size_t count, float* dst) {
+    std::string path = std::string(dir) + "/" + file;
+    FILE* f = fopen(path.c_str(), "rb");
+    if (!f) {
+        snprintf(g_err, sizeof(g_err), "cannot open %s", path.c_str());
+        return FLOWGNN_ERR_IO;
+    }
+    int rc = 0;
+    if (fseek(f, (long)(offset_floats * sizeof(float)), SEEK_SET) != 0 || fread(dst, sizeof(float), count, f) != count) {
+        snprintf(g_err, sizeof(g_err), "short read of %zu floats at offset %zu from %s", count, offset_floats, path.c_str());
+        rc = FLOWGNN_ERR_IO;
+    }
+    fclose(f);
+    return rc;
+}
+
+// ------------------------------------------------------------------ profiler
+Profiler::~Profiler() {
+    for (auto& p : pending_) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
+    for (auto e : free_) hipEventDestroy(e);
+}
+int Profiler::slot(const char* name) {
+    for (size_t i = 0; i < names.size(); i++)
+        if (names[i] == name) return (int)i;
+    names.push_back(name);
+    total_ms.push_back(0.0);
+    launches.push_back(0);
+    return (int)names.size() - 1;
+}
+hipEvent_t Profiler::get_event() {
+    if (!free_.empty()) { hipEvent_t e = free_.back(); free_.pop_back(); return e; }
+    hipEvent_t e;
+    hipEventCreate(&e);
+    return e;
+}
+void Profiler::begin(int slot, hipStream_t s) {
+    Pending p{slot, get_event(), get_event()};
+    hipEventRecord(p.a, s);
+    pending_.push_back(p);
+}
+void Profiler::end(int slot, hipStream_t s) {
+    for (size_t i = pending_.size(); i-- > 0;)
+        if (pending_[i].slot == slot) { hipEventRecord(pending_[i].b, s); break; }
+}
+void Profiler::collect() {
+    for (auto& p : pending_) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+            total_ms[p.slot] += ms;
+            launches[p.slot] += 1;
+        }
+        free_.push_back(p.a);
+        free_.push_back(p.b);
+    }
+    pending_.clear();
+}
+void Profiler::reset() {
+    collect();
+    for (auto& x : total_ms) x = 0.0;
+    for (auto& x : launches) x = 0;
+}
+
+}  // namespace fg
+
+using namespace fg;
+
+// ------------------------------------------------------------------ engine object
+struct flowgnn_engine {
+    int model_id = 0;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    Model* model = nullptr;
+    Profiler prof;
+    std::string err;
+
+    // resident batch
+    bool batch_ready = false;
+    bool ran = false;
+    long long G = 0, N = 0, E = 0;
+    size_t capG = 0, capN = 0, capE = 0;
+    int *d_nn = nullptr, *d_ne = nullptr, *d_noff = nullptr, *d_eoff = nullptr;
+    int *d_nf = nullptr, *d_el = nullptr, *d_ea = nullptr;
+    float* d_eig = nullptr;
+    int *d_rowptr = nullptr, *d_src = nullptr, *d_eid = nullptr, *d_outdeg = nullptr, *d_gsrc = nullptr, *d_gdst = nullptr,
+        *d_cursor = nullptr, *d_tmp = nullptr, *d_bsums = nullptr, *d_err = nullptr;
+    uint8_t* d_ecode = nullptr;
+    float *d_h0 = nullptr, *d_h1 = nullptr, *d_scratch = nullptr, *d_out = nullptr;
+    bool has_attr = false, has_eig = false;
+    DeviceBatch db{};
+
+    void free_batch() {
+        void* ptrs[] = {d_nn, d_ne, d_noff, d_eoff, d_nf, d_el, d_ea, d_eig, d_rowptr, d_src, d_eid, d_outdeg, d_gsrc,
+                        d_gdst, d_cursor, d_tmp, d_bsums, d_ecode, d_h0, d_h1, d_scratch, d_out};
+        for (void* p : ptrs)
+            if (p) hipFree(p);
+        d_nn = d_ne = d_noff = d_eoff = d_nf = d_el = d_ea = nullptr;
+        d_eig = nullptr;
+        d_rowptr = d_src = d_eid = d_outdeg = d_gsrc = d_gdst = d_cursor = d_tmp = d_bsums = nullptr;
+        d_ecode = nullptr;
+        d_h0 = d_h1 = d_scratch = d_out = nullptr;
+        capG = capN = capE = 0;
+    }
+};
+
+#define ENGINE_TRY(e, expr)                                     \
+    do {                                                        \
+        int _rc = (expr);                                       \
+        if (_rc) { (e)->err = fg::last_error_text(); return _rc; } \
+    } while (0)
+
+static int use_device(flowgnn_engine* e) {
+    FG_HIP_TRY(hipSetDevice(e->device));
+    return 0;
+}
+
+extern "C" {
+
+int flowgnn_create(int model, int device_id, flowgnn_engine** out) {
+    if (!out) return FLOWGNN_ERR_ARG;
+    *out = nullptr;
+    Model* m = nullptr;
+    switch (model) {
+        case FLOWGNN_MODEL_GIN:
+        case FLOWGNN_MODEL_GIN_VN: m = make_gin_model(); break;
+        default: return FLOWGNN_ERR_UNSUPPORTED;
+    }
+    flowgnn_engine* e = new flowgnn_engine();
+    e->model_id = model;
+    e->device = device_id;
+    e->model = m;
+    int rc = use_device(e);
+    if (!rc) {
+        hipError_t he = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
+        if (he == hipSuccess) he = hipMalloc((void**)&e->d_err, sizeof(int));
+        if (he == hipSuccess) he = hipMemset(e->d_err, 0, sizeof(int));
+        if (he != hipSuccess) {
+            set_hip_error("engine init", he, __FILE__, __LINE__);
+            rc = FLOWGNN_ERR_HIP;
+        }
+    }
+    if (rc) {
+        delete m;
+        delete e;
+        return rc;
+    }
+    *out = e;
+    return FLOWGNN_OK;
+}
+
+int flowgnn_destroy(flowgnn_engine* e) {
+    if (!e) return FLOWGNN_ERR_ARG;
+    hipSetDevice(e->device);
+    if (e->stream) hipStreamSynchronize(e->stream);
+    e->free_batch();
+    if (e->d_err) hipFree(e->d_err);
+    delete e->model;
+    if (e->stream) hipStreamDestroy(e->stream);
+    delete e;
+    return FLOWGNN_OK;
+}
+
+const char* flowgnn_last_error(const flowgnn_engine* e) {
+    if (e && !e->err.empty()) return e->err.c_str();
+    return fg::last_error_text();
+}
+
+int flowgnn_set_weights_gin(flowgnn_engine* e, const float* node_embedding_weight, const float* edge_embedding_weight,
+                            const float* node_mlp_1_weights, const float* node_mlp_1_bias,
+                            const float* node_mlp_2_weights, const float* node_mlp_2_bias,
+                            const float* graph_pred_weights, const float* graph_pred_bias) {
+    if (!e || (e->model_id != FLOWGNN_MODEL_GIN && e->model_id != FLOWGNN_MODEL_GIN_VN)) return FLOWGNN_ERR_ARG;
+    const float* t[8] = {node_embedding_weight, edge_embedding_weight, node_mlp_1_weights, node_mlp_1_bias,
+                         node_mlp_2_weights,    node_mlp_2_bias,       graph_pred_weights, graph_pred_bias};
+    for (auto p : t)
+        if (!p) return FLOWGNN_ERR_ARG;
+    ENGINE_TRY(e, use_device(e));
+    if (e->stream) hipStreamSynchronize(e->stream);
+    ENGINE_TRY(e, e->model->set_weights(t));
+    return FLOWGNN_OK;
+}
+
+int flowgnn_load_weights_dir(flowgnn_engine* e, const char* dir) {
+    if (!e || !dir) return FLOWGNN_ERR_ARG;
+    ENGINE_TRY(e, use_device(e));
+    if (e->stream) hipStreamSynchronize(e->stream);
+    ENGINE_TRY(e, e->model->load_weights_dir(dir));
+    return FLOWGNN_OK;
+}
+
+static int alloc_batch(flowgnn_engine* e, size_t G, size_t N, size_t E, bool attr, bool eig) {
+    const int D = e->model->emb_dim(), SD = e->model->scratch_dim();
+    if (G > e->capG || N > e->capN || E > e->capE || (attr && !e->d_ea) || (eig && !e->d_eig)) {
+        e->free_batch();
+        const size_t g1 = G ? G : 1, n1 = N ? N : 1, e1 = E ? E : 1;
+        FG_HIP_TRY(hipMalloc((void**)&e->d_nn, sizeof(int) * g1));
+        FG_HIP_TRY(hipMalloc((void**)&e->d_ne, sizeof(int) * g1));
+        FG_HIP_TRY(hipMalloc((void**)&e->d_noff, sizeof(int) * (g1 + 1)));
+        FG_HIP_TRY(hipMalloc((void**)&e->d_eoff, sizeof(int) * (g1 + 1)));
+        FG_HIP_TRY(hipMalloc((void**)&e->d_nf, sizeof(int) * n1 * ND_FEATURE));
+        FG_HIP_TRY(hipMalloc((void**)&e->d_el, sizeof(int) * e1 * 2));
+        if (attr) FG_HIP_TRY(hipMalloc((void**)&e->d_ea, sizeof(int) * e1 * EDGE_ATTR));
+        if (eig) FG_HIP_TRY(hipMalloc((void**)&e->d_eig, sizeof(float) * n1 * 4));
+        FG_HIP_TRY(hipMalloc((void**)&e->d_rowptr, sizeof(int) * (n1 + 1)));
+        FG_HIP_TRY(hipMalloc((void**)&e->d_src, sizeof(int) * e1));
+        FG_HIP_TRY(hipMalloc((void**)&e->d_eid, sizeof(int) * e1));
+        FG_HIP_TRY(hipMalloc((void**)&e->d_ecode, sizeof(uint8_t) * e1));
+        FG_HIP_TRY(hipMalloc((void**)&e->d_outdeg, sizeof(int) * n1));
+        FG_HIP_TRY(hipMalloc((void**)&e->d_gsrc, sizeof(int) * e1));
+        FG_HIP_TRY(hipMalloc((void**)&e->d_gdst, sizeof(int) * e1));
+        FG_HIP_TRY(hipMalloc((void**)&e->d_cursor, sizeof(int) * n1));
+        FG_HIP_TRY(hipMalloc((void**)&e->d_tmp, sizeof(int) * e1 * 2));
+        FG_HIP_TRY(hipMalloc((void**)&e->d_bsums, sizeof(int) * (n1 / 2048 + 2)));
+        FG_HIP_TRY(hipMalloc((void**)&e->d_h0, sizeof(float) * n1 * D));
+        FG_HIP_TRY(hipMalloc((void**)&e->d_h1, sizeof(float) * n1 * D));
+        FG_HIP_TRY(hipMalloc((void**)&e->d_scratch, sizeof(float) * n1 * (SD > 0 ? SD : 1)));
+        FG_HIP_TRY(hipMalloc((void**)&e->d_out, sizeof(float) * g1));
+        e->capG = G; e->capN = N; e->capE = E;
+    }
+    return 0;
+}
+
+int flowgnn_set_batch(flowgnn_engine* e, int num_graphs, const int* nums_of_nodes, const int* nums_of_edges,
+                      const int* node_feature, const int* edge_list, const int* edge_attr, const float* node_eigen) {
+    if (!e || num_graphs < 0) return FLOWGNN_ERR_ARG;
+    if (num_graphs > 0 && (!nums_of_nodes || !nums_of_edges)) return FLOWGNN_ERR_ARG;
+    const bool attr = e->model->has_edge_attr();
+    const bool eig = (e->model_id == FLOWGNN_MODEL_DGN);
+    // prefix sums of node / edge counts: what the reference carries as nodes_offset / edges_offset
+    // (GIN/src/GIN_compute.cc:44,96-97)
+    std::vector<int> noff((size_t)num_graphs + 1), eoff((size_t)num_graphs + 1);
+    long long N = 0, E = 0;
+    for (int g = 0; g < num_graphs; g++) {
+        if (nums_of_nodes[g] <= 0 || nums_of_edges[g] < 0) {
+            e->err = "graph with num_of_nodes <= 0 or num_of_edges < 0";
+            return FLOWGNN_ERR_ARG;
+        }
+        noff[g] = (int)N;
+        eoff[g] = (int)E;
+        N += nums_of_nodes[g];
+        E += nums_of_edges[g];
+        if (N > 0x7fffffffLL / 128 || E > 0x7fffffffLL / 4) {
+            e->err = "batch too large for int32 indexing";
+            return FLOWGNN_ERR_ARG;
+        }
+    }
+    noff[num_graphs] = (int)N;
+    eoff[num_graphs] = (int)E;
+    if (N > 0 && !node_feature) return FLOWGNN_ERR_ARG;
+    if (E > 0 && (!edge_list || (attr && !edge_attr))) return FLOWGNN_ERR_ARG;
+    if (eig && N > 0 && !node_eigen) return FLOWGNN_ERR_ARG;
+
+    ENGINE_TRY(e, use_device(e));
+    if (e->stream) hipStreamSynchronize(e->stream);
+    e->batch_ready = false;
+    e->ran = false;
+    ENGINE_TRY(e, alloc_batch(e, (size_t)num_graphs, (size_t)N, (size_t)E, attr, eig));
+    auto h2d = [&](void* dst, const void* src, size_t bytes) -> int {
+        if (bytes == 0) return 0;
+        FG_HIP_TRY(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
+        return 0;
+    };
+    ENGINE_TRY(e, h2d(e->d_nn, nums_of_nodes, sizeof(int) * (size_t)num_graphs));
+    ENGINE_TRY(e, h2d(e->d_ne, nums_of_edges, sizeof(int) * (size_t)num_graphs));
+    ENGINE_TRY(e, h2d(e->d_noff, noff.data(), sizeof(int) * ((size_t)num_graphs + 1)));
+    ENGINE_TRY(e, h2d(e->d_eoff, eoff.data(), sizeof(int) * ((size_t)num_graphs + 1)));
+    ENGINE_TRY(e, h2d(e->d_nf, node_feature, sizeof(int) * (size_t)N * ND_FEATURE));
+    ENGINE_TRY(e, h2d(e->d_el, edge_list, sizeof(int) * (size_t)E * 2));
+    if (attr) ENGINE_TRY(e, h2d(e->d_ea, edge_attr, sizeof(int) * (size_t)E * EDGE_ATTR));
+    if (eig) ENGINE_TRY(e, h2d(e->d_eig, node_eigen, sizeof(float) * (size_t)N * 4));
+
+    e->G = num_graphs; e->N = N; e->E = E;
+    e->has_attr = attr; e->has_eig = eig;
+    DeviceBatch& db = e->db;
+    db.b.num_graphs = num_graphs; db.b.n_tot = (int)N; db.b.e_tot = (int)E;
+    db.b.nums_of_nodes = e->d_nn; db.b.nums_of_edges = e->d_ne;
+    db.b.node_off = e->d_noff; db.b.edge_off = e->d_eoff;
+    db.b.node_feature = e->d_nf; db.b.edge_list = e->d_el; db.b.edge_attr = attr ? e->d_ea : nullptr;
+    db.csr.row_ptr = e->d_rowptr; db.csr.src = e->d_src; db.csr.eid = e->d_eid;
+    db.csr.ecode = e->d_ecode; db.csr.out_deg = e->d_outdeg;
+    db.csr.gsrc = e->d_gsrc; db.csr.gdst = e->d_gdst; db.csr.cursor = e->d_cursor; db.csr.tmp = e->d_tmp;
+    db.csr.block_sums = e->d_bsums; db.csr.err = e->d_err;
+    db.node_eigen = eig ? e->d_eig : nullptr;
+    db.h[0] = e->d_h0; db.h[1] = e->d_h1; db.scratch = e->d_scratch; db.out = e->d_out;
+    db.final_h = 0;
+    FG_HIP_TRY(hipMemset(e->d_err, 0, sizeof(int)));
+    e->batch_ready = true;
+    return FLOWGNN_OK;
+}
+
+int flowgnn_run(flowgnn_engine* e) {
+    if (!e) return FLOWGNN_ERR_ARG;
+    if (!e->batch_ready || !e->model->weights_ready()) {
+        e->err = "flowgnn_run: weights or batch not set";
+        return FLOWGNN_ERR_STATE;
+    }
+    ENGINE_TRY(e, use_device(e));
+    if (e->G == 0) { e->ran = true; return FLOWGNN_OK; }
+    {
+        ProfScope p(e->prof, "build_csr", e->stream);
+        launch_build_csr(e->db.b, e->db.csr, e->has_attr, e->stream);
+    }
+    ENGINE_TRY(e, e->model->forward(e->db, e->prof, e->stream));
+    hipError_t he = hipGetLastError();
+    if (he != hipSuccess) {
+        set_hip_error("kernel launch", he, __FILE__, __LINE__);
+        e->err = fg::last_error_text();
+        return FLOWGNN_ERR_HIP;
+    }
+    e->ran = true;
+    return FLOWGNN_OK;
+}
+
+int flowgnn_sync(flowgnn_engine* e) {
+    if (!e) return FLOWGNN_ERR_ARG;
+    ENGINE_TRY(e, use_device(e));
+    hipError_t he = hipStreamSynchronize(e->stream);
+    if (he != hipSuccess) {
+        set_hip_error("hipStreamSynchronize", he, __FILE__, __LINE__);
+        e->err = fg::last_error_text();
+        return FLOWGNN_ERR_HIP;
+    }
+    e->prof.collect();
+    int flag = 0;
+    he = hipMemcpy(&flag, e->d_err, sizeof(int), hipMemcpyDeviceToHost);
+    if (he != hipSuccess) {
+        set_hip_error("read error flag", he, __FILE__, __LINE__);
+        e->err = fg::last_error_text();
+        return FLOWGNN_ERR_HIP;
+    }
+    if (flag) {
+        e->err = "input validation failed on device (edge endpoint / edge attribute / node feature out of range)";
+        return flag;
+    }
+    return FLOWGNN_OK;
+}
+
+int flowgnn_get_results(flowgnn_engine* e, float* out_host) {
+    if (!e || (!out_host && e->G > 0)) return FLOWGNN_ERR_ARG;
+    if (!e->ran) { e->err = "flowgnn_get_results before flowgnn_run"; return FLOWGNN_ERR_STATE; }
+    int rc = flowgnn_sync(e);
+    if (rc) return rc;
+    if (e->G > 0) {
+        hipError_t he = hipMemcpy(out_host, e->db.out, sizeof(float) * (size_t)e->G, hipMemcpyDeviceToHost);
+        if (he != hipSuccess) {
+            set_hip_error("copy results", he, __FILE__, __LINE__);
+            e->err = fg::last_error_text();
+            return FLOWGNN_ERR_HIP;
+        }
+    }
+    return FLOWGNN_OK;
+}
+
+int flowgnn_results_device(flowgnn_engine* e, void** d_out) {
+    if (!e || !d_out) return FLOWGNN_ERR_ARG;
+    if (!e->batch_ready) return FLOWGNN_ERR_STATE;
+    *d_out = e->db.out;
+    return FLOWGNN_OK;
+}
+
+int flowgnn_set_results_buffer(flowgnn_engine* e, void* device_ptr) {
+    if (!e) return FLOWGNN_ERR_ARG;
+    if (!e->batch_ready) return FLOWGNN_ERR_STATE;
+    ENGINE_TRY(e, use_device(e));
+    hipStreamSynchronize(e->stream);
+    e->db.out = device_ptr ? (float*)device_ptr : e->d_out;
+    return FLOWGNN_OK;
+}
+
+int flowgnn_stream(flowgnn_engine* e, void** stream) {
+    if (!e || !stream) return FLOWGNN_ERR_ARG;
+    *stream = (void*)e->stream;
+    return FLOWGNN_OK;
+}
+
+int flowgnn_batch_info(const flowgnn_engine* e, long long* num_graphs, long long* total_nodes, long long* total_edges) {
+    if (!e) return FLOWGNN_ERR_ARG;
+    if (num_graphs) *num_graphs = e->G;
+    if (total_nodes) *total_nodes = e->N;
+    if (total_edges) *total_edges = e->E;
+    return FLOWGNN_OK;
+}
+
+int flowgnn_get_csr(flowgnn_engine* e, int* row_ptr, int* src, int* eid, int* out_deg) {
+    if (!e) return FLOWGNN_ERR_ARG;
+    if (!e->ran) return FLOWGNN_ERR_STATE;
+    int rc = flowgnn_sync(e);
+    if (rc) return rc;
+    if (row_ptr) FG_HIP_TRY(hipMemcpy(row_ptr, e->d_rowptr, sizeof(int) * ((size_t)e->N + 1), hipMemcpyDeviceToHost));
+    if (src && e->E) FG_HIP_TRY(hipMemcpy(src, e->d_src, sizeof(int) * (size_t)e->E, hipMemcpyDeviceToHost));
+    if (eid && e->E) FG_HIP_TRY(hipMemcpy(eid, e->d_eid, sizeof(int) * (size_t)e->E, hipMemcpyDeviceToHost));
+    if (out_deg && e->N) FG_HIP_TRY(hipMemcpy(out_deg, e->d_outdeg, sizeof(int) * (size_t)e->N, hipMemcpyDeviceToHost));
+    return FLOWGNN_OK;
+}
+
+int flowgnn_get_h(flowgnn_engine* e, float* h_host, int* dim) {
+    if (!e) return FLOWGNN_ERR_ARG;
+    if (!e->ran) return FLOWGNN_ERR_STATE;
+    int rc = flowgnn_sync(e);
+    if (rc) return rc;
+    const int D = e->model->emb_dim();
+    if (dim) *dim = D;
+    if (h_host && e->N)
+        FG_HIP_TRY(hipMemcpy(h_host, e->db.h[e->db.final_h], sizeof(float) * (size_t)e->N * D, hipMemcpyDeviceToHost));
+    return FLOWGNN_OK;
+}
+
+int flowgnn_profile_enable(flowgnn_engine* e, int on) {
+    if (!e) return FLOWGNN_ERR_ARG;
+    ENGINE_TRY(e, use_device(e));
+    hipStreamSynchronize(e->stream);
+    e->prof.reset();
+    e->prof.enabled = on != 0;
+    return FLOWGNN_OK;
+}
+
+int flowgnn_profile_read(flowgnn_engine* e, int* count, const char** names, double* total_ms, long long* launches) {
+    if (!e || !count) return FLOWGNN_ERR_ARG;
+    ENGINE_TRY(e, use_device(e));
+    hipStreamSynchronize(e->stream);
+    e->prof.collect();
+    int n = (int)e->prof.names.size();
+    if (n > FLOWGNN_MAX_PROFILE_SLOTS) n = FLOWGNN_MAX_PROFILE_SLOTS;
+    for (int i = 0; i < n; i++) {
+        if (names) names[i] = e->prof.names[i].c_str();
+        if (total_ms) total_ms[i] = e->prof.total_ms[i];
+        if (launches) launches[i] = e->prof.launches[i];
+    }
+    *count = n;
+    return FLOWGNN_OK;
+}
+
+int flowgnn_run_aggregation_only(flowgnn_engine* e, int layer, int iters, float* avg_ms) {
+    if (!e || iters <= 0) return FLOWGNN_ERR_ARG;
+    if (!e->ran) { e->err = "flowgnn_run_aggregation_only needs a prior flowgnn_run"; return FLOWGNN_ERR_STATE; }
+    ENGINE_TRY(e, use_device(e));
+    hipEvent_t a, b;
+    FG_HIP_TRY(hipEventCreate(&a));
+    FG_HIP_TRY(hipEventCreate(&b));
+    int rc = e->model->aggregation_only(e->db, layer, e->stream);  // warm-up
+    if (rc) return rc;
+    FG_HIP_TRY(hipEventRecord(a, e->stream));
+    for (int i = 0; i < iters; i++) e->model->aggregation_only(e->db, layer, e->stream);
+    FG_HIP_TRY(hipEventRecord(b, e->stream));
+    FG_HIP_TRY(hipEventSynchronize(b));
+    float ms = 0.f;
+    FG_HIP_TRY(hipEventElapsedTime(&ms, a, b));
+    hipEventDestroy(a);
+    hipEventDestroy(b);
+    if (avg_ms) *avg_ms = ms / iters;
+    return FLOWGNN_OK;
+}
+
+// ------------------------------------------------------------------ reference-compatible entry point
+// Splits the batch into runs of constant weight set (reload_weights semantics of
+// GIN/src/GIN_compute.cc:44,51-53) and runs each through a process-wide engine on device 0.
+static std::mutex g_entry_mutex;
+
+int GIN_compute_graphs(int num_graphs, int* nums_of_nodes, int* nums_of_edges, int* reload_weights, float* out,
+                       int* node_feature_in, int* edge_list_in, int* edge_attr_in, float* node_embedding_weight_in,
+                       float* edge_embedding_weight_in, float* node_mlp_1_weights, float* node_mlp_1_bias,
+                       float* node_mlp_2_weights, float* node_mlp_2_bias, float* graph_pred_weights_in,
+                       float* graph_pred_bias_in) {
+    if (num_graphs < 0) return FLOWGNN_ERR_ARG;
+    if (num_graphs == 0) return FLOWGNN_OK;
+    if (!nums_of_nodes || !nums_of_edges || !reload_weights || !out || !node_feature_in) return FLOWGNN_ERR_ARG;
+    if (!reload_weights[0]) return FLOWGNN_ERR_ARG;  // the reference would index weight set -1
+    std::lock_guard<std::mutex> lock(g_entry_mutex);
+    static flowgnn_engine* eng = nullptr;
+    if (!eng) {
+        const char* dev = getenv("FLOWGNN_DEVICE");
+        int rc = flowgnn_create(FLOWGNN_MODEL_GIN, dev ? atoi(dev) : 0, &eng);
+        if (rc) return rc;
+    }
+    long long noff = 0, eoff = 0;
+    int set = -1, g = 0;
+    while (g < num_graphs) {
+        set++;
+        int g1 = g + 1;
+        while (g1 < num_graphs && !reload_weights[g1]) g1++;
+        long long n = 0, m = 0;
+        for (int i = g; i < g1; i++) { n += nums_of_nodes[i]; m += nums_of_edges[i]; }
+        const size_t s = (size_t)set;
+        int rc = flowgnn_set_weights_gin(eng, node_embedding_weight_in + s * 173 * 100, edge_embedding_weight_in + s * 5 * 13 * 100,
+                                         node_mlp_1_weights + s * 5 * 200 * 100, node_mlp_1_bias + s * 5 * 200,
+                                         node_mlp_2_weights + s * 5 * 100 * 200, node_mlp_2_bias + s * 5 * 100,
+                                         graph_pred_weights_in + s * 100, graph_pred_bias_in + s);
+        if (rc) return rc;
+        rc = flowgnn_set_batch(eng, g1 - g, nums_of_nodes + g, nums_of_edges + g, node_feature_in + noff * 9,
+                               edge_list_in ? edge_list_in + eoff * 2 : nullptr,
+                               edge_attr_in ? edge_attr_in + eoff * 3 : nullptr, nullptr);
+        if (rc) return rc;
+        rc = flowgnn_run(eng);
+        if (rc) return rc;
+        rc = flowgnn_get_results(eng, out + g);
+        if (rc) return rc;
+        noff += n;
+        eoff += m;
+        g = g1;
+    }
+    return FLOWGNN_OK;
+}
+
+}  // extern "C"

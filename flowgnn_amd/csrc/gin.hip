@@ -1,0 +1,433 @@
+// gin.hip -- GIN / GIN-VN hot path for gfx950 (MI355X).
+//
+// What the reference does per graph (one NT unit + 4 MP units, GIN/src/*.cc):
+//   h0[v]   = sum_{k<9} NodeEmb[off_k + feat_k(v)]                          load_inputs.cc:193-212
+//   m_l[v]  = sum_{(u->v)} relu(h_l[u] + sum_{k<3} EdgeEmb_l[off_k+attr_k])  message_passing.cc:136-145
+//   a       = m_l[v] + (1 + eps) h_l[v],  eps == 0 (never loaded)            node_embedding.cc:117
+//   hid     = b1 + W1 a  (200x100),  h_{l+1} = b2 + W2 relu(hid) (100x200)   node_embedding.cc:124-191
+//   out[g]  = pb + pw . mean_v h_5[v]                                        finalize.cc:36-113
+//
+// Here: the whole batch is one super-graph in HBM, h is [N_tot][100] fp32 (row stride
+// 100 floats, rows of a graph contiguous), and per layer there are two kernels:
+//   gin_aggregate : HBM-bound gather + per-destination ordered sum over the CSR
+//   gin_mlp       : the dense update on fp32 MFMA (v_mfma_f32_16x16x4_f32), transposed so
+//                   that nodes are MFMA columns and the MLP1 accumulators feed MLP2 directly
+//                   as B operands (no LDS round trip, no transpose)
+#include "common.h"
+#include <cstring>
+#include <cstdio>
+
+namespace fg {
+
+constexpr int GIN_D = 100;
+constexpr int GIN_H = 200;
+constexpr int GIN_L = 5;
+constexpr int GIN_C = GIN_D / 4;   // float4 chunks per row
+constexpr int GIN_T1 = 13;         // 16-row tiles of the hidden layer (208 >= 200)
+constexpr int GIN_T2 = 7;          // 16-row tiles of the output layer (112 >= 100)
+
+// reference tables
+__constant__ int c_nd_off[ND_FEATURE] = {0, 119, 123, 135, 147, 157, 163, 169, 171};  // load_inputs.cc:5
+__constant__ int c_nd_card[ND_FEATURE] = {119, 4, 12, 12, 10, 6, 6, 2, 2};            // host_load.cc:5
+
+typedef float float4_t __attribute__((ext_vector_type(4)));
+
+__device__ inline float relu1(float x) { return x < 0.0f ? 0.0f : x; }
+
+// ---------------------------------------------------------------- atom encoder
+// One lane per (node, float4 chunk); fully coalesced 1 KiB stores per wave.
+template <int D>
+__global__ __launch_bounds__(256) void atom_encoder_kernel(const int* __restrict__ node_feature,
+                                                            const float* __restrict__ table,  // [173][D]
+                                                            float* __restrict__ h, int n_tot, int* __restrict__ err) {
+    constexpr int C = D / 4;
+    const long long total = (long long)n_tot * C;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int v = (int)(i / C);
+        const int c = (int)(i - (long long)v * C);
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int k = 0; k < ND_FEATURE; k++) {
+            int f = node_feature[(size_t)v * ND_FEATURE + k];
+            if (f < 0 || f >= c_nd_card[k]) {
+                atomicMax(err, ERR_NODE_FEAT);
+                f = 0;
+            }
+            const float4 w = reinterpret_cast<const float4*>(table)[(size_t)(c_nd_off[k] + f) * C + c];
+            s.x += w.x; s.y += w.y; s.z += w.z; s.w += w.w;
+        }
+        reinterpret_cast<float4*>(h)[i] = s;
+    }
+}
+
+// ---------------------------------------------------------------- aggregation (MP unit)
+// a[v] = h[v] + sum over in-edges (ascending source, ties in input order) of relu(h[u] + ecomb[code]).
+// ecomb[code] = ((0 + E[a0]) + E[5+a1]) + E[11+a2], precombined on the host in the reference's
+// accumulation order, so the per-edge value is bit-identical to message_passing.cc:136-145.
+// Work item = (destination row, float4 chunk) in flattened order: every load/store of a row is a
+// contiguous 400 B, a wave covers ~2.5 consecutive rows, the 24 KB combo table sits in LDS.
+template <int D, bool ADD_SELF>
+__global__ __launch_bounds__(256) void gin_aggregate_kernel(const float* __restrict__ h, float* __restrict__ a,
+                                                             const int* __restrict__ row_ptr,
+                                                             const int* __restrict__ src,
+                                                             const uint8_t* __restrict__ ecode,
+                                                             const float* __restrict__ ecomb, int n_tot) {
+    constexpr int C = D / 4;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float4* s_ecomb = reinterpret_cast<float4*>(smem_raw);
+    for (int i = threadIdx.x; i < EDGE_COMBOS * C; i += 256) s_ecomb[i] = reinterpret_cast<const float4*>(ecomb)[i];
+    __syncthreads();
+    const float4* h4 = reinterpret_cast<const float4*>(h);
+    const long long total = (long long)n_tot * C;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int v = (int)(i / C);
+        const int c = (int)(i - (long long)v * C);
+        const int beg = row_ptr[v], end = row_ptr[v + 1];
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        int e = beg;
+        for (; e + 1 < end; e += 2) {  // two gathers in flight
+            const int u0 = src[e], u1 = src[e + 1];
+            const int k0 = ecode[e], k1 = ecode[e + 1];
+            const float4 x0 = h4[(size_t)u0 * C + c];
+            const float4 x1 = h4[(size_t)u1 * C + c];
+            const float4 w0 = s_ecomb[k0 * C + c];
+            const float4 w1 = s_ecomb[k1 * C + c];
+            acc.x += relu1(w0.x + x0.x); acc.y += relu1(w0.y + x0.y); acc.z += relu1(w0.z + x0.z); acc.w += relu1(w0.w + x0.w);
+            acc.x += relu1(w1.x + x1.x); acc.y += relu1(w1.y + x1.y); acc.z += relu1(w1.z + x1.z); acc.w += relu1(w1.w + x1.w);
+        }
+        if (e < end) {
+            const int u0 = src[e];
+            const int k0 = ecode[e];
+            const float4 x0 = h4[(size_t)u0 * C + c];
+            const float4 w0 = s_ecomb[k0 * C + c];
+            acc.x += relu1(w0.x + x0.x); acc.y += relu1(w0.y + x0.y); acc.z += relu1(w0.z + x0.z); acc.w += relu1(w0.w + x0.w);
+        }
+        if (ADD_SELF) {
+            const float4 self = h4[i];
+            acc.x += self.x; acc.y += self.y; acc.z += self.z; acc.w += self.w;
+        }
+        reinterpret_cast<float4*>(a)[i] = acc;
+    }
+}
+
+// ---------------------------------------------------------------- node MLP (NT unit) on fp32 MFMA
+// Transposed formulation, one wavefront owns NT tiles of 16 nodes:
+//   hid^T[o][node] = b1[o] + sum_k W1[o][k] a[node][k]        A = W1 fragment, B = a^T
+//   out^T[d][node] = b2[d] + sum_k W2[d][k] relu(hid^T[k][node])   A = W2 fragment, B = hid^T
+// v_mfma_f32_16x16x4_f32: lane l = (i = l & 15, g = l >> 4) supplies A[i][k=g], B[k=g][j=i] and
+// receives D[row = 4 g + r][col = i] in register r.  So after MLP1 tile t, lane (j,g) holds hidden
+// rows 16 t + 4 g + r of node j: exactly a B operand of MLP2 for the k-step "(t, r)" if the W2
+// fragment for that step carries k = 16 t + 4 g + r in slot g.  Same trick on the input side:
+// lane (j,g) loads a[j][16 q + 4 g .. +3] as float4 (q < 6) plus a[j][96 + g], and the W1
+// fragments are packed with the matching k per slot.  Fragment packing: GinModel::set_weights.
+struct GinLayerDev {
+    const float* ecomb;    // [60][100]
+    const float* w1f;      // [13][6][64][4]   (t, q, lane, r)
+    const float* w1tail;   // [13][64]         k = 96 + g
+    const float* b1p;      // [208]
+    const float* w2f;      // [13][7][64][4]   (t, t2, lane, r)
+    const float* b2p;      // [112]
+};
+
+template <int NT>
+__global__ __launch_bounds__(256) void gin_mlp_kernel(const float* __restrict__ a, float* __restrict__ hout,
+                                                       GinLayerDev w, int n_tot, int relu_out) {
+    const int lane = threadIdx.x & 63;
+    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int j = lane & 15, g = lane >> 4;
+    const long long node_base = (long long)wave * (16 * NT);
+    if (node_base >= n_tot) return;
+
+    float bq[NT][25];
+#pragma unroll
+    for (int nt = 0; nt < NT; nt++) {
+        long long node = node_base + nt * 16 + j;
+        if (node >= n_tot) node = n_tot - 1;  // clamp: computed, never stored
+        const float* row = a + (size_t)node * GIN_D;
+#pragma unroll
+        for (int q = 0; q < 6; q++) {
+            const float4 x = *reinterpret_cast<const float4*>(row + 16 * q + 4 * g);
+            bq[nt][4 * q + 0] = x.x; bq[nt][4 * q + 1] = x.y; bq[nt][4 * q + 2] = x.z; bq[nt][4 * q + 3] = x.w;
+        }
+        bq[nt][24] = row[96 + g];
+    }
+
+    float4_t acc2[NT][GIN_T2];
+#pragma unroll
+    for (int t2 = 0; t2 < GIN_T2; t2++) {
+        const float4 b = *reinterpret_cast<const float4*>(w.b2p + 16 * t2 + 4 * g);
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++) acc2[nt][t2] = (float4_t){b.x, b.y, b.z, b.w};
+    }
+
+    const float4* w1f4 = reinterpret_cast<const float4*>(w.w1f);
+    const float4* w2f4 = reinterpret_cast<const float4*>(w.w2f);
+#pragma unroll 1
+    for (int t = 0; t < GIN_T1; t++) {
+        float4_t acc1[NT];
+        {
+            const float4 b = *reinterpret_cast<const float4*>(w.b1p + 16 * t + 4 * g);
+#pragma unroll
+            for (int nt = 0; nt < NT; nt++) acc1[nt] = (float4_t){b.x, b.y, b.z, b.w};
+        }
+#pragma unroll
+        for (int q = 0; q < 6; q++) {
+            const float4 af = w1f4[(size_t)(t * 6 + q) * 64 + lane];
+#pragma unroll
+            for (int nt = 0; nt < NT; nt++) acc1[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af.x, bq[nt][4 * q + 0], acc1[nt], 0, 0, 0);
+#pragma unroll
+            for (int nt = 0; nt < NT; nt++) acc1[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af.y, bq[nt][4 * q + 1], acc1[nt], 0, 0, 0);
+#pragma unroll
+            for (int nt = 0; nt < NT; nt++) acc1[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af.z, bq[nt][4 * q + 2], acc1[nt], 0, 0, 0);
+#pragma unroll
+            for (int nt = 0; nt < NT; nt++) acc1[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af.w, bq[nt][4 * q + 3], acc1[nt], 0, 0, 0);
+        }
+        {
+            const float at = w.w1tail[t * 64 + lane];
+#pragma unroll
+            for (int nt = 0; nt < NT; nt++) acc1[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(at, bq[nt][24], acc1[nt], 0, 0, 0);
+        }
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++) {
+            acc1[nt].x = relu1(acc1[nt].x); acc1[nt].y = relu1(acc1[nt].y);
+            acc1[nt].z = relu1(acc1[nt].z); acc1[nt].w = relu1(acc1[nt].w);
+        }
+#pragma unroll
+        for (int t2 = 0; t2 < GIN_T2; t2++) {
+            const float4 af = w2f4[(size_t)(t * GIN_T2 + t2) * 64 + lane];
+#pragma unroll
+            for (int nt = 0; nt < NT; nt++) acc2[nt][t2] = __builtin_amdgcn_mfma_f32_16x16x4f32(af.x, acc1[nt].x, acc2[nt][t2], 0, 0, 0);
+#pragma unroll
+            for (int nt = 0; nt < NT; nt++) acc2[nt][t2] = __builtin_amdgcn_mfma_f32_16x16x4f32(af.y, acc1[nt].y, acc2[nt][t2], 0, 0, 0);
+#pragma unroll
+            for (int nt = 0; nt < NT; nt++) acc2[nt][t2] = __builtin_amdgcn_mfma_f32_16x16x4f32(af.z, acc1[nt].z, acc2[nt][t2], 0, 0, 0);
+#pragma unroll
+            for (int nt = 0; nt < NT; nt++) acc2[nt][t2] = __builtin_amdgcn_mfma_f32_16x16x4f32(af.w, acc1[nt].w, acc2[nt][t2], 0, 0, 0);
+        }
+    }
+
+#pragma unroll
+    for (int nt = 0; nt < NT; nt++) {
+        const long long node = node_base + nt * 16 + j;
+        if (node >= n_tot) continue;
+        float* row = hout + (size_t)node * GIN_D;
+#pragma unroll
+        for (int t2 = 0; t2 < GIN_T2; t2++) {
+            const int col = 16 * t2 + 4 * g;
+            if (col < GIN_D) {
+                float4_t r = acc2[nt][t2];
+                if (relu_out) { r.x = relu1(r.x); r.y = relu1(r.y); r.z = relu1(r.z); r.w = relu1(r.w); }
+                *reinterpret_cast<float4*>(row + col) = make_float4(r.x, r.y, r.z, r.w);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------- readout: mean pool + linear head
+// One wavefront per graph; lanes 0..24 take even rows, lanes 32..56 odd rows (float4 chunks).
+template <int D>
+__global__ __launch_bounds__(256) void mean_pool_linear_kernel(const float* __restrict__ h,
+                                                                const int* __restrict__ node_off,
+                                                                const float* __restrict__ pw,
+                                                                const float* __restrict__ pb,
+                                                                float* __restrict__ out, int num_graphs) {
+    constexpr int C = D / 4;
+    static_assert(C <= 32, "row must fit half a wavefront in float4 chunks");
+    const int lane = threadIdx.x & 63;
+    const int g = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (g >= num_graphs) return;
+    const int n0 = node_off[g], n1 = node_off[g + 1];
+    const int half = lane >> 5, c = lane & 31;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c < C)
+        for (int v = n0 + half; v < n1; v += 2) {
+            const float4 x = reinterpret_cast<const float4*>(h)[(size_t)v * C + c];
+            acc.x += x.x; acc.y += x.y; acc.z += x.z; acc.w += x.w;
+        }
+    acc.x += __shfl_down(acc.x, 32, 64); acc.y += __shfl_down(acc.y, 32, 64);
+    acc.z += __shfl_down(acc.z, 32, 64); acc.w += __shfl_down(acc.w, 32, 64);
+    float part = 0.f;
+    if (half == 0 && c < C) {
+        const float n = (float)(n1 - n0);
+        const float4 w = reinterpret_cast<const float4*>(pw)[c];
+        part = (acc.x / n) * w.x + (acc.y / n) * w.y + (acc.z / n) * w.z + (acc.w / n) * w.w;
+    }
+#pragma unroll
+    for (int d = 16; d >= 1; d >>= 1) part += __shfl_down(part, d, 64);
+    if (lane == 0) out[g] = pb[0] + part;
+}
+
+// ---------------------------------------------------------------- host side: weights + forward
+static int grid_for(long long items, int per_block, int cap) {
+    long long nb = (items + per_block - 1) / per_block;
+    if (nb > cap) nb = cap;
+    if (nb < 1) nb = 1;
+    return (int)nb;
+}
+
+class GinModel : public Model {
+public:
+    ~GinModel() override { free_all(); }
+    int emb_dim() const override { return GIN_D; }
+    int scratch_dim() const override { return GIN_D; }
+    bool has_edge_attr() const override { return true; }
+    int num_weight_tensors() const override { return 8; }
+    bool weights_ready() const override { return ready_; }
+
+    // host tensors: node_emb[173][100], edge_emb[5][13][100], w1[5][200][100], b1[5][200],
+    //               w2[5][100][200], b2[5][100], pred_w[1][100], pred_b[1]
+    int set_weights(const float* const* t) override {
+        const float *nemb = t[0], *eemb = t[1], *w1 = t[2], *b1 = t[3], *w2 = t[4], *b2 = t[5], *pw = t[6], *pb = t[7];
+        std::vector<float> v_nemb(nemb, nemb + ND_FEATURE_TOTAL * GIN_D);
+        std::vector<float> v_pw(pw, pw + GIN_D), v_pb(pb, pb + 1);
+        std::vector<float> ecomb((size_t)GIN_L * EDGE_COMBOS * GIN_D);
+        std::vector<float> w1f((size_t)GIN_L * GIN_T1 * 6 * 64 * 4), w1tail((size_t)GIN_L * GIN_T1 * 64);
+        std::vector<float> b1p((size_t)GIN_L * GIN_T1 * 16), b2p((size_t)GIN_L * GIN_T2 * 16);
+        std::vector<float> w2f((size_t)GIN_L * GIN_T1 * GIN_T2 * 64 * 4);
+        static const int ed_off[3] = {0, 5, 11};  // message_passing.cc:3
+        for (int l = 0; l < GIN_L; l++) {
+            const float* E = eemb + (size_t)l * ED_FEATURE_PER_LAYER * GIN_D;
+            for (int a0 = 0; a0 < 5; a0++)
+                for (int a1 = 0; a1 < 6; a1++)
+                    for (int a2 = 0; a2 < 2; a2++) {
+                        const int code = (a0 * 6 + a1) * 2 + a2;
+                        for (int d = 0; d < GIN_D; d++) {
+                            float s = 0.0f;  // same order as the reference's edge_embed loop
+                            s += E[(ed_off[0] + a0) * GIN_D + d];
+                            s += E[(ed_off[1] + a1) * GIN_D + d];
+                            s += E[(ed_off[2] + a2) * GIN_D + d];
+                            ecomb[((size_t)l * EDGE_COMBOS + code) * GIN_D + d] = s;
+                        }
+                    }
+            const float* W1 = w1 + (size_t)l * GIN_H * GIN_D;
+            const float* W2 = w2 + (size_t)l * GIN_D * GIN_H;
+            for (int tt = 0; tt < GIN_T1; tt++) {
+                for (int lane = 0; lane < 64; lane++) {
+                    const int i = lane & 15, g = lane >> 4;
+                    const int o = 16 * tt + i;
+                    for (int q = 0; q < 6; q++)
+                        for (int r = 0; r < 4; r++) {
+                            const int k = 16 * q + 4 * g + r;
+                            w1f[((((size_t)l * GIN_T1 + tt) * 6 + q) * 64 + lane) * 4 + r] = (o < GIN_H) ? W1[o * GIN_D + k] : 0.0f;
+                        }
+                    w1tail[((size_t)l * GIN_T1 + tt) * 64 + lane] = (o < GIN_H) ? W1[o * GIN_D + 96 + g] : 0.0f;
+                    for (int t2 = 0; t2 < GIN_T2; t2++) {
+                        const int d = 16 * t2 + i;
+                        for (int r = 0; r < 4; r++) {
+                            const int k = 16 * tt + 4 * g + r;
+                            w2f[((((size_t)l * GIN_T1 + tt) * GIN_T2 + t2) * 64 + lane) * 4 + r] =
+                                (d < GIN_D && k < GIN_H) ? W2[d * GIN_H + k] : 0.0f;
+                        }
+                    }
+                }
+                for (int x = 0; x < 16; x++) {
+                    const int o = 16 * tt + x;
+                    b1p[((size_t)l * GIN_T1 + tt) * 16 + x] = (o < GIN_H) ? b1[l * GIN_H + o] : 0.0f;
+                }
+            }
+            for (int x = 0; x < GIN_T2 * 16; x++) b2p[(size_t)l * GIN_T2 * 16 + x] = (x < GIN_D) ? b2[l * GIN_D + x] : 0.0f;
+        }
+        int rc;
+        if ((rc = upload(&d_nemb_, v_nemb))) return rc;
+        if ((rc = upload(&d_pw_, v_pw))) return rc;
+        if ((rc = upload(&d_pb_, v_pb))) return rc;
+        if ((rc = upload(&d_ecomb_, ecomb))) return rc;
+        if ((rc = upload(&d_w1f_, w1f))) return rc;
+        if ((rc = upload(&d_w1tail_, w1tail))) return rc;
+        if ((rc = upload(&d_b1p_, b1p))) return rc;
+        if ((rc = upload(&d_w2f_, w2f))) return rc;
+        if ((rc = upload(&d_b2p_, b2p))) return rc;
+        ready_ = true;
+        return 0;
+    }
+
+    // GIN/src/host_load.cc:24-58 (file names, element counts, raw LE float32, no header)
+    int load_weights_dir(const char* dir) override {
+        std::vector<float> w1((size_t)GIN_L * GIN_H * GIN_D), b1((size_t)GIN_L * GIN_H), w2((size_t)GIN_L * GIN_D * GIN_H),
+            b2((size_t)GIN_L * GIN_D), nemb((size_t)ND_FEATURE_TOTAL * GIN_D), eemb((size_t)GIN_L * ED_FEATURE_PER_LAYER * GIN_D),
+            pw(GIN_D), pb(1);
+        int rc;
+        if ((rc = read_floats(dir, "gin_ep1_mlp_1_weights_dim100.bin", 0, w1.size(), w1.data()))) return rc;
+        if ((rc = read_floats(dir, "gin_ep1_mlp_1_bias_dim100.bin", 0, b1.size(), b1.data()))) return rc;
+        if ((rc = read_floats(dir, "gin_ep1_mlp_2_weights_dim100.bin", 0, w2.size(), w2.data()))) return rc;
+        if ((rc = read_floats(dir, "gin_ep1_mlp_2_bias_dim100.bin", 0, b2.size(), b2.data()))) return rc;
+        // gin_ep1_eps_dim100.bin is read by the reference host and never used (host.cc:185-200)
+        if ((rc = read_floats(dir, "gin_ep1_nd_embed_dim100.bin", 0, nemb.size(), nemb.data()))) return rc;
+        if ((rc = read_floats(dir, "gin_ep1_ed_embed_dim100.bin", 0, eemb.size(), eemb.data()))) return rc;
+        if ((rc = read_floats(dir, "gin_ep1_pred_weights_dim100.bin", 0, pw.size(), pw.data()))) return rc;
+        if ((rc = read_floats(dir, "gin_ep1_pred_bias_dim100.bin", 0, pb.size(), pb.data()))) return rc;
+        const float* t[8] = {nemb.data(), eemb.data(), w1.data(), b1.data(), w2.data(), b2.data(), pw.data(), pb.data()};
+        return set_weights(t);
+    }
+
+    GinLayerDev layer_dev(int l) const {
+        GinLayerDev w;
+        w.ecomb = d_ecomb_ + (size_t)l * EDGE_COMBOS * GIN_D;
+        w.w1f = d_w1f_ + (size_t)l * GIN_T1 * 6 * 64 * 4;
+        w.w1tail = d_w1tail_ + (size_t)l * GIN_T1 * 64;
+        w.b1p = d_b1p_ + (size_t)l * GIN_T1 * 16;
+        w.w2f = d_w2f_ + (size_t)l * GIN_T1 * GIN_T2 * 64 * 4;
+        w.b2p = d_b2p_ + (size_t)l * GIN_T2 * 16;
+        return w;
+    }
+
+    void launch_aggregate(const DeviceBatch& db, int l, const float* hin, float* a, hipStream_t s) {
+        const long long items = (long long)db.b.n_tot * GIN_C;
+        const int grid = grid_for(items, 256, 256 * 6);
+        const size_t lds = sizeof(float) * EDGE_COMBOS * GIN_D;
+        gin_aggregate_kernel<GIN_D, true><<<grid, 256, lds, s>>>(hin, a, db.csr.row_ptr, db.csr.src, db.csr.ecode,
+                                                                 layer_dev(l).ecomb, db.b.n_tot);
+    }
+
+    int forward(DeviceBatch& db, Profiler& prof, hipStream_t s) override {
+        const int n = db.b.n_tot;
+        if (n <= 0) return 0;
+        {
+            ProfScope p(prof, "atom_encoder", s);
+            const int grid = grid_for((long long)n * GIN_C, 256, 256 * 8);
+            atom_encoder_kernel<GIN_D><<<grid, 256, 0, s>>>(db.b.node_feature, d_nemb_, db.h[0], n, db.csr.err);
+        }
+        int cur = 0;
+        for (int l = 0; l < GIN_L; l++) {
+            {
+                ProfScope p(prof, "gin_aggregate", s);
+                launch_aggregate(db, l, db.h[cur], db.scratch, s);
+            }
+            {
+                ProfScope p(prof, "gin_mlp", s);
+                constexpr int NT = 2;
+                const int waves = (int)ceil_div_ll(n, 16 * NT);
+                gin_mlp_kernel<NT><<<(waves + 3) / 4, 256, 0, s>>>(db.scratch, db.h[cur ^ 1], layer_dev(l), n,
+                                                                     l != GIN_L - 1);
+            }
+            cur ^= 1;
+        }
+        db.final_h = cur;
+        {
+            ProfScope p(prof, "mean_pool_linear", s);
+            mean_pool_linear_kernel<GIN_D><<<(db.b.num_graphs + 3) / 4, 256, 0, s>>>(db.h[cur], db.b.node_off, d_pw_, d_pb_,
+                                                                                     db.out, db.b.num_graphs);
+        }
+        return 0;
+    }
+
+    int aggregation_only(DeviceBatch& db, int layer, hipStream_t s) override {
+        if (layer < 0 || layer >= GIN_L) return 1;
+        launch_aggregate(db, layer, db.h[db.final_h], db.scratch, s);
+        return 0;
+    }
+
+private:
+    void free_all() {
+        float** ptrs[] = {&d_nemb_, &d_pw_, &d_pb_, &d_ecomb_, &d_w1f_, &d_w1tail_, &d_b1p_, &d_w2f_, &d_b2p_};
+        for (auto p : ptrs)
+            if (*p) { hipFree(*p); *p = nullptr; }
+    }
+    bool ready_ = false;
+    float *d_nemb_ = nullptr, *d_pw_ = nullptr, *d_pb_ = nullptr, *d_ecomb_ = nullptr, *d_w1f_ = nullptr,
+          *d_w1tail_ = nullptr, *d_b1p_ = nullptr, *d_w2f_ = nullptr, *d_b2p_ = nullptr;
+};
+
+Model* make_gin_model() { return new GinModel(); }
+
+}  // namespace fg

@@ -1,0 +1,189 @@
+// graph_build.hip -- batched load_graph for the whole super-graph, on the GPU.
+//
+// Replaces the reference's per-graph, serial load_graph (GIN/src/load_inputs.cc:87-172):
+// there, an edge list is bucketed into four per-PE tables ordered by source id (stable in
+// input order), and the scatter units replay them, so the messages of a destination v
+// arrive in ascending source id, ties in input order.  Here the same ordering is produced
+// for ALL graphs of the batch at once as one destination-major CSR over global node ids:
+//
+//   row v = { input edges (u -> v) } sorted by (u, input index)
+//
+// Integer work only; tests compare it bit-exactly with the oracle's tables.
+//
+// Kernels (all flat over edges / nodes, no per-graph size cap):
+//   globalize_count : wave per graph; local -> global ids, in-degree / out-degree histograms,
+//                     range validation of endpoints and edge attributes
+//   exclusive scan  : in-degree -> row_ptr
+//   place           : arbitrary-order placement with a per-row cursor
+//   rank            : per-row rank sort by (u, input index) -> deterministic final order
+#include "common.h"
+
+namespace fg {
+
+// ------------------------------------------------------------------ scan
+constexpr int SCAN_THREADS = 256;
+constexpr int SCAN_ITEMS = 8;
+constexpr int SCAN_TILE = SCAN_THREADS * SCAN_ITEMS;
+
+__device__ inline int wave_inclusive_scan(int x) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        int y = __shfl_up(x, d, 64);
+        if (lane >= d) x += y;
+    }
+    return x;
+}
+
+// out[i] = exclusive scan within the tile; block_sums[b] = tile total
+__global__ __launch_bounds__(SCAN_THREADS) void scan_tile_kernel(const int* __restrict__ in, int* __restrict__ out,
+                                                                  int* __restrict__ block_sums, int n) {
+    __shared__ int wave_tot[SCAN_THREADS / 64];
+    const int base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
+    int v[SCAN_ITEMS];
+    int sum = 0;
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; i++) {
+        v[i] = (base + i < n) ? in[base + i] : 0;
+        sum += v[i];
+    }
+    int incl = wave_inclusive_scan(sum);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 63) wave_tot[wave] = incl;
+    __syncthreads();
+    int wave_base = 0;
+    for (int w = 0; w < wave; w++) wave_base += wave_tot[w];
+    int run = wave_base + incl - sum;
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; i++) {
+        if (base + i < n) out[base + i] = run;
+        run += v[i];
+    }
+    if (threadIdx.x == SCAN_THREADS - 1) block_sums[blockIdx.x] = run;
+}
+
+// single block: exclusive scan of block_sums in place; writes grand total to *total
+__global__ __launch_bounds__(SCAN_THREADS) void scan_sums_kernel(int* __restrict__ block_sums, int nblocks,
+                                                                  int* __restrict__ total) {
+    __shared__ int wave_tot[SCAN_THREADS / 64];
+    __shared__ int carry_s;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (int base = 0; base < nblocks; base += SCAN_THREADS) {
+        int i = base + threadIdx.x;
+        int x = (i < nblocks) ? block_sums[i] : 0;
+        int incl = wave_inclusive_scan(x);
+        const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+        if (lane == 63) wave_tot[wave] = incl;
+        __syncthreads();
+        int wave_base = 0;
+        for (int w = 0; w < wave; w++) wave_base += wave_tot[w];
+        int carry = carry_s;
+        if (i < nblocks) block_sums[i] = carry + wave_base + incl - x;
+        __syncthreads();
+        if (threadIdx.x == SCAN_THREADS - 1) carry_s = carry + wave_base + incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *total = carry_s;
+}
+
+__global__ __launch_bounds__(SCAN_THREADS) void scan_add_kernel(int* __restrict__ out, const int* __restrict__ block_sums,
+                                                                 int n) {
+    const int off = block_sums[blockIdx.x];
+    const int base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; i++)
+        if (base + i < n) out[base + i] += off;
+}
+
+// in-place exclusive scan of data[0..n), total written to data[n]
+static void exclusive_scan_inplace(int* data, int n, int* block_sums, hipStream_t s) {
+    if (n <= 0) {
+        hipMemsetAsync(data, 0, sizeof(int), s);
+        return;
+    }
+    int nblocks = (n + SCAN_TILE - 1) / SCAN_TILE;
+    scan_tile_kernel<<<nblocks, SCAN_THREADS, 0, s>>>(data, data, block_sums, n);
+    scan_sums_kernel<<<1, SCAN_THREADS, 0, s>>>(block_sums, nblocks, data + n);
+    if (nblocks > 1) scan_add_kernel<<<nblocks, SCAN_THREADS, 0, s>>>(data, block_sums, n);
+}
+
+// ------------------------------------------------------------------ globalize + histograms
+// One wavefront per graph: its edges are a contiguous slice of the edge list.
+__global__ __launch_bounds__(256) void globalize_count_kernel(BatchView b, CsrView c, bool has_attr) {
+    const int wave_in_block = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int g = blockIdx.x * 4 + wave_in_block;
+    if (g >= b.num_graphs) return;
+    const int n = b.nums_of_nodes[g];
+    const int noff = b.node_off[g];
+    const int e0 = b.edge_off[g], e1 = b.edge_off[g + 1];
+    for (int e = e0 + lane; e < e1; e += 64) {
+        const int2 uv = reinterpret_cast<const int2*>(b.edge_list)[e];
+        int u = uv.x, v = uv.y;
+        const bool ok = (u >= 0) & (u < n) & (v >= 0) & (v < n);
+        if (!ok) {  // flag it, then treat as a self-loop on node 0 so every later index stays in range
+            atomicMax(c.err, ERR_EDGE_RANGE);
+            u = 0;
+            v = 0;
+        }
+        c.gsrc[e] = noff + u;
+        c.gdst[e] = noff + v;
+        atomicAdd(&c.row_ptr[noff + v], 1);   // in-degree histogram (scanned into row_ptr later)
+        atomicAdd(&c.out_deg[noff + u], 1);   // reference degree_table[u] (load_inputs.cc:128)
+        if (has_attr) {
+            const int a0 = b.edge_attr[3 * (size_t)e], a1 = b.edge_attr[3 * (size_t)e + 1],
+                      a2 = b.edge_attr[3 * (size_t)e + 2];
+            // table cardinalities {5,6,2}: GIN/src/host_load.cc:6
+            bool aok = (a0 >= 0) & (a0 < 5) & (a1 >= 0) & (a1 < 6) & (a2 >= 0) & (a2 < 2);
+            if (!aok) atomicMax(c.err, ERR_EDGE_ATTR);
+            c.tmp[e] = aok ? (a0 * 6 + a1) * 2 + a2 : 0;  // staged per input edge; permuted in rank
+        }
+    }
+}
+
+// arbitrary-order placement: slot = row_ptr[v] + cursor[v]++
+__global__ __launch_bounds__(256) void place_kernel(CsrView c, int e_tot, int* __restrict__ slot_edge) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= e_tot) return;
+    const int v = c.gdst[e];
+    const int slot = c.row_ptr[v] + atomicAdd(&c.cursor[v], 1);
+    slot_edge[slot] = e;
+}
+
+// rank sort inside each row by (source id, input index): unique keys => deterministic order
+__global__ __launch_bounds__(256) void rank_kernel(CsrView c, int e_tot, const int* __restrict__ slot_edge,
+                                                    const int* __restrict__ code_by_edge) {
+    const int s = blockIdx.x * 256 + threadIdx.x;
+    if (s >= e_tot) return;
+    const int e = slot_edge[s];
+    const int v = c.gdst[e], u = c.gsrc[e];
+    const int beg = c.row_ptr[v], end = c.row_ptr[v + 1];
+    int rank = 0;
+    for (int t = beg; t < end; t++) {
+        const int e2 = slot_edge[t];
+        const int u2 = c.gsrc[e2];
+        rank += (u2 < u) | ((u2 == u) & (e2 < e));
+    }
+    c.src[beg + rank] = u;
+    c.eid[beg + rank] = e;
+    if (code_by_edge) c.ecode[beg + rank] = (uint8_t)code_by_edge[e];
+}
+
+void launch_build_csr(const BatchView& b, const CsrView& c, bool has_edge_attr, hipStream_t s) {
+    // c.tmp holds [E] edge codes (first half) and [E] slot->edge map (second half): sized 2E by the engine
+    int* code_by_edge = c.tmp;
+    int* slot_edge = c.tmp + b.e_tot;
+    hipMemsetAsync(c.row_ptr, 0, sizeof(int) * ((size_t)b.n_tot + 1), s);
+    hipMemsetAsync(c.out_deg, 0, sizeof(int) * (size_t)b.n_tot, s);
+    hipMemsetAsync(c.cursor, 0, sizeof(int) * (size_t)b.n_tot, s);
+    if (b.num_graphs > 0)
+        globalize_count_kernel<<<(b.num_graphs + 3) / 4, 256, 0, s>>>(b, c, has_edge_attr);
+    exclusive_scan_inplace(c.row_ptr, b.n_tot, c.block_sums, s);
+    if (b.e_tot > 0) {
+        const int nb = (b.e_tot + 255) / 256;
+        place_kernel<<<nb, 256, 0, s>>>(c, b.e_tot, slot_edge);
+        rank_kernel<<<nb, 256, 0, s>>>(c, b.e_tot, slot_edge, has_edge_attr ? code_by_edge : nullptr);
+    }
+}
+
+}  // namespace fg

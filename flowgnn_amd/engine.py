@@ -1,0 +1,170 @@
+"""Host-side mirror of the reference's per-model entry points over the C ABI.
+
+`Engine` wraps the handle API (flowgnn_create / set_weights / set_batch / run / get_results);
+`compute_graphs` calls the reference-compatible `<M>_compute_graphs` symbol with host arrays,
+exactly the argument list of the reference kernel (GIN/src/dcl.h:75-94).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional
+
+import numpy as np
+
+from . import _lib
+from .graphpack import GraphBatch
+
+
+class FlowGNNError(RuntimeError):
+    def __init__(self, code: int, where: str, detail: str = ""):
+        self.code = code
+        super().__init__(f"{where}: {_lib.STATUS.get(code, code)} {detail}".strip())
+
+
+def _i32(a) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def _f32(a) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _pi(a: Optional[np.ndarray]):
+    return None if a is None else a.ctypes.data_as(_lib.p_int)
+
+
+def _pf(a: Optional[np.ndarray]):
+    return None if a is None else a.ctypes.data_as(_lib.p_float)
+
+
+class Engine:
+    """One engine = one GPU, one stream, one model's weights, one resident batch."""
+
+    def __init__(self, model: str = "GIN", device: int = 0):
+        self.lib = _lib.load()
+        self.model = model.upper()
+        if self.model not in _lib.MODEL_IDS:
+            raise ValueError(f"unknown model {model}")
+        self._h = C.c_void_p()
+        self._check(self.lib.flowgnn_create(_lib.MODEL_IDS[self.model], device, C.byref(self._h)), "flowgnn_create")
+        self._keep = []
+
+    def _check(self, rc: int, where: str):
+        if rc != 0:
+            detail = ""
+            if self._h:
+                detail = (self.lib.flowgnn_last_error(self._h) or b"").decode(errors="replace")
+            raise FlowGNNError(rc, where, detail)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.flowgnn_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- weights
+    def set_weights(self, w: Dict[str, np.ndarray]):
+        arrs = [_f32(v) for v in w.values()]
+        if self.model in ("GIN", "GIN-VN"):
+            self._check(self.lib.flowgnn_set_weights_gin(self._h, *[_pf(a) for a in arrs]), "flowgnn_set_weights_gin")
+        else:
+            raise NotImplementedError(self.model)
+
+    def load_weights_dir(self, directory: str):
+        self._check(self.lib.flowgnn_load_weights_dir(self._h, directory.encode()), "flowgnn_load_weights_dir")
+
+    # ---- batch
+    def set_batch(self, batch: GraphBatch):
+        nn, ne = _i32(batch.nums_of_nodes), _i32(batch.nums_of_edges)
+        nf, el, ea = _i32(batch.node_feature), _i32(batch.edge_list), _i32(batch.edge_attr)
+        eig = None if batch.node_eigen is None else _f32(batch.node_eigen)
+        self._check(self.lib.flowgnn_set_batch(self._h, batch.num_graphs, _pi(nn), _pi(ne), _pi(nf), _pi(el), _pi(ea),
+                                               _pf(eig)), "flowgnn_set_batch")
+        self.num_graphs = batch.num_graphs
+        self.total_nodes = batch.total_nodes
+        self.total_edges = batch.total_edges
+
+    def run(self):
+        self._check(self.lib.flowgnn_run(self._h), "flowgnn_run")
+
+    def sync(self):
+        self._check(self.lib.flowgnn_sync(self._h), "flowgnn_sync")
+
+    def results(self) -> np.ndarray:
+        out = np.empty(self.num_graphs, dtype=np.float32)
+        self._check(self.lib.flowgnn_get_results(self._h, _pf(out)), "flowgnn_get_results")
+        return out
+
+    def results_device_ptr(self) -> int:
+        p = C.c_void_p()
+        self._check(self.lib.flowgnn_results_device(self._h, C.byref(p)), "flowgnn_results_device")
+        return int(p.value or 0)
+
+    def set_results_buffer(self, device_ptr: int):
+        self._check(self.lib.flowgnn_set_results_buffer(self._h, C.c_void_p(device_ptr)), "flowgnn_set_results_buffer")
+
+    def forward(self, batch: GraphBatch) -> np.ndarray:
+        self.set_batch(batch)
+        self.run()
+        return self.results()
+
+    # ---- taps
+    def csr(self):
+        n, e = self.total_nodes, self.total_edges
+        row_ptr = np.empty(n + 1, dtype=np.int32)
+        src = np.empty(e, dtype=np.int32)
+        eid = np.empty(e, dtype=np.int32)
+        out_deg = np.empty(n, dtype=np.int32)
+        self._check(self.lib.flowgnn_get_csr(self._h, _pi(row_ptr), _pi(src), _pi(eid), _pi(out_deg)), "flowgnn_get_csr")
+        return row_ptr, src, eid, out_deg
+
+    def final_h(self) -> np.ndarray:
+        dim = C.c_int()
+        self._check(self.lib.flowgnn_get_h(self._h, None, C.byref(dim)), "flowgnn_get_h")
+        h = np.empty((self.total_nodes, dim.value), dtype=np.float32)
+        self._check(self.lib.flowgnn_get_h(self._h, _pf(h), C.byref(dim)), "flowgnn_get_h")
+        return h
+
+    # ---- profiling
+    def profile_enable(self, on: bool = True):
+        self._check(self.lib.flowgnn_profile_enable(self._h, 1 if on else 0), "flowgnn_profile_enable")
+
+    def profile_read(self) -> Dict[str, Dict[str, float]]:
+        n = C.c_int()
+        names = (C.c_char_p * 32)()
+        ms = (C.c_double * 32)()
+        cnt = (C.c_longlong * 32)()
+        self._check(self.lib.flowgnn_profile_read(self._h, C.byref(n), names, ms, cnt), "flowgnn_profile_read")
+        return {names[i].decode(): {"total_ms": ms[i], "launches": int(cnt[i])} for i in range(n.value)}
+
+    def aggregation_only_ms(self, layer: int = 0, iters: int = 10) -> float:
+        ms = C.c_float()
+        self._check(self.lib.flowgnn_run_aggregation_only(self._h, layer, iters, C.byref(ms)),
+                    "flowgnn_run_aggregation_only")
+        return float(ms.value)
+
+
+def GIN_compute_graphs(batch: GraphBatch, weight_sets, reload_weights=None) -> np.ndarray:
+    """Call the reference-compatible C symbol GIN_compute_graphs (GIN/src/dcl.h:75-94).
+    `weight_sets` is a list of weight dicts (leading [S] dimension of every weight pointer)."""
+    lib = _lib.load()
+    G = batch.num_graphs
+    if reload_weights is None:
+        reload_weights = np.zeros(G, dtype=np.int32)
+        if G:
+            reload_weights[0] = 1
+    stacked = [np.ascontiguousarray(np.stack([np.asarray(ws[k], dtype=np.float32) for ws in weight_sets]))
+               for k in weight_sets[0].keys()]
+    out = np.zeros(G, dtype=np.float32)
+    nn, ne, rw = _i32(batch.nums_of_nodes), _i32(batch.nums_of_edges), _i32(reload_weights)
+    nf, el, ea = _i32(batch.node_feature), _i32(batch.edge_list), _i32(batch.edge_attr)
+    rc = lib.GIN_compute_graphs(G, _pi(nn), _pi(ne), _pi(rw), _pf(out), _pi(nf), _pi(el), _pi(ea),
+                                *[_pf(a) for a in stacked])
+    if rc:
+        raise FlowGNNError(rc, "GIN_compute_graphs")
+    return out

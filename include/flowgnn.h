@@ -1,0 +1,178 @@
+/*
+ * flowgnn.h -- C ABI of the MI355X-native FlowGNN inference engine.
+ *
+ * This is the drop-in boundary for FlowGNN's NT/MP hot path.  Two layers:
+ *
+ *  (1) Reference-compatible entry points  <M>_compute_graphs(...)
+ *      Same symbol names and argument order as the reference's HLS kernels
+ *      (cited per function; paths relative to the reference repo), with `float` in
+ *      place of FM_TYPE/WT_TYPE (ap_fixed<16,6>) and `int` status instead of `void`.
+ *      All pointers are caller-owned HOST buffers; `out` is written on return.
+ *      Graphs are concatenated with node ids LOCAL to each graph, exactly as the
+ *      reference host builds them (GIN/src/host.cc:119-138).
+ *
+ *  (2) Handle API  flowgnn_*  (what (1) is implemented on)
+ *      One engine per GPU, one HIP stream per engine; weights and the graph batch
+ *      stay resident in HBM across runs, so a caller can time the device path
+ *      alone, as the reference times kernel execution alone (run_experiments.sh:44).
+ *
+ * No torch / C++ types cross this boundary: plain pointers and sizes only.
+ */
+#ifndef FLOWGNN_H
+#define FLOWGNN_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- status codes (the reference returns void and never checks) ---- */
+#define FLOWGNN_OK 0
+#define FLOWGNN_ERR_ARG 1          /* null pointer, negative count, num_nodes <= 0 */
+#define FLOWGNN_ERR_EDGE_RANGE 2   /* edge endpoint outside [0, num_nodes) of its graph */
+#define FLOWGNN_ERR_EDGE_ATTR 3    /* edge attribute outside its embedding table */
+#define FLOWGNN_ERR_NODE_FEAT 4    /* node feature outside its embedding table */
+#define FLOWGNN_ERR_HIP 5          /* HIP runtime error (see flowgnn_last_error) */
+#define FLOWGNN_ERR_STATE 6        /* weights or batch not set */
+#define FLOWGNN_ERR_IO 7           /* weight / graph file missing or short */
+#define FLOWGNN_ERR_UNSUPPORTED 8
+
+/* ---- model ids ---- */
+#define FLOWGNN_MODEL_GIN 0
+#define FLOWGNN_MODEL_GIN_VN 1 /* same kernel as GIN; host appends a virtual node (GIN-VN/src/host_load.cc:125-153) */
+#define FLOWGNN_MODEL_GCN 2
+#define FLOWGNN_MODEL_GAT 3
+#define FLOWGNN_MODEL_PNA 4
+#define FLOWGNN_MODEL_DGN 5
+
+/* ---- fixed model constants (GIN/src/dcl.h:16-26) ---- */
+#define FLOWGNN_ND_FEATURE 9
+#define FLOWGNN_ND_FEATURE_TOTAL 173
+#define FLOWGNN_EDGE_ATTR 3
+#define FLOWGNN_ED_FEATURE_PER_LAYER 13
+
+/* =====================================================================
+ * (1) Reference-compatible entry points
+ * ===================================================================== */
+
+/*
+ * Replaces GIN_compute_graphs, GIN/src/dcl.h:75-94 (def. GIN/src/GIN_compute.cc:7-99);
+ * also the GIN-VN kernel (GIN-VN/src/dcl.h, byte-identical).
+ *   out                      [num_graphs][1]
+ *   node_feature_in          int [N_tot][9]
+ *   edge_list_in             int [E_tot][2]  (u, v): h[u] is sent to v
+ *   edge_attr_in             int [E_tot][3]
+ *   *_weight*                leading dimension = weight-set index, selected by the
+ *                            running count of reload_weights[] (GIN_compute.cc:51-53)
+ *   node_embedding_weight_in [S][173][100]   edge_embedding_weight_in [S][5][13][100]
+ *   node_mlp_1_weights [S][5][200][100]  node_mlp_1_bias [S][5][200]
+ *   node_mlp_2_weights [S][5][100][200]  node_mlp_2_bias [S][5][100]
+ *   graph_pred_weights_in [S][1][100]    graph_pred_bias_in [S][1]
+ */
+int GIN_compute_graphs(int num_graphs, int* nums_of_nodes, int* nums_of_edges,
+                       int* reload_weights, float* out,
+                       int* node_feature_in, int* edge_list_in, int* edge_attr_in,
+                       float* node_embedding_weight_in, float* edge_embedding_weight_in,
+                       float* node_mlp_1_weights, float* node_mlp_1_bias,
+                       float* node_mlp_2_weights, float* node_mlp_2_bias,
+                       float* graph_pred_weights_in, float* graph_pred_bias_in);
+
+/* =====================================================================
+ * (2) Handle API
+ * ===================================================================== */
+typedef struct flowgnn_engine flowgnn_engine;
+
+/* Create an engine for `model` on HIP device `device_id`. */
+int flowgnn_create(int model, int device_id, flowgnn_engine** out);
+int flowgnn_destroy(flowgnn_engine* e);
+/* Last HIP / IO error text for this engine (static storage, never NULL). */
+const char* flowgnn_last_error(const flowgnn_engine* e);
+
+/*
+ * Weights, one weight set, host pointers, layouts as in the entry points above
+ * without the leading [S].  Replaces the device-side load_weights
+ * (GIN/src/load_inputs.cc:7-85).
+ */
+int flowgnn_set_weights_gin(flowgnn_engine* e,
+                            const float* node_embedding_weight, const float* edge_embedding_weight,
+                            const float* node_mlp_1_weights, const float* node_mlp_1_bias,
+                            const float* node_mlp_2_weights, const float* node_mlp_2_bias,
+                            const float* graph_pred_weights, const float* graph_pred_bias);
+
+/*
+ * Read the reference's raw little-endian float32 .bin weight files from `dir`
+ * (file names and offsets of <M>/src/host_load.cc; GIN: host_load.cc:24-58).
+ */
+int flowgnn_load_weights_dir(flowgnn_engine* e, const char* dir);
+
+/*
+ * Upload one concatenated batch (host pointers; copied to HBM, synchronous).
+ * edge_attr may be NULL for models without edge features (GAT/PNA/DGN);
+ * node_eigen ([N_tot][4] float, DGN/src/dcl.h:67) may be NULL except for DGN.
+ * Replaces the host's flat-vector assembly + buffer migration
+ * (GIN/src/host.cc:119-182).
+ */
+int flowgnn_set_batch(flowgnn_engine* e, int num_graphs,
+                      const int* nums_of_nodes, const int* nums_of_edges,
+                      const int* node_feature, const int* edge_list, const int* edge_attr,
+                      const float* node_eigen);
+
+/*
+ * Enqueue one full forward of the resident batch on the engine's stream:
+ * batched load_graph (CSR by destination) -> atom encoder -> conv layers ->
+ * readout.  Asynchronous; results land in the engine's device result buffer.
+ * Replaces one enqueueTask of <M>_compute_graphs (GIN/src/host.cc:203-210).
+ */
+int flowgnn_run(flowgnn_engine* e);
+/* Wait for the engine's stream; returns the first validation / HIP error seen. */
+int flowgnn_sync(flowgnn_engine* e);
+/* Copy results [num_graphs] to host (synchronises the stream first). */
+int flowgnn_get_results(flowgnn_engine* e, float* out_host);
+/* Device pointer of the result buffer (float[num_graphs]); valid until next set_batch. */
+int flowgnn_results_device(flowgnn_engine* e, void** d_out);
+/*
+ * Redirect results into a caller-owned DEVICE buffer of at least num_graphs floats (e.g. a
+ * torch tensor's data_ptr(), so RCCL can all-gather it without a copy); NULL restores the
+ * engine's own buffer.  Applies to the resident batch and is reset by flowgnn_set_batch.
+ */
+int flowgnn_set_results_buffer(flowgnn_engine* e, void* device_ptr);
+/* The engine's hipStream_t as an opaque pointer (for event timing by a caller). */
+int flowgnn_stream(flowgnn_engine* e, void** stream);
+
+/* Totals of the resident batch. */
+int flowgnn_batch_info(const flowgnn_engine* e, long long* num_graphs,
+                       long long* total_nodes, long long* total_edges);
+
+/*
+ * Debug / parity taps (device -> host copies; synchronise first).
+ *  flowgnn_get_csr: the batched destination-major CSR built by load_graph:
+ *     row_ptr[N_tot+1], src[E_tot] (global source id, ascending per row, ties in
+ *     input order), eid[E_tot] (input edge index), out_deg[N_tot].
+ *  flowgnn_get_h: node embeddings after the last executed stage, [N_tot][dim].
+ */
+int flowgnn_get_csr(flowgnn_engine* e, int* row_ptr, int* src, int* eid, int* out_deg);
+int flowgnn_get_h(flowgnn_engine* e, float* h_host, int* dim);
+
+/*
+ * Per-kernel profile with HIP events on the engine's stream.
+ *  flowgnn_profile_enable(e, 1) brackets every kernel launch of subsequent runs
+ *  with events; flowgnn_profile_read fills, for kernel slot k < *count,
+ *  total milliseconds and launch counts since enable, and the kernel names.
+ */
+#define FLOWGNN_MAX_PROFILE_SLOTS 32
+int flowgnn_profile_enable(flowgnn_engine* e, int on);
+int flowgnn_profile_read(flowgnn_engine* e, int* count, const char** names,
+                         double* total_ms, long long* launches);
+
+/*
+ * Standalone aggregation kernel of layer `layer` on the resident batch (the
+ * message-passing unit alone, m written to HBM): used to measure the HBM roofline
+ * of the gather + segmented-sum path.  Requires a prior flowgnn_run.
+ */
+int flowgnn_run_aggregation_only(flowgnn_engine* e, int layer, int iters, float* avg_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

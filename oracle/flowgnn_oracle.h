@@ -1,0 +1,67 @@
+/*
+ * flowgnn_oracle.h -- CPU restatement of FlowGNN's NT/MP hot path (TEST INFRASTRUCTURE).
+ *
+ * PARITY UNPINNED: the reference ships no golden vectors, no tests and no graph
+ * packs, and its kernel sources cannot be built
+ * in this image without Vitis HLS headers (ap_fixed.h, hls_stream.h, hls_math.h),
+ * which are not vendored.  This oracle is therefore a from-reading restatement of
+ * the reference algorithm with FM_TYPE = WT_TYPE = float, loop order and
+ * summation order preserved; it is cross-checked by an independent float64 NumPy
+ * restatement on the batched super-graph (tests/test_oracle_vs_numpy.py).
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may link or
+ * call this library.  The product path (flowgnn_amd/) never does.
+ *
+ * Every function cites the reference file:line it follows (paths relative to
+ * /root/reference).
+ */
+#ifndef FLOWGNN_ORACLE_H
+#define FLOWGNN_ORACLE_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Model constants, GIN/src/dcl.h:16-34 (same in GCN; PNA/DGN/GAT override some). */
+#define ORC_ND_FEATURE 9
+#define ORC_ND_FEATURE_TOTAL 173
+#define ORC_EDGE_ATTR 3
+#define ORC_ED_FEATURE_PER_LAYER 13
+#define ORC_EDGE_PARALLEL 4
+
+/*
+ * Index bookkeeping of ONE graph exactly as GIN/src/load_inputs.cc:87-172 builds
+ * it: per-PE (bank = v % 4) source-bucketed neighbour tables.  Caller allocates:
+ *   degree_table[n], degree_tables[4*n] (pe-major), neighbor_tables[4*e] (pe-major,
+ *   stride e), edge_attrs[4*e*3] (pe-major, stride e*3), num_of_edges_per_pe[4].
+ * Integer work: the GPU CSR must reproduce the per-destination order this implies
+ * bit-exactly.
+ */
+void orc_gin_load_graph(const int* edge_list, const int* edge_attr, int n, int e,
+                        int* degree_table, int* degree_tables, int* neighbor_tables,
+                        int* edge_attrs, int* num_of_edges_per_pe);
+
+/*
+ * GIN / GIN-VN forward over a concatenated batch, float semantics.
+ * Mirrors GIN_compute_graphs, GIN/src/GIN_compute.cc:7-99 (argument order of
+ * GIN/src/dcl.h:75-94 with float for FM_TYPE/WT_TYPE).
+ * h_dump (optional, may be NULL): receives h after every NT stage,
+ *   layout [6][N_tot][100] (index 0 = atom encoder output, 1..5 = layer outputs).
+ * nthreads <= 1: scalar; > 1: OpenMP over graphs (results identical, graphs are
+ * independent).  Returns 0, or nonzero on a feature index outside its table.
+ */
+int orc_GIN_compute_graphs(int num_graphs, const int* nums_of_nodes, const int* nums_of_edges,
+                           const int* reload_weights, float* out,
+                           const int* node_feature_in, const int* edge_list_in,
+                           const int* edge_attr_in,
+                           const float* node_embedding_weight_in,
+                           const float* edge_embedding_weight_in,
+                           const float* node_mlp_1_weights, const float* node_mlp_1_bias,
+                           const float* node_mlp_2_weights, const float* node_mlp_2_bias,
+                           const float* graph_pred_weights_in, const float* graph_pred_bias_in,
+                           float* h_dump, int nthreads);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

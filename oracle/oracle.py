@@ -1,0 +1,83 @@
+"""ctypes binding of oracle/liboracle.so -- TEST INFRASTRUCTURE ONLY (see flowgnn_oracle.h).
+
+Importable only from tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "liboracle.so")
+_lib = None
+
+_pi = C.POINTER(C.c_int)
+_pf = C.POINTER(C.c_float)
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", _HERE])
+
+
+def load():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB):
+            build()
+        lib = C.CDLL(_LIB)
+        lib.orc_gin_load_graph.argtypes = [_pi, _pi, C.c_int, C.c_int, _pi, _pi, _pi, _pi, _pi]
+        lib.orc_gin_load_graph.restype = None
+        lib.orc_GIN_compute_graphs.argtypes = [C.c_int, _pi, _pi, _pi, _pf, _pi, _pi, _pi] + [_pf] * 8 + [_pf, C.c_int]
+        lib.orc_GIN_compute_graphs.restype = C.c_int
+        _lib = lib
+    return _lib
+
+
+def _i(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def _f(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def gin_load_graph(edge_list, edge_attr, n):
+    """Reference load_graph tables of one graph (GIN/src/load_inputs.cc:87-172)."""
+    lib = load()
+    el, ea = _i(edge_list).reshape(-1, 2), _i(edge_attr).reshape(-1, 3)
+    e = el.shape[0]
+    deg = np.zeros(max(n, 1), np.int32)
+    degs = np.zeros(4 * max(n, 1), np.int32)
+    nbr = np.zeros(4 * max(e, 1), np.int32)
+    att = np.zeros(4 * max(e, 1) * 3, np.int32)
+    epp = np.zeros(4, np.int32)
+    lib.orc_gin_load_graph(el.ctypes.data_as(_pi), ea.ctypes.data_as(_pi), n, e, deg.ctypes.data_as(_pi),
+                           degs.ctypes.data_as(_pi), nbr.ctypes.data_as(_pi), att.ctypes.data_as(_pi),
+                           epp.ctypes.data_as(_pi))
+    return dict(degree_table=deg[:n], degree_tables=degs.reshape(4, -1)[:, :n],
+                neighbor_tables=nbr.reshape(4, -1), edge_attrs=att.reshape(4, -1, 3), num_of_edges_per_pe=epp)
+
+
+def gin_forward(batch, weight_sets, reload_weights=None, dump_h=False, nthreads=1):
+    """orc_GIN_compute_graphs over a GraphBatch; weight_sets = list of weight dicts."""
+    lib = load()
+    G = batch.num_graphs
+    if reload_weights is None:
+        reload_weights = np.zeros(G, np.int32)
+        if G:
+            reload_weights[0] = 1
+    keys = list(weight_sets[0].keys())
+    stacked = [_f(np.stack([np.asarray(ws[k], np.float32) for ws in weight_sets])) for k in keys]
+    out = np.zeros(G, np.float32)
+    nn, ne, rw = _i(batch.nums_of_nodes), _i(batch.nums_of_edges), _i(reload_weights)
+    nf, el, ea = _i(batch.node_feature), _i(batch.edge_list), _i(batch.edge_attr)
+    hd = np.zeros((6, batch.total_nodes, 100), np.float32) if dump_h else None
+    rc = lib.orc_GIN_compute_graphs(G, nn.ctypes.data_as(_pi), ne.ctypes.data_as(_pi), rw.ctypes.data_as(_pi),
+                                    out.ctypes.data_as(_pf), nf.ctypes.data_as(_pi), el.ctypes.data_as(_pi),
+                                    ea.ctypes.data_as(_pi), *[a.ctypes.data_as(_pf) for a in stacked],
+                                    None if hd is None else hd.ctypes.data_as(_pf), nthreads)
+    if rc:
+        raise RuntimeError(f"oracle GIN rc={rc}")
+    return (out, hd) if dump_h else out
