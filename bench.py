@@ -41,7 +41,7 @@ def cpu_baseline(batch, w, budget_s: float = 15.0):
     """The oracle (CPU restatement of the reference, kind='port') timed on this host's cores on a
     bounded sample of the same workload."""
     from oracle import oracle
-    cores = os.cpu_count() or 1
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     probe = batch.slice(0, min(256, batch.num_graphs))
     t0 = time.perf_counter()
     oracle.gin_forward(probe, [w], nthreads=1)
@@ -131,6 +131,8 @@ def main():
         agg_bytes, mlp_flops = algorithmic(N, E)
         kern = {k: (v["total_ms"] / max(v["launches"], 1)) for k, v in prof.items()}
         dominant = max(prof.items(), key=lambda kv: kv[1]["total_ms"])[0] if prof else None
+        if "gin_aggregate" not in kern:  # fused layer: measure the message-passing unit alone as well
+            kern["gin_aggregate"] = eng.aggregation_only_ms(layer=0, iters=10)
         roof = None
         if dominant == "gin_aggregate":
             ach = agg_bytes / (kern[dominant] * 1e-3) / 1e9

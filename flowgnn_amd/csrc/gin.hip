@@ -16,6 +16,7 @@
 #include "common.h"
 #include <cstring>
 #include <cstdio>
+#include <cstdlib>
 
 namespace fg {
 
@@ -79,7 +80,12 @@ __global__ __launch_bounds__(256) void gin_aggregate_kernel(const float* __restr
     __syncthreads();
     const float4* h4 = reinterpret_cast<const float4*>(h);
     const long long total = (long long)n_tot * C;
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    // each workgroup walks ONE contiguous span of rows: a row's neighbours (same graph, a few rows away)
+    // are then re-read from this CU's L1 / this XCD's L2 instead of being fetched again by another XCD
+    long long span = (total + gridDim.x - 1) / gridDim.x;
+    span = (span + 255) / 256 * 256;
+    const long long i_end = (span * (blockIdx.x + 1) < total) ? span * (blockIdx.x + 1) : total;
+    for (long long i = span * blockIdx.x + threadIdx.x; i < i_end; i += 256) {
         const int v = (int)(i / C);
         const int c = (int)(i - (long long)v * C);
         const int beg = row_ptr[v], end = row_ptr[v + 1];
@@ -223,6 +229,210 @@ __global__ __launch_bounds__(256) void gin_mlp_kernel(const float* __restrict__ 
     }
 }
 
+// ---------------------------------------------------------------- fused layer: MP + NT in one kernel
+// One workgroup (4 waves) owns a tile of 64*NT consecutive destination nodes; each wave owns NT MFMA
+// column tiles of 16 nodes and runs them end to end:
+//   gather   lane (j, g) walks node j's CSR row and accumulates relu(h[u] + ecomb[code]) directly in the
+//            register layout of the MLP1 B operand (k = 16 q + 4 g + r, plus k = 96 + g), adds h[v];
+//            rows of a graph are neighbours in memory, so the re-reads are L1/L2 hits
+//   MLP      as gin_mlp_kernel, but the weight fragments are streamed L2 -> LDS by LDS-DMA
+//            (global_load_lds_dwordx4), double buffered, one barrier per step; the message m and the
+//            hidden layer never leave registers.  Step c runs MLP1 of hidden tile c (25 dependent MFMAs
+//            on one accumulator) interleaved with MLP2 of hidden tile c-1 (28 MFMAs on 7 accumulators),
+//            so one wave alone can keep the matrix pipe issuing.
+// Weight stream per layer: 14 chunks of 14 KiB (GinModel::set_weights packs them); chunk c holds
+//   floats [0,1536) W1 tile c (q, lane, r) | [1536,1600) W1 tail tile c | [1600,3392) W2 tile c-1 (t2, lane, r)
+//          [3392,3408) b1 slice tile c | [3408,3520) b2 padded | pad to 3584
+// LDS: region A 24000 B = edge-embedding combos during the gather, then weight buffer for odd chunks;
+//      region B 14336 B = weight buffer for even chunks.  38336 B per workgroup -> 4 workgroups per CU.
+constexpr int GIN_CHUNKS = GIN_T1 + 1;
+constexpr int GIN_CHUNK_FLOATS = 3584;
+constexpr int GIN_CHUNK_BYTES = GIN_CHUNK_FLOATS * 4;   // 14 pieces of 1 KiB
+constexpr int GIN_ECOMB_BYTES = EDGE_COMBOS * GIN_D * 4;  // 24000
+constexpr int GIN_FUSED_LDS = GIN_ECOMB_BYTES + GIN_CHUNK_BYTES;
+
+__device__ inline void gin_issue_chunk(const float* __restrict__ gchunk, char* lds_buf, int wave, int lane) {
+#pragma unroll
+    for (int p = 0; p < 4; p++) {
+        const int piece = wave + 4 * p;
+        if (piece < GIN_CHUNK_BYTES / 1024) {
+            const char* g = reinterpret_cast<const char*>(gchunk) + piece * 1024 + lane * 16;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                             (__attribute__((address_space(3))) void*)(lds_buf + piece * 1024), 16, 0, 0);
+        }
+    }
+}
+
+#define GIN_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+
+template <int NT>
+__global__ __launch_bounds__(256) void gin_layer_fused_kernel(const float* __restrict__ h, float* __restrict__ hout,
+                                                               const int* __restrict__ row_ptr,
+                                                               const int* __restrict__ src,
+                                                               const uint8_t* __restrict__ ecode,
+                                                               const float* __restrict__ ecomb,
+                                                               const float* __restrict__ wchunks, int n_tot,
+                                                               int relu_out) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* s_a = smem;                     // ecomb, later odd chunks
+    char* s_b = smem + GIN_ECOMB_BYTES;   // even chunks
+    float* s_ecomb = reinterpret_cast<float*>(s_a);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 15, g = lane >> 4;
+    const long long node_base = (long long)blockIdx.x * (64 * NT) + wave * (16 * NT);
+
+    gin_issue_chunk(wchunks, s_b, wave, lane);  // chunk 0 in flight while we gather
+    for (int i = threadIdx.x; i < GIN_ECOMB_BYTES / 16; i += 256)
+        reinterpret_cast<float4*>(s_ecomb)[i] = reinterpret_cast<const float4*>(ecomb)[i];
+    __syncthreads();
+
+    // ---- gather (MP unit): a = h[v] + sum_e relu(h[src_e] + ecomb[code_e]), CSR order
+    float bq[NT][25];
+    int e_cur[NT], e_end[NT], u_nx[NT], c_nx[NT];
+    long long self_row[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; nt++) {
+        long long node = node_base + nt * 16 + j;
+        const bool valid = node < n_tot;
+        if (!valid) node = n_tot - 1;
+        self_row[nt] = node;
+        e_cur[nt] = valid ? row_ptr[node] : 0;
+        e_end[nt] = valid ? row_ptr[node + 1] : 0;
+#pragma unroll
+        for (int k = 0; k < 25; k++) bq[nt][k] = 0.0f;
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT; nt++) {  // indices one edge ahead of the feature gathers
+        const bool on = e_cur[nt] < e_end[nt];
+        u_nx[nt] = on ? src[e_cur[nt]] : 0;
+        c_nx[nt] = on ? ecode[e_cur[nt]] : 0;
+    }
+    while (true) {
+        bool any = false;
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++) any |= (e_cur[nt] < e_end[nt]);
+        if (!__any(any)) break;
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++) {
+            if (e_cur[nt] < e_end[nt]) {
+                const int u = u_nx[nt];
+                const int code = c_nx[nt];
+                e_cur[nt]++;
+                if (e_cur[nt] < e_end[nt]) {
+                    u_nx[nt] = src[e_cur[nt]];
+                    c_nx[nt] = ecode[e_cur[nt]];
+                }
+                const float* hr = h + (size_t)u * GIN_D + 4 * g;
+                const float* er = s_ecomb + code * GIN_D + 4 * g;
+                float4 x[6];
+#pragma unroll
+                for (int q = 0; q < 6; q++) x[q] = *reinterpret_cast<const float4*>(hr + 16 * q);
+                const float xt = h[(size_t)u * GIN_D + 96 + g];
+#pragma unroll
+                for (int q = 0; q < 6; q++) {
+                    const float4 w = *reinterpret_cast<const float4*>(er + 16 * q);
+                    bq[nt][4 * q + 0] += relu1(w.x + x[q].x);
+                    bq[nt][4 * q + 1] += relu1(w.y + x[q].y);
+                    bq[nt][4 * q + 2] += relu1(w.z + x[q].z);
+                    bq[nt][4 * q + 3] += relu1(w.w + x[q].w);
+                }
+                bq[nt][24] += relu1(s_ecomb[code * GIN_D + 96 + g] + xt);
+            }
+        }
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT; nt++) {  // + (1 + eps) h[v], eps == 0
+        const float* hr = h + (size_t)self_row[nt] * GIN_D + 4 * g;
+#pragma unroll
+        for (int q = 0; q < 6; q++) {
+            const float4 x = *reinterpret_cast<const float4*>(hr + 16 * q);
+            bq[nt][4 * q + 0] += x.x; bq[nt][4 * q + 1] += x.y; bq[nt][4 * q + 2] += x.z; bq[nt][4 * q + 3] += x.w;
+        }
+        bq[nt][24] += h[(size_t)self_row[nt] * GIN_D + 96 + g];
+    }
+    __syncthreads();  // every wave is done with the edge-embedding combos: region A may be overwritten
+
+    // ---- node MLP (NT unit) on fp32 MFMA, weights streamed through LDS
+    float4_t acc2[NT][GIN_T2];
+    {
+        const float* b2 = reinterpret_cast<const float*>(s_b) + 3408;  // chunk 0 is resident (first barrier)
+#pragma unroll
+        for (int t2 = 0; t2 < GIN_T2; t2++) {
+            const float4 b = *reinterpret_cast<const float4*>(b2 + 16 * t2 + 4 * g);
+#pragma unroll
+            for (int nt = 0; nt < NT; nt++) acc2[nt][t2] = (float4_t){b.x, b.y, b.z, b.w};
+        }
+    }
+    float4_t hid[NT];  // relu(hidden tile c-1), the MLP2 B operand of this step
+#pragma unroll
+    for (int nt = 0; nt < NT; nt++) hid[nt] = (float4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+    for (int c = 0; c < GIN_CHUNKS; c++) {
+        const float* wb = reinterpret_cast<const float*>((c & 1) ? s_a : s_b);
+        if (c + 1 < GIN_CHUNKS)
+            gin_issue_chunk(wchunks + (size_t)(c + 1) * GIN_CHUNK_FLOATS, (c & 1) ? s_b : s_a, wave, lane);
+        float4_t acc1[NT];
+        {
+            const float4 b = *reinterpret_cast<const float4*>(wb + 3392 + 4 * g);
+#pragma unroll
+            for (int nt = 0; nt < NT; nt++) acc1[nt] = (float4_t){b.x, b.y, b.z, b.w};
+        }
+        // 6 x { 4 MLP1 k-steps of tile c  +  one output tile (4 k-steps) of MLP2 for tile c-1 }
+        // chunk 0 carries zero W2 fragments and chunk 13 zero W1 fragments, so no branches are needed
+#pragma unroll
+        for (int q = 0; q < 6; q++) {
+            const float4 a1 = *reinterpret_cast<const float4*>(wb + (q * 64 + lane) * 4);
+            const float4 a2 = *reinterpret_cast<const float4*>(wb + 1600 + (q * 64 + lane) * 4);
+#pragma unroll
+            for (int nt = 0; nt < NT; nt++) {
+                acc1[nt] = GIN_MFMA(a1.x, bq[nt][4 * q + 0], acc1[nt]);
+                acc2[nt][q] = GIN_MFMA(a2.x, hid[nt].x, acc2[nt][q]);
+                acc1[nt] = GIN_MFMA(a1.y, bq[nt][4 * q + 1], acc1[nt]);
+                acc2[nt][q] = GIN_MFMA(a2.y, hid[nt].y, acc2[nt][q]);
+                acc1[nt] = GIN_MFMA(a1.z, bq[nt][4 * q + 2], acc1[nt]);
+                acc2[nt][q] = GIN_MFMA(a2.z, hid[nt].z, acc2[nt][q]);
+                acc1[nt] = GIN_MFMA(a1.w, bq[nt][4 * q + 3], acc1[nt]);
+                acc2[nt][q] = GIN_MFMA(a2.w, hid[nt].w, acc2[nt][q]);
+            }
+        }
+        {
+            const float at = wb[1536 + lane];
+            const float4 a2 = *reinterpret_cast<const float4*>(wb + 1600 + (6 * 64 + lane) * 4);
+#pragma unroll
+            for (int nt = 0; nt < NT; nt++) {
+                acc1[nt] = GIN_MFMA(at, bq[nt][24], acc1[nt]);
+                acc2[nt][6] = GIN_MFMA(a2.x, hid[nt].x, acc2[nt][6]);
+                acc2[nt][6] = GIN_MFMA(a2.y, hid[nt].y, acc2[nt][6]);
+                acc2[nt][6] = GIN_MFMA(a2.z, hid[nt].z, acc2[nt][6]);
+                acc2[nt][6] = GIN_MFMA(a2.w, hid[nt].w, acc2[nt][6]);
+            }
+        }
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++) {
+            hid[nt].x = relu1(acc1[nt].x); hid[nt].y = relu1(acc1[nt].y);
+            hid[nt].z = relu1(acc1[nt].z); hid[nt].w = relu1(acc1[nt].w);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of chunk c+1 have landed
+        __syncthreads();  // everyone's pieces landed; everyone is done reading chunk c
+    }
+
+#pragma unroll
+    for (int nt = 0; nt < NT; nt++) {
+        const long long node = node_base + nt * 16 + j;
+        if (node >= n_tot) continue;
+        float* row = hout + (size_t)node * GIN_D;
+#pragma unroll
+        for (int t2 = 0; t2 < GIN_T2; t2++) {
+            const int col = 16 * t2 + 4 * g;
+            if (col < GIN_D) {
+                float4_t r = acc2[nt][t2];
+                if (relu_out) { r.x = relu1(r.x); r.y = relu1(r.y); r.z = relu1(r.z); r.w = relu1(r.w); }
+                *reinterpret_cast<float4*>(row + col) = make_float4(r.x, r.y, r.z, r.w);
+            }
+        }
+    }
+}
+
 // ---------------------------------------------------------------- readout: mean pool + linear head
 // One wavefront per graph; lanes 0..24 take even rows, lanes 32..56 odd rows (float4 chunks).
 template <int D>
@@ -327,7 +537,23 @@ public:
             }
             for (int x = 0; x < GIN_T2 * 16; x++) b2p[(size_t)l * GIN_T2 * 16 + x] = (x < GIN_D) ? b2[l * GIN_D + x] : 0.0f;
         }
+        // weight stream of the fused layer kernel: per layer 14 chunks of 14 KiB; chunk c = W1 of hidden
+        // tile c (absent for c = 13) + W2 columns of hidden tile c-1 (absent for c = 0) + biases
+        std::vector<float> chunks((size_t)GIN_L * GIN_CHUNKS * GIN_CHUNK_FLOATS, 0.0f);
+        for (int l = 0; l < GIN_L; l++)
+            for (int c = 0; c < GIN_CHUNKS; c++) {
+                float* ck = &chunks[((size_t)l * GIN_CHUNKS + c) * GIN_CHUNK_FLOATS];
+                if (c < GIN_T1) {
+                    memcpy(ck, &w1f[(((size_t)l * GIN_T1 + c) * 6) * 64 * 4], sizeof(float) * 6 * 64 * 4);
+                    memcpy(ck + 1536, &w1tail[((size_t)l * GIN_T1 + c) * 64], sizeof(float) * 64);
+                    memcpy(ck + 3392, &b1p[((size_t)l * GIN_T1 + c) * 16], sizeof(float) * 16);
+                }
+                if (c >= 1)
+                    memcpy(ck + 1600, &w2f[(((size_t)l * GIN_T1 + (c - 1)) * GIN_T2) * 64 * 4], sizeof(float) * GIN_T2 * 64 * 4);
+                memcpy(ck + 3408, &b2p[(size_t)l * GIN_T2 * 16], sizeof(float) * GIN_T2 * 16);
+            }
         int rc;
+        if ((rc = upload(&d_chunks_, chunks))) return rc;
         if ((rc = upload(&d_nemb_, v_nemb))) return rc;
         if ((rc = upload(&d_pw_, v_pw))) return rc;
         if ((rc = upload(&d_pb_, v_pb))) return rc;
@@ -389,6 +615,16 @@ public:
         }
         int cur = 0;
         for (int l = 0; l < GIN_L; l++) {
+            if (fused_) {
+                ProfScope p(prof, "gin_layer_fused", s);
+                constexpr int NT = 1;
+                const int blocks = (int)ceil_div_ll(n, 64 * NT);
+                gin_layer_fused_kernel<NT><<<blocks, 256, GIN_FUSED_LDS, s>>>(
+                    db.h[cur], db.h[cur ^ 1], db.csr.row_ptr, db.csr.src, db.csr.ecode, layer_dev(l).ecomb,
+                    d_chunks_ + (size_t)l * GIN_CHUNKS * GIN_CHUNK_FLOATS, n, l != GIN_L - 1);
+                cur ^= 1;
+                continue;
+            }
             {
                 ProfScope p(prof, "gin_aggregate", s);
                 launch_aggregate(db, l, db.h[cur], db.scratch, s);
@@ -419,11 +655,14 @@ public:
 
 private:
     void free_all() {
-        float** ptrs[] = {&d_nemb_, &d_pw_, &d_pb_, &d_ecomb_, &d_w1f_, &d_w1tail_, &d_b1p_, &d_w2f_, &d_b2p_};
+        float** ptrs[] = {&d_chunks_, &d_nemb_, &d_pw_, &d_pb_, &d_ecomb_, &d_w1f_, &d_w1tail_, &d_b1p_, &d_w2f_, &d_b2p_};
         for (auto p : ptrs)
             if (*p) { hipFree(*p); *p = nullptr; }
     }
     bool ready_ = false;
+    // FLOWGNN_GIN_UNFUSED=1 keeps the two-kernel layer (aggregate + mlp) for A/B measurements
+    bool fused_ = !(getenv("FLOWGNN_GIN_UNFUSED") && atoi(getenv("FLOWGNN_GIN_UNFUSED")) != 0);
+    float* d_chunks_ = nullptr;
     float *d_nemb_ = nullptr, *d_pw_ = nullptr, *d_pb_ = nullptr, *d_ecomb_ = nullptr, *d_w1f_ = nullptr,
           *d_w1tail_ = nullptr, *d_b1p_ = nullptr, *d_w2f_ = nullptr, *d_b2p_ = nullptr;
 };

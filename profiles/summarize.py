@@ -1,0 +1,49 @@
+#!/usr/bin/env python3
+"""Condense rocprofv3 CSV output into the small per-kernel summaries committed under profiles/.
+
+  python profiles/summarize.py stats  <kernel_stats.csv | kernel_trace.csv>  > profiles/rNN_*.txt
+  python profiles/summarize.py pmc    <counter_collection.csv> COUNTER       > profiles/rNN_*.txt
+"""
+import csv
+import sys
+from collections import defaultdict
+
+
+def stats(path):
+    rows = list(csv.DictReader(open(path)))
+    if rows and "Start_Timestamp" in rows[0]:  # kernel_trace.csv -> aggregate ourselves
+        agg = defaultdict(lambda: [0, 0.0])
+        for r in rows:
+            d = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+            a = agg[r["Kernel_Name"]]
+            a[0] += 1
+            a[1] += d
+        tot = sum(v[1] for v in agg.values())
+        print(f"{'kernel':<70} {'calls':>7} {'total_ms':>10} {'avg_us':>10} {'pct':>6}")
+        for k, (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+            print(f"{k[:70]:<70} {c:>7} {t/1e6:>10.3f} {t/c/1e3:>10.2f} {100*t/tot:>6.2f}")
+    else:
+        cols = rows[0].keys() if rows else []
+        print(",".join(cols))
+        for r in rows:
+            print(",".join(str(r[c])[:80] for c in cols))
+
+
+def pmc(path, counter):
+    agg = defaultdict(lambda: [0, 0.0])
+    for r in csv.DictReader(open(path)):
+        if r.get("Counter_Name") != counter:
+            continue
+        a = agg[r["Kernel_Name"]]
+        a[0] += 1
+        a[1] += float(r["Counter_Value"])
+    print(f"{'kernel':<70} {'dispatches':>10} {counter + '_avg':>16} {counter + '_total':>18}")
+    for k, (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+        print(f"{k[:70]:<70} {c:>10} {t/c:>16.1f} {t:>18.1f}")
+
+
+if __name__ == "__main__":
+    if sys.argv[1] == "stats":
+        stats(sys.argv[2])
+    else:
+        pmc(sys.argv[2], sys.argv[3])
