@@ -131,6 +131,7 @@ public:
 };
 
 Model* make_gin_model();
+Model* make_gcn_model();
 
 // helpers
 int read_floats(const char* dir, const char* file, size_t offset_floats, size_t count, float* dst);

@@ -1,0 +1,172 @@
+// device_common.h -- device code shared by the per-model translation units (included, not linked:
+// every kernel here is a template or static).
+#pragma once
+#include "common.h"
+
+namespace fg {
+
+// reference tables
+static __constant__ int c_nd_off[ND_FEATURE] = {0, 119, 123, 135, 147, 157, 163, 169, 171};  // load_inputs.cc:5
+static __constant__ int c_nd_card[ND_FEATURE] = {119, 4, 12, 12, 10, 6, 6, 2, 2};            // host_load.cc:5
+
+typedef float float4_t __attribute__((ext_vector_type(4)));
+
+__device__ inline float relu1(float x) { return x < 0.0f ? 0.0f : x; }
+
+// ---------------------------------------------------------------- atom encoder
+// One lane per (node, float4 chunk); fully coalesced 1 KiB stores per wave.
+template <int D>
+__global__ __launch_bounds__(256) void atom_encoder_kernel(const int* __restrict__ node_feature,
+                                                            const float* __restrict__ table,  // [173][D]
+                                                            float* __restrict__ h, int n_tot, int* __restrict__ err) {
+    constexpr int C = D / 4;
+    const long long total = (long long)n_tot * C;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int v = (int)(i / C);
+        const int c = (int)(i - (long long)v * C);
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int k = 0; k < ND_FEATURE; k++) {
+            int f = node_feature[(size_t)v * ND_FEATURE + k];
+            if (f < 0 || f >= c_nd_card[k]) {
+                atomicMax(err, ERR_NODE_FEAT);
+                f = 0;
+            }
+            const float4 w = reinterpret_cast<const float4*>(table)[(size_t)(c_nd_off[k] + f) * C + c];
+            s.x += w.x; s.y += w.y; s.z += w.z; s.w += w.w;
+        }
+        reinterpret_cast<float4*>(h)[i] = s;
+    }
+}
+
+// ---------------------------------------------------------------- readout: mean pool + linear head
+// One wavefront per graph; lanes 0..24 take even rows, lanes 32..56 odd rows (float4 chunks).
+template <int D>
+__global__ __launch_bounds__(256) void mean_pool_linear_kernel(const float* __restrict__ h,
+                                                                const int* __restrict__ node_off,
+                                                                const float* __restrict__ pw,
+                                                                const float* __restrict__ pb,
+                                                                float* __restrict__ out, int num_graphs) {
+    constexpr int C = D / 4;
+    static_assert(C <= 32, "row must fit half a wavefront in float4 chunks");
+    const int lane = threadIdx.x & 63;
+    const int g = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (g >= num_graphs) return;
+    const int n0 = node_off[g], n1 = node_off[g + 1];
+    const int half = lane >> 5, c = lane & 31;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c < C)
+        for (int v = n0 + half; v < n1; v += 2) {
+            const float4 x = reinterpret_cast<const float4*>(h)[(size_t)v * C + c];
+            acc.x += x.x; acc.y += x.y; acc.z += x.z; acc.w += x.w;
+        }
+    acc.x += __shfl_down(acc.x, 32, 64); acc.y += __shfl_down(acc.y, 32, 64);
+    acc.z += __shfl_down(acc.z, 32, 64); acc.w += __shfl_down(acc.w, 32, 64);
+    float part = 0.f;
+    if (half == 0 && c < C) {
+        const float n = (float)(n1 - n0);
+        const float4 w = reinterpret_cast<const float4*>(pw)[c];
+        part = (acc.x / n) * w.x + (acc.y / n) * w.y + (acc.z / n) * w.z + (acc.w / n) * w.w;
+    }
+#pragma unroll
+    for (int d = 16; d >= 1; d >>= 1) part += __shfl_down(part, d, 64);
+    if (lane == 0) out[g] = pb[0] + part;
+}
+
+static inline int grid_for(long long items, int per_block, int cap) {
+    long long nb = (items + per_block - 1) / per_block;
+    if (nb > cap) nb = cap;
+    if (nb < 1) nb = 1;
+    return (int)nb;
+}
+
+
+// ---------------------------------------------------------------- dense layer on fp32 MFMA, input from HBM
+// out[node][o] = bias[o] + sum_k W[o][k] in[node][k]   for K = 100 inputs, OUT = 16 * OT outputs (padded).
+// Transposed formulation (nodes are MFMA columns), as described in gin.hip: lane (j, g) of a wave loads
+// in[j][16 q + 4 g .. +3] (q < 6) and in[j][96 + g]; the W fragments carry the matching k per slot.
+// Fragments: wf [OT][6][64][4] (t, q, lane, r), wtail [OT][64], bias padded to 16 * OT.
+// pack_dense100() builds them on the host.
+template <int OT, int NT, bool RELU_OUT>
+__global__ __launch_bounds__(256) void dense100_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                        const float* __restrict__ wf, const float* __restrict__ wtail,
+                                                        const float* __restrict__ biasp, int n_tot, int out_dim) {
+    const int lane = threadIdx.x & 63;
+    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int j = lane & 15, g = lane >> 4;
+    const long long node_base = (long long)wave * (16 * NT);
+    if (node_base >= n_tot) return;
+    float bq[NT][25];
+#pragma unroll
+    for (int nt = 0; nt < NT; nt++) {
+        long long node = node_base + nt * 16 + j;
+        if (node >= n_tot) node = n_tot - 1;
+        const float* row = in + (size_t)node * 100;
+#pragma unroll
+        for (int q = 0; q < 6; q++) {
+            const float4 x = *reinterpret_cast<const float4*>(row + 16 * q + 4 * g);
+            bq[nt][4 * q + 0] = x.x; bq[nt][4 * q + 1] = x.y; bq[nt][4 * q + 2] = x.z; bq[nt][4 * q + 3] = x.w;
+        }
+        bq[nt][24] = row[96 + g];
+    }
+    const float4* wf4 = reinterpret_cast<const float4*>(wf);
+#pragma unroll 1
+    for (int t = 0; t < OT; t++) {
+        float4_t acc[NT];
+        {
+            const float4 b = *reinterpret_cast<const float4*>(biasp + 16 * t + 4 * g);
+#pragma unroll
+            for (int nt = 0; nt < NT; nt++) acc[nt] = (float4_t){b.x, b.y, b.z, b.w};
+        }
+#pragma unroll
+        for (int q = 0; q < 6; q++) {
+            const float4 af = wf4[(size_t)(t * 6 + q) * 64 + lane];
+#pragma unroll
+            for (int nt = 0; nt < NT; nt++) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af.x, bq[nt][4 * q + 0], acc[nt], 0, 0, 0);
+#pragma unroll
+            for (int nt = 0; nt < NT; nt++) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af.y, bq[nt][4 * q + 1], acc[nt], 0, 0, 0);
+#pragma unroll
+            for (int nt = 0; nt < NT; nt++) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af.z, bq[nt][4 * q + 2], acc[nt], 0, 0, 0);
+#pragma unroll
+            for (int nt = 0; nt < NT; nt++) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af.w, bq[nt][4 * q + 3], acc[nt], 0, 0, 0);
+        }
+        {
+            const float at = wtail[t * 64 + lane];
+#pragma unroll
+            for (int nt = 0; nt < NT; nt++) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(at, bq[nt][24], acc[nt], 0, 0, 0);
+        }
+        const int col = 16 * t + 4 * g;
+        if (col < out_dim) {
+#pragma unroll
+            for (int nt = 0; nt < NT; nt++) {
+                const long long node = node_base + nt * 16 + j;
+                if (node < n_tot) {
+                    float4_t r = acc[nt];
+                    if (RELU_OUT) { r.x = relu1(r.x); r.y = relu1(r.y); r.z = relu1(r.z); r.w = relu1(r.w); }
+                    *reinterpret_cast<float4*>(out + (size_t)node * out_dim + col) = make_float4(r.x, r.y, r.z, r.w);
+                }
+            }
+        }
+    }
+}
+
+// host: W [out_dim][100] row-major, b [out_dim]  ->  fragments for dense100_kernel<OT>
+static inline void pack_dense100(const float* W, const float* b, int out_dim, int OT, std::vector<float>& wf,
+                                 std::vector<float>& wtail, std::vector<float>& biasp) {
+    wf.assign((size_t)OT * 6 * 64 * 4, 0.0f);
+    wtail.assign((size_t)OT * 64, 0.0f);
+    biasp.assign((size_t)OT * 16, 0.0f);
+    for (int t = 0; t < OT; t++) {
+        for (int lane = 0; lane < 64; lane++) {
+            const int i = lane & 15, g = lane >> 4, o = 16 * t + i;
+            if (o >= out_dim) continue;
+            for (int q = 0; q < 6; q++)
+                for (int r = 0; r < 4; r++) wf[(((size_t)t * 6 + q) * 64 + lane) * 4 + r] = W[(size_t)o * 100 + 16 * q + 4 * g + r];
+            wtail[(size_t)t * 64 + lane] = W[(size_t)o * 100 + 96 + g];
+        }
+        for (int x = 0; x < 16; x++)
+            if (16 * t + x < out_dim) biasp[(size_t)t * 16 + x] = b[16 * t + x];
+    }
+}
+
+}  // namespace fg

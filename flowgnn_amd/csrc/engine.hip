@@ -145,6 +145,7 @@ int flowgnn_create(int model, int device_id, flowgnn_engine** out) {
     switch (model) {
         case FLOWGNN_MODEL_GIN:
         case FLOWGNN_MODEL_GIN_VN: m = make_gin_model(); break;
+        case FLOWGNN_MODEL_GCN: m = make_gcn_model(); break;
         default: return FLOWGNN_ERR_UNSUPPORTED;
     }
     flowgnn_engine* e = new flowgnn_engine();
@@ -199,6 +200,16 @@ int flowgnn_set_weights_gin(flowgnn_engine* e, const float* node_embedding_weigh
     ENGINE_TRY(e, use_device(e));
     if (e->stream) hipStreamSynchronize(e->stream);
     ENGINE_TRY(e, e->model->set_weights(t));
+    return FLOWGNN_OK;
+}
+
+int flowgnn_set_weights(flowgnn_engine* e, int count, const float* const* tensors) {
+    if (!e || !tensors || count != e->model->num_weight_tensors()) return FLOWGNN_ERR_ARG;
+    for (int i = 0; i < count; i++)
+        if (!tensors[i]) return FLOWGNN_ERR_ARG;
+    ENGINE_TRY(e, use_device(e));
+    if (e->stream) hipStreamSynchronize(e->stream);
+    ENGINE_TRY(e, e->model->set_weights(tensors));
     return FLOWGNN_OK;
 }
 
@@ -473,44 +484,44 @@ int flowgnn_run_aggregation_only(flowgnn_engine* e, int layer, int iters, float*
     return FLOWGNN_OK;
 }
 
-// ------------------------------------------------------------------ reference-compatible entry point
-// Splits the batch into runs of constant weight set (reload_weights semantics of
-// GIN/src/GIN_compute.cc:44,51-53) and runs each through a process-wide engine on device 0.
+// ------------------------------------------------------------------ reference-compatible entry points
+// Split the batch into runs of constant weight set (reload_weights semantics of
+// GIN/src/GIN_compute.cc:44,51-53) and run each through a process-wide engine per model.
 static std::mutex g_entry_mutex;
+static flowgnn_engine* g_entry_engine[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 
-int GIN_compute_graphs(int num_graphs, int* nums_of_nodes, int* nums_of_edges, int* reload_weights, float* out,
-                       int* node_feature_in, int* edge_list_in, int* edge_attr_in, float* node_embedding_weight_in,
-                       float* edge_embedding_weight_in, float* node_mlp_1_weights, float* node_mlp_1_bias,
-                       float* node_mlp_2_weights, float* node_mlp_2_bias, float* graph_pred_weights_in,
-                       float* graph_pred_bias_in) {
+static int compute_graphs_generic(int model, int num_graphs, const int* nums_of_nodes, const int* nums_of_edges,
+                                  const int* reload_weights, float* out, const int* node_feature, const float* node_eigen,
+                                  const int* edge_list, const int* edge_attr, int ntens, const float* const* tens,
+                                  const size_t* tens_elems) {
     if (num_graphs < 0) return FLOWGNN_ERR_ARG;
     if (num_graphs == 0) return FLOWGNN_OK;
-    if (!nums_of_nodes || !nums_of_edges || !reload_weights || !out || !node_feature_in) return FLOWGNN_ERR_ARG;
+    if (!nums_of_nodes || !nums_of_edges || !reload_weights || !out || !node_feature) return FLOWGNN_ERR_ARG;
+    for (int i = 0; i < ntens; i++)
+        if (!tens[i]) return FLOWGNN_ERR_ARG;
     if (!reload_weights[0]) return FLOWGNN_ERR_ARG;  // the reference would index weight set -1
     std::lock_guard<std::mutex> lock(g_entry_mutex);
-    static flowgnn_engine* eng = nullptr;
+    flowgnn_engine*& eng = g_entry_engine[model];
     if (!eng) {
         const char* dev = getenv("FLOWGNN_DEVICE");
-        int rc = flowgnn_create(FLOWGNN_MODEL_GIN, dev ? atoi(dev) : 0, &eng);
+        int rc = flowgnn_create(model, dev ? atoi(dev) : 0, &eng);
         if (rc) return rc;
     }
     long long noff = 0, eoff = 0;
     int set = -1, g = 0;
+    const float* cur[16];
     while (g < num_graphs) {
         set++;
         int g1 = g + 1;
         while (g1 < num_graphs && !reload_weights[g1]) g1++;
         long long n = 0, m = 0;
         for (int i = g; i < g1; i++) { n += nums_of_nodes[i]; m += nums_of_edges[i]; }
-        const size_t s = (size_t)set;
-        int rc = flowgnn_set_weights_gin(eng, node_embedding_weight_in + s * 173 * 100, edge_embedding_weight_in + s * 5 * 13 * 100,
-                                         node_mlp_1_weights + s * 5 * 200 * 100, node_mlp_1_bias + s * 5 * 200,
-                                         node_mlp_2_weights + s * 5 * 100 * 200, node_mlp_2_bias + s * 5 * 100,
-                                         graph_pred_weights_in + s * 100, graph_pred_bias_in + s);
+        for (int i = 0; i < ntens; i++) cur[i] = tens[i] + (size_t)set * tens_elems[i];
+        int rc = flowgnn_set_weights(eng, ntens, cur);
         if (rc) return rc;
-        rc = flowgnn_set_batch(eng, g1 - g, nums_of_nodes + g, nums_of_edges + g, node_feature_in + noff * 9,
-                               edge_list_in ? edge_list_in + eoff * 2 : nullptr,
-                               edge_attr_in ? edge_attr_in + eoff * 3 : nullptr, nullptr);
+        rc = flowgnn_set_batch(eng, g1 - g, nums_of_nodes + g, nums_of_edges + g, node_feature + noff * 9,
+                               edge_list ? edge_list + eoff * 2 : nullptr, edge_attr ? edge_attr + eoff * 3 : nullptr,
+                               node_eigen ? node_eigen + noff * 4 : nullptr);
         if (rc) return rc;
         rc = flowgnn_run(eng);
         if (rc) return rc;
@@ -521,6 +532,31 @@ int GIN_compute_graphs(int num_graphs, int* nums_of_nodes, int* nums_of_edges, i
         g = g1;
     }
     return FLOWGNN_OK;
+}
+
+int GIN_compute_graphs(int num_graphs, int* nums_of_nodes, int* nums_of_edges, int* reload_weights, float* out,
+                       int* node_feature_in, int* edge_list_in, int* edge_attr_in, float* node_embedding_weight_in,
+                       float* edge_embedding_weight_in, float* node_mlp_1_weights, float* node_mlp_1_bias,
+                       float* node_mlp_2_weights, float* node_mlp_2_bias, float* graph_pred_weights_in,
+                       float* graph_pred_bias_in) {
+    const float* t[8] = {node_embedding_weight_in, edge_embedding_weight_in, node_mlp_1_weights, node_mlp_1_bias,
+                         node_mlp_2_weights,       node_mlp_2_bias,          graph_pred_weights_in, graph_pred_bias_in};
+    static const size_t sz[8] = {173 * 100, 5 * 13 * 100, 5 * 200 * 100, 5 * 200, 5 * 100 * 200, 5 * 100, 100, 1};
+    return compute_graphs_generic(FLOWGNN_MODEL_GIN, num_graphs, nums_of_nodes, nums_of_edges, reload_weights, out,
+                                  node_feature_in, nullptr, edge_list_in, edge_attr_in, 8, t, sz);
+}
+
+int GCN_compute_graphs(int num_graphs, int* nums_of_nodes, int* nums_of_edges, int* reload_weights, float* out,
+                       int* node_feature_in, int* edge_list_in, int* edge_attr_in, float* node_embedding_weight_in,
+                       float* edge_embedding_weight_in, float* convs_weight_in, float* convs_bias_in,
+                       float* convs_root_emb_weight_in, float* bn_weight_in, float* bn_bias_in, float* bn_mean_in,
+                       float* bn_var_in, float* graph_pred_weights_in, float* graph_pred_bias_in) {
+    const float* t[11] = {node_embedding_weight_in, edge_embedding_weight_in, convs_weight_in, convs_bias_in,
+                          convs_root_emb_weight_in, bn_weight_in, bn_bias_in, bn_mean_in, bn_var_in,
+                          graph_pred_weights_in, graph_pred_bias_in};
+    static const size_t sz[11] = {173 * 100, 5 * 13 * 100, 5 * 100 * 100, 500, 500, 500, 500, 500, 500, 100, 1};
+    return compute_graphs_generic(FLOWGNN_MODEL_GCN, num_graphs, nums_of_nodes, nums_of_edges, reload_weights, out,
+                                  node_feature_in, nullptr, edge_list_in, edge_attr_in, 11, t, sz);
 }
 
 }  // extern "C"

@@ -1,0 +1,248 @@
+// gcn.hip -- GCN hot path for gfx950 (MI355X).
+//
+// Reference per graph (GCN/src/*.cc), x_l = output of the NT unit of layer l:
+//   h0[v]   = sum_{k<9} NodeEmb[off_k + feat_k(v)]                                load_inputs.cc:168-215
+//   a_0     = h0;   a_l = relu(BN_{l-1}(m_{l-1}[v] + relu(x_{l-1}[v] + root_{l-1}) / (deg(v)+1)))   node_embedding.cc:123-138
+//   x_l     = b_l + W_l a_l   (100x100)                                           node_embedding.cc:140-146
+//   m_l[v]  = sum_{(u->v)} norm(u,v) relu(x_l[u] + sum_k EdgeEmb_l[off_k+attr_k])   message_passing.cc:158-167
+//   norm    = dinv[u] dinv[v], dinv[i] = outdeg(i) > 0 ? 1/sqrt(outdeg(i)+1) : 0   load_inputs.cc:122,163
+//   out[g]  = pb + pw . mean_v BN_4(m_4[v] + relu(x_4[v] + root_4)/(deg(v)+1))       finalize.cc:79-113
+//   deg(v) is the OUT-degree table of load_graph (load_inputs.cc:120), BN is eval-mode with
+//   sqrt(var + 2^-10) (load_inputs.cc:32).
+//
+// Here, on the batched super-graph: per layer one HBM-bound aggregation kernel that also applies the
+// root / degree / BatchNorm / ReLU epilogue (so a_l is written once), and one fp32-MFMA dense kernel.
+#include "common.h"
+#include "device_common.h"
+#include <cmath>
+#include <cstring>
+
+namespace fg {
+
+constexpr int GCN_D = 100;
+constexpr int GCN_L = 5;
+constexpr int GCN_C = GCN_D / 4;
+constexpr int GCN_OT = 7;
+
+struct GcnEpilogue {
+    const float* root;      // [100]
+    const float* bn_mean;   // [100]
+    const float* bn_sqrtv;  // [100] sqrt(var + 2^-10)
+    const float* bn_w;      // [100]
+    const float* bn_b;      // [100]
+};
+
+// a[v] = epilogue( sum_e norm_e relu(x[src_e] + ecomb[code_e]), x[v], outdeg[v] ), CSR order.
+// Same flattened (row, float4 chunk) work decomposition as gin_aggregate_kernel.
+template <bool RELU_OUT>
+__global__ __launch_bounds__(256) void gcn_aggregate_kernel(const float* __restrict__ x, float* __restrict__ a,
+                                                             const int* __restrict__ row_ptr,
+                                                             const int* __restrict__ src,
+                                                             const uint8_t* __restrict__ ecode,
+                                                             const int* __restrict__ out_deg,
+                                                             const float* __restrict__ ecomb, GcnEpilogue ep, int n_tot) {
+    constexpr int C = GCN_C;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float4* s_ecomb = reinterpret_cast<float4*>(smem_raw);
+    for (int i = threadIdx.x; i < EDGE_COMBOS * C; i += 256) s_ecomb[i] = reinterpret_cast<const float4*>(ecomb)[i];
+    __syncthreads();
+    const float4* x4 = reinterpret_cast<const float4*>(x);
+    const long long total = (long long)n_tot * C;
+    long long span = (total + gridDim.x - 1) / gridDim.x;
+    span = (span + 255) / 256 * 256;
+    const long long i_end = (span * (blockIdx.x + 1) < total) ? span * (blockIdx.x + 1) : total;
+    for (long long i = span * blockIdx.x + threadIdx.x; i < i_end; i += 256) {
+        const int v = (int)(i / C);
+        const int c = (int)(i - (long long)v * C);
+        const int beg = row_ptr[v], end = row_ptr[v + 1];
+        const int dv = out_deg[v];
+        const float dinv_v = dv > 0 ? 1.0f / sqrtf((float)(dv + 1)) : 0.0f;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int e = beg; e < end; e++) {
+            const int u = src[e];
+            const int k = ecode[e];
+            const int du = out_deg[u];
+            const float norm = (du > 0 ? 1.0f / sqrtf((float)(du + 1)) : 0.0f) * dinv_v;
+            const float4 xu = x4[(size_t)u * C + c];
+            const float4 w = s_ecomb[k * C + c];
+            acc.x += norm * relu1(w.x + xu.x); acc.y += norm * relu1(w.y + xu.y);
+            acc.z += norm * relu1(w.z + xu.z); acc.w += norm * relu1(w.w + xu.w);
+        }
+        const float4 xs = x4[i];
+        const float4 rt = reinterpret_cast<const float4*>(ep.root)[c];
+        const float4 mu = reinterpret_cast<const float4*>(ep.bn_mean)[c];
+        const float4 sv = reinterpret_cast<const float4*>(ep.bn_sqrtv)[c];
+        const float4 bw = reinterpret_cast<const float4*>(ep.bn_w)[c];
+        const float4 bb = reinterpret_cast<const float4*>(ep.bn_b)[c];
+        const float dp1 = (float)(dv + 1);
+        float4 r;
+        r.x = (acc.x + relu1(xs.x + rt.x) / dp1 - mu.x) / sv.x * bw.x + bb.x;
+        r.y = (acc.y + relu1(xs.y + rt.y) / dp1 - mu.y) / sv.y * bw.y + bb.y;
+        r.z = (acc.z + relu1(xs.z + rt.z) / dp1 - mu.z) / sv.z * bw.z + bb.z;
+        r.w = (acc.w + relu1(xs.w + rt.w) / dp1 - mu.w) / sv.w * bw.w + bb.w;
+        if (RELU_OUT) { r.x = relu1(r.x); r.y = relu1(r.y); r.z = relu1(r.z); r.w = relu1(r.w); }
+        reinterpret_cast<float4*>(a)[i] = r;
+    }
+}
+
+class GcnModel : public Model {
+public:
+    ~GcnModel() override { free_all(); }
+    int emb_dim() const override { return GCN_D; }
+    int scratch_dim() const override { return GCN_D; }
+    bool has_edge_attr() const override { return true; }
+    int num_weight_tensors() const override { return 11; }
+    bool weights_ready() const override { return ready_; }
+
+    // host tensors (GCN/src/dcl.h:83-96): node_emb[173][100], edge_emb[5][13][100], convs_weight[5][100][100],
+    // convs_bias[5][100], root_emb[5][100], bn_weight/bias/mean/var[5][100], pred_w[1][100], pred_b[1]
+    int set_weights(const float* const* t) override {
+        const float *nemb = t[0], *eemb = t[1], *cw = t[2], *cb = t[3], *root = t[4], *bnw = t[5], *bnb = t[6], *bnm = t[7],
+                    *bnv = t[8], *pw = t[9], *pb = t[10];
+        std::vector<float> v_nemb(nemb, nemb + ND_FEATURE_TOTAL * GCN_D), v_pw(pw, pw + GCN_D), v_pb(pb, pb + 1);
+        std::vector<float> ecomb((size_t)GCN_L * EDGE_COMBOS * GCN_D), ep((size_t)GCN_L * 5 * GCN_D);
+        std::vector<float> wf_all, wt_all, bp_all;
+        static const int ed_off[3] = {0, 5, 11};
+        for (int l = 0; l < GCN_L; l++) {
+            const float* E = eemb + (size_t)l * ED_FEATURE_PER_LAYER * GCN_D;
+            for (int a0 = 0; a0 < 5; a0++)
+                for (int a1 = 0; a1 < 6; a1++)
+                    for (int a2 = 0; a2 < 2; a2++)
+                        for (int d = 0; d < GCN_D; d++) {
+                            float s = 0.0f;
+                            s += E[(ed_off[0] + a0) * GCN_D + d];
+                            s += E[(ed_off[1] + a1) * GCN_D + d];
+                            s += E[(ed_off[2] + a2) * GCN_D + d];
+                            ecomb[((size_t)l * EDGE_COMBOS + (a0 * 6 + a1) * 2 + a2) * GCN_D + d] = s;
+                        }
+            float* e = &ep[(size_t)l * 5 * GCN_D];
+            for (int d = 0; d < GCN_D; d++) {
+                e[0 * GCN_D + d] = root[l * GCN_D + d];
+                e[1 * GCN_D + d] = bnm[l * GCN_D + d];
+                e[2 * GCN_D + d] = sqrtf(bnv[l * GCN_D + d] + 1.0f / 1024.0f);  // load_inputs.cc:32
+                e[3 * GCN_D + d] = bnw[l * GCN_D + d];
+                e[4 * GCN_D + d] = bnb[l * GCN_D + d];
+            }
+            std::vector<float> wf, wt, bp;
+            pack_dense100(cw + (size_t)l * GCN_D * GCN_D, cb + (size_t)l * GCN_D, GCN_D, GCN_OT, wf, wt, bp);
+            wf_all.insert(wf_all.end(), wf.begin(), wf.end());
+            wt_all.insert(wt_all.end(), wt.begin(), wt.end());
+            bp_all.insert(bp_all.end(), bp.begin(), bp.end());
+        }
+        int rc;
+        if ((rc = upload(&d_nemb_, v_nemb))) return rc;
+        if ((rc = upload(&d_pw_, v_pw))) return rc;
+        if ((rc = upload(&d_pb_, v_pb))) return rc;
+        if ((rc = upload(&d_ecomb_, ecomb))) return rc;
+        if ((rc = upload(&d_ep_, ep))) return rc;
+        if ((rc = upload(&d_wf_, wf_all))) return rc;
+        if ((rc = upload(&d_wt_, wt_all))) return rc;
+        if ((rc = upload(&d_bp_, bp_all))) return rc;
+        ready_ = true;
+        return 0;
+    }
+
+    // GCN/src/host_load.cc:31-170: one file, hard-coded float offsets
+    int load_weights_dir(const char* dir) override {
+        const char* f = "gcn_ep1_dim100.weights.all.bin";
+        std::vector<float> nemb(173 * 100), eemb(5 * 13 * 100), cw(5 * 100 * 100), cb(500), root(500), bnw(500), bnb(500),
+            bnm(500), bnv(500), pw(100), pb(1);
+        int rc;
+        if ((rc = read_floats(dir, f, 0, nemb.size(), nemb.data()))) return rc;
+        for (int l = 0; l < GCN_L; l++) {
+            const size_t base = 17300 + 11500 * (size_t)l;
+            if ((rc = read_floats(dir, f, base, 10000, &cw[(size_t)l * 10000]))) return rc;
+            if ((rc = read_floats(dir, f, base + 10000, 100, &cb[l * 100]))) return rc;
+            if ((rc = read_floats(dir, f, base + 10100, 100, &root[l * 100]))) return rc;
+            if ((rc = read_floats(dir, f, base + 10200, 1300, &eemb[(size_t)l * 1300]))) return rc;
+            const size_t bn = 74800 + 401 * (size_t)l;  // 4 x 100 floats + one skipped counter per layer
+            if ((rc = read_floats(dir, f, bn, 100, &bnw[l * 100]))) return rc;
+            if ((rc = read_floats(dir, f, bn + 100, 100, &bnb[l * 100]))) return rc;
+            if ((rc = read_floats(dir, f, bn + 200, 100, &bnm[l * 100]))) return rc;
+            if ((rc = read_floats(dir, f, bn + 300, 100, &bnv[l * 100]))) return rc;
+        }
+        if ((rc = read_floats(dir, f, 76805, 100, pw.data()))) return rc;
+        if ((rc = read_floats(dir, f, 76905, 1, pb.data()))) return rc;
+        const float* t[11] = {nemb.data(), eemb.data(), cw.data(), cb.data(), root.data(), bnw.data(),
+                              bnb.data(),  bnm.data(),  bnv.data(), pw.data(), pb.data()};
+        return set_weights(t);
+    }
+
+    GcnEpilogue epilogue(int l) const {
+        const float* e = d_ep_ + (size_t)l * 5 * GCN_D;
+        return GcnEpilogue{e, e + GCN_D, e + 2 * GCN_D, e + 3 * GCN_D, e + 4 * GCN_D};
+    }
+
+    template <bool RELU_OUT>
+    void launch_aggregate(const DeviceBatch& db, int l, const float* x, float* a, hipStream_t s) {
+        const int grid = grid_for((long long)db.b.n_tot * GCN_C, 256, 256 * 6);
+        gcn_aggregate_kernel<RELU_OUT><<<grid, 256, sizeof(float) * EDGE_COMBOS * GCN_D, s>>>(
+            x, a, db.csr.row_ptr, db.csr.src, db.csr.ecode, db.csr.out_deg, d_ecomb_ + (size_t)l * EDGE_COMBOS * GCN_D,
+            epilogue(l), db.b.n_tot);
+    }
+
+    void launch_dense(int l, const float* a, float* x, int n, hipStream_t s) {
+        constexpr int NT = 2;
+        const int waves = (int)ceil_div_ll(n, 16 * NT);
+        dense100_kernel<GCN_OT, NT, false><<<(waves + 3) / 4, 256, 0, s>>>(
+            a, x, d_wf_ + (size_t)l * GCN_OT * 6 * 64 * 4, d_wt_ + (size_t)l * GCN_OT * 64, d_bp_ + (size_t)l * GCN_OT * 16, n,
+            GCN_D);
+    }
+
+    int forward(DeviceBatch& db, Profiler& prof, hipStream_t s) override {
+        const int n = db.b.n_tot;
+        if (n <= 0) return 0;
+        {
+            ProfScope p(prof, "atom_encoder", s);
+            atom_encoder_kernel<GCN_D><<<grid_for((long long)n * GCN_C, 256, 256 * 8), 256, 0, s>>>(
+                db.b.node_feature, d_nemb_, db.scratch, n, db.csr.err);
+        }
+        int cur = 0;
+        {
+            ProfScope p(prof, "gcn_dense", s);
+            launch_dense(0, db.scratch, db.h[cur], n, s);  // x_0 = W_0 h0 + b_0
+        }
+        for (int l = 1; l < GCN_L; l++) {
+            {
+                ProfScope p(prof, "gcn_aggregate", s);
+                launch_aggregate<true>(db, l - 1, db.h[cur], db.scratch, s);  // a_l
+            }
+            {
+                ProfScope p(prof, "gcn_dense", s);
+                launch_dense(l, db.scratch, db.h[cur ^ 1], n, s);  // x_l
+            }
+            cur ^= 1;
+        }
+        db.final_h = cur;
+        {
+            ProfScope p(prof, "gcn_aggregate", s);
+            launch_aggregate<false>(db, GCN_L - 1, db.h[cur], db.scratch, s);  // BN_4(...), no ReLU
+        }
+        {
+            ProfScope p(prof, "mean_pool_linear", s);
+            mean_pool_linear_kernel<GCN_D><<<(db.b.num_graphs + 3) / 4, 256, 0, s>>>(db.scratch, db.b.node_off, d_pw_, d_pb_,
+                                                                                     db.out, db.b.num_graphs);
+        }
+        return 0;
+    }
+
+    int aggregation_only(DeviceBatch& db, int layer, hipStream_t s) override {
+        if (layer < 0 || layer >= GCN_L) return 1;
+        launch_aggregate<true>(db, layer, db.h[db.final_h], db.scratch, s);
+        return 0;
+    }
+
+private:
+    void free_all() {
+        float** ptrs[] = {&d_nemb_, &d_pw_, &d_pb_, &d_ecomb_, &d_ep_, &d_wf_, &d_wt_, &d_bp_};
+        for (auto p : ptrs)
+            if (*p) { hipFree(*p); *p = nullptr; }
+    }
+    bool ready_ = false;
+    float *d_nemb_ = nullptr, *d_pw_ = nullptr, *d_pb_ = nullptr, *d_ecomb_ = nullptr, *d_ep_ = nullptr, *d_wf_ = nullptr,
+          *d_wt_ = nullptr, *d_bp_ = nullptr;
+};
+
+Model* make_gcn_model() { return new GcnModel(); }
+
+}  // namespace fg

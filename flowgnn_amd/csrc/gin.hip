@@ -14,6 +14,7 @@
 //                   that nodes are MFMA columns and the MLP1 accumulators feed MLP2 directly
 //                   as B operands (no LDS round trip, no transpose)
 #include "common.h"
+#include "device_common.h"
 #include <cstring>
 #include <cstdio>
 #include <cstdlib>
@@ -26,40 +27,6 @@ constexpr int GIN_L = 5;
 constexpr int GIN_C = GIN_D / 4;   // float4 chunks per row
 constexpr int GIN_T1 = 13;         // 16-row tiles of the hidden layer (208 >= 200)
 constexpr int GIN_T2 = 7;          // 16-row tiles of the output layer (112 >= 100)
-
-// reference tables
-__constant__ int c_nd_off[ND_FEATURE] = {0, 119, 123, 135, 147, 157, 163, 169, 171};  // load_inputs.cc:5
-__constant__ int c_nd_card[ND_FEATURE] = {119, 4, 12, 12, 10, 6, 6, 2, 2};            // host_load.cc:5
-
-typedef float float4_t __attribute__((ext_vector_type(4)));
-
-__device__ inline float relu1(float x) { return x < 0.0f ? 0.0f : x; }
-
-// ---------------------------------------------------------------- atom encoder
-// One lane per (node, float4 chunk); fully coalesced 1 KiB stores per wave.
-template <int D>
-__global__ __launch_bounds__(256) void atom_encoder_kernel(const int* __restrict__ node_feature,
-                                                            const float* __restrict__ table,  // [173][D]
-                                                            float* __restrict__ h, int n_tot, int* __restrict__ err) {
-    constexpr int C = D / 4;
-    const long long total = (long long)n_tot * C;
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-        const int v = (int)(i / C);
-        const int c = (int)(i - (long long)v * C);
-        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-        for (int k = 0; k < ND_FEATURE; k++) {
-            int f = node_feature[(size_t)v * ND_FEATURE + k];
-            if (f < 0 || f >= c_nd_card[k]) {
-                atomicMax(err, ERR_NODE_FEAT);
-                f = 0;
-            }
-            const float4 w = reinterpret_cast<const float4*>(table)[(size_t)(c_nd_off[k] + f) * C + c];
-            s.x += w.x; s.y += w.y; s.z += w.z; s.w += w.w;
-        }
-        reinterpret_cast<float4*>(h)[i] = s;
-    }
-}
 
 // ---------------------------------------------------------------- aggregation (MP unit)
 // a[v] = h[v] + sum over in-edges (ascending source, ties in input order) of relu(h[u] + ecomb[code]).
@@ -661,48 +628,7 @@ __global__ __launch_bounds__(256) void gin_layer_pipelined_kernel(const float* _
     }
 }
 
-// ---------------------------------------------------------------- readout: mean pool + linear head
-// One wavefront per graph; lanes 0..24 take even rows, lanes 32..56 odd rows (float4 chunks).
-template <int D>
-__global__ __launch_bounds__(256) void mean_pool_linear_kernel(const float* __restrict__ h,
-                                                                const int* __restrict__ node_off,
-                                                                const float* __restrict__ pw,
-                                                                const float* __restrict__ pb,
-                                                                float* __restrict__ out, int num_graphs) {
-    constexpr int C = D / 4;
-    static_assert(C <= 32, "row must fit half a wavefront in float4 chunks");
-    const int lane = threadIdx.x & 63;
-    const int g = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (g >= num_graphs) return;
-    const int n0 = node_off[g], n1 = node_off[g + 1];
-    const int half = lane >> 5, c = lane & 31;
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (c < C)
-        for (int v = n0 + half; v < n1; v += 2) {
-            const float4 x = reinterpret_cast<const float4*>(h)[(size_t)v * C + c];
-            acc.x += x.x; acc.y += x.y; acc.z += x.z; acc.w += x.w;
-        }
-    acc.x += __shfl_down(acc.x, 32, 64); acc.y += __shfl_down(acc.y, 32, 64);
-    acc.z += __shfl_down(acc.z, 32, 64); acc.w += __shfl_down(acc.w, 32, 64);
-    float part = 0.f;
-    if (half == 0 && c < C) {
-        const float n = (float)(n1 - n0);
-        const float4 w = reinterpret_cast<const float4*>(pw)[c];
-        part = (acc.x / n) * w.x + (acc.y / n) * w.y + (acc.z / n) * w.z + (acc.w / n) * w.w;
-    }
-#pragma unroll
-    for (int d = 16; d >= 1; d >>= 1) part += __shfl_down(part, d, 64);
-    if (lane == 0) out[g] = pb[0] + part;
-}
-
 // ---------------------------------------------------------------- host side: weights + forward
-static int grid_for(long long items, int per_block, int cap) {
-    long long nb = (items + per_block - 1) / per_block;
-    if (nb > cap) nb = cap;
-    if (nb < 1) nb = 1;
-    return (int)nb;
-}
-
 class GinModel : public Model {
 public:
     ~GinModel() override { free_all(); }

@@ -69,11 +69,10 @@ class Engine:
 
     # ---- weights
     def set_weights(self, w: Dict[str, np.ndarray]):
+        """`w`: OrderedDict in the argument order of the model's <M>_compute_graphs entry point."""
         arrs = [_f32(v) for v in w.values()]
-        if self.model in ("GIN", "GIN-VN"):
-            self._check(self.lib.flowgnn_set_weights_gin(self._h, *[_pf(a) for a in arrs]), "flowgnn_set_weights_gin")
-        else:
-            raise NotImplementedError(self.model)
+        ptrs = (_lib.p_float * len(arrs))(*[_pf(a) for a in arrs])
+        self._check(self.lib.flowgnn_set_weights(self._h, len(arrs), ptrs), "flowgnn_set_weights")
 
     def load_weights_dir(self, directory: str):
         self._check(self.lib.flowgnn_load_weights_dir(self._h, directory.encode()), "flowgnn_load_weights_dir")
@@ -149,10 +148,12 @@ class Engine:
         return float(ms.value)
 
 
-def GIN_compute_graphs(batch: GraphBatch, weight_sets, reload_weights=None) -> np.ndarray:
-    """Call the reference-compatible C symbol GIN_compute_graphs (GIN/src/dcl.h:75-94).
-    `weight_sets` is a list of weight dicts (leading [S] dimension of every weight pointer)."""
+def compute_graphs(model: str, batch: GraphBatch, weight_sets, reload_weights=None) -> np.ndarray:
+    """Call the reference-compatible C symbol <M>_compute_graphs (e.g. GIN/src/dcl.h:75-94) with host
+    arrays.  `weight_sets` is a list of weight dicts: the leading [S] dimension of every weight pointer,
+    selected per graph by the running count of reload_weights (GIN/src/GIN_compute.cc:51-53)."""
     lib = _lib.load()
+    model = model.upper()
     G = batch.num_graphs
     if reload_weights is None:
         reload_weights = np.zeros(G, dtype=np.int32)
@@ -163,8 +164,21 @@ def GIN_compute_graphs(batch: GraphBatch, weight_sets, reload_weights=None) -> n
     out = np.zeros(G, dtype=np.float32)
     nn, ne, rw = _i32(batch.nums_of_nodes), _i32(batch.nums_of_edges), _i32(reload_weights)
     nf, el, ea = _i32(batch.node_feature), _i32(batch.edge_list), _i32(batch.edge_attr)
-    rc = lib.GIN_compute_graphs(G, _pi(nn), _pi(ne), _pi(rw), _pf(out), _pi(nf), _pi(el), _pi(ea),
-                                *[_pf(a) for a in stacked])
+    wp = [_pf(a) for a in stacked]
+    if model in ("GIN", "GIN-VN"):
+        rc = lib.GIN_compute_graphs(G, _pi(nn), _pi(ne), _pi(rw), _pf(out), _pi(nf), _pi(el), _pi(ea), *wp)
+    elif model == "GCN":
+        rc = lib.GCN_compute_graphs(G, _pi(nn), _pi(ne), _pi(rw), _pf(out), _pi(nf), _pi(el), _pi(ea), *wp)
+    else:
+        raise ValueError(model)
     if rc:
-        raise FlowGNNError(rc, "GIN_compute_graphs")
+        raise FlowGNNError(rc, f"{model}_compute_graphs")
     return out
+
+
+def GIN_compute_graphs(batch: GraphBatch, weight_sets, reload_weights=None) -> np.ndarray:
+    return compute_graphs("GIN", batch, weight_sets, reload_weights)
+
+
+def GCN_compute_graphs(batch: GraphBatch, weight_sets, reload_weights=None) -> np.ndarray:
+    return compute_graphs("GCN", batch, weight_sets, reload_weights)

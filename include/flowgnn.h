@@ -78,6 +78,20 @@ int GIN_compute_graphs(int num_graphs, int* nums_of_nodes, int* nums_of_edges,
                        float* node_mlp_2_weights, float* node_mlp_2_bias,
                        float* graph_pred_weights_in, float* graph_pred_bias_in);
 
+/*
+ * Replaces GCN_compute_graphs, GCN/src/dcl.h:75-97 (def. GCN/src/GCN_compute.cc:7-112).
+ *   out [num_graphs]; graph arrays as for GIN
+ *   convs_weight_in [S][5][100][100]  convs_bias_in [S][5][100]  convs_root_emb_weight_in [S][5][100]
+ *   bn_weight_in / bn_bias_in / bn_mean_in / bn_var_in [S][5][100]   (eval-mode BatchNorm)
+ */
+int GCN_compute_graphs(int num_graphs, int* nums_of_nodes, int* nums_of_edges,
+                       int* reload_weights, float* out,
+                       int* node_feature_in, int* edge_list_in, int* edge_attr_in,
+                       float* node_embedding_weight_in, float* edge_embedding_weight_in,
+                       float* convs_weight_in, float* convs_bias_in, float* convs_root_emb_weight_in,
+                       float* bn_weight_in, float* bn_bias_in, float* bn_mean_in, float* bn_var_in,
+                       float* graph_pred_weights_in, float* graph_pred_bias_in);
+
 /* =====================================================================
  * (2) Handle API
  * ===================================================================== */
@@ -99,6 +113,12 @@ int flowgnn_set_weights_gin(flowgnn_engine* e,
                             const float* node_mlp_1_weights, const float* node_mlp_1_bias,
                             const float* node_mlp_2_weights, const float* node_mlp_2_bias,
                             const float* graph_pred_weights, const float* graph_pred_bias);
+
+/*
+ * Generic form: `count` host tensors of ONE weight set, in the argument order of the model's
+ * <M>_compute_graphs entry point (GIN 8, GCN 11 tensors).
+ */
+int flowgnn_set_weights(flowgnn_engine* e, int count, const float* const* tensors);
 
 /*
  * Read the reference's raw little-endian float32 .bin weight files from `dir`

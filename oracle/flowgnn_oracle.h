@@ -61,6 +61,20 @@ int orc_GIN_compute_graphs(int num_graphs, const int* nums_of_nodes, const int* 
                            const float* graph_pred_weights_in, const float* graph_pred_bias_in,
                            float* h_dump, int nthreads);
 
+/*
+ * GCN forward, float semantics.  Mirrors GCN_compute_graphs, GCN/src/GCN_compute.cc:7-112
+ * (argument order of GCN/src/dcl.h:75-97).  x_dump (optional): [5][N_tot][100], x_l = NT(l) output.
+ */
+int orc_GCN_compute_graphs(int num_graphs, const int* nums_of_nodes, const int* nums_of_edges,
+                           const int* reload_weights, float* out, const int* node_feature_in,
+                           const int* edge_list_in, const int* edge_attr_in,
+                           const float* node_embedding_weight_in, const float* edge_embedding_weight_in,
+                           const float* convs_weight_in, const float* convs_bias_in,
+                           const float* convs_root_emb_weight_in, const float* bn_weight_in,
+                           const float* bn_bias_in, const float* bn_mean_in, const float* bn_var_in,
+                           const float* graph_pred_weights_in, const float* graph_pred_bias_in,
+                           float* x_dump, int nthreads);
+
 #ifdef __cplusplus
 }
 #endif

@@ -31,6 +31,8 @@ def load():
         lib.orc_gin_load_graph.restype = None
         lib.orc_GIN_compute_graphs.argtypes = [C.c_int, _pi, _pi, _pi, _pf, _pi, _pi, _pi] + [_pf] * 8 + [_pf, C.c_int]
         lib.orc_GIN_compute_graphs.restype = C.c_int
+        lib.orc_GCN_compute_graphs.argtypes = [C.c_int, _pi, _pi, _pi, _pf, _pi, _pi, _pi] + [_pf] * 11 + [_pf, C.c_int]
+        lib.orc_GCN_compute_graphs.restype = C.c_int
         _lib = lib
     return _lib
 
@@ -81,3 +83,38 @@ def gin_forward(batch, weight_sets, reload_weights=None, dump_h=False, nthreads=
     if rc:
         raise RuntimeError(f"oracle GIN rc={rc}")
     return (out, hd) if dump_h else out
+
+
+def _forward(fn_name, batch, weight_sets, reload_weights, dump_shape, nthreads, with_attr=True, eig=False):
+    lib = load()
+    G = batch.num_graphs
+    if reload_weights is None:
+        reload_weights = np.zeros(G, np.int32)
+        if G:
+            reload_weights[0] = 1
+    keys = list(weight_sets[0].keys())
+    stacked = [_f(np.stack([np.asarray(ws[k], np.float32) for ws in weight_sets])) for k in keys]
+    out = np.zeros(G, np.float32)
+    nn, ne, rw = _i(batch.nums_of_nodes), _i(batch.nums_of_edges), _i(reload_weights)
+    nf, el, ea = _i(batch.node_feature), _i(batch.edge_list), _i(batch.edge_attr)
+    hd = np.zeros(dump_shape, np.float32) if dump_shape is not None else None
+    args = [G, nn.ctypes.data_as(_pi), ne.ctypes.data_as(_pi), rw.ctypes.data_as(_pi), out.ctypes.data_as(_pf),
+            nf.ctypes.data_as(_pi)]
+    if eig:
+        ev = _f(batch.node_eigen)
+        args.append(ev.ctypes.data_as(_pf))
+    args.append(el.ctypes.data_as(_pi))
+    if with_attr:
+        args.append(ea.ctypes.data_as(_pi))
+    args += [a.ctypes.data_as(_pf) for a in stacked]
+    args += [None if hd is None else hd.ctypes.data_as(_pf), nthreads]
+    rc = getattr(lib, fn_name)(*args)
+    if rc:
+        raise RuntimeError(f"oracle {fn_name} rc={rc}")
+    return (out, hd) if hd is not None else out
+
+
+def gcn_forward(batch, weight_sets, reload_weights=None, dump_h=False, nthreads=1):
+    """orc_GCN_compute_graphs; dump = x_l (NT outputs) [5][N][100]."""
+    return _forward("orc_GCN_compute_graphs", batch, weight_sets, reload_weights,
+                    (5, batch.total_nodes, 100) if dump_h else None, nthreads)
