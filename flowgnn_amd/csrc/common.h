@@ -132,6 +132,8 @@ public:
 
 Model* make_gin_model();
 Model* make_gcn_model();
+Model* make_pna_model();
+Model* make_dgn_model();
 
 // helpers
 int read_floats(const char* dir, const char* file, size_t offset_floats, size_t count, float* dst);

@@ -81,6 +81,53 @@ static inline int grid_for(long long items, int per_block, int cap) {
 }
 
 
+// ---------------------------------------------------------------- readout: mean pool + 3-layer head, one wavefront per graph (PNA D=80, DGN D=100 share it)
+template <int D, int H1, int H2>
+__global__ __launch_bounds__(256) void pool_mlp3_kernel(const float* __restrict__ h, const int* __restrict__ node_off,
+                                                         const float* __restrict__ w1, const float* __restrict__ b1,
+                                                         const float* __restrict__ w2, const float* __restrict__ b2,
+                                                         const float* __restrict__ w3, const float* __restrict__ b3,
+                                                         float* __restrict__ out, int num_graphs) {
+    constexpr int C = D / 4;
+    static_assert(C <= 32 && H1 <= 64 && H2 <= 64, "sizes must fit one wavefront");
+    __shared__ float s_hg[4][D];
+    __shared__ float s_o1[4][H1];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int g = blockIdx.x * 4 + wv;
+    if (g >= num_graphs) return;
+    const int n0 = node_off[g], n1 = node_off[g + 1];
+    const int half = lane >> 5, c = lane & 31;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c < C)
+        for (int v = n0 + half; v < n1; v += 2) {
+            const float4 x = reinterpret_cast<const float4*>(h)[(size_t)v * C + c];
+            acc.x += x.x; acc.y += x.y; acc.z += x.z; acc.w += x.w;
+        }
+    acc.x += __shfl_down(acc.x, 32, 64); acc.y += __shfl_down(acc.y, 32, 64);
+    acc.z += __shfl_down(acc.z, 32, 64); acc.w += __shfl_down(acc.w, 32, 64);
+    if (half == 0 && c < C) {
+        const float n = (float)(n1 - n0);
+        s_hg[wv][4 * c + 0] = acc.x / n; s_hg[wv][4 * c + 1] = acc.y / n;
+        s_hg[wv][4 * c + 2] = acc.z / n; s_hg[wv][4 * c + 3] = acc.w / n;
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (lane < H1) {
+        float s = b1[lane];
+        for (int i = 0; i < D; i++) s += s_hg[wv][i] * w1[lane * D + i];
+        s_o1[wv][lane] = relu1(s);
+    }
+    __builtin_amdgcn_wave_barrier();
+    float part = 0.f;
+    if (lane < H2) {
+        float s = b2[lane];
+        for (int i = 0; i < H1; i++) s += s_o1[wv][i] * w2[lane * H1 + i];
+        part = relu1(s) * w3[lane];
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) part += __shfl_down(part, d, 64);
+    if (lane == 0) out[g] = b3[0] + part;
+}
+
 // ---------------------------------------------------------------- dense layer on fp32 MFMA, input from HBM
 // out[node][o] = bias[o] + sum_k W[o][k] in[node][k]   for K = 100 inputs, OUT = 16 * OT outputs (padded).
 // Transposed formulation (nodes are MFMA columns), as described in gin.hip: lane (j, g) of a wave loads

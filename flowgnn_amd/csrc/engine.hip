@@ -146,6 +146,8 @@ int flowgnn_create(int model, int device_id, flowgnn_engine** out) {
         case FLOWGNN_MODEL_GIN:
         case FLOWGNN_MODEL_GIN_VN: m = make_gin_model(); break;
         case FLOWGNN_MODEL_GCN: m = make_gcn_model(); break;
+        case FLOWGNN_MODEL_PNA: m = make_pna_model(); break;
+        case FLOWGNN_MODEL_DGN: m = make_dgn_model(); break;
         default: return FLOWGNN_ERR_UNSUPPORTED;
     }
     flowgnn_engine* e = new flowgnn_engine();
@@ -557,6 +559,38 @@ int GCN_compute_graphs(int num_graphs, int* nums_of_nodes, int* nums_of_edges, i
     static const size_t sz[11] = {173 * 100, 5 * 13 * 100, 5 * 100 * 100, 500, 500, 500, 500, 500, 500, 100, 1};
     return compute_graphs_generic(FLOWGNN_MODEL_GCN, num_graphs, nums_of_nodes, nums_of_edges, reload_weights, out,
                                   node_feature_in, nullptr, edge_list_in, edge_attr_in, 11, t, sz);
+}
+
+int PNA_compute_graphs(int num_graphs, int* nums_of_nodes, int* nums_of_edges, int* reload_weights, float* out,
+                       int* node_feature_in, int* edge_list_in, float* node_embedding_weight_in,
+                       float* node_conv_weights_in, float* node_conv_bias_in, float* graph_mlp_1_weights_in,
+                       float* graph_mlp_1_bias_in, float* graph_mlp_2_weights_in, float* graph_mlp_2_bias_in,
+                       float* graph_mlp_3_weights_in, float* graph_mlp_3_bias_in, float* avg_deg_in) {
+    const float* t[10] = {node_embedding_weight_in, node_conv_weights_in, node_conv_bias_in, graph_mlp_1_weights_in,
+                          graph_mlp_1_bias_in, graph_mlp_2_weights_in, graph_mlp_2_bias_in, graph_mlp_3_weights_in,
+                          graph_mlp_3_bias_in, avg_deg_in};
+    static const size_t sz[10] = {173 * 80, 4 * 80 * 3 * 4 * 80, 4 * 80, 40 * 80, 40, 20 * 40, 20, 20, 1, 1};
+    return compute_graphs_generic(FLOWGNN_MODEL_PNA, num_graphs, nums_of_nodes, nums_of_edges, reload_weights, out,
+                                  node_feature_in, nullptr, edge_list_in, nullptr, 10, t, sz);
+}
+
+int DGN_compute_graphs(int num_graphs, int* nums_of_nodes, int* nums_of_edges, int* reload_weights, float* out,
+                       int* node_feature_in, float* node_eigen_in, int* edge_list_in,
+                       float* embedding_h_atom_embedding_list_weights_in,
+                       float* layers_posttrans_fully_connected_0_linear_weight_in,
+                       float* layers_posttrans_fully_connected_0_linear_bias_in, float* MLP_layer_FC_layers_0_weight_in,
+                       float* MLP_layer_FC_layers_0_bias_in, float* MLP_layer_FC_layers_1_weight_in,
+                       float* MLP_layer_FC_layers_1_bias_in, float* MLP_layer_FC_layers_2_weight_in,
+                       float* MLP_layer_FC_layers_2_bias_in) {
+    const float* t[9] = {embedding_h_atom_embedding_list_weights_in,
+                         layers_posttrans_fully_connected_0_linear_weight_in,
+                         layers_posttrans_fully_connected_0_linear_bias_in,
+                         MLP_layer_FC_layers_0_weight_in, MLP_layer_FC_layers_0_bias_in, MLP_layer_FC_layers_1_weight_in,
+                         MLP_layer_FC_layers_1_bias_in, MLP_layer_FC_layers_2_weight_in, MLP_layer_FC_layers_2_bias_in};
+    static const size_t sz[9] = {9 * 119 * 100, 4 * 100 * 200, 4 * 100, 50 * 100, 50, 25 * 50, 25, 25, 1};
+    if (num_graphs > 0 && !node_eigen_in) return FLOWGNN_ERR_ARG;
+    return compute_graphs_generic(FLOWGNN_MODEL_DGN, num_graphs, nums_of_nodes, nums_of_edges, reload_weights, out,
+                                  node_feature_in, node_eigen_in, edge_list_in, nullptr, 9, t, sz);
 }
 
 }  // extern "C"

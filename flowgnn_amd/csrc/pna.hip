@@ -1,0 +1,259 @@
+// pna.hip -- PNA hot path for gfx950 (MI355X).
+//
+// Reference per graph (PNA/src/*.cc), 4 layers, dim 80, no edge features:
+//   h0[v]    = sum_{k<9} NodeEmb[off_k + feat_k(v)]                              load_inputs.cc:133-179
+//   per (v, d): S = sum h[u][d], Q = sum h[u][d]^2, mn = min, mx = max over in-edges (u -> v);
+//               mn / mx start from +31.999 / -32 (ap_fixed<16,6> limits) and keep them when v has no
+//               in-edge                                                            message_passing.cc:127-147
+//   mean = S / indeg (0 -> 1), std = sqrt(relu(Q / indeg - mean^2))               node_embedding.cc:123,143-145
+//   t = log(outdeg+1) / avg_deg, scale = avg_deg / log(outdeg+1) (log == 0 -> 1)  node_embedding.cc:148-150
+//   acc[o]   = b[o] + sum_i sum_{s,a} W[o][s][a][i] agg_a[i] sf_s,  sf = {1, t, scale}   node_embedding.cc:158-189
+//   h'[v]    = h[v] + relu(acc)                                                   node_embedding.cc:205-213
+//   out[g]   = head(mean_v h_4[v]),  head = 80 -> 40 (ReLU) -> 20 (ReLU) -> 1     finalize.cc:34-52
+//
+// Here: acc = b + Y_0 + t Y_1 + scale Y_2 with Y_s = W_s agg  (three 80 x 320 contractions per node on
+// fp32 MFMA, per-node scalars applied to the accumulators), one HBM-bound aggregation kernel that writes
+// agg[v] = [mean | min | max | std][80], and one wave-per-graph readout kernel.
+#include "common.h"
+#include "device_common.h"
+#include <cmath>
+#include <cstring>
+
+namespace fg {
+
+constexpr int PNA_D = 80;
+constexpr int PNA_L = 4;
+constexpr int PNA_C = PNA_D / 4;   // 20 float4 chunks per row
+constexpr int PNA_OT = 5;          // 16-row output tiles
+constexpr int PNA_NA = 4;          // aggregators, reference enum order: mean, min, max, std
+constexpr int PNA_NS = 3;          // scalers: none, t, scale
+constexpr float PNA_SENT_MAX = 31.9990234375f;  // ap_fixed_max<ap_fixed<16,6>>, PNA/src/util.h:41-46
+constexpr float PNA_SENT_MIN = -32.0f;          // ap_fixed_min, PNA/src/util.h:34-39
+
+// agg[v][a][d], a = {mean, min, max, std}; flattened (row, float4 chunk) work items as in gin_aggregate_kernel
+__global__ __launch_bounds__(256) void pna_aggregate_kernel(const float* __restrict__ h, float* __restrict__ agg,
+                                                             const int* __restrict__ row_ptr,
+                                                             const int* __restrict__ src, int n_tot) {
+    constexpr int C = PNA_C;
+    const float4* h4 = reinterpret_cast<const float4*>(h);
+    const long long total = (long long)n_tot * C;
+    long long span = (total + gridDim.x - 1) / gridDim.x;
+    span = (span + 255) / 256 * 256;
+    const long long i_end = (span * (blockIdx.x + 1) < total) ? span * (blockIdx.x + 1) : total;
+    for (long long i = span * blockIdx.x + threadIdx.x; i < i_end; i += 256) {
+        const int v = (int)(i / C);
+        const int c = (int)(i - (long long)v * C);
+        const int beg = row_ptr[v], end = row_ptr[v + 1];
+        float4 S = make_float4(0.f, 0.f, 0.f, 0.f), Q = S;
+        float4 mn = make_float4(PNA_SENT_MAX, PNA_SENT_MAX, PNA_SENT_MAX, PNA_SENT_MAX);
+        float4 mx = make_float4(PNA_SENT_MIN, PNA_SENT_MIN, PNA_SENT_MIN, PNA_SENT_MIN);
+        for (int e = beg; e < end; e++) {
+            const float4 x = h4[(size_t)src[e] * C + c];
+            S.x += x.x; S.y += x.y; S.z += x.z; S.w += x.w;
+            Q.x += x.x * x.x; Q.y += x.y * x.y; Q.z += x.z * x.z; Q.w += x.w * x.w;
+            mn.x = x.x < mn.x ? x.x : mn.x; mn.y = x.y < mn.y ? x.y : mn.y; mn.z = x.z < mn.z ? x.z : mn.z; mn.w = x.w < mn.w ? x.w : mn.w;
+            mx.x = x.x > mx.x ? x.x : mx.x; mx.y = x.y > mx.y ? x.y : mx.y; mx.z = x.z > mx.z ? x.z : mx.z; mx.w = x.w > mx.w ? x.w : mx.w;
+        }
+        const float deg = (float)((end - beg) == 0 ? 1 : (end - beg));
+        float4 mean, sd;
+        mean.x = S.x / deg; mean.y = S.y / deg; mean.z = S.z / deg; mean.w = S.w / deg;
+        sd.x = sqrtf(relu1(Q.x / deg - mean.x * mean.x)); sd.y = sqrtf(relu1(Q.y / deg - mean.y * mean.y));
+        sd.z = sqrtf(relu1(Q.z / deg - mean.z * mean.z)); sd.w = sqrtf(relu1(Q.w / deg - mean.w * mean.w));
+        float4* o = reinterpret_cast<float4*>(agg) + (size_t)v * (PNA_NA * C) + c;
+        o[0 * C] = mean; o[1 * C] = mn; o[2 * C] = mx; o[3 * C] = sd;
+    }
+}
+
+// h'[v] = h[v] + relu(b + Y_0 + t Y_1 + scale Y_2),  Y_s = W_s agg[v]   (K = 320, 80 outputs)
+// One wave = 16 nodes (MFMA columns).  Lane (j, g) holds agg[j][a][16 q + 4 g + r]; the W fragment for
+// (s, t, a, q) carries W[16 t + i][s][a][16 q + 4 g + r] in slot g.  Fragments [3][5][4][5][64][4].
+__global__ __launch_bounds__(256) void pna_dense_kernel(const float* __restrict__ agg, const float* __restrict__ h,
+                                                         float* __restrict__ hout, const int* __restrict__ out_deg,
+                                                         const float* __restrict__ wf, const float* __restrict__ bias,
+                                                         float avg_deg, int n_tot) {
+    const int lane = threadIdx.x & 63;
+    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int j = lane & 15, g = lane >> 4;
+    const long long node_base = (long long)wave * 16;
+    if (node_base >= n_tot) return;
+    long long node = node_base + j;
+    const bool valid = node < n_tot;
+    if (!valid) node = n_tot - 1;
+
+    float bq[PNA_NA][20];
+#pragma unroll
+    for (int a = 0; a < PNA_NA; a++) {
+        const float* row = agg + ((size_t)node * PNA_NA + a) * PNA_D + 4 * g;
+#pragma unroll
+        for (int q = 0; q < 5; q++) {
+            const float4 x = *reinterpret_cast<const float4*>(row + 16 * q);
+            bq[a][4 * q + 0] = x.x; bq[a][4 * q + 1] = x.y; bq[a][4 * q + 2] = x.z; bq[a][4 * q + 3] = x.w;
+        }
+    }
+    const float logd = logf((float)(out_deg[node] + 1));  // load_inputs.cc:110 (out-degree)
+    const float sf_t = logd / avg_deg;
+    const float sf_scale = (logd == 0.0f) ? 1.0f : avg_deg / logd;
+
+    float4_t fin[PNA_OT];
+#pragma unroll
+    for (int t = 0; t < PNA_OT; t++) {
+        const float4 b = *reinterpret_cast<const float4*>(bias + 16 * t + 4 * g);
+        fin[t] = (float4_t){b.x, b.y, b.z, b.w};
+    }
+    const float4* wf4 = reinterpret_cast<const float4*>(wf);
+#pragma unroll 1
+    for (int s = 0; s < PNA_NS; s++) {
+        const float sf = s == 0 ? 1.0f : (s == 1 ? sf_t : sf_scale);
+#pragma unroll
+        for (int t = 0; t < PNA_OT; t++) {
+            float4_t y0 = (float4_t){0.f, 0.f, 0.f, 0.f}, y1 = y0;  // two accumulators: no back-to-back dependency
+#pragma unroll
+            for (int a = 0; a < PNA_NA; a++) {
+#pragma unroll
+                for (int q = 0; q < 5; q++) {
+                    const float4 af = wf4[((((size_t)s * PNA_OT + t) * PNA_NA + a) * 5 + q) * 64 + lane];
+                    y0 = __builtin_amdgcn_mfma_f32_16x16x4f32(af.x, bq[a][4 * q + 0], y0, 0, 0, 0);
+                    y1 = __builtin_amdgcn_mfma_f32_16x16x4f32(af.y, bq[a][4 * q + 1], y1, 0, 0, 0);
+                    y0 = __builtin_amdgcn_mfma_f32_16x16x4f32(af.z, bq[a][4 * q + 2], y0, 0, 0, 0);
+                    y1 = __builtin_amdgcn_mfma_f32_16x16x4f32(af.w, bq[a][4 * q + 3], y1, 0, 0, 0);
+                }
+            }
+            fin[t].x += sf * (y0.x + y1.x); fin[t].y += sf * (y0.y + y1.y);
+            fin[t].z += sf * (y0.z + y1.z); fin[t].w += sf * (y0.w + y1.w);
+        }
+    }
+    if (valid) {
+#pragma unroll
+        for (int t = 0; t < PNA_OT; t++) {
+            const size_t off = (size_t)node * PNA_D + 16 * t + 4 * g;
+            const float4 hv = *reinterpret_cast<const float4*>(h + off);
+            *reinterpret_cast<float4*>(hout + off) =
+                make_float4(hv.x + relu1(fin[t].x), hv.y + relu1(fin[t].y), hv.z + relu1(fin[t].z), hv.w + relu1(fin[t].w));
+        }
+    }
+}
+
+class PnaModel : public Model {
+public:
+    ~PnaModel() override { free_all(); }
+    int emb_dim() const override { return PNA_D; }
+    int scratch_dim() const override { return PNA_D * PNA_NA; }
+    bool has_edge_attr() const override { return false; }
+    int num_weight_tensors() const override { return 10; }
+    bool weights_ready() const override { return ready_; }
+
+    // host tensors (PNA/src/dcl.h:98-110): node_emb[173][80], conv_w[4][80][3][4][80] (out, scaler, aggr, in),
+    // conv_b[4][80], mlp1_w[40][80], mlp1_b[40], mlp2_w[20][40], mlp2_b[20], mlp3_w[1][20], mlp3_b[1], avg_deg[1]
+    int set_weights(const float* const* t) override {
+        const float *nemb = t[0], *cw = t[1], *cb = t[2];
+        std::vector<float> v_nemb(nemb, nemb + ND_FEATURE_TOTAL * PNA_D), v_cb(cb, cb + PNA_L * PNA_D);
+        std::vector<float> v_w1(t[3], t[3] + 40 * 80), v_b1(t[4], t[4] + 40), v_w2(t[5], t[5] + 20 * 40), v_b2(t[6], t[6] + 20),
+            v_w3(t[7], t[7] + 20), v_b3(t[8], t[8] + 1);
+        avg_deg_ = t[9][0];
+        std::vector<float> wf((size_t)PNA_L * PNA_NS * PNA_OT * PNA_NA * 5 * 64 * 4);
+        for (int l = 0; l < PNA_L; l++)
+            for (int s = 0; s < PNA_NS; s++)
+                for (int tt = 0; tt < PNA_OT; tt++)
+                    for (int a = 0; a < PNA_NA; a++)
+                        for (int q = 0; q < 5; q++)
+                            for (int lane = 0; lane < 64; lane++)
+                                for (int r = 0; r < 4; r++) {
+                                    const int i = lane & 15, g = lane >> 4;
+                                    const int o = 16 * tt + i, k = 16 * q + 4 * g + r;
+                                    wf[((((((size_t)l * PNA_NS + s) * PNA_OT + tt) * PNA_NA + a) * 5 + q) * 64 + lane) * 4 + r] =
+                                        cw[((((size_t)l * PNA_D + o) * PNA_NS + s) * PNA_NA + a) * PNA_D + k];
+                                }
+        int rc;
+        if ((rc = upload(&d_nemb_, v_nemb))) return rc;
+        if ((rc = upload(&d_wf_, wf))) return rc;
+        if ((rc = upload(&d_cb_, v_cb))) return rc;
+        if ((rc = upload(&d_w1_, v_w1))) return rc;
+        if ((rc = upload(&d_b1_, v_b1))) return rc;
+        if ((rc = upload(&d_w2_, v_w2))) return rc;
+        if ((rc = upload(&d_b2_, v_b2))) return rc;
+        if ((rc = upload(&d_w3_, v_w3))) return rc;
+        if ((rc = upload(&d_b3_, v_b3))) return rc;
+        ready_ = true;
+        return 0;
+    }
+
+    // PNA/src/host_load.cc:23-68,127: one file, hard-coded float offsets; avg_deg is a host constant
+    int load_weights_dir(const char* dir) override {
+        const char* f = "pna_ep1_noBN_dim80.weights.all.bin";
+        std::vector<float> nemb(173 * 80), cw((size_t)4 * 76800), cb(4 * 80), w1(3200), b1(40), w2(800), b2(20), w3(20), b3(1);
+        int rc;
+        if ((rc = read_floats(dir, f, 0, nemb.size(), nemb.data()))) return rc;
+        for (int l = 0; l < PNA_L; l++) {
+            const size_t base = 13840 + 76880 * (size_t)l;
+            if ((rc = read_floats(dir, f, base, 76800, &cw[(size_t)l * 76800]))) return rc;
+            if ((rc = read_floats(dir, f, base + 76800, 80, &cb[l * 80]))) return rc;
+        }
+        if ((rc = read_floats(dir, f, 321360, 3200, w1.data()))) return rc;
+        if ((rc = read_floats(dir, f, 324560, 40, b1.data()))) return rc;
+        if ((rc = read_floats(dir, f, 324600, 800, w2.data()))) return rc;
+        if ((rc = read_floats(dir, f, 325400, 20, b2.data()))) return rc;
+        if ((rc = read_floats(dir, f, 325420, 20, w3.data()))) return rc;
+        if ((rc = read_floats(dir, f, 325440, 1, b3.data()))) return rc;
+        const float avg = 6.885701656341553f;  // host_load.cc:127
+        const float* t[10] = {nemb.data(), cw.data(), cb.data(), w1.data(), b1.data(), w2.data(), b2.data(), w3.data(), b3.data(), &avg};
+        return set_weights(t);
+    }
+
+    void launch_aggregate(const DeviceBatch& db, const float* hin, hipStream_t s) {
+        const int grid = grid_for((long long)db.b.n_tot * PNA_C, 256, 256 * 8);
+        pna_aggregate_kernel<<<grid, 256, 0, s>>>(hin, db.scratch, db.csr.row_ptr, db.csr.src, db.b.n_tot);
+    }
+
+    int forward(DeviceBatch& db, Profiler& prof, hipStream_t s) override {
+        const int n = db.b.n_tot;
+        if (n <= 0) return 0;
+        {
+            ProfScope p(prof, "atom_encoder", s);
+            atom_encoder_kernel<PNA_D><<<grid_for((long long)n * PNA_C, 256, 256 * 8), 256, 0, s>>>(db.b.node_feature, d_nemb_,
+                                                                                                    db.h[0], n, db.csr.err);
+        }
+        int cur = 0;
+        for (int l = 0; l < PNA_L; l++) {
+            {
+                ProfScope p(prof, "pna_aggregate", s);
+                launch_aggregate(db, db.h[cur], s);
+            }
+            {
+                ProfScope p(prof, "pna_dense", s);
+                const int waves = (int)ceil_div_ll(n, 16);
+                pna_dense_kernel<<<(waves + 3) / 4, 256, 0, s>>>(db.scratch, db.h[cur], db.h[cur ^ 1], db.csr.out_deg,
+                                                                  d_wf_ + (size_t)l * PNA_NS * PNA_OT * PNA_NA * 5 * 64 * 4,
+                                                                  d_cb_ + (size_t)l * PNA_D, avg_deg_, n);
+            }
+            cur ^= 1;
+        }
+        db.final_h = cur;
+        {
+            ProfScope p(prof, "pool_mlp3", s);
+            pool_mlp3_kernel<PNA_D, 40, 20><<<(db.b.num_graphs + 3) / 4, 256, 0, s>>>(db.h[cur], db.b.node_off, d_w1_, d_b1_, d_w2_,
+                                                                                      d_b2_, d_w3_, d_b3_, db.out, db.b.num_graphs);
+        }
+        return 0;
+    }
+
+    int aggregation_only(DeviceBatch& db, int layer, hipStream_t s) override {
+        if (layer < 0 || layer >= PNA_L) return 1;
+        launch_aggregate(db, db.h[db.final_h], s);
+        return 0;
+    }
+
+private:
+    void free_all() {
+        float** ptrs[] = {&d_nemb_, &d_wf_, &d_cb_, &d_w1_, &d_b1_, &d_w2_, &d_b2_, &d_w3_, &d_b3_};
+        for (auto p : ptrs)
+            if (*p) { hipFree(*p); *p = nullptr; }
+    }
+    bool ready_ = false;
+    float avg_deg_ = 1.0f;
+    float *d_nemb_ = nullptr, *d_wf_ = nullptr, *d_cb_ = nullptr, *d_w1_ = nullptr, *d_b1_ = nullptr, *d_w2_ = nullptr,
+          *d_b2_ = nullptr, *d_w3_ = nullptr, *d_b3_ = nullptr;
+};
+
+Model* make_pna_model() { return new PnaModel(); }
+
+}  // namespace fg

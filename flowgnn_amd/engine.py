@@ -160,7 +160,7 @@ def compute_graphs(model: str, batch: GraphBatch, weight_sets, reload_weights=No
         if G:
             reload_weights[0] = 1
     stacked = [np.ascontiguousarray(np.stack([np.asarray(ws[k], dtype=np.float32) for ws in weight_sets]))
-               for k in weight_sets[0].keys()]
+               for k in weight_sets[0].keys()]  # [S, ...] per tensor (avg_deg: [S, 1] == float[S])
     out = np.zeros(G, dtype=np.float32)
     nn, ne, rw = _i32(batch.nums_of_nodes), _i32(batch.nums_of_edges), _i32(reload_weights)
     nf, el, ea = _i32(batch.node_feature), _i32(batch.edge_list), _i32(batch.edge_attr)
@@ -169,6 +169,11 @@ def compute_graphs(model: str, batch: GraphBatch, weight_sets, reload_weights=No
         rc = lib.GIN_compute_graphs(G, _pi(nn), _pi(ne), _pi(rw), _pf(out), _pi(nf), _pi(el), _pi(ea), *wp)
     elif model == "GCN":
         rc = lib.GCN_compute_graphs(G, _pi(nn), _pi(ne), _pi(rw), _pf(out), _pi(nf), _pi(el), _pi(ea), *wp)
+    elif model == "PNA":
+        rc = lib.PNA_compute_graphs(G, _pi(nn), _pi(ne), _pi(rw), _pf(out), _pi(nf), _pi(el), *wp)
+    elif model == "DGN":
+        eig = _f32(batch.node_eigen)
+        rc = lib.DGN_compute_graphs(G, _pi(nn), _pi(ne), _pi(rw), _pf(out), _pi(nf), _pf(eig), _pi(el), *wp)
     else:
         raise ValueError(model)
     if rc:

@@ -131,6 +131,117 @@ def synth_gcn_weights(seed: int = 7) -> Dict[str, np.ndarray]:
     return w
 
 
-LOADERS = {"GIN": load_gin_weights, "GIN-VN": load_gin_weights, "GCN": load_gcn_weights}
-SYNTH = {"GIN": synth_gin_weights, "GIN-VN": synth_gin_weights, "GCN": synth_gcn_weights}
-SAVERS = {"GIN": save_gin_weights, "GIN-VN": save_gin_weights, "GCN": save_gcn_weights}
+# --------------------------------------------------------------------------- PNA
+PNA_FILE = "pna_ep1_noBN_dim80.weights.all.bin"
+PNA_AVG_DEG = 6.885701656341553  # PNA/src/host_load.cc:127 (host constant, not in the file)
+PNA_SHAPES = OrderedDict([
+    ("node_embedding_weight", (173, 80)), ("node_conv_weights", (4, 80, 3, 4, 80)), ("node_conv_bias", (4, 80)),
+    ("graph_mlp_1_weights", (40, 80)), ("graph_mlp_1_bias", (40,)), ("graph_mlp_2_weights", (20, 40)),
+    ("graph_mlp_2_bias", (20,)), ("graph_mlp_3_weights", (1, 20)), ("graph_mlp_3_bias", (1,)), ("avg_deg", (1,)),
+])
+_PNA_TAIL = OrderedDict([("graph_mlp_1_weights", 321360), ("graph_mlp_1_bias", 324560), ("graph_mlp_2_weights", 324600),
+                         ("graph_mlp_2_bias", 325400), ("graph_mlp_3_weights", 325420), ("graph_mlp_3_bias", 325440)])
+
+
+def load_pna_weights(directory: str) -> Dict[str, np.ndarray]:
+    """PNA/src/host_load.cc:23-68: node_emb at 0, layer l weights at 13840 + 76880 l (76800) + bias (80)."""
+    path = os.path.join(directory, PNA_FILE)
+    w = OrderedDict()
+    w["node_embedding_weight"] = _read(path, (173, 80), 0)
+    w["node_conv_weights"] = np.stack([_read(path, (80, 3, 4, 80), 13840 + 76880 * l) for l in range(4)])
+    w["node_conv_bias"] = np.stack([_read(path, (80,), 13840 + 76880 * l + 76800) for l in range(4)])
+    for k, off in _PNA_TAIL.items():
+        w[k] = _read(path, PNA_SHAPES[k], off)
+    w["avg_deg"] = np.array([PNA_AVG_DEG], dtype=np.float32)
+    return w
+
+
+def save_pna_weights(w: Dict[str, np.ndarray], directory: str) -> None:
+    os.makedirs(directory, exist_ok=True)
+    buf = np.zeros(325441, dtype="<f4")
+    buf[0:13840] = np.asarray(w["node_embedding_weight"], np.float32).ravel()
+    for l in range(4):
+        base = 13840 + 76880 * l
+        buf[base:base + 76800] = np.asarray(w["node_conv_weights"], np.float32)[l].ravel()
+        buf[base + 76800:base + 76880] = np.asarray(w["node_conv_bias"], np.float32)[l].ravel()
+    for k, off in _PNA_TAIL.items():
+        a = np.asarray(w[k], np.float32).ravel()
+        buf[off:off + a.size] = a
+    buf.tofile(os.path.join(directory, PNA_FILE))
+
+
+def synth_pna_weights(seed: int = 7) -> Dict[str, np.ndarray]:
+    rng = np.random.default_rng(seed)
+    scale = {"node_embedding_weight": 0.11, "node_conv_weights": 0.012, "node_conv_bias": 0.1, "graph_mlp_1_weights": 0.1,
+             "graph_mlp_1_bias": 0.1, "graph_mlp_2_weights": 0.15, "graph_mlp_2_bias": 0.1, "graph_mlp_3_weights": 0.2,
+             "graph_mlp_3_bias": 0.1}
+    w = OrderedDict((k, (rng.standard_normal(shp) * scale[k]).astype(np.float32)) for k, shp in PNA_SHAPES.items()
+                    if k != "avg_deg")
+    w["avg_deg"] = np.array([PNA_AVG_DEG], dtype=np.float32)
+    return w
+
+
+# --------------------------------------------------------------------------- DGN
+DGN_FILE = "dgn_ep1_noBN_dim100.weights.all.bin"
+DGN_SHAPES = OrderedDict([
+    ("embedding_h_atom_embedding_list_weights", (9, 119, 100)),
+    ("layers_posttrans_fully_connected_0_linear_weight", (4, 100, 200)),
+    ("layers_posttrans_fully_connected_0_linear_bias", (4, 100)),
+    ("MLP_layer_FC_layers_0_weight", (50, 100)), ("MLP_layer_FC_layers_0_bias", (50,)),
+    ("MLP_layer_FC_layers_1_weight", (25, 50)), ("MLP_layer_FC_layers_1_bias", (25,)),
+    ("MLP_layer_FC_layers_2_weight", (1, 25)), ("MLP_layer_FC_layers_2_bias", (1,)),
+])
+_DGN_TABLE_OFF = [0, 11900, 12300, 13500, 14700, 15700, 16300, 16900, 17100]  # DGN/src/host_load.cc:12-64
+_DGN_TAIL = OrderedDict([("MLP_layer_FC_layers_0_weight", 97700), ("MLP_layer_FC_layers_0_bias", 102700),
+                         ("MLP_layer_FC_layers_1_weight", 102750), ("MLP_layer_FC_layers_1_bias", 104000),
+                         ("MLP_layer_FC_layers_2_weight", 104025), ("MLP_layer_FC_layers_2_bias", 104050)])
+_CARD = [119, 4, 12, 12, 10, 6, 6, 2, 2]
+
+
+def load_dgn_weights(directory: str) -> Dict[str, np.ndarray]:
+    path = os.path.join(directory, DGN_FILE)
+    emb = np.zeros((9, 119, 100), dtype=np.float32)
+    for k in range(9):
+        emb[k, :_CARD[k]] = _read(path, (_CARD[k], 100), _DGN_TABLE_OFF[k])
+    w = OrderedDict()
+    w["embedding_h_atom_embedding_list_weights"] = emb
+    w["layers_posttrans_fully_connected_0_linear_weight"] = np.stack(
+        [_read(path, (100, 200), 17300 + 20100 * l) for l in range(4)])
+    w["layers_posttrans_fully_connected_0_linear_bias"] = np.stack(
+        [_read(path, (100,), 17300 + 20100 * l + 20000) for l in range(4)])
+    for k, off in _DGN_TAIL.items():
+        w[k] = _read(path, DGN_SHAPES[k], off)
+    return w
+
+
+def save_dgn_weights(w: Dict[str, np.ndarray], directory: str) -> None:
+    os.makedirs(directory, exist_ok=True)
+    buf = np.zeros(104051, dtype="<f4")
+    emb = np.asarray(w["embedding_h_atom_embedding_list_weights"], np.float32)
+    for k in range(9):
+        buf[_DGN_TABLE_OFF[k]:_DGN_TABLE_OFF[k] + _CARD[k] * 100] = emb[k, :_CARD[k]].ravel()
+    for l in range(4):
+        base = 17300 + 20100 * l
+        buf[base:base + 20000] = np.asarray(w["layers_posttrans_fully_connected_0_linear_weight"], np.float32)[l].ravel()
+        buf[base + 20000:base + 20100] = np.asarray(w["layers_posttrans_fully_connected_0_linear_bias"], np.float32)[l].ravel()
+    for k, off in _DGN_TAIL.items():
+        a = np.asarray(w[k], np.float32).ravel()
+        buf[off:off + a.size] = a
+    buf.tofile(os.path.join(directory, DGN_FILE))
+
+
+def synth_dgn_weights(seed: int = 7) -> Dict[str, np.ndarray]:
+    rng = np.random.default_rng(seed)
+    scale = {"embedding_h_atom_embedding_list_weights": 0.11, "layers_posttrans_fully_connected_0_linear_weight": 0.05,
+             "layers_posttrans_fully_connected_0_linear_bias": 0.1, "MLP_layer_FC_layers_0_weight": 0.1,
+             "MLP_layer_FC_layers_0_bias": 0.1, "MLP_layer_FC_layers_1_weight": 0.15, "MLP_layer_FC_layers_1_bias": 0.1,
+             "MLP_layer_FC_layers_2_weight": 0.2, "MLP_layer_FC_layers_2_bias": 0.1}
+    w = OrderedDict((k, (rng.standard_normal(shp) * scale[k]).astype(np.float32)) for k, shp in DGN_SHAPES.items())
+    for k in range(9):  # rows beyond a table's cardinality do not exist in the file
+        w["embedding_h_atom_embedding_list_weights"][k, _CARD[k]:] = 0.0
+    return w
+
+
+LOADERS = {"GIN": load_gin_weights, "GIN-VN": load_gin_weights, "GCN": load_gcn_weights, "PNA": load_pna_weights, "DGN": load_dgn_weights}
+SYNTH = {"GIN": synth_gin_weights, "GIN-VN": synth_gin_weights, "GCN": synth_gcn_weights, "PNA": synth_pna_weights, "DGN": synth_dgn_weights}
+SAVERS = {"GIN": save_gin_weights, "GIN-VN": save_gin_weights, "GCN": save_gcn_weights, "PNA": save_pna_weights, "DGN": save_dgn_weights}

@@ -92,6 +92,41 @@ int GCN_compute_graphs(int num_graphs, int* nums_of_nodes, int* nums_of_edges,
                        float* bn_weight_in, float* bn_bias_in, float* bn_mean_in, float* bn_var_in,
                        float* graph_pred_weights_in, float* graph_pred_bias_in);
 
+/*
+ * Replaces PNA_compute_graphs, PNA/src/dcl.h:91-111 (def. PNA/src/PNA_compute.cc:7-101).  No edge features.
+ *   node_embedding_weight_in [S][173][80]
+ *   node_conv_weights_in [S][4][80][3][4][80]  (layer, out, scaler {none,t,scale}, aggregator {mean,min,max,std}, in)
+ *   node_conv_bias_in [S][4][80]
+ *   graph_mlp_1_weights_in [S][40][80] / _bias [S][40];  graph_mlp_2 [S][20][40] / [S][20];  graph_mlp_3 [S][1][20] / [S][1]
+ *   avg_deg_in [S]   (the reference host passes 6.885701656341553, PNA/src/host_load.cc:127)
+ */
+int PNA_compute_graphs(int num_graphs, int* nums_of_nodes, int* nums_of_edges,
+                       int* reload_weights, float* out,
+                       int* node_feature_in, int* edge_list_in,
+                       float* node_embedding_weight_in,
+                       float* node_conv_weights_in, float* node_conv_bias_in,
+                       float* graph_mlp_1_weights_in, float* graph_mlp_1_bias_in,
+                       float* graph_mlp_2_weights_in, float* graph_mlp_2_bias_in,
+                       float* graph_mlp_3_weights_in, float* graph_mlp_3_bias_in,
+                       float* avg_deg_in);
+
+/*
+ * Replaces DGN_compute_graphs, DGN/src/dcl.h:71-91 (def. DGN/src/DGN_compute.cc:6-104).  No edge features.
+ *   node_eigen_in float [N_tot][4]  (node_eigen_t, DGN/src/dcl.h:67; column 1 is the one used)
+ *   embedding_h_atom_embedding_list_weights_in [S][9][119][100]  (dense per-feature tables)
+ *   layers_posttrans_fully_connected_0_linear_weight_in [S][4][100][200] (= [out][2][in]) / _bias_in [S][4][100]
+ *   MLP_layer_FC_layers_0 [S][50][100] / [S][50];  _1 [S][25][50] / [S][25];  _2 [S][1][25] / [S][1]
+ */
+int DGN_compute_graphs(int num_graphs, int* nums_of_nodes, int* nums_of_edges,
+                       int* reload_weights, float* out,
+                       int* node_feature_in, float* node_eigen_in, int* edge_list_in,
+                       float* embedding_h_atom_embedding_list_weights_in,
+                       float* layers_posttrans_fully_connected_0_linear_weight_in,
+                       float* layers_posttrans_fully_connected_0_linear_bias_in,
+                       float* MLP_layer_FC_layers_0_weight_in, float* MLP_layer_FC_layers_0_bias_in,
+                       float* MLP_layer_FC_layers_1_weight_in, float* MLP_layer_FC_layers_1_bias_in,
+                       float* MLP_layer_FC_layers_2_weight_in, float* MLP_layer_FC_layers_2_bias_in);
+
 /* =====================================================================
  * (2) Handle API
  * ===================================================================== */
@@ -116,7 +151,7 @@ int flowgnn_set_weights_gin(flowgnn_engine* e,
 
 /*
  * Generic form: `count` host tensors of ONE weight set, in the argument order of the model's
- * <M>_compute_graphs entry point (GIN 8, GCN 11 tensors).
+ * <M>_compute_graphs entry point (GIN 8, GCN 11, PNA 10, DGN 9 tensors).
  */
 int flowgnn_set_weights(flowgnn_engine* e, int count, const float* const* tensors);
 

@@ -75,6 +75,34 @@ int orc_GCN_compute_graphs(int num_graphs, const int* nums_of_nodes, const int* 
                            const float* graph_pred_weights_in, const float* graph_pred_bias_in,
                            float* x_dump, int nthreads);
 
+/*
+ * PNA forward, float semantics.  Mirrors PNA_compute_graphs, PNA/src/PNA_compute.cc:7-101 (argument order
+ * of PNA/src/dcl.h:91-111).  h_dump (optional): [5][N_tot][80] (0 = encoder, 1..4 = layer outputs).
+ */
+int orc_PNA_compute_graphs(int num_graphs, const int* nums_of_nodes, const int* nums_of_edges,
+                           const int* reload_weights, float* out, const int* node_feature_in,
+                           const int* edge_list_in, const float* node_embedding_weight_in,
+                           const float* node_conv_weights_in, const float* node_conv_bias_in,
+                           const float* graph_mlp_1_weights_in, const float* graph_mlp_1_bias_in,
+                           const float* graph_mlp_2_weights_in, const float* graph_mlp_2_bias_in,
+                           const float* graph_mlp_3_weights_in, const float* graph_mlp_3_bias_in,
+                           const float* avg_deg_in, float* h_dump, int nthreads);
+
+/*
+ * DGN forward, float semantics.  Mirrors DGN_compute_graphs, DGN/src/DGN_compute.cc:6-104 (argument order of
+ * DGN/src/dcl.h:71-91; node_eigen_in is float [N_tot][4]).  h_dump (optional): [5][N_tot][100].
+ */
+int orc_DGN_compute_graphs(int num_graphs, const int* nums_of_nodes, const int* nums_of_edges,
+                           const int* reload_weights, float* out, const int* node_feature_in,
+                           const float* node_eigen_in, const int* edge_list_in,
+                           const float* embedding_h_atom_embedding_list_weights_in,
+                           const float* layers_posttrans_fully_connected_0_linear_weight_in,
+                           const float* layers_posttrans_fully_connected_0_linear_bias_in,
+                           const float* MLP_layer_FC_layers_0_weight_in, const float* MLP_layer_FC_layers_0_bias_in,
+                           const float* MLP_layer_FC_layers_1_weight_in, const float* MLP_layer_FC_layers_1_bias_in,
+                           const float* MLP_layer_FC_layers_2_weight_in, const float* MLP_layer_FC_layers_2_bias_in,
+                           float* h_dump, int nthreads);
+
 #ifdef __cplusplus
 }
 #endif

@@ -33,6 +33,10 @@ def load():
         lib.orc_GIN_compute_graphs.restype = C.c_int
         lib.orc_GCN_compute_graphs.argtypes = [C.c_int, _pi, _pi, _pi, _pf, _pi, _pi, _pi] + [_pf] * 11 + [_pf, C.c_int]
         lib.orc_GCN_compute_graphs.restype = C.c_int
+        lib.orc_PNA_compute_graphs.argtypes = [C.c_int, _pi, _pi, _pi, _pf, _pi, _pi] + [_pf] * 10 + [_pf, C.c_int]
+        lib.orc_PNA_compute_graphs.restype = C.c_int
+        lib.orc_DGN_compute_graphs.argtypes = [C.c_int, _pi, _pi, _pi, _pf, _pi, _pf, _pi] + [_pf] * 9 + [_pf, C.c_int]
+        lib.orc_DGN_compute_graphs.restype = C.c_int
         _lib = lib
     return _lib
 
@@ -118,3 +122,15 @@ def gcn_forward(batch, weight_sets, reload_weights=None, dump_h=False, nthreads=
     """orc_GCN_compute_graphs; dump = x_l (NT outputs) [5][N][100]."""
     return _forward("orc_GCN_compute_graphs", batch, weight_sets, reload_weights,
                     (5, batch.total_nodes, 100) if dump_h else None, nthreads)
+
+
+def pna_forward(batch, weight_sets, reload_weights=None, dump_h=False, nthreads=1):
+    """orc_PNA_compute_graphs; dump = h after encoder and each layer, [5][N][80]."""
+    return _forward("orc_PNA_compute_graphs", batch, weight_sets, reload_weights,
+                    (5, batch.total_nodes, 80) if dump_h else None, nthreads, with_attr=False)
+
+
+def dgn_forward(batch, weight_sets, reload_weights=None, dump_h=False, nthreads=1):
+    """orc_DGN_compute_graphs; dump = h after encoder and each layer, [5][N][100]."""
+    return _forward("orc_DGN_compute_graphs", batch, weight_sets, reload_weights,
+                    (5, batch.total_nodes, 100) if dump_h else None, nthreads, with_attr=False, eig=True)

@@ -67,3 +67,74 @@ def gcn_forward(batch, w, return_x=False):
     pooled = np.add.reduceat(pre, off[:-1], axis=0) / batch.nums_of_nodes[:, None]
     out = pooled @ pw + pb
     return (out, np.stack(xs)) if return_x else out
+
+
+def pna_forward(batch, w, return_h=False):
+    """PNA equations on the batched super-graph, float64."""
+    f64 = lambda a: np.asarray(a, dtype=np.float64)
+    nemb, cw, cb = f64(w["node_embedding_weight"]), f64(w["node_conv_weights"]), f64(w["node_conv_bias"])
+    avg = float(np.asarray(w["avg_deg"]).reshape(-1)[0])
+    N = batch.total_nodes
+    ge = batch.global_edges()
+    u, v = ge[:, 0], ge[:, 1]
+    indeg = np.bincount(v, minlength=N).astype(np.float64)
+    outdeg = np.bincount(u, minlength=N).astype(np.float64)
+    logd = np.log(outdeg + 1.0)
+    t = logd / avg
+    scale = np.where(logd == 0, 1.0, avg / np.where(logd == 0, 1.0, logd))
+    sf = np.stack([np.ones(N), t, scale], axis=1)  # [N, 3]
+    deg1 = np.maximum(indeg, 1.0)[:, None]
+    h = nemb[batch.node_feature.astype(np.int64) + ND_OFF[None, :]].sum(axis=1)
+    hs = [h]
+    for l in range(4):
+        x = h[u]
+        S = np.zeros((N, 80)); Q = np.zeros((N, 80))
+        np.add.at(S, v, x); np.add.at(Q, v, x * x)
+        mn = np.full((N, 80), 31.9990234375); mx = np.full((N, 80), -32.0)
+        np.minimum.at(mn, v, x); np.maximum.at(mx, v, x)
+        mean = S / deg1
+        std = np.sqrt(np.maximum(Q / deg1 - mean * mean, 0.0))
+        agg = np.stack([mean, mn, mx, std], axis=1)  # [N, 4(aggr enum order), 80]
+        y = np.einsum("osai,nai->nso", cw[l], agg)    # [N, 3, 80]
+        acc = cb[l] + (y * sf[:, :, None]).sum(axis=1)
+        h = h + np.maximum(acc, 0.0)
+        hs.append(h)
+    off = batch.node_offsets()
+    hg = np.add.reduceat(h, off[:-1], axis=0) / batch.nums_of_nodes[:, None]
+    o1 = np.maximum(hg @ f64(w["graph_mlp_1_weights"]).T + f64(w["graph_mlp_1_bias"]), 0.0)
+    o2 = np.maximum(o1 @ f64(w["graph_mlp_2_weights"]).T + f64(w["graph_mlp_2_bias"]), 0.0)
+    out = o2 @ f64(w["graph_mlp_3_weights"]).reshape(-1) + float(np.asarray(w["graph_mlp_3_bias"]).reshape(-1)[0])
+    return (out, np.stack(hs)) if return_h else out
+
+
+def dgn_forward(batch, w, return_h=False):
+    """DGN equations on the batched super-graph, float64; x / 0 = 0 for the out-degree divide."""
+    f64 = lambda a: np.asarray(a, dtype=np.float64)
+    emb = f64(w["embedding_h_atom_embedding_list_weights"])
+    lw, lb = f64(w["layers_posttrans_fully_connected_0_linear_weight"]), f64(w["layers_posttrans_fully_connected_0_linear_bias"])
+    N = batch.total_nodes
+    ge = batch.global_edges()
+    u, v = ge[:, 0], ge[:, 1]
+    eig1 = f64(batch.node_eigen)[:, 1]
+    we = eig1[u] - eig1[v]
+    wsum = np.bincount(v, weights=we, minlength=N)
+    abssum = np.bincount(v, weights=np.abs(we), minlength=N)
+    abssum = np.where(abssum == 0, 2.0 ** -13, abssum)
+    outdeg = np.bincount(u, minlength=N).astype(np.float64)
+    h = emb[np.arange(9)[None, :], batch.node_feature.astype(np.int64)].sum(axis=1)
+    hs = [h]
+    for l in range(4):
+        m1 = np.zeros((N, 100)); m2 = np.zeros((N, 100))
+        np.add.at(m1, v, h[u]); np.add.at(m2, v, h[u] * we[:, None])
+        a1 = np.where(outdeg[:, None] == 0, 0.0, m1 / np.maximum(outdeg, 1.0)[:, None])
+        a2 = np.abs((m2 - wsum[:, None] * h) / abssum[:, None])
+        W = lw[l].reshape(100, 2, 100)
+        acc = lb[l] + a1 @ W[:, 0, :].T + a2 @ W[:, 1, :].T
+        h = h + np.maximum(acc, 0.0)
+        hs.append(h)
+    off = batch.node_offsets()
+    hg = np.add.reduceat(h, off[:-1], axis=0) / batch.nums_of_nodes[:, None]
+    o1 = np.maximum(hg @ f64(w["MLP_layer_FC_layers_0_weight"]).T + f64(w["MLP_layer_FC_layers_0_bias"]), 0.0)
+    o2 = np.maximum(o1 @ f64(w["MLP_layer_FC_layers_1_weight"]).T + f64(w["MLP_layer_FC_layers_1_bias"]), 0.0)
+    out = o2 @ f64(w["MLP_layer_FC_layers_2_weight"]).reshape(-1) + float(np.asarray(w["MLP_layer_FC_layers_2_bias"]).reshape(-1)[0])
+    return (out, np.stack(hs)) if return_h else out
