@@ -51,12 +51,13 @@ def _declare(lib):
     lib.GIN_compute_graphs.argtypes = [C.c_int, p_int, p_int, p_int, p_float, p_int, p_int, p_int] + [p_float] * 8
     lib.PNA_compute_graphs.argtypes = [C.c_int, p_int, p_int, p_int, p_float, p_int, p_int] + [p_float] * 10
     lib.DGN_compute_graphs.argtypes = [C.c_int, p_int, p_int, p_int, p_float, p_int, p_float, p_int] + [p_float] * 9
+    lib.GAT_compute_graphs.argtypes = [C.c_int, p_int, p_int, p_int, p_float, p_int, p_int] + [p_float] * 6
     lib.GCN_compute_graphs.argtypes = [C.c_int, p_int, p_int, p_int, p_float, p_int, p_int, p_int] + [p_float] * 11
     for name in ("flowgnn_create", "flowgnn_destroy", "flowgnn_set_weights_gin", "flowgnn_set_weights", "flowgnn_load_weights_dir",
                  "flowgnn_set_batch", "flowgnn_run", "flowgnn_sync", "flowgnn_get_results",
                  "flowgnn_results_device", "flowgnn_set_results_buffer", "flowgnn_stream", "flowgnn_batch_info", "flowgnn_get_csr",
                  "flowgnn_get_h", "flowgnn_profile_enable", "flowgnn_profile_read",
-                 "flowgnn_run_aggregation_only", "GIN_compute_graphs", "GCN_compute_graphs", "PNA_compute_graphs", "DGN_compute_graphs"):
+                 "flowgnn_run_aggregation_only", "GIN_compute_graphs", "GCN_compute_graphs", "PNA_compute_graphs", "DGN_compute_graphs", "GAT_compute_graphs"):
         getattr(lib, name).restype = C.c_int
 
 

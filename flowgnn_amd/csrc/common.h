@@ -114,6 +114,8 @@ struct DeviceBatch {
     float* scratch;           // [N][scratch_dim] model scratch (aggregates)
     float* out;               // [G]
     int final_h;              // which h[] holds the last stage's output (set by forward)
+    const float* tap;         // optional debug tap returned by flowgnn_get_h instead of h[final_h]
+    int tap_dim;
 };
 
 class Model {
@@ -134,6 +136,7 @@ Model* make_gin_model();
 Model* make_gcn_model();
 Model* make_pna_model();
 Model* make_dgn_model();
+Model* make_gat_model();
 
 // helpers
 int read_floats(const char* dir, const char* file, size_t offset_floats, size_t count, float* dst);

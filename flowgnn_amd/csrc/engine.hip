@@ -148,6 +148,7 @@ int flowgnn_create(int model, int device_id, flowgnn_engine** out) {
         case FLOWGNN_MODEL_GCN: m = make_gcn_model(); break;
         case FLOWGNN_MODEL_PNA: m = make_pna_model(); break;
         case FLOWGNN_MODEL_DGN: m = make_dgn_model(); break;
+        case FLOWGNN_MODEL_GAT: m = make_gat_model(); break;
         default: return FLOWGNN_ERR_UNSUPPORTED;
     }
     flowgnn_engine* e = new flowgnn_engine();
@@ -318,6 +319,8 @@ int flowgnn_set_batch(flowgnn_engine* e, int num_graphs, const int* nums_of_node
     db.node_eigen = eig ? e->d_eig : nullptr;
     db.h[0] = e->d_h0; db.h[1] = e->d_h1; db.scratch = e->d_scratch; db.out = e->d_out;
     db.final_h = 0;
+    db.tap = nullptr;
+    db.tap_dim = 0;
     FG_HIP_TRY(hipMemset(e->d_err, 0, sizeof(int)));
     e->batch_ready = true;
     return FLOWGNN_OK;
@@ -335,6 +338,8 @@ int flowgnn_run(flowgnn_engine* e) {
         ProfScope p(e->prof, "build_csr", e->stream);
         launch_build_csr(e->db.b, e->db.csr, e->has_attr, e->stream);
     }
+    e->db.tap = nullptr;
+    e->db.tap_dim = 0;
     ENGINE_TRY(e, e->model->forward(e->db, e->prof, e->stream));
     hipError_t he = hipGetLastError();
     if (he != hipSuccess) {
@@ -433,10 +438,10 @@ int flowgnn_get_h(flowgnn_engine* e, float* h_host, int* dim) {
     if (!e->ran) return FLOWGNN_ERR_STATE;
     int rc = flowgnn_sync(e);
     if (rc) return rc;
-    const int D = e->model->emb_dim();
+    const int D = e->db.tap ? e->db.tap_dim : e->model->emb_dim();
+    const float* srcp = e->db.tap ? e->db.tap : e->db.h[e->db.final_h];
     if (dim) *dim = D;
-    if (h_host && e->N)
-        FG_HIP_TRY(hipMemcpy(h_host, e->db.h[e->db.final_h], sizeof(float) * (size_t)e->N * D, hipMemcpyDeviceToHost));
+    if (h_host && e->N) FG_HIP_TRY(hipMemcpy(h_host, srcp, sizeof(float) * (size_t)e->N * D, hipMemcpyDeviceToHost));
     return FLOWGNN_OK;
 }
 
@@ -591,6 +596,17 @@ int DGN_compute_graphs(int num_graphs, int* nums_of_nodes, int* nums_of_edges, i
     if (num_graphs > 0 && !node_eigen_in) return FLOWGNN_ERR_ARG;
     return compute_graphs_generic(FLOWGNN_MODEL_DGN, num_graphs, nums_of_nodes, nums_of_edges, reload_weights, out,
                                   node_feature_in, node_eigen_in, edge_list_in, nullptr, 9, t, sz);
+}
+
+int GAT_compute_graphs(int num_graphs, int* nums_of_nodes, int* nums_of_edges, int* reload_weights, float* out,
+                       int* node_feature_in, int* edge_list_in, float* scoring_fn_target_in, float* scoring_fn_source_in,
+                       float* linear_proj_weights_in, float* skip_proj_weights_in, float* graph_pred_weights_in,
+                       float* graph_pred_bias_in) {
+    const float* t[6] = {scoring_fn_target_in, scoring_fn_source_in, linear_proj_weights_in, skip_proj_weights_in,
+                         graph_pred_weights_in, graph_pred_bias_in};
+    static const size_t sz[6] = {5 * 4 * 16, 5 * 4 * 16, 5 * 4 * 16 * 4 * 16, 5 * 4 * 16 * 4 * 16, 16, 1};
+    return compute_graphs_generic(FLOWGNN_MODEL_GAT, num_graphs, nums_of_nodes, nums_of_edges, reload_weights, out,
+                                  node_feature_in, nullptr, edge_list_in, nullptr, 6, t, sz);
 }
 
 }  // extern "C"

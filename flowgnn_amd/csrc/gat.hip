@@ -1,0 +1,360 @@
+// gat.hip -- GAT (5 layers, 4 heads x 16 dims) hot path for gfx950 (MI355X).
+//
+// Reference per graph (GAT/src/*.cc); per node 64 features, index f = dim * 4 + head (the reference's FM_VEC):
+//   proj_0[v]   = W_lin0 feat(v)      (raw integer atom features, 9 inputs)            load_inputs.cc:184-201
+//   skip_0[v]   = feat(v) in dims 0..8 of head 0, else 0                               load_inputs.cc:190-191
+//   ssrc_l[v][h] = sum_d proj_l[v][d][h] a_src[l][h][d],  stgt likewise               load_inputs.cc:203-224, node_embedding.cc:235-268
+//   per destination v, over its in-neighbours u plus v itself:
+//     e[h] = exp(leaky_0.2(ssrc[v][h] + stgt[u][h]))   (no max subtraction)            message_passing.cc:122-128
+//     msg[v][d][h] = sum_u e[h] proj[u][d][h] / sum_u e[h]                              message_passing.cc:130-141, conv_layer.cc:158-177
+//   o = ELU(msg + W_skip_l skip_l),  skip_{l+1} = o,  proj_{l+1} = W_lin_{l+1} o       node_embedding.cc:157-195
+//   last layer: emb[v][d] = mean_h (msg + W_skip_4 skip_4)[d][h];  out = pb + pw . mean_v emb   finalize.cc:46-112
+//
+// Here ONE fused kernel per layer: a wave owns 16 destination nodes; lane (j, g) gathers node j's attention
+// message for dims {g, 4+g, 8+g, 12+g} x 4 heads straight into the MFMA accumulator layout, then runs both
+// 64x64 contractions on fp32 MFMA chained through registers (as in gin.hip), and reduces the next scores with
+// two shuffles.  Traffic per node-layer ~ 1 KB; the kernel is HBM-bound.
+#include "common.h"
+#include "device_common.h"
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+
+namespace fg {
+
+constexpr int GAT_D = 16;
+constexpr int GAT_H = 4;
+constexpr int GAT_F = GAT_D * GAT_H;  // 64
+constexpr int GAT_L = 5;
+
+// lane = (node, dim): proj_0, skip_0 and the layer-0 scores
+__global__ __launch_bounds__(256) void gat_encoder_kernel(const int* __restrict__ node_feature,
+                                                           const int* __restrict__ feat_row,  // null = identity
+                                                           const float* __restrict__ lin0,    // [16 dim][9][4 head]
+                                                           const float* __restrict__ a_src,   // [16 dim][4 head] of layer 0
+                                                           const float* __restrict__ a_tgt, float* __restrict__ proj,
+                                                           float* __restrict__ skipin, float* __restrict__ scores, int n_tot) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long v = i >> 4;
+    const int d = (int)(i & 15);
+    const bool valid = v < n_tot;
+    const long long vv = valid ? v : n_tot - 1;
+    const long long row = feat_row ? feat_row[vv] : vv;
+    float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
+    float fd = 0.f;
+#pragma unroll
+    for (int k = 0; k < ND_FEATURE; k++) {
+        const float f = (float)node_feature[(size_t)row * ND_FEATURE + k];
+        const float4 w = reinterpret_cast<const float4*>(lin0)[d * ND_FEATURE + k];
+        p.x += f * w.x; p.y += f * w.y; p.z += f * w.z; p.w += f * w.w;
+        if (k == d) fd = f;
+    }
+    const float4 as = reinterpret_cast<const float4*>(a_src)[d], at = reinterpret_cast<const float4*>(a_tgt)[d];
+    float4 ss = make_float4(p.x * as.x, p.y * as.y, p.z * as.z, p.w * as.w);
+    float4 st = make_float4(p.x * at.x, p.y * at.y, p.z * at.z, p.w * at.w);
+#pragma unroll
+    for (int m = 1; m < 16; m <<= 1) {
+        ss.x += __shfl_xor(ss.x, m, 64); ss.y += __shfl_xor(ss.y, m, 64); ss.z += __shfl_xor(ss.z, m, 64); ss.w += __shfl_xor(ss.w, m, 64);
+        st.x += __shfl_xor(st.x, m, 64); st.y += __shfl_xor(st.y, m, 64); st.z += __shfl_xor(st.z, m, 64); st.w += __shfl_xor(st.w, m, 64);
+    }
+    if (!valid) return;
+    reinterpret_cast<float4*>(proj)[i] = p;
+    reinterpret_cast<float4*>(skipin)[i] = make_float4(d < ND_FEATURE ? fd : 0.f, 0.f, 0.f, 0.f);
+    if (d == 0) {
+        reinterpret_cast<float4*>(scores)[v * 2 + 0] = ss;
+        reinterpret_cast<float4*>(scores)[v * 2 + 1] = st;
+    }
+}
+
+// local node index per node (reference quirk mode: every graph reads the first rows of the batch)
+__global__ __launch_bounds__(256) void gat_local_rows_kernel(const int* __restrict__ node_off, int* __restrict__ feat_row,
+                                                              int num_graphs) {
+    const int lane = threadIdx.x & 63;
+    const int g = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (g >= num_graphs) return;
+    for (int v = node_off[g] + lane; v < node_off[g + 1]; v += 64) feat_row[v] = v - node_off[g];
+}
+
+struct GatLayerDev {
+    const float* wskip;  // fragments [4 t][4 q][64][4]: W_skip_l[f_o = 16 t + i][f_i = 16 q + 4 g + r]
+    const float* wlin;   // fragments [4 t][4 t2][64][4]: W_lin_{l+1}[f_o = 16 t2 + i][f_i = 16 t + 4 g + r]
+    const float* a_src;  // [16 dim][4 head] of layer l+1
+    const float* a_tgt;
+};
+
+template <bool FINAL>
+__global__ __launch_bounds__(256) void gat_layer_kernel(const float* __restrict__ proj, const float* __restrict__ skipin,
+                                                         const float* __restrict__ scores, float* __restrict__ proj_out,
+                                                         float* __restrict__ skip_out, float* __restrict__ scores_out,
+                                                         float* __restrict__ emb_out, const int* __restrict__ row_ptr,
+                                                         const int* __restrict__ src, GatLayerDev w, int n_tot) {
+    const int lane = threadIdx.x & 63;
+    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int j = lane & 15, g = lane >> 4;
+    const long long node_base = (long long)wave * 16;
+    if (node_base >= n_tot) return;
+    long long node = node_base + j;
+    const bool valid = node < n_tot;
+    if (!valid) node = n_tot - 1;
+    const float4* proj4 = reinterpret_cast<const float4*>(proj);
+    const float4* sc4 = reinterpret_cast<const float4*>(scores);
+
+    // ---- attention gather (pull): self edge first, then the CSR row (ascending source)
+    const float4 ssrc = sc4[node * 2 + 0];
+    float4 den = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 num[4];
+#pragma unroll
+    for (int t = 0; t < 4; t++) num[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+    int e = valid ? row_ptr[node] : 0;
+    const int e_end = valid ? row_ptr[node + 1] : 0;
+    int u = (int)node;  // the self edge
+    bool more = true;
+    while (__any(more)) {
+        if (more) {
+            const float4 st = sc4[(size_t)u * 2 + 1];
+            float4 s = make_float4(ssrc.x + st.x, ssrc.y + st.y, ssrc.z + st.z, ssrc.w + st.w);
+            s.x = expf(s.x < 0.f ? s.x * 0.2f : s.x); s.y = expf(s.y < 0.f ? s.y * 0.2f : s.y);
+            s.z = expf(s.z < 0.f ? s.z * 0.2f : s.z); s.w = expf(s.w < 0.f ? s.w * 0.2f : s.w);
+            den.x += s.x; den.y += s.y; den.z += s.z; den.w += s.w;
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                const float4 p = proj4[(size_t)u * 16 + 4 * t + g];
+                num[t].x += s.x * p.x; num[t].y += s.y * p.y; num[t].z += s.z * p.z; num[t].w += s.w * p.w;
+            }
+            more = e < e_end;
+            if (more) u = src[e++];
+        }
+    }
+
+    // ---- o = msg + W_skip skip   (accumulators start from the message: rows 16 t + 4 g + r = dim 4 t + g, head r)
+    float bq[16];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const float4 x = *reinterpret_cast<const float4*>(skipin + (size_t)node * GAT_F + 16 * q + 4 * g);
+        bq[4 * q + 0] = x.x; bq[4 * q + 1] = x.y; bq[4 * q + 2] = x.z; bq[4 * q + 3] = x.w;
+    }
+    float4_t acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; t++) acc[t] = (float4_t){num[t].x / den.x, num[t].y / den.y, num[t].z / den.z, num[t].w / den.w};
+    const float4* ws4 = reinterpret_cast<const float4*>(w.wskip);
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            const float4 af = ws4[(size_t)(t * 4 + q) * 64 + lane];
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(af.x, bq[4 * q + 0], acc[t], 0, 0, 0);
+        }
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            const float4 af = ws4[(size_t)(t * 4 + q) * 64 + lane];
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(af.y, bq[4 * q + 1], acc[t], 0, 0, 0);
+        }
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            const float4 af = ws4[(size_t)(t * 4 + q) * 64 + lane];
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(af.z, bq[4 * q + 2], acc[t], 0, 0, 0);
+        }
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            const float4 af = ws4[(size_t)(t * 4 + q) * 64 + lane];
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(af.w, bq[4 * q + 3], acc[t], 0, 0, 0);
+        }
+    }
+
+    if (FINAL) {
+        if (valid) {
+#pragma unroll
+            for (int t = 0; t < 4; t++) emb_out[(size_t)node * GAT_D + 4 * t + g] = (acc[t].x + acc[t].y + acc[t].z + acc[t].w) / (float)GAT_H;
+        }
+        return;
+    }
+
+    // ---- ELU, next skip input, next projection (chained through registers), next scores
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+        acc[t].x = acc[t].x <= 0.f ? expf(acc[t].x) - 1.0f : acc[t].x; acc[t].y = acc[t].y <= 0.f ? expf(acc[t].y) - 1.0f : acc[t].y;
+        acc[t].z = acc[t].z <= 0.f ? expf(acc[t].z) - 1.0f : acc[t].z; acc[t].w = acc[t].w <= 0.f ? expf(acc[t].w) - 1.0f : acc[t].w;
+        if (valid)
+            *reinterpret_cast<float4*>(skip_out + (size_t)node * GAT_F + 16 * t + 4 * g) = make_float4(acc[t].x, acc[t].y, acc[t].z, acc[t].w);
+    }
+    float4_t pr[4];
+#pragma unroll
+    for (int t2 = 0; t2 < 4; t2++) pr[t2] = (float4_t){0.f, 0.f, 0.f, 0.f};
+    const float4* wl4 = reinterpret_cast<const float4*>(w.wlin);
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+        float4 af[4];
+#pragma unroll
+        for (int t2 = 0; t2 < 4; t2++) af[t2] = wl4[(size_t)(t * 4 + t2) * 64 + lane];
+#pragma unroll
+        for (int t2 = 0; t2 < 4; t2++) pr[t2] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[t2].x, acc[t].x, pr[t2], 0, 0, 0);
+#pragma unroll
+        for (int t2 = 0; t2 < 4; t2++) pr[t2] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[t2].y, acc[t].y, pr[t2], 0, 0, 0);
+#pragma unroll
+        for (int t2 = 0; t2 < 4; t2++) pr[t2] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[t2].z, acc[t].z, pr[t2], 0, 0, 0);
+#pragma unroll
+        for (int t2 = 0; t2 < 4; t2++) pr[t2] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[t2].w, acc[t].w, pr[t2], 0, 0, 0);
+    }
+    float4 ss = make_float4(0.f, 0.f, 0.f, 0.f), st = ss;
+#pragma unroll
+    for (int t2 = 0; t2 < 4; t2++) {
+        if (valid)
+            *reinterpret_cast<float4*>(proj_out + (size_t)node * GAT_F + 16 * t2 + 4 * g) = make_float4(pr[t2].x, pr[t2].y, pr[t2].z, pr[t2].w);
+        const float4 as = reinterpret_cast<const float4*>(w.a_src)[4 * t2 + g], at = reinterpret_cast<const float4*>(w.a_tgt)[4 * t2 + g];
+        ss.x += pr[t2].x * as.x; ss.y += pr[t2].y * as.y; ss.z += pr[t2].z * as.z; ss.w += pr[t2].w * as.w;
+        st.x += pr[t2].x * at.x; st.y += pr[t2].y * at.y; st.z += pr[t2].z * at.z; st.w += pr[t2].w * at.w;
+    }
+#pragma unroll
+    for (int m = 16; m < 64; m <<= 1) {
+        ss.x += __shfl_xor(ss.x, m, 64); ss.y += __shfl_xor(ss.y, m, 64); ss.z += __shfl_xor(ss.z, m, 64); ss.w += __shfl_xor(ss.w, m, 64);
+        st.x += __shfl_xor(st.x, m, 64); st.y += __shfl_xor(st.y, m, 64); st.z += __shfl_xor(st.z, m, 64); st.w += __shfl_xor(st.w, m, 64);
+    }
+    if (valid && g == 0) {
+        reinterpret_cast<float4*>(scores_out)[node * 2 + 0] = ss;
+        reinterpret_cast<float4*>(scores_out)[node * 2 + 1] = st;
+    }
+}
+
+class GatModel : public Model {
+public:
+    ~GatModel() override { free_all(); }
+    int emb_dim() const override { return GAT_F; }
+    int scratch_dim() const override { return 2 * GAT_F + 2 * 8 + GAT_D + 1; }  // skip x2, scores x2, emb, feat_row
+    bool has_edge_attr() const override { return false; }
+    int num_weight_tensors() const override { return 6; }
+    bool weights_ready() const override { return ready_; }
+
+    // host tensors (GAT/src/dcl.h:86-93): scoring_fn_target[5][4][16], scoring_fn_source[5][4][16],
+    // linear_proj[5][4][16][4][16], skip_proj[5][4][16][4][16] (layer 0: only [ho][do][0][<9] is used), pred_w[1][16], pred_b[1]
+    int set_weights(const float* const* t) override {
+        const float *tgt = t[0], *srcw = t[1], *lin = t[2], *skip = t[3];
+        auto W = [](const float* w, int l, int ho, int dout, int hi, int din) {
+            return w[(((((size_t)l * GAT_H + ho) * GAT_D + dout) * GAT_H + hi) * GAT_D) + din];
+        };
+        std::vector<float> lin0((size_t)GAT_D * ND_FEATURE * GAT_H);
+        for (int d = 0; d < GAT_D; d++)
+            for (int k = 0; k < ND_FEATURE; k++)
+                for (int h = 0; h < GAT_H; h++) lin0[((size_t)d * ND_FEATURE + k) * GAT_H + h] = W(lin, 0, h, d, 0, k);
+        std::vector<float> asrc((size_t)GAT_L * GAT_D * GAT_H), atgt(asrc.size());
+        for (int l = 0; l < GAT_L; l++)
+            for (int d = 0; d < GAT_D; d++)
+                for (int h = 0; h < GAT_H; h++) {
+                    asrc[((size_t)l * GAT_D + d) * GAT_H + h] = srcw[((size_t)l * GAT_H + h) * GAT_D + d];
+                    atgt[((size_t)l * GAT_D + d) * GAT_H + h] = tgt[((size_t)l * GAT_H + h) * GAT_D + d];
+                }
+        // dense 64 x 64 views, f = dim * 4 + head, then MFMA fragments
+        std::vector<float> wskip((size_t)GAT_L * 16 * 64 * 4), wlin((size_t)GAT_L * 16 * 64 * 4, 0.0f);
+        auto M = [&](const float* w, int l, int fo, int fi) { return W(w, l, fo & 3, fo >> 2, fi & 3, fi >> 2); };
+        for (int l = 0; l < GAT_L; l++)
+            for (int a = 0; a < 4; a++)
+                for (int b = 0; b < 4; b++)
+                    for (int lane = 0; lane < 64; lane++)
+                        for (int r = 0; r < 4; r++) {
+                            const int i = lane & 15, g = lane >> 4;
+                            // skip: (t = a, q = b): rows 16 t + i, cols 16 q + 4 g + r
+                            wskip[((((size_t)l * 4 + a) * 4 + b) * 64 + lane) * 4 + r] = M(skip, l, 16 * a + i, 16 * b + 4 * g + r);
+                            // lin of layer l+1, consumed by layer l: (t = a, t2 = b): rows 16 t2 + i, cols 16 t + 4 g + r
+                            if (l + 1 < GAT_L)
+                                wlin[((((size_t)l * 4 + a) * 4 + b) * 64 + lane) * 4 + r] = M(lin, l + 1, 16 * b + i, 16 * a + 4 * g + r);
+                        }
+        std::vector<float> v_pw(t[4], t[4] + GAT_D), v_pb(t[5], t[5] + 1);
+        int rc;
+        if ((rc = upload(&d_lin0_, lin0))) return rc;
+        if ((rc = upload(&d_asrc_, asrc))) return rc;
+        if ((rc = upload(&d_atgt_, atgt))) return rc;
+        if ((rc = upload(&d_wskip_, wskip))) return rc;
+        if ((rc = upload(&d_wlin_, wlin))) return rc;
+        if ((rc = upload(&d_pw_, v_pw))) return rc;
+        if ((rc = upload(&d_pb_, v_pb))) return rc;
+        ready_ = true;
+        return 0;
+    }
+
+    // GAT/src/host_load.cc:20-91: eight files; layer 0 lives in the [ho][do][head_in = 0][dim_in < 9] corner
+    int load_weights_dir(const char* dir) override {
+        std::vector<float> pw(16), pb(1), tgt(5 * 4 * 16), srcw(5 * 4 * 16), l0(4 * 16 * 9), l1((size_t)4 * 4 * 16 * 4 * 16), s0(4 * 16 * 9),
+            s1((size_t)4 * 4 * 16 * 4 * 16);
+        int rc;
+        if ((rc = read_floats(dir, "gat_ep1_pred_weights_layer5.bin", 0, pw.size(), pw.data()))) return rc;
+        if ((rc = read_floats(dir, "gat_ep1_pred_bias_layer5.bin", 0, 1, pb.data()))) return rc;
+        if ((rc = read_floats(dir, "gat_ep1_scoring_fn_target_layer5.bin", 0, tgt.size(), tgt.data()))) return rc;
+        if ((rc = read_floats(dir, "gat_ep1_scoring_fn_source_layer5.bin", 0, srcw.size(), srcw.data()))) return rc;
+        if ((rc = read_floats(dir, "gat_ep1_linear_proj_weight_0_layer5.bin", 0, l0.size(), l0.data()))) return rc;
+        if ((rc = read_floats(dir, "gat_ep1_linear_proj_weight_1_layer5.bin", 0, l1.size(), l1.data()))) return rc;
+        if ((rc = read_floats(dir, "gat_ep1_skip_proj_weight_0_layer5.bin", 0, s0.size(), s0.data()))) return rc;
+        if ((rc = read_floats(dir, "gat_ep1_skip_proj_weight_1_layer5.bin", 0, s1.size(), s1.data()))) return rc;
+        std::vector<float> lin((size_t)5 * 4096, 0.0f), skip((size_t)5 * 4096, 0.0f);
+        for (int ho = 0; ho < 4; ho++)
+            for (int d = 0; d < 16; d++)
+                for (int k = 0; k < 9; k++) {
+                    lin[(((size_t)ho * 16 + d) * 4 + 0) * 16 + k] = l0[((size_t)ho * 16 + d) * 9 + k];
+                    skip[(((size_t)ho * 16 + d) * 4 + 0) * 16 + k] = s0[((size_t)ho * 16 + d) * 9 + k];
+                }
+        memcpy(&lin[4096], l1.data(), sizeof(float) * l1.size());
+        memcpy(&skip[4096], s1.data(), sizeof(float) * s1.size());
+        const float* t[6] = {tgt.data(), srcw.data(), lin.data(), skip.data(), pw.data(), pb.data()};
+        return set_weights(t);
+    }
+
+    int forward(DeviceBatch& db, Profiler& prof, hipStream_t s) override {
+        const int n = db.b.n_tot;
+        if (n <= 0) return 0;
+        float* skipb[2] = {db.scratch, db.scratch + (size_t)n * GAT_F};
+        float* scoreb[2] = {db.scratch + (size_t)n * 2 * GAT_F, db.scratch + (size_t)n * (2 * GAT_F + 8)};
+        float* emb = db.scratch + (size_t)n * (2 * GAT_F + 16);
+        int* feat_row = nullptr;
+        // FLOWGNN_GAT_REFERENCE_QUIRK=1: node features read without the per-graph offset (GAT_compute.cc:72)
+        const char* q = getenv("FLOWGNN_GAT_REFERENCE_QUIRK");
+        if (q && atoi(q) != 0) {
+            feat_row = reinterpret_cast<int*>(db.scratch + (size_t)n * (2 * GAT_F + 16 + GAT_D));
+            gat_local_rows_kernel<<<(db.b.num_graphs + 3) / 4, 256, 0, s>>>(db.b.node_off, feat_row, db.b.num_graphs);
+        }
+        {
+            ProfScope p(prof, "gat_encoder", s);
+            const long long items = (long long)n * 16;
+            gat_encoder_kernel<<<(int)((items + 255) / 256), 256, 0, s>>>(db.b.node_feature, feat_row, d_lin0_, d_asrc_, d_atgt_,
+                                                                        db.h[0], skipb[0], scoreb[0], n);
+        }
+        int cur = 0;
+        const int waves = (int)ceil_div_ll(n, 16);
+        for (int l = 0; l < GAT_L; l++) {
+            GatLayerDev w;
+            w.wskip = d_wskip_ + (size_t)l * 16 * 64 * 4;
+            w.wlin = d_wlin_ + (size_t)l * 16 * 64 * 4;
+            w.a_src = d_asrc_ + (size_t)(l + 1 < GAT_L ? l + 1 : l) * GAT_D * GAT_H;
+            w.a_tgt = d_atgt_ + (size_t)(l + 1 < GAT_L ? l + 1 : l) * GAT_D * GAT_H;
+            ProfScope p(prof, "gat_layer", s);
+            if (l < GAT_L - 1) {
+                gat_layer_kernel<false><<<(waves + 3) / 4, 256, 0, s>>>(db.h[cur], skipb[cur], scoreb[cur], db.h[cur ^ 1], skipb[cur ^ 1],
+                                                                         scoreb[cur ^ 1], emb, db.csr.row_ptr, db.csr.src, w, n);
+                cur ^= 1;
+            } else {
+                gat_layer_kernel<true><<<(waves + 3) / 4, 256, 0, s>>>(db.h[cur], skipb[cur], scoreb[cur], nullptr, nullptr, nullptr, emb,
+                                                                        db.csr.row_ptr, db.csr.src, w, n);
+            }
+        }
+        db.final_h = cur;
+        db.tap = skipb[cur];  // ELU output of layer 3
+        db.tap_dim = GAT_F;
+        {
+            ProfScope p(prof, "mean_pool_linear", s);
+            mean_pool_linear_kernel<GAT_D><<<(db.b.num_graphs + 3) / 4, 256, 0, s>>>(emb, db.b.node_off, d_pw_, d_pb_, db.out,
+                                                                                     db.b.num_graphs);
+        }
+        return 0;
+    }
+
+private:
+    void free_all() {
+        float** ptrs[] = {&d_lin0_, &d_asrc_, &d_atgt_, &d_wskip_, &d_wlin_, &d_pw_, &d_pb_};
+        for (auto p : ptrs)
+            if (*p) { hipFree(*p); *p = nullptr; }
+    }
+    bool ready_ = false;
+    float *d_lin0_ = nullptr, *d_asrc_ = nullptr, *d_atgt_ = nullptr, *d_wskip_ = nullptr, *d_wlin_ = nullptr, *d_pw_ = nullptr,
+          *d_pb_ = nullptr;
+};
+
+Model* make_gat_model() { return new GatModel(); }
+
+}  // namespace fg

@@ -171,6 +171,8 @@ def compute_graphs(model: str, batch: GraphBatch, weight_sets, reload_weights=No
         rc = lib.GCN_compute_graphs(G, _pi(nn), _pi(ne), _pi(rw), _pf(out), _pi(nf), _pi(el), _pi(ea), *wp)
     elif model == "PNA":
         rc = lib.PNA_compute_graphs(G, _pi(nn), _pi(ne), _pi(rw), _pf(out), _pi(nf), _pi(el), *wp)
+    elif model == "GAT":
+        rc = lib.GAT_compute_graphs(G, _pi(nn), _pi(ne), _pi(rw), _pf(out), _pi(nf), _pi(el), *wp)
     elif model == "DGN":
         eig = _f32(batch.node_eigen)
         rc = lib.DGN_compute_graphs(G, _pi(nn), _pi(ne), _pi(rw), _pf(out), _pi(nf), _pf(eig), _pi(el), *wp)

@@ -242,6 +242,57 @@ def synth_dgn_weights(seed: int = 7) -> Dict[str, np.ndarray]:
     return w
 
 
-LOADERS = {"GIN": load_gin_weights, "GIN-VN": load_gin_weights, "GCN": load_gcn_weights, "PNA": load_pna_weights, "DGN": load_dgn_weights}
-SYNTH = {"GIN": synth_gin_weights, "GIN-VN": synth_gin_weights, "GCN": synth_gcn_weights, "PNA": synth_pna_weights, "DGN": synth_dgn_weights}
-SAVERS = {"GIN": save_gin_weights, "GIN-VN": save_gin_weights, "GCN": save_gcn_weights, "PNA": save_pna_weights, "DGN": save_dgn_weights}
+# --------------------------------------------------------------------------- GAT
+GAT_SHAPES = OrderedDict([
+    ("scoring_fn_target", (5, 4, 16)), ("scoring_fn_source", (5, 4, 16)),
+    ("linear_proj_weights", (5, 4, 16, 4, 16)), ("skip_proj_weights", (5, 4, 16, 4, 16)),
+    ("graph_pred_weights", (1, 16)), ("graph_pred_bias", (1,)),
+])
+_GAT_FILES = {"graph_pred_weights": "gat_ep1_pred_weights_layer5.bin", "graph_pred_bias": "gat_ep1_pred_bias_layer5.bin",
+              "scoring_fn_target": "gat_ep1_scoring_fn_target_layer5.bin",
+              "scoring_fn_source": "gat_ep1_scoring_fn_source_layer5.bin"}
+
+
+def load_gat_weights(directory: str) -> Dict[str, np.ndarray]:
+    """GAT/src/host_load.cc:20-91: layer 0 of linear/skip proj is a [4][16][1][9] file placed in the
+    [head_out][dim_out][head_in = 0][dim_in < 9] corner of a zero [4][16][4][16] tensor."""
+    w = OrderedDict()
+    for k in ("scoring_fn_target", "scoring_fn_source"):
+        w[k] = _read(os.path.join(directory, _GAT_FILES[k]), GAT_SHAPES[k])
+    for k, stem in (("linear_proj_weights", "linear_proj_weight"), ("skip_proj_weights", "skip_proj_weight")):
+        full = np.zeros((5, 4, 16, 4, 16), dtype=np.float32)
+        full[0, :, :, 0, :9] = _read(os.path.join(directory, f"gat_ep1_{stem}_0_layer5.bin"), (4, 16, 9))
+        full[1:] = _read(os.path.join(directory, f"gat_ep1_{stem}_1_layer5.bin"), (4, 4, 16, 4, 16))
+        w[k] = full
+    for k in ("graph_pred_weights", "graph_pred_bias"):
+        w[k] = _read(os.path.join(directory, _GAT_FILES[k]), GAT_SHAPES[k])
+    return w
+
+
+def save_gat_weights(w: Dict[str, np.ndarray], directory: str) -> None:
+    os.makedirs(directory, exist_ok=True)
+    for k, f in _GAT_FILES.items():
+        np.asarray(w[k], dtype="<f4").tofile(os.path.join(directory, f))
+    for k, stem in (("linear_proj_weights", "linear_proj_weight"), ("skip_proj_weights", "skip_proj_weight")):
+        a = np.asarray(w[k], dtype="<f4")
+        np.ascontiguousarray(a[0, :, :, 0, :9]).tofile(os.path.join(directory, f"gat_ep1_{stem}_0_layer5.bin"))
+        np.ascontiguousarray(a[1:]).tofile(os.path.join(directory, f"gat_ep1_{stem}_1_layer5.bin"))
+
+
+def synth_gat_weights(seed: int = 7) -> Dict[str, np.ndarray]:
+    """Small weights: the reference feeds raw atom numbers (0..118) into layer 0 and exponentiates the
+    attention scores without max subtraction, so the scale has to keep exp() finite."""
+    rng = np.random.default_rng(seed)
+    scale = {"scoring_fn_target": 0.1, "scoring_fn_source": 0.1, "linear_proj_weights": 0.08, "skip_proj_weights": 0.08,
+             "graph_pred_weights": 0.2, "graph_pred_bias": 0.1}
+    w = OrderedDict((k, (rng.standard_normal(shp) * scale[k]).astype(np.float32)) for k, shp in GAT_SHAPES.items())
+    for k in ("linear_proj_weights", "skip_proj_weights"):
+        corner = w[k][0, :, :, 0, :9].copy() * 0.02  # raw integer inputs
+        w[k][0] = 0.0
+        w[k][0, :, :, 0, :9] = corner
+    return w
+
+
+LOADERS = {"GIN": load_gin_weights, "GIN-VN": load_gin_weights, "GCN": load_gcn_weights, "PNA": load_pna_weights, "DGN": load_dgn_weights, "GAT": load_gat_weights}
+SYNTH = {"GIN": synth_gin_weights, "GIN-VN": synth_gin_weights, "GCN": synth_gcn_weights, "PNA": synth_pna_weights, "DGN": synth_dgn_weights, "GAT": synth_gat_weights}
+SAVERS = {"GIN": save_gin_weights, "GIN-VN": save_gin_weights, "GCN": save_gcn_weights, "PNA": save_pna_weights, "DGN": save_dgn_weights, "GAT": save_gat_weights}

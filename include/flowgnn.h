@@ -127,6 +127,23 @@ int DGN_compute_graphs(int num_graphs, int* nums_of_nodes, int* nums_of_edges,
                        float* MLP_layer_FC_layers_1_weight_in, float* MLP_layer_FC_layers_1_bias_in,
                        float* MLP_layer_FC_layers_2_weight_in, float* MLP_layer_FC_layers_2_bias_in);
 
+/*
+ * Replaces GAT_compute_graphs, GAT/src/dcl.h:78-94 (def. GAT/src/GAT_compute.cc:7-112).  No edge features; the
+ * node features are used as raw numbers (GAT/src/load_inputs.cc:190-191).
+ *   scoring_fn_target_in / scoring_fn_source_in [S][5][4][16]
+ *   linear_proj_weights_in / skip_proj_weights_in [S][5][4][16][4][16]  (layer, head_out, dim_out, head_in, dim_in);
+ *       layer 0 uses only [head_out][dim_out][0][dim_in < 9] (GAT/src/host_load.cc:69-78)
+ *   graph_pred_weights_in [S][1][16], graph_pred_bias_in [S][1]
+ * Per-graph node-feature offsets ARE applied (the reference omits them, GAT_compute.cc:72); set the environment
+ * variable FLOWGNN_GAT_REFERENCE_QUIRK=1 to reproduce the reference behaviour.
+ */
+int GAT_compute_graphs(int num_graphs, int* nums_of_nodes, int* nums_of_edges,
+                       int* reload_weights, float* out,
+                       int* node_feature_in, int* edge_list_in,
+                       float* scoring_fn_target_in, float* scoring_fn_source_in,
+                       float* linear_proj_weights_in, float* skip_proj_weights_in,
+                       float* graph_pred_weights_in, float* graph_pred_bias_in);
+
 /* =====================================================================
  * (2) Handle API
  * ===================================================================== */
@@ -151,7 +168,7 @@ int flowgnn_set_weights_gin(flowgnn_engine* e,
 
 /*
  * Generic form: `count` host tensors of ONE weight set, in the argument order of the model's
- * <M>_compute_graphs entry point (GIN 8, GCN 11, PNA 10, DGN 9 tensors).
+ * <M>_compute_graphs entry point (GIN 8, GCN 11, GAT 6, PNA 10, DGN 9 tensors).
  */
 int flowgnn_set_weights(flowgnn_engine* e, int count, const float* const* tensors);
 

@@ -103,6 +103,18 @@ int orc_DGN_compute_graphs(int num_graphs, const int* nums_of_nodes, const int* 
                            const float* MLP_layer_FC_layers_2_weight_in, const float* MLP_layer_FC_layers_2_bias_in,
                            float* h_dump, int nthreads);
 
+/*
+ * GAT forward, float semantics.  Mirrors GAT_compute_graphs, GAT/src/GAT_compute.cc:7-112 (argument order of
+ * GAT/src/dcl.h:78-94).  feature_offset_quirk != 0 reproduces GAT_compute.cc:72 (node features read without
+ * the per-graph offset).  dump (optional): [4][N_tot][64] = ELU outputs of layers 0..3, index dim*4 + head.
+ */
+int orc_GAT_compute_graphs(int num_graphs, const int* nums_of_nodes, const int* nums_of_edges,
+                           const int* reload_weights, float* out, const int* node_feature_in,
+                           const int* edge_list_in, const float* scoring_fn_target_in,
+                           const float* scoring_fn_source_in, const float* linear_proj_weights_in,
+                           const float* skip_proj_weights_in, const float* graph_pred_weights_in,
+                           const float* graph_pred_bias_in, int feature_offset_quirk, float* dump, int nthreads);
+
 #ifdef __cplusplus
 }
 #endif

@@ -37,6 +37,8 @@ def load():
         lib.orc_PNA_compute_graphs.restype = C.c_int
         lib.orc_DGN_compute_graphs.argtypes = [C.c_int, _pi, _pi, _pi, _pf, _pi, _pf, _pi] + [_pf] * 9 + [_pf, C.c_int]
         lib.orc_DGN_compute_graphs.restype = C.c_int
+        lib.orc_GAT_compute_graphs.argtypes = [C.c_int, _pi, _pi, _pi, _pf, _pi, _pi] + [_pf] * 6 + [C.c_int, _pf, C.c_int]
+        lib.orc_GAT_compute_graphs.restype = C.c_int
         _lib = lib
     return _lib
 
@@ -134,3 +136,26 @@ def dgn_forward(batch, weight_sets, reload_weights=None, dump_h=False, nthreads=
     """orc_DGN_compute_graphs; dump = h after encoder and each layer, [5][N][100]."""
     return _forward("orc_DGN_compute_graphs", batch, weight_sets, reload_weights,
                     (5, batch.total_nodes, 100) if dump_h else None, nthreads, with_attr=False, eig=True)
+
+
+def gat_forward(batch, weight_sets, reload_weights=None, dump_h=False, nthreads=1, feature_offset_quirk=False):
+    """orc_GAT_compute_graphs; dump = ELU outputs of layers 0..3, [4][N][64] (index dim*4 + head)."""
+    lib = load()
+    G = batch.num_graphs
+    if reload_weights is None:
+        reload_weights = np.zeros(G, np.int32)
+        if G:
+            reload_weights[0] = 1
+    keys = list(weight_sets[0].keys())
+    stacked = [_f(np.stack([np.asarray(ws[k], np.float32) for ws in weight_sets])) for k in keys]
+    out = np.zeros(G, np.float32)
+    nn, ne, rw = _i(batch.nums_of_nodes), _i(batch.nums_of_edges), _i(reload_weights)
+    nf, el = _i(batch.node_feature), _i(batch.edge_list)
+    hd = np.zeros((4, batch.total_nodes, 64), np.float32) if dump_h else None
+    rc = lib.orc_GAT_compute_graphs(G, nn.ctypes.data_as(_pi), ne.ctypes.data_as(_pi), rw.ctypes.data_as(_pi),
+                                    out.ctypes.data_as(_pf), nf.ctypes.data_as(_pi), el.ctypes.data_as(_pi),
+                                    *[a.ctypes.data_as(_pf) for a in stacked], 1 if feature_offset_quirk else 0,
+                                    None if hd is None else hd.ctypes.data_as(_pf), nthreads)
+    if rc:
+        raise RuntimeError(f"oracle GAT rc={rc}")
+    return (out, hd) if dump_h else out

@@ -138,3 +138,41 @@ def dgn_forward(batch, w, return_h=False):
     o2 = np.maximum(o1 @ f64(w["MLP_layer_FC_layers_1_weight"]).T + f64(w["MLP_layer_FC_layers_1_bias"]), 0.0)
     out = o2 @ f64(w["MLP_layer_FC_layers_2_weight"]).reshape(-1) + float(np.asarray(w["MLP_layer_FC_layers_2_bias"]).reshape(-1)[0])
     return (out, np.stack(hs)) if return_h else out
+
+
+def gat_forward(batch, w, return_h=False):
+    """GAT equations on the batched super-graph, float64, per-graph feature offsets applied.
+    Feature index f = dim * 4 + head."""
+    f64 = lambda a: np.asarray(a, dtype=np.float64)
+    tgt, srcw = f64(w["scoring_fn_target"]), f64(w["scoring_fn_source"])      # [5][4 head][16 dim]
+    lin, skip = f64(w["linear_proj_weights"]), f64(w["skip_proj_weights"])    # [5][ho][do][hi][di]
+    N = batch.total_nodes
+    ge = batch.global_edges()
+    u = np.concatenate([np.arange(N), ge[:, 0]])   # self edge for every node
+    v = np.concatenate([np.arange(N), ge[:, 1]])
+    mat = lambda t, l: t[l].transpose(1, 0, 3, 2).reshape(64, 64)   # [do, ho, di, hi] -> rows do*4+ho, cols di*4+hi
+    feat = batch.node_feature.astype(np.float64)
+    skipin = np.zeros((N, 16, 4)); skipin[:, :9, 0] = feat
+    skipin = skipin.reshape(N, 64)
+    proj = skipin @ mat(lin, 0).T
+    outs = []
+    for l in range(5):
+        p3 = proj.reshape(N, 16, 4)
+        ssrc = np.einsum("ndh,hd->nh", p3, srcw[l]); stgt = np.einsum("ndh,hd->nh", p3, tgt[l])
+        s = ssrc[v] + stgt[u]
+        e = np.exp(np.where(s < 0, 0.2 * s, s))
+        den = np.zeros((N, 4)); np.add.at(den, v, e)
+        num = np.zeros((N, 16, 4)); np.add.at(num, v, e[:, None, :] * p3[u])
+        msg = (num / den[:, None, :]).reshape(N, 64)
+        o = msg + skipin @ mat(skip, l).T
+        if l == 4:
+            emb = o.reshape(N, 16, 4).mean(axis=2)
+            break
+        o = np.where(o <= 0, np.exp(o) - 1.0, o)
+        outs.append(o)
+        skipin = o
+        proj = o @ mat(lin, l + 1).T
+    off = batch.node_offsets()
+    hg = np.add.reduceat(emb, off[:-1], axis=0) / batch.nums_of_nodes[:, None]
+    out = hg @ f64(w["graph_pred_weights"]).reshape(-1) + float(np.asarray(w["graph_pred_bias"]).reshape(-1)[0])
+    return (out, np.stack(outs)) if return_h else out

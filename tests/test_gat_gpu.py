@@ -1,0 +1,85 @@
+"""GPU parity tests for GAT (BASELINE config 4): fused attention-gather + projection kernel vs the CPU oracle.
+Tolerance: 2e-4 relative to the activation scale (exp() of un-normalised scores on both sides)."""
+import os
+
+import numpy as np
+import pytest
+
+from flowgnn_amd import Engine, compute_graphs, graphpack as gp, weights
+from tests.test_oracle_gcn import directed_variant
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden", "gat_molhiv48.npz")
+
+
+def close(a, b, scale=1.0):
+    return np.allclose(a, b, rtol=2e-4, atol=2e-4 * max(1.0, scale))
+
+
+@pytest.fixture(scope="module")
+def w():
+    return weights.synth_gat_weights(seed=7)
+
+
+@pytest.fixture(scope="module")
+def eng(w):
+    e = Engine("GAT", device=0)
+    e.set_weights(w)
+    yield e
+    e.close()
+
+
+def test_forward_matches_oracle(eng, oracle, w):
+    for b in (gp.synth_molhiv_batch(200, seed=31), directed_variant(gp.synth_molhiv_batch(40, seed=12)),
+              gp.synth_hep10k_batch(12, seed=4, with_eigen=False)):
+        got = eng.forward(b)
+        want, hd = oracle.gat_forward(b, [w], dump_h=True, nthreads=8)
+        scale = float(np.abs(hd).max())
+        assert np.isfinite(got).all()
+        assert close(eng.final_h(), hd[3], scale), np.abs(eng.final_h() - hd[3]).max()
+        assert close(got, want, scale), np.abs(got - want).max()
+
+
+def test_golden_vectors(eng):
+    z = np.load(GOLDEN)
+    b = gp.GraphBatch(z["nums_of_nodes"], z["nums_of_edges"], z["node_feature"], z["edge_list"], z["edge_attr"])
+    assert close(eng.forward(b), z["logits_synth_weights"], 10.0)
+
+
+def test_reference_feature_quirk(oracle, w, monkeypatch):
+    b = gp.synth_molhiv_batch(12, seed=3)
+    monkeypatch.setenv("FLOWGNN_GAT_REFERENCE_QUIRK", "1")
+    e = Engine("GAT", device=0)
+    e.set_weights(w)
+    assert close(e.forward(b), oracle.gat_forward(b, [w], feature_offset_quirk=True), 10.0)
+    e.close()
+
+
+def test_entry_point_bin_loader_and_edge_cases(tmp_path, oracle, w):
+    b = gp.synth_molhiv_batch(9, seed=5)
+    w2 = weights.synth_gat_weights(seed=8)
+    rw = np.array([1, 0, 0, 0, 1, 0, 0, 0, 0], np.int32)
+    assert close(compute_graphs("GAT", b, [w, w2], rw), oracle.gat_forward(b, [w, w2], reload_weights=rw), 10.0)
+    weights.save_gat_weights(w2, str(tmp_path))
+    e = Engine("GAT", device=0)
+    e.load_weights_dir(str(tmp_path))
+    assert close(e.forward(b), oracle.gat_forward(b, [w2]), 10.0)
+    nn = np.array([1, 2, 17], np.int32)
+    ne = np.array([0, 1, 0], np.int32)
+    nf = np.zeros((20, 9), np.int32)
+    nf[:, 0] = np.arange(20) % 7
+    tiny = gp.GraphBatch(nn, ne, nf, np.array([[1, 0]], np.int32), np.zeros((1, 3), np.int32))
+    assert close(e.forward(tiny), oracle.gat_forward(tiny, [w2]), 10.0)
+    e.close()
+
+
+def test_full_molhiv_size_properties(eng, oracle, w):
+    """BASELINE config 4 size (4 113 graphs)."""
+    b = gp.synth_molhiv_batch(4113, seed=1234)
+    out = eng.forward(b)
+    assert out.shape == (4113,) and np.isfinite(out).all()
+    assert np.array_equal(out, eng.forward(b))
+    assert np.array_equal(eng.forward(b.slice(1000, 1500)), out[1000:1500])
+    idx = np.random.default_rng(0).choice(4113, 128, replace=False)
+    sample = gp.concat_batches([b.slice(int(g), int(g) + 1) for g in idx])
+    assert close(out[idx], oracle.gat_forward(sample, [w], nthreads=8), 10.0)
