@@ -1,0 +1,47 @@
+"""The C++ host binary (counterpart of the reference's <M>/src/host.cc) on packs in the reference's on-disk
+layout: HLS_output.txt must agree with the oracle for every model, including GIN-VN's host-side virtual node."""
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from flowgnn_amd import graphpack as gp, weights
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HOST = os.path.join(ROOT, "flowgnn_amd", "host")
+
+
+def run_host(model, tmp_path, batch, w):
+    gdir, wdir, out = tmp_path / "graphs", tmp_path / "weights", tmp_path / "HLS_output.txt"
+    gp.write_pack(batch, str(gdir), eig_dir=str(tmp_path / "eig"))
+    weights.SAVERS[model](w, str(wdir))
+    cmd = [HOST, model, "--graphs", str(gdir), "--weights", str(wdir), "--eig", str(tmp_path / "eig"), "--trials", "2",
+           "--out", str(out), "ignored.xclbin"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "ms per graph" in r.stdout
+    lines = open(out).read().strip().splitlines()
+    assert all(re.fullmatch(r"g\d+: -?\d+\.\d{8}", ln) for ln in lines), lines[:3]
+    assert [int(ln.split(":")[0][1:]) for ln in lines] == list(range(1, batch.num_graphs + 1))
+    return np.array([float(ln.split(":")[1]) for ln in lines], dtype=np.float32)
+
+
+@pytest.mark.parametrize("model", ["GIN", "GIN-VN", "GCN", "GAT", "PNA", "DGN"])
+def test_host_matches_oracle(model, tmp_path, oracle):
+    w = weights.SYNTH[model](seed=7)
+    batch = gp.synth_hep10k_batch(5, seed=3) if model in ("PNA", "DGN") else gp.synth_molhiv_batch(12, seed=3)
+    got = run_host(model, tmp_path, batch, w)
+    if model == "GIN-VN":
+        want = oracle.gin_forward(gp.add_virtual_nodes(batch), [w])
+    else:
+        want = getattr(oracle, model.lower() + "_forward")(batch, [w])
+    assert np.allclose(got, want, rtol=3e-4, atol=3e-4 * max(1.0, np.abs(want).max())), np.abs(got - want).max()
+
+
+def test_host_reports_missing_inputs(tmp_path):
+    r = subprocess.run([HOST, "GIN", "--graphs", str(tmp_path), "--weights", str(tmp_path), "--num-graphs", "1"],
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "loading weights failed" in r.stderr
