@@ -28,32 +28,75 @@ FP32_MFMA_PEAK_TF = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 / 32x3
 FPGA_U50_GRAPHS_PER_S = 20214.0  # GIN molhiv on Alveo U50 (other hardware; informational)
 
 
-def algorithmic(n_tot: int, e_tot: int):
-    """Per-launch algorithmic work of the two per-layer kernels (DESIGN.md 'Kernels'):
-    aggregation bytes = N*D*4 (read h once) + N*D*4 (write) + E*(8 index + 12 attrs)   [SURVEY 8d]
-    node-MLP flops    = N * 2*(100*200 + 200*100)                                        [SURVEY 8d]"""
-    agg_bytes = n_tot * 100 * 4 * 2 + e_tot * 20
-    mlp_flops = n_tot * 2 * (100 * 200 + 200 * 100)
-    return agg_bytes, mlp_flops
+# Per-model bench table.  Algorithmic work per launch of the two kernel classes (DESIGN.md "Kernels"):
+#   aggregation bytes (unpadded): read h once + write the aggregates + edge index (8 B) + edge payload
+#   transform flops: 2 x MACs of the dense update per node per layer
+MODELS = {
+    "GIN": dict(metric="graphs/sec on ogbg-molhiv (GIN, dim=100)", dataset="molhiv", graphs=1 << 18,
+                agg_bytes=lambda n, e: n * 400 * 2 + e * 20, flops=lambda n, e: n * 80000,
+                hbm_kernels=("gin_aggregate",), mfma_kernels=("gin_layer_fused", "gin_mlp"),
+                workload="GIN dim=100, batched ogbg-molhiv-shaped graphs on MI355X (BASELINE configs[1])"),
+    "GIN-VN": dict(metric="graphs/sec on ogbg-molhiv (GIN-VN, dim=100)", dataset="molhiv-vn", graphs=1 << 18,
+                   agg_bytes=lambda n, e: n * 400 * 2 + e * 20, flops=lambda n, e: n * 80000,
+                   hbm_kernels=("gin_aggregate",), mfma_kernels=("gin_layer_fused", "gin_mlp"),
+                   workload="GIN-VN dim=100 (virtual node per graph), ogbg-molhiv-shaped graphs"),
+    "GCN": dict(metric="graphs/sec on ogbg-molpcba (GCN, dim=100)", dataset="molpcba", graphs=1 << 18,
+                agg_bytes=lambda n, e: n * 400 * 2 + e * 24, flops=lambda n, e: n * 20000,
+                hbm_kernels=("gcn_aggregate",), mfma_kernels=("gcn_dense",),
+                workload="GCN dim=100, batched ogbg-molpcba-shaped graphs on MI355X (BASELINE configs[2])"),
+    "GAT": dict(metric="graphs/sec on ogbg-molhiv (GAT, 4 heads x 16)", dataset="molhiv", graphs=1 << 18,
+                agg_bytes=lambda n, e: n * (256 + 32) + n * 256 + (e + n) * 8, flops=lambda n, e: n * 16384,
+                hbm_kernels=("gat_layer",), mfma_kernels=(),
+                workload="GAT 5-layer, 4 heads x 16, ogbg-molhiv-shaped graphs on MI355X (BASELINE configs[3])"),
+    "PNA": dict(metric="graphs/sec on hep10k (PNA, dim=80)", dataset="hep10k", graphs=1 << 15,
+                agg_bytes=lambda n, e: n * 320 + n * 320 * 4 + e * 8, flops=lambda n, e: n * 153600,
+                hbm_kernels=("pna_aggregate",), mfma_kernels=("pna_dense",),
+                workload="PNA dim=80, hep10k-shaped kNN graphs on MI355X (BASELINE configs[4])"),
+    "DGN": dict(metric="graphs/sec on hep10k (DGN, dim=100)", dataset="hep10k", graphs=1 << 15,
+                agg_bytes=lambda n, e: n * 400 * 3 + e * 12, flops=lambda n, e: n * 40000,
+                hbm_kernels=("dgn_aggregate",), mfma_kernels=("dgn_dense",),
+                workload="DGN dim=100, hep10k-shaped kNN graphs on MI355X (BASELINE configs[4])"),
+}
 
 
-def cpu_baseline(batch, w, budget_s: float = 15.0):
+def make_batch(dataset: str, graphs: int, seed: int):
+    from flowgnn_amd import graphpack as gp
+    if dataset == "molhiv":
+        return gp.synth_molhiv_batch(graphs, seed=seed)
+    if dataset == "molhiv-vn":
+        return gp.add_virtual_nodes(gp.synth_molhiv_batch(graphs, seed=seed))
+    if dataset == "molpcba":
+        return gp.synth_molpcba_batch(graphs, seed=seed)
+    if dataset == "hep10k":
+        return gp.synth_hep10k_batch(graphs, seed=seed)
+    raise ValueError(dataset)
+
+
+def oracle_forward(model: str, batch, w, nthreads: int):
+    from oracle import oracle
+    fn = {"GIN": oracle.gin_forward, "GIN-VN": oracle.gin_forward, "GCN": oracle.gcn_forward, "GAT": oracle.gat_forward,
+          "PNA": oracle.pna_forward, "DGN": oracle.dgn_forward}[model]
+    return fn(batch, [w], nthreads=nthreads)
+
+
+def cpu_baseline(model, batch, w, budget_s: float = 15.0):
     """The oracle (CPU restatement of the reference, kind='port') timed on this host's cores on a
     bounded sample of the same workload."""
-    from oracle import oracle
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    probe = batch.slice(0, min(256, batch.num_graphs))
+    probe = batch.slice(0, min(128, batch.num_graphs))
     t0 = time.perf_counter()
-    oracle.gin_forward(probe, [w], nthreads=1)
+    oracle_forward(model, probe, w, 1)
     t1 = time.perf_counter()
     rate1 = probe.num_graphs / (t1 - t0)
-    n = int(min(batch.num_graphs, max(256, rate1 * cores * budget_s * 0.6)))
+    # OpenMP over graphs scales sub-linearly on a big host; size the sample for ~budget_s at ~1/8 efficiency
+    n = int(min(batch.num_graphs, max(256, rate1 * cores * budget_s / 8)))
     sample = batch.slice(0, n)
     t0 = time.perf_counter()
-    oracle.gin_forward(sample, [w], nthreads=cores)
+    oracle_forward(model, sample, w, cores)
     t1 = time.perf_counter()
     return {"value": n / (t1 - t0), "unit": "graphs/s", "cores": cores, "kind": "port",
-            "sample": f"first {n} graphs of the bench batch, oracle/gin_oracle.c, OpenMP over graphs, {cores} threads",
+            "sample": f"first {n} graphs of the bench batch, oracle/{model.lower().replace('-vn', '')}_oracle.c, "
+                      f"OpenMP over graphs, {cores} threads",
             "single_core_value": rate1}
 
 
@@ -62,7 +105,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--graphs", type=int, default=1 << 18, help="graphs per GPU per step")
+    ap.add_argument("--model", default="GIN", choices=sorted(MODELS))
+    ap.add_argument("--graphs", type=int, default=0, help="graphs per GPU per step (default: the model's roofline batch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -81,11 +125,13 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
-    from flowgnn_amd import Engine, graphpack as gp, weights
+    from flowgnn_amd import Engine, weights
 
-    batch = gp.synth_molhiv_batch(args.graphs, seed=1234 + rank)  # each rank its own shard of the job
-    w = weights.synth_gin_weights(seed=7)
-    eng = Engine("GIN", device=local_rank)
+    M = MODELS[args.model]
+    graphs = args.graphs or M["graphs"]
+    batch = make_batch(M["dataset"], graphs, seed=1234 + rank)  # each rank its own shard of the job
+    w = weights.SYNTH[args.model](seed=7)
+    eng = Engine(args.model, device=local_rank)
     eng.set_weights(w)
     eng.set_batch(batch)
     G, N, E = batch.num_graphs, batch.total_nodes, batch.total_edges
@@ -128,41 +174,44 @@ def main():
     if rank == 0:
         total_graphs = G * world * args.steps  # every rank carries the same number of graphs
         value = total_graphs / elapsed
-        agg_bytes, mlp_flops = algorithmic(N, E)
+        agg_bytes, mlp_flops = M["agg_bytes"](N, E), M["flops"](N, E)
         kern = {k: (v["total_ms"] / max(v["launches"], 1)) for k, v in prof.items()}
-        dominant = max(prof.items(), key=lambda kv: kv[1]["total_ms"])[0] if prof else None
-        if "gin_aggregate" not in kern:  # fused layer: measure the message-passing unit alone as well
-            kern["gin_aggregate"] = eng.aggregation_only_ms(layer=0, iters=10)
+        layer = {k: v for k, v in prof.items() if k in M["hbm_kernels"] + M["mfma_kernels"]}
+        dominant = max(layer.items(), key=lambda kv: kv[1]["total_ms"])[0] if layer else None
+        agg_name = M["hbm_kernels"][0]
+        if agg_name not in kern:  # fused layer: measure the message-passing unit alone as well
+            kern[agg_name] = eng.aggregation_only_ms(layer=0, iters=10)
+
+        def hbm_obj(name):
+            ach = agg_bytes / (kern[name] * 1e-3) / 1e9
+            return {"kernel": name, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": ach / HBM_PEAK_GBS, "traffic": None, "avg_ms": kern[name], "bytes_per_launch": agg_bytes}
+
         roof = None
-        if dominant == "gin_aggregate":
-            ach = agg_bytes / (kern[dominant] * 1e-3) / 1e9
-            roof = {"kernel": dominant, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": ach / HBM_PEAK_GBS, "traffic": None}
-        elif dominant is not None and dominant in kern and dominant.startswith("gin_"):
+        if dominant in M["hbm_kernels"]:
+            roof = hbm_obj(dominant)
+        elif dominant is not None:
             ach = mlp_flops / (kern[dominant] * 1e-3) / 1e12
             roof = {"kernel": dominant, "bound": "mfma", "achieved": ach, "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s",
-                    "frac": ach / FP32_MFMA_PEAK_TF, "traffic": None}
-        agg = None
-        if "gin_aggregate" in kern:
-            ach = agg_bytes / (kern["gin_aggregate"] * 1e-3) / 1e9
-            agg = {"kernel": "gin_aggregate", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                   "frac": ach / HBM_PEAK_GBS, "avg_ms": kern["gin_aggregate"], "bytes_per_launch": agg_bytes}
+                    "frac": ach / FP32_MFMA_PEAK_TF, "traffic": None, "avg_ms": kern[dominant],
+                    "flops_per_launch": mlp_flops}
+        agg = hbm_obj(agg_name)
         line = {
-            "metric": "graphs/sec on ogbg-molhiv (GIN, dim=100)",
+            "metric": M["metric"],
             "value": value, "unit": "graphs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "GIN dim=100, batched ogbg-molhiv-shaped graphs on MI355X (BASELINE configs[1])",
+            "config": {"workload": M["workload"],
                        "graphs_per_gpu_per_step": G, "nodes_per_gpu": N, "edges_per_gpu": E,
                        "parallelism": f"batch-sharded x{world}, RCCL all-gather of logits"},
             "finite": ok,
             "roofline": roof,
             "aggregation_roofline": agg,
             "kernel_avg_ms": kern,
-            "vs_fpga_u50": value / FPGA_U50_GRAPHS_PER_S,
+            "vs_fpga_u50": (value / FPGA_U50_GRAPHS_PER_S) if args.model == "GIN" else None,
         }
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(batch, w)
+            line["cpu_baseline"] = cpu_baseline(args.model, batch, w)
             line["gpu_over_cpu"] = value / line["cpu_baseline"]["value"]
         print(json.dumps(line), flush=True)
     eng.close()
