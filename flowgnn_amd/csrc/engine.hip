@@ -247,9 +247,10 @@ static int alloc_batch(flowgnn_engine* e, size_t G, size_t N, size_t E, bool att
         FG_HIP_TRY(hipMalloc((void**)&e->d_cursor, sizeof(int) * n1));
         FG_HIP_TRY(hipMalloc((void**)&e->d_tmp, sizeof(int) * e1 * 2));
         FG_HIP_TRY(hipMalloc((void**)&e->d_bsums, sizeof(int) * (n1 / 2048 + 2)));
-        FG_HIP_TRY(hipMalloc((void**)&e->d_h0, sizeof(float) * n1 * D));
-        FG_HIP_TRY(hipMalloc((void**)&e->d_h1, sizeof(float) * n1 * D));
-        FG_HIP_TRY(hipMalloc((void**)&e->d_scratch, sizeof(float) * n1 * (SD > 0 ? SD : 1)));
+        // + 4 KiB slack: tile loaders read whole 1 KiB pieces and may run past the last row
+        FG_HIP_TRY(hipMalloc((void**)&e->d_h0, sizeof(float) * n1 * D + 4096));
+        FG_HIP_TRY(hipMalloc((void**)&e->d_h1, sizeof(float) * n1 * D + 4096));
+        FG_HIP_TRY(hipMalloc((void**)&e->d_scratch, sizeof(float) * n1 * (SD > 0 ? SD : 1) + 4096));
         FG_HIP_TRY(hipMalloc((void**)&e->d_out, sizeof(float) * g1));
         e->capG = G; e->capN = N; e->capE = E;
     }
