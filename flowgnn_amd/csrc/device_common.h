@@ -11,7 +11,8 @@ static __constant__ int c_nd_card[ND_FEATURE] = {119, 4, 12, 12, 10, 6, 6, 2, 2}
 
 typedef float float4_t __attribute__((ext_vector_type(4)));
 
-__device__ inline float relu1(float x) { return x < 0.0f ? 0.0f : x; }
+// one v_max_f32 (the compare + select form costs three issue slots); differs from `x < 0 ? 0 : x` only for NaN
+__device__ inline float relu1(float x) { return __builtin_fmaxf(x, 0.0f); }
 
 // ---------------------------------------------------------------- atom encoder
 // One lane per (node, float4 chunk); fully coalesced 1 KiB stores per wave.

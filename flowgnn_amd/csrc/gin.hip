@@ -109,8 +109,7 @@ __global__ __launch_bounds__(256) void gin_aggregate_tiled_kernel(const float* _
     __shared__ __attribute__((aligned(16))) float4 s_ecomb[EDGE_COMBOS * C];
     __shared__ __attribute__((aligned(16))) float4 s_h[GIN_TR * C];
     __shared__ int s_rp[GIN_TR + 1];
-    __shared__ int s_src[GIN_TE];
-    __shared__ uint8_t s_code[GIN_TE];
+    __shared__ unsigned s_edge[GIN_TE];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int i = threadIdx.x; i < EDGE_COMBOS * C; i += 256) s_ecomb[i] = reinterpret_cast<const float4*>(ecomb)[i];
     const float4* h4 = reinterpret_cast<const float4*>(h);
@@ -128,12 +127,12 @@ __global__ __launch_bounds__(256) void gin_aggregate_tiled_kernel(const float* _
         if (threadIdx.x <= rows) s_rp[threadIdx.x] = row_ptr[t0 + threadIdx.x];
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        // stage 2: the tile's CSR entries
+        // stage 2: the tile's CSR entries, one packed word each: (row inside the tile, or 0xFFFFFF) << 8 | combo code
         const int e0 = s_rp[0];
         const int ne = s_rp[rows] - e0;
         for (int i = threadIdx.x; i < ne && i < GIN_TE; i += 256) {
-            s_src[i] = src[e0 + i];
-            s_code[i] = ecode[e0 + i];
+            const unsigned ul = (unsigned)(src[e0 + i] - t0);
+            s_edge[i] = ((ul < (unsigned)GIN_TR ? ul : 0xFFFFFFu) << 8) | ecode[e0 + i];
         }
         __syncthreads();
         // stage 3: ordered sums
@@ -146,19 +145,17 @@ __global__ __launch_bounds__(256) void gin_aggregate_tiled_kernel(const float* _
                 // LDS reads are unconditional (clamped index) and pinned with an empty asm; global memory is touched
                 // only in the rare fall-back branches.  A `cond ? lds : global` select makes hipcc emit flat loads
                 // with a full s_waitcnt after each one.
-                const int el = e < GIN_TE ? e : GIN_TE - 1;
-                int u = s_src[el];
-                int k = s_code[el];
-                asm volatile("" : "+v"(u), "+v"(k));
+                unsigned pk = s_edge[e < GIN_TE ? e : GIN_TE - 1];
+                asm volatile("" : "+v"(pk));
                 if (e >= GIN_TE) {
-                    u = src[e0 + e];
-                    k = ecode[e0 + e];
+                    const unsigned ul = (unsigned)(src[e0 + e] - t0);
+                    pk = ((ul < (unsigned)GIN_TR ? ul : 0xFFFFFFu) << 8) | ecode[e0 + e];
                 }
-                const unsigned ul = (unsigned)(u - t0);
-                const float4 w = s_ecomb[k * C + c];
+                const unsigned ul = pk >> 8;
+                const float4 w = s_ecomb[(pk & 0xFFu) * C + c];
                 float4 x = s_h[(ul < (unsigned)GIN_TR ? ul : 0u) * C + c];
                 asm volatile("" : "+v"(x.x), "+v"(x.y), "+v"(x.z), "+v"(x.w));
-                if (ul >= (unsigned)GIN_TR) x = h4[(size_t)u * C + c];
+                if (ul >= (unsigned)GIN_TR) x = h4[(size_t)src[e0 + e] * C + c];
                 acc.x += relu1(w.x + x.x); acc.y += relu1(w.y + x.y); acc.z += relu1(w.z + x.z); acc.w += relu1(w.w + x.w);
             }
             if (ADD_SELF) {
