@@ -135,34 +135,64 @@ __global__ __launch_bounds__(256) void gin_aggregate_tiled_kernel(const float* _
             s_edge[i] = ((ul < (unsigned)GIN_TR ? ul : 0xFFFFFFu) << 8) | ecode[e0 + i];
         }
         __syncthreads();
-        // stage 3: ordered sums
-        for (int idx = threadIdx.x; idx < rows * C; idx += 256) {
-            const int r = idx / C;
-            const int c = idx - r * C;
-            const int beg = s_rp[r] - e0, end = s_rp[r + 1] - e0;
-            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-            for (int e = beg; e < end; e++) {
-                // LDS reads are unconditional (clamped index) and pinned with an empty asm; global memory is touched
-                // only in the rare fall-back branches.  A `cond ? lds : global` select makes hipcc emit flat loads
-                // with a full s_waitcnt after each one.
-                unsigned pk = s_edge[e < GIN_TE ? e : GIN_TE - 1];
-                asm volatile("" : "+v"(pk));
-                if (e >= GIN_TE) {
-                    const unsigned ul = (unsigned)(src[e0 + e] - t0);
-                    pk = ((ul < (unsigned)GIN_TR ? ul : 0xFFFFFFu) << 8) | ecode[e0 + e];
+        // stage 3: ordered sums.  The common case (all CSR entries of the tile staged) runs a loop with no clamps
+        // and no fall-back branches; LDS byte offsets are carried incrementally (256 = 10 * 25 + 6).
+        const char* sh_b = reinterpret_cast<const char*>(s_h);
+        const char* se_b = reinterpret_cast<const char*>(s_ecomb);
+        int r = threadIdx.x / C, c = threadIdx.x - r * C;
+        if (ne <= GIN_TE) {
+            for (int idx = threadIdx.x; idx < rows * C; idx += 256) {
+                const int beg = s_rp[r] - e0, end = s_rp[r + 1] - e0;
+                float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+                for (int e = beg; e < end; e++) {
+                    unsigned pk = s_edge[e];
+                    asm volatile("" : "+v"(pk));  // keep it a ds_read (see below)
+                    const unsigned ul = pk >> 8;
+                    const float4 w = *reinterpret_cast<const float4*>(se_b + (pk & 0xFFu) * (D * 4) + c * 16);
+                    float4 x = *reinterpret_cast<const float4*>(sh_b + (ul < (unsigned)GIN_TR ? ul : 0u) * (D * 4) + c * 16);
+                    asm volatile("" : "+v"(x.x), "+v"(x.y), "+v"(x.z), "+v"(x.w));
+                    if (ul >= (unsigned)GIN_TR) x = h4[(size_t)src[e0 + e] * C + c];
+                    acc.x += relu1(w.x + x.x); acc.y += relu1(w.y + x.y); acc.z += relu1(w.z + x.z); acc.w += relu1(w.w + x.w);
                 }
-                const unsigned ul = pk >> 8;
-                const float4 w = s_ecomb[(pk & 0xFFu) * C + c];
-                float4 x = s_h[(ul < (unsigned)GIN_TR ? ul : 0u) * C + c];
-                asm volatile("" : "+v"(x.x), "+v"(x.y), "+v"(x.z), "+v"(x.w));
-                if (ul >= (unsigned)GIN_TR) x = h4[(size_t)src[e0 + e] * C + c];
-                acc.x += relu1(w.x + x.x); acc.y += relu1(w.y + x.y); acc.z += relu1(w.z + x.z); acc.w += relu1(w.w + x.w);
+                if (ADD_SELF) {
+                    const float4 self = s_h[idx];
+                    acc.x += self.x; acc.y += self.y; acc.z += self.z; acc.w += self.w;
+                }
+                reinterpret_cast<float4*>(a)[(size_t)t0 * C + idx] = acc;
+                c += 256 % C;
+                r += 256 / C;
+                if (c >= C) { c -= C; r++; }
             }
-            if (ADD_SELF) {
-                const float4 self = s_h[idx];
-                acc.x += self.x; acc.y += self.y; acc.z += self.z; acc.w += self.w;
+        } else {
+            // dense tiles (kNN graphs, hub nodes): entries beyond the staged ones come from global memory.
+            // LDS reads stay unconditional (clamped) and pinned with an empty asm, global memory is touched only in
+            // branches: a `cond ? lds : global` select makes hipcc emit flat loads with a full wait after each.
+            for (int idx = threadIdx.x; idx < rows * C; idx += 256) {
+                const int beg = s_rp[r] - e0, end = s_rp[r + 1] - e0;
+                float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+                for (int e = beg; e < end; e++) {
+                    unsigned pk = s_edge[e < GIN_TE ? e : GIN_TE - 1];
+                    asm volatile("" : "+v"(pk));
+                    if (e >= GIN_TE) {
+                        const unsigned ul2 = (unsigned)(src[e0 + e] - t0);
+                        pk = ((ul2 < (unsigned)GIN_TR ? ul2 : 0xFFFFFFu) << 8) | ecode[e0 + e];
+                    }
+                    const unsigned ul = pk >> 8;
+                    const float4 w = *reinterpret_cast<const float4*>(se_b + (pk & 0xFFu) * (D * 4) + c * 16);
+                    float4 x = *reinterpret_cast<const float4*>(sh_b + (ul < (unsigned)GIN_TR ? ul : 0u) * (D * 4) + c * 16);
+                    asm volatile("" : "+v"(x.x), "+v"(x.y), "+v"(x.z), "+v"(x.w));
+                    if (ul >= (unsigned)GIN_TR) x = h4[(size_t)src[e0 + e] * C + c];
+                    acc.x += relu1(w.x + x.x); acc.y += relu1(w.y + x.y); acc.z += relu1(w.z + x.z); acc.w += relu1(w.w + x.w);
+                }
+                if (ADD_SELF) {
+                    const float4 self = s_h[idx];
+                    acc.x += self.x; acc.y += self.y; acc.z += self.z; acc.w += self.w;
+                }
+                reinterpret_cast<float4*>(a)[(size_t)t0 * C + idx] = acc;
+                c += 256 % C;
+                r += 256 / C;
+                if (c >= C) { c -= C; r++; }
             }
-            reinterpret_cast<float4*>(a)[(size_t)t0 * C + idx] = acc;
         }
     }
 }
