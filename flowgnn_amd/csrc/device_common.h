@@ -11,6 +11,20 @@ static __constant__ int c_nd_card[ND_FEATURE] = {119, 4, 12, 12, 10, 6, 6, 2, 2}
 
 typedef float float4_t __attribute__((ext_vector_type(4)));
 
+// A global load that hipcc's wait-count tracking does not see: issued and waited for inside one asm statement.
+// For RARE fall-back paths inside hot loops -- an ordinary load in a branch makes the compiler put an unconditional
+// `s_waitcnt vmcnt(0)` at the merge point, which then waits for every outstanding store and prefetch on every trip.
+__device__ inline float4 load_f4_rare(const float4* p) {
+    float4_t v;
+    asm volatile("global_load_dwordx4 %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ inline int load_i32_rare(const int* p) {
+    int v;
+    asm volatile("global_load_dword %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+
 // one v_max_f32 (the compare + select form costs three issue slots); differs from `x < 0 ? 0 : x` only for NaN
 __device__ inline float relu1(float x) { return __builtin_fmaxf(x, 0.0f); }
 

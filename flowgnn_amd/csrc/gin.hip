@@ -151,7 +151,7 @@ __global__ __launch_bounds__(256) void gin_aggregate_tiled_kernel(const float* _
                     const float4 w = *reinterpret_cast<const float4*>(se_b + (pk & 0xFFu) * (D * 4) + c * 16);
                     float4 x = *reinterpret_cast<const float4*>(sh_b + (ul < (unsigned)GIN_TR ? ul : 0u) * (D * 4) + c * 16);
                     asm volatile("" : "+v"(x.x), "+v"(x.y), "+v"(x.z), "+v"(x.w));
-                    if (ul >= (unsigned)GIN_TR) x = h4[(size_t)src[e0 + e] * C + c];
+                    if (ul >= (unsigned)GIN_TR) x = load_f4_rare(h4 + (size_t)load_i32_rare(src + e0 + e) * C + c);
                     acc.x += relu1(w.x + x.x); acc.y += relu1(w.y + x.y); acc.z += relu1(w.z + x.z); acc.w += relu1(w.w + x.w);
                 }
                 if (ADD_SELF) {
@@ -181,7 +181,7 @@ __global__ __launch_bounds__(256) void gin_aggregate_tiled_kernel(const float* _
                     const float4 w = *reinterpret_cast<const float4*>(se_b + (pk & 0xFFu) * (D * 4) + c * 16);
                     float4 x = *reinterpret_cast<const float4*>(sh_b + (ul < (unsigned)GIN_TR ? ul : 0u) * (D * 4) + c * 16);
                     asm volatile("" : "+v"(x.x), "+v"(x.y), "+v"(x.z), "+v"(x.w));
-                    if (ul >= (unsigned)GIN_TR) x = h4[(size_t)src[e0 + e] * C + c];
+                    if (ul >= (unsigned)GIN_TR) x = load_f4_rare(h4 + (size_t)load_i32_rare(src + e0 + e) * C + c);
                     acc.x += relu1(w.x + x.x); acc.y += relu1(w.y + x.y); acc.z += relu1(w.z + x.z); acc.w += relu1(w.w + x.w);
                 }
                 if (ADD_SELF) {
@@ -195,6 +195,169 @@ __global__ __launch_bounds__(256) void gin_aggregate_tiled_kernel(const float* _
             }
         }
     }
+}
+
+// ---------------------------------------------------------------- tiled aggregation, double buffered
+// gin_aggregate_tiled_kernel leaves its waves waiting 76 % of the time (PMC: SQ_WAIT_ANY / SQ_WAVE_CYCLES): each
+// tile pays two global round trips (rows + row_ptr, then CSR entries) before it can compute, and 52 KB of LDS caps
+// the CU at three workgroups.  Here a workgroup prefetches tile i+1 completely while it computes tile i:
+//   top of step i : DMA h(i+1) -> the other row buffer; CSR entries of tile i+1 -> registers; row_ptr(i+2) -> register
+//   compute tile i (LDS only, plus rare out-of-tile gathers)
+//   end of step i : registers -> LDS rings, s_waitcnt vmcnt(0), one barrier
+// The two row buffers are distinct __shared__ objects (so the DMA provably does not alias the compute's ds_reads);
+// row_ptr slices live in a 3-deep ring and edge words in a 2-deep ring addressed at run time.
+template <int D, bool ADD_SELF>
+__device__ __forceinline__ void gin_agg_compute_tile(const float4* __restrict__ s_hc, const float4* __restrict__ s_ecomb,
+                                                     const int* __restrict__ rp, const unsigned* __restrict__ edge,
+                                                     const float* __restrict__ h, float* __restrict__ a,
+                                                     const int* __restrict__ src, const uint8_t* __restrict__ ecode,
+                                                     int t0, int rows) {
+    constexpr int C = D / 4;
+    const float4* h4 = reinterpret_cast<const float4*>(h);
+    const char* sh_b = reinterpret_cast<const char*>(s_hc);
+    const char* se_b = reinterpret_cast<const char*>(s_ecomb);
+    const int e0 = rp[0];
+    const int ne = rp[rows] - e0;
+    int r = threadIdx.x / C, c = threadIdx.x - r * C;
+    for (int idx = threadIdx.x; idx < rows * C; idx += 256) {
+        const int beg = rp[r] - e0, end = rp[r + 1] - e0;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ne <= GIN_TE) {
+            for (int e = beg; e < end; e++) {
+                unsigned pk = edge[e];
+                asm volatile("" : "+v"(pk));
+                const unsigned ul = pk >> 8;
+                const float4 w = *reinterpret_cast<const float4*>(se_b + (pk & 0xFFu) * (D * 4) + c * 16);
+                float4 x = *reinterpret_cast<const float4*>(sh_b + (ul < (unsigned)GIN_TR ? ul : 0u) * (D * 4) + c * 16);
+                asm volatile("" : "+v"(x.x), "+v"(x.y), "+v"(x.z), "+v"(x.w));
+                if (ul >= (unsigned)GIN_TR) x = load_f4_rare(h4 + (size_t)load_i32_rare(src + e0 + e) * C + c);
+                acc.x += relu1(w.x + x.x); acc.y += relu1(w.y + x.y); acc.z += relu1(w.z + x.z); acc.w += relu1(w.w + x.w);
+            }
+        } else {
+            for (int e = beg; e < end; e++) {
+                unsigned pk = edge[e < GIN_TE ? e : GIN_TE - 1];
+                asm volatile("" : "+v"(pk));
+                if (e >= GIN_TE) {
+                    const unsigned ul2 = (unsigned)(src[e0 + e] - t0);
+                    pk = ((ul2 < (unsigned)GIN_TR ? ul2 : 0xFFFFFFu) << 8) | ecode[e0 + e];
+                }
+                const unsigned ul = pk >> 8;
+                const float4 w = *reinterpret_cast<const float4*>(se_b + (pk & 0xFFu) * (D * 4) + c * 16);
+                float4 x = *reinterpret_cast<const float4*>(sh_b + (ul < (unsigned)GIN_TR ? ul : 0u) * (D * 4) + c * 16);
+                asm volatile("" : "+v"(x.x), "+v"(x.y), "+v"(x.z), "+v"(x.w));
+                if (ul >= (unsigned)GIN_TR) x = load_f4_rare(h4 + (size_t)load_i32_rare(src + e0 + e) * C + c);
+                acc.x += relu1(w.x + x.x); acc.y += relu1(w.y + x.y); acc.z += relu1(w.z + x.z); acc.w += relu1(w.w + x.w);
+            }
+        }
+        if (ADD_SELF) {
+            const float4 self = s_hc[idx];
+            acc.x += self.x; acc.y += self.y; acc.z += self.z; acc.w += self.w;
+        }
+        reinterpret_cast<float4*>(a)[(size_t)t0 * C + idx] = acc;
+        c += 256 % C;
+        r += 256 / C;
+        if (c >= C) { c -= C; r++; }
+    }
+}
+
+template <int D>
+__device__ __forceinline__ void gin_agg_issue_rows(const float* __restrict__ h, float4* s_hb, int t0, int n_tot, int wave, int lane) {
+    constexpr int PIECES = GIN_TR * D * 4 / 1024;
+    const long long left = ((long long)n_tot - t0) * D * 4;
+    for (int p = wave; p < PIECES && (long long)p * 1024 < left; p += 4) {
+        const char* g = reinterpret_cast<const char*>(h) + (size_t)t0 * D * 4 + p * 1024 + lane * 16;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                         (__attribute__((address_space(3))) void*)(reinterpret_cast<char*>(s_hb) + p * 1024), 16, 0, 0);
+    }
+}
+
+template <int D, bool ADD_SELF>
+__global__ __launch_bounds__(256) void gin_aggregate_tiled2_kernel(const float* __restrict__ h, float* __restrict__ a,
+                                                                    const int* __restrict__ row_ptr,
+                                                                    const int* __restrict__ src,
+                                                                    const uint8_t* __restrict__ ecode,
+                                                                    const float* __restrict__ ecomb, int n_tot, int n_tiles) {
+    constexpr int C = D / 4;
+    constexpr int RPS = GIN_TR + 1;
+    __shared__ __attribute__((aligned(16))) float4 s_ecomb[EDGE_COMBOS * C];
+    __shared__ __attribute__((aligned(16))) float4 s_h0[GIN_TR * C];
+    __shared__ __attribute__((aligned(16))) float4 s_h1[GIN_TR * C];
+    __shared__ int s_rp[3][RPS];
+    __shared__ unsigned s_edge[2][GIN_TE];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int tid = threadIdx.x;
+    const int stride = gridDim.x;
+    int tile = blockIdx.x;
+    if (tile >= n_tiles) return;
+    auto rows_of = [&](int t) { const int t0 = t * GIN_TR; return (n_tot - t0) < GIN_TR ? (n_tot - t0) : GIN_TR; };
+    auto load_rp = [&](int t) -> int {  // entry `tid` of tile t's row_ptr slice (clamped to the array)
+        if (t >= n_tiles) return 0;
+        const long long i = (long long)t * GIN_TR + tid;
+        return row_ptr[i <= n_tot ? i : n_tot];
+    };
+    auto edge_word = [&](int t0, int e0, int ne, int i) -> unsigned {
+        if (i >= ne || i >= GIN_TE) return 0u;
+        const unsigned ul = (unsigned)(src[e0 + i] - t0);
+        return ((ul < (unsigned)GIN_TR ? ul : 0xFFFFFFu) << 8) | ecode[e0 + i];
+    };
+
+    // prologue: combos, tile 0 complete, row_ptr of tile 1
+    for (int i = tid; i < EDGE_COMBOS * C; i += 256) s_ecomb[i] = reinterpret_cast<const float4*>(ecomb)[i];
+    gin_agg_issue_rows<D>(h, s_h0, tile * GIN_TR, n_tot, wave, lane);
+    if (tid < RPS) {
+        s_rp[0][tid] = load_rp(tile);
+        s_rp[1][tid] = load_rp(tile + stride);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    {
+        const int e0 = s_rp[0][0], ne = s_rp[0][rows_of(tile)] - e0;
+        s_edge[0][tid] = edge_word(tile * GIN_TR, e0, ne, tid);
+        s_edge[0][tid + 256] = edge_word(tile * GIN_TR, e0, ne, tid + 256);
+    }
+    __syncthreads();
+
+    int ring = 0;  // s_rp[ring] = current tile, s_rp[(ring+1)%3] = next tile
+    // One pipeline step with STATIC buffers (CUR computes, NXT receives the DMA).  Even and odd steps are written out
+    // one after the other instead of being selected by `step & 1`: at a control-flow merge hipcc's wait-count
+    // tracking unions the pending LDS-DMA of both branches and then guards every ds_read with s_waitcnt vmcnt(0).
+#define GIN_AGG_STEP(CUR, NXT, EP)                                                                                      \
+    {                                                                                                                   \
+        const int nxt = tile + stride;                                                                                  \
+        const bool has_next = nxt < n_tiles; /* workgroup-uniform */                                                    \
+        const int r1 = ring == 2 ? 0 : ring + 1, r2 = r1 == 2 ? 0 : r1 + 1;                                            \
+        /* prefetch tile i+1 (rows by DMA, RAW CSR entries into registers) and row_ptr of tile i+2.  Nothing loaded */ \
+        /* here may be touched before the compute is over: the first use of a load result makes hipcc drain vmcnt   */ \
+        /* to 0, DMA included, so the packing of the edge words is deferred and pinned by the asm below.            */ \
+        int su0 = 0, su1 = 0, sc0 = 0, sc1 = 0, rp2 = 0, e0n = 0, nen = 0;                                              \
+        if (has_next) {                                                                                                 \
+            e0n = s_rp[r1][0];                                                                                          \
+            nen = s_rp[r1][rows_of(nxt)] - e0n;                                                                         \
+            gin_agg_issue_rows<D>(h, NXT, nxt * GIN_TR, n_tot, wave, lane);                                             \
+            if (tid < nen) { su0 = src[e0n + tid]; sc0 = ecode[e0n + tid]; }                                            \
+            if (tid + 256 < nen) { su1 = src[e0n + tid + 256]; sc1 = ecode[e0n + tid + 256]; }                          \
+            if (tid < RPS) rp2 = load_rp(nxt + stride);                                                                 \
+        }                                                                                                               \
+        gin_agg_compute_tile<D, ADD_SELF>(CUR, s_ecomb, s_rp[ring], s_edge[EP], h, a, src, ecode, tile * GIN_TR, rows_of(tile)); \
+        if (!has_next) break;                                                                                           \
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(su0), "+v"(su1), "+v"(sc0), "+v"(sc1), "+v"(rp2) : : "memory");       \
+        {                                                                                                               \
+            const int t0n = nxt * GIN_TR;                                                                               \
+            const unsigned ul0 = (unsigned)(su0 - t0n), ul1 = (unsigned)(su1 - t0n);                                    \
+            s_edge[1 - EP][tid] = tid < nen ? (((ul0 < (unsigned)GIN_TR ? ul0 : 0xFFFFFFu) << 8) | (unsigned)sc0) : 0u; \
+            s_edge[1 - EP][tid + 256] =                                                                                 \
+                tid + 256 < nen ? (((ul1 < (unsigned)GIN_TR ? ul1 : 0xFFFFFFu) << 8) | (unsigned)sc1) : 0u;             \
+        }                                                                                                               \
+        if (tid < RPS) s_rp[r2][tid] = rp2;                                                                             \
+        __syncthreads();                                                                                                \
+        tile = nxt;                                                                                                     \
+        ring = r1;                                                                                                      \
+    }
+    for (;;) {
+        GIN_AGG_STEP(s_h0, s_h1, 0)
+        GIN_AGG_STEP(s_h1, s_h0, 1)
+    }
+#undef GIN_AGG_STEP
 }
 
 // ---------------------------------------------------------------- node MLP (NT unit) on fp32 MFMA
@@ -874,6 +1037,13 @@ public:
             const int n_tiles = (int)ceil_div_ll(db.b.n_tot, GIN_TR);
             int g2 = 256 * 3;  // persistent: three workgroups per CU (52 KB of LDS each)
             if (g2 > n_tiles) g2 = n_tiles;
+            if (getenv("FLOWGNN_GIN_AGG_DB") && atoi(getenv("FLOWGNN_GIN_AGG_DB")) != 0) {
+                int g3 = 256 * 2;
+                if (g3 > n_tiles) g3 = n_tiles;
+                gin_aggregate_tiled2_kernel<GIN_D, true><<<g3, 256, 0, s>>>(hin, a, db.csr.row_ptr, db.csr.src, db.csr.ecode,
+                                                                            layer_dev(l).ecomb, db.b.n_tot, n_tiles);
+                return;
+            }
             gin_aggregate_tiled_kernel<GIN_D, true><<<g2, 256, 0, s>>>(hin, a, db.csr.row_ptr, db.csr.src, db.csr.ecode,
                                                                        layer_dev(l).ecomb, db.b.n_tot, n_tiles);
             return;
