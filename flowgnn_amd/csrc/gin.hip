@@ -113,27 +113,33 @@ __global__ __launch_bounds__(256) void gin_aggregate_tiled_kernel(const float* _
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int i = threadIdx.x; i < EDGE_COMBOS * C; i += 256) s_ecomb[i] = reinterpret_cast<const float4*>(ecomb)[i];
     const float4* h4 = reinterpret_cast<const float4*>(h);
+    auto load_rp = [&](int t) -> int {  // entry threadIdx.x of tile t's row_ptr slice (clamped to the array)
+        if (t >= n_tiles || threadIdx.x > GIN_TR) return 0;
+        const long long i = (long long)t * GIN_TR + threadIdx.x;
+        return row_ptr[i <= n_tot ? i : n_tot];
+    };
+    int rp_next = load_rp(blockIdx.x);  // the row_ptr slice of a tile is fetched one tile ahead
     for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const int t0 = tile * GIN_TR;
         const int rows = (n_tot - t0) < GIN_TR ? (n_tot - t0) : GIN_TR;
         __syncthreads();  // previous tile fully consumed (and, first time, the combos are in place)
-        // stage 1: the tile's rows of h (DMA) and its slice of row_ptr
+        if (threadIdx.x <= GIN_TR) s_rp[threadIdx.x] = rp_next;
+        __syncthreads();
+        // one global round trip per tile: rows of h (DMA), the tile's CSR entries, the next tile's row_ptr slice
+        const int e0 = s_rp[0];
+        const int ne = s_rp[rows] - e0;
         const long long tile_bytes_left = ((long long)n_tot - t0) * D * 4;  // pieces past the last row are skipped
         for (int p = wave; p < PIECES && (long long)p * 1024 < tile_bytes_left; p += 4) {
             const char* g = reinterpret_cast<const char*>(h) + (size_t)t0 * D * 4 + p * 1024 + lane * 16;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                              (__attribute__((address_space(3))) void*)(reinterpret_cast<char*>(s_h) + p * 1024), 16, 0, 0);
         }
-        if (threadIdx.x <= rows) s_rp[threadIdx.x] = row_ptr[t0 + threadIdx.x];
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        // stage 2: the tile's CSR entries, one packed word each: (row inside the tile, or 0xFFFFFF) << 8 | combo code
-        const int e0 = s_rp[0];
-        const int ne = s_rp[rows] - e0;
+        rp_next = load_rp(tile + gridDim.x);
         for (int i = threadIdx.x; i < ne && i < GIN_TE; i += 256) {
             const unsigned ul = (unsigned)(src[e0 + i] - t0);
             s_edge[i] = ((ul < (unsigned)GIN_TR ? ul : 0xFFFFFFu) << 8) | ecode[e0 + i];
         }
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(rp_next) : : "memory");
         __syncthreads();
         // stage 3: ordered sums.  The common case (all CSR entries of the tile staged) runs a loop with no clamps
         // and no fall-back branches; LDS byte offsets are carried incrementally (256 = 10 * 25 + 6).
