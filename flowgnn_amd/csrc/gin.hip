@@ -94,50 +94,52 @@ __global__ __launch_bounds__(256) void gin_aggregate_kernel(const float* __restr
 // for 21.5 M row reads (L1 hit rate ~ 0) and an L2 hit rate of 54 %, i.e. 3.87 GB fetched for 2.78 GB of
 // algorithmic reads, behind a three-deep dependent chain row_ptr -> src -> h[u] per item.
 constexpr int GIN_TR = 64;
-constexpr int GIN_TE = 512;  // CSR entries of a tile kept in LDS (a molhiv tile has ~141); the rest is read from global
+constexpr int GIN_TE = 512;  // (double-buffered variant) CSR entries of a tile kept in LDS; the rest is read from global
 
-template <int D, bool ADD_SELF>
-__global__ __launch_bounds__(256) void gin_aggregate_tiled_kernel(const float* __restrict__ h, float* __restrict__ a,
+template <int D, bool ADD_SELF, int TR, int NTHR>
+__global__ __launch_bounds__(NTHR) void gin_aggregate_tiled_kernel(const float* __restrict__ h, float* __restrict__ a,
                                                                    const int* __restrict__ row_ptr,
                                                                    const int* __restrict__ src,
                                                                    const uint8_t* __restrict__ ecode,
                                                                    const float* __restrict__ ecomb, int n_tot, int n_tiles) {
     constexpr int C = D / 4;
-    constexpr int TILE_BYTES = GIN_TR * D * 4;
+    constexpr int TE = 8 * TR;  // CSR entries of a tile kept in LDS (a molhiv tile of 64 rows has ~141)
+    constexpr int NW = NTHR / 64;
+    constexpr int TILE_BYTES = TR * D * 4;
     static_assert(TILE_BYTES % 1024 == 0, "tile must be whole 1 KiB DMA pieces");
     constexpr int PIECES = TILE_BYTES / 1024;
     __shared__ __attribute__((aligned(16))) float4 s_ecomb[EDGE_COMBOS * C];
-    __shared__ __attribute__((aligned(16))) float4 s_h[GIN_TR * C];
-    __shared__ int s_rp[GIN_TR + 1];
-    __shared__ unsigned s_edge[GIN_TE];
+    __shared__ __attribute__((aligned(16))) float4 s_h[TR * C];
+    __shared__ int s_rp[TR + 1];
+    __shared__ unsigned s_edge[TE];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int i = threadIdx.x; i < EDGE_COMBOS * C; i += 256) s_ecomb[i] = reinterpret_cast<const float4*>(ecomb)[i];
+    for (int i = threadIdx.x; i < EDGE_COMBOS * C; i += NTHR) s_ecomb[i] = reinterpret_cast<const float4*>(ecomb)[i];
     const float4* h4 = reinterpret_cast<const float4*>(h);
     auto load_rp = [&](int t) -> int {  // entry threadIdx.x of tile t's row_ptr slice (clamped to the array)
-        if (t >= n_tiles || threadIdx.x > GIN_TR) return 0;
-        const long long i = (long long)t * GIN_TR + threadIdx.x;
+        if (t >= n_tiles || threadIdx.x > TR) return 0;
+        const long long i = (long long)t * TR + threadIdx.x;
         return row_ptr[i <= n_tot ? i : n_tot];
     };
     int rp_next = load_rp(blockIdx.x);  // the row_ptr slice of a tile is fetched one tile ahead
     for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        const int t0 = tile * GIN_TR;
-        const int rows = (n_tot - t0) < GIN_TR ? (n_tot - t0) : GIN_TR;
+        const int t0 = tile * TR;
+        const int rows = (n_tot - t0) < TR ? (n_tot - t0) : TR;
         __syncthreads();  // previous tile fully consumed (and, first time, the combos are in place)
-        if (threadIdx.x <= GIN_TR) s_rp[threadIdx.x] = rp_next;
+        if (threadIdx.x <= TR) s_rp[threadIdx.x] = rp_next;
         __syncthreads();
         // one global round trip per tile: rows of h (DMA), the tile's CSR entries, the next tile's row_ptr slice
         const int e0 = s_rp[0];
         const int ne = s_rp[rows] - e0;
         const long long tile_bytes_left = ((long long)n_tot - t0) * D * 4;  // pieces past the last row are skipped
-        for (int p = wave; p < PIECES && (long long)p * 1024 < tile_bytes_left; p += 4) {
+        for (int p = wave; p < PIECES && (long long)p * 1024 < tile_bytes_left; p += NW) {
             const char* g = reinterpret_cast<const char*>(h) + (size_t)t0 * D * 4 + p * 1024 + lane * 16;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                              (__attribute__((address_space(3))) void*)(reinterpret_cast<char*>(s_h) + p * 1024), 16, 0, 0);
         }
         rp_next = load_rp(tile + gridDim.x);
-        for (int i = threadIdx.x; i < ne && i < GIN_TE; i += 256) {
+        for (int i = threadIdx.x; i < ne && i < TE; i += NTHR) {
             const unsigned ul = (unsigned)(src[e0 + i] - t0);
-            s_edge[i] = ((ul < (unsigned)GIN_TR ? ul : 0xFFFFFFu) << 8) | ecode[e0 + i];
+            s_edge[i] = ((ul < (unsigned)TR ? ul : 0xFFFFFFu) << 8) | ecode[e0 + i];
         }
         asm volatile("s_waitcnt vmcnt(0)" : "+v"(rp_next) : : "memory");
         __syncthreads();
@@ -146,8 +148,8 @@ __global__ __launch_bounds__(256) void gin_aggregate_tiled_kernel(const float* _
         const char* sh_b = reinterpret_cast<const char*>(s_h);
         const char* se_b = reinterpret_cast<const char*>(s_ecomb);
         int r = threadIdx.x / C, c = threadIdx.x - r * C;
-        if (ne <= GIN_TE) {
-            for (int idx = threadIdx.x; idx < rows * C; idx += 256) {
+        if (ne <= TE) {
+            for (int idx = threadIdx.x; idx < rows * C; idx += NTHR) {
                 const int beg = s_rp[r] - e0, end = s_rp[r + 1] - e0;
                 float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
                 for (int e = beg; e < end; e++) {
@@ -155,9 +157,9 @@ __global__ __launch_bounds__(256) void gin_aggregate_tiled_kernel(const float* _
                     asm volatile("" : "+v"(pk));  // keep it a ds_read (see below)
                     const unsigned ul = pk >> 8;
                     const float4 w = *reinterpret_cast<const float4*>(se_b + (pk & 0xFFu) * (D * 4) + c * 16);
-                    float4 x = *reinterpret_cast<const float4*>(sh_b + (ul < (unsigned)GIN_TR ? ul : 0u) * (D * 4) + c * 16);
+                    float4 x = *reinterpret_cast<const float4*>(sh_b + (ul < (unsigned)TR ? ul : 0u) * (D * 4) + c * 16);
                     asm volatile("" : "+v"(x.x), "+v"(x.y), "+v"(x.z), "+v"(x.w));
-                    if (ul >= (unsigned)GIN_TR) x = load_f4_rare(h4 + (size_t)load_i32_rare(src + e0 + e) * C + c);
+                    if (ul >= (unsigned)TR) x = load_f4_rare(h4 + (size_t)load_i32_rare(src + e0 + e) * C + c);
                     acc.x += relu1(w.x + x.x); acc.y += relu1(w.y + x.y); acc.z += relu1(w.z + x.z); acc.w += relu1(w.w + x.w);
                 }
                 if (ADD_SELF) {
@@ -165,29 +167,29 @@ __global__ __launch_bounds__(256) void gin_aggregate_tiled_kernel(const float* _
                     acc.x += self.x; acc.y += self.y; acc.z += self.z; acc.w += self.w;
                 }
                 reinterpret_cast<float4*>(a)[(size_t)t0 * C + idx] = acc;
-                c += 256 % C;
-                r += 256 / C;
+                c += NTHR % C;
+                r += NTHR / C;
                 if (c >= C) { c -= C; r++; }
             }
         } else {
             // dense tiles (kNN graphs, hub nodes): entries beyond the staged ones come from global memory.
             // LDS reads stay unconditional (clamped) and pinned with an empty asm, global memory is touched only in
             // branches: a `cond ? lds : global` select makes hipcc emit flat loads with a full wait after each.
-            for (int idx = threadIdx.x; idx < rows * C; idx += 256) {
+            for (int idx = threadIdx.x; idx < rows * C; idx += NTHR) {
                 const int beg = s_rp[r] - e0, end = s_rp[r + 1] - e0;
                 float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
                 for (int e = beg; e < end; e++) {
-                    unsigned pk = s_edge[e < GIN_TE ? e : GIN_TE - 1];
+                    unsigned pk = s_edge[e < TE ? e : TE - 1];
                     asm volatile("" : "+v"(pk));
-                    if (e >= GIN_TE) {
+                    if (e >= TE) {
                         const unsigned ul2 = (unsigned)(src[e0 + e] - t0);
-                        pk = ((ul2 < (unsigned)GIN_TR ? ul2 : 0xFFFFFFu) << 8) | ecode[e0 + e];
+                        pk = ((ul2 < (unsigned)TR ? ul2 : 0xFFFFFFu) << 8) | ecode[e0 + e];
                     }
                     const unsigned ul = pk >> 8;
                     const float4 w = *reinterpret_cast<const float4*>(se_b + (pk & 0xFFu) * (D * 4) + c * 16);
-                    float4 x = *reinterpret_cast<const float4*>(sh_b + (ul < (unsigned)GIN_TR ? ul : 0u) * (D * 4) + c * 16);
+                    float4 x = *reinterpret_cast<const float4*>(sh_b + (ul < (unsigned)TR ? ul : 0u) * (D * 4) + c * 16);
                     asm volatile("" : "+v"(x.x), "+v"(x.y), "+v"(x.z), "+v"(x.w));
-                    if (ul >= (unsigned)GIN_TR) x = load_f4_rare(h4 + (size_t)load_i32_rare(src + e0 + e) * C + c);
+                    if (ul >= (unsigned)TR) x = load_f4_rare(h4 + (size_t)load_i32_rare(src + e0 + e) * C + c);
                     acc.x += relu1(w.x + x.x); acc.y += relu1(w.y + x.y); acc.z += relu1(w.z + x.z); acc.w += relu1(w.w + x.w);
                 }
                 if (ADD_SELF) {
@@ -195,8 +197,8 @@ __global__ __launch_bounds__(256) void gin_aggregate_tiled_kernel(const float* _
                     acc.x += self.x; acc.y += self.y; acc.z += self.z; acc.w += self.w;
                 }
                 reinterpret_cast<float4*>(a)[(size_t)t0 * C + idx] = acc;
-                c += 256 % C;
-                r += 256 / C;
+                c += NTHR % C;
+                r += NTHR / C;
                 if (c >= C) { c -= C; r++; }
             }
         }
@@ -1050,8 +1052,23 @@ public:
                                                                             layer_dev(l).ecomb, db.b.n_tot, n_tiles);
                 return;
             }
-            gin_aggregate_tiled_kernel<GIN_D, true><<<g2, 256, 0, s>>>(hin, a, db.csr.row_ptr, db.csr.src, db.csr.ecode,
-                                                                       layer_dev(l).ecomb, db.b.n_tot, n_tiles);
+            // tile = 128 rows per 512-thread workgroup, 2 workgroups per CU (78 KB of LDS each): 1.17 ms at 2^18
+            // molhiv graphs vs 1.26-1.30 ms for 64 rows x 256 threads x 3 per CU (FLOWGNN_GIN_AGG_TILE=64 / 256)
+            const int tv = getenv("FLOWGNN_GIN_AGG_TILE") ? atoi(getenv("FLOWGNN_GIN_AGG_TILE")) : 128;
+            if (tv == 128 || tv == 256) {
+                const int nt2 = (int)ceil_div_ll(db.b.n_tot, tv);
+                int g4 = tv == 128 ? 256 * 2 : 256;
+                if (g4 > nt2) g4 = nt2;
+                if (tv == 128)
+                    gin_aggregate_tiled_kernel<GIN_D, true, 128, 512><<<g4, 512, 0, s>>>(hin, a, db.csr.row_ptr, db.csr.src, db.csr.ecode,
+                                                                                         layer_dev(l).ecomb, db.b.n_tot, nt2);
+                else
+                    gin_aggregate_tiled_kernel<GIN_D, true, 256, 1024><<<g4, 1024, 0, s>>>(hin, a, db.csr.row_ptr, db.csr.src, db.csr.ecode,
+                                                                                           layer_dev(l).ecomb, db.b.n_tot, nt2);
+                return;
+            }
+            gin_aggregate_tiled_kernel<GIN_D, true, GIN_TR, 256><<<g2, 256, 0, s>>>(hin, a, db.csr.row_ptr, db.csr.src, db.csr.ecode,
+                                                                                    layer_dev(l).ecomb, db.b.n_tot, n_tiles);
             return;
         }
         gin_aggregate_kernel<GIN_D, true><<<grid, 256, lds, s>>>(hin, a, db.csr.row_ptr, db.csr.src, db.csr.ecode,
