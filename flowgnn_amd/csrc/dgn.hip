@@ -48,49 +48,45 @@ __global__ __launch_bounds__(256) void dgn_encoder_kernel(const int* __restrict_
     }
 }
 
-// z[v] = [a1 | a2]; flattened (row, float4 chunk) work items
-__global__ __launch_bounds__(256) void dgn_aggregate_kernel(const float* __restrict__ h, float* __restrict__ z,
-                                                             const int* __restrict__ row_ptr,
-                                                             const int* __restrict__ src,
-                                                             const int* __restrict__ out_deg,
-                                                             const float* __restrict__ eig,  // [N][4]
-                                                             int n_tot) {
-    constexpr int C = DGN_C;
-    const float4* h4 = reinterpret_cast<const float4*>(h);
-    const long long total = (long long)n_tot * C;
-    long long span = (total + gridDim.x - 1) / gridDim.x;
-    span = (span + 255) / 256 * 256;
-    const long long i_end = (span * (blockIdx.x + 1) < total) ? span * (blockIdx.x + 1) : total;
-    for (long long i = span * blockIdx.x + threadIdx.x; i < i_end; i += 256) {
-        const int v = (int)(i / C);
-        const int c = (int)(i - (long long)v * C);
-        const int beg = row_ptr[v], end = row_ptr[v + 1];
-        const float ev = eig[(size_t)v * 4 + 1];
-        float4 m1 = make_float4(0.f, 0.f, 0.f, 0.f), m2 = m1;
-        float wsum = 0.f, abssum = 0.f;
-        for (int e = beg; e < end; e++) {
-            const int u = src[e];
-            const float w = eig[(size_t)u * 4 + 1] - ev;
-            wsum += w;
-            abssum += fabsf(w);
-            const float4 x = h4[(size_t)u * C + c];
-            m1.x += x.x; m1.y += x.y; m1.z += x.z; m1.w += x.w;
-            m2.x += x.x * w; m2.y += x.y * w; m2.z += x.z * w; m2.w += x.w * w;
-        }
-        if (abssum == 0.0f) abssum = 1.0f / 8192.0f;  // epsilon of ap_fixed<16,3>
-        const int dv = out_deg[v];
-        const float deg = (float)dv;
-        const float4 hv = h4[i];
-        float4 a1, a2;
-        a1.x = dv == 0 ? 0.f : m1.x / deg; a1.y = dv == 0 ? 0.f : m1.y / deg;
-        a1.z = dv == 0 ? 0.f : m1.z / deg; a1.w = dv == 0 ? 0.f : m1.w / deg;
-        a2.x = fabsf((m2.x - wsum * hv.x) / abssum); a2.y = fabsf((m2.y - wsum * hv.y) / abssum);
-        a2.z = fabsf((m2.z - wsum * hv.z) / abssum); a2.w = fabsf((m2.w - wsum * hv.w) / abssum);
-        float4* o = reinterpret_cast<float4*>(z) + (size_t)v * (2 * C) + c;
-        o[0] = a1;
-        o[C] = a2;
+// z[v] = [a1 | a2]: policy of the generic tiled aggregation (device_common.h).  The directional weight of an edge
+// is eig1[u] - eig1[v]: the source half is staged per CSR entry, the destination half is read once per item.
+struct DgnAggPolicy {
+    static constexpr int D = DGN_D, TR = 128, NTHR = 512, TE = 20 * 128, TABLE_ROWS = 0;
+    static constexpr bool HAS_SCALAR = true;
+    struct Params {
+        const float* eig;     // [N][4]
+        const int* out_deg;
+    };
+    struct Acc { float4 m1, m2; float wsum, abssum; };
+    __device__ static float src_scalar(const Params& p, int u) { return p.eig[(size_t)u * 4 + 1]; }
+    __device__ static float dst_scalar(const Params& p, int v) { return p.eig[(size_t)v * 4 + 1]; }
+    __device__ static void init(Acc& a) {
+        a.m1 = make_float4(0.f, 0.f, 0.f, 0.f);
+        a.m2 = a.m1;
+        a.wsum = 0.f;
+        a.abssum = 0.f;
     }
-}
+    __device__ static void edge(Acc& a, const float4& x, const float4&, float ss, float sd) {
+        const float w = ss - sd;
+        a.wsum += w;
+        a.abssum += fabsf(w);
+        a.m1.x += x.x; a.m1.y += x.y; a.m1.z += x.z; a.m1.w += x.w;
+        a.m2.x += x.x * w; a.m2.y += x.y * w; a.m2.z += x.z * w; a.m2.w += x.w * w;
+    }
+    __device__ static void finish(const Params& p, const Acc& a, const float4& hv, int v, int c, int, float* out) {
+        const float abssum = a.abssum == 0.0f ? 1.0f / 8192.0f : a.abssum;  // epsilon of ap_fixed<16,3>
+        const int dv = p.out_deg[v];
+        const float deg = (float)dv;
+        float4 a1, a2;
+        a1.x = dv == 0 ? 0.f : a.m1.x / deg; a1.y = dv == 0 ? 0.f : a.m1.y / deg;
+        a1.z = dv == 0 ? 0.f : a.m1.z / deg; a1.w = dv == 0 ? 0.f : a.m1.w / deg;
+        a2.x = fabsf((a.m2.x - a.wsum * hv.x) / abssum); a2.y = fabsf((a.m2.y - a.wsum * hv.y) / abssum);
+        a2.z = fabsf((a.m2.z - a.wsum * hv.z) / abssum); a2.w = fabsf((a.m2.w - a.wsum * hv.w) / abssum);
+        float4* o = reinterpret_cast<float4*>(out) + (size_t)v * (2 * DGN_C) + c;
+        o[0] = a1;
+        o[DGN_C] = a2;
+    }
+};
 
 // h'[v] = h[v] + relu(b + W0 a1 + W1 a2), K = 2 x 100.  One wave = 16 nodes; fragments [2][7][6][64][4] + tails [2][7][64]
 __global__ __launch_bounds__(256) void dgn_dense_kernel(const float* __restrict__ z, const float* __restrict__ h,
@@ -220,9 +216,8 @@ public:
     }
 
     void launch_aggregate(const DeviceBatch& db, const float* hin, hipStream_t s) {
-        const int grid = grid_for((long long)db.b.n_tot * DGN_C, 256, 256 * 8);
-        dgn_aggregate_kernel<<<grid, 256, 0, s>>>(hin, db.scratch, db.csr.row_ptr, db.csr.src, db.csr.out_deg, db.node_eigen,
-                                                  db.b.n_tot);
+        DgnAggPolicy::Params prm{db.node_eigen, db.csr.out_deg};
+        launch_tiled_aggregate<DgnAggPolicy>(prm, hin, db.scratch, db.csr, nullptr, db.b.n_tot, s);
     }
 
     int forward(DeviceBatch& db, Profiler& prof, hipStream_t s) override {

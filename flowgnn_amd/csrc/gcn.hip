@@ -32,58 +32,43 @@ struct GcnEpilogue {
     const float* bn_b;      // [100]
 };
 
-// a[v] = epilogue( sum_e norm_e relu(x[src_e] + ecomb[code_e]), x[v], outdeg[v] ), CSR order.
-// Same flattened (row, float4 chunk) work decomposition as gin_aggregate_kernel.
+// a[v] = epilogue( sum_e norm_e relu(x[src_e] + ecomb[code_e]), x[v], outdeg[v] ), CSR order: policy of the generic
+// tiled aggregation (device_common.h).  norm_e = dinv[u] dinv[v] with dinv from the out-degree table.
 template <bool RELU_OUT>
-__global__ __launch_bounds__(256) void gcn_aggregate_kernel(const float* __restrict__ x, float* __restrict__ a,
-                                                             const int* __restrict__ row_ptr,
-                                                             const int* __restrict__ src,
-                                                             const uint8_t* __restrict__ ecode,
-                                                             const int* __restrict__ out_deg,
-                                                             const float* __restrict__ ecomb, GcnEpilogue ep, int n_tot) {
-    constexpr int C = GCN_C;
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    float4* s_ecomb = reinterpret_cast<float4*>(smem_raw);
-    for (int i = threadIdx.x; i < EDGE_COMBOS * C; i += 256) s_ecomb[i] = reinterpret_cast<const float4*>(ecomb)[i];
-    __syncthreads();
-    const float4* x4 = reinterpret_cast<const float4*>(x);
-    const long long total = (long long)n_tot * C;
-    long long span = (total + gridDim.x - 1) / gridDim.x;
-    span = (span + 255) / 256 * 256;
-    const long long i_end = (span * (blockIdx.x + 1) < total) ? span * (blockIdx.x + 1) : total;
-    for (long long i = span * blockIdx.x + threadIdx.x; i < i_end; i += 256) {
-        const int v = (int)(i / C);
-        const int c = (int)(i - (long long)v * C);
-        const int beg = row_ptr[v], end = row_ptr[v + 1];
-        const int dv = out_deg[v];
-        const float dinv_v = dv > 0 ? 1.0f / sqrtf((float)(dv + 1)) : 0.0f;
-        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int e = beg; e < end; e++) {
-            const int u = src[e];
-            const int k = ecode[e];
-            const int du = out_deg[u];
-            const float norm = (du > 0 ? 1.0f / sqrtf((float)(du + 1)) : 0.0f) * dinv_v;
-            const float4 xu = x4[(size_t)u * C + c];
-            const float4 w = s_ecomb[k * C + c];
-            acc.x += norm * relu1(w.x + xu.x); acc.y += norm * relu1(w.y + xu.y);
-            acc.z += norm * relu1(w.z + xu.z); acc.w += norm * relu1(w.w + xu.w);
-        }
-        const float4 xs = x4[i];
+struct GcnAggPolicy {
+    static constexpr int D = GCN_D, TR = 128, NTHR = 512, TE = 8 * 128, TABLE_ROWS = EDGE_COMBOS;
+    static constexpr bool HAS_SCALAR = true;
+    struct Params {
+        const int* out_deg;
+        GcnEpilogue ep;
+    };
+    struct Acc { float4 m; };
+    __device__ static float dinv(int d) { return d > 0 ? 1.0f / sqrtf((float)(d + 1)) : 0.0f; }  // load_inputs.cc:122
+    __device__ static float src_scalar(const Params& p, int u) { return dinv(p.out_deg[u]); }
+    __device__ static float dst_scalar(const Params& p, int v) { return dinv(p.out_deg[v]); }
+    __device__ static void init(Acc& a) { a.m = make_float4(0.f, 0.f, 0.f, 0.f); }
+    __device__ static void edge(Acc& a, const float4& x, const float4& w, float ss, float sd) {
+        const float norm = ss * sd;
+        a.m.x += norm * relu1(w.x + x.x); a.m.y += norm * relu1(w.y + x.y);
+        a.m.z += norm * relu1(w.z + x.z); a.m.w += norm * relu1(w.w + x.w);
+    }
+    __device__ static void finish(const Params& p, const Acc& a, const float4& xs, int v, int c, int, float* out) {
+        const GcnEpilogue& ep = p.ep;
         const float4 rt = reinterpret_cast<const float4*>(ep.root)[c];
         const float4 mu = reinterpret_cast<const float4*>(ep.bn_mean)[c];
         const float4 sv = reinterpret_cast<const float4*>(ep.bn_sqrtv)[c];
         const float4 bw = reinterpret_cast<const float4*>(ep.bn_w)[c];
         const float4 bb = reinterpret_cast<const float4*>(ep.bn_b)[c];
-        const float dp1 = (float)(dv + 1);
+        const float dp1 = (float)(p.out_deg[v] + 1);
         float4 r;
-        r.x = (acc.x + relu1(xs.x + rt.x) / dp1 - mu.x) / sv.x * bw.x + bb.x;
-        r.y = (acc.y + relu1(xs.y + rt.y) / dp1 - mu.y) / sv.y * bw.y + bb.y;
-        r.z = (acc.z + relu1(xs.z + rt.z) / dp1 - mu.z) / sv.z * bw.z + bb.z;
-        r.w = (acc.w + relu1(xs.w + rt.w) / dp1 - mu.w) / sv.w * bw.w + bb.w;
+        r.x = (a.m.x + relu1(xs.x + rt.x) / dp1 - mu.x) / sv.x * bw.x + bb.x;
+        r.y = (a.m.y + relu1(xs.y + rt.y) / dp1 - mu.y) / sv.y * bw.y + bb.y;
+        r.z = (a.m.z + relu1(xs.z + rt.z) / dp1 - mu.z) / sv.z * bw.z + bb.z;
+        r.w = (a.m.w + relu1(xs.w + rt.w) / dp1 - mu.w) / sv.w * bw.w + bb.w;
         if (RELU_OUT) { r.x = relu1(r.x); r.y = relu1(r.y); r.z = relu1(r.z); r.w = relu1(r.w); }
-        reinterpret_cast<float4*>(a)[i] = r;
+        reinterpret_cast<float4*>(out)[(size_t)v * GCN_C + c] = r;
     }
-}
+};
 
 class GcnModel : public Model {
 public:
@@ -175,10 +160,8 @@ public:
 
     template <bool RELU_OUT>
     void launch_aggregate(const DeviceBatch& db, int l, const float* x, float* a, hipStream_t s) {
-        const int grid = grid_for((long long)db.b.n_tot * GCN_C, 256, 256 * 6);
-        gcn_aggregate_kernel<RELU_OUT><<<grid, 256, sizeof(float) * EDGE_COMBOS * GCN_D, s>>>(
-            x, a, db.csr.row_ptr, db.csr.src, db.csr.ecode, db.csr.out_deg, d_ecomb_ + (size_t)l * EDGE_COMBOS * GCN_D,
-            epilogue(l), db.b.n_tot);
+        typename GcnAggPolicy<RELU_OUT>::Params prm{db.csr.out_deg, epilogue(l)};
+        launch_tiled_aggregate<GcnAggPolicy<RELU_OUT>>(prm, x, a, db.csr, d_ecomb_ + (size_t)l * EDGE_COMBOS * GCN_D, db.b.n_tot, s);
     }
 
     void launch_dense(int l, const float* a, float* x, int n, hipStream_t s) {

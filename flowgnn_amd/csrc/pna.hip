@@ -30,39 +30,38 @@ constexpr int PNA_NS = 3;          // scalers: none, t, scale
 constexpr float PNA_SENT_MAX = 31.9990234375f;  // ap_fixed_max<ap_fixed<16,6>>, PNA/src/util.h:41-46
 constexpr float PNA_SENT_MIN = -32.0f;          // ap_fixed_min, PNA/src/util.h:34-39
 
-// agg[v][a][d], a = {mean, min, max, std}; flattened (row, float4 chunk) work items as in gin_aggregate_kernel
-__global__ __launch_bounds__(256) void pna_aggregate_kernel(const float* __restrict__ h, float* __restrict__ agg,
-                                                             const int* __restrict__ row_ptr,
-                                                             const int* __restrict__ src, int n_tot) {
-    constexpr int C = PNA_C;
-    const float4* h4 = reinterpret_cast<const float4*>(h);
-    const long long total = (long long)n_tot * C;
-    long long span = (total + gridDim.x - 1) / gridDim.x;
-    span = (span + 255) / 256 * 256;
-    const long long i_end = (span * (blockIdx.x + 1) < total) ? span * (blockIdx.x + 1) : total;
-    for (long long i = span * blockIdx.x + threadIdx.x; i < i_end; i += 256) {
-        const int v = (int)(i / C);
-        const int c = (int)(i - (long long)v * C);
-        const int beg = row_ptr[v], end = row_ptr[v + 1];
-        float4 S = make_float4(0.f, 0.f, 0.f, 0.f), Q = S;
-        float4 mn = make_float4(PNA_SENT_MAX, PNA_SENT_MAX, PNA_SENT_MAX, PNA_SENT_MAX);
-        float4 mx = make_float4(PNA_SENT_MIN, PNA_SENT_MIN, PNA_SENT_MIN, PNA_SENT_MIN);
-        for (int e = beg; e < end; e++) {
-            const float4 x = h4[(size_t)src[e] * C + c];
-            S.x += x.x; S.y += x.y; S.z += x.z; S.w += x.w;
-            Q.x += x.x * x.x; Q.y += x.y * x.y; Q.z += x.z * x.z; Q.w += x.w * x.w;
-            mn.x = x.x < mn.x ? x.x : mn.x; mn.y = x.y < mn.y ? x.y : mn.y; mn.z = x.z < mn.z ? x.z : mn.z; mn.w = x.w < mn.w ? x.w : mn.w;
-            mx.x = x.x > mx.x ? x.x : mx.x; mx.y = x.y > mx.y ? x.y : mx.y; mx.z = x.z > mx.z ? x.z : mx.z; mx.w = x.w > mx.w ? x.w : mx.w;
-        }
-        const float deg = (float)((end - beg) == 0 ? 1 : (end - beg));
-        float4 mean, sd;
-        mean.x = S.x / deg; mean.y = S.y / deg; mean.z = S.z / deg; mean.w = S.w / deg;
-        sd.x = sqrtf(relu1(Q.x / deg - mean.x * mean.x)); sd.y = sqrtf(relu1(Q.y / deg - mean.y * mean.y));
-        sd.z = sqrtf(relu1(Q.z / deg - mean.z * mean.z)); sd.w = sqrtf(relu1(Q.w / deg - mean.w * mean.w));
-        float4* o = reinterpret_cast<float4*>(agg) + (size_t)v * (PNA_NA * C) + c;
-        o[0 * C] = mean; o[1 * C] = mn; o[2 * C] = mx; o[3 * C] = sd;
+// agg[v][a][d], a = {mean, min, max, std}: policy of the generic tiled aggregation (device_common.h)
+struct PnaAggPolicy {
+    static constexpr int D = PNA_D, TR = 128, NTHR = 512, TE = 20 * 128, TABLE_ROWS = 0;
+    static constexpr bool HAS_SCALAR = false;
+    struct Params { int unused; };
+    struct Acc { float4 S, Q, mn, mx; };
+    __device__ static float src_scalar(const Params&, int) { return 0.f; }
+    __device__ static float dst_scalar(const Params&, int) { return 0.f; }
+    __device__ static void init(Acc& a) {
+        a.S = make_float4(0.f, 0.f, 0.f, 0.f);
+        a.Q = a.S;
+        a.mn = make_float4(PNA_SENT_MAX, PNA_SENT_MAX, PNA_SENT_MAX, PNA_SENT_MAX);
+        a.mx = make_float4(PNA_SENT_MIN, PNA_SENT_MIN, PNA_SENT_MIN, PNA_SENT_MIN);
     }
-}
+    __device__ static void edge(Acc& a, const float4& x, const float4&, float, float) {
+        a.S.x += x.x; a.S.y += x.y; a.S.z += x.z; a.S.w += x.w;
+        a.Q.x += x.x * x.x; a.Q.y += x.y * x.y; a.Q.z += x.z * x.z; a.Q.w += x.w * x.w;
+        a.mn.x = x.x < a.mn.x ? x.x : a.mn.x; a.mn.y = x.y < a.mn.y ? x.y : a.mn.y;
+        a.mn.z = x.z < a.mn.z ? x.z : a.mn.z; a.mn.w = x.w < a.mn.w ? x.w : a.mn.w;
+        a.mx.x = x.x > a.mx.x ? x.x : a.mx.x; a.mx.y = x.y > a.mx.y ? x.y : a.mx.y;
+        a.mx.z = x.z > a.mx.z ? x.z : a.mx.z; a.mx.w = x.w > a.mx.w ? x.w : a.mx.w;
+    }
+    __device__ static void finish(const Params&, const Acc& a, const float4&, int v, int c, int indeg, float* out) {
+        const float deg = (float)(indeg == 0 ? 1 : indeg);
+        float4 mean, sd;
+        mean.x = a.S.x / deg; mean.y = a.S.y / deg; mean.z = a.S.z / deg; mean.w = a.S.w / deg;
+        sd.x = sqrtf(relu1(a.Q.x / deg - mean.x * mean.x)); sd.y = sqrtf(relu1(a.Q.y / deg - mean.y * mean.y));
+        sd.z = sqrtf(relu1(a.Q.z / deg - mean.z * mean.z)); sd.w = sqrtf(relu1(a.Q.w / deg - mean.w * mean.w));
+        float4* o = reinterpret_cast<float4*>(out) + (size_t)v * (PNA_NA * PNA_C) + c;
+        o[0 * PNA_C] = mean; o[1 * PNA_C] = a.mn; o[2 * PNA_C] = a.mx; o[3 * PNA_C] = sd;
+    }
+};
 
 // h'[v] = h[v] + relu(b + Y_0 + t Y_1 + scale Y_2),  Y_s = W_s agg[v]   (K = 320, 80 outputs)
 // One wave = 16 nodes (MFMA columns).  Lane (j, g) holds agg[j][a][16 q + 4 g + r]; the W fragment for
@@ -200,8 +199,8 @@ public:
     }
 
     void launch_aggregate(const DeviceBatch& db, const float* hin, hipStream_t s) {
-        const int grid = grid_for((long long)db.b.n_tot * PNA_C, 256, 256 * 8);
-        pna_aggregate_kernel<<<grid, 256, 0, s>>>(hin, db.scratch, db.csr.row_ptr, db.csr.src, db.b.n_tot);
+        PnaAggPolicy::Params prm{0};
+        launch_tiled_aggregate<PnaAggPolicy>(prm, hin, db.scratch, db.csr, nullptr, db.b.n_tot, s);
     }
 
     int forward(DeviceBatch& db, Profiler& prof, hipStream_t s) override {
