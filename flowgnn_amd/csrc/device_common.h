@@ -157,9 +157,13 @@ __global__ __launch_bounds__(256) void pool_mlp3_kernel(const float* __restrict_
 // Policy: D, TR, NTHR, TE (CSR entries of a tile staged in LDS: ~2.2 per row for molecules, 16 per row for the kNN
 //   graphs), TABLE_ROWS (rows of a [TABLE_ROWS][D] per-edge-code table kept in LDS, 0 = none),
 //   HAS_SCALAR; struct Params; struct Acc;
-//   src_scalar(p, u) -> float (global reads allowed, runs at staging)
-//   init(acc); edge(acc, x, w, s_src, s_dst) ; dst_scalar(p, v) -> float (once per item)
-//   finish(p, acc, self, v, c, in_degree, out_base)  (writes the item's outputs)
+//   NDST (0..2 per-DESTINATION floats staged per tile row), CONST_FLOATS (per-layer constants kept in LDS);
+//   src_scalar(p, u) -> float, dst_stage(p, v, float[NDST]) (global reads allowed: both run at staging),
+//   const_ptr(p) -> global pointer to CONST_FLOATS floats;
+//   init(acc); edge(acc, x, w, s_src, dst[NDST]);
+//   finish(p, acc, self, v, c, in_degree, dst[NDST], s_const, out_base)  (writes the item's outputs)
+// Stage 3 touches global memory only for its stores (and the rare out-of-tile gather): any ordinary load inside
+// the item loop would make hipcc wait for vmcnt(0), i.e. for the previous item's stores, on every trip.
 template <class P>
 __global__ __launch_bounds__(P::NTHR) void tiled_aggregate_kernel(typename P::Params prm, const float* __restrict__ h,
                                                                    float* __restrict__ out, const int* __restrict__ row_ptr,
@@ -176,9 +180,13 @@ __global__ __launch_bounds__(P::NTHR) void tiled_aggregate_kernel(typename P::Pa
     __shared__ int s_rp[TR + 1];
     __shared__ unsigned s_edge[TE];
     __shared__ float s_es[P::HAS_SCALAR ? TE : 1];
+    __shared__ float s_dst[P::NDST > 0 ? P::NDST * TR : 1];
+    __shared__ __attribute__((aligned(16))) float s_const[P::CONST_FLOATS > 0 ? P::CONST_FLOATS : 4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (P::TABLE_ROWS > 0)
         for (int i = threadIdx.x; i < P::TABLE_ROWS * C; i += NTHR) s_tab[i] = reinterpret_cast<const float4*>(table)[i];
+    if (P::CONST_FLOATS > 0)
+        for (int i = threadIdx.x; i < P::CONST_FLOATS; i += NTHR) s_const[i] = P::const_ptr(prm)[i];
     const float4* h4 = reinterpret_cast<const float4*>(h);
     auto load_rp = [&](int t) -> int {
         if (t >= n_tiles || threadIdx.x > TR) return 0;
@@ -210,6 +218,12 @@ __global__ __launch_bounds__(P::NTHR) void tiled_aggregate_kernel(typename P::Pa
             s_edge[i] = pack(u, ecode ? (int)ecode[e0 + i] : 0, t0);
             if (P::HAS_SCALAR) s_es[i] = P::src_scalar(prm, u);
         }
+        if (P::NDST > 0 && threadIdx.x < rows) {
+            float dv[P::NDST > 0 ? P::NDST : 1];
+            P::dst_stage(prm, t0 + threadIdx.x, dv);
+#pragma unroll
+            for (int k = 0; k < P::NDST; k++) s_dst[k * TR + threadIdx.x] = dv[k];
+        }
         asm volatile("s_waitcnt vmcnt(0)" : "+v"(rp_next) : : "memory");
         __syncthreads();
 
@@ -219,7 +233,9 @@ __global__ __launch_bounds__(P::NTHR) void tiled_aggregate_kernel(typename P::Pa
         for (int idx = threadIdx.x; idx < rows * C; idx += NTHR) {
             const int v = t0 + r;
             const int beg = s_rp[r] - e0, end = s_rp[r + 1] - e0;
-            const float sd = P::dst_scalar(prm, v);
+            float sd[P::NDST > 0 ? P::NDST : 1];
+#pragma unroll
+            for (int k = 0; k < (P::NDST > 0 ? P::NDST : 1); k++) sd[k] = P::NDST > 0 ? s_dst[k * TR + r] : 0.f;
             typename P::Acc acc;
             P::init(acc);
             if (ne <= TE) {
@@ -254,7 +270,7 @@ __global__ __launch_bounds__(P::NTHR) void tiled_aggregate_kernel(typename P::Pa
                     P::edge(acc, x, w, ss, sd);
                 }
             }
-            P::finish(prm, acc, s_h[idx], v, c, end - beg, out);
+            P::finish(prm, acc, s_h[idx], v, c, end - beg, sd, s_const, out);
             c += NTHR % C;
             r += NTHR / C;
             if (c >= C) { c -= C; r++; }
@@ -268,7 +284,7 @@ static inline void launch_tiled_aggregate(const typename P::Params& prm, const f
     const int n_tiles = (int)ceil_div_ll(n_tot, P::TR);
     if (n_tiles <= 0) return;
     constexpr int lds = (P::TABLE_ROWS > 0 ? P::TABLE_ROWS * P::D * 4 : 16) + P::TR * P::D * 4 + (P::TR + 1) * 4 + P::TE * 4 +
-                        (P::HAS_SCALAR ? P::TE * 4 : 4);
+                        (P::HAS_SCALAR ? P::TE * 4 : 4) + P::NDST * P::TR * 4 + P::CONST_FLOATS * 4;
     int per_cu = 160 * 1024 / (lds + 256);
     if (per_cu < 1) per_cu = 1;
     if (per_cu * P::NTHR > 2048) per_cu = 2048 / P::NTHR;

@@ -53,33 +53,39 @@ __global__ __launch_bounds__(256) void dgn_encoder_kernel(const int* __restrict_
 struct DgnAggPolicy {
     static constexpr int D = DGN_D, TR = 128, NTHR = 512, TE = 20 * 128, TABLE_ROWS = 0;
     static constexpr bool HAS_SCALAR = true;
+    static constexpr int NDST = 2, CONST_FLOATS = 0;  // eig1[v], outdeg(v)
     struct Params {
         const float* eig;     // [N][4]
         const int* out_deg;
     };
     struct Acc { float4 m1, m2; float wsum, abssum; };
     __device__ static float src_scalar(const Params& p, int u) { return p.eig[(size_t)u * 4 + 1]; }
-    __device__ static float dst_scalar(const Params& p, int v) { return p.eig[(size_t)v * 4 + 1]; }
+    __device__ static void dst_stage(const Params& p, int v, float* o) {
+        o[0] = p.eig[(size_t)v * 4 + 1];
+        o[1] = (float)p.out_deg[v];
+    }
+    __device__ static const float* const_ptr(const Params&) { return nullptr; }
     __device__ static void init(Acc& a) {
         a.m1 = make_float4(0.f, 0.f, 0.f, 0.f);
         a.m2 = a.m1;
         a.wsum = 0.f;
         a.abssum = 0.f;
     }
-    __device__ static void edge(Acc& a, const float4& x, const float4&, float ss, float sd) {
-        const float w = ss - sd;
+    __device__ static void edge(Acc& a, const float4& x, const float4&, float ss, const float* sd) {
+        const float w = ss - sd[0];
         a.wsum += w;
         a.abssum += fabsf(w);
         a.m1.x += x.x; a.m1.y += x.y; a.m1.z += x.z; a.m1.w += x.w;
         a.m2.x += x.x * w; a.m2.y += x.y * w; a.m2.z += x.z * w; a.m2.w += x.w * w;
     }
-    __device__ static void finish(const Params& p, const Acc& a, const float4& hv, int v, int c, int, float* out) {
+    __device__ static void finish(const Params&, const Acc& a, const float4& hv, int v, int c, int, const float* sd, const float*,
+                                  float* out) {
         const float abssum = a.abssum == 0.0f ? 1.0f / 8192.0f : a.abssum;  // epsilon of ap_fixed<16,3>
-        const int dv = p.out_deg[v];
-        const float deg = (float)dv;
+        const float deg = sd[1];
+        const bool dv = deg == 0.0f;
         float4 a1, a2;
-        a1.x = dv == 0 ? 0.f : a.m1.x / deg; a1.y = dv == 0 ? 0.f : a.m1.y / deg;
-        a1.z = dv == 0 ? 0.f : a.m1.z / deg; a1.w = dv == 0 ? 0.f : a.m1.w / deg;
+        a1.x = dv ? 0.f : a.m1.x / deg; a1.y = dv ? 0.f : a.m1.y / deg;
+        a1.z = dv ? 0.f : a.m1.z / deg; a1.w = dv ? 0.f : a.m1.w / deg;
         a2.x = fabsf((a.m2.x - a.wsum * hv.x) / abssum); a2.y = fabsf((a.m2.y - a.wsum * hv.y) / abssum);
         a2.z = fabsf((a.m2.z - a.wsum * hv.z) / abssum); a2.w = fabsf((a.m2.w - a.wsum * hv.w) / abssum);
         float4* o = reinterpret_cast<float4*>(out) + (size_t)v * (2 * DGN_C) + c;

@@ -38,28 +38,35 @@ template <bool RELU_OUT>
 struct GcnAggPolicy {
     static constexpr int D = GCN_D, TR = 128, NTHR = 512, TE = 8 * 128, TABLE_ROWS = EDGE_COMBOS;
     static constexpr bool HAS_SCALAR = true;
+    static constexpr int NDST = 2;                 // dinv[v], outdeg(v) + 1
+    static constexpr int CONST_FLOATS = 5 * GCN_D;  // root | bn_mean | bn_sqrtv | bn_w | bn_b of the layer
     struct Params {
         const int* out_deg;
-        GcnEpilogue ep;
+        const float* ep;  // the five epilogue vectors, contiguous
     };
     struct Acc { float4 m; };
     __device__ static float dinv(int d) { return d > 0 ? 1.0f / sqrtf((float)(d + 1)) : 0.0f; }  // load_inputs.cc:122
     __device__ static float src_scalar(const Params& p, int u) { return dinv(p.out_deg[u]); }
-    __device__ static float dst_scalar(const Params& p, int v) { return dinv(p.out_deg[v]); }
+    __device__ static void dst_stage(const Params& p, int v, float* o) {
+        const int d = p.out_deg[v];
+        o[0] = dinv(d);
+        o[1] = (float)(d + 1);
+    }
+    __device__ static const float* const_ptr(const Params& p) { return p.ep; }
     __device__ static void init(Acc& a) { a.m = make_float4(0.f, 0.f, 0.f, 0.f); }
-    __device__ static void edge(Acc& a, const float4& x, const float4& w, float ss, float sd) {
-        const float norm = ss * sd;
+    __device__ static void edge(Acc& a, const float4& x, const float4& w, float ss, const float* sd) {
+        const float norm = ss * sd[0];
         a.m.x += norm * relu1(w.x + x.x); a.m.y += norm * relu1(w.y + x.y);
         a.m.z += norm * relu1(w.z + x.z); a.m.w += norm * relu1(w.w + x.w);
     }
-    __device__ static void finish(const Params& p, const Acc& a, const float4& xs, int v, int c, int, float* out) {
-        const GcnEpilogue& ep = p.ep;
-        const float4 rt = reinterpret_cast<const float4*>(ep.root)[c];
-        const float4 mu = reinterpret_cast<const float4*>(ep.bn_mean)[c];
-        const float4 sv = reinterpret_cast<const float4*>(ep.bn_sqrtv)[c];
-        const float4 bw = reinterpret_cast<const float4*>(ep.bn_w)[c];
-        const float4 bb = reinterpret_cast<const float4*>(ep.bn_b)[c];
-        const float dp1 = (float)(p.out_deg[v] + 1);
+    __device__ static void finish(const Params&, const Acc& a, const float4& xs, int v, int c, int, const float* sd,
+                                  const float* cst, float* out) {
+        const float4 rt = reinterpret_cast<const float4*>(cst)[c];
+        const float4 mu = reinterpret_cast<const float4*>(cst + GCN_D)[c];
+        const float4 sv = reinterpret_cast<const float4*>(cst + 2 * GCN_D)[c];
+        const float4 bw = reinterpret_cast<const float4*>(cst + 3 * GCN_D)[c];
+        const float4 bb = reinterpret_cast<const float4*>(cst + 4 * GCN_D)[c];
+        const float dp1 = sd[1];
         float4 r;
         r.x = (a.m.x + relu1(xs.x + rt.x) / dp1 - mu.x) / sv.x * bw.x + bb.x;
         r.y = (a.m.y + relu1(xs.y + rt.y) / dp1 - mu.y) / sv.y * bw.y + bb.y;
@@ -160,7 +167,7 @@ public:
 
     template <bool RELU_OUT>
     void launch_aggregate(const DeviceBatch& db, int l, const float* x, float* a, hipStream_t s) {
-        typename GcnAggPolicy<RELU_OUT>::Params prm{db.csr.out_deg, epilogue(l)};
+        typename GcnAggPolicy<RELU_OUT>::Params prm{db.csr.out_deg, d_ep_ + (size_t)l * 5 * GCN_D};
         launch_tiled_aggregate<GcnAggPolicy<RELU_OUT>>(prm, x, a, db.csr, d_ecomb_ + (size_t)l * EDGE_COMBOS * GCN_D, db.b.n_tot, s);
     }
 

@@ -34,17 +34,19 @@ constexpr float PNA_SENT_MIN = -32.0f;          // ap_fixed_min, PNA/src/util.h:
 struct PnaAggPolicy {
     static constexpr int D = PNA_D, TR = 128, NTHR = 512, TE = 20 * 128, TABLE_ROWS = 0;
     static constexpr bool HAS_SCALAR = false;
+    static constexpr int NDST = 0, CONST_FLOATS = 0;
     struct Params { int unused; };
     struct Acc { float4 S, Q, mn, mx; };
     __device__ static float src_scalar(const Params&, int) { return 0.f; }
-    __device__ static float dst_scalar(const Params&, int) { return 0.f; }
+    __device__ static void dst_stage(const Params&, int, float*) {}
+    __device__ static const float* const_ptr(const Params&) { return nullptr; }
     __device__ static void init(Acc& a) {
         a.S = make_float4(0.f, 0.f, 0.f, 0.f);
         a.Q = a.S;
         a.mn = make_float4(PNA_SENT_MAX, PNA_SENT_MAX, PNA_SENT_MAX, PNA_SENT_MAX);
         a.mx = make_float4(PNA_SENT_MIN, PNA_SENT_MIN, PNA_SENT_MIN, PNA_SENT_MIN);
     }
-    __device__ static void edge(Acc& a, const float4& x, const float4&, float, float) {
+    __device__ static void edge(Acc& a, const float4& x, const float4&, float, const float*) {
         a.S.x += x.x; a.S.y += x.y; a.S.z += x.z; a.S.w += x.w;
         a.Q.x += x.x * x.x; a.Q.y += x.y * x.y; a.Q.z += x.z * x.z; a.Q.w += x.w * x.w;
         a.mn.x = x.x < a.mn.x ? x.x : a.mn.x; a.mn.y = x.y < a.mn.y ? x.y : a.mn.y;
@@ -52,7 +54,8 @@ struct PnaAggPolicy {
         a.mx.x = x.x > a.mx.x ? x.x : a.mx.x; a.mx.y = x.y > a.mx.y ? x.y : a.mx.y;
         a.mx.z = x.z > a.mx.z ? x.z : a.mx.z; a.mx.w = x.w > a.mx.w ? x.w : a.mx.w;
     }
-    __device__ static void finish(const Params&, const Acc& a, const float4&, int v, int c, int indeg, float* out) {
+    __device__ static void finish(const Params&, const Acc& a, const float4&, int v, int c, int indeg, const float*, const float*,
+                                  float* out) {
         const float deg = (float)(indeg == 0 ? 1 : indeg);
         float4 mean, sd;
         mean.x = a.S.x / deg; mean.y = a.S.y / deg; mean.z = a.S.z / deg; mean.w = a.S.w / deg;
