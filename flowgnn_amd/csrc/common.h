@@ -53,7 +53,8 @@ struct CsrView {
 };
 
 // graph_build.hip
-void launch_build_csr(const BatchView& b, const CsrView& c, bool has_edge_attr, hipStream_t s);
+// max_nodes / max_edges: largest graph of the batch (selects the per-graph LDS build or the flat global build)
+void launch_build_csr(const BatchView& b, const CsrView& c, bool has_edge_attr, int max_nodes, int max_edges, hipStream_t s);
 
 }  // namespace fg
 

@@ -100,6 +100,7 @@ struct flowgnn_engine {
     bool batch_ready = false;
     bool ran = false;
     long long G = 0, N = 0, E = 0;
+    int max_nodes = 0, max_edges = 0;
     size_t capG = 0, capN = 0, capE = 0;
     int *d_nn = nullptr, *d_ne = nullptr, *d_noff = nullptr, *d_eoff = nullptr;
     int *d_nf = nullptr, *d_el = nullptr, *d_ea = nullptr;
@@ -267,6 +268,7 @@ int flowgnn_set_batch(flowgnn_engine* e, int num_graphs, const int* nums_of_node
     // (GIN/src/GIN_compute.cc:44,96-97)
     std::vector<int> noff((size_t)num_graphs + 1), eoff((size_t)num_graphs + 1);
     long long N = 0, E = 0;
+    int mx_n = 0, mx_e = 0;
     for (int g = 0; g < num_graphs; g++) {
         if (nums_of_nodes[g] <= 0 || nums_of_edges[g] < 0) {
             e->err = "graph with num_of_nodes <= 0 or num_of_edges < 0";
@@ -274,6 +276,8 @@ int flowgnn_set_batch(flowgnn_engine* e, int num_graphs, const int* nums_of_node
         }
         noff[g] = (int)N;
         eoff[g] = (int)E;
+        if (nums_of_nodes[g] > mx_n) mx_n = nums_of_nodes[g];
+        if (nums_of_edges[g] > mx_e) mx_e = nums_of_edges[g];
         N += nums_of_nodes[g];
         E += nums_of_edges[g];
         if (N > 0x7fffffffLL / 128 || E > 0x7fffffffLL / 4) {
@@ -307,6 +311,7 @@ int flowgnn_set_batch(flowgnn_engine* e, int num_graphs, const int* nums_of_node
     if (eig) ENGINE_TRY(e, h2d(e->d_eig, node_eigen, sizeof(float) * (size_t)N * 4));
 
     e->G = num_graphs; e->N = N; e->E = E;
+    e->max_nodes = mx_n; e->max_edges = mx_e;
     e->has_attr = attr; e->has_eig = eig;
     DeviceBatch& db = e->db;
     db.b.num_graphs = num_graphs; db.b.n_tot = (int)N; db.b.e_tot = (int)E;
@@ -337,7 +342,8 @@ int flowgnn_run(flowgnn_engine* e) {
     if (e->G == 0) { e->ran = true; return FLOWGNN_OK; }
     {
         ProfScope p(e->prof, "build_csr", e->stream);
-        launch_build_csr(e->db.b, e->db.csr, e->has_attr, e->stream);
+        const bool flat = getenv("FLOWGNN_CSR_FLAT") && atoi(getenv("FLOWGNN_CSR_FLAT")) != 0;  // A/B: force the global path
+        launch_build_csr(e->db.b, e->db.csr, e->has_attr, flat ? (1 << 30) : e->max_nodes, flat ? (1 << 30) : e->max_edges, e->stream);
     }
     e->db.tap = nullptr;
     e->db.tap_dim = 0;

@@ -24,13 +24,6 @@ constexpr int GCN_L = 5;
 constexpr int GCN_C = GCN_D / 4;
 constexpr int GCN_OT = 7;
 
-struct GcnEpilogue {
-    const float* root;      // [100]
-    const float* bn_mean;   // [100]
-    const float* bn_sqrtv;  // [100] sqrt(var + 2^-10)
-    const float* bn_w;      // [100]
-    const float* bn_b;      // [100]
-};
 
 // a[v] = epilogue( sum_e norm_e relu(x[src_e] + ecomb[code_e]), x[v], outdeg[v] ), CSR order: policy of the generic
 // tiled aggregation (device_common.h).  norm_e = dinv[u] dinv[v] with dinv from the out-degree table.
@@ -38,11 +31,11 @@ template <bool RELU_OUT>
 struct GcnAggPolicy {
     static constexpr int D = GCN_D, TR = 128, NTHR = 512, TE = 8 * 128, TABLE_ROWS = EDGE_COMBOS;
     static constexpr bool HAS_SCALAR = true;
-    static constexpr int NDST = 2;                 // dinv[v], outdeg(v) + 1
-    static constexpr int CONST_FLOATS = 5 * GCN_D;  // root | bn_mean | bn_sqrtv | bn_w | bn_b of the layer
+    static constexpr int NDST = 2;                 // dinv[v], 1 / (outdeg(v) + 1)
+    static constexpr int CONST_FLOATS = 3 * GCN_D;  // root | folded BN scale | folded BN shift of the layer
     struct Params {
         const int* out_deg;
-        const float* ep;  // the five epilogue vectors, contiguous
+        const float* ep;  // the three epilogue vectors, contiguous
     };
     struct Acc { float4 m; };
     __device__ static float dinv(int d) { return d > 0 ? 1.0f / sqrtf((float)(d + 1)) : 0.0f; }  // load_inputs.cc:122
@@ -50,7 +43,7 @@ struct GcnAggPolicy {
     __device__ static void dst_stage(const Params& p, int v, float* o) {
         const int d = p.out_deg[v];
         o[0] = dinv(d);
-        o[1] = (float)(d + 1);
+        o[1] = 1.0f / (float)(d + 1);
     }
     __device__ static const float* const_ptr(const Params& p) { return p.ep; }
     __device__ static void init(Acc& a) { a.m = make_float4(0.f, 0.f, 0.f, 0.f); }
@@ -61,17 +54,17 @@ struct GcnAggPolicy {
     }
     __device__ static void finish(const Params&, const Acc& a, const float4& xs, int v, int c, int, const float* sd,
                                   const float* cst, float* out) {
+        // BatchNorm folded on the host: (t - mean) / sqrt(var + 2^-10) * w + b  ==  t * scale + shift (one FMA instead of
+        // a subtract, an IEEE divide, a multiply and an add); 1 / (deg + 1) is staged per row.
         const float4 rt = reinterpret_cast<const float4*>(cst)[c];
-        const float4 mu = reinterpret_cast<const float4*>(cst + GCN_D)[c];
-        const float4 sv = reinterpret_cast<const float4*>(cst + 2 * GCN_D)[c];
-        const float4 bw = reinterpret_cast<const float4*>(cst + 3 * GCN_D)[c];
-        const float4 bb = reinterpret_cast<const float4*>(cst + 4 * GCN_D)[c];
-        const float dp1 = sd[1];
+        const float4 sc = reinterpret_cast<const float4*>(cst + GCN_D)[c];
+        const float4 sh = reinterpret_cast<const float4*>(cst + 2 * GCN_D)[c];
+        const float idp1 = sd[1];
         float4 r;
-        r.x = (a.m.x + relu1(xs.x + rt.x) / dp1 - mu.x) / sv.x * bw.x + bb.x;
-        r.y = (a.m.y + relu1(xs.y + rt.y) / dp1 - mu.y) / sv.y * bw.y + bb.y;
-        r.z = (a.m.z + relu1(xs.z + rt.z) / dp1 - mu.z) / sv.z * bw.z + bb.z;
-        r.w = (a.m.w + relu1(xs.w + rt.w) / dp1 - mu.w) / sv.w * bw.w + bb.w;
+        r.x = (a.m.x + relu1(xs.x + rt.x) * idp1) * sc.x + sh.x;
+        r.y = (a.m.y + relu1(xs.y + rt.y) * idp1) * sc.y + sh.y;
+        r.z = (a.m.z + relu1(xs.z + rt.z) * idp1) * sc.z + sh.z;
+        r.w = (a.m.w + relu1(xs.w + rt.w) * idp1) * sc.w + sh.w;
         if (RELU_OUT) { r.x = relu1(r.x); r.y = relu1(r.y); r.z = relu1(r.z); r.w = relu1(r.w); }
         reinterpret_cast<float4*>(out)[(size_t)v * GCN_C + c] = r;
     }
@@ -92,7 +85,7 @@ public:
         const float *nemb = t[0], *eemb = t[1], *cw = t[2], *cb = t[3], *root = t[4], *bnw = t[5], *bnb = t[6], *bnm = t[7],
                     *bnv = t[8], *pw = t[9], *pb = t[10];
         std::vector<float> v_nemb(nemb, nemb + ND_FEATURE_TOTAL * GCN_D), v_pw(pw, pw + GCN_D), v_pb(pb, pb + 1);
-        std::vector<float> ecomb((size_t)GCN_L * EDGE_COMBOS * GCN_D), ep((size_t)GCN_L * 5 * GCN_D);
+        std::vector<float> ecomb((size_t)GCN_L * EDGE_COMBOS * GCN_D), ep((size_t)GCN_L * 3 * GCN_D);
         std::vector<float> wf_all, wt_all, bp_all;
         static const int ed_off[3] = {0, 5, 11};
         for (int l = 0; l < GCN_L; l++) {
@@ -107,13 +100,13 @@ public:
                             s += E[(ed_off[2] + a2) * GCN_D + d];
                             ecomb[((size_t)l * EDGE_COMBOS + (a0 * 6 + a1) * 2 + a2) * GCN_D + d] = s;
                         }
-            float* e = &ep[(size_t)l * 5 * GCN_D];
+            float* e = &ep[(size_t)l * 3 * GCN_D];
             for (int d = 0; d < GCN_D; d++) {
+                const double sv = sqrt((double)(bnv[l * GCN_D + d] + 1.0f / 1024.0f));  // load_inputs.cc:32
+                const double scale = (double)bnw[l * GCN_D + d] / sv;
                 e[0 * GCN_D + d] = root[l * GCN_D + d];
-                e[1 * GCN_D + d] = bnm[l * GCN_D + d];
-                e[2 * GCN_D + d] = sqrtf(bnv[l * GCN_D + d] + 1.0f / 1024.0f);  // load_inputs.cc:32
-                e[3 * GCN_D + d] = bnw[l * GCN_D + d];
-                e[4 * GCN_D + d] = bnb[l * GCN_D + d];
+                e[1 * GCN_D + d] = (float)scale;
+                e[2 * GCN_D + d] = (float)((double)bnb[l * GCN_D + d] - (double)bnm[l * GCN_D + d] * scale);
             }
             std::vector<float> wf, wt, bp;
             pack_dense100(cw + (size_t)l * GCN_D * GCN_D, cb + (size_t)l * GCN_D, GCN_D, GCN_OT, wf, wt, bp);
@@ -160,14 +153,10 @@ public:
         return set_weights(t);
     }
 
-    GcnEpilogue epilogue(int l) const {
-        const float* e = d_ep_ + (size_t)l * 5 * GCN_D;
-        return GcnEpilogue{e, e + GCN_D, e + 2 * GCN_D, e + 3 * GCN_D, e + 4 * GCN_D};
-    }
 
     template <bool RELU_OUT>
     void launch_aggregate(const DeviceBatch& db, int l, const float* x, float* a, hipStream_t s) {
-        typename GcnAggPolicy<RELU_OUT>::Params prm{db.csr.out_deg, d_ep_ + (size_t)l * 5 * GCN_D};
+        typename GcnAggPolicy<RELU_OUT>::Params prm{db.csr.out_deg, d_ep_ + (size_t)l * 3 * GCN_D};
         launch_tiled_aggregate<GcnAggPolicy<RELU_OUT>>(prm, x, a, db.csr, d_ecomb_ + (size_t)l * EDGE_COMBOS * GCN_D, db.b.n_tot, s);
     }
 

@@ -169,7 +169,116 @@ __global__ __launch_bounds__(256) void rank_kernel(CsrView c, int e_tot, const i
     if (code_by_edge) c.ecode[beg + rank] = (uint8_t)code_by_edge[e];
 }
 
-void launch_build_csr(const BatchView& b, const CsrView& c, bool has_edge_attr, hipStream_t s) {
+// ------------------------------------------------------------------ per-graph build in LDS
+// A graph's edges are a contiguous slice of the edge list and its CSR rows a contiguous slice of the CSR, so one
+// workgroup can build a whole graph's rows in LDS with no global atomics and no global scratch: histogram, scan,
+// cursor placement, rank sort -- the same four steps as above, on LDS copies of the endpoints.  Global traffic is one
+// read of the edge list / attributes and one write of row_ptr / src / eid / ecode / out_deg.  Used when every graph of
+// the batch fits the class (the reference itself caps graphs at 500 nodes / 5500 edges, GIN/src/dcl.h:17-18);
+// otherwise the flat global path above runs.  Same output, bit for bit (the keys are unique).
+template <int NT, int NMAX, int EMAX, typename IdxT>
+__global__ __launch_bounds__(NT) void build_csr_graph_kernel(BatchView b, CsrView c, bool has_attr) {
+    __shared__ int s_cnt[NMAX + 1];   // in-degree, then exclusive scan = row start
+    __shared__ int s_cur[NMAX];
+    __shared__ int s_odeg[NMAX];
+    __shared__ IdxT s_u[EMAX], s_v[EMAX], s_slot[EMAX];
+    __shared__ uint8_t s_code[EMAX];
+    __shared__ int s_wtot[NT / 64];
+    const int g = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int n = b.nums_of_nodes[g];
+    const int noff = b.node_off[g];
+    const int e0 = b.edge_off[g];
+    const int ne = b.edge_off[g + 1] - e0;
+    for (int i = tid; i <= n; i += NT) {
+        s_cnt[i] = 0;
+        if (i < n) { s_cur[i] = 0; s_odeg[i] = 0; }
+    }
+    __syncthreads();
+    for (int e = tid; e < ne; e += NT) {
+        const int2 uv = reinterpret_cast<const int2*>(b.edge_list)[e0 + e];
+        int u = uv.x, v = uv.y;
+        if (!((u >= 0) & (u < n) & (v >= 0) & (v < n))) {
+            atomicMax(c.err, ERR_EDGE_RANGE);
+            u = 0;
+            v = 0;
+        }
+        s_u[e] = (IdxT)u;
+        s_v[e] = (IdxT)v;
+        atomicAdd(&s_cnt[v], 1);
+        atomicAdd(&s_odeg[u], 1);
+        int code = 0;
+        if (has_attr) {
+            const int a0 = b.edge_attr[3 * (size_t)(e0 + e)], a1 = b.edge_attr[3 * (size_t)(e0 + e) + 1],
+                      a2 = b.edge_attr[3 * (size_t)(e0 + e) + 2];
+            const bool aok = (a0 >= 0) & (a0 < 5) & (a1 >= 0) & (a1 < 6) & (a2 >= 0) & (a2 < 2);
+            if (!aok) atomicMax(c.err, ERR_EDGE_ATTR);
+            code = aok ? (a0 * 6 + a1) * 2 + a2 : 0;
+        }
+        s_code[e] = (uint8_t)code;
+    }
+    __syncthreads();
+    // exclusive scan of s_cnt[0..n) in place, s_cnt[n] = ne
+    {
+        constexpr int PER = (NMAX + NT - 1) / NT;
+        int vals[PER], sum = 0;
+#pragma unroll
+        for (int k = 0; k < PER; k++) {
+            const int i = tid * PER + k;
+            vals[k] = i < n ? s_cnt[i] : 0;
+            sum += vals[k];
+        }
+        const int incl = wave_inclusive_scan(sum);
+        if ((tid & 63) == 63) s_wtot[tid >> 6] = incl;
+        __syncthreads();
+        int base = incl - sum;
+        for (int w = 0; w < (tid >> 6); w++) base += s_wtot[w];
+#pragma unroll
+        for (int k = 0; k < PER; k++) {
+            const int i = tid * PER + k;
+            if (i < n) s_cnt[i] = base;
+            base += vals[k];
+        }
+        if (tid == 0) s_cnt[n] = ne;
+    }
+    __syncthreads();
+    for (int i = tid; i < n; i += NT) {
+        c.row_ptr[noff + i] = e0 + s_cnt[i];
+        c.out_deg[noff + i] = s_odeg[i];
+    }
+    if (g == b.num_graphs - 1 && tid == 0) c.row_ptr[b.n_tot] = b.e_tot;
+    for (int e = tid; e < ne; e += NT) {
+        const int v = s_v[e];
+        s_slot[s_cnt[v] + atomicAdd(&s_cur[v], 1)] = (IdxT)e;
+    }
+    __syncthreads();
+    for (int sl = tid; sl < ne; sl += NT) {
+        const int e = s_slot[sl];
+        const int v = s_v[e], u = s_u[e];
+        const int beg = s_cnt[v], end = s_cnt[v + 1];
+        int rank = 0;
+        for (int t = beg; t < end; t++) {
+            const int e2 = s_slot[t];
+            const int u2 = s_u[e2];
+            rank += (u2 < u) | ((u2 == u) & (e2 < e));
+        }
+        const int pos = e0 + beg + rank;
+        c.src[pos] = noff + u;
+        c.eid[pos] = e0 + e;
+        if (has_attr) c.ecode[pos] = s_code[e];
+    }
+}
+
+void launch_build_csr(const BatchView& b, const CsrView& c, bool has_edge_attr, int max_nodes, int max_edges, hipStream_t s) {
+    if (b.num_graphs > 0 && max_nodes <= 256 && max_edges <= 1024) {
+        build_csr_graph_kernel<64, 256, 1024, uint16_t><<<b.num_graphs, 64, 0, s>>>(b, c, has_edge_attr);
+        return;
+    }
+    if (b.num_graphs > 0 && max_nodes <= 2048 && max_edges <= 16384) {
+        build_csr_graph_kernel<256, 2048, 16384, uint16_t><<<b.num_graphs, 256, 0, s>>>(b, c, has_edge_attr);
+        return;
+    }
+    // flat global path: any graph size
     // c.tmp holds [E] edge codes (first half) and [E] slot->edge map (second half): sized 2E by the engine
     int* code_by_edge = c.tmp;
     int* slot_edge = c.tmp + b.e_tot;
