@@ -99,6 +99,8 @@ struct flowgnn_engine {
     // resident batch
     bool batch_ready = false;
     bool ran = false;
+    bool force_exact = false;   // the resident batch tripped the range flag once: run it on the exact kernels
+    int exact_reruns = 0;
     long long G = 0, N = 0, E = 0;
     int max_nodes = 0, max_edges = 0;
     size_t capG = 0, capN = 0, capE = 0;
@@ -159,8 +161,8 @@ int flowgnn_create(int model, int device_id, flowgnn_engine** out) {
     int rc = use_device(e);
     if (!rc) {
         hipError_t he = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
-        if (he == hipSuccess) he = hipMalloc((void**)&e->d_err, sizeof(int));
-        if (he == hipSuccess) he = hipMemset(e->d_err, 0, sizeof(int));
+        if (he == hipSuccess) he = hipMalloc((void**)&e->d_err, 2 * sizeof(int));  // [0] validation, [1] range flag
+        if (he == hipSuccess) he = hipMemset(e->d_err, 0, 2 * sizeof(int));
         if (he != hipSuccess) {
             set_hip_error("engine init", he, __FILE__, __LINE__);
             rc = FLOWGNN_ERR_HIP;
@@ -327,7 +329,9 @@ int flowgnn_set_batch(flowgnn_engine* e, int num_graphs, const int* nums_of_node
     db.final_h = 0;
     db.tap = nullptr;
     db.tap_dim = 0;
-    FG_HIP_TRY(hipMemset(e->d_err, 0, sizeof(int)));
+    FG_HIP_TRY(hipMemset(e->d_err, 0, 2 * sizeof(int)));
+    e->db.range_flag = e->d_err + 1;
+    e->force_exact = false;
     e->batch_ready = true;
     return FLOWGNN_OK;
 }
@@ -347,6 +351,7 @@ int flowgnn_run(flowgnn_engine* e) {
     }
     e->db.tap = nullptr;
     e->db.tap_dim = 0;
+    e->model->set_exact(e->force_exact);
     ENGINE_TRY(e, e->model->forward(e->db, e->prof, e->stream));
     hipError_t he = hipGetLastError();
     if (he != hipSuccess) {
@@ -368,12 +373,29 @@ int flowgnn_sync(flowgnn_engine* e) {
         return FLOWGNN_ERR_HIP;
     }
     e->prof.collect();
-    int flag = 0;
-    he = hipMemcpy(&flag, e->d_err, sizeof(int), hipMemcpyDeviceToHost);
+    int flags[2] = {0, 0};
+    he = hipMemcpy(flags, e->d_err, sizeof(flags), hipMemcpyDeviceToHost);
     if (he != hipSuccess) {
         set_hip_error("read error flag", he, __FILE__, __LINE__);
         e->err = fg::last_error_text();
         return FLOWGNN_ERR_HIP;
+    }
+    const int flag = flags[0];
+    if (!flag && flags[1] && e->ran && !e->force_exact) {
+        // an operand left the range in which the default kernels are fp32-accurate: repeat the pass on the exact
+        // kernels, and keep this batch on them for later runs
+        e->force_exact = true;
+        e->exact_reruns++;
+        FG_HIP_TRY(hipMemsetAsync(e->d_err + 1, 0, sizeof(int), e->stream));
+        e->model->set_exact(true);
+        ENGINE_TRY(e, e->model->forward(e->db, e->prof, e->stream));
+        he = hipStreamSynchronize(e->stream);
+        if (he != hipSuccess) {
+            set_hip_error("hipStreamSynchronize (exact re-run)", he, __FILE__, __LINE__);
+            e->err = fg::last_error_text();
+            return FLOWGNN_ERR_HIP;
+        }
+        e->prof.collect();
     }
     if (flag) {
         e->err = "input validation failed on device (edge endpoint / edge attribute / node feature out of range)";
@@ -427,6 +449,8 @@ int flowgnn_batch_info(const flowgnn_engine* e, long long* num_graphs, long long
     if (total_edges) *total_edges = e->E;
     return FLOWGNN_OK;
 }
+
+int flowgnn_exact_reruns(const flowgnn_engine* e) { return e ? e->exact_reruns : -1; }
 
 int flowgnn_get_csr(flowgnn_engine* e, int* row_ptr, int* src, int* eid, int* out_deg) {
     if (!e) return FLOWGNN_ERR_ARG;

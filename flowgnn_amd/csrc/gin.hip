@@ -15,6 +15,7 @@
 //                   as B operands (no LDS round trip, no transpose)
 #include "common.h"
 #include "device_common.h"
+#include "gin_split.h"
 #include <cstring>
 #include <cstdio>
 #include <cstdlib>
@@ -991,7 +992,13 @@ public:
                     memcpy(ck + 1600, &w2f[(((size_t)l * GIN_T1 + (c - 1)) * GIN_T2) * 64 * 4], sizeof(float) * GIN_T2 * 64 * 4);
                 memcpy(ck + 3408, &b2p[(size_t)l * GIN_T2 * 16], sizeof(float) * GIN_T2 * 16);
             }
+        // weight stream of the split-f16 layer kernel (gin_split.hip)
+        std::vector<uint8_t> split((size_t)GIN_L * GS_LAYER_BYTES);
+        for (int l = 0; l < GIN_L; l++)
+            gin_split_pack_layer(w1 + (size_t)l * GIN_H * GIN_D, b1 + (size_t)l * GIN_H, w2 + (size_t)l * GIN_D * GIN_H,
+                                 b2 + (size_t)l * GIN_D, split.data() + (size_t)l * GS_LAYER_BYTES);
         int rc;
+        if ((rc = upload(&d_split_, split))) return rc;
         if ((rc = upload(&d_chunks_, chunks))) return rc;
         if ((rc = upload(&d_nemb_, v_nemb))) return rc;
         if ((rc = upload(&d_pw_, v_pw))) return rc;
@@ -1085,7 +1092,14 @@ public:
         }
         int cur = 0;
         for (int l = 0; l < GIN_L; l++) {
-            if (fused_ && pipelined_) {
+            if (fused_ && variant_ == 0 && split_ && !exact_) {
+                ProfScope p(prof, "gin_layer_fused", s);
+                launch_gin_layer_split(db.h[cur], db.h[cur ^ 1], db.csr.row_ptr, db.csr.src, db.csr.ecode, layer_dev(l).ecomb,
+                                       d_split_ + (size_t)l * GS_LAYER_BYTES, n, l != GIN_L - 1, db.range_flag, split_nt_, s);
+                cur ^= 1;
+                continue;
+            }
+            if (fused_ && variant_ == 1) {
                 ProfScope p(prof, "gin_layer_fused", s);
                 const int n_tiles = (int)ceil_div_ll(n, 64);
                 int grid = 256 * 2;  // persistent: two workgroups per CU
@@ -1128,6 +1142,8 @@ public:
         return 0;
     }
 
+    void set_exact(bool on) override { exact_ = on; }
+
     int aggregation_only(DeviceBatch& db, int layer, hipStream_t s) override {
         if (layer < 0 || layer >= GIN_L) return 1;
         launch_aggregate(db, layer, db.h[db.final_h], db.scratch, s);
@@ -1139,14 +1155,20 @@ private:
         float** ptrs[] = {&d_chunks_, &d_nemb_, &d_pw_, &d_pb_, &d_ecomb_, &d_w1f_, &d_w1tail_, &d_b1p_, &d_w2f_, &d_b2p_};
         for (auto p : ptrs)
             if (*p) { hipFree(*p); *p = nullptr; }
+        if (d_split_) { hipFree(d_split_); d_split_ = nullptr; }
     }
     bool ready_ = false;
     // FLOWGNN_GIN_UNFUSED=1 keeps the two-kernel layer (aggregate + mlp) for A/B measurements
     bool fused_ = !(getenv("FLOWGNN_GIN_UNFUSED") && atoi(getenv("FLOWGNN_GIN_UNFUSED")) != 0);
-    // FLOWGNN_GIN_PIPELINED=1 selects the persistent, software-pipelined variant (experimental: measured
-    // 6.2 ms/layer vs 5.3 ms for the plain fused kernel at 2^18 molhiv graphs -- two waves per SIMD fall
-    // into lock step and expose the per-step LDS/barrier time; kept for the ping-pong follow-up)
-    bool pipelined_ = getenv("FLOWGNN_GIN_PIPELINED") && atoi(getenv("FLOWGNN_GIN_PIPELINED")) != 0;
+    // FLOWGNN_GIN_LAYER selects the fused-layer kernel for A/B runs: 0 = gin_layer_fused_kernel (one tile per
+    // workgroup, 3 workgroups per CU), 1 = gin_layer_pipelined_kernel
+    int variant_ = getenv("FLOWGNN_GIN_LAYER") ? atoi(getenv("FLOWGNN_GIN_LAYER")) : 0;
+    // FLOWGNN_GIN_MFMA=f32 keeps the dense update on the fp32 matrix pipe (gin_layer_fused_kernel); the default runs it
+    // as three f16 MFMAs per product (gin_split.hip), with the engine falling back to fp32 when the range flag trips
+    bool split_ = !(getenv("FLOWGNN_GIN_MFMA") && strcmp(getenv("FLOWGNN_GIN_MFMA"), "f32") == 0);
+    int split_nt_ = getenv("FLOWGNN_GIN_SPLIT_NT") ? atoi(getenv("FLOWGNN_GIN_SPLIT_NT")) : 1;
+    bool exact_ = false;
+    uint8_t* d_split_ = nullptr;
     float* d_chunks_ = nullptr;
     float *d_nemb_ = nullptr, *d_pw_ = nullptr, *d_pb_ = nullptr, *d_ecomb_ = nullptr, *d_w1f_ = nullptr,
           *d_w1tail_ = nullptr, *d_b1p_ = nullptr, *d_w2f_ = nullptr, *d_b2p_ = nullptr;

@@ -1,0 +1,30 @@
+// GIN layer with the dense 100->200->100 update on the f16 matrix pipe, fp32-accurate by operand splitting.
+// See gin_split.hip for the scheme; gin.hip owns the model and decides which layer kernel runs.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+#include <cstdint>
+
+namespace fg {
+
+// weight stream: 8 chunks per layer; chunk s = W1 fragments of hidden tiles 2s, 2s+1 (absent for s = 7) +
+// W2 fragments of K-step s-1 (absent for s = 0, where the space holds b2 and the output scale)
+constexpr int GS_STEPS = 8;
+constexpr int GS_TAIL_OFF = 12288;     // bytes [0,12288): 2 hidden tiles x 3 K-steps x {hi,lo} x 1 KiB
+constexpr int GS_B1_OFF = 12800;       // bytes [12288,12800): fp32 K-tail fragments, 2 x 64 floats
+constexpr int GS_W2_OFF = 12928;       // bytes [12800,12928): b1 slices, 2 x 16 floats
+constexpr int GS_CHUNK_BYTES = 27264;  // bytes [12928,27264): 7 output tiles x {hi,lo} x 1 KiB
+constexpr int GS_CHUNK_STRIDE = 27648; // in global memory: 27 pieces of 1 KiB
+constexpr size_t GS_LAYER_BYTES = (size_t)GS_STEPS * GS_CHUNK_STRIDE;
+
+// w1[200][100], b1[200], w2[100][200], b2[100] (row-major, host) -> GS_LAYER_BYTES at `out` (host)
+void gin_split_pack_layer(const float* w1, const float* b1, const float* w2, const float* b2, uint8_t* out);
+
+// one GIN layer: hout = MLP(h[v] + sum_e relu(h[src_e] + ecomb[code_e])); *range_flag |= 1 if an operand left the
+// range in which the split is fp32-accurate (the caller then repeats the forward pass on the fp32 MFMA kernel)
+void launch_gin_layer_split(const float* h, float* hout, const int* row_ptr, const int* src, const uint8_t* ecode,
+                            const float* ecomb, const uint8_t* chunks, int n_tot, int relu_out, int* range_flag, int nt,
+                            hipStream_t s);
+
+}  // namespace fg

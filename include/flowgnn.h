@@ -217,6 +217,16 @@ int flowgnn_batch_info(const flowgnn_engine* e, long long* num_graphs,
                        long long* total_nodes, long long* total_edges);
 
 /*
+ * Number of forward passes this engine repeated on its exact-fp32 kernels because
+ * an operand left the range in which the default kernels are fp32-accurate (GIN:
+ * the dense update runs as three f16 MFMAs per product, accurate to 2^-20 while
+ * |activation| < 6e4; the reference's own Q6.10 activations live in [-32,32)).
+ * The check happens in flowgnn_sync / flowgnn_get_results: device-side consumers
+ * of flowgnn_results_device must call flowgnn_sync first.  -1 for a null handle.
+ */
+int flowgnn_exact_reruns(const flowgnn_engine* e);
+
+/*
  * Debug / parity taps (device -> host copies; synchronise first).
  *  flowgnn_get_csr: the batched destination-major CSR built by load_graph:
  *     row_ptr[N_tot+1], src[E_tot] (global source id, ascending per row, ties in
