@@ -19,6 +19,11 @@ __device__ inline float4 load_f4_rare(const float4* p) {
     asm volatile("global_load_dwordx4 %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
     return make_float4(v.x, v.y, v.z, v.w);
 }
+__device__ inline float load_f32_rare(const float* p) {
+    float v;
+    asm volatile("global_load_dword %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
 __device__ inline int load_i32_rare(const int* p) {
     int v;
     asm volatile("global_load_dword %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
