@@ -21,8 +21,8 @@ constexpr size_t GS_LAYER_BYTES = (size_t)GS_STEPS * GS_CHUNK_STRIDE;
 // w1[200][100], b1[200], w2[100][200], b2[100] (row-major, host) -> GS_LAYER_BYTES at `out` (host)
 void gin_split_pack_layer(const float* w1, const float* b1, const float* w2, const float* b2, uint8_t* out);
 
-// variant: 3 = persistent tile-staged kernel (default; molecule-like batches), 1 / 2 = one workgroup per 64 / 128
-// nodes (any degree distribution), 0 = persistent with register-pipelined gather (kept for A/B runs)
+// variant: 1 / 2 = one workgroup per 64 / 128 nodes (any degree distribution; 1 is the default), 3 = persistent
+// tile-staged kernel for molecule-like batches (FLOWGNN_GIN_SPLIT_NT=3; see gin_split.hip for what it does and costs)
 // one GIN layer: hout = MLP(h[v] + sum_e relu(h[src_e] + ecomb[code_e])); *range_flag |= 1 if an operand left the
 // range in which the split is fp32-accurate (the caller then repeats the forward pass on the fp32 MFMA kernel)
 void launch_gin_layer_split(const float* h, float* hout, const int* row_ptr, const int* src, const uint8_t* ecode,

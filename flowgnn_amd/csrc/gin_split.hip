@@ -29,10 +29,10 @@
 #include <cmath>
 #include <cstring>
 #include <cstdlib>
+#include <cstdio>
 #include <vector>
 
 #include "device_common.h"
-#include "gin_pipe.h"
 
 namespace fg {
 
@@ -60,10 +60,11 @@ typedef uint32_t uint4_t __attribute__((ext_vector_type(4)));
         (LO) = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(a_ - (float)hp_.x, b_ - (float)hp_.y));   \
     } while (0)
 
+template <int WAVES>
 __device__ __forceinline__ void gs_issue_chunk(const uint8_t* __restrict__ gchunk, char* lds_buf, int wave, int lane) {
 #pragma unroll
-    for (int p = 0; p < 7; p++) {
-        const int piece = wave + 4 * p;  // 26 full pieces of 1 KiB + 640 B
+    for (int p = 0; p < (27 + WAVES - 1) / WAVES; p++) {
+        const int piece = wave + WAVES * p;  // 26 full pieces of 1 KiB + 640 B
         if (piece < 26 || (piece == 26 && lane < 40)) {
             const uint8_t* g = gchunk + piece * 1024 + lane * 16;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
@@ -161,14 +162,14 @@ __device__ __forceinline__ void gs_step(const char* wb, int s, int lane, int g, 
     }
 }
 
-template <int NT>
-__global__ __launch_bounds__(256) void gin_layer_split_kernel(const float* __restrict__ h, float* __restrict__ hout,
+template <int NT, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void gin_layer_split_kernel(const float* __restrict__ h, float* __restrict__ hout,
                                                                const int* __restrict__ row_ptr,
                                                                const int* __restrict__ src,
                                                                const uint8_t* __restrict__ ecode,
                                                                const float* __restrict__ ecomb,
                                                                const uint8_t* __restrict__ wchunks, int n_tot, int relu_out,
-                                                               int* __restrict__ range_flag, int abl) {
+                                                               int* __restrict__ range_flag) {
     // two DISTINCT LDS objects: the compiler can then prove that the LDS-DMA into one does not alias the ds_reads
     // of the other and leaves the DMA in flight under the MFMAs (see gin_layer_fused_kernel)
     __shared__ __attribute__((aligned(16))) char s_a[GS_CHUNK_BYTES];  // edge-embedding combos, then odd chunks
@@ -176,10 +177,10 @@ __global__ __launch_bounds__(256) void gin_layer_split_kernel(const float* __res
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // in an SGPR: DMA addresses = scalar base + lane * 16
     const int j = lane & 15, g = lane >> 4;
-    const long long node_base = (long long)blockIdx.x * (64 * NT) + wave * (16 * NT);
+    const long long node_base = (long long)blockIdx.x * (WAVES * 16 * NT) + wave * (16 * NT);
 
-    gs_issue_chunk(wchunks, s_b, wave, lane);  // chunk 0 in flight while we gather
-    for (int i = threadIdx.x; i < GS_ECOMB_BYTES / 16; i += 256)
+    gs_issue_chunk<WAVES>(wchunks, s_b, wave, lane);  // chunk 0 in flight while we gather
+    for (int i = threadIdx.x; i < GS_ECOMB_BYTES / 16; i += WAVES * 64)
         reinterpret_cast<float4*>(s_a)[i] = reinterpret_cast<const float4*>(ecomb)[i];
     __syncthreads();
     const float* s_ecomb = reinterpret_cast<const float*>(s_a);
@@ -196,7 +197,6 @@ __global__ __launch_bounds__(256) void gin_layer_split_kernel(const float* __res
         self_row[nt] = node;
         e_cur[nt] = valid ? row_ptr[node] : 0;
         e_end[nt] = valid ? row_ptr[node + 1] : 0;
-        if (abl & 1) e_end[nt] = e_cur[nt];
 #pragma unroll
         for (int k = 0; k < 25; k++) bq[nt][k] = 0.0f;
     }
@@ -279,14 +279,14 @@ __global__ __launch_bounds__(256) void gin_layer_split_kernel(const float* __res
 #pragma unroll
     for (int nt = 0; nt < NT; nt++) { h_hi[nt] = (uint4_t){0, 0, 0, 0}; h_lo[nt] = (uint4_t){0, 0, 0, 0}; }
 #pragma unroll 1
-    for (int c = 0; c < ((abl & 2) ? 0 : GS_STEPS); c += 2) {
+    for (int c = 0; c < GS_STEPS; c += 2) {
         // even step: compute from s_b while chunk c+1 streams into s_a
-        gs_issue_chunk(wchunks + (size_t)(c + 1) * GS_CHUNK_STRIDE, s_a, wave, lane);
+        gs_issue_chunk<WAVES>(wchunks + (size_t)(c + 1) * GS_CHUNK_STRIDE, s_a, wave, lane);
         gs_step<NT>(s_b, c, lane, g, in_hi, in_lo, in_t, h_hi, h_lo, acc2, vmax);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of chunk c+1 have landed
         __syncthreads();                                  // everyone's landed; everyone is done with s_b
         // odd step: compute from s_a while chunk c+2 streams into s_b
-        if (c + 2 < GS_STEPS) gs_issue_chunk(wchunks + (size_t)(c + 2) * GS_CHUNK_STRIDE, s_b, wave, lane);
+        if (c + 2 < GS_STEPS) gs_issue_chunk<WAVES>(wchunks + (size_t)(c + 2) * GS_CHUNK_STRIDE, s_b, wave, lane);
         gs_step<NT>(s_a, c + 1, lane, g, in_hi, in_lo, in_t, h_hi, h_lo, acc2, vmax);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -313,39 +313,8 @@ __global__ __launch_bounds__(256) void gin_layer_split_kernel(const float* __res
     }
 }
 
-// ---------------------------------------------------------------- persistent + software-pipelined variant
-// Same math, but one persistent 12-wave workgroup per CU walks tiles of 192 nodes, and
-//  * every wave gathers its NEXT tile while the MFMA steps of the current one run (gin_pipe.h: step 0 CSR row bounds,
-//    step 1 own row, steps 2..7 one in-edge each; in-degrees above 6 finish in a residual loop), so HBM/L2 latency
-//    hides behind the matrix pipe instead of being a per-tile prologue;
-//  * the weight stream is read once per 192 nodes instead of once per 64 (7.6 GB instead of 23 GB of L2 -> LDS traffic
-//    per layer at 2^18 molhiv graphs) and runs TWO steps ahead through four LDS buffers: with 16x faster MFMAs a
-//    step lasts well under a microsecond, less than the latency of the LDS-DMA that feeds the next one.
-// A step issues, in this order, its gather slice and then exactly GSP_PIECES LDS-DMA instructions per wave; its single wait
-// is s_waitcnt vmcnt(GSP_PIECES): loads return in order, so everything older than this step's DMA -- the gather slice and the
-// previous step's DMA, i.e. the chunk the next step reads -- has landed, while this step's DMA stays in flight.
-#define GSP_PIECES 4  // LDS-DMA instructions per wave and chunk: ceil(27 / GSP_WAVES)
-#define GSP_STR2(x) #x
-#define GSP_STR(x) GSP_STR2(x)
-constexpr int GSP_WAVES = 8;
-static_assert(GSP_PIECES * GSP_WAVES >= GS_CHUNK_STRIDE / 1024 && (GSP_PIECES - 1) * GSP_WAVES < GS_CHUNK_STRIDE / 1024, "piece count");
-constexpr int GSP_TILE = GSP_WAVES * 16;
-
-__device__ __forceinline__ void gsp_issue_chunk(const uint8_t* __restrict__ gchunk, char* lds_buf, int wave, int lane) {
-    // opaque per call: otherwise the 64-bit per-lane addresses of all 8 x GSP_PIECES (chunk, piece) pairs become
-    // loop invariants of the tile loop, spill, and their scratch reloads break the step's vmcnt accounting
-    uint32_t lane_off = lane * 16;
-    asm volatile("" : "+v"(lane_off));
-#pragma unroll
-    for (int p = 0; p < GSP_PIECES; p++) {
-        int piece = wave + GSP_WAVES * p;              // 27 pieces of 1 KiB over the waves
-        if (piece >= GS_CHUNK_STRIDE / 1024) piece = wave;  // past the end: this wave's first piece again (same bytes)
-        const uint8_t* g = gchunk + piece * 1024 + lane_off;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                         (__attribute__((address_space(3))) void*)(lds_buf + piece * 1024), 16, 0, 0);
-    }
-}
-
+// workgroup barrier without the fence of __syncthreads(): the fence makes hipcc wait for vmcnt(0) first, and the
+// kernels below keep transfers in flight across barriers on purpose (LDS visibility of a landed DMA needs no fence)
 #define GSP_BAR()                                          \
     do {                                                   \
         __builtin_amdgcn_sched_barrier(0);                 \
@@ -353,173 +322,6 @@ __device__ __forceinline__ void gsp_issue_chunk(const uint8_t* __restrict__ gchu
         __builtin_amdgcn_s_barrier();                      \
         __builtin_amdgcn_sched_barrier(0);                 \
     } while (0)
-
-// step S of a tile: reads chunk S from BUF_CUR, streams chunk S+2 (of this or the next tile) into BUF_PF
-#define GSP_STEP(S, BUF_CUR, BUF_PF)                                                                      \
-    do {                                                                                                  \
-        GIN_PIPE_ISSUE(S);                                                                                \
-        __builtin_amdgcn_sched_barrier(0);                                                                \
-        gsp_issue_chunk(wchunks + (size_t)(((S) + 2) & 7) * GS_CHUNK_STRIDE, BUF_PF, wave, lane);         \
-        __builtin_amdgcn_sched_barrier(0);                                                                \
-        gs_step<1>(BUF_CUR, S, lane, g, in_hi, in_lo, in_t, h_hi, h_lo, acc2, vmax);                      \
-        GIN_PIPE_WAIT_N(GSP_STR(GSP_PIECES));                                                                             \
-        GIN_PIPE_CONSUME();                                                                               \
-        GSP_BAR();                                                                                        \
-    } while (0)
-
-__global__ __launch_bounds__(GSP_WAVES * 64) void gin_layer_split_persistent_kernel(
-    const float* __restrict__ h, float* __restrict__ hout, const int* __restrict__ row_ptr, const int* __restrict__ src,
-    const uint8_t* __restrict__ ecode, const float* __restrict__ ecomb, const uint8_t* __restrict__ wchunks, int n_tot,
-    int n_tiles, int relu_out, int* __restrict__ range_flag, int getenv_abl) {
-    // five DISTINCT LDS objects: the DMA into one weight buffer provably does not alias the ds_reads of another
-    __shared__ __attribute__((aligned(16))) float s_ecomb[GS_ECOMB_BYTES / 4];
-    __shared__ __attribute__((aligned(16))) char s_w0[GS_CHUNK_STRIDE];
-    __shared__ __attribute__((aligned(16))) char s_w1[GS_CHUNK_STRIDE];
-    __shared__ __attribute__((aligned(16))) char s_w2[GS_CHUNK_STRIDE];
-    __shared__ __attribute__((aligned(16))) char s_w3[GS_CHUNK_STRIDE];
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // in an SGPR: DMA addresses = scalar base + lane * 16
-    const int j = lane & 15, g = lane >> 4;
-    int tile = blockIdx.x;
-    if (tile >= n_tiles) return;
-
-    gsp_issue_chunk(wchunks, s_w0, wave, lane);
-    gsp_issue_chunk(wchunks + GS_CHUNK_STRIDE, s_w1, wave, lane);
-    for (int i = threadIdx.x; i < GS_ECOMB_BYTES / 16; i += GSP_WAVES * 64)
-        reinterpret_cast<float4*>(s_ecomb)[i] = reinterpret_cast<const float4*>(ecomb)[i];
-    __syncthreads();
-
-    // ---- prologue: un-pipelined gather of the first tile
-    float bq[25];
-    {
-        long long node = (long long)tile * GSP_TILE + wave * 16 + j;
-        const bool valid = node < n_tot;
-        if (!valid) node = n_tot - 1;
-        int e = valid ? row_ptr[node] : 0;
-        const int e_end = valid ? row_ptr[node + 1] : 0;
-        const float* hr = h + (size_t)node * GS_D + 4 * g;
-#pragma unroll
-        for (int q = 0; q < 6; q++) {
-            const float4 x = *reinterpret_cast<const float4*>(hr + 16 * q);
-            bq[4 * q + 0] = x.x; bq[4 * q + 1] = x.y; bq[4 * q + 2] = x.z; bq[4 * q + 3] = x.w;
-        }
-        bq[24] = h[(size_t)node * GS_D + 96 + g];
-        while (__any(e < e_end)) {
-            if (e < e_end) {
-                const int u = src[e];
-                const int code = ecode[e];
-                e++;
-                const float* ur = h + (size_t)u * GS_D + 4 * g;
-                const float* er = s_ecomb + code * GS_D + 4 * g;
-#pragma unroll
-                for (int q = 0; q < 6; q++) {
-                    const float4 x = *reinterpret_cast<const float4*>(ur + 16 * q);
-                    const float4 w = *reinterpret_cast<const float4*>(er + 16 * q);
-                    bq[4 * q + 0] += relu1(w.x + x.x); bq[4 * q + 1] += relu1(w.y + x.y);
-                    bq[4 * q + 2] += relu1(w.z + x.z); bq[4 * q + 3] += relu1(w.w + x.w);
-                }
-                bq[24] += relu1(s_ecomb[code * GS_D + 96 + g] + h[(size_t)u * GS_D + 96 + g]);
-            }
-        }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();  // chunks 0 and 1 resident
-
-    float vmax = 0.0f;
-    while (true) {
-        const int next = tile + gridDim.x;
-        const bool has_next = next < n_tiles;  // workgroup-uniform
-        long long nnode = (long long)next * GSP_TILE + wave * 16 + j;
-        const bool nvalid = has_next && nnode < n_tot && !getenv_abl;
-        if (!nvalid) nnode = n_tot - 1;
-        float bqn[25];
-        int p_ecur = 0, p_eend = 0, p_unx = 0, p_cnx = 0, p_unew = 0, p_cnew = 0, p_code = 0, p_mode = 0, p_rp0 = 0, p_rp1 = 0;
-        float4_t px0 = (float4_t){0.f, 0.f, 0.f, 0.f}, px1 = px0, px2 = px0, px3 = px0, px4 = px0, px5 = px0;
-        float pxt = 0.f;
-#pragma unroll
-        for (int k = 0; k < 25; k++) bqn[k] = 0.0f;
-
-        // B operands of this tile's first linear layer
-        uint4_t in_hi[1][3], in_lo[1][3];
-        float in_t[1];
-#pragma unroll
-        for (int ks = 0; ks < 3; ks++) {
-            GS_SPLIT2(bq[8 * ks + 0], bq[8 * ks + 1], in_hi[0][ks].x, in_lo[0][ks].x);
-            GS_SPLIT2(bq[8 * ks + 2], bq[8 * ks + 3], in_hi[0][ks].y, in_lo[0][ks].y);
-            GS_SPLIT2(bq[8 * ks + 4], bq[8 * ks + 5], in_hi[0][ks].z, in_lo[0][ks].z);
-            GS_SPLIT2(bq[8 * ks + 6], bq[8 * ks + 7], in_hi[0][ks].w, in_lo[0][ks].w);
-        }
-#pragma unroll
-        for (int k = 0; k < 24; k += 2)
-            vmax = __builtin_fmaxf(__builtin_fmaxf(vmax, __builtin_fabsf(bq[k])), __builtin_fabsf(bq[k + 1]));
-        asm volatile("" : "+v"(vmax));  // here, not sunk to its next use: that kept all of bq live across step 0 (spills)
-        in_t[0] = bq[24];
-
-        float4_t acc2[1][GS_T2];
-#pragma unroll
-        for (int t2 = 0; t2 < GS_T2; t2++) {
-            const float4 b = *reinterpret_cast<const float4*>(s_w0 + GS_W2_OFF + (16 * t2 + 4 * g) * 4);  // chunk 0 is resident
-            acc2[0][t2] = (float4_t){b.x, b.y, b.z, b.w};
-        }
-        const float oscale = *reinterpret_cast<const float*>(s_w0 + GS_W2_OFF + 112 * 4);
-        uint4_t h_hi[1], h_lo[1];
-        h_hi[0] = (uint4_t){0, 0, 0, 0};
-        h_lo[0] = (uint4_t){0, 0, 0, 0};
-
-        GSP_STEP(0, s_w0, s_w2);
-        GSP_STEP(1, s_w1, s_w3);
-        GSP_STEP(2, s_w2, s_w0);
-        GSP_STEP(3, s_w3, s_w1);
-        GSP_STEP(4, s_w0, s_w2);
-        GSP_STEP(5, s_w1, s_w3);
-        GSP_STEP(6, s_w2, s_w0);  // chunk 0 of the next tile
-        GSP_STEP(7, s_w3, s_w1);  // chunk 1 of the next tile
-
-        {
-            const long long node = (long long)tile * GSP_TILE + wave * 16 + j;
-            if (node < n_tot) {
-                float* row = hout + (size_t)node * GS_D;
-#pragma unroll
-                for (int t2 = 0; t2 < GS_T2; t2++) {
-                    const int col = 16 * t2 + 4 * g;
-                    if (col < GS_D) {
-                        float4_t r = acc2[0][t2] * oscale;
-                        if (relu_out) { r.x = relu1(r.x); r.y = relu1(r.y); r.z = relu1(r.z); r.w = relu1(r.w); }
-                        *reinterpret_cast<float4*>(row + col) = make_float4(r.x, r.y, r.z, r.w);
-                    }
-                }
-            }
-        }
-        if (!has_next) break;
-
-        // residual: in-degree > 6 (hub nodes, kNN graphs) -- not overlapped, same order
-        while (__any(p_ecur < p_eend)) {
-            if (p_ecur < p_eend) {
-                const int u = p_unx;
-                const int code = p_cnx;
-                p_ecur++;
-                if (p_ecur < p_eend) { p_unx = src[p_ecur]; p_cnx = ecode[p_ecur]; }
-                const float* ur = h + (size_t)u * GS_D + 4 * g;
-                const float* er = s_ecomb + code * GS_D + 4 * g;
-#pragma unroll
-                for (int q = 0; q < 6; q++) {
-                    const float4 x = *reinterpret_cast<const float4*>(ur + 16 * q);
-                    const float4 w = *reinterpret_cast<const float4*>(er + 16 * q);
-                    bqn[4 * q + 0] += relu1(w.x + x.x); bqn[4 * q + 1] += relu1(w.y + x.y);
-                    bqn[4 * q + 2] += relu1(w.z + x.z); bqn[4 * q + 3] += relu1(w.w + x.w);
-                }
-                bqn[24] += relu1(s_ecomb[code * GS_D + 96 + g] + h[(size_t)u * GS_D + 96 + g]);
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < 25; k++) bq[k] = bqn[k];
-        tile = next;
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the last steps' prefetches
-    if (__any(!(vmax < 6.0e4f))) {
-        if (lane == 0) atomicOr(range_flag, 1);
-    }
-}
 
 // gs_step for one node tile per wave, written as an explicit software pipeline: the fragments of group k+1 are
 // read from LDS while the MFMAs of group k issue, and scheduling fences keep the compiler from hoisting all 26
@@ -540,10 +342,45 @@ __device__ __forceinline__ void gs_mm2(const uint4_t (&f)[4], const uint4_t& bh,
     c0 = GS_MFMA16(f[1], bh, c0); c1 = GS_MFMA16(f[3], bh, c1);
 }
 
+// The step also issues the LDS-DMA of a later chunk, one 1 KiB piece after each of its first three groups rather than
+// three in a row at the top of the step: the vector-memory path takes 64 B per clock and CU, so twelve waves issuing 36
+// pieces together sat in front of a full queue for about 900 cycles per step -- with their MFMAs behind it.
+// LDS-DMA with a scalar base and a 32-bit per-lane offset ("saddr" addressing): no 64-bit per-lane addresses, which
+// hipcc otherwise precomputes for every (step, piece) pair at the top of the tile loop and spills.
+__device__ __forceinline__ void gs_dma16s(const void* sbase, uint32_t voff, uint32_t lds_addr) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(sbase), "s"(lds_addr) : "memory");
+}
+
+struct GsDma {
+    const uint8_t* g;  // global address of piece 0 of the chunk (wave-uniform)
+    uint32_t lane_off; // lane * 16
+    uint32_t l;        // LDS address of piece 0 of the destination buffer (wave-uniform)
+    int p0, p1, p2;    // this wave's three pieces (wave-uniform)
+    bool on;
+    // step 1 of the tile-staged kernel: 7 more pieces (rows of the next tile), issued after the chunk's
+    bool rows;
+    const char* rbase;   // first row of the tile in h (wave-uniform)
+    uint32_t rlim;       // last valid 16-byte offset from rbase (bytes past the end of h are read from its last 16 bytes)
+    int rwave, rwaves, rpieces;
+    uint32_t rl;         // LDS address of row piece 0
+};
+__device__ __forceinline__ void gs_dma_row(const GsDma& d, int k) {
+    if (d.rows) {
+        int piece = d.rwave + d.rwaves * k;
+        if (piece >= d.rpieces) piece = d.rwave;  // past the end: this wave's first piece again (same bytes)
+        uint32_t off = piece * 1024 + d.lane_off;
+        off = off < d.rlim ? off : d.rlim;
+        gs_dma16s(d.rbase, off, d.rl + piece * 1024);
+    }
+}
+__device__ __forceinline__ void gs_dma_piece(const GsDma& d, int piece) {
+    if (d.on) gs_dma16s(d.g + piece * 1024, d.lane_off, d.l + piece * 1024);
+}
+
 template <int S>
 __device__ __forceinline__ void gs_step_p(const char* wb, int lane, int g, const uint4_t (&in_hi)[1][3],
                                           const uint4_t (&in_lo)[1][3], const float (&in_t)[1], uint4_t (&h_hi)[1],
-                                          uint4_t (&h_lo)[1], float4_t (&acc2)[1][GS_T2], float& vmax) {
+                                          uint4_t (&h_lo)[1], float4_t (&acc2)[1][GS_T2], float& vmax, const GsDma& dma) {
     constexpr bool M1 = S < GS_STEPS - 1, M2 = S > 0;
     uint4_t fa[4], fb[4];
     float4_t a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0;
@@ -558,28 +395,36 @@ __device__ __forceinline__ void gs_step_p(const char* wb, int lane, int g, const
         GS_FENCE();
         gs_ld4(fb, wb + 4096, lane);
         gs_mm2(fa, in_hi[0][0], in_lo[0][0], a0, a1);
+        gs_dma_piece(dma, dma.p0);
         GS_FENCE();
         gs_ld4(fa, wb + 8192, lane);
         gs_mm2(fb, in_hi[0][1], in_lo[0][1], a0, a1);
+        gs_dma_piece(dma, dma.p1);
         GS_FENCE();
         t0 = *reinterpret_cast<const float*>(wb + GS_TAIL_OFF + lane * 4);
         t1 = *reinterpret_cast<const float*>(wb + GS_TAIL_OFF + 256 + lane * 4);
         if (M2) gs_ld4(fb, w2, lane);
         gs_mm2(fa, in_hi[0][2], in_lo[0][2], a0, a1);
+        gs_dma_piece(dma, dma.p2);
         GS_FENCE();
         a0 = GS_MFMA32(t0, in_t[0], a0);
         a1 = GS_MFMA32(t1, in_t[0], a1);
     } else {
         gs_ld4(fb, w2, lane);
+        gs_dma_piece(dma, dma.p0);
+        gs_dma_piece(dma, dma.p1);
+        gs_dma_piece(dma, dma.p2);
         GS_FENCE();
     }
     uint4_t n_hi = {0, 0, 0, 0}, n_lo = {0, 0, 0, 0};
     if (M2) {
         gs_ld4(fa, w2 + 4096, lane);
         gs_mm2(fb, h_hi[0], h_lo[0], acc2[0][0], acc2[0][1]);
+        if (S == 2) { gs_dma_row(dma, 0); gs_dma_row(dma, 1); }
         GS_FENCE();
         gs_ld4(fb, w2 + 8192, lane);
         gs_mm2(fa, h_hi[0], h_lo[0], acc2[0][2], acc2[0][3]);
+        if (S == 2) { gs_dma_row(dma, 2); gs_dma_row(dma, 3); }
     }
     if (M1) {  // under the MLP2 MFMAs just issued
         a0.x = relu1(a0.x); a0.y = relu1(a0.y); a0.z = relu1(a0.z); a0.w = relu1(a0.w);
@@ -599,184 +444,267 @@ __device__ __forceinline__ void gs_step_p(const char* wb, int lane, int g, const
         fa[0] = *reinterpret_cast<const uint4_t*>(w2 + 12288 + lane * 16);
         fa[1] = *reinterpret_cast<const uint4_t*>(w2 + 13312 + lane * 16);
         gs_mm2(fb, h_hi[0], h_lo[0], acc2[0][4], acc2[0][5]);
+        if (S == 2) { gs_dma_row(dma, 4); gs_dma_row(dma, 5); }
         GS_FENCE();
         acc2[0][6] = GS_MFMA16(fa[0], h_hi[0], acc2[0][6]);
         acc2[0][6] = GS_MFMA16(fa[0], h_lo[0], acc2[0][6]);
         acc2[0][6] = GS_MFMA16(fa[1], h_hi[0], acc2[0][6]);
+        if (S == 2) gs_dma_row(dma, 6);
     }
     if (M1) { h_hi[0] = n_hi; h_lo[0] = n_lo; }
 }
 
-// ---------------------------------------------------------------- persistent, tile-staged variant (default)
+// ---------------------------------------------------------------- persistent, tile-staged variant (FLOWGNN_GIN_SPLIT_NT=3)
 // The two kernels above leave the matrix pipe idle most of the time for the same reason: every wave waits for
 // global memory inside its own critical path -- gin_layer_split_kernel in a per-tile gather prologue (three dependent
 // round trips row_ptr -> src -> h[u] with 12 waves per CU to hide them), the pipelined one at the end of every step
-// (a step lasts 0.6 us, a gather round trip under load about 2 us, so the step becomes the round trip).  Here global
-// memory is touched only by transfers that are issued a whole step or more before anything depends on them:
+// (a step lasts about 1 us, a gather round trip under load about 2 us, so the step becomes the round trip).  Here
+// global memory is touched only by LDS-DMA transfers that are issued a whole step or more before anything depends
+// on them, and all of them are contiguous:
 //   * one persistent 12-wave workgroup per CU walks tiles of 192 consecutive nodes;
-//   * the 192 rows of the NEXT tile are copied into LDS by LDS-DMA while the MLP of the current tile runs (molecule
-//     batches are block diagonal with consecutive node ids, so a node's neighbours are almost always rows of its
-//     own tile; the rare exception is fetched from global memory), and each lane prefetches the CSR row bounds and
-//     the first four CSR entries of the node it handles next into registers (steps 0 and 1 of the 8 MLP steps);
-//   * the gather of a tile is then a short LDS-only burst at the top of the tile (rows, edge-embedding combos),
-//     in CSR order, followed by the 8 weight-stream steps of gin_layer_split_kernel (two LDS buffers, one step
-//     ahead: with 3 waves per SIMD a step is about 1 us).
-// vmcnt bookkeeping: loads return in order, so "s_waitcnt vmcnt(N)" after issuing N LDS-DMA instructions last means
-// "everything issued before them has landed".  Every wave issues exactly GT_P weight pieces per step and exactly
-// GT_R row pieces in step 1 (out-of-range pieces are clamped to valid addresses, not skipped).
+//   * while the MLP of tile t runs, the 192 rows of tile t+1 (76.8 KB), its row_ptr slice and the CSR entries of its
+//     rows (src ids and edge codes: contiguous ranges of the CSR arrays) are copied into LDS.  Molecule batches are
+//     block diagonal with consecutive node ids, so a node's neighbours are almost always rows of its own tile; the
+//     rare exception (a graph straddling a tile boundary) is fetched from global memory.  (Per-lane loads of the
+//     CSR entries were tried first: 96 divergent load instructions per tile kept the CU's vector-memory pipeline,
+//     and the waves queued behind it, busy for 3400 cycles.)
+//   * the gather of tile t+1 is LDS-only and is folded into steps 3..7 of tile t, one in-edge per step, after the
+//     wave's MFMAs of that step (the VALU work of one wave runs under the MFMAs of the other two on its SIMD);
+//     in-degrees above 5 and the node's own row finish in a short loop at the end of the tile;
+//   * the 8 weight-stream steps are those of gin_layer_split_kernel (two LDS buffers, one step ahead); the DMA pieces
+//     of a step are issued between its MFMA groups, not in a burst at its top (the vector-memory path moves 64 B
+//     per clock and CU; twelve waves issuing 36 KiB together queued for ~900 cycles with their MFMAs behind them).
+// Waits: every step ends with s_waitcnt vmcnt(0) + one workgroup barrier.  Partial waits ("vmcnt(7): everything but the
+// seven row pieces issued last") were tried and are NOT safe: now and then a wave passed one with a weight piece still
+// in flight (17 of 4113 molhiv graphs wrong), i.e. LDS-DMA transfers of a wave do not retire strictly in issue order.
+// The DMA is issued from inline asm (see gs_dma16s), so hipcc neither counts it nor waits for it, and the end-of-step
+// waits are the s_waitcnt BUILTIN so that hipcc's own bookkeeping of its loads and stores is reset at the same points.
 constexpr int GT_WAVES = 12;
 constexpr int GT_TILE = GT_WAVES * 16;            // 192 rows
 constexpr int GT_ROW_BYTES = GT_TILE * GS_D * 4;  // 76800 = 75 pieces of 1 KiB
-#define GT_P 3  // weight pieces per wave and step: ceil(27 / 12)
+constexpr int GT_ECAP = GT_WAVES * 64;            // CSR entries of a tile staged in LDS (a molhiv tile has ~420)
 #define GT_R 7  // row pieces per wave and tile: ceil(75 / 12)
-static_assert(GT_P * GT_WAVES >= GS_CHUNK_STRIDE / 1024 && GT_R * GT_WAVES >= GT_ROW_BYTES / 1024, "piece counts");
+static_assert(3 * GT_WAVES >= GS_CHUNK_STRIDE / 1024 && GT_R * GT_WAVES >= GT_ROW_BYTES / 1024, "piece counts");
 #define GT_STR2(x) #x
 #define GT_STR(x) GT_STR2(x)
+// LDS map (one object, carved by hand, weight buffers first: their fragment reads are then "lane * 16 + immediate";
+// ds_read offsets are 16 bit, and above 64 KB every fragment needed its own address register)
+constexpr int GT_OFF_WA = 0;                               // even chunks
+constexpr int GT_OFF_WB = GS_CHUNK_STRIDE;                 // odd chunks
+constexpr int GT_OFF_ECOMB = 2 * GS_CHUNK_STRIDE;          // 60 edge-embedding combos
+constexpr int GT_OFF_ROWS = GT_OFF_ECOMB + GS_ECOMB_BYTES;  // h rows of the next / current tile
+constexpr int GT_OFF_RP = GT_OFF_ROWS + GT_ROW_BYTES;      // row_ptr[tile_base .. +255]
+constexpr int GT_OFF_SRC = GT_OFF_RP + 1024;               // src[e0 .. e0 + GT_ECAP)
+constexpr int GT_OFF_CODE = GT_OFF_SRC + GT_ECAP * 4;      // ecode[e0 & ~3 .. +1024)
+constexpr int GT_LDS_BYTES = GT_OFF_CODE + 1024;
+static_assert(GT_LDS_BYTES <= 160 * 1024, "LDS budget");
 
 // One LDS-DMA instruction (64 lanes x 16 B, lane-linear from M0) issued from inline asm.  hipcc then neither counts it
 // nor orders LDS reads against it: with the builtin, its waitcnt pass put "s_waitcnt vmcnt(0)" in front of the first
 // ds_read of every odd step (reads of the higher-addressed buffer while the DMA into the lower one was in flight),
-// which is the very stall this kernel is built to avoid.  All waits for these transfers are explicit below.
+// which is the very stall this kernel is built to avoid.
 __device__ __forceinline__ void gt_dma16(const void* gaddr, uint32_t lds_addr) {
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(gaddr), "s"(lds_addr) : "memory");
 }
 __device__ __forceinline__ uint32_t gt_lds_addr(const void* p) {
     return (uint32_t)(size_t)(const __attribute__((address_space(3))) char*)p;
 }
+__device__ __forceinline__ int load_u8_rare(const uint8_t* p) {
+    int v;
+    asm volatile("global_load_ubyte %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
 
 __device__ __forceinline__ void gt_issue_chunk(const uint8_t* __restrict__ gchunk, char* lds_buf, int wave, int lane) {
     uint32_t lane_off = lane * 16;
     asm volatile("" : "+v"(lane_off));  // keep the per-lane addresses out of the tile loop's invariants (they spill)
 #pragma unroll
-    for (int p = 0; p < GT_P; p++) {
+    for (int p = 0; p < 3; p++) {
         int piece = wave + GT_WAVES * p;
         if (piece >= GS_CHUNK_STRIDE / 1024) piece = wave;  // past the end: this wave's first piece again (same bytes)
         gt_dma16(gchunk + piece * 1024 + lane_off, __builtin_amdgcn_readfirstlane(gt_lds_addr(lds_buf) + piece * 1024));
     }
 }
 
-// rows [tile * 192, +192) of h -> s_rows; bytes past the end of h are read from its last 16 bytes instead (those LDS
-// rows belong to no node)
-__device__ __forceinline__ void gt_issue_rows(const float* __restrict__ h, float* s_rows, long long tile, int n_tot, int wave,
-                                              int lane) {
-    uint32_t lane_off = lane * 16;
-    asm volatile("" : "+v"(lane_off));
+// this lane's global address of row piece `piece` of tile `tile`; bytes past the end of h are read from its last 16
+// bytes instead (those LDS rows belong to no node)
+__device__ __forceinline__ const char* gt_row_addr(const float* __restrict__ h, long long tile, int n_tot, int piece, uint32_t lane_off) {
     const long long lim = (long long)n_tot * (GS_D * 4) - 16;
-#pragma unroll
-    for (int p = 0; p < GT_R; p++) {
-        int piece = wave + GT_WAVES * p;
-        if (piece >= GT_ROW_BYTES / 1024) piece = wave;
-        long long off = tile * GT_ROW_BYTES + piece * 1024 + lane_off;
-        off = off < lim ? off : lim;
-        gt_dma16(reinterpret_cast<const char*>(h) + off, __builtin_amdgcn_readfirstlane(gt_lds_addr(s_rows) + piece * 1024));
+    long long off = tile * GT_ROW_BYTES + piece * 1024 + lane_off;
+    off = off < lim ? off : lim;
+    return reinterpret_cast<const char*>(h) + off;
+}
+__device__ __forceinline__ int gt_row_piece(int wave, int k) {
+    const int piece = wave + GT_WAVES * k;
+    return piece < GT_ROW_BYTES / 1024 ? piece : wave;
+}
+
+// row_ptr slice, src ids and edge codes of tile `tile` (first CSR entry e0) -> LDS; 1 or 2 instructions per wave.
+// Scalar base + 32-bit lane offset; lanes past the end of an array re-read its last element (entries of no row).
+__device__ __forceinline__ void gt_dma4s(const void* sbase, uint32_t voff, uint32_t lds_addr) {  // 64 lanes x 4 B
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" : : "v"(voff), "s"(sbase), "s"(lds_addr) : "memory");
+}
+__device__ __forceinline__ void gt_issue_csr(const int* __restrict__ row_ptr, const int* __restrict__ src,
+                                             const uint8_t* __restrict__ ecode, char* smem, long long tile, int e0, int n_tot,
+                                             int e_tot, int wave, int lane) {
+    {
+        const int eb = e0 < e_tot ? e0 : e_tot - 1;  // wave-uniform
+        const uint32_t last = (uint32_t)(e_tot - 1 - eb) * 4u;
+        uint32_t off = (uint32_t)(wave * 64 + lane) * 4u;
+        off = off < last ? off : last;
+        gt_dma4s(src + eb, off, __builtin_amdgcn_readfirstlane(gt_lds_addr(smem + GT_OFF_SRC) + wave * 256));
+    }
+    if (wave < 4) {
+        const int ab = (e0 < e_tot ? e0 : e_tot - 1) & ~3;
+        const uint32_t last = (uint32_t)(((e_tot - 1) & ~3) - ab);
+        uint32_t off = (uint32_t)(wave * 64 + lane) * 4u;
+        off = off < last ? off : last;
+        gt_dma4s(ecode + ab, off, __builtin_amdgcn_readfirstlane(gt_lds_addr(smem + GT_OFF_CODE) + wave * 256));
+    } else if (wave < 8) {
+        const long long nb = tile * GT_TILE;
+        const uint32_t last = (uint32_t)(n_tot - nb) * 4u;  // row_ptr has n_tot + 1 entries
+        uint32_t off = (uint32_t)((wave - 4) * 64 + lane) * 4u;
+        off = off < last ? off : last;
+        gt_dma4s(row_ptr + nb, off, __builtin_amdgcn_readfirstlane(gt_lds_addr(smem + GT_OFF_RP) + (wave - 4) * 256));
     }
 }
+
+// One in-edge of the node this lane gathers for: bqn += relu(h[src] + ecomb[code]); everything from LDS except
+// neighbours outside the tile and CSR entries beyond the staged GT_ECAP (dense tiles: kNN graphs).
+// LDS reads are unconditional (clamped) and pinned with an empty asm, global memory is touched only in branches through
+// asm loads: a `cond ? lds : global` select makes hipcc emit flat loads with a full wait after each.
+#define GT_ROUND()                                                                                                     \
+    do {                                                                                                               \
+        if (ecur < eend) {                                                                                             \
+            const int ei_ = ecur < GT_ECAP ? ecur : GT_ECAP - 1;                                                       \
+            int u_ = s_src[ei_];                                                                                       \
+            int code_ = s_code[coff + ei_];                                                                            \
+            asm volatile("" : "+v"(u_), "+v"(code_));                                                                  \
+            if (ecur >= GT_ECAP) {                                                                                     \
+                u_ = load_i32_rare(src + (size_t)e0n + ecur);                                                          \
+                code_ = load_u8_rare(ecode + (size_t)e0n + ecur);                                                      \
+            }                                                                                                          \
+            ecur++;                                                                                                    \
+            const unsigned ul_ = (unsigned)(u_ - nbase);                                                               \
+            const bool in_ = ul_ < (unsigned)GT_TILE;                                                                  \
+            const float* ur_ = s_rows + (in_ ? ul_ : 0u) * GS_D + 4 * g;                                               \
+            const float* er_ = s_ecomb + code_ * GS_D + 4 * g;                                                         \
+            float4 x_[6];                                                                                              \
+            _Pragma("unroll") for (int q = 0; q < 6; q++) {                                                            \
+                x_[q] = *reinterpret_cast<const float4*>(ur_ + 16 * q);                                                \
+                asm volatile("" : "+v"(x_[q].x), "+v"(x_[q].y), "+v"(x_[q].z), "+v"(x_[q].w));                         \
+            }                                                                                                          \
+            float xt_ = ur_[96 - 3 * g];                                                                               \
+            asm volatile("" : "+v"(xt_));                                                                              \
+            if (!in_) {                                                                                                \
+                const float* gr_ = h + (size_t)u_ * GS_D + 4 * g;                                                      \
+                _Pragma("unroll") for (int q = 0; q < 6; q++)                                                          \
+                    x_[q] = load_f4_rare(reinterpret_cast<const float4*>(gr_ + 16 * q));                               \
+                xt_ = load_f32_rare(h + (size_t)u_ * GS_D + 96 + g);                                                   \
+            }                                                                                                          \
+            _Pragma("unroll") for (int q = 0; q < 6; q++) {                                                            \
+                const float4 w_ = *reinterpret_cast<const float4*>(er_ + 16 * q);                                      \
+                bqn[4 * q + 0] += relu1(w_.x + x_[q].x);                                                               \
+                bqn[4 * q + 1] += relu1(w_.y + x_[q].y);                                                               \
+                bqn[4 * q + 2] += relu1(w_.z + x_[q].z);                                                               \
+                bqn[4 * q + 3] += relu1(w_.w + x_[q].w);                                                               \
+            }                                                                                                          \
+            bqn[24] += relu1(er_[96 - 3 * g] + xt_);                                                                   \
+        }                                                                                                              \
+    } while (0)
+
+// start of a gather: this lane's CSR row bounds (relative to the tile's first entry) from the staged row_ptr slice
+#define GT_GATHER_INIT(valid_)                                                           \
+    do {                                                                                 \
+        const int nl_ = wave * 16 + j;                                                   \
+        const int r0_ = s_rp[nl_], r1_ = s_rp[nl_ + 1];                                  \
+        ecur = (valid_) ? r0_ - e0n : 0;                                                 \
+        eend = (valid_) ? r1_ - e0n : 0;                                                 \
+        _Pragma("unroll") for (int k = 0; k < 25; k++) bqn[k] = 0.0f;                    \
+    } while (0)
+
+// end of a gather: remaining in-edges, then + (1 + eps) h[v], eps == 0 (the oracle's order: edges, then the own row)
+#define GT_GATHER_FINISH()                                                               \
+    do {                                                                                 \
+        while (__any(ecur < eend)) GT_ROUND();                                           \
+        const float* sr_ = s_rows + (wave * 16 + j) * GS_D + 4 * g;                      \
+        _Pragma("unroll") for (int q = 0; q < 6; q++) {                                  \
+            const float4 x_ = *reinterpret_cast<const float4*>(sr_ + 16 * q);            \
+            bqn[4 * q + 0] += x_.x; bqn[4 * q + 1] += x_.y; bqn[4 * q + 2] += x_.z; bqn[4 * q + 3] += x_.w; \
+        }                                                                                \
+        bqn[24] += sr_[96 - 3 * g];                                                      \
+    } while (0)
+
+// The end-of-step wait is the BUILTIN s_waitcnt vmcnt(0) (0x0F70: expcnt and lgkmcnt untouched), not inline asm: hipcc's
+// waitcnt pass then knows that nothing of its own is pending any more.  With an asm wait it kept the tile's output
+// stores on its books and, when it reused their data registers early in the next step 0, inserted "s_waitcnt vmcnt(1)"
+// -- which, because it cannot see the asm-issued DMA, was a wait for the chunk that had just been requested.
+#define GT_WAIT_ALL()                          \
+    do {                                       \
+        __builtin_amdgcn_sched_barrier(0);     \
+        __builtin_amdgcn_s_waitcnt(0x0F70);    \
+        __builtin_amdgcn_sched_barrier(0);     \
+    } while (0)
 
 __global__ __launch_bounds__(GT_WAVES * 64) void gin_layer_split_tiled_kernel(
     const float* __restrict__ h, float* __restrict__ hout, const int* __restrict__ row_ptr, const int* __restrict__ src,
     const uint8_t* __restrict__ ecode, const float* __restrict__ ecomb, const uint8_t* __restrict__ wchunks, int n_tot,
-    int n_tiles, int relu_out, int* __restrict__ range_flag) {
-    // ONE LDS object, carved by hand, weight buffers first: their fragment reads are then "lane * 16 + immediate"
-    // (ds_read offsets are 16 bit; above 64 KB every fragment needed its own address register).  The DMA is issued
-    // from inline asm, so there is no alias analysis to help by splitting the buffers into separate objects.
-    __shared__ __attribute__((aligned(16))) char smem[2 * GS_CHUNK_STRIDE + GS_ECOMB_BYTES + GT_ROW_BYTES];
-    char* const s_wa = smem;                    // even chunks
-    char* const s_wb = smem + GS_CHUNK_STRIDE;  // odd chunks
-    float* const s_ecomb = reinterpret_cast<float*>(smem + 2 * GS_CHUNK_STRIDE);
-    float* const s_rows = reinterpret_cast<float*>(smem + 2 * GS_CHUNK_STRIDE + GS_ECOMB_BYTES);
+    int e_tot, int n_tiles, int relu_out, int* __restrict__ range_flag) {
+    __shared__ __attribute__((aligned(16))) char smem[GT_LDS_BYTES];
+    char* const s_wa = smem + GT_OFF_WA;
+    char* const s_wb = smem + GT_OFF_WB;
+    float* const s_ecomb = reinterpret_cast<float*>(smem + GT_OFF_ECOMB);
+    float* const s_rows = reinterpret_cast<float*>(smem + GT_OFF_ROWS);
+    const int* const s_rp = reinterpret_cast<const int*>(smem + GT_OFF_RP);
+    const int* const s_src = reinterpret_cast<const int*>(smem + GT_OFF_SRC);
+    const uint8_t* const s_code = reinterpret_cast<const uint8_t*>(smem + GT_OFF_CODE);
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int j = lane & 15, g = lane >> 4;
-    int tile = blockIdx.x;
+    int tile = blockIdx.x;  // wave-uniform, as is everything derived from it
     if (tile >= n_tiles) return;
+    uint32_t lane_off = lane * 16;
+    asm volatile("" : "+v"(lane_off));  // keeps 64-bit per-lane DMA addresses from becoming (spilled) loop invariants
 
-    // ---- prologue: chunk 0, rows and CSR prefetch of the first tile, edge-embedding combos
-    gt_issue_chunk(wchunks, s_wa, wave, lane);
-    gt_issue_rows(h, s_rows, tile, n_tot, wave, lane);
-    for (int i = threadIdx.x; i < GS_ECOMB_BYTES / 16; i += GT_WAVES * 64)
-        reinterpret_cast<float4*>(s_ecomb)[i] = reinterpret_cast<const float4*>(ecomb)[i];
-    int e_cur = 0, e_end = 0, su0 = 0, su1 = 0, su2 = 0, su3 = 0, sc0 = 0, sc1 = 0, sc2 = 0, sc3 = 0;
+    // ---- prologue: chunk 0, rows + CSR of the first tile, edge-embedding combos; then its gather, not overlapped
+    float bqn[25];
+    int ecur, eend;
     {
-        const long long node = (long long)tile * GT_TILE + wave * 16 + j;
-        if (node < n_tot) {
-            e_cur = row_ptr[node];
-            e_end = row_ptr[node + 1];
-            if (e_cur + 0 < e_end) { su0 = src[e_cur + 0]; sc0 = ecode[e_cur + 0]; }
-            if (e_cur + 1 < e_end) { su1 = src[e_cur + 1]; sc1 = ecode[e_cur + 1]; }
-            if (e_cur + 2 < e_end) { su2 = src[e_cur + 2]; sc2 = ecode[e_cur + 2]; }
-            if (e_cur + 3 < e_end) { su3 = src[e_cur + 3]; sc3 = ecode[e_cur + 3]; }
+        const int e0n = row_ptr[(long long)tile * GT_TILE];
+        const int nbase = tile * GT_TILE;
+        const int coff = e0n & 3;
+        gt_issue_chunk(wchunks, s_wa, wave, lane);
+        gt_issue_csr(row_ptr, src, ecode, smem, tile, e0n, n_tot, e_tot, wave, lane);
+#pragma unroll
+        for (int k = 0; k < GT_R; k++) {
+            const int piece = gt_row_piece(wave, k);
+            gt_dma16(gt_row_addr(h, tile, n_tot, piece, lane_off), __builtin_amdgcn_readfirstlane(gt_lds_addr(s_rows) + piece * 1024));
         }
+        for (int i = threadIdx.x; i < GS_ECOMB_BYTES / 16; i += GT_WAVES * 64)
+            reinterpret_cast<float4*>(s_ecomb)[i] = reinterpret_cast<const float4*>(ecomb)[i];
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        GT_GATHER_INIT((long long)nbase + wave * 16 + j < n_tot);
+        GT_GATHER_FINISH();
     }
-    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
-    __syncthreads();
 
     float vmax = 0.0f;
     while (true) {
-        // ---- gather (MP unit), LDS only: a = sum_e relu(h[src_e] + ecomb[code_e]) in CSR order, then + h[v]
-        float bq[25];
-#pragma unroll
-        for (int k = 0; k < 25; k++) bq[k] = 0.0f;
-        {
-            const int tbase = tile * GT_TILE;
-            for (int e = e_cur; __any(e < e_end); e++) {
-                const int u = su0, code = sc0;
-                su0 = su1; su1 = su2; su2 = su3;
-                sc0 = sc1; sc1 = sc2; sc2 = sc3;
-                if (e + 4 < e_end) { su3 = src[e + 4]; sc3 = ecode[e + 4]; }  // degrees above 4: four entries ahead
-                if (e < e_end) {
-                    const unsigned ul = (unsigned)(u - tbase);
-                    const bool in = ul < (unsigned)GT_TILE;
-                    const float* ur = s_rows + (in ? ul : 0u) * GS_D + 4 * g;
-                    const float* er = s_ecomb + code * GS_D + 4 * g;
-                    float4 x[6];
-#pragma unroll
-                    for (int q = 0; q < 6; q++) {
-                        x[q] = *reinterpret_cast<const float4*>(ur + 16 * q);
-                        // pinned: a `in ? lds : global` select would become flat loads with a full wait after each
-                        asm volatile("" : "+v"(x[q].x), "+v"(x[q].y), "+v"(x[q].z), "+v"(x[q].w));
-                    }
-                    float xt = ur[96 - 3 * g];  // feature 96 + g
-                    asm volatile("" : "+v"(xt));
-                    if (!in) {  // neighbour outside the tile (graph straddling a tile boundary): from global memory
-                        const float* gr = h + (size_t)u * GS_D + 4 * g;
-#pragma unroll
-                        for (int q = 0; q < 6; q++) x[q] = load_f4_rare(reinterpret_cast<const float4*>(gr + 16 * q));
-                        xt = load_f32_rare(h + (size_t)u * GS_D + 96 + g);
-                    }
-#pragma unroll
-                    for (int q = 0; q < 6; q++) {
-                        const float4 w = *reinterpret_cast<const float4*>(er + 16 * q);
-                        bq[4 * q + 0] += relu1(w.x + x[q].x);
-                        bq[4 * q + 1] += relu1(w.y + x[q].y);
-                        bq[4 * q + 2] += relu1(w.z + x[q].z);
-                        bq[4 * q + 3] += relu1(w.w + x[q].w);
-                    }
-                    bq[24] += relu1(er[96 - 3 * g] + xt);
-                }
-            }
-            const float* sr = s_rows + (wave * 16 + j) * GS_D + 4 * g;  // + (1 + eps) h[v], eps == 0
-#pragma unroll
-            for (int q = 0; q < 6; q++) {
-                const float4 x = *reinterpret_cast<const float4*>(sr + 16 * q);
-                bq[4 * q + 0] += x.x; bq[4 * q + 1] += x.y; bq[4 * q + 2] += x.z; bq[4 * q + 3] += x.w;
-            }
-            bq[24] += sr[96 - 3 * g];
-        }
-        // B operands of the first linear layer
+        // B operands of this tile's first linear layer from the finished gather
         uint4_t in_hi[1][3], in_lo[1][3];
         float in_t[1];
 #pragma unroll
         for (int ks = 0; ks < 3; ks++) {
-            GS_SPLIT2(bq[8 * ks + 0], bq[8 * ks + 1], in_hi[0][ks].x, in_lo[0][ks].x);
-            GS_SPLIT2(bq[8 * ks + 2], bq[8 * ks + 3], in_hi[0][ks].y, in_lo[0][ks].y);
-            GS_SPLIT2(bq[8 * ks + 4], bq[8 * ks + 5], in_hi[0][ks].z, in_lo[0][ks].z);
-            GS_SPLIT2(bq[8 * ks + 6], bq[8 * ks + 7], in_hi[0][ks].w, in_lo[0][ks].w);
+            GS_SPLIT2(bqn[8 * ks + 0], bqn[8 * ks + 1], in_hi[0][ks].x, in_lo[0][ks].x);
+            GS_SPLIT2(bqn[8 * ks + 2], bqn[8 * ks + 3], in_hi[0][ks].y, in_lo[0][ks].y);
+            GS_SPLIT2(bqn[8 * ks + 4], bqn[8 * ks + 5], in_hi[0][ks].z, in_lo[0][ks].z);
+            GS_SPLIT2(bqn[8 * ks + 6], bqn[8 * ks + 7], in_hi[0][ks].w, in_lo[0][ks].w);
         }
 #pragma unroll
         for (int k = 0; k < 24; k += 2)
-            vmax = __builtin_fmaxf(__builtin_fmaxf(vmax, __builtin_fabsf(bq[k])), __builtin_fabsf(bq[k + 1]));
-        asm volatile("" : "+v"(vmax));  // here, not sunk to its next use: that kept all of bq live across step 0 (spills)
-        in_t[0] = bq[24];
+            vmax = __builtin_fmaxf(__builtin_fmaxf(vmax, __builtin_fabsf(bqn[k])), __builtin_fabsf(bqn[k + 1]));
+        asm volatile("" : "+v"(vmax));  // here, not sunk to its next use: that kept all of bqn live across step 0 (spills)
+        in_t[0] = bqn[24];
         float4_t acc2[1][GS_T2];
 #pragma unroll
         for (int t2 = 0; t2 < GS_T2; t2++) {
@@ -790,86 +718,80 @@ __global__ __launch_bounds__(GT_WAVES * 64) void gin_layer_split_tiled_kernel(
 
         const int next = tile + gridDim.x;
         const bool has_next = next < n_tiles;  // workgroup-uniform
-        const long long nnode = (long long)next * GT_TILE + wave * 16 + j;
-        const bool nvalid = has_next && nnode < n_tot;
-        int n_rp0 = 0, n_rp1 = 0, nu0 = 0, nu1 = 0, nu2 = 0, nu3 = 0, nc0 = 0, nc1 = 0, nc2 = 0, nc3 = 0;
+        const int nbase = next * GT_TILE;
+        const bool nvalid = has_next && (long long)nbase + wave * 16 + j < n_tot;
+        const int e0n = has_next ? row_ptr[(long long)nbase] : 0;  // scalar load: first CSR entry of the next tile
+        const int coff = e0n & 3;
 
-// The end-of-step wait is the BUILTIN s_waitcnt vmcnt(0) (0x0F70: expcnt and lgkmcnt untouched), not inline asm: hipcc's
-// waitcnt pass then knows that nothing of its own is pending any more.  With an asm wait it kept the tile's output
-// stores on its books and, when it reused their data registers early in the next step 0, inserted "s_waitcnt vmcnt(1)"
-// -- which, because it cannot see the asm-issued DMA, was a wait for the chunk that had just been requested.
-#define GT_WAIT_ALL()                          \
-    do {                                       \
-        __builtin_amdgcn_sched_barrier(0);     \
-        __builtin_amdgcn_s_waitcnt(0x0F70);    \
-        __builtin_amdgcn_sched_barrier(0);     \
-    } while (0)
-// the tile's outputs, stored inside step 7 so that the step's own wait covers them
-#define GT_STORE()                                                                                                   \
-    do {                                                                                                             \
-        const long long node_ = (long long)tile * GT_TILE + wave * 16 + j;                                           \
-        if (node_ < n_tot) {                                                                                         \
-            float* row_ = hout + (size_t)node_ * GS_D;                                                               \
-            _Pragma("unroll") for (int t2 = 0; t2 < GS_T2; t2++) {                                                   \
-                const int col_ = 16 * t2 + 4 * g;                                                                    \
-                if (col_ < GS_D) {                                                                                   \
-                    float4_t r_ = acc2[0][t2] * oscale;                                                              \
-                    if (relu_out) { r_.x = relu1(r_.x); r_.y = relu1(r_.y); r_.z = relu1(r_.z); r_.w = relu1(r_.w); } \
-                    *reinterpret_cast<float4*>(row_ + col_) = make_float4(r_.x, r_.y, r_.z, r_.w);                   \
-                }                                                                                                    \
-            }                                                                                                        \
-        }                                                                                                            \
-    } while (0)
-        // ---- step 0: CSR row bounds of this lane's next node; chunk 1 -> B
-        // (unconditional loads from clamped addresses, masked after the wait: a conditional load merges with the
-        // default value in a copy, and hipcc waits for the load in front of that copy, i.e. right here)
-        n_rp0 = row_ptr[nvalid ? nnode : 0];
-        n_rp1 = row_ptr[nvalid ? nnode + 1 : 0];
-        __builtin_amdgcn_sched_barrier(0);
-        gt_issue_chunk(wchunks + 1 * GS_CHUNK_STRIDE, s_wb, wave, lane);
-        __builtin_amdgcn_sched_barrier(0);
-        gs_step_p<0>(s_wa, lane, g, in_hi, in_lo, in_t, h_hi, h_lo, acc2, vmax);
+        GsDma dma;
+        dma.on = true;
+        dma.p0 = wave; dma.p1 = wave + GT_WAVES;
+        dma.p2 = wave + 2 * GT_WAVES < GS_CHUNK_STRIDE / 1024 ? wave + 2 * GT_WAVES : wave;
+        dma.rows = false;
+        dma.lane_off = lane_off;
+        const uint8_t* const wl = wchunks;
+        const uint32_t la = gt_lds_addr(s_wa), lb = gt_lds_addr(s_wb);
+
+        // ---- step 0: chunk 1 -> B
+        GT_WAIT_ALL();  // the previous tile's stores (long done): nothing of hipcc's own may be pending when DMA is in flight
+        dma.g = wl + 1 * GS_CHUNK_STRIDE; dma.l = lb;
+        gs_step_p<0>(s_wa, lane, g, in_hi, in_lo, in_t, h_hi, h_lo, acc2, vmax, dma);
         GT_WAIT_ALL();
-        GSP_BAR();  // every wave has finished its gather: s_rows may be overwritten
-        // ---- step 1: its first four CSR entries; chunk 2 -> A; then the rows of the next tile -> s_rows
-        if (!nvalid) n_rp1 = n_rp0;
-        {   // entries past the row's end re-read its first entry (or entry 0 for an empty row); they are never used
-            const int eb = n_rp0 < n_rp1 ? n_rp0 : 0;
-            const int i1 = n_rp0 + 1 < n_rp1 ? n_rp0 + 1 : eb, i2 = n_rp0 + 2 < n_rp1 ? n_rp0 + 2 : eb,
-                      i3 = n_rp0 + 3 < n_rp1 ? n_rp0 + 3 : eb;
-            nu0 = src[eb]; nc0 = ecode[eb];
-            nu1 = src[i1]; nc1 = ecode[i1];
-            nu2 = src[i2]; nc2 = ecode[i2];
-            nu3 = src[i3]; nc3 = ecode[i3];
-        }
+        GSP_BAR();  // every wave has finished the gather of this tile: rows and CSR staging may be overwritten
+        // ---- step 1: CSR of the next tile; chunk 2 -> A
+        if (has_next) gt_issue_csr(row_ptr, src, ecode, smem, next, e0n, n_tot, e_tot, wave, lane);
         __builtin_amdgcn_sched_barrier(0);
-        gt_issue_chunk(wchunks + 2 * GS_CHUNK_STRIDE, s_wa, wave, lane);
-        gt_issue_rows(h, s_rows, has_next ? next : tile, n_tot, wave, lane);
-        __builtin_amdgcn_sched_barrier(0);
-        gs_step_p<1>(s_wb, lane, g, in_hi, in_lo, in_t, h_hi, h_lo, acc2, vmax);
-        // chunk 2 has landed, the rows stay in flight.  The CSR registers are NOT tied here: hipcc waits for a
-        // pending load in front of its first use, with a count that ignores the asm-issued DMA, i.e. for the rows.
-        asm volatile("s_waitcnt vmcnt(" GT_STR(GT_R) ")" ::: "memory");
+        dma.g = wl + 2 * GS_CHUNK_STRIDE; dma.l = la;
+        gs_step_p<1>(s_wb, lane, g, in_hi, in_lo, in_t, h_hi, h_lo, acc2, vmax, dma);
+        GT_WAIT_ALL();
         GSP_BAR();
-        // ---- steps 2..7 (the wait of step 2 also covers the rows)
-#define GT_STEP(S, CUR, NXT)                                                                          \
-    gt_issue_chunk(wchunks + (size_t)(((S) + 1) & 7) * GS_CHUNK_STRIDE, NXT, wave, lane);             \
+        // ---- step 2: chunk 3 -> B; then the rows of the next tile, between the MLP2 groups
+        dma.g = wl + 3 * GS_CHUNK_STRIDE; dma.l = lb;
+        dma.rows = true;
+        dma.rl = gt_lds_addr(s_rows);
+        {
+            const long long roff = (long long)(has_next ? next : tile) * GT_ROW_BYTES;
+            const long long rest = (long long)n_tot * (GS_D * 4) - 16 - roff;  // >= 0: the tile has at least one row
+            dma.rbase = reinterpret_cast<const char*>(h) + roff;
+            dma.rlim = rest < GT_ROW_BYTES ? (uint32_t)rest : (uint32_t)GT_ROW_BYTES;
+        }
+        dma.rwave = wave; dma.rwaves = GT_WAVES; dma.rpieces = GT_ROW_BYTES / 1024;
+        gs_step_p<2>(s_wa, lane, g, in_hi, in_lo, in_t, h_hi, h_lo, acc2, vmax, dma);
+        dma.rows = false;
+        GT_WAIT_ALL();
+        GSP_BAR();
+        // ---- steps 3..7: one in-edge of the next tile's gather after the MFMAs of each
+        GT_GATHER_INIT(nvalid);
+#define GT_STEP(S, CUR)                                                                               \
+    dma.g = wl + (size_t)(((S) + 1) & 7) * GS_CHUNK_STRIDE; dma.l = ((S) & 1) ? la : lb;              \
+    gs_step_p<S>(CUR, lane, g, in_hi, in_lo, in_t, h_hi, h_lo, acc2, vmax, dma);                      \
     __builtin_amdgcn_sched_barrier(0);                                                                \
-    gs_step_p<S>(CUR, lane, g, in_hi, in_lo, in_t, h_hi, h_lo, acc2, vmax);                           \
-    if ((S) == 7) GT_STORE();                                                                         \
-    GT_WAIT_ALL();                                                                                    \
-    GSP_BAR()
-        GT_STEP(2, s_wa, s_wb);
-        GT_STEP(3, s_wb, s_wa);
-        GT_STEP(4, s_wa, s_wb);
-        GT_STEP(5, s_wb, s_wa);
-        GT_STEP(6, s_wa, s_wb);
-        GT_STEP(7, s_wb, s_wa);  // chunk 0 again, for the next tile
+    GT_ROUND()
+        GT_STEP(3, s_wb); GT_WAIT_ALL(); GSP_BAR();
+        GT_STEP(4, s_wa); GT_WAIT_ALL(); GSP_BAR();
+        GT_STEP(5, s_wb); GT_WAIT_ALL(); GSP_BAR();
+        GT_STEP(6, s_wa); GT_WAIT_ALL(); GSP_BAR();
+        GT_STEP(7, s_wb);  // chunk 0 again, for the next tile
 #undef GT_STEP
+        {   // the tile's outputs, stored inside step 7 so that its wait overlaps them with the other waves' work
+            const long long node = (long long)tile * GT_TILE + wave * 16 + j;
+            if (node < n_tot) {
+                float* row = hout + (size_t)node * GS_D;
+#pragma unroll
+                for (int t2 = 0; t2 < GS_T2; t2++) {
+                    const int col = 16 * t2 + 4 * g;
+                    if (col < GS_D) {
+                        float4_t r = acc2[0][t2] * oscale;
+                        if (relu_out) { r.x = relu1(r.x); r.y = relu1(r.y); r.z = relu1(r.z); r.w = relu1(r.w); }
+                        *reinterpret_cast<float4*>(row + col) = make_float4(r.x, r.y, r.z, r.w);
+                    }
+                }
+            }
+        }
+        GT_WAIT_ALL();
+        GSP_BAR();
         if (!has_next) break;
-        e_cur = n_rp0; e_end = n_rp1;
-        su0 = nu0; su1 = nu1; su2 = nu2; su3 = nu3;
-        sc0 = nc0; sc1 = nc1; sc2 = nc2; sc3 = nc3;
+        GT_GATHER_FINISH();
         tile = next;
     }
     if (__any(!(vmax < 6.0e4f))) {
@@ -945,27 +867,25 @@ void gin_split_pack_layer(const float* w1, const float* b1, const float* w2, con
 void launch_gin_layer_split(const float* h, float* hout, const int* row_ptr, const int* src, const uint8_t* ecode,
                             const float* ecomb, const uint8_t* chunks, int n_tot, int e_tot, int relu_out, int* range_flag,
                             int nt, hipStream_t s) {
-    if (e_tot == 0 && (nt == 3 || nt == 0)) nt = 1;  // the persistent kernels prefetch CSR entry 0 unconditionally
+    if (e_tot == 0 && nt == 3) nt = 1;  // the tile-staged kernel stages CSR entries unconditionally
     if (nt == 3) {
         const int n_tiles = (int)ceil_div_ll(n_tot, GT_TILE);
         const int grid = n_tiles < 256 ? n_tiles : 256;  // persistent: one 12-wave workgroup per CU
-        gin_layer_split_tiled_kernel<<<grid, GT_WAVES * 64, 0, s>>>(h, hout, row_ptr, src, ecode, ecomb, chunks, n_tot, n_tiles, relu_out,
-                                                                    range_flag);
+        gin_layer_split_tiled_kernel<<<grid, GT_WAVES * 64, 0, s>>>(h, hout, row_ptr, src, ecode, ecomb, chunks, n_tot, e_tot, n_tiles,
+                                                                    relu_out, range_flag);
         return;
     }
-    if (nt == 0) {
-        const int n_tiles = (int)ceil_div_ll(n_tot, GSP_TILE);
-        const int grid = n_tiles < 256 ? n_tiles : 256;  // persistent: one 12-wave workgroup per CU
-        gin_layer_split_persistent_kernel<<<grid, GSP_WAVES * 64, 0, s>>>(h, hout, row_ptr, src, ecode, ecomb, chunks, n_tot, n_tiles,
-                                                                         relu_out, range_flag, getenv("FLOWGNN_GS_ABL") ? atoi(getenv("FLOWGNN_GS_ABL")) : 0);
+    if (nt == 4) {  // 8 waves, 128 nodes per workgroup, 2 workgroups per CU
+        const int blocks = (int)ceil_div_ll(n_tot, 128);
+        gin_layer_split_kernel<1, 8><<<blocks, 512, 0, s>>>(h, hout, row_ptr, src, ecode, ecomb, chunks, n_tot, relu_out, range_flag);
         return;
     }
     if (nt == 2) {
         const int blocks = (int)ceil_div_ll(n_tot, 128);
-        gin_layer_split_kernel<2><<<blocks, 256, 0, s>>>(h, hout, row_ptr, src, ecode, ecomb, chunks, n_tot, relu_out, range_flag, getenv("FLOWGNN_GS_ABL") ? atoi(getenv("FLOWGNN_GS_ABL")) : 0);
+        gin_layer_split_kernel<2, 4><<<blocks, 256, 0, s>>>(h, hout, row_ptr, src, ecode, ecomb, chunks, n_tot, relu_out, range_flag);
     } else {
         const int blocks = (int)ceil_div_ll(n_tot, 64);
-        gin_layer_split_kernel<1><<<blocks, 256, 0, s>>>(h, hout, row_ptr, src, ecode, ecomb, chunks, n_tot, relu_out, range_flag, getenv("FLOWGNN_GS_ABL") ? atoi(getenv("FLOWGNN_GS_ABL")) : 0);
+        gin_layer_split_kernel<1, 4><<<blocks, 256, 0, s>>>(h, hout, row_ptr, src, ecode, ecomb, chunks, n_tot, relu_out, range_flag);
     }
 }
 
