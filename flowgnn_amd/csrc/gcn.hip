@@ -173,7 +173,7 @@ public:
         if (n <= 0) return 0;
         {
             ProfScope p(prof, "atom_encoder", s);
-            atom_encoder_kernel<GCN_D><<<grid_for((long long)n * GCN_C, 256, 256 * 8), 256, 0, s>>>(
+            atom_encoder_kernel<GCN_D><<<atom_encoder_grid(n, GCN_C), 512, 0, s>>>(
                 db.b.node_feature, d_nemb_, db.scratch, n, db.csr.err);
         }
         int cur = 0;

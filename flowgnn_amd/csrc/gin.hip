@@ -1020,8 +1020,7 @@ public:
         if (n <= 0) return 0;
         {
             ProfScope p(prof, "atom_encoder", s);
-            const int grid = grid_for((long long)n * GIN_C, 256, 256 * 8);
-            atom_encoder_kernel<GIN_D><<<grid, 256, 0, s>>>(db.b.node_feature, d_nemb_, db.h[0], n, db.csr.err);
+            atom_encoder_kernel<GIN_D><<<atom_encoder_grid(n, GIN_C), 512, 0, s>>>(db.b.node_feature, d_nemb_, db.h[0], n, db.csr.err);
         }
         int cur = 0;
         for (int l = 0; l < GIN_L; l++) {
@@ -1099,7 +1098,8 @@ private:
     // FLOWGNN_GIN_MFMA=f32 keeps the dense update on the fp32 matrix pipe (gin_layer_fused_kernel); the default runs it
     // as three f16 MFMAs per product (gin_split.hip), with the engine falling back to fp32 when the range flag trips
     bool split_ = !(getenv("FLOWGNN_GIN_MFMA") && strcmp(getenv("FLOWGNN_GIN_MFMA"), "f32") == 0);
-    int split_nt_ = getenv("FLOWGNN_GIN_SPLIT_NT") ? atoi(getenv("FLOWGNN_GIN_SPLIT_NT")) : 1;
+    // 4 = eight-wave workgroups of 128 nodes (default), 1 / 2 = four waves x 1 / 2 node tiles, 3 = persistent tile-staged kernel
+    int split_nt_ = getenv("FLOWGNN_GIN_SPLIT_NT") ? atoi(getenv("FLOWGNN_GIN_SPLIT_NT")) : 4;
     bool exact_ = false;
     uint8_t* d_split_ = nullptr;
     float* d_chunks_ = nullptr;

@@ -211,7 +211,7 @@ public:
         if (n <= 0) return 0;
         {
             ProfScope p(prof, "atom_encoder", s);
-            atom_encoder_kernel<PNA_D><<<grid_for((long long)n * PNA_C, 256, 256 * 8), 256, 0, s>>>(db.b.node_feature, d_nemb_,
+            atom_encoder_kernel<PNA_D><<<atom_encoder_grid(n, PNA_C), 512, 0, s>>>(db.b.node_feature, d_nemb_,
                                                                                                     db.h[0], n, db.csr.err);
         }
         int cur = 0;
