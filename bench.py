@@ -25,6 +25,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP32_MFMA_PEAK_TF = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 / 32x32x2_f32, dense
+F16_MFMA_PEAK_TF = 2500.0   # MI355X_MICROARCH.md: dense f16/bf16 MFMA peak (measured here: 1947, tools/mfma_f16_split.hip)
 FPGA_U50_GRAPHS_PER_S = 20214.0  # GIN molhiv on Alveo U50 (other hardware; informational)
 
 
@@ -34,10 +35,13 @@ FPGA_U50_GRAPHS_PER_S = 20214.0  # GIN molhiv on Alveo U50 (other h
 MODELS = {
     "GIN": dict(metric="graphs/sec on ogbg-molhiv (GIN, dim=100)", dataset="molhiv", graphs=1 << 18,
                 agg_bytes=lambda n, e: n * 400 * 2 + e * 20, flops=lambda n, e: n * 80000,
+                # fused layer: read h once + write h' + CSR (row_ptr 4 B/node, src 4 B + edge code 1 B per edge)
+                fused_bytes=lambda n, e: n * 400 * 2 + n * 4 + e * 5,
                 hbm_kernels=("gin_aggregate",), mfma_kernels=("gin_layer_fused", "gin_mlp"),
                 workload="GIN dim=100, batched ogbg-molhiv-shaped graphs on MI355X (BASELINE configs[1])"),
     "GIN-VN": dict(metric="graphs/sec on ogbg-molhiv (GIN-VN, dim=100)", dataset="molhiv-vn", graphs=1 << 18,
                    agg_bytes=lambda n, e: n * 400 * 2 + e * 20, flops=lambda n, e: n * 80000,
+                   fused_bytes=lambda n, e: n * 400 * 2 + n * 4 + e * 5,
                    hbm_kernels=("gin_aggregate",), mfma_kernels=("gin_layer_fused", "gin_mlp"),
                    workload="GIN-VN dim=100 (virtual node per graph), ogbg-molhiv-shaped graphs"),
     "GCN": dict(metric="graphs/sec on ogbg-molpcba (GCN, dim=100)", dataset="molpcba", graphs=1 << 18,
@@ -88,8 +92,13 @@ def cpu_baseline(model, batch, w, budget_s: float = 15.0):
     oracle_forward(model, probe, w, 1)
     t1 = time.perf_counter()
     rate1 = probe.num_graphs / (t1 - t0)
-    # OpenMP over graphs scales sub-linearly on a big host; size the sample for ~budget_s at ~1/8 efficiency
-    n = int(min(batch.num_graphs, max(256, rate1 * cores * budget_s / 8)))
+    # OpenMP over graphs scales far from linearly on a big host: measure the parallel rate on a small sample first,
+    # then size the timed sample for about budget_s seconds of wall clock
+    warm = batch.slice(0, min(batch.num_graphs, 16 * cores))
+    t0 = time.perf_counter()
+    oracle_forward(model, warm, w, cores)
+    ratep = warm.num_graphs / (time.perf_counter() - t0)
+    n = int(min(batch.num_graphs, max(256, ratep * budget_s)))
     sample = batch.slice(0, n)
     t0 = time.perf_counter()
     oracle_forward(model, sample, w, cores)
@@ -187,24 +196,43 @@ def main():
             return {"kernel": name, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": ach / HBM_PEAK_GBS, "traffic": None, "avg_ms": kern[name], "bytes_per_launch": agg_bytes}
 
+        # GIN's dense update runs as three f16 MFMAs per fp32 product unless FLOWGNN_GIN_MFMA=f32 (gin_split.hip)
+        split = args.model.startswith("GIN") and os.environ.get("FLOWGNN_GIN_MFMA", "") != "f32"
         roof = None
         if dominant in M["hbm_kernels"]:
             roof = hbm_obj(dominant)
         elif dominant is not None:
-            ach = mlp_flops / (kern[dominant] * 1e-3) / 1e12
-            roof = {"kernel": dominant, "bound": "mfma", "achieved": ach, "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s",
-                    "frac": ach / FP32_MFMA_PEAK_TF, "traffic": None, "avg_ms": kern[dominant],
-                    "flops_per_launch": mlp_flops}
+            t_s = kern[dominant] * 1e-3
+            if split:
+                # three f16 products per algorithmic fp32 product, priced against the f16 pipe the kernel uses
+                ach, peak = 3 * mlp_flops / t_s / 1e12, F16_MFMA_PEAK_TF
+                mfma = {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
+                        "pipe": "f16 (3 products per fp32 product, fp32 accumulate)", "flops_per_launch": 3 * mlp_flops,
+                        "fp32_equivalent_tflops": mlp_flops / t_s / 1e12}
+            else:
+                ach = mlp_flops / t_s / 1e12
+                mfma = {"bound": "mfma", "achieved": ach, "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s",
+                        "frac": ach / FP32_MFMA_PEAK_TF, "pipe": "f32", "flops_per_launch": mlp_flops}
+            if split and "fused_bytes" in M:
+                # with the f16 pipe the fused layer's HBM floor (0.7 ms) is above its MFMA floor (0.6 ms): HBM-bound
+                fb = M["fused_bytes"](N, E)
+                ach = fb / t_s / 1e9
+                roof = {"kernel": dominant, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": ach / HBM_PEAK_GBS, "traffic": None, "avg_ms": kern[dominant], "bytes_per_launch": fb,
+                        "mfma": mfma}
+            else:
+                roof = dict({"kernel": dominant, "traffic": None, "avg_ms": kern[dominant]}, **mfma)
         agg = hbm_obj(agg_name)
         line = {
             "metric": M["metric"],
             "value": value, "unit": "graphs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "mfma_mode": "f16x3-split (fp32-accurate; exact-f32 re-run on range overflow)" if split else "f32",
             "config": {"workload": M["workload"],
                        "graphs_per_gpu_per_step": G, "nodes_per_gpu": N, "edges_per_gpu": E,
                        "parallelism": f"batch-sharded x{world}, RCCL all-gather of logits"},
-            "finite": ok,
+            "finite": ok, "exact_reruns": eng.exact_reruns(),
             "roofline": roof,
             "aggregation_roofline": agg,
             "kernel_avg_ms": kern,

@@ -113,6 +113,10 @@ class Engine:
         return self.results()
 
     # ---- taps
+    def exact_reruns(self) -> int:
+        """Forward passes repeated on the exact-fp32 kernels (flowgnn.h: flowgnn_exact_reruns)."""
+        return int(self.lib.flowgnn_exact_reruns(self._h))
+
     def csr(self):
         n, e = self.total_nodes, self.total_edges
         row_ptr = np.empty(n + 1, dtype=np.int32)

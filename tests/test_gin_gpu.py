@@ -192,3 +192,27 @@ def test_full_molhiv_size_properties(eng, oracle, gin_weights):
     idx = rng.choice(4113, 128, replace=False)
     sample = gp.concat_batches([b.slice(int(g), int(g) + 1) for g in idx])
     assert close(out[idx], oracle.gin_forward(sample, [gin_weights], nthreads=8))
+
+
+def test_split_precision_and_range_fallback(oracle, gin_weights):
+    """The default GIN layer kernel evaluates every fp32 product of the dense update as three f16 MFMAs
+    (gin_split.hip).  (1) On reference-scale weights it agrees with the fp32 oracle far inside the stated
+    tolerance and never needs the exact-fp32 re-run.  (2) Activations beyond the f16 range (here: the node
+    embedding table scaled by 1e5) trip the range flag; the engine repeats the pass on the fp32 MFMA kernels and
+    the result still matches the oracle (relative tolerance: the logits are ~1e5)."""
+    b = gp.synth_molhiv_batch(200, seed=21)
+    e = Engine("GIN", device=0)
+    e.set_weights(gin_weights)
+    got, want = e.forward(b), oracle.gin_forward(b, [gin_weights])
+    assert np.abs(got - want).max() < 2e-5, np.abs(got - want).max()
+    assert e.exact_reruns() == 0
+    big = dict(gin_weights)
+    big["node_embedding_weight"] = gin_weights["node_embedding_weight"] * np.float32(1e5)
+    e.set_weights(big)
+    got, want = e.forward(b), oracle.gin_forward(b, [big])
+    assert e.exact_reruns() == 1
+    assert np.isfinite(got).all()
+    assert np.allclose(got, want, rtol=1e-4, atol=1e-4 * np.abs(want).max()), np.abs(got - want).max()
+    e.run()  # same resident batch: it stays on the exact kernels, no second detour
+    assert np.array_equal(e.results(), got) and e.exact_reruns() == 1
+    e.close()
