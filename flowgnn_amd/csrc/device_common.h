@@ -191,6 +191,29 @@ __global__ __launch_bounds__(256) void pool_mlp3_kernel(const float* __restrict_
 //   finish(p, acc, self, v, c, in_degree, dst[NDST], s_const, out_base)  (writes the item's outputs)
 // Stage 3 touches global memory only for its stores (and the rare out-of-tile gather): any ordinary load inside
 // the item loop would make hipcc wait for vmcnt(0), i.e. for the previous item's stores, on every trip.
+// model-owned device buffer that grows to the largest batch seen (per-edge scalars)
+struct GrowBuf {
+    float* p = nullptr;
+    size_t cap = 0;
+    int reserve(size_t n) {
+        if (n <= cap) return 0;
+        if (p) hipFree(p);
+        p = nullptr; cap = 0;
+        FG_HIP_TRY(hipMalloc((void**)&p, n * sizeof(float)));
+        cap = n;
+        return 0;
+    }
+    void release() { if (p) hipFree(p); p = nullptr; cap = 0; }
+};
+
+// esc[e] = Policy::src_scalar(src[e]) for every CSR entry: once per forward pass (the scalar depends on the batch only)
+template <class P>
+__global__ __launch_bounds__(256) void edge_scalar_kernel(typename P::Params prm, const int* __restrict__ src,
+                                                           float* __restrict__ esc, int e_tot) {
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < e_tot; e += (long long)gridDim.x * 256)
+        esc[e] = P::src_scalar(prm, src[e]);
+}
+
 template <class P>
 __global__ __launch_bounds__(P::NTHR) void tiled_aggregate_kernel(typename P::Params prm, const float* __restrict__ h,
                                                                    float* __restrict__ out, const int* __restrict__ row_ptr,
@@ -243,7 +266,9 @@ __global__ __launch_bounds__(P::NTHR) void tiled_aggregate_kernel(typename P::Pa
         for (int i = threadIdx.x; i < ne && i < TE; i += NTHR) {
             const int u = src[e0 + i];
             s_edge[i] = pack(u, ecode ? (int)ecode[e0 + i] : 0, t0);
-            if (P::HAS_SCALAR) s_es[i] = P::src_scalar(prm, u);
+            // per-edge source scalar, precomputed in CSR order (edge_scalar_kernel): reading Policy::src_scalar(u) here
+            // would hang a second global round trip (the scalar of node u) behind the load of u itself
+            if constexpr (P::HAS_SCALAR) s_es[i] = prm.esc[e0 + i];
         }
         if (P::NDST > 0 && threadIdx.x < rows) {
             float dv[P::NDST > 0 ? P::NDST : 1];

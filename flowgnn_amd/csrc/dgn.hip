@@ -57,6 +57,7 @@ struct DgnAggPolicy {
     struct Params {
         const float* eig;     // [N][4]
         const int* out_deg;
+        const float* esc;     // [E] eig1[src_e] in CSR order (edge_scalar_kernel)
     };
     struct Acc { float4 m1, m2; float wsum, abssum; };
     __device__ static float src_scalar(const Params& p, int u) { return p.eig[(size_t)u * 4 + 1]; }
@@ -222,7 +223,7 @@ public:
     }
 
     void launch_aggregate(const DeviceBatch& db, const float* hin, hipStream_t s) {
-        DgnAggPolicy::Params prm{db.node_eigen, db.csr.out_deg};
+        DgnAggPolicy::Params prm{db.node_eigen, db.csr.out_deg, esc_.p};
         launch_tiled_aggregate<DgnAggPolicy>(prm, hin, db.scratch, db.csr, nullptr, db.b.n_tot, s);
     }
 
@@ -234,6 +235,12 @@ public:
             ProfScope p(prof, "atom_encoder", s);
             dgn_encoder_kernel<<<grid_for((long long)n * DGN_C, 256, 256 * 8), 256, 0, s>>>(db.b.node_feature, d_emb_, db.h[0], n,
                                                                                           db.csr.err);
+        }
+        if (db.b.e_tot > 0) {  // eig1[src_e] per CSR entry, once per pass
+            if (int rc = esc_.reserve((size_t)db.b.e_tot)) return rc;
+            ProfScope p(prof, "edge_scalar", s);
+            DgnAggPolicy::Params prm{db.node_eigen, db.csr.out_deg, nullptr};
+            edge_scalar_kernel<DgnAggPolicy><<<grid_for(db.b.e_tot, 256, 256 * 8), 256, 0, s>>>(prm, db.csr.src, esc_.p, db.b.e_tot);
         }
         int cur = 0;
         for (int l = 0; l < DGN_L; l++) {
@@ -270,8 +277,10 @@ private:
         float** ptrs[] = {&d_emb_, &d_wf_, &d_wt_, &d_bp_, &d_w0_, &d_b0_, &d_w1_, &d_b1_, &d_w2_, &d_b2_};
         for (auto p : ptrs)
             if (*p) { hipFree(*p); *p = nullptr; }
+        esc_.release();
     }
     bool ready_ = false;
+    GrowBuf esc_;
     float *d_emb_ = nullptr, *d_wf_ = nullptr, *d_wt_ = nullptr, *d_bp_ = nullptr, *d_w0_ = nullptr, *d_b0_ = nullptr,
           *d_w1_ = nullptr, *d_b1_ = nullptr, *d_w2_ = nullptr, *d_b2_ = nullptr;
 };

@@ -14,6 +14,7 @@
 // root / degree / BatchNorm / ReLU epilogue (so a_l is written once), and one fp32-MFMA dense kernel.
 #include "common.h"
 #include "device_common.h"
+#include "dense_split.h"
 #include <cmath>
 #include <cstring>
 
@@ -29,13 +30,15 @@ constexpr int GCN_OT = 7;
 // tiled aggregation (device_common.h).  norm_e = dinv[u] dinv[v] with dinv from the out-degree table.
 template <bool RELU_OUT>
 struct GcnAggPolicy {
-    static constexpr int D = GCN_D, TR = 128, NTHR = 512, TE = 8 * 128, TABLE_ROWS = EDGE_COMBOS;
+    // TE = 448 staged CSR entries (a molpcba tile has ~300): 81.6 KB of LDS, i.e. TWO workgroups per CU; with 1024 it was one
+    static constexpr int D = GCN_D, TR = 128, NTHR = 512, TE = 448, TABLE_ROWS = EDGE_COMBOS;
     static constexpr bool HAS_SCALAR = true;
     static constexpr int NDST = 2;                 // dinv[v], 1 / (outdeg(v) + 1)
     static constexpr int CONST_FLOATS = 3 * GCN_D;  // root | folded BN scale | folded BN shift of the layer
     struct Params {
         const int* out_deg;
-        const float* ep;  // the three epilogue vectors, contiguous
+        const float* ep;   // the three epilogue vectors, contiguous
+        const float* esc;  // [E] dinv[src_e] in CSR order (edge_scalar_kernel)
     };
     struct Acc { float4 m; };
     __device__ static float dinv(int d) { return d > 0 ? 1.0f / sqrtf((float)(d + 1)) : 0.0f; }  // load_inputs.cc:122
@@ -87,6 +90,7 @@ public:
         std::vector<float> v_nemb(nemb, nemb + ND_FEATURE_TOTAL * GCN_D), v_pw(pw, pw + GCN_D), v_pb(pb, pb + 1);
         std::vector<float> ecomb((size_t)GCN_L * EDGE_COMBOS * GCN_D), ep((size_t)GCN_L * 3 * GCN_D);
         std::vector<float> wf_all, wt_all, bp_all;
+        std::vector<uint8_t> split_all;
         static const int ed_off[3] = {0, 5, 11};
         for (int l = 0; l < GCN_L; l++) {
             const float* E = eemb + (size_t)l * ED_FEATURE_PER_LAYER * GCN_D;
@@ -113,8 +117,12 @@ public:
             wf_all.insert(wf_all.end(), wf.begin(), wf.end());
             wt_all.insert(wt_all.end(), wt.begin(), wt.end());
             bp_all.insert(bp_all.end(), bp.begin(), bp.end());
+            const size_t off = split_all.size();
+            split_all.resize(off + dense100_split_bytes(GCN_OT));
+            pack_dense100_split(cw + (size_t)l * GCN_D * GCN_D, cb + (size_t)l * GCN_D, GCN_D, GCN_OT, split_all.data() + off);
         }
         int rc;
+        if ((rc = upload(&d_split_, split_all))) return rc;
         if ((rc = upload(&d_nemb_, v_nemb))) return rc;
         if ((rc = upload(&d_pw_, v_pw))) return rc;
         if ((rc = upload(&d_pb_, v_pb))) return rc;
@@ -156,11 +164,18 @@ public:
 
     template <bool RELU_OUT>
     void launch_aggregate(const DeviceBatch& db, int l, const float* x, float* a, hipStream_t s) {
-        typename GcnAggPolicy<RELU_OUT>::Params prm{db.csr.out_deg, d_ep_ + (size_t)l * 3 * GCN_D};
+        typename GcnAggPolicy<RELU_OUT>::Params prm{db.csr.out_deg, d_ep_ + (size_t)l * 3 * GCN_D, esc_.p};
         launch_tiled_aggregate<GcnAggPolicy<RELU_OUT>>(prm, x, a, db.csr, d_ecomb_ + (size_t)l * EDGE_COMBOS * GCN_D, db.b.n_tot, s);
     }
 
-    void launch_dense(int l, const float* a, float* x, int n, hipStream_t s) {
+    void launch_dense(int l, const float* a, float* x, int n, int* range_flag, hipStream_t s) {
+        if (split_ && !exact_) {
+            const long long wgs = ceil_div_ll(n, 128);
+            const int grid = (int)(wgs < 768 ? wgs : 768);  // persistent: three 8-wave workgroups per CU (45 KB of LDS each)
+            dense100_split_kernel<GCN_OT, false><<<grid, 512, 0, s>>>(a, x, d_split_ + (size_t)l * dense100_split_bytes(GCN_OT), n,
+                                                                      GCN_D, range_flag);
+            return;
+        }
         constexpr int NT = 2;
         const int waves = (int)ceil_div_ll(n, 16 * NT);
         dense100_kernel<GCN_OT, NT, false><<<(waves + 3) / 4, 256, 0, s>>>(
@@ -176,10 +191,16 @@ public:
             atom_encoder_kernel<GCN_D><<<atom_encoder_grid(n, GCN_C), 512, 0, s>>>(
                 db.b.node_feature, d_nemb_, db.scratch, n, db.csr.err);
         }
+        if (db.b.e_tot > 0) {  // dinv[src_e] per CSR entry, once per pass
+            if (int rc = esc_.reserve((size_t)db.b.e_tot)) return rc;
+            ProfScope p(prof, "edge_scalar", s);
+            typename GcnAggPolicy<true>::Params prm{db.csr.out_deg, nullptr, nullptr};
+            edge_scalar_kernel<GcnAggPolicy<true>><<<grid_for(db.b.e_tot, 256, 256 * 8), 256, 0, s>>>(prm, db.csr.src, esc_.p, db.b.e_tot);
+        }
         int cur = 0;
         {
             ProfScope p(prof, "gcn_dense", s);
-            launch_dense(0, db.scratch, db.h[cur], n, s);  // x_0 = W_0 h0 + b_0
+            launch_dense(0, db.scratch, db.h[cur], n, db.range_flag, s);  // x_0 = W_0 h0 + b_0
         }
         for (int l = 1; l < GCN_L; l++) {
             {
@@ -188,7 +209,7 @@ public:
             }
             {
                 ProfScope p(prof, "gcn_dense", s);
-                launch_dense(l, db.scratch, db.h[cur ^ 1], n, s);  // x_l
+                launch_dense(l, db.scratch, db.h[cur ^ 1], n, db.range_flag, s);  // x_l
             }
             cur ^= 1;
         }
@@ -205,6 +226,8 @@ public:
         return 0;
     }
 
+    void set_exact(bool on) override { exact_ = on; }
+
     int aggregation_only(DeviceBatch& db, int layer, hipStream_t s) override {
         if (layer < 0 || layer >= GCN_L) return 1;
         launch_aggregate<true>(db, layer, db.h[db.final_h], db.scratch, s);
@@ -216,8 +239,16 @@ private:
         float** ptrs[] = {&d_nemb_, &d_pw_, &d_pb_, &d_ecomb_, &d_ep_, &d_wf_, &d_wt_, &d_bp_};
         for (auto p : ptrs)
             if (*p) { hipFree(*p); *p = nullptr; }
+        if (d_split_) { hipFree(d_split_); d_split_ = nullptr; }
+        esc_.release();
     }
     bool ready_ = false;
+    GrowBuf esc_;
+    // FLOWGNN_GCN_MFMA=f32 keeps the dense layers on the fp32 matrix pipe (dense100_kernel); the default runs them as three
+    // f16 MFMAs per product (dense_split.h), with the engine falling back to fp32 when the range flag trips
+    bool split_ = !(getenv("FLOWGNN_GCN_MFMA") && strcmp(getenv("FLOWGNN_GCN_MFMA"), "f32") == 0);
+    bool exact_ = false;
+    uint8_t* d_split_ = nullptr;
     float *d_nemb_ = nullptr, *d_pw_ = nullptr, *d_pb_ = nullptr, *d_ecomb_ = nullptr, *d_ep_ = nullptr, *d_wf_ = nullptr,
           *d_wt_ = nullptr, *d_bp_ = nullptr;
 };
