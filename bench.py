@@ -46,6 +46,7 @@ MODELS = {
                    workload="GIN-VN dim=100 (virtual node per graph), ogbg-molhiv-shaped graphs"),
     "GCN": dict(metric="graphs/sec on ogbg-molpcba (GCN, dim=100)", dataset="molpcba", graphs=1 << 18,
                 agg_bytes=lambda n, e: n * 400 * 2 + e * 24, flops=lambda n, e: n * 20000,
+                fused_bytes=lambda n, e: n * 400 * 2,  # split dense layer: read a row, write a row
                 hbm_kernels=("gcn_aggregate",), mfma_kernels=("gcn_dense",),
                 workload="GCN dim=100, batched ogbg-molpcba-shaped graphs on MI355X (BASELINE configs[2])"),
     "GAT": dict(metric="graphs/sec on ogbg-molhiv (GAT, 4 heads x 16)", dataset="molhiv", graphs=1 << 18,
@@ -191,13 +192,25 @@ def main():
         if agg_name not in kern:  # fused layer: measure the message-passing unit alone as well
             kern[agg_name] = eng.aggregation_only_ms(layer=0, iters=10)
 
+        traffic_db = {}
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+            if tj.get(args.model, {}).get("graphs") == G:
+                traffic_db = tj[args.model]
+        except (OSError, ValueError):
+            pass
+
+        def traffic_of(name):  # PMC-measured HBM bytes per launch of the same batch (committed profile), or None
+            return (traffic_db.get(name) or {}).get("bytes")
+
         def hbm_obj(name):
             ach = agg_bytes / (kern[name] * 1e-3) / 1e9
             return {"kernel": name, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": ach / HBM_PEAK_GBS, "traffic": None, "avg_ms": kern[name], "bytes_per_launch": agg_bytes}
+                    "frac": ach / HBM_PEAK_GBS, "traffic": traffic_of(name), "avg_ms": kern[name], "bytes_per_launch": agg_bytes}
 
-        # GIN's dense update runs as three f16 MFMAs per fp32 product unless FLOWGNN_GIN_MFMA=f32 (gin_split.hip)
-        split = args.model.startswith("GIN") and os.environ.get("FLOWGNN_GIN_MFMA", "") != "f32"
+        # GIN's and GCN's dense updates run as three f16 MFMAs per fp32 product unless FLOWGNN_{GIN,GCN}_MFMA=f32
+        split = (args.model.startswith("GIN") and os.environ.get("FLOWGNN_GIN_MFMA", "") != "f32") or \
+                (args.model == "GCN" and os.environ.get("FLOWGNN_GCN_MFMA", "") != "f32")
         roof = None
         if dominant in M["hbm_kernels"]:
             roof = hbm_obj(dominant)
@@ -218,8 +231,8 @@ def main():
                 fb = M["fused_bytes"](N, E)
                 ach = fb / t_s / 1e9
                 roof = {"kernel": dominant, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": ach / HBM_PEAK_GBS, "traffic": None, "avg_ms": kern[dominant], "bytes_per_launch": fb,
-                        "mfma": mfma}
+                        "frac": ach / HBM_PEAK_GBS, "traffic": traffic_of(dominant), "avg_ms": kern[dominant],
+                        "bytes_per_launch": fb, "mfma": mfma}
             else:
                 roof = dict({"kernel": dominant, "traffic": None, "avg_ms": kern[dominant]}, **mfma)
         agg = hbm_obj(agg_name)
