@@ -16,6 +16,7 @@
 // agg[v] = [mean | min | max | std][80], and one wave-per-graph readout kernel.
 #include "common.h"
 #include "device_common.h"
+#include "dense_split.h"
 #include <cmath>
 #include <cstring>
 
@@ -135,6 +136,140 @@ __global__ __launch_bounds__(256) void pna_dense_kernel(const float* __restrict_
     }
 }
 
+// The same update on the f16 matrix pipe, every fp32 product split into three f16 products (dense_split.h / DESIGN.md
+// section 4).  pna_dense_kernel reads its 300 KiB of fp32 fragments per layer from L2 in every wave (30 GB per launch
+// at 2^15 hep10k graphs: L2-bound at 3.3 ms); here a workgroup of 8 waves (128 nodes) streams them through LDS once,
+// K-step by K-step: chunk ks holds the hi/lo fragments of all 15 (scaler, output tile) pairs for the 32 aggregate
+// features of K-step ks (30 KiB, double buffered), and each wave keeps 15 accumulators (60 registers) while the B
+// operand of a K-step (two float4 of the node's aggregate row, split on the fly) is loaded one K-step ahead.
+// K = 320 = 10 K-steps exactly: slot e of K-step ks is aggregate feature [a][16 q + 4 g + (e & 3)] with
+// 5 a + q = 2 ks + (e >> 2).  The scalers are applied to the accumulators in the epilogue, in the oracle's order.
+constexpr int PNA_KS = 10;
+constexpr int PNA_CHUNK = PNA_NS * PNA_OT * 2 * 1024;  // 30 KiB
+constexpr size_t PNA_SPLIT_LAYER_BYTES = (size_t)PNA_KS * PNA_CHUNK;
+
+__device__ __forceinline__ void pna_issue_chunk(const uint8_t* __restrict__ gchunk, char* lds_buf, int wave, int lane) {
+#pragma unroll
+    for (int p = 0; p < 4; p++) {
+        const int piece = wave + 8 * p;  // 30 pieces of 1 KiB over 8 waves
+        if (piece < PNA_CHUNK / 1024) {
+            const uint8_t* g = gchunk + piece * 1024 + lane * 16;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                             (__attribute__((address_space(3))) void*)(lds_buf + piece * 1024), 16, 0, 0);
+        }
+    }
+}
+
+__device__ __forceinline__ void pna_split_step(const char* wb, int lane, const float4& x0, const float4& x1, float4_t (&y)[PNA_NS * PNA_OT],
+                                               float& vmax) {
+    ds_uint4_t b_hi, b_lo;
+    DS_SPLIT2(x0.x, x0.y, b_hi.x, b_lo.x);
+    DS_SPLIT2(x0.z, x0.w, b_hi.y, b_lo.y);
+    DS_SPLIT2(x1.x, x1.y, b_hi.z, b_lo.z);
+    DS_SPLIT2(x1.z, x1.w, b_hi.w, b_lo.w);
+    vmax = __builtin_fmaxf(__builtin_fmaxf(vmax, __builtin_fabsf(x0.x)), __builtin_fabsf(x0.y));
+    vmax = __builtin_fmaxf(__builtin_fmaxf(vmax, __builtin_fabsf(x0.z)), __builtin_fabsf(x0.w));
+    vmax = __builtin_fmaxf(__builtin_fmaxf(vmax, __builtin_fabsf(x1.x)), __builtin_fabsf(x1.y));
+    vmax = __builtin_fmaxf(__builtin_fmaxf(vmax, __builtin_fabsf(x1.z)), __builtin_fabsf(x1.w));
+    asm volatile("" : "+v"(vmax));  // computed here, not sunk to the kernel's end with all its inputs kept alive
+#pragma unroll
+    for (int st = 0; st < PNA_NS * PNA_OT; st++) {
+        const ds_uint4_t a_hi = *reinterpret_cast<const ds_uint4_t*>(wb + (st * 2 + 0) * 1024 + lane * 16);
+        const ds_uint4_t a_lo = *reinterpret_cast<const ds_uint4_t*>(wb + (st * 2 + 1) * 1024 + lane * 16);
+        y[st] = DS_MFMA16(a_hi, b_hi, y[st]);
+        y[st] = DS_MFMA16(a_hi, b_lo, y[st]);
+        y[st] = DS_MFMA16(a_lo, b_hi, y[st]);
+    }
+}
+
+__global__ __launch_bounds__(512) void pna_dense_split_kernel(const float* __restrict__ agg, const float* __restrict__ h,
+                                                               float* __restrict__ hout, const int* __restrict__ out_deg,
+                                                               const uint8_t* __restrict__ wpk, const float* __restrict__ bias,
+                                                               float avg_deg, float oscale, int n_tot,
+                                                               int* __restrict__ range_flag) {
+    // two DISTINCT LDS objects: hipcc can then prove that the DMA into one does not alias the ds_reads of the other
+    __shared__ __attribute__((aligned(16))) char s_a[PNA_CHUNK];  // even K-steps
+    __shared__ __attribute__((aligned(16))) char s_b[PNA_CHUNK];  // odd K-steps
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 15, g = lane >> 4;
+    long long node = (long long)blockIdx.x * 128 + wave * 16 + j;
+    const bool valid = node < n_tot;
+    if (!valid) node = n_tot - 1;
+    pna_issue_chunk(wpk, s_a, wave, lane);
+    // aggregate row of this lane's node as K-step operands: Q = 5 a + q, float4 at [a][16 q + 4 g]
+    const float* row = agg + (size_t)node * (PNA_NA * PNA_D) + 4 * g;
+    auto qoff = [](int Q) { return (Q / 5) * PNA_D + (Q % 5) * 16; };
+    float4 x0 = *reinterpret_cast<const float4*>(row + qoff(0)), x1 = *reinterpret_cast<const float4*>(row + qoff(1));
+    float4_t y[PNA_NS * PNA_OT];
+#pragma unroll
+    for (int i = 0; i < PNA_NS * PNA_OT; i++) y[i] = (float4_t){0.f, 0.f, 0.f, 0.f};
+    float vmax = 0.0f;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+#pragma unroll 1
+    for (int ks = 0; ks < PNA_KS; ks += 2) {
+        // even K-step from s_a while chunk ks+1 streams into s_b and its B operand into registers
+        pna_issue_chunk(wpk + (size_t)(ks + 1) * PNA_CHUNK, s_b, wave, lane);
+        const float4 n0 = *reinterpret_cast<const float4*>(row + qoff(2 * ks + 2)), n1 = *reinterpret_cast<const float4*>(row + qoff(2 * ks + 3));
+        pna_split_step(s_a, lane, x0, x1, y, vmax);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        float4 m0 = n0, m1 = n1;
+        if (ks + 2 < PNA_KS) {
+            pna_issue_chunk(wpk + (size_t)(ks + 2) * PNA_CHUNK, s_a, wave, lane);
+            m0 = *reinterpret_cast<const float4*>(row + qoff(2 * ks + 4));
+            m1 = *reinterpret_cast<const float4*>(row + qoff(2 * ks + 5));
+        }
+        pna_split_step(s_b, lane, n0, n1, y, vmax);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        x0 = m0; x1 = m1;
+    }
+    const float logd = logf((float)(out_deg[node] + 1));  // load_inputs.cc:110 (out-degree)
+    const float sf_t = logd / avg_deg;
+    const float sf_scale = (logd == 0.0f) ? 1.0f : avg_deg / logd;
+    if (valid) {
+#pragma unroll
+        for (int t = 0; t < PNA_OT; t++) {
+            const float4 b = *reinterpret_cast<const float4*>(bias + 16 * t + 4 * g);
+            float4_t fin = {b.x, b.y, b.z, b.w};
+            fin += y[0 * PNA_OT + t] * oscale;
+            fin += sf_t * (y[1 * PNA_OT + t] * oscale);
+            fin += sf_scale * (y[2 * PNA_OT + t] * oscale);
+            const size_t off = (size_t)node * PNA_D + 16 * t + 4 * g;
+            const float4 hv = *reinterpret_cast<const float4*>(h + off);
+            *reinterpret_cast<float4*>(hout + off) =
+                make_float4(hv.x + relu1(fin.x), hv.y + relu1(fin.y), hv.z + relu1(fin.z), hv.w + relu1(fin.w));
+        }
+    }
+    if (__any(!(vmax < 6.0e4f))) {
+        if (lane == 0) atomicOr(range_flag, 1);
+    }
+}
+
+// host: conv_w of one layer [80][3][4][80] -> PNA_SPLIT_LAYER_BYTES; returns 1 / scale
+static float pna_pack_split_layer(const float* cw, uint8_t* out) {
+    float m = 0.0f;
+    for (size_t i = 0; i < (size_t)PNA_D * PNA_NS * PNA_NA * PNA_D; i++) m = std::fmax(m, std::fabs(cw[i]));
+    const float sc = (m > 0.0f && std::isfinite(m)) ? std::ldexp(1.0f, -std::ilogb(m)) : 1.0f;
+    for (int ks = 0; ks < PNA_KS; ks++)
+        for (int s = 0; s < PNA_NS; s++)
+            for (int t = 0; t < PNA_OT; t++)
+                for (int lane = 0; lane < 64; lane++) {
+                    const int i = lane & 15, gk = lane >> 4, o = 16 * t + i;
+                    uint8_t* f = out + (size_t)ks * PNA_CHUNK + (size_t)((s * PNA_OT + t) * 2) * 1024;
+                    for (int e = 0; e < 8; e++) {
+                        const int Q = 2 * ks + (e >> 2), a = Q / 5, q = Q % 5, k = 16 * q + 4 * gk + (e & 3);
+                        const float v = cw[(((size_t)o * PNA_NS + s) * PNA_NA + a) * PNA_D + k] * sc;
+                        const _Float16 hi = (_Float16)v;
+                        const _Float16 lo = (_Float16)(v - (float)hi);
+                        std::memcpy(f + lane * 16 + e * 2, &hi, 2);
+                        std::memcpy(f + 1024 + lane * 16 + e * 2, &lo, 2);
+                    }
+                }
+    return 1.0f / sc;
+}
+
 class PnaModel : public Model {
 public:
     ~PnaModel() override { free_all(); }
@@ -165,7 +300,11 @@ public:
                                     wf[((((((size_t)l * PNA_NS + s) * PNA_OT + tt) * PNA_NA + a) * 5 + q) * 64 + lane) * 4 + r] =
                                         cw[((((size_t)l * PNA_D + o) * PNA_NS + s) * PNA_NA + a) * PNA_D + k];
                                 }
+        std::vector<uint8_t> split((size_t)PNA_L * PNA_SPLIT_LAYER_BYTES);
+        for (int l = 0; l < PNA_L; l++)
+            oscale_[l] = pna_pack_split_layer(cw + (size_t)l * PNA_D * PNA_NS * PNA_NA * PNA_D, split.data() + (size_t)l * PNA_SPLIT_LAYER_BYTES);
         int rc;
+        if ((rc = upload(&d_split_, split))) return rc;
         if ((rc = upload(&d_nemb_, v_nemb))) return rc;
         if ((rc = upload(&d_wf_, wf))) return rc;
         if ((rc = upload(&d_cb_, v_cb))) return rc;
@@ -223,6 +362,12 @@ public:
             {
                 ProfScope p(prof, "pna_dense", s);
                 const int waves = (int)ceil_div_ll(n, 16);
+                if (split_ && !exact_) {
+                    pna_dense_split_kernel<<<(int)ceil_div_ll(n, 128), 512, 0, s>>>(db.scratch, db.h[cur], db.h[cur ^ 1], db.csr.out_deg,
+                                                                                    d_split_ + (size_t)l * PNA_SPLIT_LAYER_BYTES,
+                                                                                    d_cb_ + (size_t)l * PNA_D, avg_deg_, oscale_[l], n,
+                                                                                    db.range_flag);
+                } else
                 pna_dense_kernel<<<(waves + 3) / 4, 256, 0, s>>>(db.scratch, db.h[cur], db.h[cur ^ 1], db.csr.out_deg,
                                                                   d_wf_ + (size_t)l * PNA_NS * PNA_OT * PNA_NA * 5 * 64 * 4,
                                                                   d_cb_ + (size_t)l * PNA_D, avg_deg_, n);
@@ -238,6 +383,8 @@ public:
         return 0;
     }
 
+    void set_exact(bool on) override { exact_ = on; }
+
     int aggregation_only(DeviceBatch& db, int layer, hipStream_t s) override {
         if (layer < 0 || layer >= PNA_L) return 1;
         launch_aggregate(db, db.h[db.final_h], s);
@@ -249,8 +396,14 @@ private:
         float** ptrs[] = {&d_nemb_, &d_wf_, &d_cb_, &d_w1_, &d_b1_, &d_w2_, &d_b2_, &d_w3_, &d_b3_};
         for (auto p : ptrs)
             if (*p) { hipFree(*p); *p = nullptr; }
+        if (d_split_) { hipFree(d_split_); d_split_ = nullptr; }
     }
     bool ready_ = false;
+    // FLOWGNN_PNA_MFMA=f32 keeps the dense update on the fp32 matrix pipe (pna_dense_kernel)
+    bool split_ = !(getenv("FLOWGNN_PNA_MFMA") && strcmp(getenv("FLOWGNN_PNA_MFMA"), "f32") == 0);
+    bool exact_ = false;
+    uint8_t* d_split_ = nullptr;
+    float oscale_[PNA_L] = {1.f, 1.f, 1.f, 1.f};
     float avg_deg_ = 1.0f;
     float *d_nemb_ = nullptr, *d_wf_ = nullptr, *d_cb_ = nullptr, *d_w1_ = nullptr, *d_b1_ = nullptr, *d_w2_ = nullptr,
           *d_b2_ = nullptr, *d_w3_ = nullptr, *d_b3_ = nullptr;
