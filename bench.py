@@ -55,10 +55,12 @@ MODELS = {
                 workload="GAT 5-layer, 4 heads x 16, ogbg-molhiv-shaped graphs on MI355X (BASELINE configs[3])"),
     "PNA": dict(metric="graphs/sec on hep10k (PNA, dim=80)", dataset="hep10k", graphs=1 << 15,
                 agg_bytes=lambda n, e: n * 320 + n * 320 * 4 + e * 8, flops=lambda n, e: n * 153600,
+                fused_bytes=lambda n, e: n * (1280 + 320 + 320),  # split dense: read 4 aggregates + h, write h'
                 hbm_kernels=("pna_aggregate",), mfma_kernels=("pna_dense",),
                 workload="PNA dim=80, hep10k-shaped kNN graphs on MI355X (BASELINE configs[4])"),
     "DGN": dict(metric="graphs/sec on hep10k (DGN, dim=100)", dataset="hep10k", graphs=1 << 15,
                 agg_bytes=lambda n, e: n * 400 * 3 + e * 12, flops=lambda n, e: n * 40000,
+                fused_bytes=lambda n, e: n * (800 + 400 + 400),  # split dense: read both aggregates + h, write h'
                 hbm_kernels=("dgn_aggregate",), mfma_kernels=("dgn_dense",),
                 workload="DGN dim=100, hep10k-shaped kNN graphs on MI355X (BASELINE configs[4])"),
 }
@@ -208,9 +210,10 @@ def main():
             return {"kernel": name, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": ach / HBM_PEAK_GBS, "traffic": traffic_of(name), "avg_ms": kern[name], "bytes_per_launch": agg_bytes}
 
-        # GIN's and GCN's dense updates run as three f16 MFMAs per fp32 product unless FLOWGNN_{GIN,GCN}_MFMA=f32
-        split = (args.model.startswith("GIN") and os.environ.get("FLOWGNN_GIN_MFMA", "") != "f32") or \
-                (args.model == "GCN" and os.environ.get("FLOWGNN_GCN_MFMA", "") != "f32")
+        # the dense updates of GIN, GCN, PNA and DGN run as three f16 MFMAs per fp32 product unless FLOWGNN_<M>_MFMA=f32
+        env = {"GIN": "FLOWGNN_GIN_MFMA", "GIN-VN": "FLOWGNN_GIN_MFMA", "GCN": "FLOWGNN_GCN_MFMA", "PNA": "FLOWGNN_PNA_MFMA",
+               "DGN": "FLOWGNN_DGN_MFMA"}.get(args.model)
+        split = env is not None and os.environ.get(env, "") != "f32"
         roof = None
         if dominant in M["hbm_kernels"]:
             roof = hbm_obj(dominant)

@@ -14,6 +14,7 @@
 // dense kernel (K = 200) with the residual in its epilogue, one wave-per-graph readout kernel.
 #include "common.h"
 #include "device_common.h"
+#include "dense_split.h"
 #include <cmath>
 #include <cstring>
 
@@ -163,6 +164,7 @@ public:
         std::vector<float> v_w0(t[3], t[3] + 50 * 100), v_b0(t[4], t[4] + 50), v_w1(t[5], t[5] + 25 * 50), v_b1(t[6], t[6] + 25),
             v_w2(t[7], t[7] + 25), v_b2(t[8], t[8] + 1);
         std::vector<float> wf_all, wt_all, bp_all;
+        std::vector<uint8_t> split_all;
         std::vector<float> Wb((size_t)DGN_D * DGN_D), zero(DGN_D, 0.0f);
         for (int l = 0; l < DGN_L; l++) {
             const float* W = t[1] + (size_t)l * DGN_D * 2 * DGN_D;  // [out][2][in]
@@ -180,8 +182,12 @@ public:
             wf_all.insert(wf_all.end(), wf2.begin(), wf2.end());
             wt_all.insert(wt_all.end(), wt2.begin(), wt2.end());
             bp_all.insert(bp_all.end(), bp.begin(), bp.end());
+            const size_t off = split_all.size();
+            split_all.resize(off + dense200_split_bytes(DGN_OT));
+            pack_dense200_split(W, t[2] + (size_t)l * DGN_D, DGN_D, DGN_OT, split_all.data() + off);
         }
         int rc;
+        if ((rc = upload(&d_split_, split_all))) return rc;
         if ((rc = upload(&d_emb_, v_emb))) return rc;
         if ((rc = upload(&d_wf_, wf_all))) return rc;
         if ((rc = upload(&d_wt_, wt_all))) return rc;
@@ -251,6 +257,11 @@ public:
             {
                 ProfScope p(prof, "dgn_dense", s);
                 const int waves = (int)ceil_div_ll(n, 16);
+                if (split_ && !exact_) {
+                    const long long wgs = ceil_div_ll(n, 256);
+                    dense200_res_relu_split_kernel<DGN_OT><<<(int)(wgs < 256 ? wgs : 256), 1024, 0, s>>>(
+                        db.scratch, db.h[cur], db.h[cur ^ 1], d_split_ + (size_t)l * dense200_split_bytes(DGN_OT), n, DGN_D, db.range_flag);
+                } else
                 dgn_dense_kernel<<<(waves + 3) / 4, 256, 0, s>>>(db.scratch, db.h[cur], db.h[cur ^ 1],
                                                                   d_wf_ + (size_t)l * 2 * DGN_OT * 6 * 64 * 4,
                                                                   d_wt_ + (size_t)l * 2 * DGN_OT * 64, d_bp_ + (size_t)l * DGN_OT * 16, n);
@@ -266,6 +277,8 @@ public:
         return 0;
     }
 
+    void set_exact(bool on) override { exact_ = on; }
+
     int aggregation_only(DeviceBatch& db, int layer, hipStream_t s) override {
         if (layer < 0 || layer >= DGN_L) return 1;
         launch_aggregate(db, db.h[db.final_h], s);
@@ -278,8 +291,13 @@ private:
         for (auto p : ptrs)
             if (*p) { hipFree(*p); *p = nullptr; }
         esc_.release();
+        if (d_split_) { hipFree(d_split_); d_split_ = nullptr; }
     }
     bool ready_ = false;
+    // FLOWGNN_DGN_MFMA=f32 keeps the dense update on the fp32 matrix pipe (dgn_dense_kernel)
+    bool split_ = !(getenv("FLOWGNN_DGN_MFMA") && strcmp(getenv("FLOWGNN_DGN_MFMA"), "f32") == 0);
+    bool exact_ = false;
+    uint8_t* d_split_ = nullptr;
     GrowBuf esc_;
     float *d_emb_ = nullptr, *d_wf_ = nullptr, *d_wt_ = nullptr, *d_bp_ = nullptr, *d_w0_ = nullptr, *d_b0_ = nullptr,
           *d_w1_ = nullptr, *d_b1_ = nullptr, *d_w2_ = nullptr, *d_b2_ = nullptr;
