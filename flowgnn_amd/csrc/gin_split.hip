@@ -60,6 +60,13 @@ typedef uint32_t uint4_t __attribute__((ext_vector_type(4)));
         (LO) = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(a_ - (float)hp_.x, b_ - (float)hp_.y));   \
     } while (0)
 
+constexpr int GS_HUB = 8;     // rows with more in-edges than this are summed by the whole wave
+constexpr int GS_MAXHUB = 4;  // ... if the wave has at most this many of them
+template <int CTRL>
+__device__ __forceinline__ float gs_dpp(float v) {  // v of another lane of the same row of 16, selected by the DPP control
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+
 template <int WAVES>
 __device__ __forceinline__ void gs_issue_chunk(const uint8_t* __restrict__ gchunk, char* lds_buf, int wave, int lane) {
 #pragma unroll
@@ -174,6 +181,7 @@ __global__ __launch_bounds__(WAVES * 64) void gin_layer_split_kernel(const float
     // of the other and leaves the DMA in flight under the MFMAs (see gin_layer_fused_kernel)
     __shared__ __attribute__((aligned(16))) char s_a[GS_CHUNK_BYTES];  // edge-embedding combos, then odd chunks
     __shared__ __attribute__((aligned(16))) char s_b[GS_CHUNK_BYTES];  // even chunks
+    __shared__ float s_hub[NT == 1 ? WAVES * GS_MAXHUB * GS_D : 1];     // parked sums of hub rows
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // in an SGPR: DMA addresses = scalar base + lane * 16
     const int j = lane & 15, g = lane >> 4;
@@ -199,6 +207,57 @@ __global__ __launch_bounds__(WAVES * 64) void gin_layer_split_kernel(const float
         e_end[nt] = valid ? row_ptr[node + 1] : 0;
 #pragma unroll
         for (int k = 0; k < 25; k++) bq[nt][k] = 0.0f;
+    }
+    // Hub rows (in-degree > GS_HUB; GIN-VN's virtual node has one in-edge per node of its graph): left to the loop below,
+    // one such row keeps its whole wave iterating with 4 of 64 lanes busy.  Instead the row's in-edges are dealt to the 16
+    // node lanes of the wave (edge i of the row to lane i mod 16), summed per lane in CSR order and combined with a
+    // butterfly over the node lanes (DPP: xor 1, xor 2, half-row mirror, row mirror).  The association differs from the
+    // oracle's strictly sequential sum (covered by the stated tolerance) but depends only on the row, not on where it
+    // sits in the batch, so results stay bit-identical under any batch split or order.  The owner lanes park the row
+    // sum in LDS (400 B per hub row) until the regular rows are done.
+    bool is_hub = false;
+    int hub_slot = 0;
+    if constexpr (NT == 1) {
+        const int deg = e_end[0] - e_cur[0];
+        unsigned long long hubs = __ballot(deg > GS_HUB) & 0xFFFFull;  // lanes 0..15: one bit per node of the wave
+        if (__popcll(hubs) > GS_MAXHUB) hubs = 0;  // uniformly dense rows (kNN graphs): the ordinary loop keeps all lanes busy
+        int nh = 0;
+        while (hubs != 0) {  // wave-uniform, at most GS_MAXHUB trips
+            const int hj = __ffsll((long long)hubs) - 1;
+            hubs &= hubs - 1;
+            const int hb = __builtin_amdgcn_readlane(e_cur[0], hj), he = __builtin_amdgcn_readlane(e_end[0], hj);
+            for (int e = hb + j; __any(e < he); e += 16) {
+                if (e < he) {
+                    const int u = src[e];
+                    const int code = ecode[e];
+                    const float* hr = h + (size_t)u * GS_D + 4 * g;
+                    const float* er = s_ecomb + code * GS_D + 4 * g;
+#pragma unroll
+                    for (int q = 0; q < 6; q++) {
+                        const float4 x = *reinterpret_cast<const float4*>(hr + 16 * q);
+                        const float4 w = *reinterpret_cast<const float4*>(er + 16 * q);
+                        bq[0][4 * q + 0] += relu1(w.x + x.x);
+                        bq[0][4 * q + 1] += relu1(w.y + x.y);
+                        bq[0][4 * q + 2] += relu1(w.z + x.z);
+                        bq[0][4 * q + 3] += relu1(w.w + x.w);
+                    }
+                    bq[0][24] += relu1(s_ecomb[code * GS_D + 96 + g] + h[(size_t)u * GS_D + 96 + g]);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 25; k++) {
+                float v = bq[0][k];
+                v += gs_dpp<0xB1>(v);   // quad_perm [1,0,3,2]
+                v += gs_dpp<0x4E>(v);   // quad_perm [2,3,0,1]
+                v += gs_dpp<0x141>(v);  // row_half_mirror
+                v += gs_dpp<0x140>(v);  // row_mirror
+                if (j == hj) s_hub[(wave * GS_MAXHUB + nh) * GS_D + g * 25 + k] = v;
+                bq[0][k] = 0.0f;
+            }
+            if (j == hj) { is_hub = true; hub_slot = nh; }
+            nh++;
+        }
+        if (is_hub) e_cur[0] = e_end[0];  // this row's edges are done
     }
 #pragma unroll
     for (int nt = 0; nt < NT; nt++) {  // indices one edge ahead of the feature gathers
@@ -237,6 +296,12 @@ __global__ __launch_bounds__(WAVES * 64) void gin_layer_split_kernel(const float
                 }
                 bq[nt][24] += relu1(s_ecomb[code * GS_D + 96 + g] + xt);
             }
+        }
+    }
+    if constexpr (NT == 1) {
+        if (is_hub) {
+#pragma unroll
+            for (int k = 0; k < 25; k++) bq[0][k] = s_hub[(wave * GS_MAXHUB + hub_slot) * GS_D + g * 25 + k];
         }
     }
     float vmax = 0.0f;
