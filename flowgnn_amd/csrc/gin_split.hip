@@ -187,15 +187,15 @@ __global__ __launch_bounds__(WAVES * 64) void gin_layer_split_kernel(const float
     const int j = lane & 15, g = lane >> 4;
     const long long node_base = (long long)blockIdx.x * (WAVES * 16 * NT) + wave * (16 * NT);
 
-    gs_issue_chunk<WAVES>(wchunks, s_b, wave, lane);  // chunk 0 in flight while we gather
-    for (int i = threadIdx.x; i < GS_ECOMB_BYTES / 16; i += WAVES * 64)
-        reinterpret_cast<float4*>(s_a)[i] = reinterpret_cast<const float4*>(ecomb)[i];
-    __syncthreads();
-    const float* s_ecomb = reinterpret_cast<const float*>(s_a);
-
     // ---- gather (MP unit): a = h[v] + sum_e relu(h[src_e] + ecomb[code_e]), CSR order
+    // A workgroup spends about half its life before its first MFMA (measured with s_memtime: staging the combos 3.5 us,
+    // gather 4.5 us, 8 MLP steps 10 us), and all of that is a chain of dependent round trips.  So: the CSR row bounds are
+    // requested first; chunk 0 and the edge-embedding combos go to LDS by DMA (no register round trip) while the row
+    // bounds come back; the node's own row and the first two CSR entries are requested next; only then does the wave wait.
     float bq[NT][25];
-    int e_cur[NT], e_end[NT], u_nx[NT], c_nx[NT];
+    int e_cur[NT], e_end[NT];
+    float4 self_x[NT][6];
+    float self_t[NT];
     long long self_row[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; nt++) {
@@ -203,11 +203,40 @@ __global__ __launch_bounds__(WAVES * 64) void gin_layer_split_kernel(const float
         const bool valid = node < n_tot;
         if (!valid) node = n_tot - 1;
         self_row[nt] = node;
-        e_cur[nt] = valid ? row_ptr[node] : 0;
-        e_end[nt] = valid ? row_ptr[node + 1] : 0;
+        e_cur[nt] = row_ptr[node];
+        e_end[nt] = row_ptr[node + 1];
+        if (!valid) e_end[nt] = e_cur[nt];
+    }
+    gs_issue_chunk<WAVES>(wchunks, s_b, wave, lane);  // chunk 0
+#pragma unroll
+    for (int p = 0; p < (24 + WAVES - 1) / WAVES; p++) {  // 60 x 400 B of combos = 23 pieces of 1 KiB + 448 B
+        const int piece = wave + WAVES * p;
+        if (piece < 23 || (piece == 23 && lane < 28)) {
+            const char* gp = reinterpret_cast<const char*>(ecomb) + piece * 1024 + lane * 16;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gp,
+                                             (__attribute__((address_space(3))) void*)(s_a + piece * 1024), 16, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT; nt++) {
+        const float* hr = h + (size_t)self_row[nt] * GS_D + 4 * g;
+#pragma unroll
+        for (int q = 0; q < 6; q++) self_x[nt][q] = *reinterpret_cast<const float4*>(hr + 16 * q);
+        self_t[nt] = h[(size_t)self_row[nt] * GS_D + 96 + g];
 #pragma unroll
         for (int k = 0; k < 25; k++) bq[nt][k] = 0.0f;
     }
+    // CSR entries two ahead of the row gathers (first use of the row bounds)
+    int ua[NT], ca[NT], ub[NT], cb[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; nt++) {
+        const int ea = e_cur[nt] < e_end[nt] ? e_cur[nt] : 0, eb = e_cur[nt] + 1 < e_end[nt] ? e_cur[nt] + 1 : 0;
+        ua[nt] = src[ea]; ca[nt] = ecode[ea];
+        ub[nt] = src[eb]; cb[nt] = ecode[eb];
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of the combos (and of chunk 0)
+    __syncthreads();
+    const float* s_ecomb = reinterpret_cast<const float*>(s_a);
     // Hub rows (in-degree > GS_HUB; GIN-VN's virtual node has one in-edge per node of its graph): left to the loop below,
     // one such row keeps its whole wave iterating with 4 of 64 lanes busy.  Instead the row's in-edges are dealt to the 16
     // node lanes of the wave (edge i of the row to lane i mod 16), summed per lane in CSR order and combined with a
@@ -259,12 +288,7 @@ __global__ __launch_bounds__(WAVES * 64) void gin_layer_split_kernel(const float
         }
         if (is_hub) e_cur[0] = e_end[0];  // this row's edges are done
     }
-#pragma unroll
-    for (int nt = 0; nt < NT; nt++) {  // indices one edge ahead of the feature gathers
-        const bool on = e_cur[nt] < e_end[nt];
-        u_nx[nt] = on ? src[e_cur[nt]] : 0;
-        c_nx[nt] = on ? ecode[e_cur[nt]] : 0;
-    }
+    // one in-edge per trip, CSR entries one trip ahead
     while (true) {
         bool any = false;
 #pragma unroll
@@ -273,12 +297,13 @@ __global__ __launch_bounds__(WAVES * 64) void gin_layer_split_kernel(const float
 #pragma unroll
         for (int nt = 0; nt < NT; nt++) {
             if (e_cur[nt] < e_end[nt]) {
-                const int u = u_nx[nt];
-                const int code = c_nx[nt];
+                const int u = ua[nt];
+                const int code = ca[nt];
                 e_cur[nt]++;
-                if (e_cur[nt] < e_end[nt]) {
-                    u_nx[nt] = src[e_cur[nt]];
-                    c_nx[nt] = ecode[e_cur[nt]];
+                ua[nt] = ub[nt]; ca[nt] = cb[nt];
+                if (e_cur[nt] + 1 < e_end[nt]) {
+                    ub[nt] = src[e_cur[nt] + 1];
+                    cb[nt] = ecode[e_cur[nt] + 1];
                 }
                 const float* hr = h + (size_t)u * GS_D + 4 * g;
                 const float* er = s_ecomb + code * GS_D + 4 * g;
@@ -309,13 +334,12 @@ __global__ __launch_bounds__(WAVES * 64) void gin_layer_split_kernel(const float
     float in_t[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; nt++) {  // + (1 + eps) h[v], eps == 0; then split into the MLP1 B operands
-        const float* hr = h + (size_t)self_row[nt] * GS_D + 4 * g;
 #pragma unroll
         for (int q = 0; q < 6; q++) {
-            const float4 x = *reinterpret_cast<const float4*>(hr + 16 * q);
+            const float4 x = self_x[nt][q];
             bq[nt][4 * q + 0] += x.x; bq[nt][4 * q + 1] += x.y; bq[nt][4 * q + 2] += x.z; bq[nt][4 * q + 3] += x.w;
         }
-        bq[nt][24] += h[(size_t)self_row[nt] * GS_D + 96 + g];
+        bq[nt][24] += self_t[nt];
 #pragma unroll
         for (int ks = 0; ks < 3; ks++) {
             GS_SPLIT2(bq[nt][8 * ks + 0], bq[nt][8 * ks + 1], in_hi[nt][ks].x, in_lo[nt][ks].x);
