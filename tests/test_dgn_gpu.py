@@ -75,3 +75,21 @@ def test_hep10k_size_properties(eng, oracle, w):
     idx = np.random.default_rng(0).choice(10000, 48, replace=False)
     sample = gp.concat_batches([b.slice(int(g), int(g) + 1) for g in idx])
     assert close(out[idx], oracle.dgn_forward(sample, [w], nthreads=8), 10.0)
+
+
+def test_split_range_fallback(oracle, w):
+    """Same contract as GCN/GIN: dense200_res_relu_split_kernel raises the range flag beyond the f16 range and the engine
+    repeats the pass on dgn_dense_kernel (fp32 MFMA)."""
+    b = gp.synth_hep10k_batch(24, seed=47)
+    e = Engine("DGN", device=0)
+    e.set_weights(w)
+    got, want = e.forward(b), oracle.dgn_forward(b, [w], nthreads=8)
+    assert e.exact_reruns() == 0 and np.allclose(got, want, rtol=1e-4, atol=1e-4 * max(1.0, np.abs(want).max()))
+    big = dict(w)
+    k = "embedding_h_atom_embedding_list_weights"
+    big[k] = w[k] * np.float32(1e6)
+    e.set_weights(big)
+    got, want = e.forward(b), oracle.dgn_forward(b, [big], nthreads=8)
+    assert e.exact_reruns() == 1 and np.isfinite(got).all()
+    assert np.allclose(got, want, rtol=2e-4, atol=2e-4 * np.abs(want).max()), np.abs(got - want).max()
+    e.close()

@@ -89,3 +89,20 @@ def test_full_molpcba_size_properties(eng, oracle, w):
     sample = gp.concat_batches([b.slice(int(g), int(g) + 1) for g in idx])
     assert np.array_equal(eng.forward(sample), out[idx])
     assert close(out[idx], oracle.gcn_forward(sample, [w], nthreads=8))
+
+
+def test_split_range_fallback(oracle, w):
+    """The dense layers run as three f16 MFMAs per fp32 product (dense_split.h).  Reference-scale weights never
+    need the exact-fp32 re-run; an embedding table scaled by 1e6 pushes activations past the f16 range, the
+    engine repeats the pass on the fp32 kernels and still matches the oracle (relative: outputs are huge)."""
+    b = gp.synth_molpcba_batch(150, seed=41)
+    e = Engine("GCN", device=0)
+    e.set_weights(w)
+    assert close(e.forward(b), oracle.gcn_forward(b, [w], nthreads=8)) and e.exact_reruns() == 0
+    big = dict(w)
+    big["node_embedding_weight"] = w["node_embedding_weight"] * np.float32(1e6)
+    e.set_weights(big)
+    got, want = e.forward(b), oracle.gcn_forward(b, [big], nthreads=8)
+    assert e.exact_reruns() == 1 and np.isfinite(got).all()
+    assert np.allclose(got, want, rtol=1e-4, atol=1e-4 * np.abs(want).max()), np.abs(got - want).max()
+    e.close()

@@ -75,3 +75,20 @@ def test_hep10k_size_properties(eng, oracle, w):
     idx = np.random.default_rng(0).choice(10000, 48, replace=False)
     sample = gp.concat_batches([b.slice(int(g), int(g) + 1) for g in idx])
     assert close(out[idx], oracle.pna_forward(sample, [w], nthreads=8), 10.0)
+
+
+def test_split_range_fallback(oracle, w):
+    """Same contract as GCN/GIN: pna_dense_split_kernel raises the range flag when an aggregate leaves the f16 range
+    and the engine repeats the pass on pna_dense_kernel (fp32 MFMA)."""
+    b = gp.synth_hep10k_batch(24, seed=43)
+    e = Engine("PNA", device=0)
+    e.set_weights(w)
+    got, want = e.forward(b), oracle.pna_forward(b, [w], nthreads=8)
+    assert e.exact_reruns() == 0 and np.allclose(got, want, rtol=1e-4, atol=1e-4 * max(1.0, np.abs(want).max()))
+    big = dict(w)
+    big["node_embedding_weight"] = w["node_embedding_weight"] * np.float32(1e6)
+    e.set_weights(big)
+    got, want = e.forward(b), oracle.pna_forward(b, [big], nthreads=8)
+    assert e.exact_reruns() == 1 and np.isfinite(got).all()
+    assert np.allclose(got, want, rtol=2e-4, atol=2e-4 * np.abs(want).max()), np.abs(got - want).max()
+    e.close()
