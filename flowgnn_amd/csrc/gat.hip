@@ -82,59 +82,97 @@ struct GatLayerDev {
     const float* a_tgt;
 };
 
-// Persistent workgroups (grid-stride over 16-node wave tiles): the layer's 32 KiB of weight fragments are staged in LDS
-// once per workgroup instead of being read from L2 by every wave (13.7 GB per launch at 2^18 molhiv graphs), and the
-// CSR entry of the next in-edge is requested one trip ahead of the score / projection loads that depend on it.
+// Persistent 8-wave workgroups walk tiles of 128 consecutive nodes.  Per tile the projections (128 x 256 B) and the
+// attention scores (128 x 32 B) of the tile's nodes are copied into LDS by LDS-DMA, and the attention gather reads its
+// neighbours from there: molecule batches are block diagonal with consecutive node ids, so almost every neighbour is a row
+// of the same tile (the rare exception -- a graph straddling a tile boundary -- is fetched from global memory by loads that
+// wait for themselves).  The layer's 32 KiB of weight fragments are staged in LDS once per workgroup instead of being read
+// from L2 by every wave (13.7 GB per launch at 2^18 molhiv graphs), and the CSR entry of the next in-edge is requested one
+// trip ahead.  68 KB of LDS: two workgroups per CU.
+constexpr int GAT_TR = 128;
 template <bool FINAL>
-__global__ __launch_bounds__(256) void gat_layer_kernel(const float* __restrict__ proj, const float* __restrict__ skipin,
+__global__ __launch_bounds__(512) void gat_layer_kernel(const float* __restrict__ proj, const float* __restrict__ skipin,
                                                          const float* __restrict__ scores, float* __restrict__ proj_out,
                                                          float* __restrict__ skip_out, float* __restrict__ scores_out,
                                                          float* __restrict__ emb_out, const int* __restrict__ row_ptr,
                                                          const int* __restrict__ src, GatLayerDev w, int n_tot) {
     __shared__ __attribute__((aligned(16))) float4 s_wskip[16 * 64];
     __shared__ __attribute__((aligned(16))) float4 s_wlin[FINAL ? 1 : 16 * 64];
-    for (int i = threadIdx.x; i < 16 * 64; i += 256) {
+    __shared__ __attribute__((aligned(16))) float4 s_proj[GAT_TR * 16];
+    __shared__ __attribute__((aligned(16))) float4 s_sc[GAT_TR * 2];
+    for (int i = threadIdx.x; i < 16 * 64; i += 512) {
         s_wskip[i] = reinterpret_cast<const float4*>(w.wskip)[i];
         if (!FINAL) s_wlin[i] = reinterpret_cast<const float4*>(w.wlin)[i];
     }
-    __syncthreads();
-    const int lane = threadIdx.x & 63;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int j = lane & 15, g = lane >> 4;
     const float4* proj4 = reinterpret_cast<const float4*>(proj);
     const float4* sc4 = reinterpret_cast<const float4*>(scores);
-    const long long n_tiles = ((long long)n_tot + 15) / 16;
-  for (long long wave = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); wave < n_tiles; wave += (long long)gridDim.x * 4) {
-    const long long node_base = wave * 16;
+    const int n_tiles = (n_tot + GAT_TR - 1) / GAT_TR;
+    const long long proj_last = (long long)n_tot * (GAT_F * 4) - 16, sc_last = (long long)n_tot * 32 - 16;
+  for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const int tbase = tile * GAT_TR;
+    __syncthreads();  // the previous tile's rows are no longer read (first time: nothing to wait for)
+#pragma unroll
+    for (int p = 0; p < 4; p++) {  // 32 pieces of 1 KiB; bytes past the end of the array: its last 16 bytes (rows of no node)
+        const int piece = wv + 8 * p;
+        long long off = (long long)tbase * (GAT_F * 4) + piece * 1024 + lane * 16;
+        off = off < proj_last ? off : proj_last;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(reinterpret_cast<const char*>(proj) + off),
+                                         (__attribute__((address_space(3))) void*)(reinterpret_cast<char*>(s_proj) + piece * 1024), 16, 0, 0);
+    }
+    if (wv < 4) {
+        long long off = (long long)tbase * 32 + wv * 1024 + lane * 16;
+        off = off < sc_last ? off : sc_last;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(reinterpret_cast<const char*>(scores) + off),
+                                         (__attribute__((address_space(3))) void*)(reinterpret_cast<char*>(s_sc) + wv * 1024), 16, 0, 0);
+    }
     int lds_lane = lane;
     asm volatile("" : "+v"(lds_lane));  // opaque per tile: otherwise all 32 fragment reads are hoisted out of the tile loop (256 VGPRs)
-    long long node = node_base + j;
+    long long node = (long long)tbase + wv * 16 + j;
     const bool valid = node < n_tot;
     if (!valid) node = n_tot - 1;
-
-    // ---- attention gather (pull): self edge first, then the CSR row (ascending source)
-    const float4 ssrc = sc4[node * 2 + 0];
-    float4 den = make_float4(0.f, 0.f, 0.f, 0.f);
-    float4 num[4];
-#pragma unroll
-    for (int t = 0; t < 4; t++) num[t] = make_float4(0.f, 0.f, 0.f, 0.f);
     int e = valid ? row_ptr[node] : 0;
     const int e_end = valid ? row_ptr[node + 1] : 0;
     int u = (int)node;  // the self edge
     int u_nx = e < e_end ? src[e] : 0;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();  // the tile's rows (and, first time, the weights) are in LDS
+
+    // ---- attention gather (pull): self edge first, then the CSR row (ascending source)
+    const float4 ssrc = s_sc[(wv * 16 + j) * 2 + 0];
+    float4 den = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 num[4];
+#pragma unroll
+    for (int t = 0; t < 4; t++) num[t] = make_float4(0.f, 0.f, 0.f, 0.f);
     bool more = true;
     while (__any(more)) {
         if (more) {
-            const float4 st = sc4[(size_t)u * 2 + 1];
+            const unsigned ul = (unsigned)(u - tbase);
+            const bool in = ul < (unsigned)GAT_TR;
+            const unsigned lr = in ? ul : 0u;
+            // LDS reads unconditional (clamped) and pinned; global memory only in a branch, through asm loads (a
+            // `cond ? lds : global` select makes hipcc emit flat loads with a full wait after each)
+            float4 st = s_sc[lr * 2 + 1];
+            asm volatile("" : "+v"(st.x), "+v"(st.y), "+v"(st.z), "+v"(st.w));
             float4 p[4];
 #pragma unroll
-            for (int t = 0; t < 4; t++) p[t] = proj4[(size_t)u * 16 + 4 * t + g];
+            for (int t = 0; t < 4; t++) {
+                p[t] = s_proj[lr * 16 + 4 * t + g];
+                asm volatile("" : "+v"(p[t].x), "+v"(p[t].y), "+v"(p[t].z), "+v"(p[t].w));
+            }
+            if (!in) {
+                st = load_f4_rare(sc4 + (size_t)u * 2 + 1);
+#pragma unroll
+                for (int t = 0; t < 4; t++) p[t] = load_f4_rare(proj4 + (size_t)u * 16 + 4 * t + g);
+            }
             more = e < e_end;
             u = u_nx;
             e++;
             if (e < e_end) u_nx = src[e];
             float4 s = make_float4(ssrc.x + st.x, ssrc.y + st.y, ssrc.z + st.z, ssrc.w + st.w);
-            s.x = expf(s.x < 0.f ? s.x * 0.2f : s.x); s.y = expf(s.y < 0.f ? s.y * 0.2f : s.y);
-            s.z = expf(s.z < 0.f ? s.z * 0.2f : s.z); s.w = expf(s.w < 0.f ? s.w * 0.2f : s.w);
+            s.x = __expf(s.x < 0.f ? s.x * 0.2f : s.x); s.y = __expf(s.y < 0.f ? s.y * 0.2f : s.y);
+            s.z = __expf(s.z < 0.f ? s.z * 0.2f : s.z); s.w = __expf(s.w < 0.f ? s.w * 0.2f : s.w);
             den.x += s.x; den.y += s.y; den.z += s.z; den.w += s.w;
 #pragma unroll
             for (int t = 0; t < 4; t++) {
@@ -189,8 +227,8 @@ __global__ __launch_bounds__(256) void gat_layer_kernel(const float* __restrict_
     // ---- ELU, next skip input, next projection (chained through registers), next scores
 #pragma unroll
     for (int t = 0; t < 4; t++) {
-        acc[t].x = acc[t].x <= 0.f ? expf(acc[t].x) - 1.0f : acc[t].x; acc[t].y = acc[t].y <= 0.f ? expf(acc[t].y) - 1.0f : acc[t].y;
-        acc[t].z = acc[t].z <= 0.f ? expf(acc[t].z) - 1.0f : acc[t].z; acc[t].w = acc[t].w <= 0.f ? expf(acc[t].w) - 1.0f : acc[t].w;
+        acc[t].x = acc[t].x <= 0.f ? __expf(acc[t].x) - 1.0f : acc[t].x; acc[t].y = acc[t].y <= 0.f ? __expf(acc[t].y) - 1.0f : acc[t].y;
+        acc[t].z = acc[t].z <= 0.f ? __expf(acc[t].z) - 1.0f : acc[t].z; acc[t].w = acc[t].w <= 0.f ? __expf(acc[t].w) - 1.0f : acc[t].w;
         if (valid)
             *reinterpret_cast<float4*>(skip_out + (size_t)node * GAT_F + 16 * t + 4 * g) = make_float4(acc[t].x, acc[t].y, acc[t].z, acc[t].w);
     }
@@ -230,7 +268,7 @@ __global__ __launch_bounds__(256) void gat_layer_kernel(const float* __restrict_
         reinterpret_cast<float4*>(scores_out)[node * 2 + 0] = ss;
         reinterpret_cast<float4*>(scores_out)[node * 2 + 1] = st;
     }
-  }  // wave tiles
+  }  // tiles
 }
 
 class GatModel : public Model {
@@ -334,7 +372,6 @@ public:
                                                                         db.h[0], skipb[0], scoreb[0], n);
         }
         int cur = 0;
-        const int waves = (int)ceil_div_ll(n, 16);
         for (int l = 0; l < GAT_L; l++) {
             GatLayerDev w;
             w.wskip = d_wskip_ + (size_t)l * 16 * 64 * 4;
@@ -342,13 +379,14 @@ public:
             w.a_src = d_asrc_ + (size_t)(l + 1 < GAT_L ? l + 1 : l) * GAT_D * GAT_H;
             w.a_tgt = d_atgt_ + (size_t)(l + 1 < GAT_L ? l + 1 : l) * GAT_D * GAT_H;
             ProfScope p(prof, "gat_layer", s);
-            const int layer_grid = (waves + 3) / 4 < 256 * 4 ? (waves + 3) / 4 : 256 * 4;  // persistent: 4 workgroups per CU (106 registers)
+            const int n_tiles = (n + GAT_TR - 1) / GAT_TR;
+            const int layer_grid = n_tiles < 512 ? n_tiles : 512;  // persistent: two 8-wave workgroups per CU (68 KB of LDS each)
             if (l < GAT_L - 1) {
-                gat_layer_kernel<false><<<layer_grid, 256, 0, s>>>(db.h[cur], skipb[cur], scoreb[cur], db.h[cur ^ 1], skipb[cur ^ 1],
+                gat_layer_kernel<false><<<layer_grid, 512, 0, s>>>(db.h[cur], skipb[cur], scoreb[cur], db.h[cur ^ 1], skipb[cur ^ 1],
                                                                          scoreb[cur ^ 1], emb, db.csr.row_ptr, db.csr.src, w, n);
                 cur ^= 1;
             } else {
-                gat_layer_kernel<true><<<layer_grid, 256, 0, s>>>(db.h[cur], skipb[cur], scoreb[cur], nullptr, nullptr, nullptr, emb,
+                gat_layer_kernel<true><<<layer_grid, 512, 0, s>>>(db.h[cur], skipb[cur], scoreb[cur], nullptr, nullptr, nullptr, emb,
                                                                         db.csr.row_ptr, db.csr.src, w, n);
             }
         }
