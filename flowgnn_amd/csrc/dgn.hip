@@ -230,7 +230,7 @@ public:
 
     void launch_aggregate(const DeviceBatch& db, const float* hin, hipStream_t s) {
         DgnAggPolicy::Params prm{db.node_eigen, db.csr.out_deg, esc_.p};
-        launch_tiled_aggregate<DgnAggPolicy>(prm, hin, db.scratch, db.csr, nullptr, db.b.n_tot, s);
+        launch_tiled_aggregate<DgnAggPolicy>(prm, hin, db.scratch, db.csr, nullptr, db.b.n_tot, tiles_.p, tile_nominal_, s);
     }
 
     int forward(DeviceBatch& db, Profiler& prof, hipStream_t s) override {
@@ -242,6 +242,7 @@ public:
             dgn_encoder_kernel<<<grid_for((long long)n * DGN_C, 256, 256 * 8), 256, 0, s>>>(db.b.node_feature, d_emb_, db.h[0], n,
                                                                                           db.csr.err);
         }
+        if (int rc = make_tile_bounds(tiles_, db.b.node_off, db.b.num_graphs, n, tile_nominal_, tile_slack_, s)) return rc;
         if (db.b.e_tot > 0) {  // eig1[src_e] per CSR entry, once per pass
             if (int rc = esc_.reserve((size_t)db.b.e_tot)) return rc;
             ProfScope p(prof, "edge_scalar", s);
@@ -291,9 +292,13 @@ private:
         for (auto p : ptrs)
             if (*p) { hipFree(*p); *p = nullptr; }
         esc_.release();
+        tiles_.release();
         if (d_split_) { hipFree(d_split_); d_split_ = nullptr; }
     }
     bool ready_ = false;
+    GrowBufI tiles_;  // graph-aligned tile starts of the resident batch (tile_bounds_kernel)
+    int tile_nominal_ = getenv("FLOWGNN_TILE_NOMINAL") ? atoi(getenv("FLOWGNN_TILE_NOMINAL")) : 64;
+    int tile_slack_ = getenv("FLOWGNN_TILE_SLACK") ? atoi(getenv("FLOWGNN_TILE_SLACK")) : 64;
     // FLOWGNN_DGN_MFMA=f32 keeps the dense update on the fp32 matrix pipe (dgn_dense_kernel)
     bool split_ = !(getenv("FLOWGNN_DGN_MFMA") && strcmp(getenv("FLOWGNN_DGN_MFMA"), "f32") == 0);
     bool exact_ = false;

@@ -165,7 +165,8 @@ public:
     template <bool RELU_OUT>
     void launch_aggregate(const DeviceBatch& db, int l, const float* x, float* a, hipStream_t s) {
         typename GcnAggPolicy<RELU_OUT>::Params prm{db.csr.out_deg, d_ep_ + (size_t)l * 3 * GCN_D, esc_.p};
-        launch_tiled_aggregate<GcnAggPolicy<RELU_OUT>>(prm, x, a, db.csr, d_ecomb_ + (size_t)l * EDGE_COMBOS * GCN_D, db.b.n_tot, s);
+        launch_tiled_aggregate<GcnAggPolicy<RELU_OUT>>(prm, x, a, db.csr, d_ecomb_ + (size_t)l * EDGE_COMBOS * GCN_D, db.b.n_tot, tiles_.p,
+                                                       tile_nominal_, s);
     }
 
     void launch_dense(int l, const float* a, float* x, int n, int* range_flag, hipStream_t s) {
@@ -191,6 +192,7 @@ public:
             atom_encoder_kernel<GCN_D><<<atom_encoder_grid(n, GCN_C), 512, 0, s>>>(
                 db.b.node_feature, d_nemb_, db.scratch, n, db.csr.err);
         }
+        if (int rc = make_tile_bounds(tiles_, db.b.node_off, db.b.num_graphs, n, tile_nominal_, tile_slack_, s)) return rc;
         if (db.b.e_tot > 0) {  // dinv[src_e] per CSR entry, once per pass
             if (int rc = esc_.reserve((size_t)db.b.e_tot)) return rc;
             ProfScope p(prof, "edge_scalar", s);
@@ -241,9 +243,13 @@ private:
             if (*p) { hipFree(*p); *p = nullptr; }
         if (d_split_) { hipFree(d_split_); d_split_ = nullptr; }
         esc_.release();
+        tiles_.release();
     }
     bool ready_ = false;
     GrowBuf esc_;
+    GrowBufI tiles_;  // graph-aligned tile starts of the resident batch (tile_bounds_kernel)
+    int tile_nominal_ = getenv("FLOWGNN_TILE_NOMINAL") ? atoi(getenv("FLOWGNN_TILE_NOMINAL")) : 96;
+    int tile_slack_ = getenv("FLOWGNN_TILE_SLACK") ? atoi(getenv("FLOWGNN_TILE_SLACK")) : 32;
     // FLOWGNN_GCN_MFMA=f32 keeps the dense layers on the fp32 matrix pipe (dense100_kernel); the default runs them as three
     // f16 MFMAs per product (dense_split.h), with the engine falling back to fp32 when the range flag trips
     bool split_ = !(getenv("FLOWGNN_GCN_MFMA") && strcmp(getenv("FLOWGNN_GCN_MFMA"), "f32") == 0);

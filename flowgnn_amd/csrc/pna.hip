@@ -33,7 +33,8 @@ constexpr float PNA_SENT_MIN = -32.0f;          // ap_fixed_min, PNA/src/util.h:
 
 // agg[v][a][d], a = {mean, min, max, std}: policy of the generic tiled aggregation (device_common.h)
 struct PnaAggPolicy {
-    static constexpr int D = PNA_D, TR = 128, NTHR = 512, TE = 20 * 128, TABLE_ROWS = 0;
+    // TR = LDS capacity in rows: tiles are graph aligned, 112 nominal rows + up to 48 to reach the graph boundary behind them
+    static constexpr int D = PNA_D, TR = 160, NTHR = 512, TE = 16 * 160, TABLE_ROWS = 0;
     static constexpr bool HAS_SCALAR = false;
     static constexpr int NDST = 0, CONST_FLOATS = 0;
     struct Params { int unused; };
@@ -342,7 +343,7 @@ public:
 
     void launch_aggregate(const DeviceBatch& db, const float* hin, hipStream_t s) {
         PnaAggPolicy::Params prm{0};
-        launch_tiled_aggregate<PnaAggPolicy>(prm, hin, db.scratch, db.csr, nullptr, db.b.n_tot, s);
+        launch_tiled_aggregate<PnaAggPolicy>(prm, hin, db.scratch, db.csr, nullptr, db.b.n_tot, tiles_.p, tile_nominal_, s);
     }
 
     int forward(DeviceBatch& db, Profiler& prof, hipStream_t s) override {
@@ -353,6 +354,7 @@ public:
             atom_encoder_kernel<PNA_D><<<atom_encoder_grid(n, PNA_C), 512, 0, s>>>(db.b.node_feature, d_nemb_,
                                                                                                     db.h[0], n, db.csr.err);
         }
+        if (int rc = make_tile_bounds(tiles_, db.b.node_off, db.b.num_graphs, n, tile_nominal_, tile_slack_, s)) return rc;
         int cur = 0;
         for (int l = 0; l < PNA_L; l++) {
             {
@@ -397,8 +399,12 @@ private:
         for (auto p : ptrs)
             if (*p) { hipFree(*p); *p = nullptr; }
         if (d_split_) { hipFree(d_split_); d_split_ = nullptr; }
+        tiles_.release();
     }
     bool ready_ = false;
+    GrowBufI tiles_;  // graph-aligned tile starts of the resident batch (tile_bounds_kernel)
+    int tile_nominal_ = getenv("FLOWGNN_TILE_NOMINAL") ? atoi(getenv("FLOWGNN_TILE_NOMINAL")) : 112;
+    int tile_slack_ = getenv("FLOWGNN_TILE_SLACK") ? atoi(getenv("FLOWGNN_TILE_SLACK")) : 48;
     // FLOWGNN_PNA_MFMA=f32 keeps the dense update on the fp32 matrix pipe (pna_dense_kernel)
     bool split_ = !(getenv("FLOWGNN_PNA_MFMA") && strcmp(getenv("FLOWGNN_PNA_MFMA"), "f32") == 0);
     bool exact_ = false;
