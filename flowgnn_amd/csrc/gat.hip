@@ -41,13 +41,11 @@ __global__ __launch_bounds__(256) void gat_encoder_kernel(const int* __restrict_
     const long long vv = valid ? v : n_tot - 1;
     const long long row = feat_row ? feat_row[vv] : vv;
     float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
-    float fd = 0.f;
 #pragma unroll
     for (int k = 0; k < ND_FEATURE; k++) {
         const float f = (float)node_feature[(size_t)row * ND_FEATURE + k];
         const float4 w = reinterpret_cast<const float4*>(lin0)[d * ND_FEATURE + k];
         p.x += f * w.x; p.y += f * w.y; p.z += f * w.z; p.w += f * w.w;
-        if (k == d) fd = f;
     }
     const float4 as = reinterpret_cast<const float4*>(a_src)[d], at = reinterpret_cast<const float4*>(a_tgt)[d];
     float4 ss = make_float4(p.x * as.x, p.y * as.y, p.z * as.z, p.w * as.w);
@@ -59,7 +57,6 @@ __global__ __launch_bounds__(256) void gat_encoder_kernel(const int* __restrict_
     }
     if (!valid) return;
     reinterpret_cast<float4*>(proj)[i] = p;
-    reinterpret_cast<float4*>(skipin)[i] = make_float4(d < ND_FEATURE ? fd : 0.f, 0.f, 0.f, 0.f);
     if (d == 0) {
         reinterpret_cast<float4*>(scores)[v * 2 + 0] = ss;
         reinterpret_cast<float4*>(scores)[v * 2 + 1] = st;
@@ -90,12 +87,13 @@ struct GatLayerDev {
 // from L2 by every wave (13.7 GB per launch at 2^18 molhiv graphs), and the CSR entry of the next in-edge is requested one
 // trip ahead.  68 KB of LDS: two workgroups per CU.
 constexpr int GAT_TR = 128;
-template <bool FINAL>
+template <bool FINAL, bool FIRST>
 __global__ __launch_bounds__(512) void gat_layer_kernel(const float* __restrict__ proj, const float* __restrict__ skipin,
                                                          const float* __restrict__ scores, float* __restrict__ proj_out,
                                                          float* __restrict__ skip_out, float* __restrict__ scores_out,
                                                          float* __restrict__ emb_out, const int* __restrict__ row_ptr,
-                                                         const int* __restrict__ src, GatLayerDev w, int n_tot) {
+                                                         const int* __restrict__ src, GatLayerDev w, int n_tot,
+                                                         const int* __restrict__ node_feature, const int* __restrict__ feat_row) {
     __shared__ __attribute__((aligned(16))) float4 s_wskip[16 * 64];
     __shared__ __attribute__((aligned(16))) float4 s_wlin[FINAL ? 1 : 16 * 64];
     __shared__ __attribute__((aligned(16))) float4 s_proj[GAT_TR * 16];
@@ -185,8 +183,17 @@ __global__ __launch_bounds__(512) void gat_layer_kernel(const float* __restrict_
     float bq[16];
 #pragma unroll
     for (int q = 0; q < 4; q++) {
-        const float4 x = *reinterpret_cast<const float4*>(skipin + (size_t)node * GAT_F + 16 * q + 4 * g);
-        bq[4 * q + 0] = x.x; bq[4 * q + 1] = x.y; bq[4 * q + 2] = x.z; bq[4 * q + 3] = x.w;
+        if (FIRST) {
+            // layer 0: the skip input is the raw integer feature vector (element 4 d of the 64-float row holds feature d < 9,
+            // everything else is zero), read from the 36-byte feature row instead of a 256-byte row the encoder would write
+            const int d = 4 * q + g;
+            const long long frow = feat_row ? feat_row[node] : node;
+            bq[4 * q + 0] = d < ND_FEATURE ? (float)node_feature[(size_t)frow * ND_FEATURE + d] : 0.0f;
+            bq[4 * q + 1] = 0.0f; bq[4 * q + 2] = 0.0f; bq[4 * q + 3] = 0.0f;
+        } else {
+            const float4 x = *reinterpret_cast<const float4*>(skipin + (size_t)node * GAT_F + 16 * q + 4 * g);
+            bq[4 * q + 0] = x.x; bq[4 * q + 1] = x.y; bq[4 * q + 2] = x.z; bq[4 * q + 3] = x.w;
+        }
     }
     float4_t acc[4];
 #pragma unroll
@@ -381,13 +388,18 @@ public:
             ProfScope p(prof, "gat_layer", s);
             const int n_tiles = (n + GAT_TR - 1) / GAT_TR;
             const int layer_grid = n_tiles < 512 ? n_tiles : 512;  // persistent: two 8-wave workgroups per CU (68 KB of LDS each)
-            if (l < GAT_L - 1) {
-                gat_layer_kernel<false><<<layer_grid, 512, 0, s>>>(db.h[cur], skipb[cur], scoreb[cur], db.h[cur ^ 1], skipb[cur ^ 1],
-                                                                         scoreb[cur ^ 1], emb, db.csr.row_ptr, db.csr.src, w, n);
+            if (l == 0) {
+                gat_layer_kernel<false, true><<<layer_grid, 512, 0, s>>>(db.h[cur], skipb[cur], scoreb[cur], db.h[cur ^ 1], skipb[cur ^ 1],
+                                                                        scoreb[cur ^ 1], emb, db.csr.row_ptr, db.csr.src, w, n,
+                                                                        db.b.node_feature, feat_row);
+                cur ^= 1;
+            } else if (l < GAT_L - 1) {
+                gat_layer_kernel<false, false><<<layer_grid, 512, 0, s>>>(db.h[cur], skipb[cur], scoreb[cur], db.h[cur ^ 1], skipb[cur ^ 1],
+                                                                         scoreb[cur ^ 1], emb, db.csr.row_ptr, db.csr.src, w, n, nullptr, nullptr);
                 cur ^= 1;
             } else {
-                gat_layer_kernel<true><<<layer_grid, 512, 0, s>>>(db.h[cur], skipb[cur], scoreb[cur], nullptr, nullptr, nullptr, emb,
-                                                                        db.csr.row_ptr, db.csr.src, w, n);
+                gat_layer_kernel<true, false><<<layer_grid, 512, 0, s>>>(db.h[cur], skipb[cur], scoreb[cur], nullptr, nullptr, nullptr, emb,
+                                                                        db.csr.row_ptr, db.csr.src, w, n, nullptr, nullptr);
             }
         }
         db.final_h = cur;
