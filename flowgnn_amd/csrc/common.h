@@ -117,6 +117,8 @@ struct DeviceBatch {
     int final_h;              // which h[] holds the last stage's output (set by forward)
     const float* tap;         // optional debug tap returned by flowgnn_get_h instead of h[final_h]
     int tap_dim;
+    bool h_valid;             // h[final_h] holds the last stage's node embeddings (false: the model folded the readout into its last
+                              // layer and never wrote them; flowgnn_get_h then repeats the pass with Model::set_keep_h(true))
     int* range_flag;          // [1] set by a reduced-range kernel whose operands left its accurate range (see Model::set_exact)
 };
 
@@ -126,6 +128,8 @@ public:
     // A model whose default kernels are fp32-accurate only inside an operand range (GIN: split-f16 MFMA) raises
     // DeviceBatch::range_flag when an input leaves it; the engine then calls set_exact(true) and repeats forward().
     virtual void set_exact(bool) {}
+    // debug taps: make forward() materialise the last layer's node embeddings even if that costs a round trip
+    virtual void set_keep_h(bool) {}
     virtual int emb_dim() const = 0;
     virtual int scratch_dim() const = 0;          // floats per node of scratch the forward needs
     virtual bool has_edge_attr() const = 0;

@@ -81,6 +81,21 @@ inline int atom_encoder_grid(long long n_tot, int C) {
     return (int)(blocks < 512 ? (blocks > 0 ? blocks : 1) : 512);
 }
 
+// ---------------------------------------------------------------- readout with the linear head already applied per node
+// out[g] = (sum of score[v] over the nodes of graph g, in node order) / n_g + bias: the second half of a mean-pool +
+// linear readout whose per-node dot products were computed in the last layer's epilogue (gin_split.hip).
+template <int UNUSED = 0>  // a template only for its linkage (the header is included by several translation units)
+__global__ __launch_bounds__(256) void segment_mean_bias_kernel(const float* __restrict__ score, const int* __restrict__ node_off,
+                                                                         const float* __restrict__ pb, float* __restrict__ out,
+                                                                         int num_graphs) {
+    const int gidx = blockIdx.x * 256 + threadIdx.x;
+    if (gidx >= num_graphs) return;
+    const int n0 = node_off[gidx], n1 = node_off[gidx + 1];
+    float s = 0.0f;
+    for (int v = n0; v < n1; v++) s += score[v];
+    out[gidx] = s / (float)(n1 - n0) + pb[0];
+}
+
 // ---------------------------------------------------------------- readout: mean pool + linear head
 // One wavefront per graph; lanes 0..24 take even rows, lanes 32..56 odd rows (float4 chunks).
 template <int D>

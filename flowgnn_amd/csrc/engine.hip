@@ -351,6 +351,7 @@ int flowgnn_run(flowgnn_engine* e) {
     }
     e->db.tap = nullptr;
     e->db.tap_dim = 0;
+    e->db.h_valid = true;
     e->model->set_exact(e->force_exact);
     ENGINE_TRY(e, e->model->forward(e->db, e->prof, e->stream));
     hipError_t he = hipGetLastError();
@@ -469,6 +470,15 @@ int flowgnn_get_h(flowgnn_engine* e, float* h_host, int* dim) {
     if (!e->ran) return FLOWGNN_ERR_STATE;
     int rc = flowgnn_sync(e);
     if (rc) return rc;
+    if (!e->db.h_valid && !e->db.tap) {  // the readout was folded into the last layer: repeat the pass with the tap on
+        e->model->set_keep_h(true);
+        e->model->set_exact(e->force_exact);
+        rc = e->model->forward(e->db, e->prof, e->stream);
+        e->model->set_keep_h(false);
+        if (rc) { e->err = fg::last_error_text(); return rc; }
+        rc = flowgnn_sync(e);
+        if (rc) return rc;
+    }
     const int D = e->db.tap ? e->db.tap_dim : e->model->emb_dim();
     const float* srcp = e->db.tap ? e->db.tap : e->db.h[e->db.final_h];
     if (dim) *dim = D;

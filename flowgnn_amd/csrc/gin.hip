@@ -1023,11 +1023,20 @@ public:
             atom_encoder_kernel<GIN_D><<<atom_encoder_grid(n, GIN_C), 512, 0, s>>>(db.b.node_feature, d_nemb_, db.h[0], n, db.csr.err);
         }
         int cur = 0;
+        bool folded = false;
         for (int l = 0; l < GIN_L; l++) {
             if (fused_ && variant_ == 0 && split_ && !exact_) {
                 ProfScope p(prof, "gin_layer_fused", s);
-                launch_gin_layer_split(db.h[cur], db.h[cur ^ 1], db.csr.row_ptr, db.csr.src, db.csr.ecode, layer_dev(l).ecomb,
-                                       d_split_ + (size_t)l * GS_LAYER_BYTES, n, db.b.e_tot, l != GIN_L - 1, db.range_flag, split_nt_, s);
+                // last layer: the readout's per-node dot product h'[v] . w_pred is taken in the epilogue and only that
+                // leaves the kernel (db.scratch as float[n]); the rows are written only for the flowgnn_get_h tap
+                const bool fold = l == GIN_L - 1 && fold_readout_ && !keep_h_;
+                launch_gin_layer_split(db.h[cur], fold ? db.scratch : db.h[cur ^ 1], db.csr.row_ptr, db.csr.src, db.csr.ecode,
+                                       layer_dev(l).ecomb, d_split_ + (size_t)l * GS_LAYER_BYTES, n, db.b.e_tot, l != GIN_L - 1,
+                                       db.range_flag, split_nt_, s, fold ? d_pw_ : nullptr);
+                if (fold) {
+                    folded = true;
+                    break;
+                }
                 cur ^= 1;
                 continue;
             }
@@ -1066,15 +1075,21 @@ public:
             cur ^= 1;
         }
         db.final_h = cur;
+        db.h_valid = !folded;
         {
             ProfScope p(prof, "mean_pool_linear", s);
-            mean_pool_linear_kernel<GIN_D><<<(db.b.num_graphs + 3) / 4, 256, 0, s>>>(db.h[cur], db.b.node_off, d_pw_, d_pb_,
-                                                                                     db.out, db.b.num_graphs);
+            if (folded)
+                segment_mean_bias_kernel<0><<<(db.b.num_graphs + 255) / 256, 256, 0, s>>>(db.scratch, db.b.node_off, d_pb_, db.out,
+                                                                                       db.b.num_graphs);
+            else
+                mean_pool_linear_kernel<GIN_D><<<(db.b.num_graphs + 3) / 4, 256, 0, s>>>(db.h[cur], db.b.node_off, d_pw_, d_pb_,
+                                                                                         db.out, db.b.num_graphs);
         }
         return 0;
     }
 
     void set_exact(bool on) override { exact_ = on; }
+    void set_keep_h(bool on) override { keep_h_ = on; }
 
     int aggregation_only(DeviceBatch& db, int layer, hipStream_t s) override {
         if (layer < 0 || layer >= GIN_L) return 1;
@@ -1101,6 +1116,9 @@ private:
     // 4 = eight-wave workgroups of 128 nodes (default), 1 / 2 = four waves x 1 / 2 node tiles, 3 = persistent tile-staged kernel
     int split_nt_ = getenv("FLOWGNN_GIN_SPLIT_NT") ? atoi(getenv("FLOWGNN_GIN_SPLIT_NT")) : 4;
     bool exact_ = false;
+    bool keep_h_ = false;
+    // FLOWGNN_GIN_FOLD_READOUT=0 keeps the separate mean-pool + linear kernel (and the last layer's 2.7 GB of rows)
+    bool fold_readout_ = !(getenv("FLOWGNN_GIN_FOLD_READOUT") && atoi(getenv("FLOWGNN_GIN_FOLD_READOUT")) == 0);
     uint8_t* d_split_ = nullptr;
     float* d_chunks_ = nullptr;
     float *d_nemb_ = nullptr, *d_pw_ = nullptr, *d_pb_ = nullptr, *d_ecomb_ = nullptr, *d_w1f_ = nullptr,

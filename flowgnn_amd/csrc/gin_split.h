@@ -23,10 +23,11 @@ void gin_split_pack_layer(const float* w1, const float* b1, const float* w2, con
 
 // variant: 1 / 2 = one workgroup per 64 / 128 nodes (any degree distribution; 1 is the default), 3 = persistent
 // tile-staged kernel for molecule-like batches (FLOWGNN_GIN_SPLIT_NT=3; see gin_split.hip for what it does and costs)
+// pool_w != null (last layer, readout folded in): hout is float[n_tot] and receives h'[v] . pool_w instead of the rows
 // one GIN layer: hout = MLP(h[v] + sum_e relu(h[src_e] + ecomb[code_e])); *range_flag |= 1 if an operand left the
 // range in which the split is fp32-accurate (the caller then repeats the forward pass on the fp32 MFMA kernel)
 void launch_gin_layer_split(const float* h, float* hout, const int* row_ptr, const int* src, const uint8_t* ecode,
                             const float* ecomb, const uint8_t* chunks, int n_tot, int e_tot, int relu_out, int* range_flag,
-                            int variant, hipStream_t s);
+                            int variant, hipStream_t s, const float* pool_w = nullptr);
 
 }  // namespace fg

@@ -176,7 +176,7 @@ __global__ __launch_bounds__(WAVES * 64) void gin_layer_split_kernel(const float
                                                                const uint8_t* __restrict__ ecode,
                                                                const float* __restrict__ ecomb,
                                                                const uint8_t* __restrict__ wchunks, int n_tot, int relu_out,
-                                                               int* __restrict__ range_flag) {
+                                                               int* __restrict__ range_flag, const float* __restrict__ pool_w) {
     // two DISTINCT LDS objects: the compiler can then prove that the LDS-DMA into one does not alias the ds_reads
     // of the other and leaves the DMA in flight under the MFMAs (see gin_layer_fused_kernel)
     __shared__ __attribute__((aligned(16))) char s_a[GS_CHUNK_BYTES];  // edge-embedding combos, then odd chunks
@@ -381,6 +381,29 @@ __global__ __launch_bounds__(WAVES * 64) void gin_layer_split_kernel(const float
         __syncthreads();
     }
 
+    if (pool_w != nullptr) {
+        // Last layer with the readout folded in: the graph logit is mean_v(h'[v]) . w + b = mean_v(h'[v] . w) + b, so only the
+        // per-node dot product leaves the kernel (4 B per node instead of a 400 B row that the readout would read back);
+        // hout is then a float[n_tot].  Fixed summation order per node (7 tiles x 4 in the lane, then the 4 lanes of the node).
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++) {
+            float part = 0.0f;
+#pragma unroll
+            for (int t2 = 0; t2 < GS_T2; t2++) {
+                const int col = 16 * t2 + 4 * g;
+                if (col < GS_D) {
+                    float4_t r = acc2[nt][t2] * oscale;
+                    if (relu_out) { r.x = relu1(r.x); r.y = relu1(r.y); r.z = relu1(r.z); r.w = relu1(r.w); }
+                    const float4 pw = *reinterpret_cast<const float4*>(pool_w + col);
+                    part += r.x * pw.x; part += r.y * pw.y; part += r.z * pw.z; part += r.w * pw.w;
+                }
+            }
+            part += __shfl_xor(part, 16, 64);
+            part += __shfl_xor(part, 32, 64);
+            const long long node = node_base + nt * 16 + j;
+            if (g == 0 && node < n_tot) hout[node] = part;
+        }
+    } else {
 #pragma unroll
     for (int nt = 0; nt < NT; nt++) {
         const long long node = node_base + nt * 16 + j;
@@ -395,6 +418,7 @@ __global__ __launch_bounds__(WAVES * 64) void gin_layer_split_kernel(const float
                 *reinterpret_cast<float4*>(row + col) = make_float4(r.x, r.y, r.z, r.w);
             }
         }
+    }
     }
     // operands beyond the f16 range (inf after pkrtz is impossible, saturation is silent): tell the engine
     if (__any(!(vmax < 6.0e4f))) {
@@ -955,7 +979,8 @@ void gin_split_pack_layer(const float* w1, const float* b1, const float* w2, con
 
 void launch_gin_layer_split(const float* h, float* hout, const int* row_ptr, const int* src, const uint8_t* ecode,
                             const float* ecomb, const uint8_t* chunks, int n_tot, int e_tot, int relu_out, int* range_flag,
-                            int nt, hipStream_t s) {
+                            int nt, hipStream_t s, const float* pool_w) {
+    if (pool_w && nt == 3) nt = 4;  // the tile-staged variant has no folded readout
     if (e_tot == 0 && nt == 3) nt = 1;  // the tile-staged kernel stages CSR entries unconditionally
     if (nt == 3) {
         const int n_tiles = (int)ceil_div_ll(n_tot, GT_TILE);
@@ -966,15 +991,15 @@ void launch_gin_layer_split(const float* h, float* hout, const int* row_ptr, con
     }
     if (nt == 4) {  // 8 waves, 128 nodes per workgroup, 2 workgroups per CU
         const int blocks = (int)ceil_div_ll(n_tot, 128);
-        gin_layer_split_kernel<1, 8><<<blocks, 512, 0, s>>>(h, hout, row_ptr, src, ecode, ecomb, chunks, n_tot, relu_out, range_flag);
+        gin_layer_split_kernel<1, 8><<<blocks, 512, 0, s>>>(h, hout, row_ptr, src, ecode, ecomb, chunks, n_tot, relu_out, range_flag, pool_w);
         return;
     }
     if (nt == 2) {
         const int blocks = (int)ceil_div_ll(n_tot, 128);
-        gin_layer_split_kernel<2, 4><<<blocks, 256, 0, s>>>(h, hout, row_ptr, src, ecode, ecomb, chunks, n_tot, relu_out, range_flag);
+        gin_layer_split_kernel<2, 4><<<blocks, 256, 0, s>>>(h, hout, row_ptr, src, ecode, ecomb, chunks, n_tot, relu_out, range_flag, pool_w);
     } else {
         const int blocks = (int)ceil_div_ll(n_tot, 64);
-        gin_layer_split_kernel<1, 4><<<blocks, 256, 0, s>>>(h, hout, row_ptr, src, ecode, ecomb, chunks, n_tot, relu_out, range_flag);
+        gin_layer_split_kernel<1, 4><<<blocks, 256, 0, s>>>(h, hout, row_ptr, src, ecode, ecomb, chunks, n_tot, relu_out, range_flag, pool_w);
     }
 }
 
