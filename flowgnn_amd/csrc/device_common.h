@@ -47,20 +47,36 @@ __global__ __launch_bounds__(512) void atom_encoder_kernel(const int* __restrict
     __shared__ int s_row[NB * ND_FEATURE];  // table row per (node, feature), validated
     for (int i = threadIdx.x; i < ND_FEATURE_TOTAL * C; i += 512) s_tab[i] = reinterpret_cast<const float4*>(table)[i];
     const int n_blocks = (n_tot + NB - 1) / NB;
+    constexpr int PER = (NB * ND_FEATURE + 511) / 512;  // feature words per thread and block (3)
+    int pre[PER];
+    auto fetch = [&](int blk) {  // this thread's feature words of block blk (requested one block ahead of their use)
+        const long long base = (long long)blk * NB * ND_FEATURE, lim = (long long)n_tot * ND_FEATURE;
+#pragma unroll
+        for (int p = 0; p < PER; p++) {
+            const long long i = base + threadIdx.x + 512 * p;
+            pre[p] = (blk < n_blocks && threadIdx.x + 512 * p < NB * ND_FEATURE && i < lim) ? node_feature[i] : 0;
+        }
+    };
+    fetch(blockIdx.x);
     for (int blk = blockIdx.x; blk < n_blocks; blk += gridDim.x) {
         const int v0 = blk * NB;
         const int nv = (n_tot - v0) < NB ? (n_tot - v0) : NB;
         __syncthreads();  // previous iteration's readers are done (first time: the table is in place)
-        for (int i = threadIdx.x; i < nv * ND_FEATURE; i += 512) {
-            const int k = i % ND_FEATURE;
-            int f = node_feature[(size_t)v0 * ND_FEATURE + i];
-            if (f < 0 || f >= c_nd_card[k]) {
-                atomicMax(err, ERR_NODE_FEAT);
-                f = 0;
+#pragma unroll
+        for (int p = 0; p < PER; p++) {
+            const int i = threadIdx.x + 512 * p;
+            if (i < nv * ND_FEATURE) {
+                const int k = i % ND_FEATURE;
+                int f = pre[p];
+                if (f < 0 || f >= c_nd_card[k]) {
+                    atomicMax(err, ERR_NODE_FEAT);
+                    f = 0;
+                }
+                s_row[i] = (c_nd_off[k] + f) * C;
             }
-            s_row[i] = (c_nd_off[k] + f) * C;
         }
         __syncthreads();
+        fetch(blk + gridDim.x);
         for (int i = threadIdx.x; i < nv * C; i += 512) {
             const int v = i / C;
             const int c = i - v * C;
