@@ -79,35 +79,37 @@ def make_batch(dataset: str, graphs: int, seed: int):
     raise ValueError(dataset)
 
 
-def oracle_forward(model: str, batch, w, nthreads: int):
+def oracle_forward(model: str, batch, w, nthreads: int, numeric: str = "f32"):
     from oracle import oracle
+    if numeric == "q6.10":
+        return oracle.gin_forward_q(batch, [w], nthreads=nthreads)[0]
     fn = {"GIN": oracle.gin_forward, "GIN-VN": oracle.gin_forward, "GCN": oracle.gcn_forward, "GAT": oracle.gat_forward,
           "PNA": oracle.pna_forward, "DGN": oracle.dgn_forward}[model]
     return fn(batch, [w], nthreads=nthreads)
 
 
-def cpu_baseline(model, batch, w, budget_s: float = 15.0):
+def cpu_baseline(model, batch, w, budget_s: float = 15.0, numeric: str = "f32"):
     """The oracle (CPU restatement of the reference, kind='port') timed on this host's cores on a
     bounded sample of the same workload."""
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     probe = batch.slice(0, min(128, batch.num_graphs))
     t0 = time.perf_counter()
-    oracle_forward(model, probe, w, 1)
+    oracle_forward(model, probe, w, 1, numeric)
     t1 = time.perf_counter()
     rate1 = probe.num_graphs / (t1 - t0)
     # OpenMP over graphs scales far from linearly on a big host: measure the parallel rate on a small sample first,
     # then size the timed sample for about budget_s seconds of wall clock
     warm = batch.slice(0, min(batch.num_graphs, 16 * cores))
     t0 = time.perf_counter()
-    oracle_forward(model, warm, w, cores)
+    oracle_forward(model, warm, w, cores, numeric)
     ratep = warm.num_graphs / (time.perf_counter() - t0)
     n = int(min(batch.num_graphs, max(256, ratep * budget_s)))
     sample = batch.slice(0, n)
     t0 = time.perf_counter()
-    oracle_forward(model, sample, w, cores)
+    oracle_forward(model, sample, w, cores, numeric)
     t1 = time.perf_counter()
     return {"value": n / (t1 - t0), "unit": "graphs/s", "cores": cores, "kind": "port",
-            "sample": f"first {n} graphs of the bench batch, oracle/{model.lower().replace('-vn', '')}_oracle.c, "
+            "sample": f"first {n} graphs of the bench batch, oracle/{'ginq' if numeric == 'q6.10' else model.lower().replace('-vn', '')}_oracle.c, "
                       f"OpenMP over graphs, {cores} threads",
             "single_core_value": rate1}
 
@@ -120,6 +122,8 @@ def main():
     ap.add_argument("--model", default="GIN", choices=sorted(MODELS))
     ap.add_argument("--graphs", type=int, default=0, help="graphs per GPU per step (default: the model's roofline batch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--numeric", default="f32", choices=["f32", "q6.10"],
+                    help="q6.10: the reference's ap_fixed<16,6> bit-faithful mode (GIN / GIN-VN only; a fidelity mode, ~10x slower)")
     args = ap.parse_args()
 
     import torch
@@ -145,6 +149,8 @@ def main():
     w = weights.SYNTH[args.model](seed=7)
     eng = Engine(args.model, device=local_rank)
     eng.set_weights(w)
+    if args.numeric != "f32":
+        eng.set_numeric_mode(args.numeric)
     eng.set_batch(batch)
     G, N, E = batch.num_graphs, batch.total_nodes, batch.total_edges
 
@@ -191,7 +197,8 @@ def main():
         layer = {k: v for k, v in prof.items() if k in M["hbm_kernels"] + M["mfma_kernels"]}
         dominant = max(layer.items(), key=lambda kv: kv[1]["total_ms"])[0] if layer else None
         agg_name = M["hbm_kernels"][0]
-        if agg_name not in kern:  # fused layer: measure the message-passing unit alone as well
+        qmode = args.numeric != "f32"
+        if agg_name not in kern and not qmode:  # fused layer: measure the message-passing unit alone as well
             kern[agg_name] = eng.aggregation_only_ms(layer=0, iters=10)
 
         traffic_db = {}
@@ -238,13 +245,15 @@ def main():
                         "bytes_per_launch": fb, "mfma": mfma}
             else:
                 roof = dict({"kernel": dominant, "traffic": None, "avg_ms": kern[dominant]}, **mfma)
-        agg = hbm_obj(agg_name)
+        agg = hbm_obj(agg_name) if not qmode else None
+        if qmode:
+            roof = None  # integer VALU work (one truncated product at a time): neither of the two rooflines applies
         line = {
             "metric": M["metric"],
             "value": value, "unit": "graphs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "mfma_mode": "f16x3-split (fp32-accurate; exact-f32 re-run on range overflow)" if split else "f32",
+            "vs_baseline": None, "dtype": "f32" if not qmode else "q6.10 (int16 patterns of ap_fixed<16,6>)", "data": "synthetic",
+            "mfma_mode": ("f16x3-split (fp32-accurate; exact-f32 re-run on range overflow)" if split else "f32") if not qmode else None,
             "config": {"workload": M["workload"],
                        "graphs_per_gpu_per_step": G, "nodes_per_gpu": N, "edges_per_gpu": E,
                        "parallelism": f"batch-sharded x{world}, RCCL all-gather of logits"},
@@ -255,7 +264,7 @@ def main():
             "vs_fpga_u50": (value / FPGA_U50_GRAPHS_PER_S) if args.model == "GIN" else None,
         }
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(args.model, batch, w)
+            line["cpu_baseline"] = cpu_baseline(args.model, batch, w, numeric=args.numeric)
             line["gpu_over_cpu"] = value / line["cpu_baseline"]["value"]
         print(json.dumps(line), flush=True)
     eng.close()

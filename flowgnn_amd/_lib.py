@@ -43,6 +43,7 @@ def _declare(lib):
     lib.flowgnn_stream.argtypes = [eng, C.POINTER(C.c_void_p)]
     lib.flowgnn_batch_info.argtypes = [eng] + [C.POINTER(C.c_longlong)] * 3
     lib.flowgnn_exact_reruns.argtypes = [eng]
+    lib.flowgnn_set_numeric_mode.argtypes = [eng, C.c_int]
     lib.flowgnn_get_csr.argtypes = [eng, p_int, p_int, p_int, p_int]
     lib.flowgnn_get_h.argtypes = [eng, p_float, p_int]
     lib.flowgnn_profile_enable.argtypes = [eng, C.c_int]
@@ -56,7 +57,7 @@ def _declare(lib):
     lib.GCN_compute_graphs.argtypes = [C.c_int, p_int, p_int, p_int, p_float, p_int, p_int, p_int] + [p_float] * 11
     for name in ("flowgnn_create", "flowgnn_destroy", "flowgnn_set_weights_gin", "flowgnn_set_weights", "flowgnn_load_weights_dir",
                  "flowgnn_set_batch", "flowgnn_run", "flowgnn_sync", "flowgnn_get_results",
-                 "flowgnn_results_device", "flowgnn_set_results_buffer", "flowgnn_stream", "flowgnn_batch_info", "flowgnn_exact_reruns", "flowgnn_get_csr",
+                 "flowgnn_results_device", "flowgnn_set_results_buffer", "flowgnn_stream", "flowgnn_batch_info", "flowgnn_exact_reruns", "flowgnn_set_numeric_mode", "flowgnn_get_csr",
                  "flowgnn_get_h", "flowgnn_profile_enable", "flowgnn_profile_read",
                  "flowgnn_run_aggregation_only", "GIN_compute_graphs", "GCN_compute_graphs", "PNA_compute_graphs", "DGN_compute_graphs", "GAT_compute_graphs"):
         getattr(lib, name).restype = C.c_int

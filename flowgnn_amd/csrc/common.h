@@ -130,6 +130,8 @@ public:
     virtual void set_exact(bool) {}
     // debug taps: make forward() materialise the last layer's node embeddings even if that costs a round trip
     virtual void set_keep_h(bool) {}
+    // 0 = fp32 (default); 1 = the reference's ap_fixed<16,6> bit patterns (GIN / GIN-VN only: ginq.hip)
+    virtual int set_numeric_mode(int mode) { return mode == 0 ? 0 : 8 /* FLOWGNN_ERR_UNSUPPORTED */; }
     virtual int emb_dim() const = 0;
     virtual int scratch_dim() const = 0;          // floats per node of scratch the forward needs
     virtual bool has_edge_attr() const = 0;

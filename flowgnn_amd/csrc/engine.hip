@@ -453,6 +453,13 @@ int flowgnn_batch_info(const flowgnn_engine* e, long long* num_graphs, long long
 
 int flowgnn_exact_reruns(const flowgnn_engine* e) { return e ? e->exact_reruns : -1; }
 
+int flowgnn_set_numeric_mode(flowgnn_engine* e, int mode) {
+    if (!e) return FLOWGNN_ERR_ARG;
+    const int rc = e->model->set_numeric_mode(mode);
+    if (rc) e->err = "flowgnn_set_numeric_mode: this model has no such mode (Q6.10 exists for GIN / GIN-VN)";
+    return rc;
+}
+
 int flowgnn_get_csr(flowgnn_engine* e, int* row_ptr, int* src, int* eid, int* out_deg) {
     if (!e) return FLOWGNN_ERR_ARG;
     if (!e->ran) return FLOWGNN_ERR_STATE;
@@ -478,6 +485,10 @@ int flowgnn_get_h(flowgnn_engine* e, float* h_host, int* dim) {
         if (rc) { e->err = fg::last_error_text(); return rc; }
         rc = flowgnn_sync(e);
         if (rc) return rc;
+        if (!e->db.h_valid && !e->db.tap) {
+            e->err = "flowgnn_get_h: node embeddings are not available as float rows in this numeric mode";
+            return FLOWGNN_ERR_UNSUPPORTED;
+        }
     }
     const int D = e->db.tap ? e->db.tap_dim : e->model->emb_dim();
     const float* srcp = e->db.tap ? e->db.tap : e->db.h[e->db.final_h];

@@ -16,6 +16,7 @@
 #include "common.h"
 #include "device_common.h"
 #include "gin_split.h"
+#include "ginq.h"
 #include "gin_pipe.h"
 #include <cstring>
 #include <cstdio>
@@ -931,6 +932,7 @@ public:
             gin_split_pack_layer(w1 + (size_t)l * GIN_H * GIN_D, b1 + (size_t)l * GIN_H, w2 + (size_t)l * GIN_D * GIN_H,
                                  b2 + (size_t)l * GIN_D, split.data() + (size_t)l * GS_LAYER_BYTES);
         int rc;
+        if ((rc = ginq_upload(qw_, nemb, eemb, w1, b1, w2, b2, pw, pb))) return rc;  // Q6.10 copies (numeric mode 1)
         if ((rc = upload(&d_split_, split))) return rc;
         if ((rc = upload(&d_chunks_, chunks))) return rc;
         if ((rc = upload(&d_nemb_, v_nemb))) return rc;
@@ -1018,6 +1020,7 @@ public:
     int forward(DeviceBatch& db, Profiler& prof, hipStream_t s) override {
         const int n = db.b.n_tot;
         if (n <= 0) return 0;
+        if (qmode_) return ginq_forward(qw_, db, prof, s);
         {
             ProfScope p(prof, "atom_encoder", s);
             atom_encoder_kernel<GIN_D><<<atom_encoder_grid(n, GIN_C), 512, 0, s>>>(db.b.node_feature, d_nemb_, db.h[0], n, db.csr.err);
@@ -1090,6 +1093,11 @@ public:
 
     void set_exact(bool on) override { exact_ = on; }
     void set_keep_h(bool on) override { keep_h_ = on; }
+    int set_numeric_mode(int mode) override {
+        if (mode != 0 && mode != 1) return 8;
+        qmode_ = mode == 1;
+        return 0;
+    }
 
     int aggregation_only(DeviceBatch& db, int layer, hipStream_t s) override {
         if (layer < 0 || layer >= GIN_L) return 1;
@@ -1103,6 +1111,7 @@ private:
         for (auto p : ptrs)
             if (*p) { hipFree(*p); *p = nullptr; }
         if (d_split_) { hipFree(d_split_); d_split_ = nullptr; }
+        qw_.release();
     }
     bool ready_ = false;
     // FLOWGNN_GIN_UNFUSED=1 keeps the two-kernel layer (aggregate + mlp) for A/B measurements
@@ -1117,6 +1126,8 @@ private:
     int split_nt_ = getenv("FLOWGNN_GIN_SPLIT_NT") ? atoi(getenv("FLOWGNN_GIN_SPLIT_NT")) : 4;
     bool exact_ = false;
     bool keep_h_ = false;
+    bool qmode_ = false;  // flowgnn_set_numeric_mode(FLOWGNN_NUMERIC_Q6_10)
+    GinQWeights qw_;
     // FLOWGNN_GIN_FOLD_READOUT=0 keeps the separate mean-pool + linear kernel (and the last layer's 2.7 GB of rows)
     bool fold_readout_ = !(getenv("FLOWGNN_GIN_FOLD_READOUT") && atoi(getenv("FLOWGNN_GIN_FOLD_READOUT")) == 0);
     uint8_t* d_split_ = nullptr;

@@ -113,6 +113,11 @@ class Engine:
         return self.results()
 
     # ---- taps
+    def set_numeric_mode(self, mode: str = "f32"):
+        """"f32" (default) or "q6.10": the reference's ap_fixed<16,6> bit patterns (GIN / GIN-VN only)."""
+        code = {"f32": 0, "q6.10": 1}[mode]
+        self._check(self.lib.flowgnn_set_numeric_mode(self._h, code), "flowgnn_set_numeric_mode")
+
     def exact_reruns(self) -> int:
         """Forward passes repeated on the exact-fp32 kernels (flowgnn.h: flowgnn_exact_reruns)."""
         return int(self.lib.flowgnn_exact_reruns(self._h))

@@ -227,6 +227,19 @@ int flowgnn_batch_info(const flowgnn_engine* e, long long* num_graphs,
 int flowgnn_exact_reruns(const flowgnn_engine* e);
 
 /*
+ * Numeric mode of the engine.  FLOWGNN_NUMERIC_F32 (default): fp32 storage and accumulation.
+ * FLOWGNN_NUMERIC_Q6_10: every value is the reference's ap_fixed<16,6> bit pattern
+ * (GIN/src/dcl.h:58-59: 10 fractional bits, truncation toward -inf, wrap on overflow), weights
+ * are quantised from the float tensors as the reference host does, and the outputs are
+ * pattern / 1024 (exact in float).  Implemented for GIN / GIN-VN;
+ * other models return FLOWGNN_ERR_UNSUPPORTED.  About 100x slower than the default
+ * path: products are truncated one at a time, as the reference does.
+ */
+#define FLOWGNN_NUMERIC_F32 0
+#define FLOWGNN_NUMERIC_Q6_10 1
+int flowgnn_set_numeric_mode(flowgnn_engine* e, int mode);
+
+/*
  * Debug / parity taps (device -> host copies; synchronise first).
  *  flowgnn_get_csr: the batched destination-major CSR built by load_graph:
  *     row_ptr[N_tot+1], src[E_tot] (global source id, ascending per row, ties in

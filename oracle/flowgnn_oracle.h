@@ -65,6 +65,21 @@ int orc_GIN_compute_graphs(int num_graphs, const int* nums_of_nodes, const int* 
  * GCN forward, float semantics.  Mirrors GCN_compute_graphs, GCN/src/GCN_compute.cc:7-112
  * (argument order of GCN/src/dcl.h:75-97).  x_dump (optional): [5][N_tot][100], x_l = NT(l) output.
  */
+/*
+ * GIN / GIN-VN in the reference's own number format ap_fixed<16,6> (ginq_oracle.c: the rules it assumes, and why
+ * it is "parity unpinned").  Float weights are quantised as the reference host does; out_q = 16-bit patterns,
+ * out = out_q / 1024 (either may be NULL); h_dump (optional) int16 [6][N_tot][100].
+ */
+#include <stdint.h>
+int orc_GIN_compute_graphs_q(int num_graphs, const int* nums_of_nodes, const int* nums_of_edges, const int* reload_weights,
+                             float* out, int16_t* out_q, const int* node_feature_in, const int* edge_list_in,
+                             const int* edge_attr_in, const float* node_embedding_weight_in,
+                             const float* edge_embedding_weight_in, const float* node_mlp_1_weights,
+                             const float* node_mlp_1_bias, const float* node_mlp_2_weights, const float* node_mlp_2_bias,
+                             const float* graph_pred_weights_in, const float* graph_pred_bias_in, int16_t* h_dump,
+                             int nthreads);
+int16_t orc_q16_from_float(float x);
+
 int orc_GCN_compute_graphs(int num_graphs, const int* nums_of_nodes, const int* nums_of_edges,
                            const int* reload_weights, float* out, const int* node_feature_in,
                            const int* edge_list_in, const int* edge_attr_in,

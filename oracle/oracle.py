@@ -91,6 +91,32 @@ def gin_forward(batch, weight_sets, reload_weights=None, dump_h=False, nthreads=
     return (out, hd) if dump_h else out
 
 
+def gin_forward_q(batch, weight_sets, reload_weights=None, dump_h=False, nthreads=1):
+    """orc_GIN_compute_graphs_q: GIN in ap_fixed<16,6> (Q6.10).  Returns (logits as float, 16-bit patterns[, h dump int16])."""
+    lib = load()
+    G = batch.num_graphs
+    if reload_weights is None:
+        reload_weights = np.zeros(G, np.int32)
+        if G:
+            reload_weights[0] = 1
+    keys = list(weight_sets[0].keys())
+    stacked = [_f(np.stack([np.asarray(ws[k], np.float32) for ws in weight_sets])) for k in keys]
+    out = np.zeros(G, np.float32)
+    out_q = np.zeros(G, np.int16)
+    nn, ne, rw = _i(batch.nums_of_nodes), _i(batch.nums_of_edges), _i(reload_weights)
+    nf, el, ea = _i(batch.node_feature), _i(batch.edge_list), _i(batch.edge_attr)
+    hd = np.zeros((6, batch.total_nodes, 100), np.int16) if dump_h else None
+    p16 = C.POINTER(C.c_int16)
+    lib.orc_GIN_compute_graphs_q.restype = C.c_int
+    rc = lib.orc_GIN_compute_graphs_q(G, nn.ctypes.data_as(_pi), ne.ctypes.data_as(_pi), rw.ctypes.data_as(_pi),
+                                      out.ctypes.data_as(_pf), out_q.ctypes.data_as(p16), nf.ctypes.data_as(_pi),
+                                      el.ctypes.data_as(_pi), ea.ctypes.data_as(_pi), *[a.ctypes.data_as(_pf) for a in stacked],
+                                      None if hd is None else hd.ctypes.data_as(p16), nthreads)
+    if rc:
+        raise RuntimeError(f"oracle GIN-Q rc={rc}")
+    return (out, out_q, hd) if dump_h else (out, out_q)
+
+
 def _forward(fn_name, batch, weight_sets, reload_weights, dump_shape, nthreads, with_attr=True, eig=False):
     lib = load()
     G = batch.num_graphs

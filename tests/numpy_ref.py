@@ -176,3 +176,51 @@ def gat_forward(batch, w, return_h=False):
     hg = np.add.reduceat(emb, off[:-1], axis=0) / batch.nums_of_nodes[:, None]
     out = hg @ f64(w["graph_pred_weights"]).reshape(-1) + float(np.asarray(w["graph_pred_bias"]).reshape(-1)[0])
     return (out, np.stack(outs)) if return_h else out
+
+
+# --------------------------------------------------------------------------- GIN in ap_fixed<16,6> (Q6.10)
+def _q(x):
+    """float -> 16-bit pattern: floor(x * 1024), low 16 bits, sign extended (as int64)."""
+    i = np.floor(np.asarray(x, np.float64) * 1024.0).astype(np.int64)
+    return _wrap16(i)
+
+
+def _wrap16(i):
+    return ((np.asarray(i, np.int64) + 32768) & 0xFFFF) - 32768
+
+
+def _dense_floor(a, wq, bq):
+    """out[n][o] = wrap16(b[o] + sum_k floor(a[n][k] * w[o][k] / 1024)): every product truncated on its own."""
+    out = np.empty((a.shape[0], wq.shape[0]), np.int64)
+    for o in range(wq.shape[0]):  # row by row keeps the [n][k] temporary small
+        out[:, o] = ((a * wq[o][None, :]) >> 10).sum(axis=1)
+    return _wrap16(out + bq[None, :])
+
+
+def gin_forward_q(batch, w, return_h=False):
+    """Independent vectorised restatement of oracle/ginq_oracle.c on the batched super-graph (int64 NumPy; arithmetic
+    mod 2^16, so the order of the sums does not matter).  Returns the 16-bit logit patterns."""
+    nemb, eemb = _q(w["node_embedding_weight"]), _q(w["edge_embedding_weight"])
+    w1, b1, w2, b2 = _q(w["node_mlp_1_weights"]), _q(w["node_mlp_1_bias"]), _q(w["node_mlp_2_weights"]), _q(w["node_mlp_2_bias"])
+    pw, pb = _q(w["graph_pred_weights"]).reshape(-1), int(_q(w["graph_pred_bias"]).reshape(-1)[0])
+    N = batch.total_nodes
+    ge = batch.global_edges()
+    u, v = ge[:, 0], ge[:, 1]
+    h = _wrap16(nemb[batch.node_feature.astype(np.int64) + ND_OFF[None, :]].sum(axis=1))
+    hs = [h]
+    for l in range(5):
+        ee = _wrap16(eemb[l][batch.edge_attr.astype(np.int64) + ED_OFF[None, :]].sum(axis=1))
+        msg = np.maximum(_wrap16(h[u] + ee), 0)
+        m = np.zeros((N, 100), np.int64)
+        np.add.at(m, v, msg)
+        a = _wrap16(m + h)
+        hid = np.maximum(_dense_floor(a, w1[l], b1[l]), 0)
+        h = _dense_floor(hid, w2[l], b2[l])
+        if l != 4:
+            h = np.maximum(h, 0)
+        hs.append(h)
+    off = batch.node_offsets()
+    sums = _wrap16(np.add.reduceat(h, off[:-1], axis=0))
+    hg = _wrap16(np.floor_divide(sums, np.asarray(batch.nums_of_nodes, np.int64)[:, None]))
+    out = _wrap16(((hg * pw[None, :]) >> 10).sum(axis=1) + pb)
+    return (out, np.stack(hs)) if return_h else out
