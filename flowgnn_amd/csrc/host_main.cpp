@@ -2,7 +2,7 @@
 // OpenCL host (GIN/src/host.cc): load the model's .bin weights, read a graph pack in the reference's on-disk
 // layout, run the whole dataset as ONE batched launch NUM_TRIALS times, write HLS_output.txt.
 //
-//   host <MODEL> [--graphs DIR] [--weights DIR] [--num-graphs N] [--trials T] [--out FILE] [--device D] [XCLBIN]
+//   host <MODEL> [--graphs DIR] [--weights DIR] [--num-graphs N] [--trials T] [--out FILE] [--device D] [--numeric f32|q6.10] [XCLBIN]
 //
 //   MODEL        GIN | GIN-VN | GCN | GAT | PNA | DGN
 //   --graphs     directory holding graph_info/ and graph_bin/      (default ../graphs, host.cc:14-15)
@@ -76,7 +76,7 @@ static bool read_eig_txt(const std::string& path, std::vector<float>& eig, size_
 int main(int argc, char** argv) {
     if (argc < 2) {
         fprintf(stderr, "Usage: %s <GIN|GIN-VN|GCN|GAT|PNA|DGN> [--graphs DIR] [--weights DIR] [--num-graphs N] [--trials T] "
-                        "[--out FILE] [--device D] [XCLBIN File]\n", argv[0]);
+                        "[--out FILE] [--device D] [--numeric f32|q6.10] [XCLBIN File]\n", argv[0]);
         return EXIT_FAILURE;
     }
     const std::string model = argv[1];
@@ -84,7 +84,7 @@ int main(int argc, char** argv) {
     if (mid < 0) { fprintf(stderr, "unknown model %s\n", model.c_str()); return EXIT_FAILURE; }
     std::string graphs = "../graphs", wdir = ".", out_path = "HLS_output.txt", eig_dir = "eig";
     long num_graphs = -1;
-    int trials = 25, device = 0;
+    int trials = 25, device = 0, numeric = FLOWGNN_NUMERIC_F32;
     for (int i = 2; i < argc; i++) {
         const std::string a = argv[i];
         auto next = [&](const char* what) -> const char* {
@@ -98,6 +98,7 @@ int main(int argc, char** argv) {
         else if (a == "--trials") trials = atoi(next("--trials"));
         else if (a == "--out") out_path = next("--out");
         else if (a == "--device") device = atoi(next("--device"));
+        else if (a == "--numeric") numeric = std::string(next("--numeric")) == "q6.10" ? FLOWGNN_NUMERIC_Q6_10 : FLOWGNN_NUMERIC_F32;
         // anything else (e.g. an .xclbin path) is ignored
     }
     if (num_graphs < 0) num_graphs = read_count_file(graphs + "/dataset_size.txt");
@@ -110,6 +111,10 @@ int main(int argc, char** argv) {
     if (rc) { fprintf(stderr, "flowgnn_create failed: %d %s\n", rc, flowgnn_last_error(nullptr)); return EXIT_FAILURE; }
     rc = flowgnn_load_weights_dir(eng, wdir.c_str());
     if (rc) { fprintf(stderr, "loading weights failed: %d %s\n", rc, flowgnn_last_error(eng)); return EXIT_FAILURE; }
+    if (numeric != FLOWGNN_NUMERIC_F32) {  // the reference's ap_fixed<16,6> bit patterns (GIN / GIN-VN)
+        rc = flowgnn_set_numeric_mode(eng, numeric);
+        if (rc) { fprintf(stderr, "numeric mode: %d %s\n", rc, flowgnn_last_error(eng)); return EXIT_FAILURE; }
+    }
     printf("\n******* Weights loading done *******\n");
 
     const bool vn = mid == FLOWGNN_MODEL_GIN_VN, dgn = mid == FLOWGNN_MODEL_DGN;
