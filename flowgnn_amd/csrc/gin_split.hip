@@ -570,7 +570,7 @@ __device__ __forceinline__ void gs_step_p(const char* wb, int lane, int g, const
 // ---------------------------------------------------------------- persistent, tile-staged variant (FLOWGNN_GIN_SPLIT_NT=3)
 // The two kernels above leave the matrix pipe idle most of the time for the same reason: every wave waits for
 // global memory inside its own critical path -- gin_layer_split_kernel in a per-tile gather prologue (three dependent
-// round trips row_ptr -> src -> h[u] with 12 waves per CU to hide them), the pipelined one at the end of every step
+// round trips row_ptr -> src -> h[u] with 12 waves per CU to hide them), a register-pipelined variant (removed) at the end of every step
 // (a step lasts about 1 us, a gather round trip under load about 2 us, so the step becomes the round trip).  Here
 // global memory is touched only by LDS-DMA transfers that are issued a whole step or more before anything depends
 // on them, and all of them are contiguous:
