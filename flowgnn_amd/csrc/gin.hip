@@ -785,7 +785,7 @@ private:
     // FLOWGNN_GIN_MFMA=f32 keeps the dense update on the fp32 matrix pipe (gin_layer_fused_kernel); the default runs it
     // as three f16 MFMAs per product (gin_split.hip), with the engine falling back to fp32 when the range flag trips
     bool split_ = !(getenv("FLOWGNN_GIN_MFMA") && strcmp(getenv("FLOWGNN_GIN_MFMA"), "f32") == 0);
-    // 4 = eight-wave workgroups of 128 nodes (default), 1 / 2 = four waves x 1 / 2 node tiles, 3 = persistent tile-staged kernel
+    // 4 = eight-wave workgroups of 128 nodes (default), 1 / 2 = four waves x 1 / 2 node tiles
     int split_nt_ = getenv("FLOWGNN_GIN_SPLIT_NT") ? atoi(getenv("FLOWGNN_GIN_SPLIT_NT")) : 4;
     bool exact_ = false;
     bool keep_h_ = false;

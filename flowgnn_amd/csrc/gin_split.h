@@ -21,8 +21,7 @@ constexpr size_t GS_LAYER_BYTES = (size_t)GS_STEPS * GS_CHUNK_STRIDE;
 // w1[200][100], b1[200], w2[100][200], b2[100] (row-major, host) -> GS_LAYER_BYTES at `out` (host)
 void gin_split_pack_layer(const float* w1, const float* b1, const float* w2, const float* b2, uint8_t* out);
 
-// variant: 1 / 2 = one workgroup per 64 / 128 nodes (any degree distribution; 1 is the default), 3 = persistent
-// tile-staged kernel for molecule-like batches (FLOWGNN_GIN_SPLIT_NT=3; see gin_split.hip for what it does and costs)
+// variant (FLOWGNN_GIN_SPLIT_NT): 4 = eight-wave workgroups of 128 nodes (default), 1 / 2 = four waves x 1 / 2 node tiles
 // pool_w != null (last layer, readout folded in): hout is float[n_tot] and receives h'[v] . pool_w instead of the rows
 // one GIN layer: hout = MLP(h[v] + sum_e relu(h[src_e] + ecomb[code_e])); *range_flag |= 1 if an operand left the
 // range in which the split is fp32-accurate (the caller then repeats the forward pass on the fp32 MFMA kernel)

@@ -41,7 +41,6 @@ namespace {
 constexpr int GS_D = 100;
 constexpr int GS_H = 200;
 constexpr int GS_T2 = 7;
-constexpr int GS_ECOMB_BYTES = EDGE_COMBOS * GS_D * 4;  // 24000 <= GS_CHUNK_BYTES: shares the odd-chunk buffer
 
 typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
 typedef uint32_t uint4_t __attribute__((ext_vector_type(4)));
@@ -426,492 +425,6 @@ __global__ __launch_bounds__(WAVES * 64) void gin_layer_split_kernel(const float
     }
 }
 
-// workgroup barrier without the fence of __syncthreads(): the fence makes hipcc wait for vmcnt(0) first, and the
-// kernels below keep transfers in flight across barriers on purpose (LDS visibility of a landed DMA needs no fence)
-#define GSP_BAR()                                          \
-    do {                                                   \
-        __builtin_amdgcn_sched_barrier(0);                 \
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
-        __builtin_amdgcn_s_barrier();                      \
-        __builtin_amdgcn_sched_barrier(0);                 \
-    } while (0)
-
-// gs_step for one node tile per wave, written as an explicit software pipeline: the fragments of group k+1 are
-// read from LDS while the MFMAs of group k issue, and scheduling fences keep the compiler from hoisting all 26
-// fragment reads of a step to its top (104 registers; with the 168 available at 3 waves per SIMD that spilled).
-// Groups: MLP1 K-steps 0,1,2 (4 fragments, 6 MFMAs each), the fp32 K-tail (2 MFMAs), MLP2 output-tile pairs
-// (0,1) (2,3) (4,5) (4 fragments, 6 MFMAs) and tile 6 (2 fragments, 3 MFMAs).  The relu + split of the new hidden
-// tiles is placed under the MLP2 MFMAs, which do not depend on it.
-#define GS_FENCE() __builtin_amdgcn_sched_barrier(0)
-
-__device__ __forceinline__ void gs_ld4(uint4_t (&f)[4], const char* p, int lane) {
-#pragma unroll
-    for (int i = 0; i < 4; i++) f[i] = *reinterpret_cast<const uint4_t*>(p + i * 1024 + lane * 16);
-}
-// two accumulators (two hidden tiles / two output tiles) x {hi hi, hi lo, lo hi}; f = {tile0 hi, tile0 lo, tile1 hi, tile1 lo}
-__device__ __forceinline__ void gs_mm2(const uint4_t (&f)[4], const uint4_t& bh, const uint4_t& bl, float4_t& c0, float4_t& c1) {
-    c0 = GS_MFMA16(f[0], bh, c0); c1 = GS_MFMA16(f[2], bh, c1);
-    c0 = GS_MFMA16(f[0], bl, c0); c1 = GS_MFMA16(f[2], bl, c1);
-    c0 = GS_MFMA16(f[1], bh, c0); c1 = GS_MFMA16(f[3], bh, c1);
-}
-
-// The step also issues the LDS-DMA of a later chunk, one 1 KiB piece after each of its first three groups rather than
-// three in a row at the top of the step: the vector-memory path takes 64 B per clock and CU, so twelve waves issuing 36
-// pieces together sat in front of a full queue for about 900 cycles per step -- with their MFMAs behind it.
-// LDS-DMA with a scalar base and a 32-bit per-lane offset ("saddr" addressing): no 64-bit per-lane addresses, which
-// hipcc otherwise precomputes for every (step, piece) pair at the top of the tile loop and spills.
-__device__ __forceinline__ void gs_dma16s(const void* sbase, uint32_t voff, uint32_t lds_addr) {
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(sbase), "s"(lds_addr) : "memory");
-}
-
-struct GsDma {
-    const uint8_t* g;  // global address of piece 0 of the chunk (wave-uniform)
-    uint32_t lane_off; // lane * 16
-    uint32_t l;        // LDS address of piece 0 of the destination buffer (wave-uniform)
-    int p0, p1, p2;    // this wave's three pieces (wave-uniform)
-    bool on;
-    // step 1 of the tile-staged kernel: 7 more pieces (rows of the next tile), issued after the chunk's
-    bool rows;
-    const char* rbase;   // first row of the tile in h (wave-uniform)
-    uint32_t rlim;       // last valid 16-byte offset from rbase (bytes past the end of h are read from its last 16 bytes)
-    int rwave, rwaves, rpieces;
-    uint32_t rl;         // LDS address of row piece 0
-};
-__device__ __forceinline__ void gs_dma_row(const GsDma& d, int k) {
-    if (d.rows) {
-        int piece = d.rwave + d.rwaves * k;
-        if (piece >= d.rpieces) piece = d.rwave;  // past the end: this wave's first piece again (same bytes)
-        uint32_t off = piece * 1024 + d.lane_off;
-        off = off < d.rlim ? off : d.rlim;
-        gs_dma16s(d.rbase, off, d.rl + piece * 1024);
-    }
-}
-__device__ __forceinline__ void gs_dma_piece(const GsDma& d, int piece) {
-    if (d.on) gs_dma16s(d.g + piece * 1024, d.lane_off, d.l + piece * 1024);
-}
-
-template <int S>
-__device__ __forceinline__ void gs_step_p(const char* wb, int lane, int g, const uint4_t (&in_hi)[1][3],
-                                          const uint4_t (&in_lo)[1][3], const float (&in_t)[1], uint4_t (&h_hi)[1],
-                                          uint4_t (&h_lo)[1], float4_t (&acc2)[1][GS_T2], float& vmax, const GsDma& dma) {
-    constexpr bool M1 = S < GS_STEPS - 1, M2 = S > 0;
-    uint4_t fa[4], fb[4];
-    float4_t a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0;
-    float t0 = 0.f, t1 = 0.f;
-    const char* w2 = wb + GS_W2_OFF;
-    if (M1) {
-        const float4 b0 = *reinterpret_cast<const float4*>(wb + GS_B1_OFF + g * 16);
-        const float4 b1 = *reinterpret_cast<const float4*>(wb + GS_B1_OFF + 64 + g * 16);
-        a0 = (float4_t){b0.x, b0.y, b0.z, b0.w};
-        a1 = (float4_t){b1.x, b1.y, b1.z, b1.w};
-        gs_ld4(fa, wb, lane);
-        GS_FENCE();
-        gs_ld4(fb, wb + 4096, lane);
-        gs_mm2(fa, in_hi[0][0], in_lo[0][0], a0, a1);
-        gs_dma_piece(dma, dma.p0);
-        GS_FENCE();
-        gs_ld4(fa, wb + 8192, lane);
-        gs_mm2(fb, in_hi[0][1], in_lo[0][1], a0, a1);
-        gs_dma_piece(dma, dma.p1);
-        GS_FENCE();
-        t0 = *reinterpret_cast<const float*>(wb + GS_TAIL_OFF + lane * 4);
-        t1 = *reinterpret_cast<const float*>(wb + GS_TAIL_OFF + 256 + lane * 4);
-        if (M2) gs_ld4(fb, w2, lane);
-        gs_mm2(fa, in_hi[0][2], in_lo[0][2], a0, a1);
-        gs_dma_piece(dma, dma.p2);
-        GS_FENCE();
-        a0 = GS_MFMA32(t0, in_t[0], a0);
-        a1 = GS_MFMA32(t1, in_t[0], a1);
-    } else {
-        gs_ld4(fb, w2, lane);
-        gs_dma_piece(dma, dma.p0);
-        gs_dma_piece(dma, dma.p1);
-        gs_dma_piece(dma, dma.p2);
-        GS_FENCE();
-    }
-    uint4_t n_hi = {0, 0, 0, 0}, n_lo = {0, 0, 0, 0};
-    if (M2) {
-        gs_ld4(fa, w2 + 4096, lane);
-        gs_mm2(fb, h_hi[0], h_lo[0], acc2[0][0], acc2[0][1]);
-        if (S == 2) { gs_dma_row(dma, 0); gs_dma_row(dma, 1); }
-        GS_FENCE();
-        gs_ld4(fb, w2 + 8192, lane);
-        gs_mm2(fa, h_hi[0], h_lo[0], acc2[0][2], acc2[0][3]);
-        if (S == 2) { gs_dma_row(dma, 2); gs_dma_row(dma, 3); }
-    }
-    if (M1) {  // under the MLP2 MFMAs just issued
-        a0.x = relu1(a0.x); a0.y = relu1(a0.y); a0.z = relu1(a0.z); a0.w = relu1(a0.w);
-        a1.x = relu1(a1.x); a1.y = relu1(a1.y); a1.z = relu1(a1.z); a1.w = relu1(a1.w);
-        vmax = __builtin_fmaxf(__builtin_fmaxf(vmax, a0.x), a0.y);
-        vmax = __builtin_fmaxf(__builtin_fmaxf(vmax, a0.z), a0.w);
-        vmax = __builtin_fmaxf(__builtin_fmaxf(vmax, a1.x), a1.y);
-        vmax = __builtin_fmaxf(__builtin_fmaxf(vmax, a1.z), a1.w);
-        asm volatile("" : "+v"(vmax));  // computed here (LLVM otherwise sinks the chain to the kernel's end and spills a0, a1)
-        GS_SPLIT2(a0.x, a0.y, n_hi.x, n_lo.x);
-        GS_SPLIT2(a0.z, a0.w, n_hi.y, n_lo.y);
-        GS_SPLIT2(a1.x, a1.y, n_hi.z, n_lo.z);
-        GS_SPLIT2(a1.z, a1.w, n_hi.w, n_lo.w);
-    }
-    if (M2) {
-        GS_FENCE();
-        fa[0] = *reinterpret_cast<const uint4_t*>(w2 + 12288 + lane * 16);
-        fa[1] = *reinterpret_cast<const uint4_t*>(w2 + 13312 + lane * 16);
-        gs_mm2(fb, h_hi[0], h_lo[0], acc2[0][4], acc2[0][5]);
-        if (S == 2) { gs_dma_row(dma, 4); gs_dma_row(dma, 5); }
-        GS_FENCE();
-        acc2[0][6] = GS_MFMA16(fa[0], h_hi[0], acc2[0][6]);
-        acc2[0][6] = GS_MFMA16(fa[0], h_lo[0], acc2[0][6]);
-        acc2[0][6] = GS_MFMA16(fa[1], h_hi[0], acc2[0][6]);
-        if (S == 2) gs_dma_row(dma, 6);
-    }
-    if (M1) { h_hi[0] = n_hi; h_lo[0] = n_lo; }
-}
-
-// ---------------------------------------------------------------- persistent, tile-staged variant (FLOWGNN_GIN_SPLIT_NT=3)
-// The two kernels above leave the matrix pipe idle most of the time for the same reason: every wave waits for
-// global memory inside its own critical path -- gin_layer_split_kernel in a per-tile gather prologue (three dependent
-// round trips row_ptr -> src -> h[u] with 12 waves per CU to hide them), a register-pipelined variant (removed) at the end of every step
-// (a step lasts about 1 us, a gather round trip under load about 2 us, so the step becomes the round trip).  Here
-// global memory is touched only by LDS-DMA transfers that are issued a whole step or more before anything depends
-// on them, and all of them are contiguous:
-//   * one persistent 12-wave workgroup per CU walks tiles of 192 consecutive nodes;
-//   * while the MLP of tile t runs, the 192 rows of tile t+1 (76.8 KB), its row_ptr slice and the CSR entries of its
-//     rows (src ids and edge codes: contiguous ranges of the CSR arrays) are copied into LDS.  Molecule batches are
-//     block diagonal with consecutive node ids, so a node's neighbours are almost always rows of its own tile; the
-//     rare exception (a graph straddling a tile boundary) is fetched from global memory.  (Per-lane loads of the
-//     CSR entries were tried first: 96 divergent load instructions per tile kept the CU's vector-memory pipeline,
-//     and the waves queued behind it, busy for 3400 cycles.)
-//   * the gather of tile t+1 is LDS-only and is folded into steps 3..7 of tile t, one in-edge per step, after the
-//     wave's MFMAs of that step (the VALU work of one wave runs under the MFMAs of the other two on its SIMD);
-//     in-degrees above 5 and the node's own row finish in a short loop at the end of the tile;
-//   * the 8 weight-stream steps are those of gin_layer_split_kernel (two LDS buffers, one step ahead); the DMA pieces
-//     of a step are issued between its MFMA groups, not in a burst at its top (the vector-memory path moves 64 B
-//     per clock and CU; twelve waves issuing 36 KiB together queued for ~900 cycles with their MFMAs behind them).
-// Waits: every step ends with s_waitcnt vmcnt(0) + one workgroup barrier.  Partial waits ("vmcnt(7): everything but the
-// seven row pieces issued last") were tried and are NOT safe: now and then a wave passed one with a weight piece still
-// in flight (17 of 4113 molhiv graphs wrong), i.e. LDS-DMA transfers of a wave do not retire strictly in issue order.
-// The DMA is issued from inline asm (see gs_dma16s), so hipcc neither counts it nor waits for it, and the end-of-step
-// waits are the s_waitcnt BUILTIN so that hipcc's own bookkeeping of its loads and stores is reset at the same points.
-constexpr int GT_WAVES = 12;
-constexpr int GT_TILE = GT_WAVES * 16;            // 192 rows
-constexpr int GT_ROW_BYTES = GT_TILE * GS_D * 4;  // 76800 = 75 pieces of 1 KiB
-constexpr int GT_ECAP = GT_WAVES * 64;            // CSR entries of a tile staged in LDS (a molhiv tile has ~420)
-#define GT_R 7  // row pieces per wave and tile: ceil(75 / 12)
-static_assert(3 * GT_WAVES >= GS_CHUNK_STRIDE / 1024 && GT_R * GT_WAVES >= GT_ROW_BYTES / 1024, "piece counts");
-#define GT_STR2(x) #x
-#define GT_STR(x) GT_STR2(x)
-// LDS map (one object, carved by hand, weight buffers first: their fragment reads are then "lane * 16 + immediate";
-// ds_read offsets are 16 bit, and above 64 KB every fragment needed its own address register)
-constexpr int GT_OFF_WA = 0;                               // even chunks
-constexpr int GT_OFF_WB = GS_CHUNK_STRIDE;                 // odd chunks
-constexpr int GT_OFF_ECOMB = 2 * GS_CHUNK_STRIDE;          // 60 edge-embedding combos
-constexpr int GT_OFF_ROWS = GT_OFF_ECOMB + GS_ECOMB_BYTES;  // h rows of the next / current tile
-constexpr int GT_OFF_RP = GT_OFF_ROWS + GT_ROW_BYTES;      // row_ptr[tile_base .. +255]
-constexpr int GT_OFF_SRC = GT_OFF_RP + 1024;               // src[e0 .. e0 + GT_ECAP)
-constexpr int GT_OFF_CODE = GT_OFF_SRC + GT_ECAP * 4;      // ecode[e0 & ~3 .. +1024)
-constexpr int GT_LDS_BYTES = GT_OFF_CODE + 1024;
-static_assert(GT_LDS_BYTES <= 160 * 1024, "LDS budget");
-
-// One LDS-DMA instruction (64 lanes x 16 B, lane-linear from M0) issued from inline asm.  hipcc then neither counts it
-// nor orders LDS reads against it: with the builtin, its waitcnt pass put "s_waitcnt vmcnt(0)" in front of the first
-// ds_read of every odd step (reads of the higher-addressed buffer while the DMA into the lower one was in flight),
-// which is the very stall this kernel is built to avoid.
-__device__ __forceinline__ void gt_dma16(const void* gaddr, uint32_t lds_addr) {
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(gaddr), "s"(lds_addr) : "memory");
-}
-__device__ __forceinline__ uint32_t gt_lds_addr(const void* p) {
-    return (uint32_t)(size_t)(const __attribute__((address_space(3))) char*)p;
-}
-__device__ __forceinline__ int load_u8_rare(const uint8_t* p) {
-    int v;
-    asm volatile("global_load_ubyte %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
-    return v;
-}
-
-__device__ __forceinline__ void gt_issue_chunk(const uint8_t* __restrict__ gchunk, char* lds_buf, int wave, int lane) {
-    uint32_t lane_off = lane * 16;
-    asm volatile("" : "+v"(lane_off));  // keep the per-lane addresses out of the tile loop's invariants (they spill)
-#pragma unroll
-    for (int p = 0; p < 3; p++) {
-        int piece = wave + GT_WAVES * p;
-        if (piece >= GS_CHUNK_STRIDE / 1024) piece = wave;  // past the end: this wave's first piece again (same bytes)
-        gt_dma16(gchunk + piece * 1024 + lane_off, __builtin_amdgcn_readfirstlane(gt_lds_addr(lds_buf) + piece * 1024));
-    }
-}
-
-// this lane's global address of row piece `piece` of tile `tile`; bytes past the end of h are read from its last 16
-// bytes instead (those LDS rows belong to no node)
-__device__ __forceinline__ const char* gt_row_addr(const float* __restrict__ h, long long tile, int n_tot, int piece, uint32_t lane_off) {
-    const long long lim = (long long)n_tot * (GS_D * 4) - 16;
-    long long off = tile * GT_ROW_BYTES + piece * 1024 + lane_off;
-    off = off < lim ? off : lim;
-    return reinterpret_cast<const char*>(h) + off;
-}
-__device__ __forceinline__ int gt_row_piece(int wave, int k) {
-    const int piece = wave + GT_WAVES * k;
-    return piece < GT_ROW_BYTES / 1024 ? piece : wave;
-}
-
-// row_ptr slice, src ids and edge codes of tile `tile` (first CSR entry e0) -> LDS; 1 or 2 instructions per wave.
-// Scalar base + 32-bit lane offset; lanes past the end of an array re-read its last element (entries of no row).
-__device__ __forceinline__ void gt_dma4s(const void* sbase, uint32_t voff, uint32_t lds_addr) {  // 64 lanes x 4 B
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" : : "v"(voff), "s"(sbase), "s"(lds_addr) : "memory");
-}
-__device__ __forceinline__ void gt_issue_csr(const int* __restrict__ row_ptr, const int* __restrict__ src,
-                                             const uint8_t* __restrict__ ecode, char* smem, long long tile, int e0, int n_tot,
-                                             int e_tot, int wave, int lane) {
-    {
-        const int eb = e0 < e_tot ? e0 : e_tot - 1;  // wave-uniform
-        const uint32_t last = (uint32_t)(e_tot - 1 - eb) * 4u;
-        uint32_t off = (uint32_t)(wave * 64 + lane) * 4u;
-        off = off < last ? off : last;
-        gt_dma4s(src + eb, off, __builtin_amdgcn_readfirstlane(gt_lds_addr(smem + GT_OFF_SRC) + wave * 256));
-    }
-    if (wave < 4) {
-        const int ab = (e0 < e_tot ? e0 : e_tot - 1) & ~3;
-        const uint32_t last = (uint32_t)(((e_tot - 1) & ~3) - ab);
-        uint32_t off = (uint32_t)(wave * 64 + lane) * 4u;
-        off = off < last ? off : last;
-        gt_dma4s(ecode + ab, off, __builtin_amdgcn_readfirstlane(gt_lds_addr(smem + GT_OFF_CODE) + wave * 256));
-    } else if (wave < 8) {
-        const long long nb = tile * GT_TILE;
-        const uint32_t last = (uint32_t)(n_tot - nb) * 4u;  // row_ptr has n_tot + 1 entries
-        uint32_t off = (uint32_t)((wave - 4) * 64 + lane) * 4u;
-        off = off < last ? off : last;
-        gt_dma4s(row_ptr + nb, off, __builtin_amdgcn_readfirstlane(gt_lds_addr(smem + GT_OFF_RP) + (wave - 4) * 256));
-    }
-}
-
-// One in-edge of the node this lane gathers for: bqn += relu(h[src] + ecomb[code]); everything from LDS except
-// neighbours outside the tile and CSR entries beyond the staged GT_ECAP (dense tiles: kNN graphs).
-// LDS reads are unconditional (clamped) and pinned with an empty asm, global memory is touched only in branches through
-// asm loads: a `cond ? lds : global` select makes hipcc emit flat loads with a full wait after each.
-#define GT_ROUND()                                                                                                     \
-    do {                                                                                                               \
-        if (ecur < eend) {                                                                                             \
-            const int ei_ = ecur < GT_ECAP ? ecur : GT_ECAP - 1;                                                       \
-            int u_ = s_src[ei_];                                                                                       \
-            int code_ = s_code[coff + ei_];                                                                            \
-            asm volatile("" : "+v"(u_), "+v"(code_));                                                                  \
-            if (ecur >= GT_ECAP) {                                                                                     \
-                u_ = load_i32_rare(src + (size_t)e0n + ecur);                                                          \
-                code_ = load_u8_rare(ecode + (size_t)e0n + ecur);                                                      \
-            }                                                                                                          \
-            ecur++;                                                                                                    \
-            const unsigned ul_ = (unsigned)(u_ - nbase);                                                               \
-            const bool in_ = ul_ < (unsigned)GT_TILE;                                                                  \
-            const float* ur_ = s_rows + (in_ ? ul_ : 0u) * GS_D + 4 * g;                                               \
-            const float* er_ = s_ecomb + code_ * GS_D + 4 * g;                                                         \
-            float4 x_[6];                                                                                              \
-            _Pragma("unroll") for (int q = 0; q < 6; q++) {                                                            \
-                x_[q] = *reinterpret_cast<const float4*>(ur_ + 16 * q);                                                \
-                asm volatile("" : "+v"(x_[q].x), "+v"(x_[q].y), "+v"(x_[q].z), "+v"(x_[q].w));                         \
-            }                                                                                                          \
-            float xt_ = ur_[96 - 3 * g];                                                                               \
-            asm volatile("" : "+v"(xt_));                                                                              \
-            if (!in_) {                                                                                                \
-                const float* gr_ = h + (size_t)u_ * GS_D + 4 * g;                                                      \
-                _Pragma("unroll") for (int q = 0; q < 6; q++)                                                          \
-                    x_[q] = load_f4_rare(reinterpret_cast<const float4*>(gr_ + 16 * q));                               \
-                xt_ = load_f32_rare(h + (size_t)u_ * GS_D + 96 + g);                                                   \
-            }                                                                                                          \
-            _Pragma("unroll") for (int q = 0; q < 6; q++) {                                                            \
-                const float4 w_ = *reinterpret_cast<const float4*>(er_ + 16 * q);                                      \
-                bqn[4 * q + 0] += relu1(w_.x + x_[q].x);                                                               \
-                bqn[4 * q + 1] += relu1(w_.y + x_[q].y);                                                               \
-                bqn[4 * q + 2] += relu1(w_.z + x_[q].z);                                                               \
-                bqn[4 * q + 3] += relu1(w_.w + x_[q].w);                                                               \
-            }                                                                                                          \
-            bqn[24] += relu1(er_[96 - 3 * g] + xt_);                                                                   \
-        }                                                                                                              \
-    } while (0)
-
-// start of a gather: this lane's CSR row bounds (relative to the tile's first entry) from the staged row_ptr slice
-#define GT_GATHER_INIT(valid_)                                                           \
-    do {                                                                                 \
-        const int nl_ = wave * 16 + j;                                                   \
-        const int r0_ = s_rp[nl_], r1_ = s_rp[nl_ + 1];                                  \
-        ecur = (valid_) ? r0_ - e0n : 0;                                                 \
-        eend = (valid_) ? r1_ - e0n : 0;                                                 \
-        _Pragma("unroll") for (int k = 0; k < 25; k++) bqn[k] = 0.0f;                    \
-    } while (0)
-
-// end of a gather: remaining in-edges, then + (1 + eps) h[v], eps == 0 (the oracle's order: edges, then the own row)
-#define GT_GATHER_FINISH()                                                               \
-    do {                                                                                 \
-        while (__any(ecur < eend)) GT_ROUND();                                           \
-        const float* sr_ = s_rows + (wave * 16 + j) * GS_D + 4 * g;                      \
-        _Pragma("unroll") for (int q = 0; q < 6; q++) {                                  \
-            const float4 x_ = *reinterpret_cast<const float4*>(sr_ + 16 * q);            \
-            bqn[4 * q + 0] += x_.x; bqn[4 * q + 1] += x_.y; bqn[4 * q + 2] += x_.z; bqn[4 * q + 3] += x_.w; \
-        }                                                                                \
-        bqn[24] += sr_[96 - 3 * g];                                                      \
-    } while (0)
-
-// The end-of-step wait is the BUILTIN s_waitcnt vmcnt(0) (0x0F70: expcnt and lgkmcnt untouched), not inline asm: hipcc's
-// waitcnt pass then knows that nothing of its own is pending any more.  With an asm wait it kept the tile's output
-// stores on its books and, when it reused their data registers early in the next step 0, inserted "s_waitcnt vmcnt(1)"
-// -- which, because it cannot see the asm-issued DMA, was a wait for the chunk that had just been requested.
-#define GT_WAIT_ALL()                          \
-    do {                                       \
-        __builtin_amdgcn_sched_barrier(0);     \
-        __builtin_amdgcn_s_waitcnt(0x0F70);    \
-        __builtin_amdgcn_sched_barrier(0);     \
-    } while (0)
-
-__global__ __launch_bounds__(GT_WAVES * 64) void gin_layer_split_tiled_kernel(
-    const float* __restrict__ h, float* __restrict__ hout, const int* __restrict__ row_ptr, const int* __restrict__ src,
-    const uint8_t* __restrict__ ecode, const float* __restrict__ ecomb, const uint8_t* __restrict__ wchunks, int n_tot,
-    int e_tot, int n_tiles, int relu_out, int* __restrict__ range_flag) {
-    __shared__ __attribute__((aligned(16))) char smem[GT_LDS_BYTES];
-    char* const s_wa = smem + GT_OFF_WA;
-    char* const s_wb = smem + GT_OFF_WB;
-    float* const s_ecomb = reinterpret_cast<float*>(smem + GT_OFF_ECOMB);
-    float* const s_rows = reinterpret_cast<float*>(smem + GT_OFF_ROWS);
-    const int* const s_rp = reinterpret_cast<const int*>(smem + GT_OFF_RP);
-    const int* const s_src = reinterpret_cast<const int*>(smem + GT_OFF_SRC);
-    const uint8_t* const s_code = reinterpret_cast<const uint8_t*>(smem + GT_OFF_CODE);
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int j = lane & 15, g = lane >> 4;
-    int tile = blockIdx.x;  // wave-uniform, as is everything derived from it
-    if (tile >= n_tiles) return;
-    uint32_t lane_off = lane * 16;
-    asm volatile("" : "+v"(lane_off));  // keeps 64-bit per-lane DMA addresses from becoming (spilled) loop invariants
-
-    // ---- prologue: chunk 0, rows + CSR of the first tile, edge-embedding combos; then its gather, not overlapped
-    float bqn[25];
-    int ecur, eend;
-    {
-        const int e0n = row_ptr[(long long)tile * GT_TILE];
-        const int nbase = tile * GT_TILE;
-        const int coff = e0n & 3;
-        gt_issue_chunk(wchunks, s_wa, wave, lane);
-        gt_issue_csr(row_ptr, src, ecode, smem, tile, e0n, n_tot, e_tot, wave, lane);
-#pragma unroll
-        for (int k = 0; k < GT_R; k++) {
-            const int piece = gt_row_piece(wave, k);
-            gt_dma16(gt_row_addr(h, tile, n_tot, piece, lane_off), __builtin_amdgcn_readfirstlane(gt_lds_addr(s_rows) + piece * 1024));
-        }
-        for (int i = threadIdx.x; i < GS_ECOMB_BYTES / 16; i += GT_WAVES * 64)
-            reinterpret_cast<float4*>(s_ecomb)[i] = reinterpret_cast<const float4*>(ecomb)[i];
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        GT_GATHER_INIT((long long)nbase + wave * 16 + j < n_tot);
-        GT_GATHER_FINISH();
-    }
-
-    float vmax = 0.0f;
-    while (true) {
-        // B operands of this tile's first linear layer from the finished gather
-        uint4_t in_hi[1][3], in_lo[1][3];
-        float in_t[1];
-#pragma unroll
-        for (int ks = 0; ks < 3; ks++) {
-            GS_SPLIT2(bqn[8 * ks + 0], bqn[8 * ks + 1], in_hi[0][ks].x, in_lo[0][ks].x);
-            GS_SPLIT2(bqn[8 * ks + 2], bqn[8 * ks + 3], in_hi[0][ks].y, in_lo[0][ks].y);
-            GS_SPLIT2(bqn[8 * ks + 4], bqn[8 * ks + 5], in_hi[0][ks].z, in_lo[0][ks].z);
-            GS_SPLIT2(bqn[8 * ks + 6], bqn[8 * ks + 7], in_hi[0][ks].w, in_lo[0][ks].w);
-        }
-#pragma unroll
-        for (int k = 0; k < 24; k += 2)
-            vmax = __builtin_fmaxf(__builtin_fmaxf(vmax, __builtin_fabsf(bqn[k])), __builtin_fabsf(bqn[k + 1]));
-        asm volatile("" : "+v"(vmax));  // here, not sunk to its next use: that kept all of bqn live across step 0 (spills)
-        in_t[0] = bqn[24];
-        float4_t acc2[1][GS_T2];
-#pragma unroll
-        for (int t2 = 0; t2 < GS_T2; t2++) {
-            const float4 b = *reinterpret_cast<const float4*>(s_wa + GS_W2_OFF + (16 * t2 + 4 * g) * 4);  // chunk 0 is resident
-            acc2[0][t2] = (float4_t){b.x, b.y, b.z, b.w};
-        }
-        const float oscale = *reinterpret_cast<const float*>(s_wa + GS_W2_OFF + 112 * 4);
-        uint4_t h_hi[1], h_lo[1];
-        h_hi[0] = (uint4_t){0, 0, 0, 0};
-        h_lo[0] = (uint4_t){0, 0, 0, 0};
-
-        const int next = tile + gridDim.x;
-        const bool has_next = next < n_tiles;  // workgroup-uniform
-        const int nbase = next * GT_TILE;
-        const bool nvalid = has_next && (long long)nbase + wave * 16 + j < n_tot;
-        const int e0n = has_next ? row_ptr[(long long)nbase] : 0;  // scalar load: first CSR entry of the next tile
-        const int coff = e0n & 3;
-
-        GsDma dma;
-        dma.on = true;
-        dma.p0 = wave; dma.p1 = wave + GT_WAVES;
-        dma.p2 = wave + 2 * GT_WAVES < GS_CHUNK_STRIDE / 1024 ? wave + 2 * GT_WAVES : wave;
-        dma.rows = false;
-        dma.lane_off = lane_off;
-        const uint8_t* const wl = wchunks;
-        const uint32_t la = gt_lds_addr(s_wa), lb = gt_lds_addr(s_wb);
-
-        // ---- step 0: chunk 1 -> B
-        GT_WAIT_ALL();  // the previous tile's stores (long done): nothing of hipcc's own may be pending when DMA is in flight
-        dma.g = wl + 1 * GS_CHUNK_STRIDE; dma.l = lb;
-        gs_step_p<0>(s_wa, lane, g, in_hi, in_lo, in_t, h_hi, h_lo, acc2, vmax, dma);
-        GT_WAIT_ALL();
-        GSP_BAR();  // every wave has finished the gather of this tile: rows and CSR staging may be overwritten
-        // ---- step 1: CSR of the next tile; chunk 2 -> A
-        if (has_next) gt_issue_csr(row_ptr, src, ecode, smem, next, e0n, n_tot, e_tot, wave, lane);
-        __builtin_amdgcn_sched_barrier(0);
-        dma.g = wl + 2 * GS_CHUNK_STRIDE; dma.l = la;
-        gs_step_p<1>(s_wb, lane, g, in_hi, in_lo, in_t, h_hi, h_lo, acc2, vmax, dma);
-        GT_WAIT_ALL();
-        GSP_BAR();
-        // ---- step 2: chunk 3 -> B; then the rows of the next tile, between the MLP2 groups
-        dma.g = wl + 3 * GS_CHUNK_STRIDE; dma.l = lb;
-        dma.rows = true;
-        dma.rl = gt_lds_addr(s_rows);
-        {
-            const long long roff = (long long)(has_next ? next : tile) * GT_ROW_BYTES;
-            const long long rest = (long long)n_tot * (GS_D * 4) - 16 - roff;  // >= 0: the tile has at least one row
-            dma.rbase = reinterpret_cast<const char*>(h) + roff;
-            dma.rlim = rest < GT_ROW_BYTES ? (uint32_t)rest : (uint32_t)GT_ROW_BYTES;
-        }
-        dma.rwave = wave; dma.rwaves = GT_WAVES; dma.rpieces = GT_ROW_BYTES / 1024;
-        gs_step_p<2>(s_wa, lane, g, in_hi, in_lo, in_t, h_hi, h_lo, acc2, vmax, dma);
-        dma.rows = false;
-        GT_WAIT_ALL();
-        GSP_BAR();
-        // ---- steps 3..7: one in-edge of the next tile's gather after the MFMAs of each
-        GT_GATHER_INIT(nvalid);
-#define GT_STEP(S, CUR)                                                                               \
-    dma.g = wl + (size_t)(((S) + 1) & 7) * GS_CHUNK_STRIDE; dma.l = ((S) & 1) ? la : lb;              \
-    gs_step_p<S>(CUR, lane, g, in_hi, in_lo, in_t, h_hi, h_lo, acc2, vmax, dma);                      \
-    __builtin_amdgcn_sched_barrier(0);                                                                \
-    GT_ROUND()
-        GT_STEP(3, s_wb); GT_WAIT_ALL(); GSP_BAR();
-        GT_STEP(4, s_wa); GT_WAIT_ALL(); GSP_BAR();
-        GT_STEP(5, s_wb); GT_WAIT_ALL(); GSP_BAR();
-        GT_STEP(6, s_wa); GT_WAIT_ALL(); GSP_BAR();
-        GT_STEP(7, s_wb);  // chunk 0 again, for the next tile
-#undef GT_STEP
-        {   // the tile's outputs, stored inside step 7 so that its wait overlaps them with the other waves' work
-            const long long node = (long long)tile * GT_TILE + wave * 16 + j;
-            if (node < n_tot) {
-                float* row = hout + (size_t)node * GS_D;
-#pragma unroll
-                for (int t2 = 0; t2 < GS_T2; t2++) {
-                    const int col = 16 * t2 + 4 * g;
-                    if (col < GS_D) {
-                        float4_t r = acc2[0][t2] * oscale;
-                        if (relu_out) { r.x = relu1(r.x); r.y = relu1(r.y); r.z = relu1(r.z); r.w = relu1(r.w); }
-                        *reinterpret_cast<float4*>(row + col) = make_float4(r.x, r.y, r.z, r.w);
-                    }
-                }
-            }
-        }
-        GT_WAIT_ALL();
-        GSP_BAR();
-        if (!has_next) break;
-        GT_GATHER_FINISH();
-        tile = next;
-    }
-    if (__any(!(vmax < 6.0e4f))) {
-        if (lane == 0) atomicOr(range_flag, 1);
-    }
-}
-
 inline float pow2_scale(const float* w, size_t n) {
     float m = 0.0f;
     for (size_t i = 0; i < n; i++) m = std::fmax(m, std::fabs(w[i]));
@@ -980,15 +493,6 @@ void gin_split_pack_layer(const float* w1, const float* b1, const float* w2, con
 void launch_gin_layer_split(const float* h, float* hout, const int* row_ptr, const int* src, const uint8_t* ecode,
                             const float* ecomb, const uint8_t* chunks, int n_tot, int e_tot, int relu_out, int* range_flag,
                             int nt, hipStream_t s, const float* pool_w) {
-    if (pool_w && nt == 3) nt = 4;  // the tile-staged variant has no folded readout
-    if (e_tot == 0 && nt == 3) nt = 1;  // the tile-staged kernel stages CSR entries unconditionally
-    if (nt == 3) {
-        const int n_tiles = (int)ceil_div_ll(n_tot, GT_TILE);
-        const int grid = n_tiles < 256 ? n_tiles : 256;  // persistent: one 12-wave workgroup per CU
-        gin_layer_split_tiled_kernel<<<grid, GT_WAVES * 64, 0, s>>>(h, hout, row_ptr, src, ecode, ecomb, chunks, n_tot, e_tot, n_tiles,
-                                                                    relu_out, range_flag);
-        return;
-    }
     if (nt == 4) {  // 8 waves, 128 nodes per workgroup, 2 workgroups per CU
         const int blocks = (int)ceil_div_ll(n_tot, 128);
         gin_layer_split_kernel<1, 8><<<blocks, 512, 0, s>>>(h, hout, row_ptr, src, ecode, ecomb, chunks, n_tot, relu_out, range_flag, pool_w);
