@@ -163,6 +163,7 @@ def main():
         if world > 1:
             eng.sync()  # results complete before the collective reads them
             dist.all_gather_into_tensor(out_all, out_local)
+            torch.cuda.current_stream().synchronize()  # ... and the gather done before the next step's readout rewrites them
 
     for _ in range(args.warmup):
         step()
