@@ -73,6 +73,129 @@ struct GcnAggPolicy {
     }
 };
 
+// One GCN layer in one kernel: a = relu(BN(aggregate(x))) as in GcnAggPolicy<true>, then x' = W a + b on the f16 matrix pipe
+// (split products, dense_split.h) -- the aggregate never goes to HBM (2 x 2.8 GB per layer at 2^18 molpcba graphs).
+// Everything the layer needs besides the rows fits LDS for the whole kernel (45 KB of weight fragments, 24 KB of
+// edge-embedding combos, the three epilogue vectors), so after the initial fill there is NO barrier: persistent
+// workgroups, each wave walks its own 16-node tiles -- gather in the B-operand register layout (lane (j, g) owns node j's
+// features 16 q + 4 g .. +3 and 96 + g), CSR entries and per-edge norms one edge ahead of the row loads, 70 MFMAs, stores --
+// and the sixteen waves of a CU drift freely against each other instead of marching through barrier-delimited steps.
+__global__ __launch_bounds__(512) void gcn_layer_fused_kernel(const float* __restrict__ x, float* __restrict__ xout,
+                                                               const int* __restrict__ row_ptr, const int* __restrict__ src,
+                                                               const uint8_t* __restrict__ ecode, const float* __restrict__ esc,
+                                                               const int* __restrict__ out_deg, const float* __restrict__ ecomb,
+                                                               const float* __restrict__ ep, const uint8_t* __restrict__ wpk, int n_tot,
+                                                               int* __restrict__ range_flag) {
+    constexpr int OT = GCN_OT;
+    constexpr int WBYTES = (int)dense100_split_bytes(OT);
+    constexpr int TAIL_OFF = OT * 6 * 1024, BIAS_OFF = TAIL_OFF + OT * 256, SCALE_OFF = BIAS_OFF + OT * 64;
+    __shared__ __attribute__((aligned(16))) char s_w[WBYTES];
+    __shared__ __attribute__((aligned(16))) float s_ecomb[EDGE_COMBOS * GCN_D];
+    __shared__ __attribute__((aligned(16))) float s_ep[3 * GCN_D];
+    for (int i = threadIdx.x; i < WBYTES / 16; i += 512) reinterpret_cast<float4*>(s_w)[i] = reinterpret_cast<const float4*>(wpk)[i];
+    for (int i = threadIdx.x; i < EDGE_COMBOS * GCN_C; i += 512)
+        reinterpret_cast<float4*>(s_ecomb)[i] = reinterpret_cast<const float4*>(ecomb)[i];
+    for (int i = threadIdx.x; i < 3 * GCN_D; i += 512) s_ep[i] = ep[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 15, g = lane >> 4;
+    const float oscale = *reinterpret_cast<const float*>(s_w + SCALE_OFF);
+    const long long n_tiles = ((long long)n_tot + 15) / 16;
+    float vmax = 0.0f;
+    for (long long tile = (long long)blockIdx.x * 8 + wave; tile < n_tiles; tile += (long long)gridDim.x * 8) {
+        long long node = tile * 16 + j;
+        const bool valid = node < n_tot;
+        if (!valid) node = n_tot - 1;
+        int e = row_ptr[node];
+        const int e_end = valid ? row_ptr[node + 1] : e;
+        const int dv = out_deg[node];
+        const float* xr = x + (size_t)node * GCN_D + 4 * g;
+        float4 xs[6];
+#pragma unroll
+        for (int q = 0; q < 6; q++) xs[q] = *reinterpret_cast<const float4*>(xr + 16 * q);
+        const float xst = x[(size_t)node * GCN_D + 96 + g];
+        const float dinv_v = dv > 0 ? 1.0f / sqrtf((float)(dv + 1)) : 0.0f;  // load_inputs.cc:122
+        const float idp1 = 1.0f / (float)(dv + 1);
+        float m[25];
+#pragma unroll
+        for (int k = 0; k < 25; k++) m[k] = 0.0f;
+        int u_nx = 0, c_nx = 0;
+        float n_nx = 0.0f;
+        if (e < e_end) { u_nx = src[e]; c_nx = ecode[e]; n_nx = esc[e]; }
+        while (__any(e < e_end)) {
+            if (e < e_end) {
+                const int u = u_nx, code = c_nx;
+                const float norm = n_nx * dinv_v;
+                e++;
+                if (e < e_end) { u_nx = src[e]; c_nx = ecode[e]; n_nx = esc[e]; }
+                const float* hr = x + (size_t)u * GCN_D + 4 * g;
+                const float* er = s_ecomb + code * GCN_D + 4 * g;
+                float4 xv[6];
+#pragma unroll
+                for (int q = 0; q < 6; q++) xv[q] = *reinterpret_cast<const float4*>(hr + 16 * q);
+                const float xt = x[(size_t)u * GCN_D + 96 + g];
+#pragma unroll
+                for (int q = 0; q < 6; q++) {
+                    const float4 w = *reinterpret_cast<const float4*>(er + 16 * q);
+                    m[4 * q + 0] += norm * relu1(w.x + xv[q].x);
+                    m[4 * q + 1] += norm * relu1(w.y + xv[q].y);
+                    m[4 * q + 2] += norm * relu1(w.z + xv[q].z);
+                    m[4 * q + 3] += norm * relu1(w.w + xv[q].w);
+                }
+                m[24] += norm * relu1(s_ecomb[code * GCN_D + 96 + g] + xt);
+            }
+        }
+        // epilogue of the aggregation (GcnAggPolicy<true>::finish): root term, folded BatchNorm, ReLU
+        float a[25];
+#pragma unroll
+        for (int q = 0; q < 6; q++) {
+            const float4 rt = *reinterpret_cast<const float4*>(s_ep + 16 * q + 4 * g);
+            const float4 sc = *reinterpret_cast<const float4*>(s_ep + GCN_D + 16 * q + 4 * g);
+            const float4 sh = *reinterpret_cast<const float4*>(s_ep + 2 * GCN_D + 16 * q + 4 * g);
+            a[4 * q + 0] = relu1((m[4 * q + 0] + relu1(xs[q].x + rt.x) * idp1) * sc.x + sh.x);
+            a[4 * q + 1] = relu1((m[4 * q + 1] + relu1(xs[q].y + rt.y) * idp1) * sc.y + sh.y);
+            a[4 * q + 2] = relu1((m[4 * q + 2] + relu1(xs[q].z + rt.z) * idp1) * sc.z + sh.z);
+            a[4 * q + 3] = relu1((m[4 * q + 3] + relu1(xs[q].w + rt.w) * idp1) * sc.w + sh.w);
+        }
+        a[24] = relu1((m[24] + relu1(xst + s_ep[96 + g]) * idp1) * s_ep[GCN_D + 96 + g] + s_ep[2 * GCN_D + 96 + g]);
+        // dense layer on the split operands
+        ds_uint4_t b_hi[3], b_lo[3];
+#pragma unroll
+        for (int ks = 0; ks < 3; ks++) {
+            DS_SPLIT2(a[8 * ks + 0], a[8 * ks + 1], b_hi[ks].x, b_lo[ks].x);
+            DS_SPLIT2(a[8 * ks + 2], a[8 * ks + 3], b_hi[ks].y, b_lo[ks].y);
+            DS_SPLIT2(a[8 * ks + 4], a[8 * ks + 5], b_hi[ks].z, b_lo[ks].z);
+            DS_SPLIT2(a[8 * ks + 6], a[8 * ks + 7], b_hi[ks].w, b_lo[ks].w);
+        }
+#pragma unroll
+        for (int k = 0; k < 24; k += 2) vmax = __builtin_fmaxf(__builtin_fmaxf(vmax, a[k]), a[k + 1]);  // a >= 0 (ReLU)
+        asm volatile("" : "+v"(vmax));
+#pragma unroll
+        for (int t = 0; t < OT; t++) {
+            const float4 bv = *reinterpret_cast<const float4*>(s_w + BIAS_OFF + (16 * t + 4 * g) * 4);
+            float4_t acc = {bv.x, bv.y, bv.z, bv.w};
+#pragma unroll
+            for (int ks = 0; ks < 3; ks++) {
+                const ds_uint4_t a_hi = *reinterpret_cast<const ds_uint4_t*>(s_w + ((t * 3 + ks) * 2 + 0) * 1024 + lane * 16);
+                const ds_uint4_t a_lo = *reinterpret_cast<const ds_uint4_t*>(s_w + ((t * 3 + ks) * 2 + 1) * 1024 + lane * 16);
+                acc = DS_MFMA16(a_hi, b_hi[ks], acc);
+                acc = DS_MFMA16(a_hi, b_lo[ks], acc);
+                acc = DS_MFMA16(a_lo, b_hi[ks], acc);
+            }
+            const float at = *reinterpret_cast<const float*>(s_w + TAIL_OFF + t * 256 + lane * 4);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(at, a[24], acc, 0, 0, 0);
+            const int col = 16 * t + 4 * g;
+            if (col < GCN_D && valid) {
+                const float4_t r = acc * oscale;
+                *reinterpret_cast<float4*>(xout + (size_t)node * GCN_D + col) = make_float4(r.x, r.y, r.z, r.w);
+            }
+        }
+    }
+    if (__any(!(vmax < 6.0e4f))) {
+        if (lane == 0) atomicOr(range_flag, 1);
+    }
+}
+
 class GcnModel : public Model {
 public:
     ~GcnModel() override { free_all(); }
@@ -205,6 +328,17 @@ public:
             launch_dense(0, db.scratch, db.h[cur], n, db.range_flag, s);  // x_0 = W_0 h0 + b_0
         }
         for (int l = 1; l < GCN_L; l++) {
+            if (split_ && !exact_ && fused_ && db.b.e_tot > 0) {
+                ProfScope p(prof, "gcn_layer_fused", s);
+                const long long wgs = ceil_div_ll(n, 128);
+                const int grid = (int)(wgs < 512 ? wgs : 512);  // persistent: two 8-wave workgroups per CU (71 KB of LDS each)
+                gcn_layer_fused_kernel<<<grid, 512, 0, s>>>(db.h[cur], db.h[cur ^ 1], db.csr.row_ptr, db.csr.src, db.csr.ecode, esc_.p,
+                                                            db.csr.out_deg, d_ecomb_ + (size_t)(l - 1) * EDGE_COMBOS * GCN_D,
+                                                            d_ep_ + (size_t)(l - 1) * 3 * GCN_D, d_split_ + (size_t)l * dense100_split_bytes(GCN_OT),
+                                                            n, db.range_flag);
+                cur ^= 1;
+                continue;
+            }
             {
                 ProfScope p(prof, "gcn_aggregate", s);
                 launch_aggregate<true>(db, l - 1, db.h[cur], db.scratch, s);  // a_l
@@ -254,6 +388,8 @@ private:
     // f16 MFMAs per product (dense_split.h), with the engine falling back to fp32 when the range flag trips
     bool split_ = !(getenv("FLOWGNN_GCN_MFMA") && strcmp(getenv("FLOWGNN_GCN_MFMA"), "f32") == 0);
     bool exact_ = false;
+    // FLOWGNN_GCN_UNFUSED=1 keeps aggregate and dense as two kernels per layer (A/B measurements)
+    bool fused_ = !(getenv("FLOWGNN_GCN_UNFUSED") && atoi(getenv("FLOWGNN_GCN_UNFUSED")) != 0);
     uint8_t* d_split_ = nullptr;
     float *d_nemb_ = nullptr, *d_pw_ = nullptr, *d_pb_ = nullptr, *d_ecomb_ = nullptr, *d_ep_ = nullptr, *d_wf_ = nullptr,
           *d_wt_ = nullptr, *d_bp_ = nullptr;
