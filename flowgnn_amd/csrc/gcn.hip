@@ -80,26 +80,30 @@ struct GcnAggPolicy {
 // workgroups, each wave walks its own 16-node tiles -- gather in the B-operand register layout (lane (j, g) owns node j's
 // features 16 q + 4 g .. +3 and 96 + g), CSR entries and per-edge norms one edge ahead of the row loads, 70 MFMAs, stores --
 // and the sixteen waves of a CU drift freely against each other instead of marching through barrier-delimited steps.
+// FINAL: the last stage has no dense layer and no ReLU; the readout's linear head is applied per node instead
+// (mean_v(a[v]) . w = mean_v(a[v] . w)) and xout is a float[n_tot] of per-node scores for segment_mean_bias_kernel.
+template <bool FINAL>
 __global__ __launch_bounds__(512) void gcn_layer_fused_kernel(const float* __restrict__ x, float* __restrict__ xout,
                                                                const int* __restrict__ row_ptr, const int* __restrict__ src,
                                                                const uint8_t* __restrict__ ecode, const float* __restrict__ esc,
                                                                const int* __restrict__ out_deg, const float* __restrict__ ecomb,
                                                                const float* __restrict__ ep, const uint8_t* __restrict__ wpk, int n_tot,
-                                                               int* __restrict__ range_flag) {
+                                                               int* __restrict__ range_flag, const float* __restrict__ pool_w) {
     constexpr int OT = GCN_OT;
     constexpr int WBYTES = (int)dense100_split_bytes(OT);
     constexpr int TAIL_OFF = OT * 6 * 1024, BIAS_OFF = TAIL_OFF + OT * 256, SCALE_OFF = BIAS_OFF + OT * 64;
     __shared__ __attribute__((aligned(16))) char s_w[WBYTES];
     __shared__ __attribute__((aligned(16))) float s_ecomb[EDGE_COMBOS * GCN_D];
     __shared__ __attribute__((aligned(16))) float s_ep[3 * GCN_D];
-    for (int i = threadIdx.x; i < WBYTES / 16; i += 512) reinterpret_cast<float4*>(s_w)[i] = reinterpret_cast<const float4*>(wpk)[i];
+    if (!FINAL)
+        for (int i = threadIdx.x; i < WBYTES / 16; i += 512) reinterpret_cast<float4*>(s_w)[i] = reinterpret_cast<const float4*>(wpk)[i];
     for (int i = threadIdx.x; i < EDGE_COMBOS * GCN_C; i += 512)
         reinterpret_cast<float4*>(s_ecomb)[i] = reinterpret_cast<const float4*>(ecomb)[i];
     for (int i = threadIdx.x; i < 3 * GCN_D; i += 512) s_ep[i] = ep[i];
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = lane & 15, g = lane >> 4;
-    const float oscale = *reinterpret_cast<const float*>(s_w + SCALE_OFF);
+    const float oscale = FINAL ? 1.0f : *reinterpret_cast<const float*>(s_w + SCALE_OFF);
     const long long n_tiles = ((long long)n_tot + 15) / 16;
     float vmax = 0.0f;
     for (long long tile = (long long)blockIdx.x * 8 + wave; tile < n_tiles; tile += (long long)gridDim.x * 8) {
@@ -152,12 +156,27 @@ __global__ __launch_bounds__(512) void gcn_layer_fused_kernel(const float* __res
             const float4 rt = *reinterpret_cast<const float4*>(s_ep + 16 * q + 4 * g);
             const float4 sc = *reinterpret_cast<const float4*>(s_ep + GCN_D + 16 * q + 4 * g);
             const float4 sh = *reinterpret_cast<const float4*>(s_ep + 2 * GCN_D + 16 * q + 4 * g);
-            a[4 * q + 0] = relu1((m[4 * q + 0] + relu1(xs[q].x + rt.x) * idp1) * sc.x + sh.x);
-            a[4 * q + 1] = relu1((m[4 * q + 1] + relu1(xs[q].y + rt.y) * idp1) * sc.y + sh.y);
-            a[4 * q + 2] = relu1((m[4 * q + 2] + relu1(xs[q].z + rt.z) * idp1) * sc.z + sh.z);
-            a[4 * q + 3] = relu1((m[4 * q + 3] + relu1(xs[q].w + rt.w) * idp1) * sc.w + sh.w);
+            a[4 * q + 0] = (m[4 * q + 0] + relu1(xs[q].x + rt.x) * idp1) * sc.x + sh.x;
+            a[4 * q + 1] = (m[4 * q + 1] + relu1(xs[q].y + rt.y) * idp1) * sc.y + sh.y;
+            a[4 * q + 2] = (m[4 * q + 2] + relu1(xs[q].z + rt.z) * idp1) * sc.z + sh.z;
+            a[4 * q + 3] = (m[4 * q + 3] + relu1(xs[q].w + rt.w) * idp1) * sc.w + sh.w;
         }
-        a[24] = relu1((m[24] + relu1(xst + s_ep[96 + g]) * idp1) * s_ep[GCN_D + 96 + g] + s_ep[2 * GCN_D + 96 + g]);
+        a[24] = (m[24] + relu1(xst + s_ep[96 + g]) * idp1) * s_ep[GCN_D + 96 + g] + s_ep[2 * GCN_D + 96 + g];
+        if (FINAL) {  // no ReLU after the last BatchNorm; per-node score, fixed order: 25 terms in the lane, then the node's 4 lanes
+            float part = 0.0f;
+#pragma unroll
+            for (int q = 0; q < 6; q++) {
+                const float4 pw = *reinterpret_cast<const float4*>(pool_w + 16 * q + 4 * g);
+                part += a[4 * q + 0] * pw.x; part += a[4 * q + 1] * pw.y; part += a[4 * q + 2] * pw.z; part += a[4 * q + 3] * pw.w;
+            }
+            part += a[24] * pool_w[96 + g];
+            part += __shfl_xor(part, 16, 64);
+            part += __shfl_xor(part, 32, 64);
+            if (g == 0 && valid) xout[node] = part;
+            continue;
+        }
+#pragma unroll
+        for (int k = 0; k < 25; k++) a[k] = relu1(a[k]);
         // dense layer on the split operands
         ds_uint4_t b_hi[3], b_lo[3];
 #pragma unroll
@@ -332,10 +351,10 @@ public:
                 ProfScope p(prof, "gcn_layer_fused", s);
                 const long long wgs = ceil_div_ll(n, 128);
                 const int grid = (int)(wgs < 512 ? wgs : 512);  // persistent: two 8-wave workgroups per CU (71 KB of LDS each)
-                gcn_layer_fused_kernel<<<grid, 512, 0, s>>>(db.h[cur], db.h[cur ^ 1], db.csr.row_ptr, db.csr.src, db.csr.ecode, esc_.p,
+                gcn_layer_fused_kernel<false><<<grid, 512, 0, s>>>(db.h[cur], db.h[cur ^ 1], db.csr.row_ptr, db.csr.src, db.csr.ecode, esc_.p,
                                                             db.csr.out_deg, d_ecomb_ + (size_t)(l - 1) * EDGE_COMBOS * GCN_D,
                                                             d_ep_ + (size_t)(l - 1) * 3 * GCN_D, d_split_ + (size_t)l * dense100_split_bytes(GCN_OT),
-                                                            n, db.range_flag);
+                                                            n, db.range_flag, nullptr);
                 cur ^= 1;
                 continue;
             }
@@ -350,6 +369,21 @@ public:
             cur ^= 1;
         }
         db.final_h = cur;
+        if (split_ && !exact_ && fused_ && db.b.e_tot > 0) {
+            // last stage: aggregation + BatchNorm with the readout's linear head folded in (per-node scores in db.scratch;
+            // flowgnn_get_h returns x_4 = db.h[final_h], which is untouched by this)
+            {
+                ProfScope p(prof, "gcn_layer_fused", s);
+                const long long wgs = ceil_div_ll(n, 128);
+                const int grid = (int)(wgs < 512 ? wgs : 512);
+                gcn_layer_fused_kernel<true><<<grid, 512, 0, s>>>(db.h[cur], db.scratch, db.csr.row_ptr, db.csr.src, db.csr.ecode, esc_.p,
+                                                                  db.csr.out_deg, d_ecomb_ + (size_t)(GCN_L - 1) * EDGE_COMBOS * GCN_D,
+                                                                  d_ep_ + (size_t)(GCN_L - 1) * 3 * GCN_D, nullptr, n, db.range_flag, d_pw_);
+            }
+            ProfScope p(prof, "mean_pool_linear", s);
+            segment_mean_bias_kernel<0><<<(db.b.num_graphs + 255) / 256, 256, 0, s>>>(db.scratch, db.b.node_off, d_pb_, db.out, db.b.num_graphs);
+            return 0;
+        }
         {
             ProfScope p(prof, "gcn_aggregate", s);
             launch_aggregate<false>(db, GCN_L - 1, db.h[cur], db.scratch, s);  // BN_4(...), no ReLU
