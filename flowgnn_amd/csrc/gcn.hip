@@ -73,6 +73,92 @@ struct GcnAggPolicy {
     }
 };
 
+// x_0 = W_0 h0 + b_0 with h0 = atom encoder output computed on the fly: the 173-row embedding table (69 KB) and the
+// layer's weight fragments (45 KB) both live in LDS, a lane sums the nine table rows of its node for the 25 features it
+// owns (same order as atom_encoder_kernel, so h0 is bit-identical) and feeds them straight to the split MFMAs.  Saves
+// the 2.8 GB write + 2.8 GB read of h0.  One persistent 16-wave workgroup per CU, no barrier after the initial fill.
+__global__ __launch_bounds__(1024) void gcn_encoder_dense_kernel(const int* __restrict__ node_feature, const float* __restrict__ table,
+                                                                  float* __restrict__ xout, const uint8_t* __restrict__ wpk, int n_tot,
+                                                                  int* __restrict__ err, int* __restrict__ range_flag) {
+    constexpr int OT = GCN_OT;
+    constexpr int WBYTES = (int)dense100_split_bytes(OT);
+    constexpr int TAIL_OFF = OT * 6 * 1024, BIAS_OFF = TAIL_OFF + OT * 256, SCALE_OFF = BIAS_OFF + OT * 64;
+    __shared__ __attribute__((aligned(16))) char s_w[WBYTES];
+    __shared__ __attribute__((aligned(16))) float s_tab[ND_FEATURE_TOTAL * GCN_D];
+    for (int i = threadIdx.x; i < WBYTES / 16; i += 1024) reinterpret_cast<float4*>(s_w)[i] = reinterpret_cast<const float4*>(wpk)[i];
+    for (int i = threadIdx.x; i < ND_FEATURE_TOTAL * GCN_C; i += 1024)
+        reinterpret_cast<float4*>(s_tab)[i] = reinterpret_cast<const float4*>(table)[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 15, g = lane >> 4;
+    const float oscale = *reinterpret_cast<const float*>(s_w + SCALE_OFF);
+    const long long n_tiles = ((long long)n_tot + 15) / 16;
+    float vmax = 0.0f;
+    for (long long tile = (long long)blockIdx.x * 16 + wave; tile < n_tiles; tile += (long long)gridDim.x * 16) {
+        long long node = tile * 16 + j;
+        const bool valid = node < n_tot;
+        if (!valid) node = n_tot - 1;
+        int rows[ND_FEATURE];
+#pragma unroll
+        for (int k = 0; k < ND_FEATURE; k++) {
+            int f = node_feature[(size_t)node * ND_FEATURE + k];
+            if (f < 0 || f >= c_nd_card[k]) {
+                atomicMax(err, ERR_NODE_FEAT);
+                f = 0;
+            }
+            rows[k] = (c_nd_off[k] + f) * GCN_D;
+        }
+        float a[25];
+#pragma unroll
+        for (int i = 0; i < 25; i++) a[i] = 0.0f;
+#pragma unroll
+        for (int k = 0; k < ND_FEATURE; k++) {
+            const float* tr = s_tab + rows[k] + 4 * g;
+#pragma unroll
+            for (int q = 0; q < 6; q++) {
+                const float4 w = *reinterpret_cast<const float4*>(tr + 16 * q);
+                a[4 * q + 0] += w.x; a[4 * q + 1] += w.y; a[4 * q + 2] += w.z; a[4 * q + 3] += w.w;
+            }
+            a[24] += s_tab[rows[k] + 96 + g];
+        }
+        ds_uint4_t b_hi[3], b_lo[3];
+#pragma unroll
+        for (int ks = 0; ks < 3; ks++) {
+            DS_SPLIT2(a[8 * ks + 0], a[8 * ks + 1], b_hi[ks].x, b_lo[ks].x);
+            DS_SPLIT2(a[8 * ks + 2], a[8 * ks + 3], b_hi[ks].y, b_lo[ks].y);
+            DS_SPLIT2(a[8 * ks + 4], a[8 * ks + 5], b_hi[ks].z, b_lo[ks].z);
+            DS_SPLIT2(a[8 * ks + 6], a[8 * ks + 7], b_hi[ks].w, b_lo[ks].w);
+        }
+#pragma unroll
+        for (int k = 0; k < 24; k += 2)
+            vmax = __builtin_fmaxf(__builtin_fmaxf(vmax, __builtin_fabsf(a[k])), __builtin_fabsf(a[k + 1]));
+        asm volatile("" : "+v"(vmax));
+#pragma unroll
+        for (int t = 0; t < OT; t++) {
+            const float4 bv = *reinterpret_cast<const float4*>(s_w + BIAS_OFF + (16 * t + 4 * g) * 4);
+            float4_t acc = {bv.x, bv.y, bv.z, bv.w};
+#pragma unroll
+            for (int ks = 0; ks < 3; ks++) {
+                const ds_uint4_t a_hi = *reinterpret_cast<const ds_uint4_t*>(s_w + ((t * 3 + ks) * 2 + 0) * 1024 + lane * 16);
+                const ds_uint4_t a_lo = *reinterpret_cast<const ds_uint4_t*>(s_w + ((t * 3 + ks) * 2 + 1) * 1024 + lane * 16);
+                acc = DS_MFMA16(a_hi, b_hi[ks], acc);
+                acc = DS_MFMA16(a_hi, b_lo[ks], acc);
+                acc = DS_MFMA16(a_lo, b_hi[ks], acc);
+            }
+            const float at = *reinterpret_cast<const float*>(s_w + TAIL_OFF + t * 256 + lane * 4);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(at, a[24], acc, 0, 0, 0);
+            const int col = 16 * t + 4 * g;
+            if (col < GCN_D && valid) {
+                const float4_t r = acc * oscale;
+                *reinterpret_cast<float4*>(xout + (size_t)node * GCN_D + col) = make_float4(r.x, r.y, r.z, r.w);
+            }
+        }
+    }
+    if (__any(!(vmax < 6.0e4f))) {
+        if (lane == 0) atomicOr(range_flag, 1);
+    }
+}
+
 // One GCN layer in one kernel: a = relu(BN(aggregate(x))) as in GcnAggPolicy<true>, then x' = W a + b on the f16 matrix pipe
 // (split products, dense_split.h) -- the aggregate never goes to HBM (2 x 2.8 GB per layer at 2^18 molpcba graphs).
 // Everything the layer needs besides the rows fits LDS for the whole kernel (45 KB of weight fragments, 24 KB of
@@ -329,11 +415,6 @@ public:
     int forward(DeviceBatch& db, Profiler& prof, hipStream_t s) override {
         const int n = db.b.n_tot;
         if (n <= 0) return 0;
-        {
-            ProfScope p(prof, "atom_encoder", s);
-            atom_encoder_kernel<GCN_D><<<atom_encoder_grid(n, GCN_C), 512, 0, s>>>(
-                db.b.node_feature, d_nemb_, db.scratch, n, db.csr.err);
-        }
         if (int rc = make_tile_bounds(tiles_, db.b.node_off, db.b.num_graphs, n, tile_nominal_, tile_slack_, s)) return rc;
         if (db.b.e_tot > 0) {  // dinv[src_e] per CSR entry, once per pass
             if (int rc = esc_.reserve((size_t)db.b.e_tot)) return rc;
@@ -342,7 +423,16 @@ public:
             edge_scalar_kernel<GcnAggPolicy<true>><<<grid_for(db.b.e_tot, 256, 256 * 8), 256, 0, s>>>(prm, db.csr.src, esc_.p, db.b.e_tot);
         }
         int cur = 0;
-        {
+        if (split_ && !exact_ && fused_) {
+            ProfScope p(prof, "gcn_encoder_dense", s);  // x_0 = W_0 (atom encoder) + b_0 in one kernel
+            const long long wgs = ceil_div_ll(n, 256);
+            gcn_encoder_dense_kernel<<<(int)(wgs < 256 ? wgs : 256), 1024, 0, s>>>(db.b.node_feature, d_nemb_, db.h[cur], d_split_, n,
+                                                                                   db.csr.err, db.range_flag);
+        } else {
+            {
+                ProfScope p(prof, "atom_encoder", s);
+                atom_encoder_kernel<GCN_D><<<atom_encoder_grid(n, GCN_C), 512, 0, s>>>(db.b.node_feature, d_nemb_, db.scratch, n, db.csr.err);
+            }
             ProfScope p(prof, "gcn_dense", s);
             launch_dense(0, db.scratch, db.h[cur], n, db.range_flag, s);  // x_0 = W_0 h0 + b_0
         }
