@@ -29,9 +29,12 @@ constexpr size_t dense100_split_bytes(int OT) { return (size_t)OT * 6 * 1024 + (
 #define DS_SPLIT2(a, b, HI, LO)                                                                                   \
     do {                                                                                                          \
         const float a_ = (a), b_ = (b);                                                                           \
-        const auto hp_ = __builtin_amdgcn_cvt_pkrtz(a_, b_);                                                      \
-        (HI) = __builtin_bit_cast(uint32_t, hp_);                                                                 \
-        (LO) = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(a_ - (float)hp_.x, b_ - (float)hp_.y));   \
+        const uint32_t hp_ = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(a_, b_));                    \
+        float la_, lb_; /* a - (float)hi: one v_fma_mix each (f16 source read in place) instead of cvt + sub */   \
+        asm("v_fma_mix_f32 %0, -%1, 1.0, %2 op_sel_hi:[1,0,0]" : "=v"(la_) : "v"(hp_), "v"(a_));                  \
+        asm("v_fma_mix_f32 %0, -%1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(lb_) : "v"(hp_), "v"(b_));   \
+        (HI) = hp_;                                                                                               \
+        (LO) = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(la_, lb_));                                \
     } while (0)
 
 template <int OT, bool RELU_OUT>

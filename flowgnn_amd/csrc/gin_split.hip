@@ -54,10 +54,18 @@ typedef uint32_t uint4_t __attribute__((ext_vector_type(4)));
 #define GS_SPLIT2(a, b, HI, LO)                                                                                   \
     do {                                                                                                          \
         const float a_ = (a), b_ = (b);                                                                           \
-        const auto hp_ = __builtin_amdgcn_cvt_pkrtz(a_, b_);                                                      \
-        (HI) = __builtin_bit_cast(uint32_t, hp_);                                                                 \
-        (LO) = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(a_ - (float)hp_.x, b_ - (float)hp_.y));   \
+        const uint32_t hp_ = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(a_, b_));                    \
+        float la_, lb_; /* a - (float)hi: one v_fma_mix each (f16 source read in place) instead of cvt + sub */   \
+        asm("v_fma_mix_f32 %0, -%1, 1.0, %2 op_sel_hi:[1,0,0]" : "=v"(la_) : "v"(hp_), "v"(a_));                  \
+        asm("v_fma_mix_f32 %0, -%1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(lb_) : "v"(hp_), "v"(b_));   \
+        (HI) = hp_;                                                                                               \
+        (LO) = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(la_, lb_));                                \
     } while (0)
+
+__device__ __forceinline__ float gs_relu(float x) {  // max(x, 0) as v_max_i32: one instruction where fmaxf on an MFMA
+    const int b = __builtin_bit_cast(int, x);         // result costs two (the compiler must quiet a possible sNaN first)
+    return __builtin_bit_cast(float, b > 0 ? b : 0);
+}
 
 constexpr int GS_HUB = 8;     // rows with more in-edges than this are summed by the whole wave
 constexpr int GS_MAXHUB = 4;  // ... if the wave has at most this many of them
@@ -122,8 +130,8 @@ __device__ __forceinline__ void gs_step(const char* wb, int s, int lane, int g, 
 #pragma unroll
         for (int nt = 0; nt < NT; nt++) {
             float4_t r0 = acc1[0][nt], r1 = acc1[1][nt];
-            r0.x = relu1(r0.x); r0.y = relu1(r0.y); r0.z = relu1(r0.z); r0.w = relu1(r0.w);
-            r1.x = relu1(r1.x); r1.y = relu1(r1.y); r1.z = relu1(r1.z); r1.w = relu1(r1.w);
+            r0.x = gs_relu(r0.x); r0.y = gs_relu(r0.y); r0.z = gs_relu(r0.z); r0.w = gs_relu(r0.w);
+            r1.x = gs_relu(r1.x); r1.y = gs_relu(r1.y); r1.z = gs_relu(r1.z); r1.w = gs_relu(r1.w);
             vmax = __builtin_fmaxf(__builtin_fmaxf(vmax, r0.x), r0.y);
             vmax = __builtin_fmaxf(__builtin_fmaxf(vmax, r0.z), r0.w);
             vmax = __builtin_fmaxf(__builtin_fmaxf(vmax, r1.x), r1.y);
@@ -392,7 +400,7 @@ __global__ __launch_bounds__(WAVES * 64) void gin_layer_split_kernel(const float
                 const int col = 16 * t2 + 4 * g;
                 if (col < GS_D) {
                     float4_t r = acc2[nt][t2] * oscale;
-                    if (relu_out) { r.x = relu1(r.x); r.y = relu1(r.y); r.z = relu1(r.z); r.w = relu1(r.w); }
+                    if (relu_out) { r.x = gs_relu(r.x); r.y = gs_relu(r.y); r.z = gs_relu(r.z); r.w = gs_relu(r.w); }
                     const float4 pw = *reinterpret_cast<const float4*>(pool_w + col);
                     part += r.x * pw.x; part += r.y * pw.y; part += r.z * pw.z; part += r.w * pw.w;
                 }
@@ -413,7 +421,7 @@ __global__ __launch_bounds__(WAVES * 64) void gin_layer_split_kernel(const float
             const int col = 16 * t2 + 4 * g;
             if (col < GS_D) {
                 float4_t r = acc2[nt][t2] * oscale;
-                if (relu_out) { r.x = relu1(r.x); r.y = relu1(r.y); r.z = relu1(r.z); r.w = relu1(r.w); }
+                if (relu_out) { r.x = gs_relu(r.x); r.y = gs_relu(r.y); r.z = gs_relu(r.z); r.w = gs_relu(r.w); }
                 *reinterpret_cast<float4*>(row + col) = make_float4(r.x, r.y, r.z, r.w);
             }
         }
