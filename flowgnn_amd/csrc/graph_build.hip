@@ -274,6 +274,16 @@ void launch_build_csr(const BatchView& b, const CsrView& c, bool has_edge_attr, 
         build_csr_graph_kernel<64, 256, 1024, uint16_t><<<b.num_graphs, 64, 0, s>>>(b, c, has_edge_attr);
         return;
     }
+    // kNN graphs of the hep10k shape (<= ~100 nodes x 16 in-edges): 18 KB of LDS per graph, so nine workgroups share a CU;
+    // in the class below one graph claims 139 KB and a CU holds a single 4-wave workgroup (0.93 -> 0.22 ms for 2^15 graphs)
+    if (b.num_graphs > 0 && max_nodes <= 256 && max_edges <= 2048) {
+        build_csr_graph_kernel<128, 256, 2048, uint16_t><<<b.num_graphs, 128, 0, s>>>(b, c, has_edge_attr);
+        return;
+    }
+    if (b.num_graphs > 0 && max_nodes <= 512 && max_edges <= 6144) {  // the reference's own caps: 500 nodes / 5500 edges
+        build_csr_graph_kernel<256, 512, 6144, uint16_t><<<b.num_graphs, 256, 0, s>>>(b, c, has_edge_attr);
+        return;
+    }
     if (b.num_graphs > 0 && max_nodes <= 2048 && max_edges <= 16384) {
         build_csr_graph_kernel<256, 2048, 16384, uint16_t><<<b.num_graphs, 256, 0, s>>>(b, c, has_edge_attr);
         return;

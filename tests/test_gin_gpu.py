@@ -75,6 +75,30 @@ def test_csr_bit_exact_vs_reference_tables(eng, oracle):
     assert (eid[1:][same] > eid[:-1][same]).all()
 
 
+@pytest.mark.parametrize("n,e", [(200, 900), (250, 2000), (500, 5500), (1500, 12000), (3000, 20000)])
+def test_csr_size_classes(eng, n, e):
+    """One graph per size class of the index build (per-graph LDS kernels of 256/1024, 256/2048, 512/6144 and
+    2048/16384 nodes/edges, then the flat global path), between small graphs: same CSR as a stable sort by
+    (destination, source, input index)."""
+    rng = np.random.default_rng(n)
+    small = gp.synth_molhiv_batch(3, seed=n)
+    nn = np.array([n], np.int32)
+    nf = np.zeros((n, 9), np.int32)
+    nf[:, 0] = rng.integers(0, 119, n)
+    el = rng.integers(0, n, (e, 2)).astype(np.int32)
+    ea = np.stack([rng.integers(0, 5, e), rng.integers(0, 6, e), rng.integers(0, 2, e)], 1).astype(np.int32)
+    big = gp.GraphBatch(nn, np.array([e], np.int32), nf, el, ea)
+    b = gp.concat_batches([small, big, small])
+    eng.forward(b)
+    row_ptr, src, eid, out_deg = eng.csr()
+    ge = b.global_edges()
+    order = np.lexsort((np.arange(len(ge)), ge[:, 0], ge[:, 1]))
+    assert np.array_equal(eid, order)
+    assert np.array_equal(src, ge[order, 0])
+    assert np.array_equal(row_ptr, np.concatenate([[0], np.cumsum(np.bincount(ge[:, 1], minlength=b.total_nodes))]))
+    assert np.array_equal(out_deg, np.bincount(ge[:, 0], minlength=b.total_nodes))
+
+
 def test_forward_matches_oracle(eng, oracle, gin_weights):
     b = gp.synth_molhiv_batch(256, seed=31)
     got = eng.forward(b)
