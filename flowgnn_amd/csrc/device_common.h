@@ -357,7 +357,35 @@ __global__ __launch_bounds__(P::NTHR) void tiled_aggregate_kernel(typename P::Pa
             typename P::Acc acc;
             P::init(acc);
             if (ne <= TE) {
-                for (int e = beg; e < end; e++) {
+                int e = beg;
+                // four in-edges per trip: their CSR words, then their rows, are four INDEPENDENT LDS reads in flight
+                // (one edge per trip is two dependent LDS round trips per edge, and on the kNN graphs -- 16 in-edges per
+                // row -- that latency, not HBM, was the whole kernel); the folds stay in CSR order
+                for (; e + 4 <= end; e += 4) {
+                    unsigned pk[4];
+                    float ss[4];
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        pk[k] = s_edge[e + k];
+                        ss[k] = P::HAS_SCALAR ? s_es[e + k] : 0.f;
+                        asm volatile("" : "+v"(pk[k]), "+v"(ss[k]));
+                    }
+                    float4 x[4], w[4];
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        const unsigned ul = pk[k] >> 8;
+                        w[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (P::TABLE_ROWS > 0) w[k] = *reinterpret_cast<const float4*>(st_b + (pk[k] & 0xFFu) * (D * 4) + c * 16);
+                        x[k] = *reinterpret_cast<const float4*>(sh_b + (ul < (unsigned)TR ? ul : 0u) * (D * 4) + c * 16);
+                        asm volatile("" : "+v"(x[k].x), "+v"(x[k].y), "+v"(x[k].z), "+v"(x[k].w));
+                    }
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        if ((pk[k] >> 8) >= (unsigned)TR) x[k] = load_f4_rare(h4 + (size_t)load_i32_rare(src + e0 + e + k) * C + c);
+                        P::edge(acc, x[k], w[k], ss[k], sd);
+                    }
+                }
+                for (; e < end; e++) {
                     unsigned pk = s_edge[e];
                     float ss = P::HAS_SCALAR ? s_es[e] : 0.f;
                     asm volatile("" : "+v"(pk), "+v"(ss));  // keep these ds_reads (no lds/global pointer select)
