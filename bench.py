@@ -128,6 +128,7 @@ def main():
                     help="q6.10: the reference's ap_fixed<16,6> bit-faithful mode (GIN / GIN-VN only; a fidelity mode, ~10x slower)")
     args = ap.parse_args()
 
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: what RCCL needs on this driver (already exported on the pool)
     import torch
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
