@@ -153,7 +153,7 @@ Model* make_gat_model();
 int read_floats(const char* dir, const char* file, size_t offset_floats, size_t count, float* dst);
 template <typename T>
 int upload(T** dptr, const std::vector<T>& host) {
-    if (*dptr) { hipFree(*dptr); *dptr = nullptr; }
+    if (*dptr) { (void)hipFree(*dptr); *dptr = nullptr; }
     FG_HIP_TRY(hipMalloc((void**)dptr, sizeof(T) * (host.empty() ? 1 : host.size())));
     if (!host.empty()) FG_HIP_TRY(hipMemcpy(*dptr, host.data(), sizeof(T) * host.size(), hipMemcpyHostToDevice));
     return 0;

@@ -228,13 +228,13 @@ struct GrowBuf {
     size_t cap = 0;
     int reserve(size_t n) {
         if (n <= cap) return 0;
-        if (p) hipFree(p);
+        if (p) (void)hipFree(p);
         p = nullptr; cap = 0;
         FG_HIP_TRY(hipMalloc((void**)&p, n * sizeof(float)));
         cap = n;
         return 0;
     }
-    void release() { if (p) hipFree(p); p = nullptr; cap = 0; }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
 };
 
 struct GrowBufI {
@@ -242,13 +242,13 @@ struct GrowBufI {
     size_t cap = 0;
     int reserve(size_t n) {
         if (n <= cap) return 0;
-        if (p) hipFree(p);
+        if (p) (void)hipFree(p);
         p = nullptr; cap = 0;
         FG_HIP_TRY(hipMalloc((void**)&p, n * sizeof(int)));
         cap = n;
         return 0;
     }
-    void release() { if (p) hipFree(p); p = nullptr; cap = 0; }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
 };
 
 // Graph-aligned tiles for the tiled kernels: tile t starts at the first row of the graph that contains row t * nominal if

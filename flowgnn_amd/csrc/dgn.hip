@@ -290,10 +290,10 @@ private:
     void free_all() {
         float** ptrs[] = {&d_emb_, &d_wf_, &d_wt_, &d_bp_, &d_w0_, &d_b0_, &d_w1_, &d_b1_, &d_w2_, &d_b2_};
         for (auto p : ptrs)
-            if (*p) { hipFree(*p); *p = nullptr; }
+            if (*p) { (void)hipFree(*p); *p = nullptr; }
         esc_.release();
         tiles_.release();
-        if (d_split_) { hipFree(d_split_); d_split_ = nullptr; }
+        if (d_split_) { (void)hipFree(d_split_); d_split_ = nullptr; }
     }
     bool ready_ = false;
     GrowBufI tiles_;  // graph-aligned tile starts of the resident batch (tile_bounds_kernel)

@@ -39,8 +39,8 @@ int read_floats(const char* dir, const char* file, size_t offset_floats, size_t 
 
 // ------------------------------------------------------------------ profiler
 Profiler::~Profiler() {
-    for (auto& p : pending_) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
-    for (auto e : free_) hipEventDestroy(e);
+    for (auto& p : pending_) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
+    for (auto e : free_) (void)hipEventDestroy(e);
 }
 int Profiler::slot(const char* name) {
     for (size_t i = 0; i < names.size(); i++)
@@ -52,18 +52,18 @@ int Profiler::slot(const char* name) {
 }
 hipEvent_t Profiler::get_event() {
     if (!free_.empty()) { hipEvent_t e = free_.back(); free_.pop_back(); return e; }
-    hipEvent_t e;
-    hipEventCreate(&e);
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);  // a failure shows up as an invalid-handle error at the first record, reported by flowgnn_run
     return e;
 }
 void Profiler::begin(int slot, hipStream_t s) {
     Pending p{slot, get_event(), get_event()};
-    hipEventRecord(p.a, s);
+    (void)hipEventRecord(p.a, s);
     pending_.push_back(p);
 }
 void Profiler::end(int slot, hipStream_t s) {
     for (size_t i = pending_.size(); i-- > 0;)
-        if (pending_[i].slot == slot) { hipEventRecord(pending_[i].b, s); break; }
+        if (pending_[i].slot == slot) { (void)hipEventRecord(pending_[i].b, s); break; }
 }
 void Profiler::collect() {
     for (auto& p : pending_) {
@@ -118,7 +118,7 @@ struct flowgnn_engine {
         void* ptrs[] = {d_nn, d_ne, d_noff, d_eoff, d_nf, d_el, d_ea, d_eig, d_rowptr, d_src, d_eid, d_outdeg, d_gsrc,
                         d_gdst, d_cursor, d_tmp, d_bsums, d_ecode, d_h0, d_h1, d_scratch, d_out};
         for (void* p : ptrs)
-            if (p) hipFree(p);
+            if (p) (void)hipFree(p);
         d_nn = d_ne = d_noff = d_eoff = d_nf = d_el = d_ea = nullptr;
         d_eig = nullptr;
         d_rowptr = d_src = d_eid = d_outdeg = d_gsrc = d_gdst = d_cursor = d_tmp = d_bsums = nullptr;
@@ -179,12 +179,13 @@ int flowgnn_create(int model, int device_id, flowgnn_engine** out) {
 
 int flowgnn_destroy(flowgnn_engine* e) {
     if (!e) return FLOWGNN_ERR_ARG;
-    hipSetDevice(e->device);
-    if (e->stream) hipStreamSynchronize(e->stream);
+    // best-effort teardown: nothing useful can be done with an error here
+    (void)hipSetDevice(e->device);
+    if (e->stream) (void)hipStreamSynchronize(e->stream);
     e->free_batch();
-    if (e->d_err) hipFree(e->d_err);
+    if (e->d_err) (void)hipFree(e->d_err);
     delete e->model;
-    if (e->stream) hipStreamDestroy(e->stream);
+    if (e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
     return FLOWGNN_OK;
 }
@@ -204,7 +205,7 @@ int flowgnn_set_weights_gin(flowgnn_engine* e, const float* node_embedding_weigh
     for (auto p : t)
         if (!p) return FLOWGNN_ERR_ARG;
     ENGINE_TRY(e, use_device(e));
-    if (e->stream) hipStreamSynchronize(e->stream);
+    if (e->stream) FG_HIP_TRY(hipStreamSynchronize(e->stream));
     ENGINE_TRY(e, e->model->set_weights(t));
     return FLOWGNN_OK;
 }
@@ -214,7 +215,7 @@ int flowgnn_set_weights(flowgnn_engine* e, int count, const float* const* tensor
     for (int i = 0; i < count; i++)
         if (!tensors[i]) return FLOWGNN_ERR_ARG;
     ENGINE_TRY(e, use_device(e));
-    if (e->stream) hipStreamSynchronize(e->stream);
+    if (e->stream) FG_HIP_TRY(hipStreamSynchronize(e->stream));
     ENGINE_TRY(e, e->model->set_weights(tensors));
     return FLOWGNN_OK;
 }
@@ -222,7 +223,7 @@ int flowgnn_set_weights(flowgnn_engine* e, int count, const float* const* tensor
 int flowgnn_load_weights_dir(flowgnn_engine* e, const char* dir) {
     if (!e || !dir) return FLOWGNN_ERR_ARG;
     ENGINE_TRY(e, use_device(e));
-    if (e->stream) hipStreamSynchronize(e->stream);
+    if (e->stream) FG_HIP_TRY(hipStreamSynchronize(e->stream));
     ENGINE_TRY(e, e->model->load_weights_dir(dir));
     return FLOWGNN_OK;
 }
@@ -294,7 +295,7 @@ int flowgnn_set_batch(flowgnn_engine* e, int num_graphs, const int* nums_of_node
     if (eig && N > 0 && !node_eigen) return FLOWGNN_ERR_ARG;
 
     ENGINE_TRY(e, use_device(e));
-    if (e->stream) hipStreamSynchronize(e->stream);
+    if (e->stream) FG_HIP_TRY(hipStreamSynchronize(e->stream));
     e->batch_ready = false;
     e->ran = false;
     ENGINE_TRY(e, alloc_batch(e, (size_t)num_graphs, (size_t)N, (size_t)E, attr, eig));
@@ -432,7 +433,7 @@ int flowgnn_set_results_buffer(flowgnn_engine* e, void* device_ptr) {
     if (!e) return FLOWGNN_ERR_ARG;
     if (!e->batch_ready) return FLOWGNN_ERR_STATE;
     ENGINE_TRY(e, use_device(e));
-    hipStreamSynchronize(e->stream);
+    FG_HIP_TRY(hipStreamSynchronize(e->stream));
     e->db.out = device_ptr ? (float*)device_ptr : e->d_out;
     return FLOWGNN_OK;
 }
@@ -500,7 +501,7 @@ int flowgnn_get_h(flowgnn_engine* e, float* h_host, int* dim) {
 int flowgnn_profile_enable(flowgnn_engine* e, int on) {
     if (!e) return FLOWGNN_ERR_ARG;
     ENGINE_TRY(e, use_device(e));
-    hipStreamSynchronize(e->stream);
+    FG_HIP_TRY(hipStreamSynchronize(e->stream));
     e->prof.reset();
     e->prof.enabled = on != 0;
     return FLOWGNN_OK;
@@ -509,7 +510,7 @@ int flowgnn_profile_enable(flowgnn_engine* e, int on) {
 int flowgnn_profile_read(flowgnn_engine* e, int* count, const char** names, double* total_ms, long long* launches) {
     if (!e || !count) return FLOWGNN_ERR_ARG;
     ENGINE_TRY(e, use_device(e));
-    hipStreamSynchronize(e->stream);
+    FG_HIP_TRY(hipStreamSynchronize(e->stream));
     e->prof.collect();
     int n = (int)e->prof.names.size();
     if (n > FLOWGNN_MAX_PROFILE_SLOTS) n = FLOWGNN_MAX_PROFILE_SLOTS;
@@ -537,8 +538,8 @@ int flowgnn_run_aggregation_only(flowgnn_engine* e, int layer, int iters, float*
     FG_HIP_TRY(hipEventSynchronize(b));
     float ms = 0.f;
     FG_HIP_TRY(hipEventElapsedTime(&ms, a, b));
-    hipEventDestroy(a);
-    hipEventDestroy(b);
+    (void)hipEventDestroy(a);
+    (void)hipEventDestroy(b);
     if (avg_ms) *avg_ms = ms / iters;
     return FLOWGNN_OK;
 }

@@ -417,7 +417,7 @@ private:
     void free_all() {
         float** ptrs[] = {&d_lin0_, &d_asrc_, &d_atgt_, &d_wskip_, &d_wlin_, &d_pw_, &d_pb_};
         for (auto p : ptrs)
-            if (*p) { hipFree(*p); *p = nullptr; }
+            if (*p) { (void)hipFree(*p); *p = nullptr; }
     }
     bool ready_ = false;
     float *d_lin0_ = nullptr, *d_asrc_ = nullptr, *d_atgt_ = nullptr, *d_wskip_ = nullptr, *d_wlin_ = nullptr, *d_pw_ = nullptr,

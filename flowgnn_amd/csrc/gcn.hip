@@ -498,8 +498,8 @@ private:
     void free_all() {
         float** ptrs[] = {&d_nemb_, &d_pw_, &d_pb_, &d_ecomb_, &d_ep_, &d_wf_, &d_wt_, &d_bp_};
         for (auto p : ptrs)
-            if (*p) { hipFree(*p); *p = nullptr; }
-        if (d_split_) { hipFree(d_split_); d_split_ = nullptr; }
+            if (*p) { (void)hipFree(*p); *p = nullptr; }
+        if (d_split_) { (void)hipFree(d_split_); d_split_ = nullptr; }
         esc_.release();
         tiles_.release();
     }

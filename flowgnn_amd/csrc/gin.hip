@@ -775,8 +775,8 @@ private:
     void free_all() {
         float** ptrs[] = {&d_chunks_, &d_nemb_, &d_pw_, &d_pb_, &d_ecomb_, &d_w1f_, &d_w1tail_, &d_b1p_, &d_w2f_, &d_b2p_};
         for (auto p : ptrs)
-            if (*p) { hipFree(*p); *p = nullptr; }
-        if (d_split_) { hipFree(d_split_); d_split_ = nullptr; }
+            if (*p) { (void)hipFree(*p); *p = nullptr; }
+        if (d_split_) { (void)hipFree(d_split_); d_split_ = nullptr; }
         qw_.release();
     }
     bool ready_ = false;

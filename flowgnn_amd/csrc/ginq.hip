@@ -189,7 +189,7 @@ int16_t q16_from_float(float x) {
 void GinQWeights::release() {
     int16_t** ptrs[] = {&nemb, &ecomb, &w1, &b1, &w2, &b2, &pw, &pb};
     for (auto p : ptrs)
-        if (*p) { hipFree(*p); *p = nullptr; }
+        if (*p) { (void)hipFree(*p); *p = nullptr; }
 }
 
 int ginq_upload(GinQWeights& q, const float* nemb, const float* eemb, const float* w1, const float* b1, const float* w2, const float* b2,

@@ -99,7 +99,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_add_kernel(int* __restrict_
 // in-place exclusive scan of data[0..n), total written to data[n]
 static void exclusive_scan_inplace(int* data, int n, int* block_sums, hipStream_t s) {
     if (n <= 0) {
-        hipMemsetAsync(data, 0, sizeof(int), s);
+        (void)hipMemsetAsync(data, 0, sizeof(int), s);  // (errors of the async calls surface in flowgnn_run's hipGetLastError)
         return;
     }
     int nblocks = (n + SCAN_TILE - 1) / SCAN_TILE;
@@ -292,9 +292,9 @@ void launch_build_csr(const BatchView& b, const CsrView& c, bool has_edge_attr, 
     // c.tmp holds [E] edge codes (first half) and [E] slot->edge map (second half): sized 2E by the engine
     int* code_by_edge = c.tmp;
     int* slot_edge = c.tmp + b.e_tot;
-    hipMemsetAsync(c.row_ptr, 0, sizeof(int) * ((size_t)b.n_tot + 1), s);
-    hipMemsetAsync(c.out_deg, 0, sizeof(int) * (size_t)b.n_tot, s);
-    hipMemsetAsync(c.cursor, 0, sizeof(int) * (size_t)b.n_tot, s);
+    (void)hipMemsetAsync(c.row_ptr, 0, sizeof(int) * ((size_t)b.n_tot + 1), s);
+    (void)hipMemsetAsync(c.out_deg, 0, sizeof(int) * (size_t)b.n_tot, s);
+    (void)hipMemsetAsync(c.cursor, 0, sizeof(int) * (size_t)b.n_tot, s);
     if (b.num_graphs > 0)
         globalize_count_kernel<<<(b.num_graphs + 3) / 4, 256, 0, s>>>(b, c, has_edge_attr);
     exclusive_scan_inplace(c.row_ptr, b.n_tot, c.block_sums, s);

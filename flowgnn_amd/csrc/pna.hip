@@ -397,8 +397,8 @@ private:
     void free_all() {
         float** ptrs[] = {&d_nemb_, &d_wf_, &d_cb_, &d_w1_, &d_b1_, &d_w2_, &d_b2_, &d_w3_, &d_b3_};
         for (auto p : ptrs)
-            if (*p) { hipFree(*p); *p = nullptr; }
-        if (d_split_) { hipFree(d_split_); d_split_ = nullptr; }
+            if (*p) { (void)hipFree(*p); *p = nullptr; }
+        if (d_split_) { (void)hipFree(d_split_); d_split_ = nullptr; }
         tiles_.release();
     }
     bool ready_ = false;
