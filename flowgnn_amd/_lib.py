@@ -43,6 +43,8 @@ def _declare(lib):
     lib.flowgnn_stream.argtypes = [eng, C.POINTER(C.c_void_p)]
     lib.flowgnn_batch_info.argtypes = [eng] + [C.POINTER(C.c_longlong)] * 3
     lib.flowgnn_exact_reruns.argtypes = [eng]
+    lib.flowgnn_graph_replays.argtypes = [eng]
+    lib.flowgnn_graph_replays.restype = C.c_longlong
     lib.flowgnn_set_numeric_mode.argtypes = [eng, C.c_int]
     lib.flowgnn_get_csr.argtypes = [eng, p_int, p_int, p_int, p_int]
     lib.flowgnn_get_h.argtypes = [eng, p_float, p_int]

@@ -114,6 +114,27 @@ struct flowgnn_engine {
     bool has_attr = false, has_eig = false;
     DeviceBatch db{};
 
+    // hipGraph replay of the launch sequence (index build + forward), opt-in (FLOWGNN_HIPGRAPH=1; 2 = batches of any size).
+    // Measured on this runtime it does not pay: asynchronous launches already pipeline, and a replay of the dozen kernels
+    // of a step is 1-4 % SLOWER than launching them (4 113 molhiv graphs: 0.267 ms plain, 0.271 ms replayed; 512 graphs:
+    // 0.099 vs 0.103 ms) -- so it is off by default and kept for hosts whose launch path is the bottleneck.
+    // The first run of a batch is plain (models size their scratch buffers there), the second is captured, later ones
+    // replay.  Every call that changes what the captured kernels would read or write drops the recording.
+    hipGraphExec_t gexec = nullptr;
+    bool graph_ok = false;
+    bool graph_h_valid = true;   // what the captured forward left in db.h_valid / tap / tap_dim / final_h (host-side outputs)
+    const float* graph_tap = nullptr;
+    int graph_tap_dim = 0, graph_final_h = 0;
+    int plain_runs = 0;
+    int graph_mode = getenv("FLOWGNN_HIPGRAPH") ? atoi(getenv("FLOWGNN_HIPGRAPH")) : 0;
+    long long graph_replays = 0;
+    void drop_graph() {
+        if (gexec) (void)hipGraphExecDestroy(gexec);
+        gexec = nullptr;
+        graph_ok = false;
+        plain_runs = 0;
+    }
+
     void free_batch() {
         void* ptrs[] = {d_nn, d_ne, d_noff, d_eoff, d_nf, d_el, d_ea, d_eig, d_rowptr, d_src, d_eid, d_outdeg, d_gsrc,
                         d_gdst, d_cursor, d_tmp, d_bsums, d_ecode, d_h0, d_h1, d_scratch, d_out};
@@ -182,6 +203,7 @@ int flowgnn_destroy(flowgnn_engine* e) {
     // best-effort teardown: nothing useful can be done with an error here
     (void)hipSetDevice(e->device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
+    e->drop_graph();
     e->free_batch();
     if (e->d_err) (void)hipFree(e->d_err);
     delete e->model;
@@ -205,6 +227,7 @@ int flowgnn_set_weights_gin(flowgnn_engine* e, const float* node_embedding_weigh
     for (auto p : t)
         if (!p) return FLOWGNN_ERR_ARG;
     ENGINE_TRY(e, use_device(e));
+    e->drop_graph();
     if (e->stream) FG_HIP_TRY(hipStreamSynchronize(e->stream));
     ENGINE_TRY(e, e->model->set_weights(t));
     return FLOWGNN_OK;
@@ -215,6 +238,7 @@ int flowgnn_set_weights(flowgnn_engine* e, int count, const float* const* tensor
     for (int i = 0; i < count; i++)
         if (!tensors[i]) return FLOWGNN_ERR_ARG;
     ENGINE_TRY(e, use_device(e));
+    e->drop_graph();
     if (e->stream) FG_HIP_TRY(hipStreamSynchronize(e->stream));
     ENGINE_TRY(e, e->model->set_weights(tensors));
     return FLOWGNN_OK;
@@ -223,6 +247,7 @@ int flowgnn_set_weights(flowgnn_engine* e, int count, const float* const* tensor
 int flowgnn_load_weights_dir(flowgnn_engine* e, const char* dir) {
     if (!e || !dir) return FLOWGNN_ERR_ARG;
     ENGINE_TRY(e, use_device(e));
+    e->drop_graph();
     if (e->stream) FG_HIP_TRY(hipStreamSynchronize(e->stream));
     ENGINE_TRY(e, e->model->load_weights_dir(dir));
     return FLOWGNN_OK;
@@ -295,6 +320,7 @@ int flowgnn_set_batch(flowgnn_engine* e, int num_graphs, const int* nums_of_node
     if (eig && N > 0 && !node_eigen) return FLOWGNN_ERR_ARG;
 
     ENGINE_TRY(e, use_device(e));
+    e->drop_graph();
     if (e->stream) FG_HIP_TRY(hipStreamSynchronize(e->stream));
     e->batch_ready = false;
     e->ran = false;
@@ -345,6 +371,27 @@ int flowgnn_run(flowgnn_engine* e) {
     }
     ENGINE_TRY(e, use_device(e));
     if (e->G == 0) { e->ran = true; return FLOWGNN_OK; }
+    const bool want_graph = e->graph_mode != 0 && !e->prof.enabled && (e->graph_mode > 1 || e->N <= (1ll << 20));
+    if (want_graph && e->graph_ok) {
+        e->db.tap = e->graph_tap;
+        e->db.tap_dim = e->graph_tap_dim;
+        e->db.final_h = e->graph_final_h;
+        e->db.h_valid = e->graph_h_valid;
+        FG_HIP_TRY(hipGraphLaunch(e->gexec, e->stream));
+        e->graph_replays++;
+        e->ran = true;
+        return FLOWGNN_OK;
+    }
+    const bool capture = want_graph && e->plain_runs >= 1;
+    if (capture) {
+        hipError_t hc = hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal);
+        if (hc != hipSuccess) {
+            (void)hipGetLastError();
+            e->graph_mode = 0;  // this runtime cannot capture: stay on plain launches
+            return flowgnn_run(e);
+        }
+    }
+    int frc = FLOWGNN_OK;
     {
         ProfScope p(e->prof, "build_csr", e->stream);
         const bool flat = getenv("FLOWGNN_CSR_FLAT") && atoi(getenv("FLOWGNN_CSR_FLAT")) != 0;  // A/B: force the global path
@@ -354,13 +401,39 @@ int flowgnn_run(flowgnn_engine* e) {
     e->db.tap_dim = 0;
     e->db.h_valid = true;
     e->model->set_exact(e->force_exact);
-    ENGINE_TRY(e, e->model->forward(e->db, e->prof, e->stream));
+    frc = e->model->forward(e->db, e->prof, e->stream);
+    if (capture) {
+        hipGraph_t g = nullptr;
+        hipError_t hc = hipStreamEndCapture(e->stream, &g);
+        if (hc == hipSuccess && frc == FLOWGNN_OK && g) hc = hipGraphInstantiate(&e->gexec, g, nullptr, nullptr, 0);
+        if (g) (void)hipGraphDestroy(g);
+        if (hc != hipSuccess || frc != FLOWGNN_OK || !e->gexec) {
+            (void)hipGetLastError();
+            e->drop_graph();
+            e->graph_mode = 0;  // something in this model's forward is not capturable: plain launches from now on
+            return flowgnn_run(e);
+        }
+        e->graph_ok = true;
+        e->graph_h_valid = e->db.h_valid;
+        e->graph_tap = e->db.tap;
+        e->graph_tap_dim = e->db.tap_dim;
+        e->graph_final_h = e->db.final_h;
+        FG_HIP_TRY(hipGraphLaunch(e->gexec, e->stream));  // the capture only recorded: this is the run itself
+        e->graph_replays++;
+        e->ran = true;
+        return FLOWGNN_OK;
+    }
+    if (frc != FLOWGNN_OK) {
+        e->err = fg::last_error_text();
+        return frc;
+    }
     hipError_t he = hipGetLastError();
     if (he != hipSuccess) {
         set_hip_error("kernel launch", he, __FILE__, __LINE__);
         e->err = fg::last_error_text();
         return FLOWGNN_ERR_HIP;
     }
+    e->plain_runs++;
     e->ran = true;
     return FLOWGNN_OK;
 }
@@ -388,6 +461,7 @@ int flowgnn_sync(flowgnn_engine* e) {
         // kernels, and keep this batch on them for later runs
         e->force_exact = true;
         e->exact_reruns++;
+        e->drop_graph();  // the captured launches are the split-f16 ones
         FG_HIP_TRY(hipMemsetAsync(e->d_err + 1, 0, sizeof(int), e->stream));
         e->model->set_exact(true);
         ENGINE_TRY(e, e->model->forward(e->db, e->prof, e->stream));
@@ -433,6 +507,7 @@ int flowgnn_set_results_buffer(flowgnn_engine* e, void* device_ptr) {
     if (!e) return FLOWGNN_ERR_ARG;
     if (!e->batch_ready) return FLOWGNN_ERR_STATE;
     ENGINE_TRY(e, use_device(e));
+    e->drop_graph();
     FG_HIP_TRY(hipStreamSynchronize(e->stream));
     e->db.out = device_ptr ? (float*)device_ptr : e->d_out;
     return FLOWGNN_OK;
@@ -454,8 +529,11 @@ int flowgnn_batch_info(const flowgnn_engine* e, long long* num_graphs, long long
 
 int flowgnn_exact_reruns(const flowgnn_engine* e) { return e ? e->exact_reruns : -1; }
 
+long long flowgnn_graph_replays(const flowgnn_engine* e) { return e ? e->graph_replays : -1; }
+
 int flowgnn_set_numeric_mode(flowgnn_engine* e, int mode) {
     if (!e) return FLOWGNN_ERR_ARG;
+    e->drop_graph();
     const int rc = e->model->set_numeric_mode(mode);
     if (rc) e->err = "flowgnn_set_numeric_mode: this model has no such mode (Q6.10 exists for GIN / GIN-VN)";
     return rc;
@@ -527,6 +605,7 @@ int flowgnn_run_aggregation_only(flowgnn_engine* e, int layer, int iters, float*
     if (!e || iters <= 0) return FLOWGNN_ERR_ARG;
     if (!e->ran) { e->err = "flowgnn_run_aggregation_only needs a prior flowgnn_run"; return FLOWGNN_ERR_STATE; }
     ENGINE_TRY(e, use_device(e));
+    e->drop_graph();
     hipEvent_t a, b;
     FG_HIP_TRY(hipEventCreate(&a));
     FG_HIP_TRY(hipEventCreate(&b));

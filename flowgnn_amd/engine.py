@@ -122,6 +122,10 @@ class Engine:
         """Forward passes repeated on the exact-fp32 kernels (flowgnn.h: flowgnn_exact_reruns)."""
         return int(self.lib.flowgnn_exact_reruns(self._h))
 
+    def graph_replays(self) -> int:
+        """Runs that were hipGraph replays of the recorded launch sequence (flowgnn.h: flowgnn_graph_replays)."""
+        return int(self.lib.flowgnn_graph_replays(self._h))
+
     def csr(self):
         n, e = self.total_nodes, self.total_edges
         row_ptr = np.empty(n + 1, dtype=np.int32)

@@ -227,6 +227,16 @@ int flowgnn_batch_info(const flowgnn_engine* e, long long* num_graphs,
 int flowgnn_exact_reruns(const flowgnn_engine* e);
 
 /*
+ * Launch-sequence replay (opt-in: FLOWGNN_HIPGRAPH=1 for resident batches of up to 2^20 nodes, 2 for any size).
+ * flowgnn_run then records its launch sequence (index build + forward pass) into a hipGraph on the second run of a
+ * batch and replays it afterwards; any call that changes what the kernels read or write (weights, batch, result
+ * buffer, numeric mode, an exact-fp32 re-run) drops the recording, and runs with the profiler enabled are never
+ * replays.  Off by default: on the measured runtime plain asynchronous launches are as fast.
+ * Returns how many runs of this engine were replays (-1 for a null handle).
+ */
+long long flowgnn_graph_replays(const flowgnn_engine* e);
+
+/*
  * Numeric mode of the engine.  FLOWGNN_NUMERIC_F32 (default): fp32 storage and accumulation.
  * FLOWGNN_NUMERIC_Q6_10: every value is the reference's ap_fixed<16,6> bit pattern
  * (GIN/src/dcl.h:58-59: 10 fractional bits, truncation toward -inf, wrap on overflow), weights
