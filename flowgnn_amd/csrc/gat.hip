@@ -27,40 +27,75 @@ constexpr int GAT_H = 4;
 constexpr int GAT_F = GAT_D * GAT_H;  // 64
 constexpr int GAT_L = 5;
 
-// lane = (node, dim): proj_0, skip_0 and the layer-0 scores
-__global__ __launch_bounds__(256) void gat_encoder_kernel(const int* __restrict__ node_feature,
-                                                           const int* __restrict__ feat_row,  // null = identity
-                                                           const float* __restrict__ lin0,    // [16 dim][9][4 head]
-                                                           const float* __restrict__ a_src,   // [16 dim][4 head] of layer 0
-                                                           const float* __restrict__ a_tgt, float* __restrict__ proj,
-                                                           float* __restrict__ skipin, float* __restrict__ scores, int n_tot) {
-    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    const long long v = i >> 4;
-    const int d = (int)(i & 15);
-    const bool valid = v < n_tot;
-    const long long vv = valid ? v : n_tot - 1;
-    const long long row = feat_row ? feat_row[vv] : vv;
+// Layer 0 has no stored projection: proj_0[v][d][h] = sum_k feat_k(v) W_lin0[d][k][h] is 9 multiply-adds per value from the
+// 36-byte integer feature row (load_inputs.cc:184-201), so the first layer kernel computes it for the rows of its tile
+// straight into LDS (and for the rare neighbour outside the tile on the fly) instead of reading 256-byte rows an encoder
+// kernel would have written: one launch and a 1.9 GB write + read less per pass.
+// proj_0 of (row, dim) from the row's nine features, heads in the float4
+__device__ __forceinline__ float4 gat_proj0(const int* f, const float4* lin0_d) {
     float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int k = 0; k < ND_FEATURE; k++) {
-        const float f = (float)node_feature[(size_t)row * ND_FEATURE + k];
-        const float4 w = reinterpret_cast<const float4*>(lin0)[d * ND_FEATURE + k];
-        p.x += f * w.x; p.y += f * w.y; p.z += f * w.z; p.w += f * w.w;
+        const float fk = (float)f[k];
+        const float4 w = lin0_d[k];
+        p.x += fk * w.x; p.y += fk * w.y; p.z += fk * w.z; p.w += fk * w.w;
     }
-    const float4 as = reinterpret_cast<const float4*>(a_src)[d], at = reinterpret_cast<const float4*>(a_tgt)[d];
-    float4 ss = make_float4(p.x * as.x, p.y * as.y, p.z * as.z, p.w * as.w);
-    float4 st = make_float4(p.x * at.x, p.y * at.y, p.z * at.z, p.w * at.w);
+    return p;
+}
+
+// scores of layer 0: sum over the 16 dims in ascending order, the same code in the tile pass and in the rare path below, so a
+// node's scores do not depend on which tile reads them
+__device__ __forceinline__ void gat_score_acc(float4& s, const float4& pd, const float4& a) {
+    s.x += pd.x * a.x; s.y += pd.y * a.y; s.z += pd.z * a.z; s.w += pd.w * a.w;
+}
+
+// A neighbour u outside the tile (layer 0): this lane's four projection rows from u's raw features (its scores come from
+// the pre-pass below, like every other node's).
+__device__ __forceinline__ void gat_layer0_rare(const int* __restrict__ node_feature, long long row, int g, const float4* s_lin0,
+                                                float4 (&p)[4]) {
+    // the 36-byte feature row in ONE round trip (three loads, one wait; nine self-waiting loads would be nine round trips)
+    typedef int int4v __attribute__((ext_vector_type(4)));
+    int4v fa, fb;
+    int fc;
+    const int* fp = node_feature + (size_t)row * ND_FEATURE;
+    asm volatile("global_load_dwordx4 %0, %3, off\n\tglobal_load_dwordx4 %1, %3, off offset:16\n\tglobal_load_dword %2, %3, off offset:32\n\t"
+                 "s_waitcnt vmcnt(0)"
+                 : "=&v"(fa), "=&v"(fb), "=&v"(fc)
+                 : "v"(fp)
+                 : "memory");
+    static_assert(ND_FEATURE == 9, "feature row = 4 + 4 + 1 words");
+    const int f[ND_FEATURE] = {fa.x, fa.y, fa.z, fa.w, fb.x, fb.y, fb.z, fb.w, fc};
+#pragma unroll 1
+    for (int t = 0; t < 4; t++) {  // rolled on purpose: this is the rare path, it must not cost the common one registers
+        const float4 pd = gat_proj0(f, s_lin0 + (4 * t + g) * ND_FEATURE);
+        if (t == 0) p[0] = pd;
+        else if (t == 1) p[1] = pd;
+        else if (t == 2) p[2] = pd;
+        else p[3] = pd;
+    }
+}
+
+// Layer-0 attention scores of every node (32 B per node from its 36-byte feature row): ssrc[v][h] = sum_d proj_0[v][d][h]
+// a_src[0][h][d], stgt likewise (load_inputs.cc:203-224), dims in ascending order.  A thread per node; the weights are
+// wave-uniform (scalar loads).
+__global__ __launch_bounds__(256) void gat_scores0_kernel(const int* __restrict__ node_feature, const int* __restrict__ feat_row,
+                                                           const float* __restrict__ lin0, const float* __restrict__ a_src,
+                                                           const float* __restrict__ a_tgt, float* __restrict__ scores, int n_tot) {
+    const long long v = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (v >= n_tot) return;
+    const long long row = feat_row ? feat_row[v] : v;
+    int f[ND_FEATURE];
 #pragma unroll
-    for (int m = 1; m < 16; m <<= 1) {
-        ss.x += __shfl_xor(ss.x, m, 64); ss.y += __shfl_xor(ss.y, m, 64); ss.z += __shfl_xor(ss.z, m, 64); ss.w += __shfl_xor(ss.w, m, 64);
-        st.x += __shfl_xor(st.x, m, 64); st.y += __shfl_xor(st.y, m, 64); st.z += __shfl_xor(st.z, m, 64); st.w += __shfl_xor(st.w, m, 64);
+    for (int k = 0; k < ND_FEATURE; k++) f[k] = node_feature[(size_t)row * ND_FEATURE + k];
+    float4 ss = make_float4(0.f, 0.f, 0.f, 0.f), st = ss;
+#pragma unroll
+    for (int d = 0; d < GAT_D; d++) {
+        const float4 pd = gat_proj0(f, reinterpret_cast<const float4*>(lin0) + d * ND_FEATURE);
+        gat_score_acc(ss, pd, reinterpret_cast<const float4*>(a_src)[d]);
+        gat_score_acc(st, pd, reinterpret_cast<const float4*>(a_tgt)[d]);
     }
-    if (!valid) return;
-    reinterpret_cast<float4*>(proj)[i] = p;
-    if (d == 0) {
-        reinterpret_cast<float4*>(scores)[v * 2 + 0] = ss;
-        reinterpret_cast<float4*>(scores)[v * 2 + 1] = st;
-    }
+    reinterpret_cast<float4*>(scores)[v * 2 + 0] = ss;
+    reinterpret_cast<float4*>(scores)[v * 2 + 1] = st;
 }
 
 // local node index per node (reference quirk mode: every graph reads the first rows of the batch)
@@ -87,20 +122,36 @@ struct GatLayerDev {
 // from L2 by every wave (13.7 GB per launch at 2^18 molhiv graphs), and the CSR entry of the next in-edge is requested one
 // trip ahead.  68 KB of LDS: two workgroups per CU.
 constexpr int GAT_TR = 128;
+struct GatLayer0Dev {
+    const float* lin0;   // [16 dim][9][4 head]
+    const float* a_src;  // [16 dim][4 head] of layer 0
+    const float* a_tgt;
+};
+
 template <bool FINAL, bool FIRST>
-__global__ __launch_bounds__(512) void gat_layer_kernel(const float* __restrict__ proj, const float* __restrict__ skipin,
+__global__ __launch_bounds__(512, 4) void gat_layer_kernel(const float* __restrict__ proj, const float* __restrict__ skipin,
                                                          const float* __restrict__ scores, float* __restrict__ proj_out,
                                                          float* __restrict__ skip_out, float* __restrict__ scores_out,
                                                          float* __restrict__ emb_out, const int* __restrict__ row_ptr,
                                                          const int* __restrict__ src, GatLayerDev w, int n_tot,
-                                                         const int* __restrict__ node_feature, const int* __restrict__ feat_row) {
+                                                         const int* __restrict__ node_feature, const int* __restrict__ feat_row,
+                                                         GatLayer0Dev w0, const float* __restrict__ pool_w) {
     __shared__ __attribute__((aligned(16))) float4 s_wskip[16 * 64];
     __shared__ __attribute__((aligned(16))) float4 s_wlin[FINAL ? 1 : 16 * 64];
+    // Staged projections, 256 B per row.  With rows stored as they are in memory every row starts in the same LDS banks and
+    // the gather -- 16 node lanes reading the same 16-byte column of 16 different rows -- is a 16-way bank conflict.  So row r
+    // is stored rotated by r columns (column c at slot (c + r) mod 16); LDS-DMA allows it because every lane supplies its own
+    // global address while the LDS side stays lane-linear.
     __shared__ __attribute__((aligned(16))) float4 s_proj[GAT_TR * 16];
     __shared__ __attribute__((aligned(16))) float4 s_sc[GAT_TR * 2];
+    __shared__ __attribute__((aligned(16))) float4 s_lin0[FIRST ? GAT_D * ND_FEATURE : 1];
+    __shared__ int s_feat[FIRST ? GAT_TR * ND_FEATURE : 1];
     for (int i = threadIdx.x; i < 16 * 64; i += 512) {
         s_wskip[i] = reinterpret_cast<const float4*>(w.wskip)[i];
         if (!FINAL) s_wlin[i] = reinterpret_cast<const float4*>(w.wlin)[i];
+    }
+    if (FIRST) {
+        for (int i = threadIdx.x; i < GAT_D * ND_FEATURE; i += 512) s_lin0[i] = reinterpret_cast<const float4*>(w0.lin0)[i];
     }
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int j = lane & 15, g = lane >> 4;
@@ -108,18 +159,59 @@ __global__ __launch_bounds__(512) void gat_layer_kernel(const float* __restrict_
     const float4* sc4 = reinterpret_cast<const float4*>(scores);
     const int n_tiles = (n_tot + GAT_TR - 1) / GAT_TR;
     const long long proj_last = (long long)n_tot * (GAT_F * 4) - 16, sc_last = (long long)n_tot * 32 - 16;
+    // layer 0: this thread's words of a tile's feature rows (36 B per row; rows past the end repeat the last one)
+    int fpre[3] = {0, 0, 0};
+    auto fetch_features = [&](int t) {
+        if (!FIRST || t >= n_tiles) return;
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const int i = threadIdx.x + 512 * k;
+            if (i < GAT_TR * ND_FEATURE) {
+                long long v = (long long)t * GAT_TR + i / ND_FEATURE;
+                if (v >= n_tot) v = n_tot - 1;
+                const long long row = feat_row ? feat_row[v] : v;
+                fpre[k] = node_feature[(size_t)row * ND_FEATURE + (i % ND_FEATURE)];
+            }
+        }
+    };
+    fetch_features(blockIdx.x);
   for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     const int tbase = tile * GAT_TR;
     __syncthreads();  // the previous tile's rows are no longer read (first time: nothing to wait for)
+    if (FIRST) {
+        // the tile's feature rows (36 B each; rows past the end repeat the last one), then proj_0 and both scores per (row, dim)
+#pragma unroll
+        for (int k = 0; k < 3; k++)
+            if (threadIdx.x + 512 * k < GAT_TR * ND_FEATURE) s_feat[threadIdx.x + 512 * k] = fpre[k];
+        __syncthreads();
+        fetch_features(tile + gridDim.x);  // the next tile's, one tile ahead of their use
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));  // opaque per tile: this lane's dim is the same for every tile, and its nine W_lin0 rows would be kept across the loop
+        {
+            // this lane's dim is the same for its four rows: its nine W_lin0 rows are read once per tile into registers
+            // (36 of them, alive only here) instead of once per value
+            const int d = tid & 15;
+            float4 wl[ND_FEATURE];
+#pragma unroll
+            for (int k = 0; k < ND_FEATURE; k++) wl[k] = s_lin0[d * ND_FEATURE + k];
+#pragma unroll
+            for (int k = 0; k < GAT_TR * GAT_D / 512; k++) {
+                const int r = (tid + 512 * k) >> 4;
+                s_proj[r * 16 + ((d + r) & 15)] = gat_proj0(&s_feat[r * ND_FEATURE], wl);
+            }
+        }
+    } else {
 #pragma unroll
     for (int p = 0; p < 4; p++) {  // 32 pieces of 1 KiB; bytes past the end of the array: its last 16 bytes (rows of no node)
         const int piece = wv + 8 * p;
-        long long off = (long long)tbase * (GAT_F * 4) + piece * 1024 + lane * 16;
+        const int rr = piece * 4 + (lane >> 4);  // row inside the tile that this lane's LDS slot belongs to
+        long long off = (long long)(tbase + rr) * (GAT_F * 4) + (((lane & 15) - rr) & 15) * 16;
         off = off < proj_last ? off : proj_last;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(reinterpret_cast<const char*>(proj) + off),
                                          (__attribute__((address_space(3))) void*)(reinterpret_cast<char*>(s_proj) + piece * 1024), 16, 0, 0);
     }
-    if (wv < 4) {
+    }
+    if (wv < 4) {  // the tile's scores (layer 0: written by gat_scores0_kernel)
         long long off = (long long)tbase * 32 + wv * 1024 + lane * 16;
         off = off < sc_last ? off : sc_last;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(reinterpret_cast<const char*>(scores) + off),
@@ -156,13 +248,17 @@ __global__ __launch_bounds__(512) void gat_layer_kernel(const float* __restrict_
             float4 p[4];
 #pragma unroll
             for (int t = 0; t < 4; t++) {
-                p[t] = s_proj[lr * 16 + 4 * t + g];
+                p[t] = s_proj[lr * 16 + ((4 * t + g + lr) & 15)];
                 asm volatile("" : "+v"(p[t].x), "+v"(p[t].y), "+v"(p[t].z), "+v"(p[t].w));
             }
             if (!in) {
                 st = load_f4_rare(sc4 + (size_t)u * 2 + 1);
+                if (FIRST) {
+                    gat_layer0_rare(node_feature, feat_row ? (long long)load_i32_rare(feat_row + u) : (long long)u, g, s_lin0, p);
+                } else {
 #pragma unroll
-                for (int t = 0; t < 4; t++) p[t] = load_f4_rare(proj4 + (size_t)u * 16 + 4 * t + g);
+                    for (int t = 0; t < 4; t++) p[t] = load_f4_rare(proj4 + (size_t)u * 16 + 4 * t + g);
+                }
             }
             more = e < e_end;
             u = u_nx;
@@ -224,7 +320,16 @@ __global__ __launch_bounds__(512) void gat_layer_kernel(const float* __restrict_
     }
 
     if (FINAL) {
-        if (valid) {
+        if (pool_w != nullptr) {
+            // readout folded in (as in gin_split.hip): the logit is mean_v(emb[v]) . w + b = mean_v(emb[v] . w) + b, so only the
+            // per-node dot product leaves the kernel (emb_out is then a float[n_tot]; 4 B instead of a 64 B row to read back)
+            float part = 0.0f;
+#pragma unroll
+            for (int t = 0; t < 4; t++) part += (acc[t].x + acc[t].y + acc[t].z + acc[t].w) / (float)GAT_H * pool_w[4 * t + g];
+            part += __shfl_xor(part, 16, 64);
+            part += __shfl_xor(part, 32, 64);
+            if (valid && g == 0) emb_out[node] = part;
+        } else if (valid) {
 #pragma unroll
             for (int t = 0; t < 4; t++) emb_out[(size_t)node * GAT_D + 4 * t + g] = (acc[t].x + acc[t].y + acc[t].z + acc[t].w) / (float)GAT_H;
         }
@@ -372,12 +477,12 @@ public:
             feat_row = reinterpret_cast<int*>(db.scratch + (size_t)n * (2 * GAT_F + 16 + GAT_D));
             gat_local_rows_kernel<<<(db.b.num_graphs + 3) / 4, 256, 0, s>>>(db.b.node_off, feat_row, db.b.num_graphs);
         }
+        const GatLayer0Dev w0{d_lin0_, d_asrc_, d_atgt_};
         {
-            ProfScope p(prof, "gat_encoder", s);
-            const long long items = (long long)n * 16;
-            gat_encoder_kernel<<<(int)((items + 255) / 256), 256, 0, s>>>(db.b.node_feature, feat_row, d_lin0_, d_asrc_, d_atgt_,
-                                                                        db.h[0], skipb[0], scoreb[0], n);
+            ProfScope p(prof, "gat_scores0", s);
+            gat_scores0_kernel<<<(n + 255) / 256, 256, 0, s>>>(db.b.node_feature, feat_row, d_lin0_, d_asrc_, d_atgt_, scoreb[0], n);
         }
+        const bool fold = fold_readout_;
         int cur = 0;
         for (int l = 0; l < GAT_L; l++) {
             GatLayerDev w;
@@ -391,15 +496,16 @@ public:
             if (l == 0) {
                 gat_layer_kernel<false, true><<<layer_grid, 512, 0, s>>>(db.h[cur], skipb[cur], scoreb[cur], db.h[cur ^ 1], skipb[cur ^ 1],
                                                                         scoreb[cur ^ 1], emb, db.csr.row_ptr, db.csr.src, w, n,
-                                                                        db.b.node_feature, feat_row);
+                                                                        db.b.node_feature, feat_row, w0, nullptr);
                 cur ^= 1;
             } else if (l < GAT_L - 1) {
                 gat_layer_kernel<false, false><<<layer_grid, 512, 0, s>>>(db.h[cur], skipb[cur], scoreb[cur], db.h[cur ^ 1], skipb[cur ^ 1],
-                                                                         scoreb[cur ^ 1], emb, db.csr.row_ptr, db.csr.src, w, n, nullptr, nullptr);
+                                                                         scoreb[cur ^ 1], emb, db.csr.row_ptr, db.csr.src, w, n, nullptr, nullptr, w0, nullptr);
                 cur ^= 1;
             } else {
                 gat_layer_kernel<true, false><<<layer_grid, 512, 0, s>>>(db.h[cur], skipb[cur], scoreb[cur], nullptr, nullptr, nullptr, emb,
-                                                                        db.csr.row_ptr, db.csr.src, w, n, nullptr, nullptr);
+                                                                        db.csr.row_ptr, db.csr.src, w, n, nullptr, nullptr, w0,
+                                                                        fold ? d_pw_ : nullptr);
             }
         }
         db.final_h = cur;
@@ -407,8 +513,11 @@ public:
         db.tap_dim = GAT_F;
         {
             ProfScope p(prof, "mean_pool_linear", s);
-            mean_pool_linear_kernel<GAT_D><<<(db.b.num_graphs + 3) / 4, 256, 0, s>>>(emb, db.b.node_off, d_pw_, d_pb_, db.out,
-                                                                                     db.b.num_graphs);
+            if (fold)
+                segment_mean_bias_kernel<0><<<(db.b.num_graphs + 255) / 256, 256, 0, s>>>(emb, db.b.node_off, d_pb_, db.out, db.b.num_graphs);
+            else
+                mean_pool_linear_kernel<GAT_D><<<(db.b.num_graphs + 3) / 4, 256, 0, s>>>(emb, db.b.node_off, d_pw_, d_pb_, db.out,
+                                                                                         db.b.num_graphs);
         }
         return 0;
     }
@@ -420,6 +529,7 @@ private:
             if (*p) { (void)hipFree(*p); *p = nullptr; }
     }
     bool ready_ = false;
+    bool fold_readout_ = !(getenv("FLOWGNN_GAT_FOLD_READOUT") && atoi(getenv("FLOWGNN_GAT_FOLD_READOUT")) == 0);
     float *d_lin0_ = nullptr, *d_asrc_ = nullptr, *d_atgt_ = nullptr, *d_wskip_ = nullptr, *d_wlin_ = nullptr, *d_pw_ = nullptr,
           *d_pb_ = nullptr;
 };
