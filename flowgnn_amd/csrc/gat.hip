@@ -52,16 +52,16 @@ __device__ __forceinline__ void gat_score_acc(float4& s, const float4& pd, const
 // A neighbour u outside the tile (layer 0): this lane's four projection rows from u's raw features (its scores come from
 // the pre-pass below, like every other node's).
 __device__ __forceinline__ void gat_layer0_rare(const int* __restrict__ node_feature, long long row, int g, const float4* s_lin0,
-                                                float4 (&p)[4]) {
-    // the 36-byte feature row in ONE round trip (three loads, one wait; nine self-waiting loads would be nine round trips)
+                                                const float4* score_ptr, float4& st, float4 (&p)[4]) {
+    // the 36-byte feature row and u's target scores in ONE round trip (four loads, one wait)
     typedef int int4v __attribute__((ext_vector_type(4)));
     int4v fa, fb;
     int fc;
     const int* fp = node_feature + (size_t)row * ND_FEATURE;
-    asm volatile("global_load_dwordx4 %0, %3, off\n\tglobal_load_dwordx4 %1, %3, off offset:16\n\tglobal_load_dword %2, %3, off offset:32\n\t"
-                 "s_waitcnt vmcnt(0)"
-                 : "=&v"(fa), "=&v"(fb), "=&v"(fc)
-                 : "v"(fp)
+    asm volatile("global_load_dwordx4 %0, %4, off\n\tglobal_load_dwordx4 %1, %4, off offset:16\n\tglobal_load_dword %2, %4, off offset:32\n\t"
+                 "global_load_dwordx4 %3, %5, off\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(fa), "=&v"(fb), "=&v"(fc), "=&v"(st)
+                 : "v"(fp), "v"(score_ptr)
                  : "memory");
     static_assert(ND_FEATURE == 9, "feature row = 4 + 4 + 1 words");
     const int f[ND_FEATURE] = {fa.x, fa.y, fa.z, fa.w, fb.x, fb.y, fb.z, fb.w, fc};
@@ -252,12 +252,18 @@ __global__ __launch_bounds__(512, 4) void gat_layer_kernel(const float* __restri
                 asm volatile("" : "+v"(p[t].x), "+v"(p[t].y), "+v"(p[t].z), "+v"(p[t].w));
             }
             if (!in) {
-                st = load_f4_rare(sc4 + (size_t)u * 2 + 1);
+                const float4* sp = sc4 + (size_t)u * 2 + 1;  // target scores of u
                 if (FIRST) {
-                    gat_layer0_rare(node_feature, feat_row ? (long long)load_i32_rare(feat_row + u) : (long long)u, g, s_lin0, p);
+                    gat_layer0_rare(node_feature, feat_row ? (long long)load_i32_rare(feat_row + u) : (long long)u, g, s_lin0, sp, st, p);
                 } else {
-#pragma unroll
-                    for (int t = 0; t < 4; t++) p[t] = load_f4_rare(proj4 + (size_t)u * 16 + 4 * t + g);
+                    // the scores and this lane's four projection rows of u in ONE round trip (five loads, one wait)
+                    const float4* pp = proj4 + (size_t)u * 16 + g;
+                    asm volatile("global_load_dwordx4 %0, %5, off\n\tglobal_load_dwordx4 %1, %6, off\n\t"
+                                 "global_load_dwordx4 %2, %6, off offset:64\n\tglobal_load_dwordx4 %3, %6, off offset:128\n\t"
+                                 "global_load_dwordx4 %4, %6, off offset:192\n\ts_waitcnt vmcnt(0)"
+                                 : "=&v"(st), "=&v"(p[0]), "=&v"(p[1]), "=&v"(p[2]), "=&v"(p[3])
+                                 : "v"(sp), "v"(pp)
+                                 : "memory");
                 }
             }
             more = e < e_end;
