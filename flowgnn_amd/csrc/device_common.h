@@ -24,10 +24,27 @@ __device__ inline float load_f32_rare(const float* p) {
     asm volatile("global_load_dword %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
     return v;
 }
+// CSR word of the tiled kernels: (source row | edge code).  A source inside the tile is its row (< TR <= 2^15); one outside
+// is bit 23 + its 23-bit signed distance from the tile start, so the rare path can form its address without first
+// re-reading src[] (one dependent round trip instead of two); a distance beyond +-2^22 rows is the escape value.
+constexpr unsigned TILE_FAR = 0x800000u, TILE_ESCAPE = 0xC00000u;  // escape = bit 23 | distance -2^22
+__device__ __forceinline__ unsigned tile_pack_src(int u, int t0, int rows) {
+    const int d = u - t0;
+    if ((unsigned)d < (unsigned)rows) return (unsigned)d;
+    return (d > -(1 << 22) && d < (1 << 22)) ? (TILE_FAR | ((unsigned)d & 0x7FFFFFu)) : TILE_ESCAPE;
+}
+// global row of an out-of-tile source (ul >= TILE_FAR); e = its CSR position, for the escape value
+__device__ __forceinline__ long long tile_far_row(unsigned ul, int t0, const int* __restrict__ src, long long e);
+
 __device__ inline int load_i32_rare(const int* p) {
     int v;
     asm volatile("global_load_dword %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
     return v;
+}
+
+__device__ __forceinline__ long long tile_far_row(unsigned ul, int t0, const int* __restrict__ src, long long e) {
+    if (ul == TILE_ESCAPE) return load_i32_rare(src + e);
+    return (long long)t0 + (((int)(ul << 9)) >> 9);  // sign-extend the 23-bit distance
 }
 
 // one v_max_f32 (the compare + select form costs three issue slots); differs from `x < 0 ? 0 : x` only for NaN
@@ -310,8 +327,7 @@ __global__ __launch_bounds__(P::NTHR) void tiled_aggregate_kernel(typename P::Pa
         return row_ptr[i <= n_tot ? i : n_tot];
     };
     auto pack = [&](int u, int code, int t0, int rows) -> unsigned {  // rows: what the tile really holds (<= TR)
-        const unsigned ul = (unsigned)(u - t0);
-        return ((ul < (unsigned)rows ? ul : 0xFFFFFFu) << 8) | (unsigned)code;
+        return (tile_pack_src(u, t0, rows) << 8) | (unsigned)code;
     };
     int rp_next = load_rp(blockIdx.x);
     for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
@@ -381,7 +397,7 @@ __global__ __launch_bounds__(P::NTHR) void tiled_aggregate_kernel(typename P::Pa
                     }
 #pragma unroll
                     for (int k = 0; k < 4; k++) {
-                        if ((pk[k] >> 8) >= (unsigned)TR) x[k] = load_f4_rare(h4 + (size_t)load_i32_rare(src + e0 + e + k) * C + c);
+                        if ((pk[k] >> 8) >= (unsigned)TR) x[k] = load_f4_rare(h4 + (size_t)tile_far_row(pk[k] >> 8, t0, src, (long long)e0 + e + k) * C + c);
                         P::edge(acc, x[k], w[k], ss[k], sd);
                     }
                 }
@@ -394,7 +410,7 @@ __global__ __launch_bounds__(P::NTHR) void tiled_aggregate_kernel(typename P::Pa
                     if (P::TABLE_ROWS > 0) w = *reinterpret_cast<const float4*>(st_b + (pk & 0xFFu) * (D * 4) + c * 16);
                     float4 x = *reinterpret_cast<const float4*>(sh_b + (ul < (unsigned)TR ? ul : 0u) * (D * 4) + c * 16);
                     asm volatile("" : "+v"(x.x), "+v"(x.y), "+v"(x.z), "+v"(x.w));
-                    if (ul >= (unsigned)TR) x = load_f4_rare(h4 + (size_t)load_i32_rare(src + e0 + e) * C + c);
+                    if (ul >= (unsigned)TR) x = load_f4_rare(h4 + (size_t)tile_far_row(ul, t0, src, (long long)e0 + e) * C + c);
                     P::edge(acc, x, w, ss, sd);
                 }
             } else {
@@ -412,7 +428,7 @@ __global__ __launch_bounds__(P::NTHR) void tiled_aggregate_kernel(typename P::Pa
                     if (P::TABLE_ROWS > 0) w = *reinterpret_cast<const float4*>(st_b + (pk & 0xFFu) * (D * 4) + c * 16);
                     float4 x = *reinterpret_cast<const float4*>(sh_b + (ul < (unsigned)TR ? ul : 0u) * (D * 4) + c * 16);
                     asm volatile("" : "+v"(x.x), "+v"(x.y), "+v"(x.z), "+v"(x.w));
-                    if (ul >= (unsigned)TR) x = load_f4_rare(h4 + (size_t)load_i32_rare(src + e0 + e) * C + c);
+                    if (ul >= (unsigned)TR) x = load_f4_rare(h4 + (size_t)tile_far_row(ul, t0, src, (long long)e0 + e) * C + c);
                     P::edge(acc, x, w, ss, sd);
                 }
             }

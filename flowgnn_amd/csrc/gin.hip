@@ -139,8 +139,7 @@ __global__ __launch_bounds__(NTHR) void gin_aggregate_tiled_kernel(const float* 
         }
         rp_next = load_rp(tile + gridDim.x);
         for (int i = threadIdx.x; i < ne && i < TE; i += NTHR) {
-            const unsigned ul = (unsigned)(src[e0 + i] - t0);
-            s_edge[i] = ((ul < (unsigned)TR ? ul : 0xFFFFFFu) << 8) | ecode[e0 + i];
+            s_edge[i] = (tile_pack_src(src[e0 + i], t0, TR) << 8) | ecode[e0 + i];
         }
         asm volatile("s_waitcnt vmcnt(0)" : "+v"(rp_next) : : "memory");
         __syncthreads();
@@ -160,7 +159,7 @@ __global__ __launch_bounds__(NTHR) void gin_aggregate_tiled_kernel(const float* 
                     const float4 w = *reinterpret_cast<const float4*>(se_b + (pk & 0xFFu) * (D * 4) + c * 16);
                     float4 x = *reinterpret_cast<const float4*>(sh_b + (ul < (unsigned)TR ? ul : 0u) * (D * 4) + c * 16);
                     asm volatile("" : "+v"(x.x), "+v"(x.y), "+v"(x.z), "+v"(x.w));
-                    if (ul >= (unsigned)TR) x = load_f4_rare(h4 + (size_t)load_i32_rare(src + e0 + e) * C + c);
+                    if (ul >= (unsigned)TR) x = load_f4_rare(h4 + (size_t)tile_far_row(ul, t0, src, (long long)e0 + e) * C + c);
                     acc.x += relu1(w.x + x.x); acc.y += relu1(w.y + x.y); acc.z += relu1(w.z + x.z); acc.w += relu1(w.w + x.w);
                 }
                 if (ADD_SELF) {
@@ -183,14 +182,13 @@ __global__ __launch_bounds__(NTHR) void gin_aggregate_tiled_kernel(const float* 
                     unsigned pk = s_edge[e < TE ? e : TE - 1];
                     asm volatile("" : "+v"(pk));
                     if (e >= TE) {
-                        const unsigned ul2 = (unsigned)(src[e0 + e] - t0);
-                        pk = ((ul2 < (unsigned)TR ? ul2 : 0xFFFFFFu) << 8) | ecode[e0 + e];
+                        pk = (tile_pack_src(src[e0 + e], t0, TR) << 8) | ecode[e0 + e];
                     }
                     const unsigned ul = pk >> 8;
                     const float4 w = *reinterpret_cast<const float4*>(se_b + (pk & 0xFFu) * (D * 4) + c * 16);
                     float4 x = *reinterpret_cast<const float4*>(sh_b + (ul < (unsigned)TR ? ul : 0u) * (D * 4) + c * 16);
                     asm volatile("" : "+v"(x.x), "+v"(x.y), "+v"(x.z), "+v"(x.w));
-                    if (ul >= (unsigned)TR) x = load_f4_rare(h4 + (size_t)load_i32_rare(src + e0 + e) * C + c);
+                    if (ul >= (unsigned)TR) x = load_f4_rare(h4 + (size_t)tile_far_row(ul, t0, src, (long long)e0 + e) * C + c);
                     acc.x += relu1(w.x + x.x); acc.y += relu1(w.y + x.y); acc.z += relu1(w.z + x.z); acc.w += relu1(w.w + x.w);
                 }
                 if (ADD_SELF) {
