@@ -94,14 +94,30 @@ __global__ __launch_bounds__(1024) void gcn_encoder_dense_kernel(const int* __re
     const float oscale = *reinterpret_cast<const float*>(s_w + SCALE_OFF);
     const long long n_tiles = ((long long)n_tot + 15) / 16;
     float vmax = 0.0f;
+    // the feature row of this lane's node, requested one tile ahead of its use (the wave's only global round trip per tile)
+    int fnext[ND_FEATURE];
+    auto fetch = [&](long long t) {
+        long long v = t * 16 + j;
+        if (v >= n_tot) v = n_tot - 1;
+#pragma unroll
+        for (int k = 0; k < ND_FEATURE; k++) fnext[k] = node_feature[(size_t)v * ND_FEATURE + k];
+    };
+    fetch((long long)blockIdx.x * 16 + wave < n_tiles ? (long long)blockIdx.x * 16 + wave : 0);
     for (long long tile = (long long)blockIdx.x * 16 + wave; tile < n_tiles; tile += (long long)gridDim.x * 16) {
         long long node = tile * 16 + j;
         const bool valid = node < n_tot;
         if (!valid) node = n_tot - 1;
         int rows[ND_FEATURE];
+        int fcur[ND_FEATURE];
+#pragma unroll
+        for (int k = 0; k < ND_FEATURE; k++) fcur[k] = fnext[k];
+        {
+            const long long tn = tile + (long long)gridDim.x * 16;
+            fetch(tn < n_tiles ? tn : tile);
+        }
 #pragma unroll
         for (int k = 0; k < ND_FEATURE; k++) {
-            int f = node_feature[(size_t)node * ND_FEATURE + k];
+            int f = fcur[k];
             if (f < 0 || f >= c_nd_card[k]) {
                 atomicMax(err, ERR_NODE_FEAT);
                 f = 0;
