@@ -103,7 +103,8 @@ __global__ __launch_bounds__(512) void atom_encoder_kernel(const int* __restrict
                 const float4 w = s_tab[s_row[v * ND_FEATURE + k] + c];
                 s.x += w.x; s.y += w.y; s.z += w.z; s.w += w.w;
             }
-            reinterpret_cast<float4*>(h)[(size_t)v0 * C + i] = s;
+            // streaming store: the rows are next read by another kernel, after 2.7 GB of other rows have gone by
+            __builtin_nontemporal_store((float4_t){s.x, s.y, s.z, s.w}, reinterpret_cast<float4_t*>(h) + (size_t)v0 * C + i);
         }
     }
 }
