@@ -47,6 +47,13 @@ __device__ __forceinline__ long long tile_far_row(unsigned ul, int t0, const int
     return (long long)t0 + (((int)(ul << 9)) >> 9);  // sign-extend the 23-bit distance
 }
 
+// Streaming (nontemporal) 16-byte store for rows that the next kernel reads only after gigabytes of other rows have gone by:
+// they need not displace the gather's working set (neighbour rows, weight stream) from the caches.
+__device__ __forceinline__ void stream_store4(float* p, float a, float b, float c, float d) {
+    __builtin_nontemporal_store((float4_t){a, b, c, d}, reinterpret_cast<float4_t*>(p));
+}
+__device__ __forceinline__ void stream_store4(float4* p, const float4& v) { stream_store4(reinterpret_cast<float*>(p), v.x, v.y, v.z, v.w); }
+
 // one v_max_f32 (the compare + select form costs three issue slots); differs from `x < 0 ? 0 : x` only for NaN
 __device__ inline float relu1(float x) { return __builtin_fmaxf(x, 0.0f); }
 

@@ -45,7 +45,7 @@ __global__ __launch_bounds__(256) void dgn_encoder_kernel(const int* __restrict_
             const float4 w = reinterpret_cast<const float4*>(table)[((size_t)k * DGN_TBL + f) * C + c];
             s.x += w.x; s.y += w.y; s.z += w.z; s.w += w.w;
         }
-        reinterpret_cast<float4*>(h)[i] = s;
+        stream_store4(reinterpret_cast<float4*>(h) + i, s);
     }
 }
 
@@ -91,8 +91,8 @@ struct DgnAggPolicy {
         a2.x = fabsf((a.m2.x - a.wsum * hv.x) / abssum); a2.y = fabsf((a.m2.y - a.wsum * hv.y) / abssum);
         a2.z = fabsf((a.m2.z - a.wsum * hv.z) / abssum); a2.w = fabsf((a.m2.w - a.wsum * hv.w) / abssum);
         float4* o = reinterpret_cast<float4*>(out) + (size_t)v * (2 * DGN_C) + c;
-        o[0] = a1;
-        o[DGN_C] = a2;
+        stream_store4(o, a1);
+        stream_store4(o + DGN_C, a2);
     }
 };
 

@@ -94,8 +94,8 @@ __global__ __launch_bounds__(256) void gat_scores0_kernel(const int* __restrict_
         gat_score_acc(ss, pd, reinterpret_cast<const float4*>(a_src)[d]);
         gat_score_acc(st, pd, reinterpret_cast<const float4*>(a_tgt)[d]);
     }
-    reinterpret_cast<float4*>(scores)[v * 2 + 0] = ss;
-    reinterpret_cast<float4*>(scores)[v * 2 + 1] = st;
+    stream_store4(reinterpret_cast<float4*>(scores) + v * 2 + 0, ss);
+    stream_store4(reinterpret_cast<float4*>(scores) + v * 2 + 1, st);
 }
 
 // local node index per node (reference quirk mode: every graph reads the first rows of the batch)

@@ -69,7 +69,7 @@ struct GcnAggPolicy {
         r.z = (a.m.z + relu1(xs.z + rt.z) * idp1) * sc.z + sh.z;
         r.w = (a.m.w + relu1(xs.w + rt.w) * idp1) * sc.w + sh.w;
         if (RELU_OUT) { r.x = relu1(r.x); r.y = relu1(r.y); r.z = relu1(r.z); r.w = relu1(r.w); }
-        reinterpret_cast<float4*>(out)[(size_t)v * GCN_C + c] = r;
+        stream_store4(reinterpret_cast<float4*>(out) + (size_t)v * GCN_C + c, r);
     }
 };
 

@@ -166,7 +166,7 @@ __global__ __launch_bounds__(NTHR) void gin_aggregate_tiled_kernel(const float* 
                     const float4 self = s_h[idx];
                     acc.x += self.x; acc.y += self.y; acc.z += self.z; acc.w += self.w;
                 }
-                reinterpret_cast<float4*>(a)[(size_t)t0 * C + idx] = acc;
+                stream_store4(reinterpret_cast<float4*>(a) + (size_t)t0 * C + idx, acc);
                 c += NTHR % C;
                 r += NTHR / C;
                 if (c >= C) { c -= C; r++; }
@@ -195,7 +195,7 @@ __global__ __launch_bounds__(NTHR) void gin_aggregate_tiled_kernel(const float* 
                     const float4 self = s_h[idx];
                     acc.x += self.x; acc.y += self.y; acc.z += self.z; acc.w += self.w;
                 }
-                reinterpret_cast<float4*>(a)[(size_t)t0 * C + idx] = acc;
+                stream_store4(reinterpret_cast<float4*>(a) + (size_t)t0 * C + idx, acc);
                 c += NTHR % C;
                 r += NTHR / C;
                 if (c >= C) { c -= C; r++; }

@@ -64,7 +64,7 @@ struct PnaAggPolicy {
         sd.x = sqrtf(relu1(a.Q.x / deg - mean.x * mean.x)); sd.y = sqrtf(relu1(a.Q.y / deg - mean.y * mean.y));
         sd.z = sqrtf(relu1(a.Q.z / deg - mean.z * mean.z)); sd.w = sqrtf(relu1(a.Q.w / deg - mean.w * mean.w));
         float4* o = reinterpret_cast<float4*>(out) + (size_t)v * (PNA_NA * PNA_C) + c;
-        o[0 * PNA_C] = mean; o[1 * PNA_C] = a.mn; o[2 * PNA_C] = a.mx; o[3 * PNA_C] = sd;
+        stream_store4(o + 0 * PNA_C, mean); stream_store4(o + 1 * PNA_C, a.mn); stream_store4(o + 2 * PNA_C, a.mx); stream_store4(o + 3 * PNA_C, sd);
     }
 };
 
