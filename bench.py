@@ -90,10 +90,29 @@ def oracle_forward(model: str, batch, w, nthreads: int, numeric: str = "f32"):
     return fn(batch, [w], nthreads=nthreads)
 
 
+def effective_cpus() -> int:
+    """CPUs this process can really use: the affinity mask, capped by the cgroup CPU quota (a container that sees 256
+    hardware threads under a 16-CPU quota runs 256 OpenMP threads at half the speed of 32)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]  # cgroup v2
+        if quota != "max":
+            n = min(n, max(1, -(-int(quota) // int(period))))
+    except (OSError, ValueError):
+        try:
+            quota = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())  # cgroup v1
+            period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota > 0 and period > 0:
+                n = min(n, max(1, -(-quota // period)))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
 def cpu_baseline(model, batch, w, budget_s: float = 15.0, numeric: str = "f32"):
     """The oracle (CPU restatement of the reference, kind='port') timed on this host's cores on a
     bounded sample of the same workload."""
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = effective_cpus()
     probe = batch.slice(0, min(128, batch.num_graphs))
     t0 = time.perf_counter()
     oracle_forward(model, probe, w, 1, numeric)
