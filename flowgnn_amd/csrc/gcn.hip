@@ -252,26 +252,31 @@ __global__ __launch_bounds__(512) void gcn_layer_fused_kernel(const float* __res
             }
         }
         // epilogue of the aggregation (GcnAggPolicy<true>::finish): root term, folded BatchNorm, ReLU
+        // (this lane's 75 epilogue constants and, in the last layer, its 25 readout weights are the same for every tile: with
+        //  the lane index left visible the compiler keeps all of them in registers across the tile loop -- 232 VGPRs and two
+        //  waves per SIMD in the last layer -- so the index is made opaque per tile and the values are re-read from LDS / L1)
+        int ge = g;
+        if (FINAL) asm volatile("" : "+v"(ge));  // (the other layers stay under 128 registers as they are, and are faster with what the compiler keeps)
         float a[25];
 #pragma unroll
         for (int q = 0; q < 6; q++) {
-            const float4 rt = *reinterpret_cast<const float4*>(s_ep + 16 * q + 4 * g);
-            const float4 sc = *reinterpret_cast<const float4*>(s_ep + GCN_D + 16 * q + 4 * g);
-            const float4 sh = *reinterpret_cast<const float4*>(s_ep + 2 * GCN_D + 16 * q + 4 * g);
+            const float4 rt = *reinterpret_cast<const float4*>(s_ep + 16 * q + 4 * ge);
+            const float4 sc = *reinterpret_cast<const float4*>(s_ep + GCN_D + 16 * q + 4 * ge);
+            const float4 sh = *reinterpret_cast<const float4*>(s_ep + 2 * GCN_D + 16 * q + 4 * ge);
             a[4 * q + 0] = (m[4 * q + 0] + relu1(xs[q].x + rt.x) * idp1) * sc.x + sh.x;
             a[4 * q + 1] = (m[4 * q + 1] + relu1(xs[q].y + rt.y) * idp1) * sc.y + sh.y;
             a[4 * q + 2] = (m[4 * q + 2] + relu1(xs[q].z + rt.z) * idp1) * sc.z + sh.z;
             a[4 * q + 3] = (m[4 * q + 3] + relu1(xs[q].w + rt.w) * idp1) * sc.w + sh.w;
         }
-        a[24] = (m[24] + relu1(xst + s_ep[96 + g]) * idp1) * s_ep[GCN_D + 96 + g] + s_ep[2 * GCN_D + 96 + g];
+        a[24] = (m[24] + relu1(xst + s_ep[96 + ge]) * idp1) * s_ep[GCN_D + 96 + ge] + s_ep[2 * GCN_D + 96 + ge];
         if (FINAL) {  // no ReLU after the last BatchNorm; per-node score, fixed order: 25 terms in the lane, then the node's 4 lanes
             float part = 0.0f;
 #pragma unroll
             for (int q = 0; q < 6; q++) {
-                const float4 pw = *reinterpret_cast<const float4*>(pool_w + 16 * q + 4 * g);
+                const float4 pw = *reinterpret_cast<const float4*>(pool_w + 16 * q + 4 * ge);
                 part += a[4 * q + 0] * pw.x; part += a[4 * q + 1] * pw.y; part += a[4 * q + 2] * pw.z; part += a[4 * q + 3] * pw.w;
             }
-            part += a[24] * pool_w[96 + g];
+            part += a[24] * pool_w[96 + ge];
             part += __shfl_xor(part, 16, 64);
             part += __shfl_xor(part, 32, 64);
             if (g == 0 && valid) xout[node] = part;
