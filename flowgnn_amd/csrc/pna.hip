@@ -207,7 +207,8 @@ __global__ __launch_bounds__(512) void pna_dense_split_kernel(const float* __res
     float vmax = 0.0f;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-#pragma unroll 1
+#pragma unroll  // fully: in a rolled loop hipcc rotates the 15 accumulators through registers and spills one per trip, and a
+                // spill reload queues behind the chunk DMA in vmcnt order
     for (int ks = 0; ks < PNA_KS; ks += 2) {
         // even K-step from s_a while chunk ks+1 streams into s_b and its B operand into registers
         pna_issue_chunk(wpk + (size_t)(ks + 1) * PNA_CHUNK, s_b, wave, lane);
