@@ -176,14 +176,30 @@ __global__ __launch_bounds__(256) void rank_kernel(CsrView c, int e_tot, const i
 // read of the edge list / attributes and one write of row_ptr / src / eid / ecode / out_deg.  Used when every graph of
 // the batch fits the class (the reference itself caps graphs at 500 nodes / 5500 edges, GIN/src/dcl.h:17-18);
 // otherwise the flat global path above runs.  Same output, bit for bit (the keys are unique).
-template <int NT, int NMAX, int EMAX, typename IdxT>
-__global__ __launch_bounds__(NT) void build_csr_graph_kernel(BatchView b, CsrView c, bool has_attr) {
-    __shared__ int s_cnt[NMAX + 1];   // in-degree, then exclusive scan = row start
-    __shared__ int s_cur[NMAX];
-    __shared__ int s_odeg[NMAX];
-    __shared__ IdxT s_u[EMAX], s_v[EMAX], s_slot[EMAX];
-    __shared__ uint8_t s_code[EMAX];
-    __shared__ int s_wtot[NT / 64];
+// LDS is sized at launch by the largest graph of the BATCH (nmax nodes, emax edges, both within the class limits NMAX /
+// EMAX): a molhiv batch (largest graph 183 nodes / 378 edges) then needs 5 KB per graph instead of the class's 10 KB, and
+// twice as many graphs are in flight per CU.
+// DYN (the single-wave class): LDS is sized at launch by the largest graph of the BATCH (nmax nodes, emax edges, within the
+// class limits) -- a molhiv batch (largest graph 183 nodes / 378 edges) then needs 5 KB per graph instead of the class's
+// 10 KB and twice as many graphs are in flight per CU (0.32 -> 0.19 ms).  The multi-wave classes keep static arrays of the
+// class size: sized by the batch they measured slower on the kNN graphs (0.23 -> 0.26 ms).
+template <int NT, int NMAX, int EMAX, typename IdxT, bool DYN>
+__global__ __launch_bounds__(NT) void build_csr_graph_kernel(BatchView b, CsrView c, bool has_attr, int nmax, int emax) {
+    extern __shared__ __attribute__((aligned(16))) char s_dyn[];
+    __shared__ int st_cnt[DYN ? 1 : NMAX + 1];
+    __shared__ int st_cur[DYN ? 1 : NMAX];
+    __shared__ int st_odeg[DYN ? 1 : NMAX];
+    __shared__ int st_wtot[DYN ? 1 : NT / 64];
+    __shared__ IdxT st_u[DYN ? 1 : EMAX], st_v[DYN ? 1 : EMAX], st_slot[DYN ? 1 : EMAX];
+    __shared__ uint8_t st_code[DYN ? 1 : EMAX];
+    int* s_cnt = DYN ? reinterpret_cast<int*>(s_dyn) : st_cnt;  // [nmax + 1] in-degree, then exclusive scan = row start
+    int* s_cur = DYN ? s_cnt + (nmax + 1) : st_cur;             // [nmax]
+    int* s_odeg = DYN ? s_cur + nmax : st_odeg;                 // [nmax]
+    int* s_wtot = DYN ? s_odeg + nmax : st_wtot;                // [NT / 64]
+    IdxT* s_u = DYN ? reinterpret_cast<IdxT*>(s_wtot + NT / 64) : st_u;  // [emax] each
+    IdxT* s_v = DYN ? s_u + emax : st_v;
+    IdxT* s_slot = DYN ? s_v + emax : st_slot;
+    uint8_t* s_code = DYN ? reinterpret_cast<uint8_t*>(s_slot + emax) : st_code;
     const int g = blockIdx.x;
     const int tid = threadIdx.x;
     const int n = b.nums_of_nodes[g];
@@ -271,21 +287,24 @@ __global__ __launch_bounds__(NT) void build_csr_graph_kernel(BatchView b, CsrVie
 
 void launch_build_csr(const BatchView& b, const CsrView& c, bool has_edge_attr, int max_nodes, int max_edges, hipStream_t s) {
     if (b.num_graphs > 0 && max_nodes <= 256 && max_edges <= 1024) {
-        build_csr_graph_kernel<64, 256, 1024, uint16_t><<<b.num_graphs, 64, 0, s>>>(b, c, has_edge_attr);
+        // dynamic LDS of one graph: 3 nmax + 1 + NT / 64 ints, 3 emax indices, emax codes
+        const int nmax = (max_nodes + 1) & ~1, emax = (max_edges + 3) & ~3;
+        const size_t lds = (size_t)(3 * nmax + 1 + 1 + 1) * 4 + (size_t)emax * (3 * sizeof(uint16_t) + 1);
+        build_csr_graph_kernel<64, 256, 1024, uint16_t, true><<<b.num_graphs, 64, lds, s>>>(b, c, has_edge_attr, nmax, emax);
         return;
     }
     // kNN graphs of the hep10k shape (<= ~100 nodes x 16 in-edges): 18 KB of LDS per graph, so nine workgroups share a CU;
     // in the class below one graph claims 139 KB and a CU holds a single 4-wave workgroup (0.93 -> 0.22 ms for 2^15 graphs)
     if (b.num_graphs > 0 && max_nodes <= 256 && max_edges <= 2048) {
-        build_csr_graph_kernel<128, 256, 2048, uint16_t><<<b.num_graphs, 128, 0, s>>>(b, c, has_edge_attr);
+        build_csr_graph_kernel<128, 256, 2048, uint16_t, false><<<b.num_graphs, 128, 0, s>>>(b, c, has_edge_attr, 256, 2048);
         return;
     }
     if (b.num_graphs > 0 && max_nodes <= 512 && max_edges <= 6144) {  // the reference's own caps: 500 nodes / 5500 edges
-        build_csr_graph_kernel<256, 512, 6144, uint16_t><<<b.num_graphs, 256, 0, s>>>(b, c, has_edge_attr);
+        build_csr_graph_kernel<256, 512, 6144, uint16_t, false><<<b.num_graphs, 256, 0, s>>>(b, c, has_edge_attr, 512, 6144);
         return;
     }
     if (b.num_graphs > 0 && max_nodes <= 2048 && max_edges <= 16384) {
-        build_csr_graph_kernel<256, 2048, 16384, uint16_t><<<b.num_graphs, 256, 0, s>>>(b, c, has_edge_attr);
+        build_csr_graph_kernel<256, 2048, 16384, uint16_t, false><<<b.num_graphs, 256, 0, s>>>(b, c, has_edge_attr, 2048, 16384);
         return;
     }
     // flat global path: any graph size
