@@ -395,6 +395,19 @@ __global__ __launch_bounds__(P::NTHR) void tiled_aggregate_kernel(typename P::Pa
                         asm volatile("" : "+v"(pk[k]), "+v"(ss[k]));
                     }
                     float4 x[4], w[4];
+                    // a source outside the tile has bit 31 of its CSR word set: one wave-wide test picks the straight-line body
+                    // (no clamps, no branches between the four folds) unless some lane has one
+                    if (!__any((int)(pk[0] | pk[1] | pk[2] | pk[3]) < 0)) {
+#pragma unroll
+                        for (int k = 0; k < 4; k++) {
+                            w[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+                            if (P::TABLE_ROWS > 0) w[k] = *reinterpret_cast<const float4*>(st_b + (pk[k] & 0xFFu) * (D * 4) + c * 16);
+                            x[k] = *reinterpret_cast<const float4*>(sh_b + (pk[k] >> 8) * (D * 4) + c * 16);
+                        }
+#pragma unroll
+                        for (int k = 0; k < 4; k++) P::edge(acc, x[k], w[k], ss[k], sd);
+                        continue;
+                    }
 #pragma unroll
                     for (int k = 0; k < 4; k++) {
                         const unsigned ul = pk[k] >> 8;
