@@ -240,9 +240,9 @@ def main():
             return {"kernel": name, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": ach / HBM_PEAK_GBS, "traffic": traffic_of(name), "avg_ms": kern[name], "bytes_per_launch": agg_bytes}
 
-        # the dense updates of GIN, GCN, PNA and DGN run as three f16 MFMAs per fp32 product unless FLOWGNN_<M>_MFMA=f32
+        # the dense updates of every model run as three f16 MFMAs per fp32 product unless FLOWGNN_<M>_MFMA=f32
         env = {"GIN": "FLOWGNN_GIN_MFMA", "GIN-VN": "FLOWGNN_GIN_MFMA", "GCN": "FLOWGNN_GCN_MFMA", "PNA": "FLOWGNN_PNA_MFMA",
-               "DGN": "FLOWGNN_DGN_MFMA"}.get(args.model)
+               "DGN": "FLOWGNN_DGN_MFMA", "GAT": "FLOWGNN_GAT_MFMA"}.get(args.model)
         split = env is not None and os.environ.get(env, "") != "f32"
         roof = None
         if dominant in M["hbm_kernels"]:

@@ -16,6 +16,7 @@
 // two shuffles.  Traffic per node-layer ~ 1 KB; the kernel is HBM-bound.
 #include "common.h"
 #include "device_common.h"
+#include "dense_split.h"
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -108,8 +109,16 @@ __global__ __launch_bounds__(256) void gat_local_rows_kernel(const int* __restri
 }
 
 struct GatLayerDev {
+    // fp32 MFMA path:
     const float* wskip;  // fragments [4 t][4 q][64][4]: W_skip_l[f_o = 16 t + i][f_i = 16 q + 4 g + r]
     const float* wlin;   // fragments [4 t][4 t2][64][4]: W_lin_{l+1}[f_o = 16 t2 + i][f_i = 16 t + 4 g + r]
+    // split-f16 path (the same two 64 x 64 matrices as f16 hi/lo fragments of v_mfma_f32_16x16x32_f16, 16 KiB each, in the
+    // same LDS space): [out tile][K-step 0..1][hi, lo][64 lanes][8 halves]; slot e of lane (i, gk) of K-step ks is
+    // W[16 t + i][16 (2 ks + (e >> 2)) + 4 gk + (e & 3)] scaled by a power of two; *_scale undoes it
+    const float* wskip_split;
+    const float* wlin_split;
+    float wskip_scale, wlin_scale;
+    int* range_flag;
     const float* a_src;  // [16 dim][4 head] of layer l+1
     const float* a_tgt;
 };
@@ -128,7 +137,7 @@ struct GatLayer0Dev {
     const float* a_tgt;
 };
 
-template <bool FINAL, bool FIRST>
+template <bool FINAL, bool FIRST, bool SPLIT>
 __global__ __launch_bounds__(512, 4) void gat_layer_kernel(const float* __restrict__ proj, const float* __restrict__ skipin,
                                                          const float* __restrict__ scores, float* __restrict__ proj_out,
                                                          float* __restrict__ skip_out, float* __restrict__ scores_out,
@@ -147,9 +156,10 @@ __global__ __launch_bounds__(512, 4) void gat_layer_kernel(const float* __restri
     __shared__ __attribute__((aligned(16))) float4 s_lin0[FIRST ? GAT_D * ND_FEATURE : 1];
     __shared__ int s_feat[FIRST ? GAT_TR * ND_FEATURE : 1];
     for (int i = threadIdx.x; i < 16 * 64; i += 512) {
-        s_wskip[i] = reinterpret_cast<const float4*>(w.wskip)[i];
-        if (!FINAL) s_wlin[i] = reinterpret_cast<const float4*>(w.wlin)[i];
+        s_wskip[i] = reinterpret_cast<const float4*>(SPLIT ? w.wskip_split : w.wskip)[i];
+        if (!FINAL) s_wlin[i] = reinterpret_cast<const float4*>(SPLIT ? w.wlin_split : w.wlin)[i];
     }
+    float vmax = 0.0f;  // SPLIT: largest operand magnitude (range check of the f16 split, see gin_split.hip)
     if (FIRST) {
         for (int i = threadIdx.x; i < GAT_D * ND_FEATURE; i += 512) s_lin0[i] = reinterpret_cast<const float4*>(w0.lin0)[i];
     }
@@ -301,6 +311,35 @@ __global__ __launch_bounds__(512, 4) void gat_layer_kernel(const float* __restri
 #pragma unroll
     for (int t = 0; t < 4; t++) acc[t] = (float4_t){num[t].x / den.x, num[t].y / den.y, num[t].z / den.z, num[t].w / den.w};
     const float4* ws4 = s_wskip;
+    if constexpr (SPLIT) {
+        // both 64 x 64 contractions of the layer as split-f16 products (3 x v_mfma_f32_16x16x32_f16 per fp32 product block,
+        // dense_split.h): 24 MFMAs of 16 cycles per contraction instead of 64 fp32 MFMAs of 32
+        ds_uint4_t b_hi[2], b_lo[2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++) {
+            DS_SPLIT2(bq[8 * ks + 0], bq[8 * ks + 1], b_hi[ks].x, b_lo[ks].x);
+            DS_SPLIT2(bq[8 * ks + 2], bq[8 * ks + 3], b_hi[ks].y, b_lo[ks].y);
+            DS_SPLIT2(bq[8 * ks + 4], bq[8 * ks + 5], b_hi[ks].z, b_lo[ks].z);
+            DS_SPLIT2(bq[8 * ks + 6], bq[8 * ks + 7], b_hi[ks].w, b_lo[ks].w);
+        }
+#pragma unroll
+        for (int k = 0; k < 16; k += 2) vmax = __builtin_fmaxf(__builtin_fmaxf(vmax, __builtin_fabsf(bq[k])), __builtin_fabsf(bq[k + 1]));
+        asm volatile("" : "+v"(vmax));
+        const char* wb = reinterpret_cast<const char*>(s_wskip);
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            float4_t sk = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 2; ks++) {
+                const ds_uint4_t a_hi = *reinterpret_cast<const ds_uint4_t*>(wb + ((t * 2 + ks) * 2 + 0) * 1024 + lds_lane * 16);
+                const ds_uint4_t a_lo = *reinterpret_cast<const ds_uint4_t*>(wb + ((t * 2 + ks) * 2 + 1) * 1024 + lds_lane * 16);
+                sk = DS_MFMA16(a_hi, b_hi[ks], sk);
+                sk = DS_MFMA16(a_hi, b_lo[ks], sk);
+                sk = DS_MFMA16(a_lo, b_hi[ks], sk);
+            }
+            acc[t] += sk * w.wskip_scale;
+        }
+    } else {
 #pragma unroll
     for (int q = 0; q < 4; q++) {
 #pragma unroll
@@ -323,6 +362,7 @@ __global__ __launch_bounds__(512, 4) void gat_layer_kernel(const float* __restri
             const float4 af = ws4[(t * 4 + q) * 64 + lds_lane];
             acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(af.w, bq[4 * q + 3], acc[t], 0, 0, 0);
         }
+    }
     }
 
     if (FINAL) {
@@ -354,6 +394,35 @@ __global__ __launch_bounds__(512, 4) void gat_layer_kernel(const float* __restri
 #pragma unroll
     for (int t2 = 0; t2 < 4; t2++) pr[t2] = (float4_t){0.f, 0.f, 0.f, 0.f};
     const float4* wl4 = s_wlin;
+    if constexpr (SPLIT) {
+        ds_uint4_t o_hi[2], o_lo[2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++) {  // output tiles 2 ks, 2 ks + 1 of the skip contraction are K-step ks of this one
+            DS_SPLIT2(acc[2 * ks].x, acc[2 * ks].y, o_hi[ks].x, o_lo[ks].x);
+            DS_SPLIT2(acc[2 * ks].z, acc[2 * ks].w, o_hi[ks].y, o_lo[ks].y);
+            DS_SPLIT2(acc[2 * ks + 1].x, acc[2 * ks + 1].y, o_hi[ks].z, o_lo[ks].z);
+            DS_SPLIT2(acc[2 * ks + 1].z, acc[2 * ks + 1].w, o_hi[ks].w, o_lo[ks].w);
+        }
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            vmax = __builtin_fmaxf(__builtin_fmaxf(vmax, __builtin_fabsf(acc[t].x)), __builtin_fabsf(acc[t].y));
+            vmax = __builtin_fmaxf(__builtin_fmaxf(vmax, __builtin_fabsf(acc[t].z)), __builtin_fabsf(acc[t].w));
+        }
+        asm volatile("" : "+v"(vmax));
+        const char* wb = reinterpret_cast<const char*>(s_wlin);
+#pragma unroll
+        for (int t2 = 0; t2 < 4; t2++) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ks++) {
+                const ds_uint4_t a_hi = *reinterpret_cast<const ds_uint4_t*>(wb + ((t2 * 2 + ks) * 2 + 0) * 1024 + lds_lane * 16);
+                const ds_uint4_t a_lo = *reinterpret_cast<const ds_uint4_t*>(wb + ((t2 * 2 + ks) * 2 + 1) * 1024 + lds_lane * 16);
+                pr[t2] = DS_MFMA16(a_hi, o_hi[ks], pr[t2]);
+                pr[t2] = DS_MFMA16(a_hi, o_lo[ks], pr[t2]);
+                pr[t2] = DS_MFMA16(a_lo, o_hi[ks], pr[t2]);
+            }
+            pr[t2] *= w.wlin_scale;
+        }
+    } else {
 #pragma unroll
     for (int t = 0; t < 4; t++) {
         float4 af[4];
@@ -367,6 +436,7 @@ __global__ __launch_bounds__(512, 4) void gat_layer_kernel(const float* __restri
         for (int t2 = 0; t2 < 4; t2++) pr[t2] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[t2].z, acc[t].z, pr[t2], 0, 0, 0);
 #pragma unroll
         for (int t2 = 0; t2 < 4; t2++) pr[t2] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[t2].w, acc[t].w, pr[t2], 0, 0, 0);
+    }
     }
     float4 ss = make_float4(0.f, 0.f, 0.f, 0.f), st = ss;
 #pragma unroll
@@ -387,6 +457,11 @@ __global__ __launch_bounds__(512, 4) void gat_layer_kernel(const float* __restri
         reinterpret_cast<float4*>(scores_out)[node * 2 + 1] = st;
     }
   }  // tiles
+    if constexpr (SPLIT) {
+        if (__any(!(vmax < 6.0e4f))) {
+            if (lane == 0) atomicOr(w.range_flag, 1);
+        }
+    }
 }
 
 class GatModel : public Model {
@@ -397,6 +472,7 @@ public:
     bool has_edge_attr() const override { return false; }
     int num_weight_tensors() const override { return 6; }
     bool weights_ready() const override { return ready_; }
+    void set_exact(bool on) override { exact_ = on; }
 
     // host tensors (GAT/src/dcl.h:86-93): scoring_fn_target[5][4][16], scoring_fn_source[5][4][16],
     // linear_proj[5][4][16][4][16], skip_proj[5][4][16][4][16] (layer 0: only [ho][do][0][<9] is used), pred_w[1][16], pred_b[1]
@@ -431,8 +507,36 @@ public:
                             if (l + 1 < GAT_L)
                                 wlin[((((size_t)l * 4 + a) * 4 + b) * 64 + lane) * 4 + r] = M(lin, l + 1, 16 * b + i, 16 * a + 4 * g + r);
                         }
+        // split-f16 fragments of the same matrices (device layout in GatLayerDev), one power-of-two scale per matrix
+        std::vector<float> wskip_s((size_t)GAT_L * 4096, 0.0f), wlin_s((size_t)GAT_L * 4096, 0.0f);
+        auto pack_split = [&](const float* w, int l, float* out_f, float& inv_scale) {
+            float mx = 0.0f;
+            for (int fo = 0; fo < 64; fo++)
+                for (int fi = 0; fi < 64; fi++) mx = std::fmax(mx, std::fabs(M(w, l, fo, fi)));
+            const float sc = (mx > 0.0f && std::isfinite(mx)) ? std::ldexp(1.0f, -std::ilogb(mx)) : 1.0f;
+            inv_scale = 1.0f / sc;
+            uint8_t* out = reinterpret_cast<uint8_t*>(out_f);
+            for (int tt = 0; tt < 4; tt++)
+                for (int ks = 0; ks < 2; ks++)
+                    for (int lane = 0; lane < 64; lane++)
+                        for (int e = 0; e < 8; e++) {
+                            const int i = lane & 15, gk = lane >> 4;
+                            const float v = M(w, l, 16 * tt + i, 16 * (2 * ks + (e >> 2)) + 4 * gk + (e & 3)) * sc;
+                            const _Float16 hi = (_Float16)v;
+                            const _Float16 lo = (_Float16)(v - (float)hi);
+                            uint8_t* f = out + (size_t)((tt * 2 + ks) * 2) * 1024 + lane * 16 + e * 2;
+                            std::memcpy(f, &hi, 2);
+                            std::memcpy(f + 1024, &lo, 2);
+                        }
+        };
+        for (int l = 0; l < GAT_L; l++) {
+            pack_split(skip, l, &wskip_s[(size_t)l * 4096], wskip_scale_[l]);
+            if (l + 1 < GAT_L) pack_split(lin, l + 1, &wlin_s[(size_t)l * 4096], wlin_scale_[l]);
+        }
         std::vector<float> v_pw(t[4], t[4] + GAT_D), v_pb(t[5], t[5] + 1);
         int rc;
+        if ((rc = upload(&d_wskip_s_, wskip_s))) return rc;
+        if ((rc = upload(&d_wlin_s_, wlin_s))) return rc;
         if ((rc = upload(&d_lin0_, lin0))) return rc;
         if ((rc = upload(&d_asrc_, asrc))) return rc;
         if ((rc = upload(&d_atgt_, atgt))) return rc;
@@ -496,24 +600,36 @@ public:
             w.wlin = d_wlin_ + (size_t)l * 16 * 64 * 4;
             w.a_src = d_asrc_ + (size_t)(l + 1 < GAT_L ? l + 1 : l) * GAT_D * GAT_H;
             w.a_tgt = d_atgt_ + (size_t)(l + 1 < GAT_L ? l + 1 : l) * GAT_D * GAT_H;
+            w.wskip_split = d_wskip_s_ + (size_t)l * 4096;
+            w.wlin_split = d_wlin_s_ + (size_t)l * 4096;
+            w.wskip_scale = wskip_scale_[l];
+            w.wlin_scale = wlin_scale_[l];
+            w.range_flag = db.range_flag;
+            const bool sp = split_ && !exact_;
             ProfScope p(prof, "gat_layer", s);
             const int n_tiles = (n + GAT_TR - 1) / GAT_TR;
             const int layer_grid = n_tiles < 512 ? n_tiles : 512;  // persistent: two 8-wave workgroups per CU (68 KB of LDS each)
+#define GAT_LAUNCH(FIN, FST, ...)                                                              \
+    do {                                                                                          \
+        if (sp) gat_layer_kernel<FIN, FST, true><<<layer_grid, 512, 0, s>>>(__VA_ARGS__);         \
+        else gat_layer_kernel<FIN, FST, false><<<layer_grid, 512, 0, s>>>(__VA_ARGS__);           \
+    } while (0)
             if (l == 0) {
-                gat_layer_kernel<false, true><<<layer_grid, 512, 0, s>>>(db.h[cur], skipb[cur], scoreb[cur], db.h[cur ^ 1], skipb[cur ^ 1],
+                GAT_LAUNCH(false, true, db.h[cur], skipb[cur], scoreb[cur], db.h[cur ^ 1], skipb[cur ^ 1],
                                                                         scoreb[cur ^ 1], emb, db.csr.row_ptr, db.csr.src, w, n,
                                                                         db.b.node_feature, feat_row, w0, nullptr);
                 cur ^= 1;
             } else if (l < GAT_L - 1) {
-                gat_layer_kernel<false, false><<<layer_grid, 512, 0, s>>>(db.h[cur], skipb[cur], scoreb[cur], db.h[cur ^ 1], skipb[cur ^ 1],
+                GAT_LAUNCH(false, false, db.h[cur], skipb[cur], scoreb[cur], db.h[cur ^ 1], skipb[cur ^ 1],
                                                                          scoreb[cur ^ 1], emb, db.csr.row_ptr, db.csr.src, w, n, nullptr, nullptr, w0, nullptr);
                 cur ^= 1;
             } else {
-                gat_layer_kernel<true, false><<<layer_grid, 512, 0, s>>>(db.h[cur], skipb[cur], scoreb[cur], nullptr, nullptr, nullptr, emb,
+                GAT_LAUNCH(true, false, db.h[cur], skipb[cur], scoreb[cur], nullptr, nullptr, nullptr, emb,
                                                                         db.csr.row_ptr, db.csr.src, w, n, nullptr, nullptr, w0,
                                                                         fold ? d_pw_ : nullptr);
             }
         }
+#undef GAT_LAUNCH
         db.final_h = cur;
         db.tap = skipb[cur];  // ELU output of layer 3
         db.tap_dim = GAT_F;
@@ -530,11 +646,17 @@ public:
 
 private:
     void free_all() {
-        float** ptrs[] = {&d_lin0_, &d_asrc_, &d_atgt_, &d_wskip_, &d_wlin_, &d_pw_, &d_pb_};
+        float** ptrs[] = {&d_lin0_, &d_asrc_, &d_atgt_, &d_wskip_, &d_wlin_, &d_pw_, &d_pb_, &d_wskip_s_, &d_wlin_s_};
         for (auto p : ptrs)
             if (*p) { (void)hipFree(*p); *p = nullptr; }
     }
     bool ready_ = false;
+    // the two 64 x 64 contractions per layer as split-f16 products unless FLOWGNN_GAT_MFMA=f32; exact_ = the engine asked for the
+    // fp32 pipe after an operand left the split's accurate range (flowgnn_sync)
+    bool split_ = !(getenv("FLOWGNN_GAT_MFMA") && strcmp(getenv("FLOWGNN_GAT_MFMA"), "f32") == 0);
+    bool exact_ = false;
+    float wskip_scale_[GAT_L] = {}, wlin_scale_[GAT_L] = {};
+    float *d_wskip_s_ = nullptr, *d_wlin_s_ = nullptr;
     bool fold_readout_ = !(getenv("FLOWGNN_GAT_FOLD_READOUT") && atoi(getenv("FLOWGNN_GAT_FOLD_READOUT")) == 0);
     float *d_lin0_ = nullptr, *d_asrc_ = nullptr, *d_atgt_ = nullptr, *d_wskip_ = nullptr, *d_wlin_ = nullptr, *d_pw_ = nullptr,
           *d_pb_ = nullptr;

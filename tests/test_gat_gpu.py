@@ -83,3 +83,26 @@ def test_full_molhiv_size_properties(eng, oracle, w):
     idx = np.random.default_rng(0).choice(4113, 128, replace=False)
     sample = gp.concat_batches([b.slice(int(g), int(g) + 1) for g in idx])
     assert close(out[idx], oracle.gat_forward(sample, [w], nthreads=8), 10.0)
+
+
+def test_split_range_fallback(oracle, w):
+    """Same contract as the other models: the split-f16 contractions of gat_layer_kernel raise the range flag when an
+    operand leaves the f16 range and the engine repeats the pass on the fp32-MFMA variant.  The huge activations are made
+    where nothing exponentiates them: layer 3's skip projection is scaled up and layer 4's linear projection is zeroed
+    (all its scores are then 0)."""
+    b = gp.synth_molhiv_batch(48, seed=53)
+    e = Engine("GAT", device=0)
+    try:
+        e.set_weights(w)
+        got, want = e.forward(b), oracle.gat_forward(b, [w], nthreads=8)
+        assert e.exact_reruns() == 0 and np.allclose(got, want, rtol=2e-4, atol=2e-4 * max(1.0, np.abs(want).max()))
+        big = {k: v.copy() for k, v in w.items()}
+        big["skip_proj_weights"][3] *= np.float32(1e6)
+        big["linear_proj_weights"][4] = 0.0
+        e.set_weights(big)
+        got, want = e.forward(b), oracle.gat_forward(b, [big], nthreads=8)
+        assert np.isfinite(want).all() and np.abs(want).max() > 1e3
+        assert e.exact_reruns() == 1 and np.isfinite(got).all()
+        assert np.allclose(got, want, rtol=2e-4, atol=2e-4 * np.abs(want).max()), np.abs(got - want).max()
+    finally:
+        e.close()
