@@ -17,7 +17,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 KERNELS = {
     "GIN": (1 << 18, "gin", {"gin_layer_fused": "gin_layer_split_kernel", "gin_aggregate": "gin_aggregate_tiled_kernel"}),
     "GCN": (1 << 18, "GCN", {"gcn_layer_fused": "gcn_layer_fused_kernel<false>", "gcn_aggregate": "tiled_aggregate_kernel<fg::GcnAggPolicy"}),
-    "GAT": (1 << 18, "GAT", {"gat_layer": "gat_layer_kernel<false, false>"}),
+    "GAT": (1 << 18, "GAT", {"gat_layer": "gat_layer_kernel<false, false"}),
     "PNA": (1 << 15, "PNA", {"pna_aggregate": "tiled_aggregate_kernel<fg::PnaAggPolicy", "pna_dense": "pna_dense_split_kernel"}),
     "DGN": (1 << 15, "DGN", {"dgn_aggregate": "tiled_aggregate_kernel<fg::DgnAggPolicy", "dgn_dense": "dense200_res_relu_split_kernel"}),
 }
