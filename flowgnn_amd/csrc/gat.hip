@@ -298,9 +298,8 @@ __global__ __launch_bounds__(512, 4) void gat_layer_kernel(const float* __restri
         if (FIRST) {
             // layer 0: the skip input is the raw integer feature vector (element 4 d of the 64-float row holds feature d < 9,
             // everything else is zero), read from the 36-byte feature row instead of a 256-byte row the encoder would write
-            const int d = 4 * q + g;
-            const long long frow = feat_row ? feat_row[node] : node;
-            bq[4 * q + 0] = d < ND_FEATURE ? (float)node_feature[(size_t)frow * ND_FEATURE + d] : 0.0f;
+            const int d = 4 * q + g;  // (the tile's feature rows are in LDS since the projection pass)
+            bq[4 * q + 0] = d < ND_FEATURE ? (float)s_feat[(wv * 16 + j) * ND_FEATURE + d] : 0.0f;
             bq[4 * q + 1] = 0.0f; bq[4 * q + 2] = 0.0f; bq[4 * q + 3] = 0.0f;
         } else {
             const float4 x = *reinterpret_cast<const float4*>(skipin + (size_t)node * GAT_F + 16 * q + 4 * g);
