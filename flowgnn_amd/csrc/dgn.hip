@@ -26,28 +26,6 @@ constexpr int DGN_C = DGN_D / 4;
 constexpr int DGN_OT = 7;
 constexpr int DGN_TBL = 119;
 
-__global__ __launch_bounds__(256) void dgn_encoder_kernel(const int* __restrict__ node_feature,
-                                                           const float* __restrict__ table,  // [9][119][100]
-                                                           float* __restrict__ h, int n_tot, int* __restrict__ err) {
-    constexpr int C = DGN_C;
-    const long long total = (long long)n_tot * C;
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-        const int v = (int)(i / C);
-        const int c = (int)(i - (long long)v * C);
-        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-        for (int k = 0; k < ND_FEATURE; k++) {
-            int f = node_feature[(size_t)v * ND_FEATURE + k];
-            if (f < 0 || f >= c_nd_card[k]) {
-                atomicMax(err, ERR_NODE_FEAT);
-                f = 0;
-            }
-            const float4 w = reinterpret_cast<const float4*>(table)[((size_t)k * DGN_TBL + f) * C + c];
-            s.x += w.x; s.y += w.y; s.z += w.z; s.w += w.w;
-        }
-        stream_store4(reinterpret_cast<float4*>(h) + i, s);
-    }
-}
 
 // z[v] = [a1 | a2]: policy of the generic tiled aggregation (device_common.h).  The directional weight of an edge
 // is eig1[u] - eig1[v]: the source half is staged per CSR entry, the destination half is read once per item.
@@ -160,7 +138,15 @@ public:
     // host tensors (DGN/src/dcl.h:81-90): atom tables [9][119][100], layer W [4][100][200], b [4][100],
     // FC0 w [50][100] b [50], FC1 w [25][50] b [25], FC2 w [1][25] b [1]
     int set_weights(const float* const* t) override {
-        std::vector<float> v_emb(t[0], t[0] + (size_t)9 * DGN_TBL * DGN_D);
+        // The reference indexes a dense [9][119][100] table (DGN/src/load_inputs.cc:124-137), but a feature k only takes values
+        // below its cardinality (validated on the device): the 173 rows that can be addressed are gathered into the compact
+        // [173][100] table the other models use (row = offset_k + value), which fits LDS (69 KB) -- the encoder then reads its nine
+        // rows per node from LDS instead of L2 (0.37 -> 0.13 ms for 2^15 hep10k graphs).
+        static const int nd_card[ND_FEATURE] = {119, 4, 12, 12, 10, 6, 6, 2, 2}, nd_off[ND_FEATURE] = {0, 119, 123, 135, 147, 157, 163, 169, 171};
+        std::vector<float> v_emb((size_t)ND_FEATURE_TOTAL * DGN_D);
+        for (int k = 0; k < ND_FEATURE; k++)
+            for (int f = 0; f < nd_card[k]; f++)
+                memcpy(&v_emb[(size_t)(nd_off[k] + f) * DGN_D], t[0] + ((size_t)k * DGN_TBL + f) * DGN_D, sizeof(float) * DGN_D);
         std::vector<float> v_w0(t[3], t[3] + 50 * 100), v_b0(t[4], t[4] + 50), v_w1(t[5], t[5] + 25 * 50), v_b1(t[6], t[6] + 25),
             v_w2(t[7], t[7] + 25), v_b2(t[8], t[8] + 1);
         std::vector<float> wf_all, wt_all, bp_all;
@@ -239,8 +225,7 @@ public:
         if (!db.node_eigen) return 1;
         {
             ProfScope p(prof, "atom_encoder", s);
-            dgn_encoder_kernel<<<grid_for((long long)n * DGN_C, 256, 256 * 8), 256, 0, s>>>(db.b.node_feature, d_emb_, db.h[0], n,
-                                                                                          db.csr.err);
+            atom_encoder_kernel<DGN_D><<<atom_encoder_grid(n, DGN_C), 512, 0, s>>>(db.b.node_feature, d_emb_, db.h[0], n, db.csr.err);
         }
         if (int rc = make_tile_bounds(tiles_, db.b.node_off, db.b.num_graphs, n, tile_nominal_, tile_slack_, s)) return rc;
         if (db.b.e_tot > 0) {  // eig1[src_e] per CSR entry, once per pass
