@@ -55,5 +55,12 @@ def test_random_batches_match_the_oracle(model, oracle):
             assert np.isfinite(want).all(), (model, seed)
             scale = max(1.0, float(np.abs(hd).max()))
             assert np.allclose(got, want, rtol=2e-4, atol=2e-4 * scale), (model, seed, np.abs(got - want).max(), scale)
+            if model == "GIN":  # the index build is bit-exact: stable order by (destination, source, input index)
+                row_ptr, src, eid, out_deg = e.csr()
+                ge = b.global_edges()
+                order = np.lexsort((np.arange(len(ge)), ge[:, 0], ge[:, 1]))
+                assert np.array_equal(eid, order) and np.array_equal(src, ge[order, 0])
+                assert np.array_equal(row_ptr, np.concatenate([[0], np.cumsum(np.bincount(ge[:, 1], minlength=b.total_nodes))]))
+                assert np.array_equal(out_deg, np.bincount(ge[:, 0], minlength=b.total_nodes))
     finally:
         e.close()
