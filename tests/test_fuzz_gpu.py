@@ -64,3 +64,20 @@ def test_random_batches_match_the_oracle(model, oracle):
                 assert np.array_equal(out_deg, np.bincount(ge[:, 0], minlength=b.total_nodes))
     finally:
         e.close()
+
+
+def test_random_batches_q6_10_bit_exact(oracle):
+    """The Q6.10 mode on the same kind of batches: integer patterns, so the GPU must equal the C oracle bit for bit."""
+    w = weights.synth_gin_weights(seed=11)
+    e = Engine("GIN", device=0)
+    try:
+        e.set_weights(w)
+        e.set_numeric_mode("q6.10")
+        for seed in range(4):
+            b = random_batch(1000 + seed, eigen=False)
+            got = e.forward(b)
+            want_f, want_q = oracle.gin_forward_q(b, [w], nthreads=8)
+            assert np.array_equal(got, want_f), (seed, np.abs(got - want_f).max())
+            assert np.array_equal(np.rint(got.astype(np.float64) * 1024).astype(np.int64), want_q.astype(np.int64))
+    finally:
+        e.close()
