@@ -1,13 +1,19 @@
 #!/usr/bin/env python3
 """bench.py -- graphs/s of the GIN (dim 100) hot path on molhiv-shaped synthetic graphs.
 
-    python bench.py --gpus N --steps K --warmup W [--graphs G_PER_GPU]
+    python bench.py --gpus N --steps K --warmup W [--model M] [--graphs G] [--scaling weak|strong]
 
 A "step" = one full batched forward of the resident batch through the C ABI (flowgnn_run):
 batched load_graph (CSR build) -> atom encoder -> 5 x (aggregation + node MLP) -> mean-pool +
-head, for G_PER_GPU graphs per GPU (weak scaling), followed for N > 1 by the RCCL all-gather that
-concatenates the per-graph results.  Inputs are resident in HBM when the timed region starts (the
-reference also times kernel execution only: run_experiments.sh:44).  Rank 0 prints ONE JSON line.
+head, for G graphs per GPU (weak scaling, default) or G graphs in the whole job cut by sum(N+E)
+(strong scaling), followed for N > 1 by the RCCL all-gather that concatenates the per-graph results.
+Inputs are resident in HBM when the timed region starts (the reference also times kernel execution
+only: run_experiments.sh:44).  Rank 0 prints ONE JSON line, which carries `roofline`, `cpu_baseline`
+(N = 1) and `parity` (GPU logits of the timed batch vs the oracle).
+
+Run plainly with --gpus N > 1 it starts the N ranks itself (one process per GPU, 127.0.0.1
+rendezvous); under torchrun it uses the launcher's RANK / LOCAL_RANK / WORLD_SIZE.  It refuses to
+run when the rank count or the visible GPU count differs from --gpus.
 
 The default batch is the "roofline batch" of SURVEY 8d: 2^18 graphs per GPU, so that every
 [N_tot][100] fp32 tensor (2.7 GB) is far larger than the 256 MiB Infinity Cache.
@@ -111,7 +117,7 @@ def effective_cpus() -> int:
 
 def cpu_baseline(model, batch, w, budget_s: float = 15.0, numeric: str = "f32"):
     """The oracle (CPU restatement of the reference, kind='port') timed on this host's cores on a
-    bounded sample of the same workload."""
+    bounded sample of the same workload.  Returns (record, oracle logits of the sample)."""
     cores = effective_cpus()
     probe = batch.slice(0, min(128, batch.num_graphs))
     t0 = time.perf_counter()
@@ -127,12 +133,115 @@ def cpu_baseline(model, batch, w, budget_s: float = 15.0, numeric: str = "f32"):
     n = int(min(batch.num_graphs, max(256, ratep * budget_s)))
     sample = batch.slice(0, n)
     t0 = time.perf_counter()
-    oracle_forward(model, sample, w, cores, numeric)
+    logits = oracle_forward(model, sample, w, cores, numeric)
     t1 = time.perf_counter()
-    return {"value": n / (t1 - t0), "unit": "graphs/s", "cores": cores, "kind": "port",
-            "sample": f"first {n} graphs of the bench batch, oracle/{'ginq' if numeric == 'q6.10' else model.lower().replace('-vn', '')}_oracle.c, "
-                      f"OpenMP over graphs, {cores} threads",
-            "single_core_value": rate1}
+    rec = {"value": n / (t1 - t0), "unit": "graphs/s", "cores": cores, "kind": "port",
+           "sample": f"first {n} graphs of the bench batch, oracle/{'ginq' if numeric == 'q6.10' else model.lower().replace('-vn', '')}_oracle.c, "
+                     f"OpenMP over graphs, {cores} threads",
+           "single_core_value": rate1}
+    return rec, np.asarray(logits, dtype=np.float32)
+
+
+# parity of the timed batch against the oracle: |gpu - oracle| <= PARITY_ATOL + PARITY_RTOL |oracle| (the tolerance of tests/test_*_gpu.py;
+# GIN / GCN: 1e-4 + 1e-4 |x|; the models with divisions / exp / cancellation carry 2e-4 relative to the activation scale)
+PARITY_TOL = {"GIN": (1e-4, 1e-4), "GIN-VN": (2e-4, 1e-3), "GCN": (1e-4, 1e-4), "GAT": (2e-4, 2e-4), "PNA": (2e-4, 2e-3), "DGN": (2e-4, 2e-3)}
+
+
+def parity_record(model, got, want, numeric="f32"):
+    got, want = np.asarray(got, np.float32), np.asarray(want, np.float32)
+    err = np.abs(got.astype(np.float64) - want.astype(np.float64))
+    if numeric != "f32":
+        return {"graphs": int(want.shape[0]), "max_abs_err": float(err.max()) if err.size else 0.0, "tol": "bit-exact (Q patterns)",
+                "ok": bool(np.array_equal(got, want))}
+    rtol, atol = PARITY_TOL[model]
+    scale = max(1.0, float(np.abs(want).max())) if want.size else 1.0
+    bound = atol * (scale if model in ("GAT", "PNA", "DGN") else 1.0) + rtol * np.abs(want)
+    return {"graphs": int(want.shape[0]), "max_abs_err": float(err.max()) if err.size else 0.0,
+            "max_abs_oracle": float(np.abs(want).max()) if want.size else 0.0,
+            "tol": f"{atol:g}{' x activation scale' if model in ('GAT', 'PNA', 'DGN') else ''} + {rtol:g}|x|",
+            "ok": bool((err <= bound).all() and np.isfinite(got).all())}
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# multi-GPU plumbing: one process per GPU, graphs are the only parallel dimension
+# ---------------------------------------------------------------------------------------------------------------------
+def plan_job(dataset: str, graphs: int, world: int, rank: int, scaling: str, make=None):
+    """The graphs this rank carries in one step, and where they sit in the job.
+    weak   : `graphs` graphs PER GPU, each rank its own synthetic shard (seed 1234 + rank): per-GPU work fixed as N grows.
+    strong : ONE job batch of `graphs` graphs (seed 1234) cut into contiguous ranges balanced by sum(N + E)
+             (flowgnn_amd.dist.shard_ranges); ragged shards, total work fixed.
+    Returns (local batch, ranges [(g0, g1)] in job order, balance record or None)."""
+    from flowgnn_amd import dist as fdist
+    make = make or make_batch
+    if scaling == "weak" or world == 1:
+        return make(dataset, graphs, 1234 + rank), [(r * graphs, (r + 1) * graphs) for r in range(world)], None
+    job = make(dataset, graphs, 1234)
+    ranges = fdist.shard_ranges(job, world)
+    work = job.nums_of_nodes.astype(np.int64) + job.nums_of_edges.astype(np.int64)
+    loads = [int(work[a:b].sum()) for a, b in ranges]
+    mean = sum(loads) / world
+    g0, g1 = ranges[rank]
+    return job.slice(g0, g1), ranges, {"graphs_per_rank": [b - a for a, b in ranges], "node_plus_edge_load_per_rank": loads,
+                                       "imbalance_max_over_mean": max(loads) / mean if mean else 1.0}
+
+
+class ShardedResults:
+    """Result concat of the job: every rank's readout kernel writes its per-graph logits into `pad` (width = widest
+    shard), ONE all_gather_into_tensor per step concatenates them (RCCL over xGMI on GPUs, gloo in the CPU test)."""
+
+    def __init__(self, ranges, rank, device, dist_mod):
+        import torch
+        self.ranges, self.rank, self.dist = ranges, rank, dist_mod
+        self.world = len(ranges)
+        self.width = max(1, max(b - a for a, b in ranges))
+        self.pad = torch.zeros(self.width, dtype=torch.float32, device=device)
+        self.all = torch.empty(self.world * self.width, dtype=torch.float32, device=device) if self.world > 1 else self.pad
+
+    def local_count(self):
+        a, b = self.ranges[self.rank]
+        return b - a
+
+    def gather(self):
+        if self.world > 1:
+            self.dist.all_gather_into_tensor(self.all, self.pad)
+
+    def assemble(self):
+        """Logits of the whole job in job order (ragged shards trimmed)."""
+        import torch
+        rows = self.all.view(self.world, self.width)
+        return torch.cat([rows[r, : b - a] for r, (a, b) in enumerate(self.ranges)])
+
+
+def launch_ranks(n: int, argv):
+    """`python bench.py --gpus N` run plainly (no launcher): start the N ranks ourselves, one process per GPU."""
+    import socket
+    import subprocess
+    import torch
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if have < n:
+        raise SystemExit(f"bench.py: --gpus {n} requested but {have} GPU(s) visible; refusing to benchmark fewer GPUs than asked for")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env))
+    rc = 0
+    live = list(procs)
+    while live:
+        for p in list(live):
+            code = p.poll()
+            if code is None:
+                continue
+            live.remove(p)
+            if code != 0 and rc == 0:
+                rc = code
+                for q in live:  # one rank failed: stop exactly the processes we started
+                    q.terminate()
+        time.sleep(0.05)
+    raise SystemExit(rc)
 
 
 def main():
@@ -141,21 +250,30 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--model", default="GIN", choices=sorted(MODELS))
-    ap.add_argument("--graphs", type=int, default=0, help="graphs per GPU per step (default: the model's roofline batch)")
+    ap.add_argument("--graphs", type=int, default=0,
+                    help="graphs per GPU per step (weak scaling; default: the model's roofline batch) or in the whole job (strong scaling)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: fixed graphs per GPU; strong: ONE job batch cut by sum(N+E) with flowgnn_amd.dist.shard_ranges")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--numeric", default="f32", choices=["f32", "q6.10"],
-                    help="q6.10: the reference's ap_fixed<16,6> bit-faithful mode (GIN / GIN-VN only; a fidelity mode, ~10x slower)")
+                    help="q6.10: the reference's ap_fixed<16,6> bit-faithful mode (a fidelity mode, ~10x slower)")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
 
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: what RCCL needs on this driver (already exported on the pool)
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        launch_ranks(args.gpus, sys.argv[1:])  # does not return
     import torch
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: refusing to report a number for a different GPU count")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    if torch.cuda.device_count() <= local_rank:
+        raise SystemExit(f"rank {rank}: LOCAL_RANK={local_rank} but {torch.cuda.device_count()} GPU(s) visible")
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
@@ -167,7 +285,7 @@ def main():
 
     M = MODELS[args.model]
     graphs = args.graphs or M["graphs"]
-    batch = make_batch(M["dataset"], graphs, seed=1234 + rank)  # each rank its own shard of the job
+    batch, ranges, balance = plan_job(M["dataset"], graphs, world, rank, args.scaling)
     w = weights.SYNTH[args.model](seed=7)
     eng = Engine(args.model, device=local_rank)
     eng.set_weights(w)
@@ -176,45 +294,50 @@ def main():
     eng.set_batch(batch)
     G, N, E = batch.num_graphs, batch.total_nodes, batch.total_edges
 
-    out_local = torch.empty(G, dtype=torch.float32, device="cuda")
-    eng.set_results_buffer(out_local.data_ptr())
-    out_all = torch.empty(G * world, dtype=torch.float32, device="cuda") if world > 1 else out_local
+    # The engine launches on the torch stream the collective orders itself against, so "forward, then all-gather" needs
+    # no host synchronisation: the gather waits for the readout kernel on the device, and the next step's readout for the
+    # gather (flowgnn_set_stream).
+    side = torch.cuda.Stream()
+    res = ShardedResults(ranges, rank, "cuda", dist)
+    eng.set_stream(side.cuda_stream)
+    eng.set_results_buffer(res.pad.data_ptr())
 
     def step():
         eng.run()
+        res.gather()
+
+    with torch.cuda.stream(side):
+        for _ in range(args.warmup):
+            step()
+        eng.sync()
+        eng.profile_enable(True)  # HIP events around every kernel launch, on the stream the kernels are launched on
         if world > 1:
-            eng.sync()  # results complete before the collective reads them
-            dist.all_gather_into_tensor(out_all, out_local)
-            torch.cuda.current_stream().synchronize()  # ... and the gather done before the next step's readout rewrites them
-
-    for _ in range(args.warmup):
-        step()
-    eng.sync()
-    eng.profile_enable(True)  # HIP events around every kernel launch, on the engine's stream
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    eng.sync()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    t1 = time.perf_counter()
-    elapsed = t1 - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    prof = eng.profile_read()
-    eng.profile_enable(False)
-
-    ok = bool(torch.isfinite(out_all).all().item())
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        eng.sync()  # inside the clock: stream sync + validation / range flags (an exact-fp32 re-run, if any, is timed too)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        t1 = time.perf_counter()
+        elapsed = t1 - t0
+        if world > 1:
+            t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        prof = eng.profile_read()
+        eng.profile_enable(False)
+        logits_all = res.assemble()
+        ok = bool(torch.isfinite(logits_all).all().item())
+        out_local = res.pad[:G].detach().cpu().numpy()
+    total_job_graphs = ranges[-1][1]
+    if int(logits_all.shape[0]) != total_job_graphs:
+        raise SystemExit(f"result concat has {int(logits_all.shape[0])} graphs, the job has {total_job_graphs}")
 
     if rank == 0:
-        total_graphs = G * world * args.steps  # every rank carries the same number of graphs
-        value = total_graphs / elapsed
+        value = total_job_graphs * args.steps / elapsed
         agg_bytes, mlp_flops = M["agg_bytes"](N, E), M["flops"](N, E)
         kern = {k: (v["total_ms"] / max(v["launches"], 1)) for k, v in prof.items()}
         layer = {k: v for k, v in prof.items() if k in M["hbm_kernels"] + M["mfma_kernels"]}
@@ -222,7 +345,10 @@ def main():
         agg_name = M["hbm_kernels"][0]
         qmode = args.numeric != "f32"
         if agg_name not in kern and not qmode:  # fused layer: measure the message-passing unit alone as well
-            kern[agg_name] = eng.aggregation_only_ms(layer=0, iters=10)
+            try:
+                kern[agg_name] = eng.aggregation_only_ms(layer=0, iters=10)
+            except Exception:  # a model without a standalone aggregation kernel
+                pass
 
         traffic_db = {}
         try:
@@ -236,6 +362,8 @@ def main():
             return (traffic_db.get(name) or {}).get("bytes")
 
         def hbm_obj(name):
+            if name not in kern:
+                return None
             ach = agg_bytes / (kern[name] * 1e-3) / 1e9
             return {"kernel": name, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": ach / HBM_PEAK_GBS, "traffic": traffic_of(name), "avg_ms": kern[name], "bytes_per_launch": agg_bytes}
@@ -248,48 +376,63 @@ def main():
         if dominant in M["hbm_kernels"]:
             roof = hbm_obj(dominant)
         elif dominant is not None:
+            launches_per_step = prof[dominant]["launches"] / max(args.steps, 1)
+            layers_per_launch = M.get("layers_per_launch", {}).get(dominant, 1)
             t_s = kern[dominant] * 1e-3
+            work_flops = mlp_flops * layers_per_launch
             if split:
                 # three f16 products per algorithmic fp32 product, priced against the f16 pipe the kernel uses
-                ach, peak = 3 * mlp_flops / t_s / 1e12, F16_MFMA_PEAK_TF
+                ach, peak = 3 * work_flops / t_s / 1e12, F16_MFMA_PEAK_TF
                 mfma = {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
-                        "pipe": "f16 (3 products per fp32 product, fp32 accumulate)", "flops_per_launch": 3 * mlp_flops,
-                        "fp32_equivalent_tflops": mlp_flops / t_s / 1e12}
+                        "pipe": "f16 (3 products per fp32 product, fp32 accumulate)", "flops_per_launch": 3 * work_flops,
+                        "fp32_equivalent_tflops": work_flops / t_s / 1e12}
             else:
-                ach = mlp_flops / t_s / 1e12
+                ach = work_flops / t_s / 1e12
                 mfma = {"bound": "mfma", "achieved": ach, "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s",
-                        "frac": ach / FP32_MFMA_PEAK_TF, "pipe": "f32", "flops_per_launch": mlp_flops}
-            if split and "fused_bytes" in M:
+                        "frac": ach / FP32_MFMA_PEAK_TF, "pipe": "f32", "flops_per_launch": work_flops}
+            fbf = M.get("fused_bytes")
+            fbf = fbf.get(dominant) if isinstance(fbf, dict) else fbf
+            if split and fbf is not None and dominant not in M.get("mfma_bound_kernels", ()):
                 # with the f16 pipe the fused layer's HBM floor (0.7 ms) is above its MFMA floor (0.6 ms): HBM-bound
-                fbf = M["fused_bytes"]
-                fb = (fbf[dominant] if isinstance(fbf, dict) else fbf)(N, E)
+                fb = fbf(N, E)
                 ach = fb / t_s / 1e9
                 roof = {"kernel": dominant, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": ach / HBM_PEAK_GBS, "traffic": traffic_of(dominant), "avg_ms": kern[dominant],
                         "bytes_per_launch": fb, "mfma": mfma}
             else:
-                roof = dict({"kernel": dominant, "traffic": None, "avg_ms": kern[dominant]}, **mfma)
+                roof = dict({"kernel": dominant, "traffic": traffic_of(dominant), "avg_ms": kern[dominant],
+                             "launches_per_step": launches_per_step}, **mfma)
+                if fbf is not None:
+                    roof["hbm_bytes_per_launch"] = fbf(N, E)
         agg = hbm_obj(agg_name) if not qmode else None
         if qmode:
             roof = None  # integer VALU work (one truncated product at a time): neither of the two rooflines applies
+        par = f"batch-sharded x{world}, RCCL all-gather of logits" if world > 1 else "single GPU"
         line = {
             "metric": M["metric"],
             "value": value, "unit": "graphs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling if world > 1 else "weak",
             "vs_baseline": None, "dtype": "f32" if not qmode else "q6.10 (int16 patterns of ap_fixed<16,6>)", "data": "synthetic",
             "mfma_mode": ("f16x3-split (fp32-accurate; exact-f32 re-run on range overflow)" if split else "f32") if not qmode else None,
             "config": {"workload": M["workload"],
-                       "graphs_per_gpu_per_step": G, "nodes_per_gpu": N, "edges_per_gpu": E,
-                       "parallelism": f"batch-sharded x{world}, RCCL all-gather of logits"},
+                       "graphs_per_step_job": total_job_graphs, "graphs_rank0": G, "nodes_rank0": N, "edges_rank0": E,
+                       "parallelism": par},
             "finite": ok, "exact_reruns": eng.exact_reruns(),
             "roofline": roof,
             "aggregation_roofline": agg,
             "kernel_avg_ms": kern,
             "vs_fpga_u50": (value / FPGA_U50_GRAPHS_PER_S) if args.model == "GIN" else None,
         }
+        if balance is not None:
+            line["shard_balance"] = balance
+        want = None
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(args.model, batch, w, numeric=args.numeric)
+            line["cpu_baseline"], want = cpu_baseline(args.model, batch, w, numeric=args.numeric)
             line["gpu_over_cpu"] = value / line["cpu_baseline"]["value"]
+        else:  # no timed CPU leg: still check a slice of rank 0's shard of the timed batch against the oracle
+            n = min(G, 4096)
+            want = np.asarray(oracle_forward(args.model, batch.slice(0, n), w, effective_cpus(), args.numeric), np.float32)
+        line["parity"] = parity_record(args.model, out_local[: want.shape[0]], want, args.numeric)
         print(json.dumps(line), flush=True)
     eng.close()
     if world > 1:

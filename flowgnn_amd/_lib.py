@@ -52,6 +52,8 @@ def _declare(lib):
     lib.flowgnn_profile_read.argtypes = [eng, p_int, C.POINTER(C.c_char_p), C.POINTER(C.c_double),
                                          C.POINTER(C.c_longlong)]
     lib.flowgnn_run_aggregation_only.argtypes = [eng, C.c_int, C.c_int, p_float]
+    lib.flowgnn_get_aggregate.argtypes = [eng, C.c_int, p_float, p_int, p_float, p_int]
+    lib.flowgnn_set_stream.argtypes = [eng, C.c_void_p, C.c_int]
     lib.GIN_compute_graphs.argtypes = [C.c_int, p_int, p_int, p_int, p_float, p_int, p_int, p_int] + [p_float] * 8
     lib.PNA_compute_graphs.argtypes = [C.c_int, p_int, p_int, p_int, p_float, p_int, p_int] + [p_float] * 10
     lib.DGN_compute_graphs.argtypes = [C.c_int, p_int, p_int, p_int, p_float, p_int, p_float, p_int] + [p_float] * 9
@@ -61,7 +63,7 @@ def _declare(lib):
                  "flowgnn_set_batch", "flowgnn_run", "flowgnn_sync", "flowgnn_get_results",
                  "flowgnn_results_device", "flowgnn_set_results_buffer", "flowgnn_stream", "flowgnn_batch_info", "flowgnn_exact_reruns", "flowgnn_set_numeric_mode", "flowgnn_get_csr",
                  "flowgnn_get_h", "flowgnn_profile_enable", "flowgnn_profile_read",
-                 "flowgnn_run_aggregation_only", "GIN_compute_graphs", "GCN_compute_graphs", "PNA_compute_graphs", "DGN_compute_graphs", "GAT_compute_graphs"):
+                 "flowgnn_run_aggregation_only", "flowgnn_get_aggregate", "flowgnn_set_stream", "GIN_compute_graphs", "GCN_compute_graphs", "PNA_compute_graphs", "DGN_compute_graphs", "GAT_compute_graphs"):
         getattr(lib, name).restype = C.c_int
 
 

@@ -141,6 +141,8 @@ public:
     virtual bool weights_ready() const = 0;
     virtual int forward(DeviceBatch& db, Profiler& prof, hipStream_t s) = 0;
     virtual int aggregation_only(DeviceBatch& db, int layer, hipStream_t s) { (void)db; (void)layer; (void)s; return 8; }
+    // floats per node that aggregation_only() writes to db.scratch (0: the model has no standalone aggregation kernel)
+    virtual int aggregate_dim() const { return 0; }
 };
 
 Model* make_gin_model();
@@ -153,8 +155,17 @@ Model* make_gat_model();
 int read_floats(const char* dir, const char* file, size_t offset_floats, size_t count, float* dst);
 template <typename T>
 int upload(T** dptr, const std::vector<T>& host) {
-    if (*dptr) { (void)hipFree(*dptr); *dptr = nullptr; }
-    FG_HIP_TRY(hipMalloc((void**)dptr, sizeof(T) * (host.empty() ? 1 : host.size())));
+    const size_t want = sizeof(T) * (host.empty() ? 1 : host.size());
+    if (*dptr) {  // keep the buffer when its size is unchanged: a weight reload must not churn the allocator
+        hipDeviceptr_t base = nullptr;
+        size_t have = 0;
+        if (hipMemGetAddressRange(&base, &have, (hipDeviceptr_t)*dptr) != hipSuccess || base != (hipDeviceptr_t)*dptr || have != want) {
+            (void)hipGetLastError();
+            (void)hipFree(*dptr);
+            *dptr = nullptr;
+        }
+    }
+    if (!*dptr) FG_HIP_TRY(hipMalloc((void**)dptr, want));
     if (!host.empty()) FG_HIP_TRY(hipMemcpy(*dptr, host.data(), sizeof(T) * host.size(), hipMemcpyHostToDevice));
     return 0;
 }

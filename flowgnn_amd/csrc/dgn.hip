@@ -131,6 +131,7 @@ public:
     ~DgnModel() override { free_all(); }
     int emb_dim() const override { return DGN_D; }
     int scratch_dim() const override { return 2 * DGN_D; }
+    int aggregate_dim() const override { return 2 * DGN_D; }
     bool has_edge_attr() const override { return false; }
     int num_weight_tensors() const override { return 9; }
     bool weights_ready() const override { return ready_; }

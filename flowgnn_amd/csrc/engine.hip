@@ -91,7 +91,8 @@ using namespace fg;
 struct flowgnn_engine {
     int model_id = 0;
     int device = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;      // the stream every launch goes to
+    hipStream_t own_stream = nullptr;  // the engine's own stream (stream == own_stream unless flowgnn_set_stream redirected it)
     Model* model = nullptr;
     Profiler prof;
     std::string err;
@@ -155,6 +156,18 @@ struct flowgnn_engine {
         if (_rc) { (e)->err = fg::last_error_text(); return _rc; } \
     } while (0)
 
+// HIP call made in an engine context: the failure text goes to the thread-local slot AND to the engine, so
+// flowgnn_last_error(e) always reports the latest failure (never a stale earlier one)
+#define EHIP_TRY(e, expr)                                                   \
+    do {                                                                    \
+        hipError_t _he = (expr);                                            \
+        if (_he != hipSuccess) {                                            \
+            fg::set_hip_error(#expr, _he, __FILE__, __LINE__);              \
+            (e)->err = fg::last_error_text();                               \
+            return FLOWGNN_ERR_HIP;                                         \
+        }                                                                   \
+    } while (0)
+
 static int use_device(flowgnn_engine* e) {
     FG_HIP_TRY(hipSetDevice(e->device));
     return 0;
@@ -181,7 +194,8 @@ int flowgnn_create(int model, int device_id, flowgnn_engine** out) {
     e->model = m;
     int rc = use_device(e);
     if (!rc) {
-        hipError_t he = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
+        hipError_t he = hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking);
+        e->stream = e->own_stream;
         if (he == hipSuccess) he = hipMalloc((void**)&e->d_err, 2 * sizeof(int));  // [0] validation, [1] range flag
         if (he == hipSuccess) he = hipMemset(e->d_err, 0, 2 * sizeof(int));
         if (he != hipSuccess) {
@@ -207,7 +221,7 @@ int flowgnn_destroy(flowgnn_engine* e) {
     e->free_batch();
     if (e->d_err) (void)hipFree(e->d_err);
     delete e->model;
-    if (e->stream) (void)hipStreamDestroy(e->stream);
+    if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
     delete e;
     return FLOWGNN_OK;
 }
@@ -228,7 +242,7 @@ int flowgnn_set_weights_gin(flowgnn_engine* e, const float* node_embedding_weigh
         if (!p) return FLOWGNN_ERR_ARG;
     ENGINE_TRY(e, use_device(e));
     e->drop_graph();
-    if (e->stream) FG_HIP_TRY(hipStreamSynchronize(e->stream));
+    if (e->stream) EHIP_TRY(e, hipStreamSynchronize(e->stream));
     ENGINE_TRY(e, e->model->set_weights(t));
     return FLOWGNN_OK;
 }
@@ -239,7 +253,7 @@ int flowgnn_set_weights(flowgnn_engine* e, int count, const float* const* tensor
         if (!tensors[i]) return FLOWGNN_ERR_ARG;
     ENGINE_TRY(e, use_device(e));
     e->drop_graph();
-    if (e->stream) FG_HIP_TRY(hipStreamSynchronize(e->stream));
+    if (e->stream) EHIP_TRY(e, hipStreamSynchronize(e->stream));
     ENGINE_TRY(e, e->model->set_weights(tensors));
     return FLOWGNN_OK;
 }
@@ -248,7 +262,7 @@ int flowgnn_load_weights_dir(flowgnn_engine* e, const char* dir) {
     if (!e || !dir) return FLOWGNN_ERR_ARG;
     ENGINE_TRY(e, use_device(e));
     e->drop_graph();
-    if (e->stream) FG_HIP_TRY(hipStreamSynchronize(e->stream));
+    if (e->stream) EHIP_TRY(e, hipStreamSynchronize(e->stream));
     ENGINE_TRY(e, e->model->load_weights_dir(dir));
     return FLOWGNN_OK;
 }
@@ -258,29 +272,29 @@ static int alloc_batch(flowgnn_engine* e, size_t G, size_t N, size_t E, bool att
     if (G > e->capG || N > e->capN || E > e->capE || (attr && !e->d_ea) || (eig && !e->d_eig)) {
         e->free_batch();
         const size_t g1 = G ? G : 1, n1 = N ? N : 1, e1 = E ? E : 1;
-        FG_HIP_TRY(hipMalloc((void**)&e->d_nn, sizeof(int) * g1));
-        FG_HIP_TRY(hipMalloc((void**)&e->d_ne, sizeof(int) * g1));
-        FG_HIP_TRY(hipMalloc((void**)&e->d_noff, sizeof(int) * (g1 + 1)));
-        FG_HIP_TRY(hipMalloc((void**)&e->d_eoff, sizeof(int) * (g1 + 1)));
-        FG_HIP_TRY(hipMalloc((void**)&e->d_nf, sizeof(int) * n1 * ND_FEATURE));
-        FG_HIP_TRY(hipMalloc((void**)&e->d_el, sizeof(int) * e1 * 2));
-        if (attr) FG_HIP_TRY(hipMalloc((void**)&e->d_ea, sizeof(int) * e1 * EDGE_ATTR));
-        if (eig) FG_HIP_TRY(hipMalloc((void**)&e->d_eig, sizeof(float) * n1 * 4));
-        FG_HIP_TRY(hipMalloc((void**)&e->d_rowptr, sizeof(int) * (n1 + 1)));
-        FG_HIP_TRY(hipMalloc((void**)&e->d_src, sizeof(int) * e1));
-        FG_HIP_TRY(hipMalloc((void**)&e->d_eid, sizeof(int) * e1));
-        FG_HIP_TRY(hipMalloc((void**)&e->d_ecode, sizeof(uint8_t) * e1));
-        FG_HIP_TRY(hipMalloc((void**)&e->d_outdeg, sizeof(int) * n1));
-        FG_HIP_TRY(hipMalloc((void**)&e->d_gsrc, sizeof(int) * e1));
-        FG_HIP_TRY(hipMalloc((void**)&e->d_gdst, sizeof(int) * e1));
-        FG_HIP_TRY(hipMalloc((void**)&e->d_cursor, sizeof(int) * n1));
-        FG_HIP_TRY(hipMalloc((void**)&e->d_tmp, sizeof(int) * e1 * 2));
-        FG_HIP_TRY(hipMalloc((void**)&e->d_bsums, sizeof(int) * (n1 / 2048 + 2)));
+        EHIP_TRY(e, hipMalloc((void**)&e->d_nn, sizeof(int) * g1));
+        EHIP_TRY(e, hipMalloc((void**)&e->d_ne, sizeof(int) * g1));
+        EHIP_TRY(e, hipMalloc((void**)&e->d_noff, sizeof(int) * (g1 + 1)));
+        EHIP_TRY(e, hipMalloc((void**)&e->d_eoff, sizeof(int) * (g1 + 1)));
+        EHIP_TRY(e, hipMalloc((void**)&e->d_nf, sizeof(int) * n1 * ND_FEATURE));
+        EHIP_TRY(e, hipMalloc((void**)&e->d_el, sizeof(int) * e1 * 2));
+        if (attr) EHIP_TRY(e, hipMalloc((void**)&e->d_ea, sizeof(int) * e1 * EDGE_ATTR));
+        if (eig) EHIP_TRY(e, hipMalloc((void**)&e->d_eig, sizeof(float) * n1 * 4));
+        EHIP_TRY(e, hipMalloc((void**)&e->d_rowptr, sizeof(int) * (n1 + 1)));
+        EHIP_TRY(e, hipMalloc((void**)&e->d_src, sizeof(int) * e1));
+        EHIP_TRY(e, hipMalloc((void**)&e->d_eid, sizeof(int) * e1));
+        EHIP_TRY(e, hipMalloc((void**)&e->d_ecode, sizeof(uint8_t) * e1));
+        EHIP_TRY(e, hipMalloc((void**)&e->d_outdeg, sizeof(int) * n1));
+        EHIP_TRY(e, hipMalloc((void**)&e->d_gsrc, sizeof(int) * e1));
+        EHIP_TRY(e, hipMalloc((void**)&e->d_gdst, sizeof(int) * e1));
+        EHIP_TRY(e, hipMalloc((void**)&e->d_cursor, sizeof(int) * n1));
+        EHIP_TRY(e, hipMalloc((void**)&e->d_tmp, sizeof(int) * e1 * 2));
+        EHIP_TRY(e, hipMalloc((void**)&e->d_bsums, sizeof(int) * (n1 / 2048 + 2)));
         // + 4 KiB slack: tile loaders read whole 1 KiB pieces and may run past the last row
-        FG_HIP_TRY(hipMalloc((void**)&e->d_h0, sizeof(float) * n1 * D + 4096));
-        FG_HIP_TRY(hipMalloc((void**)&e->d_h1, sizeof(float) * n1 * D + 4096));
-        FG_HIP_TRY(hipMalloc((void**)&e->d_scratch, sizeof(float) * n1 * (SD > 0 ? SD : 1) + 4096));
-        FG_HIP_TRY(hipMalloc((void**)&e->d_out, sizeof(float) * g1));
+        EHIP_TRY(e, hipMalloc((void**)&e->d_h0, sizeof(float) * n1 * D + 4096));
+        EHIP_TRY(e, hipMalloc((void**)&e->d_h1, sizeof(float) * n1 * D + 4096));
+        EHIP_TRY(e, hipMalloc((void**)&e->d_scratch, sizeof(float) * n1 * (SD > 0 ? SD : 1) + 4096));
+        EHIP_TRY(e, hipMalloc((void**)&e->d_out, sizeof(float) * g1));
         e->capG = G; e->capN = N; e->capE = E;
     }
     return 0;
@@ -321,13 +335,13 @@ int flowgnn_set_batch(flowgnn_engine* e, int num_graphs, const int* nums_of_node
 
     ENGINE_TRY(e, use_device(e));
     e->drop_graph();
-    if (e->stream) FG_HIP_TRY(hipStreamSynchronize(e->stream));
+    if (e->stream) EHIP_TRY(e, hipStreamSynchronize(e->stream));
     e->batch_ready = false;
     e->ran = false;
     ENGINE_TRY(e, alloc_batch(e, (size_t)num_graphs, (size_t)N, (size_t)E, attr, eig));
     auto h2d = [&](void* dst, const void* src, size_t bytes) -> int {
         if (bytes == 0) return 0;
-        FG_HIP_TRY(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
+        EHIP_TRY(e, hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
         return 0;
     };
     ENGINE_TRY(e, h2d(e->d_nn, nums_of_nodes, sizeof(int) * (size_t)num_graphs));
@@ -356,7 +370,7 @@ int flowgnn_set_batch(flowgnn_engine* e, int num_graphs, const int* nums_of_node
     db.final_h = 0;
     db.tap = nullptr;
     db.tap_dim = 0;
-    FG_HIP_TRY(hipMemset(e->d_err, 0, 2 * sizeof(int)));
+    EHIP_TRY(e, hipMemset(e->d_err, 0, 2 * sizeof(int)));
     e->db.range_flag = e->d_err + 1;
     e->force_exact = false;
     e->batch_ready = true;
@@ -377,7 +391,7 @@ int flowgnn_run(flowgnn_engine* e) {
         e->db.tap_dim = e->graph_tap_dim;
         e->db.final_h = e->graph_final_h;
         e->db.h_valid = e->graph_h_valid;
-        FG_HIP_TRY(hipGraphLaunch(e->gexec, e->stream));
+        EHIP_TRY(e, hipGraphLaunch(e->gexec, e->stream));
         e->graph_replays++;
         e->ran = true;
         return FLOWGNN_OK;
@@ -418,7 +432,7 @@ int flowgnn_run(flowgnn_engine* e) {
         e->graph_tap = e->db.tap;
         e->graph_tap_dim = e->db.tap_dim;
         e->graph_final_h = e->db.final_h;
-        FG_HIP_TRY(hipGraphLaunch(e->gexec, e->stream));  // the capture only recorded: this is the run itself
+        EHIP_TRY(e, hipGraphLaunch(e->gexec, e->stream));  // the capture only recorded: this is the run itself
         e->graph_replays++;
         e->ran = true;
         return FLOWGNN_OK;
@@ -462,7 +476,7 @@ int flowgnn_sync(flowgnn_engine* e) {
         e->force_exact = true;
         e->exact_reruns++;
         e->drop_graph();  // the captured launches are the split-f16 ones
-        FG_HIP_TRY(hipMemsetAsync(e->d_err + 1, 0, sizeof(int), e->stream));
+        EHIP_TRY(e, hipMemsetAsync(e->d_err + 1, 0, sizeof(int), e->stream));
         e->model->set_exact(true);
         ENGINE_TRY(e, e->model->forward(e->db, e->prof, e->stream));
         he = hipStreamSynchronize(e->stream);
@@ -508,7 +522,7 @@ int flowgnn_set_results_buffer(flowgnn_engine* e, void* device_ptr) {
     if (!e->batch_ready) return FLOWGNN_ERR_STATE;
     ENGINE_TRY(e, use_device(e));
     e->drop_graph();
-    FG_HIP_TRY(hipStreamSynchronize(e->stream));
+    EHIP_TRY(e, hipStreamSynchronize(e->stream));
     e->db.out = device_ptr ? (float*)device_ptr : e->d_out;
     return FLOWGNN_OK;
 }
@@ -516,6 +530,16 @@ int flowgnn_set_results_buffer(flowgnn_engine* e, void* device_ptr) {
 int flowgnn_stream(flowgnn_engine* e, void** stream) {
     if (!e || !stream) return FLOWGNN_ERR_ARG;
     *stream = (void*)e->stream;
+    return FLOWGNN_OK;
+}
+
+int flowgnn_set_stream(flowgnn_engine* e, void* stream, int use_external) {
+    if (!e) return FLOWGNN_ERR_ARG;
+    ENGINE_TRY(e, use_device(e));
+    e->drop_graph();
+    EHIP_TRY(e, hipStreamSynchronize(e->stream));
+    e->prof.collect();
+    e->stream = use_external ? (hipStream_t)stream : e->own_stream;
     return FLOWGNN_OK;
 }
 
@@ -544,10 +568,11 @@ int flowgnn_get_csr(flowgnn_engine* e, int* row_ptr, int* src, int* eid, int* ou
     if (!e->ran) return FLOWGNN_ERR_STATE;
     int rc = flowgnn_sync(e);
     if (rc) return rc;
-    if (row_ptr) FG_HIP_TRY(hipMemcpy(row_ptr, e->d_rowptr, sizeof(int) * ((size_t)e->N + 1), hipMemcpyDeviceToHost));
-    if (src && e->E) FG_HIP_TRY(hipMemcpy(src, e->d_src, sizeof(int) * (size_t)e->E, hipMemcpyDeviceToHost));
-    if (eid && e->E) FG_HIP_TRY(hipMemcpy(eid, e->d_eid, sizeof(int) * (size_t)e->E, hipMemcpyDeviceToHost));
-    if (out_deg && e->N) FG_HIP_TRY(hipMemcpy(out_deg, e->d_outdeg, sizeof(int) * (size_t)e->N, hipMemcpyDeviceToHost));
+    if (row_ptr && e->N == 0) row_ptr[0] = 0;  // empty batch: nothing was built (and nothing may have been allocated)
+    if (row_ptr && e->N) EHIP_TRY(e, hipMemcpy(row_ptr, e->d_rowptr, sizeof(int) * ((size_t)e->N + 1), hipMemcpyDeviceToHost));
+    if (src && e->E) EHIP_TRY(e, hipMemcpy(src, e->d_src, sizeof(int) * (size_t)e->E, hipMemcpyDeviceToHost));
+    if (eid && e->E) EHIP_TRY(e, hipMemcpy(eid, e->d_eid, sizeof(int) * (size_t)e->E, hipMemcpyDeviceToHost));
+    if (out_deg && e->N) EHIP_TRY(e, hipMemcpy(out_deg, e->d_outdeg, sizeof(int) * (size_t)e->N, hipMemcpyDeviceToHost));
     return FLOWGNN_OK;
 }
 
@@ -572,14 +597,14 @@ int flowgnn_get_h(flowgnn_engine* e, float* h_host, int* dim) {
     const int D = e->db.tap ? e->db.tap_dim : e->model->emb_dim();
     const float* srcp = e->db.tap ? e->db.tap : e->db.h[e->db.final_h];
     if (dim) *dim = D;
-    if (h_host && e->N) FG_HIP_TRY(hipMemcpy(h_host, srcp, sizeof(float) * (size_t)e->N * D, hipMemcpyDeviceToHost));
+    if (h_host && e->N) EHIP_TRY(e, hipMemcpy(h_host, srcp, sizeof(float) * (size_t)e->N * D, hipMemcpyDeviceToHost));
     return FLOWGNN_OK;
 }
 
 int flowgnn_profile_enable(flowgnn_engine* e, int on) {
     if (!e) return FLOWGNN_ERR_ARG;
     ENGINE_TRY(e, use_device(e));
-    FG_HIP_TRY(hipStreamSynchronize(e->stream));
+    EHIP_TRY(e, hipStreamSynchronize(e->stream));
     e->prof.reset();
     e->prof.enabled = on != 0;
     return FLOWGNN_OK;
@@ -588,7 +613,7 @@ int flowgnn_profile_enable(flowgnn_engine* e, int on) {
 int flowgnn_profile_read(flowgnn_engine* e, int* count, const char** names, double* total_ms, long long* launches) {
     if (!e || !count) return FLOWGNN_ERR_ARG;
     ENGINE_TRY(e, use_device(e));
-    FG_HIP_TRY(hipStreamSynchronize(e->stream));
+    EHIP_TRY(e, hipStreamSynchronize(e->stream));
     e->prof.collect();
     int n = (int)e->prof.names.size();
     if (n > FLOWGNN_MAX_PROFILE_SLOTS) n = FLOWGNN_MAX_PROFILE_SLOTS;
@@ -606,20 +631,50 @@ int flowgnn_run_aggregation_only(flowgnn_engine* e, int layer, int iters, float*
     if (!e->ran) { e->err = "flowgnn_run_aggregation_only needs a prior flowgnn_run"; return FLOWGNN_ERR_STATE; }
     ENGINE_TRY(e, use_device(e));
     e->drop_graph();
-    hipEvent_t a, b;
-    FG_HIP_TRY(hipEventCreate(&a));
-    FG_HIP_TRY(hipEventCreate(&b));
-    int rc = e->model->aggregation_only(e->db, layer, e->stream);  // warm-up
-    if (rc) return rc;
-    FG_HIP_TRY(hipEventRecord(a, e->stream));
-    for (int i = 0; i < iters; i++) e->model->aggregation_only(e->db, layer, e->stream);
-    FG_HIP_TRY(hipEventRecord(b, e->stream));
-    FG_HIP_TRY(hipEventSynchronize(b));
+    int rc = e->model->aggregation_only(e->db, layer, e->stream);  // warm-up; also the model's verdict on `layer`
+    if (rc) {
+        e->err = rc == FLOWGNN_ERR_UNSUPPORTED ? "this model has no standalone aggregation kernel" : "flowgnn_run_aggregation_only: bad layer";
+        return rc;
+    }
+    hipEvent_t a = nullptr, b = nullptr;
+    hipError_t he = hipEventCreate(&a);
+    if (he == hipSuccess) he = hipEventCreate(&b);
+    if (he == hipSuccess) he = hipEventRecord(a, e->stream);
+    for (int i = 0; i < iters && he == hipSuccess && rc == 0; i++) rc = e->model->aggregation_only(e->db, layer, e->stream);
+    if (he == hipSuccess) he = hipEventRecord(b, e->stream);
+    if (he == hipSuccess) he = hipEventSynchronize(b);
     float ms = 0.f;
-    FG_HIP_TRY(hipEventElapsedTime(&ms, a, b));
-    (void)hipEventDestroy(a);
-    (void)hipEventDestroy(b);
+    if (he == hipSuccess) he = hipEventElapsedTime(&ms, a, b);
+    if (a) (void)hipEventDestroy(a);
+    if (b) (void)hipEventDestroy(b);
+    if (he != hipSuccess) {
+        set_hip_error("flowgnn_run_aggregation_only", he, __FILE__, __LINE__);
+        e->err = fg::last_error_text();
+        return FLOWGNN_ERR_HIP;
+    }
+    if (rc) { e->err = fg::last_error_text(); return rc; }
     if (avg_ms) *avg_ms = ms / iters;
+    return FLOWGNN_OK;
+}
+
+int flowgnn_get_aggregate(flowgnn_engine* e, int layer, float* h_in_host, int* in_dim, float* agg_host, int* agg_dim) {
+    if (!e) return FLOWGNN_ERR_ARG;
+    if (!e->ran) { e->err = "flowgnn_get_aggregate needs a prior flowgnn_run"; return FLOWGNN_ERR_STATE; }
+    int rc = flowgnn_sync(e);
+    if (rc) return rc;
+    e->drop_graph();
+    const int D = e->model->emb_dim(), AD = e->model->aggregate_dim();
+    if (in_dim) *in_dim = D;
+    if (agg_dim) *agg_dim = AD;
+    if (AD <= 0) { e->err = "this model has no standalone aggregation kernel"; return FLOWGNN_ERR_UNSUPPORTED; }
+    if (e->N == 0 || (!h_in_host && !agg_host)) return FLOWGNN_OK;
+    rc = e->model->aggregation_only(e->db, layer, e->stream);
+    if (rc) { e->err = "flowgnn_get_aggregate: bad layer"; return rc; }
+    EHIP_TRY(e, hipStreamSynchronize(e->stream));
+    if (h_in_host)
+        EHIP_TRY(e, hipMemcpy(h_in_host, e->db.h[e->db.final_h], sizeof(float) * (size_t)e->N * D, hipMemcpyDeviceToHost));
+    if (agg_host) EHIP_TRY(e, hipMemcpy(agg_host, e->db.scratch, sizeof(float) * (size_t)e->N * AD, hipMemcpyDeviceToHost));
+    // the model's last launch may have left per-node readout terms in scratch: the next flowgnn_run rewrites them
     return FLOWGNN_OK;
 }
 
@@ -628,6 +683,20 @@ int flowgnn_run_aggregation_only(flowgnn_engine* e, int layer, int iters, float*
 // GIN/src/GIN_compute.cc:44,51-53) and run each through a process-wide engine per model.
 static std::mutex g_entry_mutex;
 static flowgnn_engine* g_entry_engine[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+// FNV-1a over the tensors of the weight set an entry-point engine holds: a caller that reloads the SAME set on every graph
+// (reload_weights = 1 everywhere is legal in the reference and cheap there) must not pay a repack + upload per graph
+static unsigned long long g_entry_whash[6] = {0, 0, 0, 0, 0, 0};
+static bool g_entry_whash_valid[6] = {false, false, false, false, false, false};
+static unsigned long long hash_tensors(int ntens, const float* const* t, const size_t* elems) {
+    unsigned long long h = 1469598103934665603ull;
+    for (int i = 0; i < ntens; i++) {
+        const unsigned* p = reinterpret_cast<const unsigned*>(t[i]);
+        for (size_t k = 0; k < elems[i]; k++) { h ^= p[k]; h *= 1099511628211ull; }
+        h ^= 0x9e3779b97f4a7c15ull + i;
+        h *= 1099511628211ull;
+    }
+    return h;
+}
 
 static int compute_graphs_generic(int model, int num_graphs, const int* nums_of_nodes, const int* nums_of_edges,
                                   const int* reload_weights, float* out, const int* node_feature, const float* node_eigen,
@@ -656,8 +725,15 @@ static int compute_graphs_generic(int model, int num_graphs, const int* nums_of_
         long long n = 0, m = 0;
         for (int i = g; i < g1; i++) { n += nums_of_nodes[i]; m += nums_of_edges[i]; }
         for (int i = 0; i < ntens; i++) cur[i] = tens[i] + (size_t)set * tens_elems[i];
-        int rc = flowgnn_set_weights(eng, ntens, cur);
-        if (rc) return rc;
+        int rc = FLOWGNN_OK;
+        const unsigned long long wh = hash_tensors(ntens, cur, tens_elems);
+        if (!g_entry_whash_valid[model] || g_entry_whash[model] != wh) {
+            g_entry_whash_valid[model] = false;
+            rc = flowgnn_set_weights(eng, ntens, cur);
+            if (rc) return rc;
+            g_entry_whash[model] = wh;
+            g_entry_whash_valid[model] = true;
+        }
         rc = flowgnn_set_batch(eng, g1 - g, nums_of_nodes + g, nums_of_edges + g, node_feature + noff * 9,
                                edge_list ? edge_list + eoff * 2 : nullptr, edge_attr ? edge_attr + eoff * 3 : nullptr,
                                node_eigen ? node_eigen + noff * 4 : nullptr);

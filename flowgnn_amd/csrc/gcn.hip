@@ -327,6 +327,7 @@ public:
     ~GcnModel() override { free_all(); }
     int emb_dim() const override { return GCN_D; }
     int scratch_dim() const override { return GCN_D; }
+    int aggregate_dim() const override { return GCN_D; }
     bool has_edge_attr() const override { return true; }
     int num_weight_tensors() const override { return 11; }
     bool weights_ready() const override { return ready_; }

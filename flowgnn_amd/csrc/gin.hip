@@ -536,6 +536,7 @@ public:
     ~GinModel() override { free_all(); }
     int emb_dim() const override { return GIN_D; }
     int scratch_dim() const override { return GIN_D; }
+    int aggregate_dim() const override { return GIN_D; }
     bool has_edge_attr() const override { return true; }
     int num_weight_tensors() const override { return 8; }
     bool weights_ready() const override { return ready_; }

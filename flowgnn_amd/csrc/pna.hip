@@ -277,6 +277,7 @@ public:
     ~PnaModel() override { free_all(); }
     int emb_dim() const override { return PNA_D; }
     int scratch_dim() const override { return PNA_D * PNA_NA; }
+    int aggregate_dim() const override { return PNA_D * PNA_NA; }
     bool has_edge_attr() const override { return false; }
     int num_weight_tensors() const override { return 10; }
     bool weights_ready() const override { return ready_; }

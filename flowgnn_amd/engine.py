@@ -161,6 +161,23 @@ class Engine:
         return float(ms.value)
 
 
+    def aggregate(self, layer: int = 0):
+        """(rows read, aggregate written) by the standalone aggregation kernel of `layer` (flowgnn_get_aggregate)."""
+        din, dagg = C.c_int(), C.c_int()
+        self._check(self.lib.flowgnn_get_aggregate(self._h, layer, None, C.byref(din), None, C.byref(dagg)), "flowgnn_get_aggregate")
+        h = np.empty((self.total_nodes, din.value), dtype=np.float32)
+        a = np.empty((self.total_nodes, dagg.value), dtype=np.float32)
+        self._check(self.lib.flowgnn_get_aggregate(self._h, layer, _pf(h), C.byref(din), _pf(a), C.byref(dagg)), "flowgnn_get_aggregate")
+        return h, a
+
+    def set_stream(self, stream_handle: Optional[int]):
+        """Launch on a caller-owned hipStream_t (e.g. torch.cuda.current_stream().cuda_stream); None restores the engine's own."""
+        if stream_handle is None:
+            self._check(self.lib.flowgnn_set_stream(self._h, None, 0), "flowgnn_set_stream")
+        else:
+            self._check(self.lib.flowgnn_set_stream(self._h, C.c_void_p(stream_handle), 1), "flowgnn_set_stream")
+
+
 def compute_graphs(model: str, batch: GraphBatch, weight_sets, reload_weights=None) -> np.ndarray:
     """Call the reference-compatible C symbol <M>_compute_graphs (e.g. GIN/src/dcl.h:75-94) with host
     arrays.  `weight_sets` is a list of weight dicts: the leading [S] dimension of every weight pointer,

@@ -212,6 +212,14 @@ int flowgnn_set_results_buffer(flowgnn_engine* e, void* device_ptr);
 /* The engine's hipStream_t as an opaque pointer (for event timing by a caller). */
 int flowgnn_stream(flowgnn_engine* e, void** stream);
 
+/*
+ * Make the engine launch on a caller-owned hipStream_t (use_external != 0; `stream` may be the null stream) instead of
+ * its own, e.g. the stream a collective library orders itself against, so that "forward, then all-gather the results"
+ * needs no host synchronisation in between.  use_external == 0 restores the engine's own stream.  The caller keeps
+ * the stream alive for as long as the engine uses it.
+ */
+int flowgnn_set_stream(flowgnn_engine* e, void* stream, int use_external);
+
 /* Totals of the resident batch. */
 int flowgnn_batch_info(const flowgnn_engine* e, long long* num_graphs,
                        long long* total_nodes, long long* total_edges);
@@ -276,6 +284,14 @@ int flowgnn_profile_read(flowgnn_engine* e, int* count, const char** names,
  * of the gather + segmented-sum path.  Requires a prior flowgnn_run.
  */
 int flowgnn_run_aggregation_only(flowgnn_engine* e, int layer, int iters, float* avg_ms);
+/*
+ * Parity tap for that kernel: runs it once, on the node embeddings the last flowgnn_run left in the engine (the input
+ * of the model's last stage when the readout was folded into it, the last layer's output otherwise), and copies to the
+ * host the rows it read (h_in_host, [N_tot][*in_dim]) and what it wrote (agg_host, [N_tot][*agg_dim]; GIN: m + h,
+ * GCN: relu(BN(...)), PNA: [mean|min|max|std] x 80, DGN: [mean | directional] x 100).  Either buffer may be NULL
+ * (dims are still reported).  The next flowgnn_run rewrites everything this touches.
+ */
+int flowgnn_get_aggregate(flowgnn_engine* e, int layer, float* h_in_host, int* in_dim, float* agg_host, int* agg_dim);
 
 #ifdef __cplusplus
 }

@@ -7,7 +7,7 @@
  * which are not vendored.  This oracle is therefore a from-reading restatement of
  * the reference algorithm with FM_TYPE = WT_TYPE = float, loop order and
  * summation order preserved; it is cross-checked by an independent float64 NumPy
- * restatement on the batched super-graph (tests/test_oracle_vs_numpy.py).
+ * restatement on the batched super-graph (tests/test_oracle_*.py against tests/numpy_ref.py).
  *
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may link or
  * call this library.  The product path (flowgnn_amd/) never does.

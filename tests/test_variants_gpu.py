@@ -1,0 +1,202 @@
+"""Every kernel variant that carries a reported number, checked against the oracle.
+
+The default forward of each model is covered by tests/test_<model>_gpu.py.  The engine also ships alternative kernels
+behind environment switches (read when a model object is created, e.g. flowgnn_amd/csrc/gin.hip `fused_`, `split_`):
+    FLOWGNN_GIN_UNFUSED=1        gin_aggregate_tiled_kernel + gin_mlp_kernel (the kernel behind `aggregation_roofline`)
+    FLOWGNN_GIN_AGG_UNTILED=1    ... with the first, un-tiled aggregation kernel;  FLOWGNN_GIN_AGG_TILE=64|256: other tilings
+    FLOWGNN_GIN_MFMA=f32         fp32-MFMA fused layer (the exact fallback)
+    FLOWGNN_GIN_SPLIT_NT=1|2     four-wave forms of the split-f16 layer kernel
+    FLOWGNN_GIN_RESIDENT=0       per-layer launches instead of the graph-resident multi-layer kernel
+    FLOWGNN_{GIN,GAT}_FOLD_READOUT=0   separate mean-pool + linear kernel
+    FLOWGNN_GCN_UNFUSED=1        tiled_aggregate_kernel<GcnAggPolicy> + dense100_split_kernel
+    FLOWGNN_<M>_MFMA=f32         fp32 matrix pipe for every model
+    FLOWGNN_CSR_FLAT=1           global-memory index build
+    FLOWGNN_HIPGRAPH             covered by tests/test_hipgraph_gpu.py
+Each variant gets a fresh Engine (fresh model object) with the switch set and must match the CPU oracle to the same
+tolerance as the default path.  The standalone aggregation kernels timed by flowgnn_run_aggregation_only are read back
+through flowgnn_get_aggregate and compared with the message-passing equations evaluated on the rows they read
+(GIN/src/message_passing.cc:136-145 + node_embedding.cc:117; GCN/src/message_passing.cc:158-167 +
+GCN/src/node_embedding.cc:123-138).
+"""
+import numpy as np
+import pytest
+
+from flowgnn_amd import Engine, graphpack as gp, weights
+from tests.numpy_ref import ED_OFF
+
+pytestmark = pytest.mark.gpu
+
+
+def fresh_forward(monkeypatch, model, env, batch, w, want_h=False):
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    e = Engine(model, device=0)
+    try:
+        e.set_weights(w)
+        out = e.forward(batch)
+        h = e.final_h() if want_h else None
+        reruns = e.exact_reruns()
+    finally:
+        e.close()
+        for k in env:
+            monkeypatch.delenv(k, raising=False)
+    return out, h, reruns
+
+
+def batch_for(model):
+    if model in ("GIN", "GAT"):
+        return gp.synth_molhiv_batch(300, seed=41)
+    if model == "GIN-VN":
+        return gp.add_virtual_nodes(gp.synth_molhiv_batch(200, seed=42))
+    if model == "GCN":
+        return gp.synth_molpcba_batch(300, seed=43)
+    return gp.synth_hep10k_batch(40, seed=44, with_eigen=(model == "DGN"))
+
+
+def oracle_fn(oracle, model):
+    return {"GIN": oracle.gin_forward, "GIN-VN": oracle.gin_forward, "GCN": oracle.gcn_forward, "GAT": oracle.gat_forward,
+            "PNA": oracle.pna_forward, "DGN": oracle.dgn_forward}[model]
+
+
+# tolerance per model: as in the model's own parity test file
+TOL = {"GIN": (1e-4, 1e-4), "GIN-VN": (2e-4, 1e-3), "GCN": (1e-4, 1e-4), "GAT": (2e-4, 2e-4), "PNA": (2e-4, 2e-3), "DGN": (2e-4, 2e-3)}
+
+GIN_VARIANTS = [
+    {"FLOWGNN_GIN_UNFUSED": "1"},
+    {"FLOWGNN_GIN_UNFUSED": "1", "FLOWGNN_GIN_AGG_UNTILED": "1"},
+    {"FLOWGNN_GIN_UNFUSED": "1", "FLOWGNN_GIN_AGG_TILE": "64"},
+    {"FLOWGNN_GIN_UNFUSED": "1", "FLOWGNN_GIN_AGG_TILE": "256"},
+    {"FLOWGNN_GIN_MFMA": "f32"},
+    {"FLOWGNN_GIN_RESIDENT": "0"},
+    {"FLOWGNN_GIN_RESIDENT": "0", "FLOWGNN_GIN_SPLIT_NT": "1"},
+    {"FLOWGNN_GIN_RESIDENT": "0", "FLOWGNN_GIN_SPLIT_NT": "2"},
+    {"FLOWGNN_GIN_RESIDENT": "0", "FLOWGNN_GIN_FOLD_READOUT": "0"},
+    {"FLOWGNN_GIN_FOLD_READOUT": "0"},
+    {"FLOWGNN_CSR_FLAT": "1"},
+]
+
+
+@pytest.mark.parametrize("env", GIN_VARIANTS, ids=lambda e: ",".join(f"{k[8:]}={v}" for k, v in e.items()))
+@pytest.mark.parametrize("model", ["GIN", "GIN-VN"])
+def test_gin_variants_match_oracle(monkeypatch, oracle, model, env):
+    b = batch_for(model)
+    w = weights.synth_gin_weights(seed=7)
+    got, h, reruns = fresh_forward(monkeypatch, model, env, b, w, want_h=True)
+    want, hd = oracle.gin_forward(b, [w], dump_h=True, nthreads=8)
+    rtol, atol = TOL[model]
+    assert np.isfinite(got).all()
+    assert np.allclose(got, want, rtol=rtol, atol=atol), (env, np.abs(got - want).max())
+    assert np.allclose(h, hd[5], rtol=rtol, atol=atol * 5), (env, np.abs(h - hd[5]).max())
+    assert reruns == 0
+
+
+OTHER_VARIANTS = [
+    ("GCN", {"FLOWGNN_GCN_UNFUSED": "1"}),
+    ("GCN", {"FLOWGNN_GCN_MFMA": "f32"}),
+    ("GCN", {"FLOWGNN_GCN_UNFUSED": "1", "FLOWGNN_GCN_MFMA": "f32"}),
+    ("GCN", {"FLOWGNN_CSR_FLAT": "1"}),
+    ("GAT", {"FLOWGNN_GAT_MFMA": "f32"}),
+    ("GAT", {"FLOWGNN_GAT_FOLD_READOUT": "0"}),
+    ("GAT", {"FLOWGNN_GAT_MFMA": "f32", "FLOWGNN_GAT_FOLD_READOUT": "0"}),
+    ("PNA", {"FLOWGNN_PNA_MFMA": "f32"}),
+    ("PNA", {"FLOWGNN_PNA_FUSED": "0"}),
+    ("DGN", {"FLOWGNN_DGN_MFMA": "f32"}),
+    ("DGN", {"FLOWGNN_DGN_FUSED": "0"}),
+    ("PNA", {"FLOWGNN_TILE_NOMINAL": "64", "FLOWGNN_TILE_SLACK": "0"}),
+    ("DGN", {"FLOWGNN_TILE_NOMINAL": "128", "FLOWGNN_TILE_SLACK": "0"}),
+]
+
+
+@pytest.mark.parametrize("model,env", OTHER_VARIANTS, ids=lambda x: x if isinstance(x, str) else ",".join(f"{k[8:]}={v}" for k, v in x.items()))
+def test_other_model_variants_match_oracle(monkeypatch, oracle, model, env):
+    b = batch_for(model)
+    w = weights.SYNTH[model](seed=7)
+    got, _, _ = fresh_forward(monkeypatch, model, env, b, w)
+    want = oracle_fn(oracle, model)(b, [w], nthreads=8)
+    rtol, atol = TOL[model]
+    scale = max(1.0, float(np.abs(want).max()))
+    assert np.isfinite(got).all()
+    assert np.allclose(got, want, rtol=rtol, atol=atol * scale), (model, env, np.abs(got - want).max())
+
+
+# ---------------------------------------------------------------- standalone aggregation kernels (roofline probes)
+def gin_aggregate_reference(h, batch, row_ptr, src, eid, eemb_l):
+    """a[v] = h[v] + sum over in-edges in CSR order of relu(h[u] + ((0 + E[a0]) + E[5+a1]) + E[11+a2]), in float32 with
+    the kernel's association: bit-exact target."""
+    ea = batch.edge_attr.astype(np.int64)[eid]
+    ee = np.zeros((len(eid), h.shape[1]), np.float32)
+    for k in range(3):
+        ee = ee + eemb_l[ea[:, k] + ED_OFF[k]]
+    msg = np.maximum(h[src] + ee, np.float32(0))
+    acc = np.zeros_like(h)
+    deg = np.diff(row_ptr)
+    for i in range(int(deg.max()) if len(deg) else 0):  # i-th in-edge of every row that has one: sequential per row
+        rows = np.nonzero(deg > i)[0]
+        acc[rows] = acc[rows] + msg[row_ptr[rows] + i]
+    return acc + h
+
+
+@pytest.mark.parametrize("env", [{}, {"FLOWGNN_GIN_AGG_UNTILED": "1"}, {"FLOWGNN_GIN_AGG_TILE": "64"}, {"FLOWGNN_GIN_AGG_TILE": "256"}],
+                         ids=["tiled128", "untiled", "tiled64", "tiled256"])
+def test_gin_aggregation_probe_is_bit_exact(monkeypatch, oracle, env):
+    """gin_aggregate_tiled_kernel, the kernel `aggregation_roofline` in bench.py is measured on."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    b = gp.concat_batches([gp.synth_molhiv_batch(500, seed=51), gp.add_virtual_nodes(gp.synth_molhiv_batch(20, seed=52)),
+                           gp.synth_hep10k_batch(6, seed=53, with_eigen=False)])
+    w = weights.synth_gin_weights(seed=7)
+    e = Engine("GIN", device=0)
+    e.set_weights(w)
+    out = e.forward(b)
+    row_ptr, src, eid, _ = e.csr()
+    want_out, hd = oracle.gin_forward(b, [w], dump_h=True, nthreads=8)
+    assert np.allclose(out, want_out, rtol=2e-4, atol=1e-3)
+    for layer in (0, 3):
+        h_in, agg = e.aggregate(layer)
+        # what the probe read is a real layer input: h_4 (readout folded into the last layer) or h_5
+        d4, d5 = np.abs(h_in - hd[4]).max(), np.abs(h_in - hd[5]).max()
+        assert min(d4, d5) < 1e-3 * max(1.0, float(np.abs(hd[4]).max())), (d4, d5)
+        want = gin_aggregate_reference(h_in, b, row_ptr, src, eid, np.asarray(w["edge_embedding_weight"], np.float32)[layer])
+        assert np.array_equal(agg, want), (layer, np.abs(agg - want).max())
+    assert np.array_equal(e.forward(b), out)  # the probe leaves the engine usable
+    e.close()
+
+
+def test_gcn_aggregation_probe_matches_equations(oracle):
+    """tiled_aggregate_kernel<GcnAggPolicy<true>> (the GCN unfused roofline probe): a = relu(BN_l(m + relu(x + root_l)/(deg+1)))."""
+    b = gp.synth_molpcba_batch(400, seed=61)
+    w = weights.synth_gcn_weights(seed=7)
+    e = Engine("GCN", device=0)
+    e.set_weights(w)
+    out = e.forward(b)
+    want_out, xd = oracle.gcn_forward(b, [w], dump_h=True, nthreads=8)
+    assert np.allclose(out, want_out, rtol=1e-4, atol=1e-4)
+    f64 = lambda a: np.asarray(a, np.float64)
+    ge = b.global_edges()
+    u, v = ge[:, 0], ge[:, 1]
+    N = b.total_nodes
+    outdeg = np.bincount(u, minlength=N).astype(np.float64)
+    dinv = np.where(outdeg > 0, 1.0 / np.sqrt(outdeg + 1.0), 0.0)
+    for layer in (0, 2):
+        x, agg = e.aggregate(layer)
+        assert np.abs(x - xd[4]).max() < 2e-4 * max(1.0, float(np.abs(xd[4]).max()))  # the rows it read: x_4
+        ee = f64(w["edge_embedding_weight"])[layer][b.edge_attr.astype(np.int64) + ED_OFF[None, :]].sum(axis=1)
+        m = np.zeros((N, 100))
+        np.add.at(m, v, (dinv[u] * dinv[v])[:, None] * np.maximum(f64(x)[u] + ee, 0.0))
+        pre = m + np.maximum(f64(x) + f64(w["convs_root_emb_weight"])[layer], 0.0) / (outdeg[:, None] + 1.0)
+        bn = (pre - f64(w["bn_mean"])[layer]) / np.sqrt(f64(w["bn_var"])[layer] + 2.0 ** -10) * f64(w["bn_weight"])[layer] + f64(w["bn_bias"])[layer]
+        want = np.maximum(bn, 0.0)
+        assert np.allclose(agg, want, rtol=1e-4, atol=1e-4), (layer, np.abs(agg - want).max())
+    e.close()
+
+
+def test_entry_point_skips_identical_weight_reloads(oracle):
+    """reload_weights = 1 on every graph with the SAME set (legal and cheap in the reference, GIN_compute.cc:51-63): same
+    results as one load; different sets still switch."""
+    from flowgnn_amd import GIN_compute_graphs
+    b = gp.synth_molhiv_batch(6, seed=5)
+    w1, w2 = weights.synth_gin_weights(seed=7), weights.synth_gin_weights(seed=8)
+    rw = np.ones(6, np.int32)
+    got = GIN_compute_graphs(b, [w1, w1, w1, w2, w2, w1], rw)
+    want = oracle.gin_forward(b, [w1, w1, w1, w2, w2, w1], reload_weights=rw)
+    assert np.allclose(got, want, rtol=1e-4, atol=1e-4), np.abs(got - want).max()
