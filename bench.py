@@ -42,13 +42,17 @@ MODELS = {
     "GIN": dict(metric="graphs/sec on ogbg-molhiv (GIN, dim=100)", dataset="molhiv", graphs=1 << 18,
                 agg_bytes=lambda n, e: n * 400 * 2 + e * 20, flops=lambda n, e: n * 80000,
                 # fused layer: read h once + write h' + CSR (row_ptr 4 B/node, src 4 B + edge code 1 B per edge)
-                fused_bytes=lambda n, e: n * 400 * 2 + n * 4 + e * 5,
-                hbm_kernels=("gin_aggregate",), mfma_kernels=("gin_layer_fused", "gin_mlp"),
+                # graph-resident kernel (all five layers in one launch): reads the encoder rows once + the CSR, writes 4 B per graph;
+                # its bound is the f16 matrix pipe (5 layers x 3 x 80 000 flop per node)
+                fused_bytes={"gin_layer_fused": lambda n, e: n * 400 * 2 + n * 4 + e * 5, "gin_resident": lambda n, e: n * 400 + n * 4 + e * 5},
+                layers_per_launch={"gin_resident": 5}, mfma_bound_kernels=("gin_resident",),
+                hbm_kernels=("gin_aggregate",), mfma_kernels=("gin_resident", "gin_layer_fused", "gin_mlp"),
                 workload="GIN dim=100, batched ogbg-molhiv-shaped graphs on MI355X (BASELINE configs[1])"),
     "GIN-VN": dict(metric="graphs/sec on ogbg-molhiv (GIN-VN, dim=100)", dataset="molhiv-vn", graphs=1 << 18,
                    agg_bytes=lambda n, e: n * 400 * 2 + e * 20, flops=lambda n, e: n * 80000,
-                   fused_bytes=lambda n, e: n * 400 * 2 + n * 4 + e * 5,
-                   hbm_kernels=("gin_aggregate",), mfma_kernels=("gin_layer_fused", "gin_mlp"),
+                   fused_bytes={"gin_layer_fused": lambda n, e: n * 400 * 2 + n * 4 + e * 5, "gin_resident": lambda n, e: n * 400 + n * 4 + e * 5},
+                   layers_per_launch={"gin_resident": 5}, mfma_bound_kernels=("gin_resident",),
+                   hbm_kernels=("gin_aggregate",), mfma_kernels=("gin_resident", "gin_layer_fused", "gin_mlp"),
                    workload="GIN-VN dim=100 (virtual node per graph), ogbg-molhiv-shaped graphs"),
     "GCN": dict(metric="graphs/sec on ogbg-molpcba (GCN, dim=100)", dataset="molpcba", graphs=1 << 18,
                 agg_bytes=lambda n, e: n * 400 * 2 + e * 24, flops=lambda n, e: n * 20000,

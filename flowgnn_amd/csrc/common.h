@@ -106,6 +106,19 @@ struct ProfScope {
     ~ProfScope() { if (slot >= 0) p.end(slot, s); }
 };
 
+// Whole graphs packed greedily (in batch order) into tiles of at most `rows` rows and `edges` in-edges: what a kernel that
+// keeps a tile of graphs on chip across all layers walks (the MI355X counterpart of the FPGA holding ONE graph in BRAM
+// across its layer loop, GIN/src/GIN_compute.cc:72-94).  Built on the host in flowgnn_set_batch from the per-graph counts
+// when the model asks for it (Model::graph_tile_limits).
+struct GraphTiles {
+    const int* row_start = nullptr;    // device [n_tiles + 1]: first row of tile t (row_start[n_tiles] = n_tot)
+    const int* graph_start = nullptr;  // device [n_tiles + 1]: first graph of tile t
+    int n_tiles = 0;
+    int rows = 0, edges = 0;           // the limits it was built for
+    bool ok = false;                   // every graph of the batch fits a tile
+    double fill = 0.0;                 // n_tot / (n_tiles * rows)
+};
+
 // Everything a model's forward needs about the resident batch.
 struct DeviceBatch {
     BatchView b;
@@ -119,6 +132,7 @@ struct DeviceBatch {
     int tap_dim;
     bool h_valid;             // h[final_h] holds the last stage's node embeddings (false: the model folded the readout into its last
                               // layer and never wrote them; flowgnn_get_h then repeats the pass with Model::set_keep_h(true))
+    GraphTiles gtiles;        // graph-aligned tiles (GraphTiles above), n_tiles == 0 if the model did not ask for them
     int* range_flag;          // [1] set by a reduced-range kernel whose operands left its accurate range (see Model::set_exact)
 };
 
@@ -132,6 +146,8 @@ public:
     virtual void set_keep_h(bool) {}
     // 0 = fp32 (default); 1 = the reference's ap_fixed<16,6> bit patterns (GIN / GIN-VN only: ginq.hip)
     virtual int set_numeric_mode(int mode) { return mode == 0 ? 0 : 8 /* FLOWGNN_ERR_UNSUPPORTED */; }
+    // rows > 0: flowgnn_set_batch packs whole graphs into tiles of at most rows rows / edges in-edges (DeviceBatch::gtiles)
+    virtual void graph_tile_limits(int& rows, int& edges) const { rows = 0; edges = 0; }
     virtual int emb_dim() const = 0;
     virtual int scratch_dim() const = 0;          // floats per node of scratch the forward needs
     virtual bool has_edge_attr() const = 0;
@@ -145,7 +161,7 @@ public:
     virtual int aggregate_dim() const { return 0; }
 };
 
-Model* make_gin_model();
+Model* make_gin_model(bool virtual_node);
 Model* make_gcn_model();
 Model* make_pna_model();
 Model* make_dgn_model();

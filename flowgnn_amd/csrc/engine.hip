@@ -112,6 +112,8 @@ struct flowgnn_engine {
         *d_cursor = nullptr, *d_tmp = nullptr, *d_bsums = nullptr, *d_err = nullptr;
     uint8_t* d_ecode = nullptr;
     float *d_h0 = nullptr, *d_h1 = nullptr, *d_scratch = nullptr, *d_out = nullptr;
+    int *d_trow = nullptr, *d_tgraph = nullptr;  // graph-aligned tiles (GraphTiles)
+    size_t cap_tiles = 0;
     bool has_attr = false, has_eig = false;
     DeviceBatch db{};
 
@@ -146,6 +148,10 @@ struct flowgnn_engine {
         d_rowptr = d_src = d_eid = d_outdeg = d_gsrc = d_gdst = d_cursor = d_tmp = d_bsums = nullptr;
         d_ecode = nullptr;
         d_h0 = d_h1 = d_scratch = d_out = nullptr;
+        if (d_trow) (void)hipFree(d_trow);
+        if (d_tgraph) (void)hipFree(d_tgraph);
+        d_trow = d_tgraph = nullptr;
+        cap_tiles = 0;
         capG = capN = capE = 0;
     }
 };
@@ -180,8 +186,8 @@ int flowgnn_create(int model, int device_id, flowgnn_engine** out) {
     *out = nullptr;
     Model* m = nullptr;
     switch (model) {
-        case FLOWGNN_MODEL_GIN:
-        case FLOWGNN_MODEL_GIN_VN: m = make_gin_model(); break;
+        case FLOWGNN_MODEL_GIN: m = make_gin_model(false); break;
+        case FLOWGNN_MODEL_GIN_VN: m = make_gin_model(true); break;
         case FLOWGNN_MODEL_GCN: m = make_gcn_model(); break;
         case FLOWGNN_MODEL_PNA: m = make_pna_model(); break;
         case FLOWGNN_MODEL_DGN: m = make_dgn_model(); break;
@@ -352,6 +358,50 @@ int flowgnn_set_batch(flowgnn_engine* e, int num_graphs, const int* nums_of_node
     ENGINE_TRY(e, h2d(e->d_el, edge_list, sizeof(int) * (size_t)E * 2));
     if (attr) ENGINE_TRY(e, h2d(e->d_ea, edge_attr, sizeof(int) * (size_t)E * EDGE_ATTR));
     if (eig) ENGINE_TRY(e, h2d(e->d_eig, node_eigen, sizeof(float) * (size_t)N * 4));
+
+    // graph-aligned tiles for kernels that keep whole graphs on chip across layers (GraphTiles, common.h)
+    e->db.gtiles = GraphTiles{};
+    {
+        int t_rows = 0, t_edges = 0;
+        e->model->graph_tile_limits(t_rows, t_edges);
+        if (t_rows > 0 && num_graphs > 0) {
+            std::vector<int> trow, tgraph;
+            trow.push_back(0);
+            tgraph.push_back(0);
+            int cr = 0, ce = 0;
+            bool fits = true;
+            for (int g = 0; g < num_graphs && fits; g++) {
+                const int n = nums_of_nodes[g], m = nums_of_edges[g];
+                if (n > t_rows || m > t_edges) { fits = false; break; }
+                if (cr + n > t_rows || ce + m > t_edges) {
+                    trow.push_back(noff[g]);
+                    tgraph.push_back(g);
+                    cr = 0; ce = 0;
+                }
+                cr += n; ce += m;
+            }
+            if (fits) {
+                trow.push_back((int)N);
+                tgraph.push_back(num_graphs);
+                const size_t cnt = trow.size();
+                if (cnt > e->cap_tiles) {
+                    if (e->d_trow) (void)hipFree(e->d_trow);
+                    if (e->d_tgraph) (void)hipFree(e->d_tgraph);
+                    e->d_trow = e->d_tgraph = nullptr;
+                    e->cap_tiles = 0;
+                    EHIP_TRY(e, hipMalloc((void**)&e->d_trow, sizeof(int) * cnt));
+                    EHIP_TRY(e, hipMalloc((void**)&e->d_tgraph, sizeof(int) * cnt));
+                    e->cap_tiles = cnt;
+                }
+                ENGINE_TRY(e, h2d(e->d_trow, trow.data(), sizeof(int) * cnt));
+                ENGINE_TRY(e, h2d(e->d_tgraph, tgraph.data(), sizeof(int) * cnt));
+                GraphTiles& gt = e->db.gtiles;
+                gt.row_start = e->d_trow; gt.graph_start = e->d_tgraph;
+                gt.n_tiles = (int)cnt - 1; gt.rows = t_rows; gt.edges = t_edges; gt.ok = true;
+                gt.fill = (double)N / ((double)gt.n_tiles * t_rows);
+            }
+        }
+    }
 
     e->G = num_graphs; e->N = N; e->E = E;
     e->max_nodes = mx_n; e->max_edges = mx_e;

@@ -533,6 +533,7 @@ __global__ __launch_bounds__(256) void gin_layer_fused_kernel(const float* __res
 // ---------------------------------------------------------------- host side: weights + forward
 class GinModel : public Model {
 public:
+    explicit GinModel(bool virtual_node) : virtual_node_(virtual_node) {}
     ~GinModel() override { free_all(); }
     int emb_dim() const override { return GIN_D; }
     int scratch_dim() const override { return GIN_D; }
@@ -614,9 +615,15 @@ public:
         for (int l = 0; l < GIN_L; l++)
             gin_split_pack_layer(w1 + (size_t)l * GIN_H * GIN_D, b1 + (size_t)l * GIN_H, w2 + (size_t)l * GIN_D * GIN_H,
                                  b2 + (size_t)l * GIN_D, split.data() + (size_t)l * GS_LAYER_BYTES);
+        // ... and of the graph-resident kernel (its own chunk format)
+        std::vector<uint8_t> rsplit((size_t)GIN_L * gin_resident_layer_bytes());
+        for (int l = 0; l < GIN_L; l++)
+            gin_resident_pack_layer(w1 + (size_t)l * GIN_H * GIN_D, b1 + (size_t)l * GIN_H, w2 + (size_t)l * GIN_D * GIN_H,
+                                    b2 + (size_t)l * GIN_D, rsplit.data() + (size_t)l * gin_resident_layer_bytes());
         int rc;
         if ((rc = ginq_upload(qw_, nemb, eemb, w1, b1, w2, b2, pw, pb))) return rc;  // Q6.10 copies (numeric mode 1)
         if ((rc = upload(&d_split_, split))) return rc;
+        if ((rc = upload(&d_rsplit_, rsplit))) return rc;
         if ((rc = upload(&d_chunks_, chunks))) return rc;
         if ((rc = upload(&d_nemb_, v_nemb))) return rc;
         if ((rc = upload(&d_pw_, v_pw))) return rc;
@@ -693,6 +700,17 @@ public:
                                                                  layer_dev(l).ecomb, db.b.n_tot);
     }
 
+    // graph-resident path (gin_split.hip, gin_resident_kernel): whole graphs packed into 256-row tiles by flowgnn_set_batch
+    void graph_tile_limits(int& rows, int& edges) const override {
+        rows = resident_ ? GIN_RESIDENT_ROWS : 0;
+        edges = resident_ ? GIN_RESIDENT_EDGES : 0;
+    }
+    bool use_resident(const DeviceBatch& db) const {
+        // tiles that are mostly empty (graphs of 130..256 nodes, or dense graphs that hit the edge limit first) waste the
+        // MFMA columns of the absent rows: below half full the per-layer kernels are the better choice
+        return resident_ && fused_ && split_ && !exact_ && db.gtiles.ok && db.gtiles.n_tiles > 0 && db.gtiles.fill >= resident_min_fill_;
+    }
+
     int forward(DeviceBatch& db, Profiler& prof, hipStream_t s) override {
         const int n = db.b.n_tot;
         if (n <= 0) return 0;
@@ -700,6 +718,17 @@ public:
         {
             ProfScope p(prof, "atom_encoder", s);
             atom_encoder_kernel<GIN_D><<<atom_encoder_grid(n, GIN_C), 512, 0, s>>>(db.b.node_feature, d_nemb_, db.h[0], n, db.csr.err);
+        }
+        if (use_resident(db)) {
+            // all five layers and the readout in one launch; h_5 rows are written (to h[1]) only for the flowgnn_get_h tap
+            if (int rc = perm_.reserve((size_t)db.gtiles.n_tiles * (GIN_RESIDENT_DESC_BYTES / 4))) return rc;
+            ProfScope p(prof, "gin_resident", s);
+            launch_gin_resident(db.h[0], keep_h_ ? db.h[1] : nullptr, db.csr.row_ptr, db.csr.src, db.csr.ecode, d_ecomb_, d_rsplit_, d_pw_, d_pb_,
+                                db.gtiles.row_start, db.gtiles.graph_start, reinterpret_cast<uint8_t*>(perm_.p), db.b.node_off, db.out,
+                                db.gtiles.n_tiles, db.range_flag, s);
+            db.final_h = keep_h_ ? 1 : 0;
+            db.h_valid = keep_h_;
+            return 0;
         }
         int cur = 0;
         bool folded = false;
@@ -776,9 +805,12 @@ private:
         for (auto p : ptrs)
             if (*p) { (void)hipFree(*p); *p = nullptr; }
         if (d_split_) { (void)hipFree(d_split_); d_split_ = nullptr; }
+        if (d_rsplit_) { (void)hipFree(d_rsplit_); d_rsplit_ = nullptr; }
+        perm_.release();
         qw_.release();
     }
     bool ready_ = false;
+    const bool virtual_node_;  // FLOWGNN_MODEL_GIN_VN: the batch carries one virtual node per graph
     // FLOWGNN_GIN_UNFUSED=1 keeps the two-kernel layer (aggregate + mlp) for A/B measurements
     bool fused_ = !(getenv("FLOWGNN_GIN_UNFUSED") && atoi(getenv("FLOWGNN_GIN_UNFUSED")) != 0);
     // FLOWGNN_GIN_MFMA=f32 keeps the dense update on the fp32 matrix pipe (gin_layer_fused_kernel); the default runs it
@@ -790,14 +822,20 @@ private:
     bool keep_h_ = false;
     bool qmode_ = false;  // flowgnn_set_numeric_mode(FLOWGNN_NUMERIC_Q6_10)
     GinQWeights qw_;
+    GrowBufI perm_;  // graph-resident path: per-tile descriptors (gin_tile_prep_kernel)
     // FLOWGNN_GIN_FOLD_READOUT=0 keeps the separate mean-pool + linear kernel (and the last layer's 2.7 GB of rows)
     bool fold_readout_ = !(getenv("FLOWGNN_GIN_FOLD_READOUT") && atoi(getenv("FLOWGNN_GIN_FOLD_READOUT")) == 0);
+    // FLOWGNN_GIN_RESIDENT=0 keeps one launch per layer (gin_layer_split_kernel); GIN-VN defaults to that path: its virtual
+    // nodes are hub rows (in-degree = graph size), which the per-layer kernel sums cooperatively and the resident one does not
+    bool resident_ = getenv("FLOWGNN_GIN_RESIDENT") ? atoi(getenv("FLOWGNN_GIN_RESIDENT")) != 0 : !virtual_node_;
+    double resident_min_fill_ = getenv("FLOWGNN_GIN_RESIDENT_MIN_FILL") ? atof(getenv("FLOWGNN_GIN_RESIDENT_MIN_FILL")) : 0.5;
     uint8_t* d_split_ = nullptr;
+    uint8_t* d_rsplit_ = nullptr;  // weight stream of the graph-resident kernel
     float* d_chunks_ = nullptr;
     float *d_nemb_ = nullptr, *d_pw_ = nullptr, *d_pb_ = nullptr, *d_ecomb_ = nullptr, *d_w1f_ = nullptr,
           *d_w1tail_ = nullptr, *d_b1p_ = nullptr, *d_w2f_ = nullptr, *d_b2p_ = nullptr;
 };
 
-Model* make_gin_model() { return new GinModel(); }
+Model* make_gin_model(bool virtual_node) { return new GinModel(virtual_node); }
 
 }  // namespace fg

@@ -29,4 +29,19 @@ void launch_gin_layer_split(const float* h, float* hout, const int* row_ptr, con
                             const float* ecomb, const uint8_t* chunks, int n_tot, int e_tot, int relu_out, int* range_flag,
                             int variant, hipStream_t s, const float* pool_w = nullptr);
 
+// Graph-resident form (gin_split.hip, gin_resident_kernel): all five layers + readout in one launch; a persistent workgroup
+// keeps a tile of whole graphs (GraphTiles: <= GIN_RESIDENT_ROWS rows, <= GIN_RESIDENT_EDGES in-edges) in LDS across the layers.
+// h0 = atom-encoder output [N][100]; ecomb_all [5][60][100]; chunks_all = 5 x gin_resident_layer_bytes(); hout (nullable): h_5 rows for
+// the flowgnn_get_h tap; out [G] receives the logits.
+// weight stream of the resident kernel (its own chunk format: gin_split.hip "GR chunks"); chunks_all = 5 x gin_resident_layer_bytes()
+size_t gin_resident_layer_bytes();
+void gin_resident_pack_layer(const float* w1, const float* b1, const float* w2, const float* b2, uint8_t* out);
+constexpr int GIN_RESIDENT_ROWS = 256;
+constexpr int GIN_RESIDENT_EDGES = 1280;
+constexpr int GIN_RESIDENT_DESC_BYTES = 3584;  // per-tile descriptor built by gin_tile_prep_kernel (CSR slice as 16-bit words, row offsets, column owners)
+void launch_gin_resident(const float* h0, float* hout, const int* row_ptr, const int* src, const uint8_t* ecode, const float* ecomb_all,
+                         const uint8_t* chunks_all, const float* pool_w, const float* pool_b, const int* tile_row, const int* tile_graph,
+                         uint8_t* tile_desc /* scratch, n_tiles x GIN_RESIDENT_DESC_BYTES */, const int* node_off, float* out, int n_tiles,
+                         int* range_flag, hipStream_t s);
+
 }  // namespace fg

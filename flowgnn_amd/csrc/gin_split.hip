@@ -433,6 +433,555 @@ __global__ __launch_bounds__(WAVES * 64) void gin_layer_split_kernel(const float
     }
 }
 
+// ---------------------------------------------------------------- graph-resident GIN: all five layers of a tile in ONE workgroup
+// The FPGA keeps one graph in BRAM across its layer loop (GIN/src/GIN_compute.cc:72-94).  The counterpart here: a
+// persistent 8-wave workgroup (one per CU) owns a tile of WHOLE graphs (<= GR_ROWS rows, <= GR_EDGES in-edges; packed on
+// the host, GraphTiles) and keeps the tile's node embeddings in LDS across all five layers:
+//   * h never goes to HBM between layers: the gather reads neighbour rows from LDS, the epilogue writes h' in place;
+//   * the tile's CSR slice is staged once per tile as 16-bit words (row inside the tile << 6 | edge code) + 16-bit row offsets;
+//   * every wave owns TWO MFMA column tiles (32 nodes): each weight fragment read from LDS feeds two MFMAs, which is what
+//     takes the LDS array out of the critical path (one column tile per wave needs 650 B of fragments per 16-cycle MFMA);
+//   * the weight stream (8 chunks + the 60-row edge-embedding table per layer, the same for every tile) runs through the two
+//     chunk buffers without ever draining: chunk s+1 lands while step s computes, the NEXT layer's table lands during step 7
+//     (so the buffers swap roles from layer to layer), chunk 0 lands during the gather;
+//   * during the last layer's MLP the NEXT tile's rows (encoder output, 400 B per node: the only per-node HBM read of the whole
+//     model) and CSR slice are brought in, an eighth per step; the readout (mean of the per-node dot products with the
+//     prediction head) happens in the kernel: 4 B per GRAPH leave it.
+// LDS: 2 x 27 264 (chunks) + 102 400 (rows) + 2 560 (edges) + 520 (row offsets) + 1 024 (per-node readout terms) = 161 032 B.
+constexpr int GR_ROWS = 256;
+constexpr int GR_EDGES = 1280;
+constexpr int GR_WAVES = 8;
+
+// Weight stream of the resident kernel ("GR chunks"; gin_resident_pack_layer builds it).  Same 8 steps as the per-layer kernel's
+// stream, with the padding taken out of the matrix work:
+//   * the K tail of the first linear layer (features 96..99) is ONE f16 MFMA per tile whose 32 K-slots carry all three split
+//     products -- slots 0-3 w_hi x_hi, 4-7 w_hi x_lo, 8-11 w_lo x_hi -- instead of an fp32 MFMA of twice the cost;
+//   * step 6 computes hidden tile 12 only (tile 13 is pure padding: 200 = 12.5 tiles);
+//   * step 7 (hidden units 192..199, the last 8 real ones) is ONE packed MFMA per output tile in the same way
+//     (slots 0-7 w_hi h_hi | w_hi h_lo of units 192..195, 8-15 the same of 196..199, 16-19 / 24-27 w_lo h_hi).
+// 526 MFMAs of 16 cycles per layer and 32-node wave instead of 574 + 28 fp32 ones (= 630 of 16 cycles).
+// chunk s:  [0, 12288)       W1 fragments: tile tl (2s + tl) at tl * 6144 + (ks * 2 + p) * 1024   (p = 0 hi, 1 lo)
+//           [12288, 13312)   K-tail fragments, 512 B per tile (lanes 0..31: g = 0 [w_hi, w_hi], g = 1 [w_lo, 0])
+//           [13312, 13440)   b1 slices, 2 x 16 floats (pre-scaled)
+//           [13440, 27776)   W2 fragments of K-step s-1: (t2 * 2 + p) * 1024; step 7: packed, t2 * 1024; chunk 0: b2[112] + 1/(s1 s2)
+constexpr int GRC_TAIL_OFF = 12288;
+constexpr int GRC_B1_OFF = 13312;
+constexpr int GRC_W2_OFF = 13440;
+constexpr int GRC_CHUNK_BYTES = 27776;
+constexpr int GRC_CHUNK_STRIDE = 28672;  // 28 pieces of 1 KiB in global memory (the last one: 128 B = 8 lanes)
+
+// LDS-DMA of one 1 KiB piece (16 B per lane) from inline asm.  Not the builtin: hipcc's wait-count pass books a
+// global_load ... lds as a FLAT access that may touch LDS, and while one is outstanding it turns every LDS wait of the wave
+// into lgkmcnt(0) -- which would serialise the fragment pipeline below (each unit's wait would also wait for the fragments just
+// requested for the next unit).  Issued like this the pass does not see the transfer at all; the kernel orders it by hand
+// (s_waitcnt vmcnt(0) + barrier before a buffer is read, as it did anyway).  gbase and lds_addr are wave-uniform.
+__device__ __forceinline__ void gr_dma16(const void* gbase, uint32_t voff, uint32_t lds_addr) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(gbase), "s"(lds_addr) : "memory", "m0");
+}
+__device__ __forceinline__ uint32_t gr_lds_addr(const void* p) {
+    return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)p;
+}
+
+__device__ __forceinline__ void grc_issue_chunk(const uint8_t* __restrict__ gchunk, char* lds_buf, int wave, int lane) {
+    const uint32_t lb = gr_lds_addr(lds_buf);
+#pragma unroll
+    for (int p = 0; p < 4; p++) {
+        const int piece = wave + 8 * p;  // 27 full pieces + 128 B
+        if (piece < 27 || (piece == 27 && lane < 8)) gr_dma16(gchunk + piece * 1024, (uint32_t)lane * 16u, lb + piece * 1024);
+    }
+}
+
+#define GR_LD(off) (*reinterpret_cast<const uint4_t*>(wb + (off) + lane * 16))
+#define GR_SB() __builtin_amdgcn_sched_barrier(0)
+
+// One step of the node MLP for TWO column tiles per wave.  The work is a chain of "units" -- two fragments (hi, lo of one
+// 16-row weight tile and one K-step) feeding six MFMAs (w_hi x_hi, w_hi x_lo, w_lo x_hi for both column tiles) -- and the
+// fragments of unit k+1 are requested before the MFMAs of unit k issue (scheduling barriers pin that order): one LDS round trip
+// is always covered by ~120 cycles of matrix pipe, with 16 fragment registers in all.
+// KIND 0: step 0 (first layer's hidden tiles 0,1 only) | 1: steps 1..5 | 2: step 6 (K-step 5 + hidden tile 12, then the packed
+// operand of step 7 is built) | 3: step 7 (packed K-step).
+template <int KIND>
+__device__ __forceinline__ void gr_step(const char* wb, int lane, int g, const uint4_t (&in_hi)[2][3], const uint4_t (&in_lo)[2][3],
+                                        const uint4_t (&in_tb)[2], uint4_t (&hb_hi)[2], uint4_t (&hb_lo)[2], float4_t (&acc2)[2][GS_T2],
+                                        float& vmax) {
+    constexpr bool DO2 = KIND == 1 || KIND == 2, DO1 = KIND != 3;
+    constexpr int NTL = KIND == 2 ? 1 : 2;
+    uint4_t f0[2], f1[2];  // fragment double buffer: f0 = even units, f1 = odd units
+#define GR_U2_LOAD(F, T) F[0] = GR_LD(GRC_W2_OFF + (2 * (T)) * 1024); F[1] = GR_LD(GRC_W2_OFF + (2 * (T) + 1) * 1024);
+#define GR_U2_MFMA(F, T)                                          \
+    acc2[0][T] = GS_MFMA16(F[0], hb_hi[0], acc2[0][T]);           \
+    acc2[1][T] = GS_MFMA16(F[0], hb_hi[1], acc2[1][T]);           \
+    acc2[0][T] = GS_MFMA16(F[0], hb_lo[0], acc2[0][T]);           \
+    acc2[1][T] = GS_MFMA16(F[0], hb_lo[1], acc2[1][T]);           \
+    acc2[0][T] = GS_MFMA16(F[1], hb_hi[0], acc2[0][T]);           \
+    acc2[1][T] = GS_MFMA16(F[1], hb_hi[1], acc2[1][T]);
+#define GR_U1_LOAD(F, TL, KS) F[0] = GR_LD((TL) * 6144 + (2 * (KS)) * 1024); F[1] = GR_LD((TL) * 6144 + (2 * (KS) + 1) * 1024);
+#define GR_U1_MFMA(F, TL, KS)                                             \
+    acc1[TL][0] = GS_MFMA16(F[0], in_hi[0][KS], acc1[TL][0]);             \
+    acc1[TL][1] = GS_MFMA16(F[0], in_hi[1][KS], acc1[TL][1]);             \
+    acc1[TL][0] = GS_MFMA16(F[0], in_lo[0][KS], acc1[TL][0]);             \
+    acc1[TL][1] = GS_MFMA16(F[0], in_lo[1][KS], acc1[TL][1]);             \
+    acc1[TL][0] = GS_MFMA16(F[1], in_hi[0][KS], acc1[TL][0]);             \
+    acc1[TL][1] = GS_MFMA16(F[1], in_hi[1][KS], acc1[TL][1]);
+    float4_t acc1[2];  // one hidden tile at a time: its ReLU + split then overlap the next tile's MFMAs
+#define GR_U1_MFMA1(F, KS)                                        \
+    acc1[0] = GS_MFMA16(F[0], in_hi[0][KS], acc1[0]);             \
+    acc1[1] = GS_MFMA16(F[0], in_hi[1][KS], acc1[1]);             \
+    acc1[0] = GS_MFMA16(F[0], in_lo[0][KS], acc1[0]);             \
+    acc1[1] = GS_MFMA16(F[0], in_lo[1][KS], acc1[1]);             \
+    acc1[0] = GS_MFMA16(F[1], in_hi[0][KS], acc1[0]);             \
+    acc1[1] = GS_MFMA16(F[1], in_hi[1][KS], acc1[1]);
+#define GR_TAIL_LOAD(F, TL) F[0] = *reinterpret_cast<const uint4_t*>(wb + GRC_TAIL_OFF + (TL) * 512 + (lane & 31) * 16);
+#define GR_BIAS(TL) acc1[0] = *reinterpret_cast<const float4_t*>(wb + GRC_B1_OFF + (TL) * 64 + g * 16);
+    // ReLU, range watch, split of hidden tile TL into its half (.xy / .zw) of the next step's B operands
+#define GR_FINISH(TL)                                                                                     \
+    _Pragma("unroll") for (int nt = 0; nt < 2; nt++) {                                                    \
+        float4_t r = acc1[nt];                                                                            \
+        r.x = gs_relu(r.x); r.y = gs_relu(r.y); r.z = gs_relu(r.z); r.w = gs_relu(r.w);                   \
+        vmax = __builtin_fmaxf(__builtin_fmaxf(vmax, r.x), r.y);                                          \
+        vmax = __builtin_fmaxf(__builtin_fmaxf(vmax, r.z), r.w);                                          \
+        if ((TL) == 0) { GS_SPLIT2(r.x, r.y, hb_hi[nt].x, hb_lo[nt].x); GS_SPLIT2(r.z, r.w, hb_hi[nt].y, hb_lo[nt].y); } \
+        else { GS_SPLIT2(r.x, r.y, hb_hi[nt].z, hb_lo[nt].z); GS_SPLIT2(r.z, r.w, hb_hi[nt].w, hb_lo[nt].w); }           \
+    }
+    if constexpr (DO2) {  // second linear layer, K-step s-1: acc2[nt][t] += W2 frag(t) x relu(hidden) of the previous step
+        GR_U2_LOAD(f0, 0)
+        GR_SB();
+        GR_U2_LOAD(f1, 1) GR_SB(); GR_U2_MFMA(f0, 0) GR_SB();
+        GR_U2_LOAD(f0, 2) GR_SB(); GR_U2_MFMA(f1, 1) GR_SB();
+        GR_U2_LOAD(f1, 3) GR_SB(); GR_U2_MFMA(f0, 2) GR_SB();
+        GR_U2_LOAD(f0, 4) GR_SB(); GR_U2_MFMA(f1, 3) GR_SB();
+        GR_U2_LOAD(f1, 5) GR_SB(); GR_U2_MFMA(f0, 4) GR_SB();
+        GR_U2_LOAD(f0, 6) GR_SB(); GR_U2_MFMA(f1, 5) GR_SB();
+        // first unit of the first layer (and its bias) requested under the last unit of the second
+        GR_U1_LOAD(f1, 0, 0)
+        GR_BIAS(0)
+        GR_SB();
+        GR_U2_MFMA(f0, 6)
+        GR_SB();
+    }
+    if constexpr (KIND == 3) {  // packed K-step: one MFMA per output tile and column tile (hb_hi holds the packed operand)
+        uint4_t p[GS_T2];
+#pragma unroll
+        for (int t = 0; t < GS_T2; t++) p[t] = GR_LD(GRC_W2_OFF + t * 1024);
+#pragma unroll
+        for (int t = 0; t < GS_T2; t++) {
+            acc2[0][t] = GS_MFMA16(p[t], hb_hi[0], acc2[0][t]);
+            acc2[1][t] = GS_MFMA16(p[t], hb_hi[1], acc2[1][t]);
+        }
+    }
+    if constexpr (DO1) {  // first linear layer: hidden tiles 2s (, 2s+1) = b1 + W1 a, K = 96 as three K-steps + the packed tail
+        if constexpr (!DO2) {
+            GR_U1_LOAD(f1, 0, 0)
+            GR_BIAS(0)
+            GR_SB();
+        }
+        acc1[1] = acc1[0];
+        GR_U1_LOAD(f0, 0, 1) GR_SB(); GR_U1_MFMA1(f1, 0) GR_SB();
+        GR_U1_LOAD(f1, 0, 2) GR_SB(); GR_U1_MFMA1(f0, 1) GR_SB();
+        GR_TAIL_LOAD(f0, 0) GR_SB(); GR_U1_MFMA1(f1, 2) GR_SB();
+        if constexpr (NTL == 2) { GR_U1_LOAD(f1, 1, 0) GR_SB(); }
+        acc1[0] = GS_MFMA16(f0[0], in_tb[0], acc1[0]);
+        acc1[1] = GS_MFMA16(f0[0], in_tb[1], acc1[1]);
+        if constexpr (NTL == 2) {
+            GR_FINISH(0)
+            GR_BIAS(1)
+            acc1[1] = acc1[0];
+            GR_U1_LOAD(f0, 1, 1) GR_SB(); GR_U1_MFMA1(f1, 0) GR_SB();
+            GR_U1_LOAD(f1, 1, 2) GR_SB(); GR_U1_MFMA1(f0, 1) GR_SB();
+            GR_TAIL_LOAD(f0, 1) GR_SB(); GR_U1_MFMA1(f1, 2) GR_SB();
+            acc1[0] = GS_MFMA16(f0[0], in_tb[0], acc1[0]);
+            acc1[1] = GS_MFMA16(f0[0], in_tb[1], acc1[1]);
+            GR_FINISH(1)
+        } else {
+            GR_FINISH(0)
+            // step 6: lanes g = 0 / 1 hold hidden units 192..195 / 196..199 (hi in hb_hi.xy, lo in hb_lo.xy); the packed operand of
+            // step 7 is  g = 0, 1: [hi, lo] (own)   g = 2, 3: [hi of lane - 32, 0]
+#pragma unroll
+            for (int nt = 0; nt < 2; nt++) {
+                const uint32_t ox = __shfl(hb_hi[nt].x, lane & 31, 64), oy = __shfl(hb_hi[nt].y, lane & 31, 64);
+                const bool own = g < 2;
+                hb_hi[nt] = own ? (uint4_t){hb_hi[nt].x, hb_hi[nt].y, hb_lo[nt].x, hb_lo[nt].y} : (uint4_t){ox, oy, 0u, 0u};
+            }
+        }
+        asm volatile("" : "+v"(vmax));
+    }
+#undef GR_U1_MFMA1
+#undef GR_TAIL_LOAD
+#undef GR_BIAS
+#undef GR_FINISH
+#undef GR_U2_LOAD
+#undef GR_U2_MFMA
+#undef GR_U1_LOAD
+#undef GR_U1_MFMA
+}
+#undef GR_LD
+
+struct GrTile { int t0, rows, g0, g1; };
+
+__device__ __forceinline__ void gr_issue_ecomb(const float* __restrict__ ecomb, char* lds_buf, int wave, int lane) {
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+        const int piece = wave + GR_WAVES * r;
+        if (piece < 23 || (piece == 23 && lane < 28)) gr_dma16(reinterpret_cast<const char*>(ecomb) + piece * 1024, (uint32_t)lane * 16u, gr_lds_addr(lds_buf) + piece * 1024);
+    }
+}
+// pieces [13 part, 13 part + 13) of the tile's rows (<= 100 pieces of 1 KiB; a piece may run past the tile's last row: the
+// rows array has 4 KiB of slack and the surplus lands in unused rows of the buffer)
+__device__ __forceinline__ void gr_issue_rows(const float* __restrict__ h0, char* s_rows, const GrTile& t, int part, int wave, int lane) {
+    const int np = (t.rows * (GS_D * 4) + 1023) >> 10;
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+        const int piece = 13 * part + wave + GR_WAVES * r;
+        if (piece < 13 * part + 13 && piece < np)
+            gr_dma16(reinterpret_cast<const char*>(h0) + (size_t)t.t0 * (GS_D * 4) + (size_t)piece * 1024, (uint32_t)lane * 16u, gr_lds_addr(s_rows) + piece * 1024);
+    }
+}
+
+__device__ __forceinline__ GrTile gr_load_tile(const int* __restrict__ tile_row, const int* __restrict__ tile_graph, int tile, int n_tiles) {
+    GrTile t{0, 0, 0, 0};
+    if (tile < n_tiles) {
+        t.t0 = tile_row[tile];
+        t.rows = tile_row[tile + 1] - t.t0;
+        t.g0 = tile_graph[tile];
+        t.g1 = tile_graph[tile + 1];
+        if (t.rows > GR_ROWS) t.rows = GR_ROWS;
+    }
+    return t;
+}
+
+// Per-tile descriptor, built by gin_tile_prep_kernel after the CSR and brought into LDS by DMA (no registers, no VALU in the
+// resident kernel):   [0, 2560)  u16 edge words of the tile's CSR slice: (row inside the tile << 6) | edge code
+//                     [2560, 3088) u16 row offsets into that slice (rows + 1 used)      [3088, 3344) u8 column owner table (below)
+constexpr int GR_DESC_RP = GR_EDGES * 2;
+constexpr int GR_DESC_PERM = GR_DESC_RP + 528;
+constexpr int GR_DESC_BYTES = 3584;  // 3.5 pieces of 1 KiB
+
+// Column owner table: which row of the tile each MFMA column (wave, column tile, lane) owns.  The gather walks the in-edges of
+// the 16 rows of a column tile in lockstep, so a column tile costs as many trips as its LONGEST row: rows are dealt to column
+// tiles in order of decreasing in-degree (stable: ties in row order), and the 16 column tiles to the 8 waves as (k, 15 - k), so
+// that every wave gets a long and a short one.  Placement never changes a row's arithmetic (MFMA columns are independent, a
+// row's in-edges are summed in CSR order whoever owns it): results are identical for any permutation.  Rows beyond the tile's
+// last sort last.   slot = wave * 32 + nt * 16 + j  ->  row inside the tile (0..255)
+__global__ __launch_bounds__(256) void gin_tile_prep_kernel(const int* __restrict__ row_ptr, const int* __restrict__ src,
+                                                            const uint8_t* __restrict__ ecode, const int* __restrict__ tile_row,
+                                                            uint8_t* __restrict__ desc, int n_tiles, int order) {
+    constexpr int NKEY = 18;
+    __shared__ int s_cnt[4][NKEY];
+    const int tile = blockIdx.x;
+    if (tile >= n_tiles) return;
+    const int t0 = tile_row[tile];
+    int rows = tile_row[tile + 1] - t0;
+    if (rows > GR_ROWS) rows = GR_ROWS;
+    const int e0 = row_ptr[t0];
+    int ne = row_ptr[t0 + rows] - e0;
+    if (ne > GR_EDGES) ne = GR_EDGES;  // cannot happen for a validated batch (the host packed by edge count); never overrun LDS
+    uint8_t* d = desc + (size_t)tile * GR_DESC_BYTES;
+    uint16_t* d_edge = reinterpret_cast<uint16_t*>(d);
+    uint16_t* d_rp = reinterpret_cast<uint16_t*>(d + GR_DESC_RP);
+    const int r = threadIdx.x, lane = r & 63, wv = r >> 6;
+    for (int i = r; i < ne; i += 256)
+        d_edge[i] = (uint16_t)((((unsigned)(src[e0 + i] - t0) & 0xFFu) << 6) | ((unsigned)ecode[e0 + i] & 63u));
+    int key = NKEY - 1;  // absent row
+    int deg = 0;
+    {
+        const int lo = r <= rows ? row_ptr[t0 + r] - e0 : ne;
+        const int lo_c = lo < 0 ? 0 : (lo > ne ? ne : lo);
+        d_rp[r] = (uint16_t)lo_c;
+        if (r == 255) d_rp[256] = (uint16_t)ne;
+        if (r < rows) {
+            const int hi = row_ptr[t0 + r + 1] - e0;
+            deg = (hi > ne ? ne : hi) - lo_c;
+            if (deg < 0) deg = 0;
+            key = 16 - (deg < 16 ? deg : 16);  // ascending key = descending in-degree
+        }
+    }
+    if (order == 1) {  // development switch: natural order (column tile k = rows 16k..16k+15)
+        d[GR_DESC_PERM + r] = (uint8_t)r;
+        return;
+    }
+    int below = 0, mine = 0;
+    for (int k = 0; k < NKEY; k++) {
+        const unsigned long long m = __ballot(key == k);
+        if (lane == 0) s_cnt[wv][k] = __popcll(m);
+        if (key == k) mine = __popcll(m & ((1ull << lane) - 1ull));
+    }
+    __syncthreads();
+    for (int k = 0; k < NKEY; k++)
+        for (int w = 0; w < 4; w++) {
+            const int c = s_cnt[w][k];
+            if (k < key || (k == key && w < wv)) below += c;
+        }
+    const int pos = below + mine;          // rank in (key, row) order, 0..255
+    const int kt = pos >> 4, j = pos & 15;  // column tile kt (0 = longest rows), lane j
+    const int wave = kt < 8 ? kt : 15 - kt, nt = kt < 8 ? 0 : 1;
+    d[GR_DESC_PERM + wave * 32 + nt * 16 + j] = (uint8_t)r;
+}
+
+__device__ __forceinline__ void gr_issue_desc(const uint8_t* __restrict__ desc, int tile, char* s_desc, int wave, int lane) {
+    if (wave < 4 && (wave < 3 || lane < 32))
+        gr_dma16(reinterpret_cast<const char*>(desc) + (size_t)tile * GR_DESC_BYTES + wave * 1024, (uint32_t)lane * 16u, gr_lds_addr(s_desc) + wave * 1024);
+}
+
+template <bool PROF>
+__device__ __forceinline__ void gr_layer(unsigned long long (&tacc)[6], char* bx, char* by, float* s_h, char* s_desc, float* s_dot,
+                                         const GrTile& cur, const GrTile& nxt, bool has_next, int next_tile, int l,
+                                         const float* __restrict__ h0, const uint8_t* __restrict__ desc, const float* __restrict__ ecomb_all,
+                                         const uint8_t* __restrict__ wchunks_all, const float* __restrict__ pool_w,
+                                         float* __restrict__ hout, float& vmax, int wave, int lane) {
+    constexpr int NT = 2;
+    const int j = lane & 15, g = lane >> 4;
+    const bool last = l == 4;
+    const uint16_t* s_edge = reinterpret_cast<const uint16_t*>(s_desc);
+    const uint16_t* s_rp = reinterpret_cast<const uint16_t*>(s_desc + GR_DESC_RP);
+    const uint8_t* s_perm = reinterpret_cast<const uint8_t*>(s_desc + GR_DESC_PERM);
+    const uint8_t* wchunks = wchunks_all + (size_t)l * GS_STEPS * GRC_CHUNK_STRIDE;
+    const int ln = last ? 0 : l + 1;  // the layer whose table is prefetched during step 7 (the next tile starts at layer 0)
+    unsigned long long tp = 0;
+    if constexpr (PROF) tp = wall_clock64();
+    grc_issue_chunk(wchunks, by, wave, lane);  // chunk 0: lands under the gather
+
+    // ---- gather (MP unit) out of LDS: a = h[v] + sum_e relu(h[src_e] + ecomb[code_e]), CSR order
+    float bq[NT][25];
+    int e_cur[NT], e_end[NT];
+    unsigned wd[NT];
+    int row[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; nt++) {
+        row[nt] = s_perm[wave * (16 * NT) + nt * 16 + j];
+        const bool valid = row[nt] < cur.rows;
+        const int rr = valid ? row[nt] : 0;
+        e_cur[nt] = s_rp[rr];
+        e_end[nt] = s_rp[rr + 1];
+        if (!valid) e_end[nt] = e_cur[nt];
+#pragma unroll
+        for (int k = 0; k < 25; k++) bq[nt][k] = 0.0f;
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT; nt++) wd[nt] = s_edge[e_cur[nt] < e_end[nt] ? e_cur[nt] : 0];
+    const float* s_ecomb = reinterpret_cast<const float*>(bx);
+    while (true) {
+        bool any = false;
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++) any |= (e_cur[nt] < e_end[nt]);
+        if (!__any(any)) break;
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++) {
+            if (e_cur[nt] < e_end[nt]) {
+                const unsigned u = wd[nt] >> 6, code = wd[nt] & 63u;
+                e_cur[nt]++;
+                if (e_cur[nt] < e_end[nt]) wd[nt] = s_edge[e_cur[nt]];
+                const float* hr = s_h + u * GS_D + 4 * g;
+                const float* er = s_ecomb + code * GS_D + 4 * g;
+                float4 x[6];
+#pragma unroll
+                for (int q = 0; q < 6; q++) x[q] = *reinterpret_cast<const float4*>(hr + 16 * q);
+                const float xt = s_h[u * GS_D + 96 + g];
+#pragma unroll
+                for (int q = 0; q < 6; q++) {
+                    const float4 w = *reinterpret_cast<const float4*>(er + 16 * q);
+                    bq[nt][4 * q + 0] += relu1(w.x + x[q].x);
+                    bq[nt][4 * q + 1] += relu1(w.y + x[q].y);
+                    bq[nt][4 * q + 2] += relu1(w.z + x[q].z);
+                    bq[nt][4 * q + 3] += relu1(w.w + x[q].w);
+                }
+                bq[nt][24] += relu1(s_ecomb[code * GS_D + 96 + g] + xt);
+            }
+        }
+    }
+    uint4_t in_hi[NT][3], in_lo[NT][3], in_tb[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; nt++) {  // + (1 + eps) h[v], eps == 0; rows beyond the tile contribute zeros
+        if (row[nt] < cur.rows) {
+            const float* hr = s_h + row[nt] * GS_D + 4 * g;
+#pragma unroll
+            for (int q = 0; q < 6; q++) {
+                const float4 x = *reinterpret_cast<const float4*>(hr + 16 * q);
+                bq[nt][4 * q + 0] += x.x; bq[nt][4 * q + 1] += x.y; bq[nt][4 * q + 2] += x.z; bq[nt][4 * q + 3] += x.w;
+            }
+            bq[nt][24] += s_h[row[nt] * GS_D + 96 + g];
+        }
+#pragma unroll
+        for (int ks = 0; ks < 3; ks++) {
+            GS_SPLIT2(bq[nt][8 * ks + 0], bq[nt][8 * ks + 1], in_hi[nt][ks].x, in_lo[nt][ks].x);
+            GS_SPLIT2(bq[nt][8 * ks + 2], bq[nt][8 * ks + 3], in_hi[nt][ks].y, in_lo[nt][ks].y);
+            GS_SPLIT2(bq[nt][8 * ks + 4], bq[nt][8 * ks + 5], in_hi[nt][ks].z, in_lo[nt][ks].z);
+            GS_SPLIT2(bq[nt][8 * ks + 6], bq[nt][8 * ks + 7], in_hi[nt][ks].w, in_lo[nt][ks].w);
+        }
+#pragma unroll
+        for (int k = 0; k < 24; k += 2)
+            vmax = __builtin_fmaxf(__builtin_fmaxf(vmax, __builtin_fabsf(bq[nt][k])), __builtin_fabsf(bq[nt][k + 1]));
+        vmax = __builtin_fmaxf(vmax, __builtin_fabsf(bq[nt][24]));
+        {   // K tail (features 96..99, one per lane group): all four to every lane, then the packed operand
+            //   g = 0: [hi(96..99), lo(96..99)]   g = 1: [hi(96..99), 0]   g = 2, 3: 0      (GR chunks, K-tail fragments)
+            const float t0 = __shfl(bq[nt][24], j, 64), t1 = __shfl(bq[nt][24], j + 16, 64);
+            const float t2 = __shfl(bq[nt][24], j + 32, 64), t3 = __shfl(bq[nt][24], j + 48, 64);
+            uint32_t h01, h23, l01, l23;
+            GS_SPLIT2(t0, t1, h01, l01);
+            GS_SPLIT2(t2, t3, h23, l23);
+            in_tb[nt] = g == 0 ? (uint4_t){h01, h23, l01, l23} : (g == 1 ? (uint4_t){h01, h23, 0u, 0u} : (uint4_t){0u, 0u, 0u, 0u});
+        }
+    }
+    if constexpr (PROF) { const unsigned long long t = wall_clock64(); tacc[0] += t - tp; tp = t; }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of chunk 0
+    __syncthreads();  // chunk 0 resident; every wave is done with the table (bx), with the tile's rows and with its CSR slice
+    if constexpr (PROF) { const unsigned long long t = wall_clock64(); tacc[1] += t - tp; tp = t; }
+
+    // last layer: the rows and the descriptor of this tile are dead -- bring in the next tile's (rows: an eighth per MLP step)
+    if (last && has_next) gr_issue_desc(desc, next_tile, s_desc, wave, lane);
+
+    // ---- node MLP (NT unit), weights streamed through LDS
+    float4_t acc2[NT][GS_T2];
+#pragma unroll
+    for (int t2 = 0; t2 < GS_T2; t2++) {
+        const float4 b = *reinterpret_cast<const float4*>(by + GRC_W2_OFF + (16 * t2 + 4 * g) * 4);
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++) acc2[nt][t2] = (float4_t){b.x, b.y, b.z, b.w};
+    }
+    const float oscale = *reinterpret_cast<const float*>(by + GRC_W2_OFF + 112 * 4);
+    uint4_t h_hi[NT], h_lo[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; nt++) { h_hi[nt] = (uint4_t){0, 0, 0, 0}; h_lo[nt] = (uint4_t){0, 0, 0, 0}; }
+#pragma unroll 1
+    for (int c = 0; c < GS_STEPS; c += 2) {
+        // even step: compute from by while chunk c+1 streams into bx
+        grc_issue_chunk(wchunks + (size_t)(c + 1) * GRC_CHUNK_STRIDE, bx, wave, lane);
+        if (last && has_next) gr_issue_rows(h0, reinterpret_cast<char*>(s_h), nxt, c, wave, lane);
+        if (c == 0) gr_step<0>(by, lane, g, in_hi, in_lo, in_tb, h_hi, h_lo, acc2, vmax);
+        else if (c == 6) gr_step<2>(by, lane, g, in_hi, in_lo, in_tb, h_hi, h_lo, acc2, vmax);
+        else gr_step<1>(by, lane, g, in_hi, in_lo, in_tb, h_hi, h_lo, acc2, vmax);
+        unsigned long long tw = 0;
+        if constexpr (PROF) tw = wall_clock64();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of chunk c+1 (and of the next tile) have landed
+        if constexpr (PROF) { const unsigned long long t = wall_clock64(); tacc[5] += t - tw; tw = t; }
+        __syncthreads();                                  // everyone's landed; everyone is done with by
+        if constexpr (PROF) { const unsigned long long t = wall_clock64(); tacc[4] += t - tw; }
+        // odd step: compute from bx while chunk c+2 (after step 7: the next layer's table) streams into by
+        if (c + 2 < GS_STEPS) grc_issue_chunk(wchunks + (size_t)(c + 2) * GRC_CHUNK_STRIDE, by, wave, lane);
+        else gr_issue_ecomb(ecomb_all + (size_t)ln * EDGE_COMBOS * GS_D, by, wave, lane);
+        if (last && has_next) gr_issue_rows(h0, reinterpret_cast<char*>(s_h), nxt, c + 1, wave, lane);
+        if (c == 6) gr_step<3>(bx, lane, g, in_hi, in_lo, in_tb, h_hi, h_lo, acc2, vmax);
+        else gr_step<1>(bx, lane, g, in_hi, in_lo, in_tb, h_hi, h_lo, acc2, vmax);
+        if (c + 2 < GS_STEPS) {
+            if constexpr (PROF) tw = wall_clock64();
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if constexpr (PROF) { const unsigned long long t = wall_clock64(); tacc[5] += t - tw; tw = t; }
+            __syncthreads();
+            if constexpr (PROF) { const unsigned long long t = wall_clock64(); tacc[4] += t - tw; }
+        }
+    }
+
+    if constexpr (PROF) { const unsigned long long t = wall_clock64(); tacc[2] += t - tp; tp = t; }
+    // ---- epilogue: h' back into the tile (in place: nobody reads the old rows any more), or the readout terms
+    if (!last) {
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++) {
+            float* rw = s_h + row[nt] * GS_D;
+#pragma unroll
+            for (int t2 = 0; t2 < GS_T2; t2++) {
+                const int col = 16 * t2 + 4 * g;
+                if (col < GS_D) {
+                    float4_t r = acc2[nt][t2] * oscale;
+                    r.x = gs_relu(r.x); r.y = gs_relu(r.y); r.z = gs_relu(r.z); r.w = gs_relu(r.w);
+                    *reinterpret_cast<float4*>(rw + col) = make_float4(r.x, r.y, r.z, r.w);
+                }
+            }
+        }
+    } else {
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++) {
+            float part = 0.0f;
+            const bool valid = row[nt] < cur.rows;
+#pragma unroll
+            for (int t2 = 0; t2 < GS_T2; t2++) {
+                const int col = 16 * t2 + 4 * g;
+                if (col < GS_D) {
+                    const float4_t r = acc2[nt][t2] * oscale;  // no ReLU after the last layer (GIN/src/node_embedding.cc:185-191)
+                    const float4 pw = *reinterpret_cast<const float4*>(pool_w + col);
+                    part += r.x * pw.x; part += r.y * pw.y; part += r.z * pw.z; part += r.w * pw.w;
+                    if (hout != nullptr && valid)  // debug tap (flowgnn_get_h): the rows themselves
+                        *reinterpret_cast<float4*>(hout + (size_t)(cur.t0 + row[nt]) * GS_D + col) = make_float4(r.x, r.y, r.z, r.w);
+                }
+            }
+            part += __shfl_xor(part, 16, 64);
+            part += __shfl_xor(part, 32, 64);
+            if (g == 0) s_dot[row[nt]] = part;
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the next layer's table (and the last pieces of the next tile)
+    __syncthreads();
+    if constexpr (PROF) { const unsigned long long t = wall_clock64(); tacc[3] += t - tp; }
+}
+
+template <bool PROF>
+__global__ __launch_bounds__(GR_WAVES * 64, 2) void gin_resident_kernel(const float* __restrict__ h0, float* __restrict__ hout,
+                                                                       const float* __restrict__ ecomb_all,
+                                                                       const uint8_t* __restrict__ wchunks_all,
+                                                                       const float* __restrict__ pool_w, const float* __restrict__ pool_b,
+                                                                       const int* __restrict__ tile_row, const int* __restrict__ tile_graph,
+                                                                       const uint8_t* __restrict__ desc,
+                                                                       const int* __restrict__ node_off, float* __restrict__ out, int n_tiles,
+                                                                       int* __restrict__ range_flag, unsigned long long* __restrict__ prof_out) {
+    __shared__ __attribute__((aligned(16))) char s_a[GRC_CHUNK_BYTES];
+    __shared__ __attribute__((aligned(16))) char s_b[GRC_CHUNK_BYTES];
+    __shared__ __attribute__((aligned(16))) float s_h[GR_ROWS * GS_D];
+    unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0};
+    unsigned long long tk0 = 0;
+    if constexpr (PROF) tk0 = wall_clock64();
+    __shared__ __attribute__((aligned(16))) char s_desc[GR_DESC_BYTES];
+    __shared__ float s_dot[GR_ROWS];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int tile = blockIdx.x;
+    if (tile >= n_tiles) return;
+    if (wave >= 4) __builtin_amdgcn_s_setprio(1);  // the second-dispatched half loses every arbitration otherwise (MI355X_MICROARCH: static priority)
+    GrTile cur = gr_load_tile(tile_row, tile_graph, tile, n_tiles);
+    // prologue: this workgroup's first tile (rows, descriptor) and the first table
+    gr_issue_ecomb(ecomb_all, s_a, wave, lane);
+    gr_issue_desc(desc, tile, s_desc, wave, lane);
+#pragma unroll 1
+    for (int part = 0; part < 8; part++) gr_issue_rows(h0, reinterpret_cast<char*>(s_h), cur, part, wave, lane);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    float vmax = 0.0f;
+    bool flip = false;
+    while (true) {
+        const int ntile = tile + gridDim.x;
+        const bool has_next = ntile < n_tiles;
+        const GrTile nxt = gr_load_tile(tile_row, tile_graph, ntile, n_tiles);  // used five layers from now
+#pragma unroll 1
+        for (int l = 0; l < 5; l++) {
+            if (!flip)
+                gr_layer<PROF>(tacc, s_a, s_b, s_h, s_desc, s_dot, cur, nxt, has_next, ntile, l, h0, desc, ecomb_all, wchunks_all, pool_w, hout, vmax, wave, lane);
+            else
+                gr_layer<PROF>(tacc, s_b, s_a, s_h, s_desc, s_dot, cur, nxt, has_next, ntile, l, h0, desc, ecomb_all, wchunks_all, pool_w, hout, vmax, wave, lane);
+            flip = !flip;
+        }
+        // readout (GIN/src/finalize.cc:36-113): out[g] = mean_v(h5[v] . w) + b, node order; the terms stay valid until the next
+        // tile's last layer rewrites them, so no barrier is needed before the next tile starts
+        {
+            const int gi = cur.g0 + (int)threadIdx.x;
+            if (gi < cur.g1) {
+                const int n0 = node_off[gi], n1 = node_off[gi + 1];
+                float sum = 0.0f;
+                for (int v = n0; v < n1; v++) sum += s_dot[v - cur.t0];
+                out[gi] = sum / (float)(n1 - n0) + pool_b[0];
+            }
+        }
+        if (!has_next) break;
+        tile = ntile;
+        cur = nxt;
+    }
+    if (__any(!(vmax < 6.0e4f))) {
+        if (lane == 0) atomicOr(range_flag, 1);
+    }
+    if constexpr (PROF) {  // per-wave phase totals in 10 ns ticks (s_memrealtime)
+        if (lane == 0) {
+            for (int i = 0; i < 6; i++) prof_out[((size_t)blockIdx.x * GR_WAVES + wave) * 7 + i] = tacc[i];
+            prof_out[((size_t)blockIdx.x * GR_WAVES + wave) * 7 + 6] = wall_clock64() - tk0;
+        }
+    }
+}
+
 inline float pow2_scale(const float* w, size_t n) {
     float m = 0.0f;
     for (size_t i = 0; i < n; i++) m = std::fmax(m, std::fabs(w[i]));
@@ -498,6 +1047,81 @@ void gin_split_pack_layer(const float* w1, const float* b1, const float* w2, con
     }
 }
 
+size_t gin_resident_layer_bytes() { return (size_t)GS_STEPS * GRC_CHUNK_STRIDE; }
+
+void gin_resident_pack_layer(const float* w1, const float* b1, const float* w2, const float* b2, uint8_t* out) {
+    std::memset(out, 0, gin_resident_layer_bytes());
+    const float s1 = pow2_scale(w1, (size_t)GS_H * GS_D);
+    const float s2 = pow2_scale(w2, (size_t)GS_D * GS_H);
+    auto w1s = [&](int o, int f) { return (o < GS_H && f < GS_D) ? w1[o * GS_D + f] * s1 : 0.0f; };
+    auto w2s = [&](int d, int k) { return (d < GS_D && k < GS_H) ? w2[d * GS_H + k] * s2 : 0.0f; };
+    auto hi16 = [](float v) { return (_Float16)v; };
+    auto lo16 = [](float v) { const _Float16 h = (_Float16)v; return (_Float16)(v - (float)h); };
+    auto put16 = [](uint8_t* p, _Float16 v) { std::memcpy(p, &v, 2); };
+    for (int s = 0; s < GS_STEPS; s++) {
+        uint8_t* ck = out + (size_t)s * GRC_CHUNK_STRIDE;
+        if (s < GS_STEPS - 1) {
+            for (int tl = 0; tl < 2; tl++) {
+                const int t = 2 * s + tl;
+                for (int lane = 0; lane < 64; lane++) {
+                    const int i = lane & 15, gk = lane >> 4;
+                    const int o = 16 * t + i;
+                    for (int ks = 0; ks < 3; ks++)
+                        for (int e = 0; e < 8; e++) {
+                            const int f = 16 * (2 * ks + (e >> 2)) + 4 * gk + (e & 3);
+                            put_split(ck + (size_t)tl * 6144 + (size_t)(ks * 2) * 1024, lane, e, w1s(o, f));
+                        }
+                    if (lane < 32) {  // K tail: g = 0 -> [w_hi(96..99), w_hi(96..99)], g = 1 -> [w_lo(96..99), 0]
+                        uint8_t* tp = ck + GRC_TAIL_OFF + tl * 512 + lane * 16;
+                        for (int e = 0; e < 4; e++) {
+                            const float v = w1s(o, 96 + e);
+                            if (gk == 0) { put16(tp + e * 2, hi16(v)); put16(tp + 8 + e * 2, hi16(v)); }
+                            else { put16(tp + e * 2, lo16(v)); put16(tp + 8 + e * 2, (_Float16)0.0f); }
+                        }
+                    }
+                }
+                for (int x = 0; x < 16; x++) {
+                    const int o = 16 * t + x;
+                    const float b = o < GS_H ? b1[o] * s1 : 0.0f;
+                    std::memcpy(ck + GRC_B1_OFF + tl * 64 + x * 4, &b, 4);
+                }
+            }
+        }
+        if (s >= 1 && s <= 6) {
+            const int ks = s - 1;
+            for (int t2 = 0; t2 < GS_T2; t2++)
+                for (int lane = 0; lane < 64; lane++) {
+                    const int i = lane & 15, gk = lane >> 4;
+                    const int d = 16 * t2 + i;
+                    for (int e = 0; e < 8; e++) {
+                        const int k = 16 * (2 * ks + (e >> 2)) + 4 * gk + (e & 3);
+                        put_split(ck + GRC_W2_OFF + (size_t)(t2 * 2) * 1024, lane, e, w2s(d, k));
+                    }
+                }
+        } else if (s == 7) {  // packed K-step: hidden units 192..199
+            for (int t2 = 0; t2 < GS_T2; t2++)
+                for (int lane = 0; lane < 64; lane++) {
+                    const int i = lane & 15, gk = lane >> 4;
+                    const int d = 16 * t2 + i;
+                    uint8_t* fp = ck + GRC_W2_OFF + (size_t)t2 * 1024 + lane * 16;
+                    const int k0 = 192 + 4 * (gk & 1);
+                    for (int e = 0; e < 4; e++) {
+                        const float v = w2s(d, k0 + e);
+                        if (gk < 2) { put16(fp + e * 2, hi16(v)); put16(fp + 8 + e * 2, hi16(v)); }
+                        else { put16(fp + e * 2, lo16(v)); put16(fp + 8 + e * 2, (_Float16)0.0f); }
+                    }
+                }
+        } else {
+            for (int x = 0; x < 16 * GS_T2; x++) {
+                const float b = x < GS_D ? b2[x] * s1 * s2 : 0.0f;
+                std::memcpy(ck + GRC_W2_OFF + x * 4, &b, 4);
+            }
+            const float os = 1.0f / (s1 * s2);
+            std::memcpy(ck + GRC_W2_OFF + 112 * 4, &os, 4);
+        }
+    }
+}
+
 void launch_gin_layer_split(const float* h, float* hout, const int* row_ptr, const int* src, const uint8_t* ecode,
                             const float* ecomb, const uint8_t* chunks, int n_tot, int e_tot, int relu_out, int* range_flag,
                             int nt, hipStream_t s, const float* pool_w) {
@@ -513,6 +1137,36 @@ void launch_gin_layer_split(const float* h, float* hout, const int* row_ptr, con
         const int blocks = (int)ceil_div_ll(n_tot, 64);
         gin_layer_split_kernel<1, 4><<<blocks, 256, 0, s>>>(h, hout, row_ptr, src, ecode, ecomb, chunks, n_tot, relu_out, range_flag, pool_w);
     }
+}
+
+void launch_gin_resident(const float* h0, float* hout, const int* row_ptr, const int* src, const uint8_t* ecode, const float* ecomb_all,
+                         const uint8_t* chunks_all, const float* pool_w, const float* pool_b, const int* tile_row, const int* tile_graph,
+                         uint8_t* tile_desc, const int* node_off, float* out, int n_tiles, int* range_flag, hipStream_t s) {
+    if (n_tiles <= 0) return;
+    static const int order = getenv("FLOWGNN_GIN_RESIDENT_NOSORT") ? atoi(getenv("FLOWGNN_GIN_RESIDENT_NOSORT")) : 0;
+    gin_tile_prep_kernel<<<n_tiles, 256, 0, s>>>(row_ptr, src, ecode, tile_row, tile_desc, n_tiles, order);
+    const int grid = n_tiles < 256 ? n_tiles : 256;  // persistent: one 8-wave workgroup per CU (157 KB of LDS)
+    static const bool prof = getenv("FLOWGNN_GIN_RESIDENT_PROF") && atoi(getenv("FLOWGNN_GIN_RESIDENT_PROF")) != 0;
+    if (prof) {  // development aid: phase breakdown from s_memrealtime stamps, printed per launch (synchronises!)
+        unsigned long long* d = nullptr;
+        const size_t cnt = (size_t)grid * GR_WAVES * 7;
+        if (hipMalloc((void**)&d, cnt * 8) != hipSuccess) return;
+        (void)hipMemsetAsync(d, 0, cnt * 8, s);
+        gin_resident_kernel<true><<<grid, GR_WAVES * 64, 0, s>>>(h0, hout, ecomb_all, chunks_all, pool_w, pool_b, tile_row,
+                                                                 tile_graph, tile_desc, node_off, out, n_tiles, range_flag, d);
+        std::vector<unsigned long long> hbuf(cnt);
+        (void)hipStreamSynchronize(s);
+        (void)hipMemcpy(hbuf.data(), d, cnt * 8, hipMemcpyDeviceToHost);
+        (void)hipFree(d);
+        double tot[7] = {0, 0, 0, 0, 0, 0, 0};
+        for (size_t i = 0; i < cnt; i++) tot[i % 7] += (double)hbuf[i];
+        const double nw = (double)grid * GR_WAVES;
+        fprintf(stderr, "[gin_resident prof] tiles %d grid %d | per wave, us: gather %.1f  wait+barrier %.1f  mlp %.1f (of which step-end DMA wait %.1f, barrier %.1f)  epilogue+barrier %.1f  kernel %.1f\n",
+                n_tiles, grid, tot[0] / nw / 100.0, tot[1] / nw / 100.0, tot[2] / nw / 100.0, tot[5] / nw / 100.0, tot[4] / nw / 100.0, tot[3] / nw / 100.0, tot[6] / nw / 100.0);
+        return;
+    }
+    gin_resident_kernel<false><<<grid, GR_WAVES * 64, 0, s>>>(h0, hout, ecomb_all, chunks_all, pool_w, pool_b, tile_row,
+                                                              tile_graph, tile_desc, node_off, out, n_tiles, range_flag, nullptr);
 }
 
 }  // namespace fg

@@ -153,9 +153,10 @@ def test_gin_aggregation_probe_is_bit_exact(monkeypatch, oracle, env):
     assert np.allclose(out, want_out, rtol=2e-4, atol=1e-3)
     for layer in (0, 3):
         h_in, agg = e.aggregate(layer)
-        # what the probe read is a real layer input: h_4 (readout folded into the last layer) or h_5
-        d4, d5 = np.abs(h_in - hd[4]).max(), np.abs(h_in - hd[5]).max()
-        assert min(d4, d5) < 1e-3 * max(1.0, float(np.abs(hd[4]).max())), (d4, d5)
+        # what the probe read is a real layer input: h_0 (graph-resident path: only the encoder output is in HBM), h_4 (readout
+        # folded into the last per-layer launch) or h_5
+        dist = [float(np.abs(h_in - hd[k]).max()) / max(1.0, float(np.abs(hd[k]).max())) for k in range(6)]
+        assert min(dist) < 1e-3, dist
         want = gin_aggregate_reference(h_in, b, row_ptr, src, eid, np.asarray(w["edge_embedding_weight"], np.float32)[layer])
         assert np.array_equal(agg, want), (layer, np.abs(agg - want).max())
     assert np.array_equal(e.forward(b), out)  # the probe leaves the engine usable
