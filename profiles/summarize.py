@@ -1,7 +1,10 @@
 #!/usr/bin/env python3
 """Condense rocprofv3 CSV output into the small per-kernel summaries committed under profiles/.
 
-  python profiles/summarize.py stats  <kernel_stats.csv | kernel_trace.csv>  > profiles/rNN_*.txt
+  python profiles/summarize.py stats  <kernel_stats.csv | kernel_trace.csv> [steps warmup]  > profiles/rNN_*.txt
+      with `steps warmup` (the bench.py arguments of the traced run) the warm-up launches of every kernel are left out, so that
+      the averages are those of the timed region (a kernel with c calls runs c / (steps + warmup) times per step; its first
+      warmup x that many calls, in time order, are dropped)
   python profiles/summarize.py pmc    <counter_collection.csv> COUNTER       > profiles/rNN_*.txt
 """
 import csv
@@ -9,13 +12,28 @@ import sys
 from collections import defaultdict
 
 
-def stats(path):
+def stats(path, steps=0, warmup=0):
     rows = list(csv.DictReader(open(path)))
     if rows and "Start_Timestamp" in rows[0]:  # kernel_trace.csv -> aggregate ourselves
-        agg = defaultdict(lambda: [0, 0.0])
+        rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+        calls = defaultdict(int)
         for r in rows:
+            calls[r["Kernel_Name"]] += 1
+        skip = {}
+        for k, c in calls.items():
+            per_step = c // (steps + warmup) if steps + warmup > 0 and c % (steps + warmup) == 0 else 0
+            skip[k] = per_step * warmup  # kernels that do not run once per step (set-up launches) are kept whole
+        if steps:
+            print(f"# timed region only: {steps} steps, the launches of the {warmup} warm-up step(s) are excluded")
+        agg = defaultdict(lambda: [0, 0.0])
+        seen = defaultdict(int)
+        for r in rows:
+            k = r["Kernel_Name"]
+            seen[k] += 1
+            if seen[k] <= skip[k]:
+                continue
             d = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
-            a = agg[r["Kernel_Name"]]
+            a = agg[k]
             a[0] += 1
             a[1] += d
         tot = sum(v[1] for v in agg.values())
@@ -44,6 +62,6 @@ def pmc(path, counter):
 
 if __name__ == "__main__":
     if sys.argv[1] == "stats":
-        stats(sys.argv[2])
+        stats(sys.argv[2], *(int(a) for a in sys.argv[3:5]))
     else:
         pmc(sys.argv[2], sys.argv[3])

@@ -41,7 +41,9 @@ def test_forward_matches_oracle(eng, oracle, w):
 
 def test_golden_vectors(eng):
     z = np.load(GOLDEN)
-    assert close(eng.forward(from_npz(z)), z["logits_synth_weights"], 50.0)
+    got, want = eng.forward(from_npz(z)), z["logits_synth_weights"]
+    # absolute + relative, not scaled by the activations: the logits are of order 1..10
+    assert np.allclose(got, want, rtol=2e-4, atol=2e-3), np.abs(got - want).max()
 
 
 def test_entry_point_bin_loader_and_edge_cases(tmp_path, oracle, w):
