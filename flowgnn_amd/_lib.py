@@ -46,6 +46,8 @@ def _declare(lib):
     lib.flowgnn_graph_replays.argtypes = [eng]
     lib.flowgnn_graph_replays.restype = C.c_longlong
     lib.flowgnn_set_numeric_mode.argtypes = [eng, C.c_int]
+    lib.flowgnn_set_num_tasks.argtypes = [eng, C.c_int]
+    lib.flowgnn_num_tasks.argtypes = [eng]
     lib.flowgnn_get_csr.argtypes = [eng, p_int, p_int, p_int, p_int]
     lib.flowgnn_get_h.argtypes = [eng, p_float, p_int]
     lib.flowgnn_profile_enable.argtypes = [eng, C.c_int]
@@ -61,7 +63,7 @@ def _declare(lib):
     lib.GCN_compute_graphs.argtypes = [C.c_int, p_int, p_int, p_int, p_float, p_int, p_int, p_int] + [p_float] * 11
     for name in ("flowgnn_create", "flowgnn_destroy", "flowgnn_set_weights_gin", "flowgnn_set_weights", "flowgnn_load_weights_dir",
                  "flowgnn_set_batch", "flowgnn_run", "flowgnn_sync", "flowgnn_get_results",
-                 "flowgnn_results_device", "flowgnn_set_results_buffer", "flowgnn_stream", "flowgnn_batch_info", "flowgnn_exact_reruns", "flowgnn_set_numeric_mode", "flowgnn_get_csr",
+                 "flowgnn_results_device", "flowgnn_set_results_buffer", "flowgnn_stream", "flowgnn_batch_info", "flowgnn_exact_reruns", "flowgnn_set_numeric_mode", "flowgnn_set_num_tasks", "flowgnn_num_tasks", "flowgnn_get_csr",
                  "flowgnn_get_h", "flowgnn_profile_enable", "flowgnn_profile_read",
                  "flowgnn_run_aggregation_only", "flowgnn_get_aggregate", "flowgnn_set_stream", "GIN_compute_graphs", "GCN_compute_graphs", "PNA_compute_graphs", "DGN_compute_graphs", "GAT_compute_graphs"):
         getattr(lib, name).restype = C.c_int

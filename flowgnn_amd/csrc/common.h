@@ -126,7 +126,8 @@ struct DeviceBatch {
     const float* node_eigen;  // [N][4] or null
     float* h[2];              // ping/pong node embeddings [N][dim]
     float* scratch;           // [N][scratch_dim] model scratch (aggregates)
-    float* out;               // [G]
+    float* out;               // [G][num_tasks]
+    int num_tasks;            // NUM_TASK of the readout (1 unless flowgnn_set_num_tasks said otherwise)
     int final_h;              // which h[] holds the last stage's output (set by forward)
     const float* tap;         // optional debug tap returned by flowgnn_get_h instead of h[final_h]
     int tap_dim;
@@ -146,6 +147,8 @@ public:
     virtual void set_keep_h(bool) {}
     // 0 = fp32 (default); 1 = the reference's ap_fixed<16,6> bit patterns (GIN / GIN-VN only: ginq.hip)
     virtual int set_numeric_mode(int mode) { return mode == 0 ? 0 : 8 /* FLOWGNN_ERR_UNSUPPORTED */; }
+    // NUM_TASK of the readout (graph_pred_weights [NUM_TASK][EMB_DIM], out [G][NUM_TASK]); takes effect at the next set_weights
+    virtual int set_num_tasks(int t) { return t == 1 ? 0 : 8; }
     // rows > 0: flowgnn_set_batch packs whole graphs into tiles of at most rows rows / edges in-edges (DeviceBatch::gtiles)
     virtual void graph_tile_limits(int& rows, int& edges) const { rows = 0; edges = 0; }
     virtual int emb_dim() const = 0;

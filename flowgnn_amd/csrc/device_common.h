@@ -171,6 +171,57 @@ __global__ __launch_bounds__(256) void mean_pool_linear_kernel(const float* __re
     if (lane == 0) out[g] = pb[0] + part;
 }
 
+// ---------------------------------------------------------------- readout: mean pool + linear head with NUM_TASK outputs
+// out[g][t] = pb[t] + sum_d mean_v(h[v][d]) pw[t][d]   (finalize + linear<EMB_DIM, NUM_TASK, ...>: GIN/src/finalize.cc:14-34,
+// GIN/src/linear.cc:26-47, with NUM_TASK -- 1 in the reference, GIN/src/dcl.h:25 -- as a run-time dimension; ogbg-molpcba has 128).
+// Persistent workgroups; the head is kept in LDS transposed ([d][t], so the lanes of a wave read consecutive words), TCH tasks
+// at a time; one wavefront per graph pools its rows (two half-waves over alternate rows, float4 chunks) and then takes the
+// tasks t = lane, lane + 64, ...  Summation order per output: d = 0..D-1.
+template <int D>
+__global__ __launch_bounds__(256) void mean_pool_linear_mt_kernel(const float* __restrict__ h, const int* __restrict__ node_off,
+                                                                   const float* __restrict__ pw, const float* __restrict__ pb,
+                                                                   float* __restrict__ out, int num_graphs, int num_tasks) {
+    constexpr int C = D / 4;
+    constexpr int TCH = 128;
+    static_assert(C <= 32, "row must fit half a wavefront in float4 chunks");
+    __shared__ float s_w[D * TCH];
+    __shared__ float s_hg[4][D];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int t0 = 0; t0 < num_tasks; t0 += TCH) {
+        const int nt = (num_tasks - t0) < TCH ? (num_tasks - t0) : TCH;
+        __syncthreads();
+        for (int i = threadIdx.x; i < nt * D; i += 256) {
+            const int t = i / D, d = i - t * D;
+            s_w[d * TCH + t] = pw[(size_t)(t0 + t) * D + d];
+        }
+        __syncthreads();
+        for (int g = blockIdx.x * 4 + wv; g < num_graphs; g += gridDim.x * 4) {
+            const int n0 = node_off[g], n1 = node_off[g + 1];
+            const int half = lane >> 5, c = lane & 31;
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (c < C)
+                for (int v = n0 + half; v < n1; v += 2) {
+                    const float4 x = reinterpret_cast<const float4*>(h)[(size_t)v * C + c];
+                    acc.x += x.x; acc.y += x.y; acc.z += x.z; acc.w += x.w;
+                }
+            acc.x += __shfl_down(acc.x, 32, 64); acc.y += __shfl_down(acc.y, 32, 64);
+            acc.z += __shfl_down(acc.z, 32, 64); acc.w += __shfl_down(acc.w, 32, 64);
+            if (half == 0 && c < C) {
+                const float n = (float)(n1 - n0);
+                s_hg[wv][4 * c + 0] = acc.x / n; s_hg[wv][4 * c + 1] = acc.y / n;
+                s_hg[wv][4 * c + 2] = acc.z / n; s_hg[wv][4 * c + 3] = acc.w / n;
+            }
+            __builtin_amdgcn_wave_barrier();
+            for (int t = lane; t < nt; t += 64) {
+                float sacc = pb[t0 + t];
+                for (int d = 0; d < D; d++) sacc += s_hg[wv][d] * s_w[d * TCH + t];
+                out[(size_t)g * num_tasks + t0 + t] = sacc;
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+}
+
 static inline int grid_for(long long items, int per_block, int cap) {
     long long nb = (items + per_block - 1) / per_block;
     if (nb > cap) nb = cap;

@@ -100,6 +100,7 @@ struct flowgnn_engine {
     // resident batch
     bool batch_ready = false;
     bool ran = false;
+    int num_tasks = 1;          // NUM_TASK of the readout: results are [G][num_tasks]
     bool force_exact = false;   // the resident batch tripped the range flag once: run it on the exact kernels
     int exact_reruns = 0;
     long long G = 0, N = 0, E = 0;
@@ -275,6 +276,7 @@ int flowgnn_load_weights_dir(flowgnn_engine* e, const char* dir) {
 
 static int alloc_batch(flowgnn_engine* e, size_t G, size_t N, size_t E, bool attr, bool eig) {
     const int D = e->model->emb_dim(), SD = e->model->scratch_dim();
+    G *= (size_t)e->num_tasks;  // capG counts result slots (only d_out and the small per-graph arrays scale with it)
     if (G > e->capG || N > e->capN || E > e->capE || (attr && !e->d_ea) || (eig && !e->d_eig)) {
         e->free_batch();
         const size_t g1 = G ? G : 1, n1 = N ? N : 1, e1 = E ? E : 1;
@@ -417,6 +419,7 @@ int flowgnn_set_batch(flowgnn_engine* e, int num_graphs, const int* nums_of_node
     db.csr.block_sums = e->d_bsums; db.csr.err = e->d_err;
     db.node_eigen = eig ? e->d_eig : nullptr;
     db.h[0] = e->d_h0; db.h[1] = e->d_h1; db.scratch = e->d_scratch; db.out = e->d_out;
+    db.num_tasks = e->num_tasks;
     db.final_h = 0;
     db.tap = nullptr;
     db.tap_dim = 0;
@@ -550,7 +553,7 @@ int flowgnn_get_results(flowgnn_engine* e, float* out_host) {
     int rc = flowgnn_sync(e);
     if (rc) return rc;
     if (e->G > 0) {
-        hipError_t he = hipMemcpy(out_host, e->db.out, sizeof(float) * (size_t)e->G, hipMemcpyDeviceToHost);
+        hipError_t he = hipMemcpy(out_host, e->db.out, sizeof(float) * (size_t)e->G * e->num_tasks, hipMemcpyDeviceToHost);
         if (he != hipSuccess) {
             set_hip_error("copy results", he, __FILE__, __LINE__);
             e->err = fg::last_error_text();
@@ -604,6 +607,21 @@ int flowgnn_batch_info(const flowgnn_engine* e, long long* num_graphs, long long
 int flowgnn_exact_reruns(const flowgnn_engine* e) { return e ? e->exact_reruns : -1; }
 
 long long flowgnn_graph_replays(const flowgnn_engine* e) { return e ? e->graph_replays : -1; }
+
+int flowgnn_set_num_tasks(flowgnn_engine* e, int num_tasks) {
+    if (!e || num_tasks < 1) return FLOWGNN_ERR_ARG;
+    ENGINE_TRY(e, use_device(e));
+    e->drop_graph();
+    if (e->stream) EHIP_TRY(e, hipStreamSynchronize(e->stream));
+    const int rc = e->model->set_num_tasks(num_tasks);
+    if (rc) { e->err = "flowgnn_set_num_tasks: this model's readout has a single task (multi-task readout exists for GIN / GIN-VN / GCN)"; return rc; }
+    e->num_tasks = num_tasks;
+    e->batch_ready = false;  // the result buffer is sized by the batch: set the batch again
+    e->ran = false;
+    return FLOWGNN_OK;
+}
+
+int flowgnn_num_tasks(const flowgnn_engine* e) { return e ? e->num_tasks : -1; }
 
 int flowgnn_set_numeric_mode(flowgnn_engine* e, int mode) {
     if (!e) return FLOWGNN_ERR_ARG;
@@ -748,10 +766,18 @@ static unsigned long long hash_tensors(int ntens, const float* const* t, const s
     return h;
 }
 
+// NUM_TASK of the GIN / GCN entry points: a compile-time constant of the reference build (GIN/src/dcl.h:25, 1 as shipped); a
+// caller whose build uses another value says so with FLOWGNN_NUM_TASK (out is then [num_graphs][NUM_TASK], as in the reference)
+static int entry_num_tasks() {
+    const char* v = getenv("FLOWGNN_NUM_TASK");
+    const int t = v ? atoi(v) : 1;
+    return t >= 1 ? t : 1;
+}
+
 static int compute_graphs_generic(int model, int num_graphs, const int* nums_of_nodes, const int* nums_of_edges,
                                   const int* reload_weights, float* out, const int* node_feature, const float* node_eigen,
                                   const int* edge_list, const int* edge_attr, int ntens, const float* const* tens,
-                                  const size_t* tens_elems) {
+                                  const size_t* tens_elems, int num_tasks = 1) {
     if (num_graphs < 0) return FLOWGNN_ERR_ARG;
     if (num_graphs == 0) return FLOWGNN_OK;
     if (!nums_of_nodes || !nums_of_edges || !reload_weights || !out || !node_feature) return FLOWGNN_ERR_ARG;
@@ -764,6 +790,11 @@ static int compute_graphs_generic(int model, int num_graphs, const int* nums_of_
         const char* dev = getenv("FLOWGNN_DEVICE");
         int rc = flowgnn_create(model, dev ? atoi(dev) : 0, &eng);
         if (rc) return rc;
+    }
+    if (eng->num_tasks != num_tasks) {
+        int rc = flowgnn_set_num_tasks(eng, num_tasks);
+        if (rc) return rc;
+        g_entry_whash_valid[model] = false;
     }
     long long noff = 0, eoff = 0;
     int set = -1, g = 0;
@@ -790,7 +821,7 @@ static int compute_graphs_generic(int model, int num_graphs, const int* nums_of_
         if (rc) return rc;
         rc = flowgnn_run(eng);
         if (rc) return rc;
-        rc = flowgnn_get_results(eng, out + g);
+        rc = flowgnn_get_results(eng, out + (size_t)g * num_tasks);
         if (rc) return rc;
         noff += n;
         eoff += m;
@@ -806,9 +837,10 @@ int GIN_compute_graphs(int num_graphs, int* nums_of_nodes, int* nums_of_edges, i
                        float* graph_pred_bias_in) {
     const float* t[8] = {node_embedding_weight_in, edge_embedding_weight_in, node_mlp_1_weights, node_mlp_1_bias,
                          node_mlp_2_weights,       node_mlp_2_bias,          graph_pred_weights_in, graph_pred_bias_in};
-    static const size_t sz[8] = {173 * 100, 5 * 13 * 100, 5 * 200 * 100, 5 * 200, 5 * 100 * 200, 5 * 100, 100, 1};
+    const int T = entry_num_tasks();
+    const size_t sz[8] = {173 * 100, 5 * 13 * 100, 5 * 200 * 100, 5 * 200, 5 * 100 * 200, 5 * 100, (size_t)T * 100, (size_t)T};
     return compute_graphs_generic(FLOWGNN_MODEL_GIN, num_graphs, nums_of_nodes, nums_of_edges, reload_weights, out,
-                                  node_feature_in, nullptr, edge_list_in, edge_attr_in, 8, t, sz);
+                                  node_feature_in, nullptr, edge_list_in, edge_attr_in, 8, t, sz, T);
 }
 
 int GCN_compute_graphs(int num_graphs, int* nums_of_nodes, int* nums_of_edges, int* reload_weights, float* out,
@@ -819,9 +851,10 @@ int GCN_compute_graphs(int num_graphs, int* nums_of_nodes, int* nums_of_edges, i
     const float* t[11] = {node_embedding_weight_in, edge_embedding_weight_in, convs_weight_in, convs_bias_in,
                           convs_root_emb_weight_in, bn_weight_in, bn_bias_in, bn_mean_in, bn_var_in,
                           graph_pred_weights_in, graph_pred_bias_in};
-    static const size_t sz[11] = {173 * 100, 5 * 13 * 100, 5 * 100 * 100, 500, 500, 500, 500, 500, 500, 100, 1};
+    const int T = entry_num_tasks();
+    const size_t sz[11] = {173 * 100, 5 * 13 * 100, 5 * 100 * 100, 500, 500, 500, 500, 500, 500, (size_t)T * 100, (size_t)T};
     return compute_graphs_generic(FLOWGNN_MODEL_GCN, num_graphs, nums_of_nodes, nums_of_edges, reload_weights, out,
-                                  node_feature_in, nullptr, edge_list_in, edge_attr_in, 11, t, sz);
+                                  node_feature_in, nullptr, edge_list_in, edge_attr_in, 11, t, sz, T);
 }
 
 int PNA_compute_graphs(int num_graphs, int* nums_of_nodes, int* nums_of_edges, int* reload_weights, float* out,

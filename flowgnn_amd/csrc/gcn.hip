@@ -337,7 +337,7 @@ public:
     int set_weights(const float* const* t) override {
         const float *nemb = t[0], *eemb = t[1], *cw = t[2], *cb = t[3], *root = t[4], *bnw = t[5], *bnb = t[6], *bnm = t[7],
                     *bnv = t[8], *pw = t[9], *pb = t[10];
-        std::vector<float> v_nemb(nemb, nemb + ND_FEATURE_TOTAL * GCN_D), v_pw(pw, pw + GCN_D), v_pb(pb, pb + 1);
+        std::vector<float> v_nemb(nemb, nemb + ND_FEATURE_TOTAL * GCN_D), v_pw(pw, pw + (size_t)num_tasks_ * GCN_D), v_pb(pb, pb + num_tasks_);
         std::vector<float> ecomb((size_t)GCN_L * EDGE_COMBOS * GCN_D), ep((size_t)GCN_L * 3 * GCN_D);
         std::vector<float> wf_all, wt_all, bp_all;
         std::vector<uint8_t> split_all;
@@ -389,7 +389,7 @@ public:
     int load_weights_dir(const char* dir) override {
         const char* f = "gcn_ep1_dim100.weights.all.bin";
         std::vector<float> nemb(173 * 100), eemb(5 * 13 * 100), cw(5 * 100 * 100), cb(500), root(500), bnw(500), bnb(500),
-            bnm(500), bnv(500), pw(100), pb(1);
+            bnm(500), bnv(500), pw((size_t)num_tasks_ * 100), pb(num_tasks_);
         int rc;
         if ((rc = read_floats(dir, f, 0, nemb.size(), nemb.data()))) return rc;
         for (int l = 0; l < GCN_L; l++) {
@@ -404,8 +404,9 @@ public:
             if ((rc = read_floats(dir, f, bn + 200, 100, &bnm[l * 100]))) return rc;
             if ((rc = read_floats(dir, f, bn + 300, 100, &bnv[l * 100]))) return rc;
         }
-        if ((rc = read_floats(dir, f, 76805, 100, pw.data()))) return rc;
-        if ((rc = read_floats(dir, f, 76905, 1, pb.data()))) return rc;
+        // graph_pred_linear: weight [NUM_TASK][100] then bias [NUM_TASK] (NUM_TASK = 1 in the reference's file: 76805, 76905)
+        if ((rc = read_floats(dir, f, 76805, pw.size(), pw.data()))) return rc;
+        if ((rc = read_floats(dir, f, 76805 + pw.size(), pb.size(), pb.data()))) return rc;
         const float* t[11] = {nemb.data(), eemb.data(), cw.data(), cb.data(), root.data(), bnw.data(),
                               bnb.data(),  bnm.data(),  bnv.data(), pw.data(), pb.data()};
         return set_weights(t);
@@ -481,7 +482,7 @@ public:
             cur ^= 1;
         }
         db.final_h = cur;
-        if (split_ && !exact_ && fused_ && db.b.e_tot > 0) {
+        if (split_ && !exact_ && fused_ && db.b.e_tot > 0 && num_tasks_ == 1) {
             // last stage: aggregation + BatchNorm with the readout's linear head folded in (per-node scores in db.scratch;
             // flowgnn_get_h returns x_4 = db.h[final_h], which is untouched by this)
             {
@@ -502,9 +503,21 @@ public:
         }
         {
             ProfScope p(prof, "mean_pool_linear", s);
+            if (num_tasks_ > 1) {  // NUM_TASK outputs per graph (linear_input_stationary over [NUM_TASK][100], GCN/src/finalize.cc:79-113)
+                const int blocks = (db.b.num_graphs + 3) / 4;
+                mean_pool_linear_mt_kernel<GCN_D><<<blocks < 512 ? blocks : 512, 256, 0, s>>>(db.scratch, db.b.node_off, d_pw_, d_pb_, db.out,
+                                                                                              db.b.num_graphs, num_tasks_);
+            } else
             mean_pool_linear_kernel<GCN_D><<<(db.b.num_graphs + 3) / 4, 256, 0, s>>>(db.scratch, db.b.node_off, d_pw_, d_pb_,
                                                                                      db.out, db.b.num_graphs);
         }
+        return 0;
+    }
+
+    int set_num_tasks(int t) override {
+        if (t < 1) return 8;
+        if (t != num_tasks_) ready_ = false;  // graph_pred_weights / bias change shape: set the weights again
+        num_tasks_ = t;
         return 0;
     }
 
@@ -526,6 +539,7 @@ private:
         tiles_.release();
     }
     bool ready_ = false;
+    int num_tasks_ = 1;  // NUM_TASK (GCN/src/dcl.h) as a run-time dimension
     GrowBuf esc_;
     GrowBufI tiles_;  // graph-aligned tile starts of the resident batch (tile_bounds_kernel)
     int tile_nominal_ = getenv("FLOWGNN_TILE_NOMINAL") ? atoi(getenv("FLOWGNN_TILE_NOMINAL")) : 96;

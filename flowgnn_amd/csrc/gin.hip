@@ -547,7 +547,7 @@ public:
     int set_weights(const float* const* t) override {
         const float *nemb = t[0], *eemb = t[1], *w1 = t[2], *b1 = t[3], *w2 = t[4], *b2 = t[5], *pw = t[6], *pb = t[7];
         std::vector<float> v_nemb(nemb, nemb + ND_FEATURE_TOTAL * GIN_D);
-        std::vector<float> v_pw(pw, pw + GIN_D), v_pb(pb, pb + 1);
+        std::vector<float> v_pw(pw, pw + (size_t)num_tasks_ * GIN_D), v_pb(pb, pb + num_tasks_);  // [NUM_TASK][100], [NUM_TASK]
         std::vector<float> ecomb((size_t)GIN_L * EDGE_COMBOS * GIN_D);
         std::vector<float> w1f((size_t)GIN_L * GIN_T1 * 6 * 64 * 4), w1tail((size_t)GIN_L * GIN_T1 * 64);
         std::vector<float> b1p((size_t)GIN_L * GIN_T1 * 16), b2p((size_t)GIN_L * GIN_T2 * 16);
@@ -642,7 +642,7 @@ public:
     int load_weights_dir(const char* dir) override {
         std::vector<float> w1((size_t)GIN_L * GIN_H * GIN_D), b1((size_t)GIN_L * GIN_H), w2((size_t)GIN_L * GIN_D * GIN_H),
             b2((size_t)GIN_L * GIN_D), nemb((size_t)ND_FEATURE_TOTAL * GIN_D), eemb((size_t)GIN_L * ED_FEATURE_PER_LAYER * GIN_D),
-            pw(GIN_D), pb(1);
+            pw((size_t)num_tasks_ * GIN_D), pb(num_tasks_);
         int rc;
         if ((rc = read_floats(dir, "gin_ep1_mlp_1_weights_dim100.bin", 0, w1.size(), w1.data()))) return rc;
         if ((rc = read_floats(dir, "gin_ep1_mlp_1_bias_dim100.bin", 0, b1.size(), b1.data()))) return rc;
@@ -719,15 +719,20 @@ public:
             ProfScope p(prof, "atom_encoder", s);
             atom_encoder_kernel<GIN_D><<<atom_encoder_grid(n, GIN_C), 512, 0, s>>>(db.b.node_feature, d_nemb_, db.h[0], n, db.csr.err);
         }
+        const bool multi = num_tasks_ > 1;  // NUM_TASK > 1: the layers leave h_5 in HBM and a multi-task readout kernel follows
         if (use_resident(db)) {
             // all five layers and the readout in one launch; h_5 rows are written (to h[1]) only for the flowgnn_get_h tap
             if (int rc = perm_.reserve((size_t)db.gtiles.n_tiles * (GIN_RESIDENT_DESC_BYTES / 4))) return rc;
-            ProfScope p(prof, "gin_resident", s);
-            launch_gin_resident(db.h[0], keep_h_ ? db.h[1] : nullptr, db.csr.row_ptr, db.csr.src, db.csr.ecode, d_ecomb_, d_rsplit_, d_pw_, d_pb_,
-                                db.gtiles.row_start, db.gtiles.graph_start, reinterpret_cast<uint8_t*>(perm_.p), db.b.node_off, db.out,
-                                db.gtiles.n_tiles, db.range_flag, s);
-            db.final_h = keep_h_ ? 1 : 0;
-            db.h_valid = keep_h_;
+            const bool rows = keep_h_ || multi;
+            {
+                ProfScope p(prof, "gin_resident", s);
+                launch_gin_resident(db.h[0], rows ? db.h[1] : nullptr, db.csr.row_ptr, db.csr.src, db.csr.ecode, d_ecomb_, d_rsplit_, d_pw_, d_pb_,
+                                    db.gtiles.row_start, db.gtiles.graph_start, reinterpret_cast<uint8_t*>(perm_.p), db.b.node_off,
+                                    multi ? nullptr : db.out, db.gtiles.n_tiles, db.range_flag, s);
+            }
+            db.final_h = rows ? 1 : 0;
+            db.h_valid = rows;
+            if (multi) launch_readout_mt(db, db.h[1], prof, s);
             return 0;
         }
         int cur = 0;
@@ -737,7 +742,7 @@ public:
                 ProfScope p(prof, "gin_layer_fused", s);
                 // last layer: the readout's per-node dot product h'[v] . w_pred is taken in the epilogue and only that
                 // leaves the kernel (db.scratch as float[n]); the rows are written only for the flowgnn_get_h tap
-                const bool fold = l == GIN_L - 1 && fold_readout_ && !keep_h_;
+                const bool fold = l == GIN_L - 1 && fold_readout_ && !keep_h_ && !multi;
                 launch_gin_layer_split(db.h[cur], fold ? db.scratch : db.h[cur ^ 1], db.csr.row_ptr, db.csr.src, db.csr.ecode,
                                        layer_dev(l).ecomb, d_split_ + (size_t)l * GS_LAYER_BYTES, n, db.b.e_tot, l != GIN_L - 1,
                                        db.range_flag, split_nt_, s, fold ? d_pw_ : nullptr);
@@ -773,6 +778,10 @@ public:
         }
         db.final_h = cur;
         db.h_valid = !folded;
+        if (multi) {
+            launch_readout_mt(db, db.h[cur], prof, s);
+            return 0;
+        }
         {
             ProfScope p(prof, "mean_pool_linear", s);
             if (folded)
@@ -785,11 +794,25 @@ public:
         return 0;
     }
 
+    void launch_readout_mt(DeviceBatch& db, const float* h, Profiler& prof, hipStream_t s) {
+        ProfScope p(prof, "mean_pool_linear", s);
+        const int blocks = (db.b.num_graphs + 3) / 4;
+        mean_pool_linear_mt_kernel<GIN_D><<<blocks < 512 ? blocks : 512, 256, 0, s>>>(h, db.b.node_off, d_pw_, d_pb_, db.out, db.b.num_graphs,
+                                                                                      num_tasks_);
+    }
+
     void set_exact(bool on) override { exact_ = on; }
     void set_keep_h(bool on) override { keep_h_ = on; }
     int set_numeric_mode(int mode) override {
         if (mode != 0 && mode != 1) return 8;
+        if (mode == 1 && num_tasks_ != 1) return 8;  // the Q6.10 readout is single-task (as the reference's)
         qmode_ = mode == 1;
+        return 0;
+    }
+    int set_num_tasks(int t) override {
+        if (t < 1 || (t != 1 && qmode_)) return 8;
+        if (t != num_tasks_) ready_ = false;  // graph_pred_weights / bias change shape: set the weights again
+        num_tasks_ = t;
         return 0;
     }
 
@@ -821,6 +844,7 @@ private:
     bool exact_ = false;
     bool keep_h_ = false;
     bool qmode_ = false;  // flowgnn_set_numeric_mode(FLOWGNN_NUMERIC_Q6_10)
+    int num_tasks_ = 1;   // NUM_TASK (GIN/src/dcl.h:25) as a run-time dimension
     GinQWeights qw_;
     GrowBufI perm_;  // graph-resident path: per-tile descriptors (gin_tile_prep_kernel)
     // FLOWGNN_GIN_FOLD_READOUT=0 keeps the separate mean-pool + linear kernel (and the last layer's 2.7 GB of rows)

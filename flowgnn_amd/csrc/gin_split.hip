@@ -960,7 +960,7 @@ __global__ __launch_bounds__(GR_WAVES * 64, 2) void gin_resident_kernel(const fl
         // tile's last layer rewrites them, so no barrier is needed before the next tile starts
         {
             const int gi = cur.g0 + (int)threadIdx.x;
-            if (gi < cur.g1) {
+            if (out != nullptr && gi < cur.g1) {  // out == null: multi-task readout, done by the caller from the hout rows
                 const int n0 = node_off[gi], n1 = node_off[gi + 1];
                 float sum = 0.0f;
                 for (int v = n0; v < n1; v++) sum += s_dot[v - cur.t0];

@@ -48,6 +48,7 @@ class Engine:
         self._h = C.c_void_p()
         self._check(self.lib.flowgnn_create(_lib.MODEL_IDS[self.model], device, C.byref(self._h)), "flowgnn_create")
         self._keep = []
+        self.num_tasks = 1
 
     def _check(self, rc: int, where: str):
         if rc != 0:
@@ -95,9 +96,14 @@ class Engine:
         self._check(self.lib.flowgnn_sync(self._h), "flowgnn_sync")
 
     def results(self) -> np.ndarray:
-        out = np.empty(self.num_graphs, dtype=np.float32)
+        out = np.empty(self.num_graphs * self.num_tasks, dtype=np.float32)
         self._check(self.lib.flowgnn_get_results(self._h, _pf(out)), "flowgnn_get_results")
-        return out
+        return out.reshape(self.num_graphs, self.num_tasks) if self.num_tasks > 1 else out
+
+    def set_num_tasks(self, num_tasks: int):
+        """NUM_TASK of the readout (GIN / GIN-VN / GCN): set before weights and batch; results become [G][num_tasks]."""
+        self._check(self.lib.flowgnn_set_num_tasks(self._h, int(num_tasks)), "flowgnn_set_num_tasks")
+        self.num_tasks = int(num_tasks)
 
     def results_device_ptr(self) -> int:
         p = C.c_void_p()
@@ -178,7 +184,7 @@ class Engine:
             self._check(self.lib.flowgnn_set_stream(self._h, C.c_void_p(stream_handle), 1), "flowgnn_set_stream")
 
 
-def compute_graphs(model: str, batch: GraphBatch, weight_sets, reload_weights=None) -> np.ndarray:
+def compute_graphs(model: str, batch: GraphBatch, weight_sets, reload_weights=None, num_tasks: int = 1) -> np.ndarray:
     """Call the reference-compatible C symbol <M>_compute_graphs (e.g. GIN/src/dcl.h:75-94) with host
     arrays.  `weight_sets` is a list of weight dicts: the leading [S] dimension of every weight pointer,
     selected per graph by the running count of reload_weights (GIN/src/GIN_compute.cc:51-53)."""
@@ -191,7 +197,10 @@ def compute_graphs(model: str, batch: GraphBatch, weight_sets, reload_weights=No
             reload_weights[0] = 1
     stacked = [np.ascontiguousarray(np.stack([np.asarray(ws[k], dtype=np.float32) for ws in weight_sets]))
                for k in weight_sets[0].keys()]  # [S, ...] per tensor (avg_deg: [S, 1] == float[S])
-    out = np.zeros(G, dtype=np.float32)
+    out = np.zeros(G * num_tasks, dtype=np.float32)
+    if num_tasks != 1:  # the entry points take NUM_TASK (a compile-time constant of the reference build) from the environment
+        import os
+        os.environ["FLOWGNN_NUM_TASK"] = str(num_tasks)
     nn, ne, rw = _i32(batch.nums_of_nodes), _i32(batch.nums_of_edges), _i32(reload_weights)
     nf, el, ea = _i32(batch.node_feature), _i32(batch.edge_list), _i32(batch.edge_attr)
     wp = [_pf(a) for a in stacked]
@@ -208,9 +217,11 @@ def compute_graphs(model: str, batch: GraphBatch, weight_sets, reload_weights=No
         rc = lib.DGN_compute_graphs(G, _pi(nn), _pi(ne), _pi(rw), _pf(out), _pi(nf), _pf(eig), _pi(el), *wp)
     else:
         raise ValueError(model)
+    if num_tasks != 1:
+        os.environ.pop("FLOWGNN_NUM_TASK", None)
     if rc:
         raise FlowGNNError(rc, f"{model}_compute_graphs")
-    return out
+    return out.reshape(G, num_tasks) if num_tasks > 1 else out
 
 
 def GIN_compute_graphs(batch: GraphBatch, weight_sets, reload_weights=None) -> np.ndarray:

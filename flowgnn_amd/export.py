@@ -64,10 +64,12 @@ def _fold_bn(w: np.ndarray, b: np.ndarray, sd: Mapping, prefix: str):
     return w * s[:, None], (b - mean) * s + beta
 
 
-def gin_weights_from_ogb_state_dict(sd: Mapping, num_layers: int = 5, eps_tol: float = 0.0) -> Dict[str, np.ndarray]:
+def gin_weights_from_ogb_state_dict(sd: Mapping, num_layers: int = 5, eps_tol: float = 0.0, multi_task: bool = False) -> Dict[str, np.ndarray]:
     """OGB `GNN(gnn_type='gin', virtual_node=False, JK='last', residual=False, graph_pooling='mean')` -> the reference's
     GIN weight set.  `convs.l.mlp` may be Linear-BatchNorm-ReLU-Linear (OGB) or Linear-ReLU-Linear; `batch_norms.l`
     (applied to the conv output before the ReLU) is folded into the second linear layer when present.
+    multi_task: keep every row of graph_pred_linear (ogbg-molpcba: 128 tasks) -- graph_pred_weights becomes [NUM_TASK][100], for
+    an engine with flowgnn_set_num_tasks(NUM_TASK); without it a head with more than one task is refused (the reference's NUM_TASK is 1).
     The reference ignores GIN's eps (GIN/src/host_load.cc reads it, nothing uses it): a trained |eps| > eps_tol is refused."""
     p = "gnn_node"
     out = OrderedDict()
@@ -91,13 +93,14 @@ def gin_weights_from_ogb_state_dict(sd: Mapping, num_layers: int = 5, eps_tol: f
     out["node_mlp_1_weights"], out["node_mlp_1_bias"] = np.stack(w1s), np.stack(b1s)
     out["node_mlp_2_weights"], out["node_mlp_2_bias"] = np.stack(w2s), np.stack(b2s)
     pw, pb = _get(sd, "graph_pred_linear.weight"), _get(sd, "graph_pred_linear.bias")
-    if pw.shape[0] != 1:
-        raise ExportError(f"graph_pred_linear has {pw.shape[0]} tasks; the reference is built with NUM_TASK = 1 (GIN/src/dcl.h:25)")
+    if pw.shape[0] != 1 and not multi_task:
+        raise ExportError(f"graph_pred_linear has {pw.shape[0]} tasks; the reference is built with NUM_TASK = 1 (GIN/src/dcl.h:25): "
+                          f"pass multi_task=True for an engine with flowgnn_set_num_tasks({pw.shape[0]})")
     out["graph_pred_weights"], out["graph_pred_bias"] = pw, pb
-    return _checked(out, _weights.GIN_FILES, lambda v: v[1])
+    return _checked(out, _weights.GIN_FILES, lambda k, v: _weights._task_shape(k, v[1], pw.shape[0]))
 
 
-def gcn_weights_from_ogb_state_dict(sd: Mapping, num_layers: int = 5) -> Dict[str, np.ndarray]:
+def gcn_weights_from_ogb_state_dict(sd: Mapping, num_layers: int = 5, multi_task: bool = False) -> Dict[str, np.ndarray]:
     """OGB `GNN(gnn_type='gcn', ...)` -> the reference's GCN weight set.  BatchNorm stays a separate step in the
     reference (GCN/src/node_embedding.cc:123-138) but with 2^-10 added to the variance instead of torch's 1e-5
     (GCN/src/load_inputs.cc:32): the exported variance is shifted by the difference so that both normalise alike."""
@@ -122,17 +125,18 @@ def gcn_weights_from_ogb_state_dict(sd: Mapping, num_layers: int = 5) -> Dict[st
     for k, v in cols.items():
         out[k] = np.stack(v)
     pw, pb = _get(sd, "graph_pred_linear.weight"), _get(sd, "graph_pred_linear.bias")
-    if pw.shape[0] != 1:
-        raise ExportError(f"graph_pred_linear has {pw.shape[0]} tasks; the reference is built with NUM_TASK = 1 (GCN/src/dcl.h)")
+    if pw.shape[0] != 1 and not multi_task:
+        raise ExportError(f"graph_pred_linear has {pw.shape[0]} tasks; the reference is built with NUM_TASK = 1 (GCN/src/dcl.h): "
+                          f"pass multi_task=True for an engine with flowgnn_set_num_tasks({pw.shape[0]})")
     out["graph_pred_weights"], out["graph_pred_bias"] = pw, pb
     ordered = OrderedDict((k, out[k]) for k in _weights.GCN_SHAPES)
-    return _checked(ordered, _weights.GCN_SHAPES, lambda v: v)
+    return _checked(ordered, _weights.GCN_SHAPES, lambda k, v: _weights._task_shape(k, v, pw.shape[0]))
 
 
 def _checked(w: Dict[str, np.ndarray], spec: Mapping, shape_of) -> Dict[str, np.ndarray]:
     res = OrderedDict()
     for k, v in spec.items():
-        shp = tuple(shape_of(v))
+        shp = tuple(shape_of(k, v))
         a = np.asarray(w[k], dtype=np.float64)
         if a.size != int(np.prod(shp)):
             raise ExportError(f"{k}: {a.shape} does not fit the reference's {shp}")
@@ -142,14 +146,15 @@ def _checked(w: Dict[str, np.ndarray], spec: Mapping, shape_of) -> Dict[str, np.
     return res
 
 
-def export_weights(model: str, sd: Mapping, directory: str) -> Dict[str, np.ndarray]:
-    """Write the `.bin` file(s) `host` / `flowgnn_load_weights_dir` read for `model` ('GIN', 'GIN-VN' or 'GCN')."""
+def export_weights(model: str, sd: Mapping, directory: str, multi_task: bool = False) -> Dict[str, np.ndarray]:
+    """Write the `.bin` file(s) `host` / `flowgnn_load_weights_dir` read for `model` ('GIN', 'GIN-VN' or 'GCN').
+    multi_task: keep all rows of the prediction head (the engine then needs flowgnn_set_num_tasks(rows) before loading)."""
     m = model.upper()
     if m in ("GIN", "GIN-VN"):
-        w = gin_weights_from_ogb_state_dict(sd)
+        w = gin_weights_from_ogb_state_dict(sd, multi_task=multi_task)
         _weights.save_gin_weights(w, directory)
     elif m == "GCN":
-        w = gcn_weights_from_ogb_state_dict(sd)
+        w = gcn_weights_from_ogb_state_dict(sd, multi_task=multi_task)
         _weights.save_gcn_weights(w, directory)
     else:
         raise ExportError(f"no OGB example model corresponds to the reference's {model} (its PNA/DGN/GAT checkpoints are already "

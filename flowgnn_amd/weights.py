@@ -37,18 +37,29 @@ def _read(path: str, shape, offset_floats: int = 0) -> np.ndarray:
     return np.ascontiguousarray(arr.reshape(shape), dtype=np.float32)
 
 
-def load_gin_weights(directory: str) -> Dict[str, np.ndarray]:
-    return OrderedDict((k, _read(os.path.join(directory, f), shp)) for k, (f, shp) in GIN_FILES.items())
+def _task_shape(k: str, shp, num_tasks: int):
+    """graph_pred_weights [NUM_TASK][D] / graph_pred_bias [NUM_TASK]: NUM_TASK is 1 in the reference (GIN/src/dcl.h:25), a
+    run-time dimension here (flowgnn_set_num_tasks)."""
+    if k == "graph_pred_weights":
+        return (num_tasks,) + tuple(shp[1:])
+    if k == "graph_pred_bias":
+        return (num_tasks,)
+    return tuple(shp)
+
+
+def load_gin_weights(directory: str, num_tasks: int = 1) -> Dict[str, np.ndarray]:
+    return OrderedDict((k, _read(os.path.join(directory, f), _task_shape(k, shp, num_tasks))) for k, (f, shp) in GIN_FILES.items())
 
 
 def save_gin_weights(w: Dict[str, np.ndarray], directory: str) -> None:
     os.makedirs(directory, exist_ok=True)
+    tasks = int(np.asarray(w["graph_pred_bias"]).size)
     for k, (f, shp) in GIN_FILES.items():
-        np.asarray(w[k], dtype="<f4").reshape(shp).tofile(os.path.join(directory, f))
+        np.asarray(w[k], dtype="<f4").reshape(_task_shape(k, shp, tasks)).tofile(os.path.join(directory, f))
     np.zeros(5, dtype="<f4").tofile(os.path.join(directory, "gin_ep1_eps_dim100.bin"))  # read, never used
 
 
-def synth_gin_weights(seed: int = 7) -> Dict[str, np.ndarray]:
+def synth_gin_weights(seed: int = 7, num_tasks: int = 1) -> Dict[str, np.ndarray]:
     """Random weights with the measured scales of the shipped GIN set:
     W1 s=0.075, b1 s=0.91, W2 s=0.053, b2 s=0.49, node/edge emb s=0.11/0.14, pred s=0.15."""
     rng = np.random.default_rng(seed)
@@ -58,7 +69,7 @@ def synth_gin_weights(seed: int = 7) -> Dict[str, np.ndarray]:
         "node_mlp_2_weights": 0.053, "node_mlp_2_bias": 0.49,
         "graph_pred_weights": 0.15, "graph_pred_bias": 0.12,
     }
-    return OrderedDict((k, (rng.standard_normal(shp) * scale[k]).astype(np.float32))
+    return OrderedDict((k, (rng.standard_normal(_task_shape(k, shp, num_tasks)) * scale[k]).astype(np.float32))
                        for k, (_, shp) in GIN_FILES.items())
 
 
@@ -72,9 +83,10 @@ GCN_SHAPES = OrderedDict([
 ])
 
 
-def _gcn_offsets():
-    """(name, layer or None) -> float offset in the .all.bin (GCN/src/host_load.cc:34-170)."""
-    off = {("node_embedding_weight", None): 0, ("graph_pred_weights", None): 76805, ("graph_pred_bias", None): 76905}
+def _gcn_offsets(num_tasks: int = 1):
+    """(name, layer or None) -> float offset in the .all.bin (GCN/src/host_load.cc:34-170); the head is the last tensor pair of
+    the flattened state_dict: weight [NUM_TASK][100] at 76805, bias [NUM_TASK] right behind it (76905 for NUM_TASK = 1)."""
+    off = {("node_embedding_weight", None): 0, ("graph_pred_weights", None): 76805, ("graph_pred_bias", None): 76805 + 100 * num_tasks}
     for l in range(5):
         base = 17300 + 11500 * l
         off[("convs_weight", l)] = base
@@ -89,13 +101,13 @@ def _gcn_offsets():
     return off
 
 
-def load_gcn_weights(directory: str) -> Dict[str, np.ndarray]:
+def load_gcn_weights(directory: str, num_tasks: int = 1) -> Dict[str, np.ndarray]:
     path = os.path.join(directory, GCN_FILE)
-    off = _gcn_offsets()
+    off = _gcn_offsets(num_tasks)
     w = OrderedDict()
     for k, shp in GCN_SHAPES.items():
         if (k, None) in off:
-            w[k] = _read(path, shp, off[(k, None)])
+            w[k] = _read(path, _task_shape(k, shp, num_tasks), off[(k, None)])
         else:
             w[k] = np.stack([_read(path, shp[1:], off[(k, l)]) for l in range(5)])
     return w
@@ -103,10 +115,11 @@ def load_gcn_weights(directory: str) -> Dict[str, np.ndarray]:
 
 def save_gcn_weights(w: Dict[str, np.ndarray], directory: str) -> None:
     os.makedirs(directory, exist_ok=True)
-    buf = np.zeros(76906, dtype="<f4")
-    off = _gcn_offsets()
+    tasks = int(np.asarray(w["graph_pred_bias"]).size)
+    buf = np.zeros(76805 + 101 * tasks, dtype="<f4")
+    off = _gcn_offsets(tasks)
     for k, shp in GCN_SHAPES.items():
-        a = np.asarray(w[k], dtype=np.float32).reshape(shp)
+        a = np.asarray(w[k], dtype=np.float32).reshape(_task_shape(k, shp, tasks))
         if (k, None) in off:
             buf[off[(k, None)]:off[(k, None)] + a.size] = a.ravel()
         else:
@@ -115,13 +128,14 @@ def save_gcn_weights(w: Dict[str, np.ndarray], directory: str) -> None:
     buf.tofile(os.path.join(directory, GCN_FILE))
 
 
-def synth_gcn_weights(seed: int = 7) -> Dict[str, np.ndarray]:
+def synth_gcn_weights(seed: int = 7, num_tasks: int = 1) -> Dict[str, np.ndarray]:
     rng = np.random.default_rng(seed)
     scale = {"node_embedding_weight": 0.11, "edge_embedding_weight": 0.14, "convs_weight": 0.09, "convs_bias": 0.1,
              "convs_root_emb_weight": 0.3, "bn_weight": 0.2, "bn_bias": 0.2, "bn_mean": 0.3,
              "graph_pred_weights": 0.15, "graph_pred_bias": 0.12}
     w = OrderedDict()
     for k, shp in GCN_SHAPES.items():
+        shp = _task_shape(k, shp, num_tasks)
         if k == "bn_var":
             w[k] = rng.uniform(0.3, 1.5, shp).astype(np.float32)
         elif k == "bn_weight":

@@ -245,6 +245,18 @@ int flowgnn_exact_reruns(const flowgnn_engine* e);
 long long flowgnn_graph_replays(const flowgnn_engine* e);
 
 /*
+ * NUM_TASK of the readout as a run-time dimension (a compile-time constant in the reference, GIN/src/dcl.h:25, 1 as
+ * shipped; ogbg-molpcba has 128 tasks).  graph_pred_weights is then [NUM_TASK][EMB_DIM], graph_pred_bias [NUM_TASK], and
+ * the results are [num_graphs][NUM_TASK] (out[g][t], as `FM_TYPE out[][NUM_TASK]`, GIN/src/dcl.h:80) -- every buffer that
+ * receives results (flowgnn_get_results, flowgnn_set_results_buffer) holds num_graphs * NUM_TASK floats.  Call it before
+ * setting weights and batch (both must be set again afterwards).  GIN / GIN-VN / GCN; the other models' readouts are
+ * single-task MLP heads and return FLOWGNN_ERR_UNSUPPORTED for NUM_TASK != 1.  The <M>_compute_graphs entry points take their
+ * NUM_TASK from the environment variable FLOWGNN_NUM_TASK (default 1).
+ */
+int flowgnn_set_num_tasks(flowgnn_engine* e, int num_tasks);
+int flowgnn_num_tasks(const flowgnn_engine* e);
+
+/*
  * Numeric mode of the engine.  FLOWGNN_NUMERIC_F32 (default): fp32 storage and accumulation.
  * FLOWGNN_NUMERIC_Q6_10: every value is the reference's ap_fixed<16,6> bit pattern
  * (GIN/src/dcl.h:58-59: 10 fractional bits, truncation toward -inf, wrap on overflow), weights

@@ -61,6 +61,17 @@ int orc_GIN_compute_graphs(int num_graphs, const int* nums_of_nodes, const int* 
                            const float* graph_pred_weights_in, const float* graph_pred_bias_in,
                            float* h_dump, int nthreads);
 
+/* NUM_TASK (GIN/src/dcl.h:25, 1 in the reference) as a run-time dimension: graph_pred_weights_in [S][num_tasks][100],
+ * graph_pred_bias_in [S][num_tasks], out [num_graphs][num_tasks] (linear<EMB_DIM, NUM_TASK, ...>, GIN/src/linear.cc:26-47). */
+int orc_GIN_compute_graphs_mt(int num_graphs, const int* nums_of_nodes, const int* nums_of_edges,
+                              const int* reload_weights, float* out,
+                              const int* node_feature_in, const int* edge_list_in, const int* edge_attr_in,
+                              const float* node_embedding_weight_in, const float* edge_embedding_weight_in,
+                              const float* node_mlp_1_weights, const float* node_mlp_1_bias,
+                              const float* node_mlp_2_weights, const float* node_mlp_2_bias,
+                              const float* graph_pred_weights_in, const float* graph_pred_bias_in,
+                              float* h_dump, int nthreads, int num_tasks);
+
 /*
  * GCN forward, float semantics.  Mirrors GCN_compute_graphs, GCN/src/GCN_compute.cc:7-112
  * (argument order of GCN/src/dcl.h:75-97).  x_dump (optional): [5][N_tot][100], x_l = NT(l) output.

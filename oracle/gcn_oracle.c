@@ -20,6 +20,7 @@ static inline float relu_f(float x) { return x < 0.0f ? 0.0f : x; }
 
 typedef struct {
     const float *nemb, *eemb, *cw, *cb, *root, *bnw, *bnb, *bnm, *bnv, *pw, *pb;
+    int nt; /* NUM_TASK (GCN/src/dcl.h): rows of graph_pred_weights, entries of graph_pred_bias and of out[] per graph */
 } gcn_w;
 
 static int gcn_one_graph(int n, int e, const int* nf, const int* el, const int* ea, const gcn_w* w, float* out,
@@ -142,14 +143,16 @@ static int gcn_one_graph(int n, int e, const int* nf, const int* el, const int* 
             }
             hg[d] = sum / (float)n;
         }
-        float o = w->pb[0];
-        for (int d = 0; d < D; d += 2) {
-            float addend = 0.0f;
-            addend += hg[d] * w->pw[d];
-            addend += hg[d + 1] * w->pw[d + 1];
-            o += addend;
+        for (int task = 0; task < w->nt; task++) {
+            float o = w->pb[task];
+            for (int d = 0; d < D; d += 2) {
+                float addend = 0.0f;
+                addend += hg[d] * w->pw[task * D + d];
+                addend += hg[d + 1] * w->pw[task * D + d + 1];
+                o += addend;
+            }
+            out[task] = o;
         }
-        out[0] = o;
     }
 done:
     free(degree_table); free(degree_tables); free(nto); free(neighbor_tables); free(edge_attrs); free(norms);
@@ -159,6 +162,16 @@ done:
 
 /* GCN_compute_graphs, GCN/src/GCN_compute.cc:7-112 (argument order of GCN/src/dcl.h:75-97).
    x_dump (optional): [5][N_tot][100], x_l = output of NT(l). */
+int orc_GCN_compute_graphs_mt(int num_graphs, const int* nums_of_nodes, const int* nums_of_edges,
+                              const int* reload_weights, float* out, const int* node_feature_in,
+                              const int* edge_list_in, const int* edge_attr_in,
+                              const float* node_embedding_weight_in, const float* edge_embedding_weight_in,
+                              const float* convs_weight_in, const float* convs_bias_in,
+                              const float* convs_root_emb_weight_in, const float* bn_weight_in,
+                              const float* bn_bias_in, const float* bn_mean_in, const float* bn_var_in,
+                              const float* graph_pred_weights_in, const float* graph_pred_bias_in,
+                              float* x_dump, int nthreads, int num_tasks);
+
 int orc_GCN_compute_graphs(int num_graphs, const int* nums_of_nodes, const int* nums_of_edges,
                            const int* reload_weights, float* out, const int* node_feature_in,
                            const int* edge_list_in, const int* edge_attr_in,
@@ -168,6 +181,24 @@ int orc_GCN_compute_graphs(int num_graphs, const int* nums_of_nodes, const int* 
                            const float* bn_bias_in, const float* bn_mean_in, const float* bn_var_in,
                            const float* graph_pred_weights_in, const float* graph_pred_bias_in,
                            float* x_dump, int nthreads)
+{
+    return orc_GCN_compute_graphs_mt(num_graphs, nums_of_nodes, nums_of_edges, reload_weights, out, node_feature_in, edge_list_in,
+                                     edge_attr_in, node_embedding_weight_in, edge_embedding_weight_in, convs_weight_in, convs_bias_in,
+                                     convs_root_emb_weight_in, bn_weight_in, bn_bias_in, bn_mean_in, bn_var_in,
+                                     graph_pred_weights_in, graph_pred_bias_in, x_dump, nthreads, 1);
+}
+
+/* The same with NUM_TASK as a run-time dimension: graph_pred_weights_in [S][num_tasks][100], graph_pred_bias_in [S][num_tasks],
+   out [num_graphs][num_tasks]. */
+int orc_GCN_compute_graphs_mt(int num_graphs, const int* nums_of_nodes, const int* nums_of_edges,
+                              const int* reload_weights, float* out, const int* node_feature_in,
+                              const int* edge_list_in, const int* edge_attr_in,
+                              const float* node_embedding_weight_in, const float* edge_embedding_weight_in,
+                              const float* convs_weight_in, const float* convs_bias_in,
+                              const float* convs_root_emb_weight_in, const float* bn_weight_in,
+                              const float* bn_bias_in, const float* bn_mean_in, const float* bn_var_in,
+                              const float* graph_pred_weights_in, const float* graph_pred_bias_in,
+                              float* x_dump, int nthreads, int num_tasks)
 {
     long* noff = (long*)malloc(sizeof(long) * (size_t)(num_graphs + 1));
     long* eoff = (long*)malloc(sizeof(long) * (size_t)(num_graphs + 1));
@@ -197,10 +228,11 @@ int orc_GCN_compute_graphs(int num_graphs, const int* nums_of_nodes, const int* 
         w.bnb = bn_bias_in + s * L * D;
         w.bnm = bn_mean_in + s * L * D;
         w.bnv = bn_var_in + s * L * D;
-        w.pw = graph_pred_weights_in + s * D;
-        w.pb = graph_pred_bias_in + s;
+        w.nt = num_tasks;
+        w.pw = graph_pred_weights_in + s * num_tasks * D;
+        w.pb = graph_pred_bias_in + s * num_tasks;
         int r = gcn_one_graph(nums_of_nodes[g], nums_of_edges[g], node_feature_in + noff[g] * 9,
-                              edge_list_in + eoff[g] * 2, edge_attr_in + eoff[g] * 3, &w, out + g, x_dump, n_tot, noff[g]);
+                              edge_list_in + eoff[g] * 2, edge_attr_in + eoff[g] * 3, &w, out + (size_t)g * num_tasks, x_dump, n_tot, noff[g]);
         if (r) {
 #ifdef _OPENMP
 #pragma omp critical

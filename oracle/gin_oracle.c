@@ -55,6 +55,7 @@ void orc_gin_load_graph(const int* edge_list, const int* edge_attr, int n, int e
 
 typedef struct {
     const float *nemb, *eemb, *w1, *b1, *w2, *b2, *pw, *pb;
+    int nt; /* NUM_TASK (GIN/src/dcl.h:25): rows of graph_pred_weights, entries of graph_pred_bias and of out[] per graph */
 } gin_w;
 
 static int gin_one_graph(int n, int e, const int* nf, const int* el, const int* ea,
@@ -141,7 +142,7 @@ static int gin_one_graph(int n, int e, const int* nf, const int* el, const int* 
     /* readout: GIN/src/finalize.cc:36-113 sums nodes two at a time (NODE_PARALLEL=2):
        pair sum first, then the running sum is added; then / n; linear GIN/src/linear.cc:36-41 */
     {
-        float res = w->pb[0];
+        float hgv[D];
         int iters = (n + 1) / 2 - 1;
         int tail = ((n - 1) % 2) + 1;
         for (int d = 0; d < D; d++) {
@@ -156,15 +157,29 @@ static int gin_one_graph(int n, int e, const int* nf, const int* el, const int* 
             float t = 0.0f;
             for (int k = 0; k < tail; k++) t += h[(2 * iters + k) * D + d];
             if (iters != 0) t += sum;
-            float hg = t / (float)n;                                    /* finalize.cc:112 */
-            res += hg * w->pw[d];
+            hgv[d] = t / (float)n;                                      /* finalize.cc:112 */
         }
-        out[0] = res;
+        for (int task = 0; task < w->nt; task++) {                      /* linear<EMB_DIM, NUM_TASK, ...>, linear.cc:26-47 */
+            float res = w->pb[task];
+            for (int d = 0; d < D; d++) res += hgv[d] * w->pw[task * D + d];
+            out[task] = res;
+        }
     }
 done:
     free(degree_table); free(degree_tables); free(neighbor_tables); free(edge_attrs); free(h); free(m);
     return rc;
 }
+
+int orc_GIN_compute_graphs_mt(int num_graphs, const int* nums_of_nodes, const int* nums_of_edges,
+                              const int* reload_weights, float* out,
+                              const int* node_feature_in, const int* edge_list_in,
+                              const int* edge_attr_in,
+                              const float* node_embedding_weight_in,
+                              const float* edge_embedding_weight_in,
+                              const float* node_mlp_1_weights, const float* node_mlp_1_bias,
+                              const float* node_mlp_2_weights, const float* node_mlp_2_bias,
+                              const float* graph_pred_weights_in, const float* graph_pred_bias_in,
+                              float* h_dump, int nthreads, int num_tasks);
 
 int orc_GIN_compute_graphs(int num_graphs, const int* nums_of_nodes, const int* nums_of_edges,
                            const int* reload_weights, float* out,
@@ -176,6 +191,25 @@ int orc_GIN_compute_graphs(int num_graphs, const int* nums_of_nodes, const int* 
                            const float* node_mlp_2_weights, const float* node_mlp_2_bias,
                            const float* graph_pred_weights_in, const float* graph_pred_bias_in,
                            float* h_dump, int nthreads)
+{
+    return orc_GIN_compute_graphs_mt(num_graphs, nums_of_nodes, nums_of_edges, reload_weights, out, node_feature_in, edge_list_in,
+                                     edge_attr_in, node_embedding_weight_in, edge_embedding_weight_in, node_mlp_1_weights,
+                                     node_mlp_1_bias, node_mlp_2_weights, node_mlp_2_bias, graph_pred_weights_in,
+                                     graph_pred_bias_in, h_dump, nthreads, 1);
+}
+
+/* The same with NUM_TASK (GIN/src/dcl.h:25; 1 in the reference) as a run-time dimension:
+   graph_pred_weights_in [S][num_tasks][100], graph_pred_bias_in [S][num_tasks], out [num_graphs][num_tasks]. */
+int orc_GIN_compute_graphs_mt(int num_graphs, const int* nums_of_nodes, const int* nums_of_edges,
+                              const int* reload_weights, float* out,
+                              const int* node_feature_in, const int* edge_list_in,
+                              const int* edge_attr_in,
+                              const float* node_embedding_weight_in,
+                              const float* edge_embedding_weight_in,
+                              const float* node_mlp_1_weights, const float* node_mlp_1_bias,
+                              const float* node_mlp_2_weights, const float* node_mlp_2_bias,
+                              const float* graph_pred_weights_in, const float* graph_pred_bias_in,
+                              float* h_dump, int nthreads, int num_tasks)
 {
     /* prefix sums of node/edge offsets and the weight-set index per graph
        (GIN/src/GIN_compute.cc:44,51-53,96-97) */
@@ -205,11 +239,12 @@ int orc_GIN_compute_graphs(int num_graphs, const int* nums_of_nodes, const int* 
         w.b1 = node_mlp_1_bias + (size_t)s * L * H;
         w.w2 = node_mlp_2_weights + (size_t)s * L * D * H;
         w.b2 = node_mlp_2_bias + (size_t)s * L * D;
-        w.pw = graph_pred_weights_in + (size_t)s * D;
-        w.pb = graph_pred_bias_in + (size_t)s;
+        w.nt = num_tasks;
+        w.pw = graph_pred_weights_in + (size_t)s * num_tasks * D;
+        w.pb = graph_pred_bias_in + (size_t)s * num_tasks;
         int r = gin_one_graph(nums_of_nodes[g], nums_of_edges[g],
                               node_feature_in + noff[g] * 9, edge_list_in + eoff[g] * 2,
-                              edge_attr_in + eoff[g] * 3, &w, out + g, h_dump, n_tot, noff[g]);
+                              edge_attr_in + eoff[g] * 3, &w, out + (size_t)g * num_tasks, h_dump, n_tot, noff[g]);
         if (r) {
 #ifdef _OPENMP
 #pragma omp critical

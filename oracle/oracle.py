@@ -68,8 +68,9 @@ def gin_load_graph(edge_list, edge_attr, n):
                 neighbor_tables=nbr.reshape(4, -1), edge_attrs=att.reshape(4, -1, 3), num_of_edges_per_pe=epp)
 
 
-def gin_forward(batch, weight_sets, reload_weights=None, dump_h=False, nthreads=1):
-    """orc_GIN_compute_graphs over a GraphBatch; weight_sets = list of weight dicts."""
+def gin_forward(batch, weight_sets, reload_weights=None, dump_h=False, nthreads=1, num_tasks=1):
+    """orc_GIN_compute_graphs over a GraphBatch; weight_sets = list of weight dicts.  num_tasks > 1: graph_pred_weights
+    [num_tasks][100], graph_pred_bias [num_tasks], result [G][num_tasks] (orc_GIN_compute_graphs_mt)."""
     lib = load()
     G = batch.num_graphs
     if reload_weights is None:
@@ -78,16 +79,20 @@ def gin_forward(batch, weight_sets, reload_weights=None, dump_h=False, nthreads=
             reload_weights[0] = 1
     keys = list(weight_sets[0].keys())
     stacked = [_f(np.stack([np.asarray(ws[k], np.float32) for ws in weight_sets])) for k in keys]
-    out = np.zeros(G, np.float32)
+    out = np.zeros(G * num_tasks, np.float32)
     nn, ne, rw = _i(batch.nums_of_nodes), _i(batch.nums_of_edges), _i(reload_weights)
     nf, el, ea = _i(batch.node_feature), _i(batch.edge_list), _i(batch.edge_attr)
     hd = np.zeros((6, batch.total_nodes, 100), np.float32) if dump_h else None
-    rc = lib.orc_GIN_compute_graphs(G, nn.ctypes.data_as(_pi), ne.ctypes.data_as(_pi), rw.ctypes.data_as(_pi),
-                                    out.ctypes.data_as(_pf), nf.ctypes.data_as(_pi), el.ctypes.data_as(_pi),
-                                    ea.ctypes.data_as(_pi), *[a.ctypes.data_as(_pf) for a in stacked],
-                                    None if hd is None else hd.ctypes.data_as(_pf), nthreads)
+    lib.orc_GIN_compute_graphs_mt.argtypes = [C.c_int, _pi, _pi, _pi, _pf, _pi, _pi, _pi] + [_pf] * 8 + [_pf, C.c_int, C.c_int]
+    lib.orc_GIN_compute_graphs_mt.restype = C.c_int
+    rc = lib.orc_GIN_compute_graphs_mt(G, nn.ctypes.data_as(_pi), ne.ctypes.data_as(_pi), rw.ctypes.data_as(_pi),
+                                       out.ctypes.data_as(_pf), nf.ctypes.data_as(_pi), el.ctypes.data_as(_pi),
+                                       ea.ctypes.data_as(_pi), *[a.ctypes.data_as(_pf) for a in stacked],
+                                       None if hd is None else hd.ctypes.data_as(_pf), nthreads, num_tasks)
     if rc:
         raise RuntimeError(f"oracle GIN rc={rc}")
+    if num_tasks > 1:
+        out = out.reshape(G, num_tasks)
     return (out, hd) if dump_h else out
 
 
@@ -146,10 +151,33 @@ def _forward(fn_name, batch, weight_sets, reload_weights, dump_shape, nthreads, 
     return (out, hd) if hd is not None else out
 
 
-def gcn_forward(batch, weight_sets, reload_weights=None, dump_h=False, nthreads=1):
-    """orc_GCN_compute_graphs; dump = x_l (NT outputs) [5][N][100]."""
-    return _forward("orc_GCN_compute_graphs", batch, weight_sets, reload_weights,
-                    (5, batch.total_nodes, 100) if dump_h else None, nthreads)
+def gcn_forward(batch, weight_sets, reload_weights=None, dump_h=False, nthreads=1, num_tasks=1):
+    """orc_GCN_compute_graphs; dump = x_l (NT outputs) [5][N][100].  num_tasks > 1: result [G][num_tasks]."""
+    if num_tasks == 1:
+        return _forward("orc_GCN_compute_graphs", batch, weight_sets, reload_weights,
+                        (5, batch.total_nodes, 100) if dump_h else None, nthreads)
+    lib = load()
+    lib.orc_GCN_compute_graphs_mt.argtypes = [C.c_int, _pi, _pi, _pi, _pf, _pi, _pi, _pi] + [_pf] * 11 + [_pf, C.c_int, C.c_int]
+    lib.orc_GCN_compute_graphs_mt.restype = C.c_int
+    G = batch.num_graphs
+    if reload_weights is None:
+        reload_weights = np.zeros(G, np.int32)
+        if G:
+            reload_weights[0] = 1
+    keys = list(weight_sets[0].keys())
+    stacked = [_f(np.stack([np.asarray(ws[k], np.float32) for ws in weight_sets])) for k in keys]
+    out = np.zeros(G * num_tasks, np.float32)
+    nn, ne, rw = _i(batch.nums_of_nodes), _i(batch.nums_of_edges), _i(reload_weights)
+    nf, el, ea = _i(batch.node_feature), _i(batch.edge_list), _i(batch.edge_attr)
+    hd = np.zeros((5, batch.total_nodes, 100), np.float32) if dump_h else None
+    rc = lib.orc_GCN_compute_graphs_mt(G, nn.ctypes.data_as(_pi), ne.ctypes.data_as(_pi), rw.ctypes.data_as(_pi),
+                                       out.ctypes.data_as(_pf), nf.ctypes.data_as(_pi), el.ctypes.data_as(_pi),
+                                       ea.ctypes.data_as(_pi), *[a.ctypes.data_as(_pf) for a in stacked],
+                                       None if hd is None else hd.ctypes.data_as(_pf), nthreads, num_tasks)
+    if rc:
+        raise RuntimeError(f"oracle GCN rc={rc}")
+    out = out.reshape(G, num_tasks)
+    return (out, hd) if dump_h else out
 
 
 def pna_forward(batch, weight_sets, reload_weights=None, dump_h=False, nthreads=1):

@@ -15,7 +15,7 @@ def gin_forward(batch, w, return_h=False):
     nemb, eemb = f64(w["node_embedding_weight"]), f64(w["edge_embedding_weight"])
     w1, b1 = f64(w["node_mlp_1_weights"]), f64(w["node_mlp_1_bias"])
     w2, b2 = f64(w["node_mlp_2_weights"]), f64(w["node_mlp_2_bias"])
-    pw, pb = f64(w["graph_pred_weights"]).reshape(-1), float(np.asarray(w["graph_pred_bias"]).reshape(-1)[0])
+    pw, pb = f64(w["graph_pred_weights"]).reshape(-1, 100), f64(w["graph_pred_bias"]).reshape(-1)  # [NUM_TASK][100], [NUM_TASK]
     N = batch.total_nodes
     ge = batch.global_edges()
     u, v = ge[:, 0], ge[:, 1]
@@ -34,7 +34,9 @@ def gin_forward(batch, w, return_h=False):
         hs.append(h)
     off = batch.node_offsets()
     pooled = np.add.reduceat(h, off[:-1], axis=0) / batch.nums_of_nodes[:, None]
-    out = pooled @ pw + pb
+    out = pooled @ pw.T + pb
+    if out.shape[1] == 1:
+        out = out[:, 0]
     return (out, np.stack(hs)) if return_h else out
 
 
@@ -44,7 +46,7 @@ def gcn_forward(batch, w, return_x=False):
     nemb, eemb = f64(w["node_embedding_weight"]), f64(w["edge_embedding_weight"])
     cw, cb, root = f64(w["convs_weight"]), f64(w["convs_bias"]), f64(w["convs_root_emb_weight"])
     bnw, bnb, bnm, bnv = f64(w["bn_weight"]), f64(w["bn_bias"]), f64(w["bn_mean"]), f64(w["bn_var"])
-    pw, pb = f64(w["graph_pred_weights"]).reshape(-1), float(np.asarray(w["graph_pred_bias"]).reshape(-1)[0])
+    pw, pb = f64(w["graph_pred_weights"]).reshape(-1, 100), f64(w["graph_pred_bias"]).reshape(-1)
     N = batch.total_nodes
     ge = batch.global_edges()
     u, v = ge[:, 0], ge[:, 1]
@@ -65,7 +67,9 @@ def gcn_forward(batch, w, return_x=False):
         a = np.maximum(pre, 0.0)
     off = batch.node_offsets()
     pooled = np.add.reduceat(pre, off[:-1], axis=0) / batch.nums_of_nodes[:, None]
-    out = pooled @ pw + pb
+    out = pooled @ pw.T + pb
+    if out.shape[1] == 1:
+        out = out[:, 0]
     return (out, np.stack(xs)) if return_x else out
 
 

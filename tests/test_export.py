@@ -84,7 +84,8 @@ def ogb_forward(kind, sd, batch):
         h = z if l == L - 1 else np.maximum(z, 0.0)
     off = batch.node_offsets()
     pooled = np.add.reduceat(h, off[:-1], axis=0) / batch.nums_of_nodes[:, None]
-    return (pooled @ sd["graph_pred_linear.weight"].T + sd["graph_pred_linear.bias"])[:, 0]
+    out = pooled @ sd["graph_pred_linear.weight"].T + sd["graph_pred_linear.bias"]
+    return out[:, 0] if out.shape[1] == 1 else out
 
 
 @pytest.mark.parametrize("with_bn", [True, False])
@@ -119,6 +120,27 @@ def test_gcn_file_is_the_flattened_state_dict(tmp_path):
     assert np.allclose(flat[17300 + 11500 * 3 + 10100:17300 + 11500 * 3 + 10200], sd["gnn_node.convs.3.root_emb.weight"].ravel().astype(np.float32))
     assert np.allclose(flat[74800 + 401 * 4 + 200:74800 + 401 * 4 + 300], sd["gnn_node.batch_norms.4.running_mean"].astype(np.float32))
     assert np.allclose(flat[76805:76905], sd["graph_pred_linear.weight"].ravel().astype(np.float32))
+
+
+@pytest.mark.parametrize("kind", ["gin", "gcn"])
+def test_multi_task_head_molpcba(tmp_path, kind, oracle):
+    """ogbg-molpcba has 128 tasks: the exporter keeps the whole head ([128][100] + [128]), the files round-trip, and the C
+    oracle's NUM_TASK-dimensioned readout (GIN/src/dcl.h:25,80; linear.cc:26-47) agrees with the OGB model's semantics."""
+    sd = ogb_state_dict(kind, 11, tasks=128)
+    batch = gp.synth_molpcba_batch(20, seed=12)
+    want = ogb_forward(kind, sd, batch)
+    assert want.shape == (20, 128)
+    export.export_weights(kind.upper(), sd, str(tmp_path), multi_task=True)
+    if kind == "gin":
+        w = weights.load_gin_weights(str(tmp_path), num_tasks=128)
+        got_np, got_c = numpy_ref.gin_forward(batch, w), oracle.gin_forward(batch, [w], num_tasks=128)
+    else:
+        assert os.path.getsize(tmp_path / weights.GCN_FILE) == (76805 + 101 * 128) * 4
+        w = weights.load_gcn_weights(str(tmp_path), num_tasks=128)
+        got_np, got_c = numpy_ref.gcn_forward(batch, w), oracle.gcn_forward(batch, [w], num_tasks=128)
+    assert w["graph_pred_weights"].shape == (128, 100) and w["graph_pred_bias"].shape == (128,)
+    assert np.allclose(got_np, want, rtol=1e-4, atol=2e-5), np.abs(got_np - want).max()
+    assert got_c.shape == (20, 128) and np.allclose(got_c, want, rtol=1e-4, atol=1e-4), np.abs(got_c - want).max()
 
 
 def test_torch_tensors_are_accepted(tmp_path):
