@@ -14,6 +14,7 @@
 // dense kernel (K = 200) with the residual in its epilogue, one wave-per-graph readout kernel.
 #include "common.h"
 #include "device_common.h"
+#include "modelq.h"
 #include "dense_split.h"
 #include <cmath>
 #include <cstring>
@@ -138,7 +139,17 @@ public:
 
     // host tensors (DGN/src/dcl.h:81-90): atom tables [9][119][100], layer W [4][100][200], b [4][100],
     // FC0 w [50][100] b [50], FC1 w [25][50] b [25], FC2 w [1][25] b [1]
+    int set_numeric_mode(int mode) override {  // mode 1 = "the reference's own format": ap_fixed<16,3> for DGN (DGN/src/dcl.h:54-55)
+        if (mode != 0 && mode != 1) return 8;
+        qmode_ = mode == 1;
+        return 0;
+    }
+
     int set_weights(const float* const* t) override {
+        {   // ap_fixed<16,3> copies of every tensor for the bit-faithful mode (modelq.hip)
+            static const size_t elems[9] = {9 * 119 * 100, 4 * 100 * 200, 4 * 100, 50 * 100, 50, 25 * 50, 25, 25, 1};
+            if (int rc = q_.upload_all(9, t, elems, 13)) return rc;
+        }
         // The reference indexes a dense [9][119][100] table (DGN/src/load_inputs.cc:124-137), but a feature k only takes values
         // below its cardinality (validated on the device): the 173 rows that can be addressed are gathered into the compact
         // [173][100] table the other models use (row = offset_k + value), which fits LDS (69 KB) -- the encoder then reads its nine
@@ -224,6 +235,7 @@ public:
         const int n = db.b.n_tot;
         if (n <= 0) return 0;
         if (!db.node_eigen) return 1;
+        if (qmode_) return dgnq_forward(q_, db, prof, s);
         {
             ProfScope p(prof, "atom_encoder", s);
             atom_encoder_kernel<DGN_D><<<atom_encoder_grid(n, DGN_C), 512, 0, s>>>(db.b.node_feature, d_emb_, db.h[0], n, db.csr.err);
@@ -279,9 +291,12 @@ private:
             if (*p) { (void)hipFree(*p); *p = nullptr; }
         esc_.release();
         tiles_.release();
+        q_.release();
         if (d_split_) { (void)hipFree(d_split_); d_split_ = nullptr; }
     }
     bool ready_ = false;
+    bool qmode_ = false;  // flowgnn_set_numeric_mode(FLOWGNN_NUMERIC_Q6_10): ap_fixed<16,3> arithmetic
+    QPack q_;
     GrowBufI tiles_;  // graph-aligned tile starts of the resident batch (tile_bounds_kernel)
     int tile_nominal_ = getenv("FLOWGNN_TILE_NOMINAL") ? atoi(getenv("FLOWGNN_TILE_NOMINAL")) : 64;
     int tile_slack_ = getenv("FLOWGNN_TILE_SLACK") ? atoi(getenv("FLOWGNN_TILE_SLACK")) : 64;

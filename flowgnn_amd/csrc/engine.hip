@@ -627,7 +627,7 @@ int flowgnn_set_numeric_mode(flowgnn_engine* e, int mode) {
     if (!e) return FLOWGNN_ERR_ARG;
     e->drop_graph();
     const int rc = e->model->set_numeric_mode(mode);
-    if (rc) e->err = "flowgnn_set_numeric_mode: this model has no such mode (Q6.10 exists for GIN / GIN-VN)";
+    if (rc) e->err = "flowgnn_set_numeric_mode: unknown mode, or the fixed-point readout is single-task and NUM_TASK != 1";
     return rc;
 }
 

@@ -17,6 +17,7 @@
 #include "common.h"
 #include "device_common.h"
 #include "dense_split.h"
+#include "modelq.h"
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -475,7 +476,17 @@ public:
 
     // host tensors (GAT/src/dcl.h:86-93): scoring_fn_target[5][4][16], scoring_fn_source[5][4][16],
     // linear_proj[5][4][16][4][16], skip_proj[5][4][16][4][16] (layer 0: only [ho][do][0][<9] is used), pred_w[1][16], pred_b[1]
+    int set_numeric_mode(int mode) override {
+        if (mode != 0 && mode != 1) return 8;
+        qmode_ = mode == 1;
+        return 0;
+    }
+
     int set_weights(const float* const* t) override {
+        {   // ap_fixed<16,6> copies of every tensor for the bit-faithful mode (modelq.hip)
+            static const size_t elems[6] = {5 * 4 * 16, 5 * 4 * 16, 5 * 4 * 16 * 4 * 16, 5 * 4 * 16 * 4 * 16, 16, 1};
+            if (int rc = q_.upload_all(6, t, elems, 10)) return rc;
+        }
         const float *tgt = t[0], *srcw = t[1], *lin = t[2], *skip = t[3];
         auto W = [](const float* w, int l, int ho, int dout, int hi, int din) {
             return w[(((((size_t)l * GAT_H + ho) * GAT_D + dout) * GAT_H + hi) * GAT_D) + din];
@@ -586,6 +597,7 @@ public:
             feat_row = reinterpret_cast<int*>(db.scratch + (size_t)n * (2 * GAT_F + 16 + GAT_D));
             gat_local_rows_kernel<<<(db.b.num_graphs + 3) / 4, 256, 0, s>>>(db.b.node_off, feat_row, db.b.num_graphs);
         }
+        if (qmode_) return gatq_forward(q_, db, feat_row, prof, s);
         const GatLayer0Dev w0{d_lin0_, d_asrc_, d_atgt_};
         {
             ProfScope p(prof, "gat_scores0", s);
@@ -648,8 +660,11 @@ private:
         float** ptrs[] = {&d_lin0_, &d_asrc_, &d_atgt_, &d_wskip_, &d_wlin_, &d_pw_, &d_pb_, &d_wskip_s_, &d_wlin_s_};
         for (auto p : ptrs)
             if (*p) { (void)hipFree(*p); *p = nullptr; }
+        q_.release();
     }
     bool ready_ = false;
+    bool qmode_ = false;  // flowgnn_set_numeric_mode(FLOWGNN_NUMERIC_Q6_10)
+    QPack q_;
     // the two 64 x 64 contractions per layer as split-f16 products unless FLOWGNN_GAT_MFMA=f32; exact_ = the engine asked for the
     // fp32 pipe after an operand left the split's accurate range (flowgnn_sync)
     bool split_ = !(getenv("FLOWGNN_GAT_MFMA") && strcmp(getenv("FLOWGNN_GAT_MFMA"), "f32") == 0);

@@ -14,6 +14,7 @@
 // root / degree / BatchNorm / ReLU epilogue (so a_l is written once), and one fp32-MFMA dense kernel.
 #include "common.h"
 #include "device_common.h"
+#include "modelq.h"
 #include "dense_split.h"
 #include <cmath>
 #include <cstring>
@@ -334,7 +335,19 @@ public:
 
     // host tensors (GCN/src/dcl.h:83-96): node_emb[173][100], edge_emb[5][13][100], convs_weight[5][100][100],
     // convs_bias[5][100], root_emb[5][100], bn_weight/bias/mean/var[5][100], pred_w[1][100], pred_b[1]
+    int set_numeric_mode(int mode) override {
+        if (mode != 0 && mode != 1) return 8;
+        if (mode == 1 && num_tasks_ != 1) return 8;  // the fixed-point readout is single-task, as the reference's
+        qmode_ = mode == 1;
+        return 0;
+    }
+
     int set_weights(const float* const* t) override {
+        {   // ap_fixed<16,6> copies of every tensor for the bit-faithful mode (modelq.hip)
+            const size_t elems[11] = {173 * 100, 5 * 13 * 100, 5 * 100 * 100, 500, 500, 500, 500, 500, 500, (size_t)num_tasks_ * 100, (size_t)num_tasks_};
+            if (int rc = q_.upload_all(11, t, elems, 10)) return rc;
+            if (q_.extra) { (void)hipFree(q_.extra); q_.extra = nullptr; }  // derived tables follow the weights
+        }
         const float *nemb = t[0], *eemb = t[1], *cw = t[2], *cb = t[3], *root = t[4], *bnw = t[5], *bnb = t[6], *bnm = t[7],
                     *bnv = t[8], *pw = t[9], *pb = t[10];
         std::vector<float> v_nemb(nemb, nemb + ND_FEATURE_TOTAL * GCN_D), v_pw(pw, pw + (size_t)num_tasks_ * GCN_D), v_pb(pb, pb + num_tasks_);
@@ -438,6 +451,7 @@ public:
     int forward(DeviceBatch& db, Profiler& prof, hipStream_t s) override {
         const int n = db.b.n_tot;
         if (n <= 0) return 0;
+        if (qmode_) return gcnq_forward(q_, db, prof, s);
         if (int rc = make_tile_bounds(tiles_, db.b.node_off, db.b.num_graphs, n, tile_nominal_, tile_slack_, s)) return rc;
         if (db.b.e_tot > 0) {  // dinv[src_e] per CSR entry, once per pass
             if (int rc = esc_.reserve((size_t)db.b.e_tot)) return rc;
@@ -515,7 +529,7 @@ public:
     }
 
     int set_num_tasks(int t) override {
-        if (t < 1) return 8;
+        if (t < 1 || (t != 1 && qmode_)) return 8;
         if (t != num_tasks_) ready_ = false;  // graph_pred_weights / bias change shape: set the weights again
         num_tasks_ = t;
         return 0;
@@ -537,8 +551,11 @@ private:
         if (d_split_) { (void)hipFree(d_split_); d_split_ = nullptr; }
         esc_.release();
         tiles_.release();
+        q_.release();
     }
     bool ready_ = false;
+    bool qmode_ = false;  // flowgnn_set_numeric_mode(FLOWGNN_NUMERIC_Q6_10)
+    QPack q_;
     int num_tasks_ = 1;  // NUM_TASK (GCN/src/dcl.h) as a run-time dimension
     GrowBuf esc_;
     GrowBufI tiles_;  // graph-aligned tile starts of the resident batch (tile_bounds_kernel)

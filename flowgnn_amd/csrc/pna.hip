@@ -16,6 +16,7 @@
 // agg[v] = [mean | min | max | std][80], and one wave-per-graph readout kernel.
 #include "common.h"
 #include "device_common.h"
+#include "modelq.h"
 #include "dense_split.h"
 #include <cmath>
 #include <cstring>
@@ -284,7 +285,17 @@ public:
 
     // host tensors (PNA/src/dcl.h:98-110): node_emb[173][80], conv_w[4][80][3][4][80] (out, scaler, aggr, in),
     // conv_b[4][80], mlp1_w[40][80], mlp1_b[40], mlp2_w[20][40], mlp2_b[20], mlp3_w[1][20], mlp3_b[1], avg_deg[1]
+    int set_numeric_mode(int mode) override {
+        if (mode != 0 && mode != 1) return 8;
+        qmode_ = mode == 1;
+        return 0;
+    }
+
     int set_weights(const float* const* t) override {
+        {   // ap_fixed<16,6> copies of every tensor for the bit-faithful mode (modelq.hip)
+            static const size_t elems[10] = {173 * 80, 4 * 80 * 3 * 4 * 80, 4 * 80, 40 * 80, 40, 20 * 40, 20, 20, 1, 1};
+            if (int rc = q_.upload_all(10, t, elems, 10)) return rc;
+        }
         const float *nemb = t[0], *cw = t[1], *cb = t[2];
         std::vector<float> v_nemb(nemb, nemb + ND_FEATURE_TOTAL * PNA_D), v_cb(cb, cb + PNA_L * PNA_D);
         std::vector<float> v_w1(t[3], t[3] + 40 * 80), v_b1(t[4], t[4] + 40), v_w2(t[5], t[5] + 20 * 40), v_b2(t[6], t[6] + 20),
@@ -351,6 +362,7 @@ public:
     int forward(DeviceBatch& db, Profiler& prof, hipStream_t s) override {
         const int n = db.b.n_tot;
         if (n <= 0) return 0;
+        if (qmode_) return pnaq_forward(q_, db, prof, s);
         {
             ProfScope p(prof, "atom_encoder", s);
             atom_encoder_kernel<PNA_D><<<atom_encoder_grid(n, PNA_C), 512, 0, s>>>(db.b.node_feature, d_nemb_,
@@ -402,8 +414,11 @@ private:
             if (*p) { (void)hipFree(*p); *p = nullptr; }
         if (d_split_) { (void)hipFree(d_split_); d_split_ = nullptr; }
         tiles_.release();
+        q_.release();
     }
     bool ready_ = false;
+    bool qmode_ = false;  // flowgnn_set_numeric_mode(FLOWGNN_NUMERIC_Q6_10)
+    QPack q_;
     GrowBufI tiles_;  // graph-aligned tile starts of the resident batch (tile_bounds_kernel)
     int tile_nominal_ = getenv("FLOWGNN_TILE_NOMINAL") ? atoi(getenv("FLOWGNN_TILE_NOMINAL")) : 112;
     int tile_slack_ = getenv("FLOWGNN_TILE_SLACK") ? atoi(getenv("FLOWGNN_TILE_SLACK")) : 48;

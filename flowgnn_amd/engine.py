@@ -120,7 +120,7 @@ class Engine:
 
     # ---- taps
     def set_numeric_mode(self, mode: str = "f32"):
-        """"f32" (default) or "q6.10": the reference's ap_fixed<16,6> bit patterns (GIN / GIN-VN only)."""
+        """"f32" (default) or "q6.10": the bit patterns of the reference's own fixed-point format (ap_fixed<16,6>; DGN: ap_fixed<16,3>)."""
         code = {"f32": 0, "q6.10": 1}[mode]
         self._check(self.lib.flowgnn_set_numeric_mode(self._h, code), "flowgnn_set_numeric_mode")
 

@@ -258,12 +258,12 @@ int flowgnn_num_tasks(const flowgnn_engine* e);
 
 /*
  * Numeric mode of the engine.  FLOWGNN_NUMERIC_F32 (default): fp32 storage and accumulation.
- * FLOWGNN_NUMERIC_Q6_10: every value is the reference's ap_fixed<16,6> bit pattern
- * (GIN/src/dcl.h:58-59: 10 fractional bits, truncation toward -inf, wrap on overflow), weights
- * are quantised from the float tensors as the reference host does, and the outputs are
- * pattern / 1024 (exact in float).  Implemented for GIN / GIN-VN;
- * other models return FLOWGNN_ERR_UNSUPPORTED.  About 100x slower than the default
- * path: products are truncated one at a time, as the reference does.
+ * FLOWGNN_NUMERIC_Q6_10: every value is the bit pattern of the reference's own number format -- ap_fixed<16,6> for GIN,
+ * GIN-VN, GCN, GAT and PNA (GIN/src/dcl.h:58-59: 10 fractional bits, truncation toward -inf, wrap on overflow), ap_fixed<16,3>
+ * for DGN (DGN/src/dcl.h:54-55: 13 fractional bits) -- weights are quantised from the float tensors as the reference host
+ * does, and the outputs are pattern / 2^F (exact in float).  The rules assumed for ap_fixed division and the hls:: math
+ * functions are written down in oracle/ginq_oracle.c and oracle/q_oracle.c.  A fidelity mode, one to two orders of
+ * magnitude slower than the default path: products are truncated one at a time, as the reference does.
  */
 #define FLOWGNN_NUMERIC_F32 0
 #define FLOWGNN_NUMERIC_Q6_10 1

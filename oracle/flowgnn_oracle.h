@@ -141,6 +141,20 @@ int orc_GAT_compute_graphs(int num_graphs, const int* nums_of_nodes, const int* 
                            const float* skip_proj_weights_in, const float* graph_pred_weights_in,
                            const float* graph_pred_bias_in, int feature_offset_quirk, float* dump, int nthreads);
 
+/*
+ * GCN / GAT / PNA (ap_fixed<16,6>) and DGN (ap_fixed<16,3>) in the reference's own number formats: q_oracle.c (the rules it
+ * assumes, R0..R8, and why it is "parity unpinned").  model = FLOWGNN_MODEL_* id (2 GCN, 3 GAT, 4 PNA, 5 DGN); tens = the model's
+ * float weight tensors in entry-point order ([S] leading), elems[i] = elements of ONE weight set of tensor i; out_q = 16-bit
+ * patterns, out = pattern / 2^F (either may be NULL).
+ */
+int orc_q_compute_graphs(int model, int num_graphs, const int* nums_of_nodes, const int* nums_of_edges, const int* reload_weights,
+                         float* out, int16_t* out_q, const int* node_feature_in, const float* node_eigen_in, const int* edge_list_in,
+                         const int* edge_attr_in, int ntens, const float* const* tens, const long* elems, int gat_feature_offset_quirk,
+                         int nthreads);
+int16_t orc_q_from_float(float x, int frac_bits);
+const int16_t* orc_q_exp_table(void);   /* [65536], indexed by the Q6.10 pattern as uint16 */
+int16_t orc_q_log(int16_t pattern);
+
 #ifdef __cplusplus
 }
 #endif

@@ -213,3 +213,36 @@ def gat_forward(batch, weight_sets, reload_weights=None, dump_h=False, nthreads=
     if rc:
         raise RuntimeError(f"oracle GAT rc={rc}")
     return (out, hd) if dump_h else out
+
+
+_Q_MODEL_IDS = {"GCN": 2, "GAT": 3, "PNA": 4, "DGN": 5}
+
+
+def q_forward(model, batch, weight_sets, reload_weights=None, nthreads=1, feature_offset_quirk=False):
+    """orc_q_compute_graphs: GCN / GAT / PNA in ap_fixed<16,6>, DGN in ap_fixed<16,3> (q_oracle.c).
+    Returns (logits as float, 16-bit patterns)."""
+    lib = load()
+    model = model.upper()
+    G = batch.num_graphs
+    if reload_weights is None:
+        reload_weights = np.zeros(G, np.int32)
+        if G:
+            reload_weights[0] = 1
+    keys = list(weight_sets[0].keys())
+    stacked = [_f(np.stack([np.asarray(ws[k], np.float32) for ws in weight_sets])) for k in keys]
+    elems = (C.c_long * len(stacked))(*[int(a[0].size) for a in stacked])
+    tens = (_pf * len(stacked))(*[a.ctypes.data_as(_pf) for a in stacked])
+    out, out_q = np.zeros(G, np.float32), np.zeros(G, np.int16)
+    nn, ne, rw = _i(batch.nums_of_nodes), _i(batch.nums_of_edges), _i(reload_weights)
+    nf, el, ea = _i(batch.node_feature), _i(batch.edge_list), _i(batch.edge_attr)
+    eig = _f(batch.node_eigen) if batch.node_eigen is not None else None
+    lib.orc_q_compute_graphs.argtypes = [C.c_int, C.c_int, _pi, _pi, _pi, _pf, C.POINTER(C.c_int16), _pi, _pf, _pi, _pi, C.c_int,
+                                         C.POINTER(_pf), C.POINTER(C.c_long), C.c_int, C.c_int]
+    lib.orc_q_compute_graphs.restype = C.c_int
+    rc = lib.orc_q_compute_graphs(_Q_MODEL_IDS[model], G, nn.ctypes.data_as(_pi), ne.ctypes.data_as(_pi), rw.ctypes.data_as(_pi),
+                                  out.ctypes.data_as(_pf), out_q.ctypes.data_as(C.POINTER(C.c_int16)), nf.ctypes.data_as(_pi),
+                                  None if eig is None else eig.ctypes.data_as(_pf), el.ctypes.data_as(_pi), ea.ctypes.data_as(_pi),
+                                  len(stacked), tens, elems, 1 if feature_offset_quirk else 0, nthreads)
+    if rc:
+        raise RuntimeError(f"oracle {model}-Q rc={rc}")
+    return out, out_q
