@@ -67,8 +67,10 @@ MODELS = {
                 workload="GAT 5-layer, 4 heads x 16, ogbg-molhiv-shaped graphs on MI355X (BASELINE configs[3])"),
     "PNA": dict(metric="graphs/sec on hep10k (PNA, dim=80)", dataset="hep10k", graphs=1 << 15,
                 agg_bytes=lambda n, e: n * 320 + n * 320 * 4 + e * 8, flops=lambda n, e: n * 153600,
-                fused_bytes=lambda n, e: n * (1280 + 320 + 320),  # split dense: read 4 aggregates + h, write h'
-                hbm_kernels=("pna_aggregate",), mfma_kernels=("pna_dense",),
+                # unfused split dense: read 4 aggregates + h, write h'; fused layer: read h (tile rows) + CSR, write h'
+                fused_bytes={"pna_dense": lambda n, e: n * (1280 + 320 + 320), "pna_layer_fused": lambda n, e: n * (320 + 320 + 4) + e * 4},
+                mfma_bound_kernels=("pna_layer_fused",),
+                hbm_kernels=("pna_aggregate",), mfma_kernels=("pna_layer_fused", "pna_dense"),
                 workload="PNA dim=80, hep10k-shaped kNN graphs on MI355X (BASELINE configs[4])"),
     "DGN": dict(metric="graphs/sec on hep10k (DGN, dim=100)", dataset="hep10k", graphs=1 << 15,
                 agg_bytes=lambda n, e: n * 400 * 3 + e * 12, flops=lambda n, e: n * 40000,

@@ -47,6 +47,23 @@ __device__ __forceinline__ long long tile_far_row(unsigned ul, int t0, const int
     return (long long)t0 + (((int)(ul << 9)) >> 9);  // sign-extend the 23-bit distance
 }
 
+// LDS-DMA of one 1 KiB piece (16 B per lane) from inline asm.  Not the builtin: hipcc's wait-count pass books a
+// global_load ... lds as a FLAT access that may touch LDS, and while one is outstanding it turns every LDS wait of the wave
+// into lgkmcnt(0) -- which serialises a software-pipelined fragment stream (each wait would also wait for the fragments just
+// requested for the next unit).  Issued like this the pass does not see the transfer at all; the kernel orders it by hand
+// (s_waitcnt vmcnt(0) + barrier before a buffer is read).  gbase and lds_addr are wave-uniform.
+__device__ __forceinline__ void lds_dma16(const void* gbase, uint32_t voff, uint32_t lds_addr) {
+    // both are wave-uniform by contract; readfirstlane makes that visible to the register allocator where it cannot prove it
+    const uint64_t gb = (uint64_t)gbase;
+    const uint64_t gu = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(gb >> 32)) << 32) |
+                        (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)gb);
+    const uint32_t la = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_addr);
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(gu), "s"(la) : "memory", "m0");
+}
+__device__ __forceinline__ uint32_t lds_addr_of(const void* p) {
+    return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)p;
+}
+
 // Streaming (nontemporal) 16-byte store for rows that the next kernel reads only after gigabytes of other rows have gone by:
 // they need not displace the gather's working set (neighbour rows, weight stream) from the caches.
 __device__ __forceinline__ void stream_store4(float* p, float a, float b, float c, float d) {

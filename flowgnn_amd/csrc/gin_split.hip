@@ -470,24 +470,12 @@ constexpr int GRC_W2_OFF = 13440;
 constexpr int GRC_CHUNK_BYTES = 27776;
 constexpr int GRC_CHUNK_STRIDE = 28672;  // 28 pieces of 1 KiB in global memory (the last one: 128 B = 8 lanes)
 
-// LDS-DMA of one 1 KiB piece (16 B per lane) from inline asm.  Not the builtin: hipcc's wait-count pass books a
-// global_load ... lds as a FLAT access that may touch LDS, and while one is outstanding it turns every LDS wait of the wave
-// into lgkmcnt(0) -- which would serialise the fragment pipeline below (each unit's wait would also wait for the fragments just
-// requested for the next unit).  Issued like this the pass does not see the transfer at all; the kernel orders it by hand
-// (s_waitcnt vmcnt(0) + barrier before a buffer is read, as it did anyway).  gbase and lds_addr are wave-uniform.
-__device__ __forceinline__ void gr_dma16(const void* gbase, uint32_t voff, uint32_t lds_addr) {
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(gbase), "s"(lds_addr) : "memory", "m0");
-}
-__device__ __forceinline__ uint32_t gr_lds_addr(const void* p) {
-    return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)p;
-}
-
 __device__ __forceinline__ void grc_issue_chunk(const uint8_t* __restrict__ gchunk, char* lds_buf, int wave, int lane) {
-    const uint32_t lb = gr_lds_addr(lds_buf);
+    const uint32_t lb = lds_addr_of(lds_buf);
 #pragma unroll
     for (int p = 0; p < 4; p++) {
         const int piece = wave + 8 * p;  // 27 full pieces + 128 B
-        if (piece < 27 || (piece == 27 && lane < 8)) gr_dma16(gchunk + piece * 1024, (uint32_t)lane * 16u, lb + piece * 1024);
+        if (piece < 27 || (piece == 27 && lane < 8)) lds_dma16(gchunk + piece * 1024, (uint32_t)lane * 16u, lb + piece * 1024);
     }
 }
 
@@ -622,7 +610,7 @@ __device__ __forceinline__ void gr_issue_ecomb(const float* __restrict__ ecomb, 
 #pragma unroll
     for (int r = 0; r < 3; r++) {
         const int piece = wave + GR_WAVES * r;
-        if (piece < 23 || (piece == 23 && lane < 28)) gr_dma16(reinterpret_cast<const char*>(ecomb) + piece * 1024, (uint32_t)lane * 16u, gr_lds_addr(lds_buf) + piece * 1024);
+        if (piece < 23 || (piece == 23 && lane < 28)) lds_dma16(reinterpret_cast<const char*>(ecomb) + piece * 1024, (uint32_t)lane * 16u, lds_addr_of(lds_buf) + piece * 1024);
     }
 }
 // pieces [13 part, 13 part + 13) of the tile's rows (<= 100 pieces of 1 KiB; a piece may run past the tile's last row: the
@@ -633,7 +621,7 @@ __device__ __forceinline__ void gr_issue_rows(const float* __restrict__ h0, char
     for (int r = 0; r < 2; r++) {
         const int piece = 13 * part + wave + GR_WAVES * r;
         if (piece < 13 * part + 13 && piece < np)
-            gr_dma16(reinterpret_cast<const char*>(h0) + (size_t)t.t0 * (GS_D * 4) + (size_t)piece * 1024, (uint32_t)lane * 16u, gr_lds_addr(s_rows) + piece * 1024);
+            lds_dma16(reinterpret_cast<const char*>(h0) + (size_t)t.t0 * (GS_D * 4) + (size_t)piece * 1024, (uint32_t)lane * 16u, lds_addr_of(s_rows) + piece * 1024);
     }
 }
 
@@ -719,7 +707,7 @@ __global__ __launch_bounds__(256) void gin_tile_prep_kernel(const int* __restric
 
 __device__ __forceinline__ void gr_issue_desc(const uint8_t* __restrict__ desc, int tile, char* s_desc, int wave, int lane) {
     if (wave < 4 && (wave < 3 || lane < 32))
-        gr_dma16(reinterpret_cast<const char*>(desc) + (size_t)tile * GR_DESC_BYTES + wave * 1024, (uint32_t)lane * 16u, gr_lds_addr(s_desc) + wave * 1024);
+        lds_dma16(reinterpret_cast<const char*>(desc) + (size_t)tile * GR_DESC_BYTES + wave * 1024, (uint32_t)lane * 16u, lds_addr_of(s_desc) + wave * 1024);
 }
 
 template <bool PROF>

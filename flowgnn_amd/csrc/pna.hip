@@ -250,6 +250,264 @@ __global__ __launch_bounds__(512) void pna_dense_split_kernel(const float* __res
     }
 }
 
+// ---------------------------------------------------------------- fused layer: aggregation + dense update in one kernel
+// The aggregates (mean | min | max | std, 1 280 B per node) never go to HBM -- nor to LDS, nor do they ever exist as a whole.
+// The contraction index is re-ordered FEATURE-major: K-step k (of 10) covers the four aggregates of features 8k .. 8k+7, lane
+// (j, g) supplying both aggregate quadruples of features 8k + 2g, 8k + 2g + 1 of node j (K-slot e: feature 8k + 2g + (e >> 2),
+// aggregator e & 3).  So a K-step's B operand needs one pass over node j's in-edges reading EIGHT bytes per neighbour row and
+// eight accumulators; its 45 MFMAs then run while the same wave already gathers the next K-step's slice -- matrix pipe and
+// VALU / LDS overlap inside every wave, and with ~110 registers sixteen waves fit a CU.
+// A persistent 16-wave workgroup (one per CU) walks tiles of WHOLE graphs (GraphTiles: <= 256 rows, <= 4 608 in-edges): the
+// tile's rows of h come into LDS by DMA (padded stride, below), its CSR slice as bytes (the first 16 in-edges of a row are kept
+// packed in four registers and re-walked per K-step); the weight chunks (30 KiB per K-step, pna_pack_stream_layer) stream
+// through two LDS buffers as in pna_dense_split_kernel.  In-edges are summed in CSR order as everywhere else.
+constexpr int PNA_FT_ROWS = 256;
+constexpr int PNA_FT_EDGES = 4608;
+// LDS row stride: 84 floats = 21 slots of 16 B.  A gather instruction reads 16 different rows at one column; with the rows'
+// natural 320 B (80 dwords = 16 mod 64) they would fall on 4 of the 16 bank groups; 84 dwords = 20 mod 64 spreads 16
+// consecutive rows over all of them.  The DMA places the padding: every lane picks its own global address.
+constexpr int PNA_FT_STRIDE = 84;
+constexpr int PNA_FT_WAVES = 16;
+
+__device__ __forceinline__ void pna_issue_chunk_asm(const uint8_t* __restrict__ gchunk, char* lds_buf, int wave, int lane) {
+    const uint32_t lb = lds_addr_of(lds_buf);
+#pragma unroll
+    for (int p = 0; p < 2; p++) {
+        const int piece = wave + PNA_FT_WAVES * p;  // 30 pieces of 1 KiB over 16 waves
+        if (piece < PNA_CHUNK / 1024) lds_dma16(gchunk + piece * 1024, (uint32_t)lane * 16u, lb + piece * 1024);
+    }
+}
+// rows of tile [t0, t0 + rows) -> LDS with the padded stride: LDS slot s = 21 row + c (c = 20 is padding) <- global slot
+// 20 row + c; <= 84 pieces of 64 slots (a piece may run past the last row: the array has slack)
+__device__ __forceinline__ void pna_issue_rows(const float* __restrict__ h, int t0, int rows, float* s_rows, int wave, int lane) {
+    const int np = (rows * 21 + 63) >> 6;
+    const uint32_t lb = lds_addr_of(s_rows);
+    const char* gb = reinterpret_cast<const char*>(h) + (size_t)t0 * (PNA_D * 4);
+#pragma unroll
+    for (int r = 0; r < 6; r++) {
+        const int piece = wave + PNA_FT_WAVES * r;
+        if (piece < np) {
+            const int sl = piece * 64 + lane, row = sl / 21, c = sl - row * 21;
+            lds_dma16(gb, (uint32_t)(row * 20 + (c < 20 ? c : 19)) * 16u, lb + piece * 1024);
+        }
+    }
+}
+
+// the 45 MFMAs of one K-step: fifteen (scaler, output tile) accumulators in five groups of three, product-major (no MFMA waits for
+// its predecessor's accumulator).  Four waves per SIMD: the fragment reads of one wave hide under the MFMAs and gathers of the others.
+__device__ __forceinline__ void pna_stream_mfma(const char* wb, int lane, const ds_uint4_t& b_hi, const ds_uint4_t& b_lo,
+                                                float4_t (&y)[PNA_NS * PNA_OT]) {
+#pragma unroll
+    for (int G = 0; G < 8; G++) {  // pairs of accumulators (the last group has one): four fragment registers sets live at a time
+        constexpr int NST = PNA_NS * PNA_OT;
+        const int n = G * 2 + 1 < NST ? 2 : 1;
+        ds_uint4_t f[4];
+#pragma unroll
+        for (int i = 0; i < 2 * n; i++) f[i] = *reinterpret_cast<const ds_uint4_t*>(wb + (G * 4 + i) * 1024 + lane * 16);
+#pragma unroll
+        for (int i = 0; i < n; i++) y[G * 2 + i] = DS_MFMA16(f[2 * i], b_hi, y[G * 2 + i]);
+#pragma unroll
+        for (int i = 0; i < n; i++) y[G * 2 + i] = DS_MFMA16(f[2 * i], b_lo, y[G * 2 + i]);
+#pragma unroll
+        for (int i = 0; i < n; i++) y[G * 2 + i] = DS_MFMA16(f[2 * i + 1], b_hi, y[G * 2 + i]);
+    }
+}
+
+// one K-step's B operand: the aggregates of features f0 = 8k + 2g, f0 + 1 of this lane's node, gathered out of the LDS tile
+struct PnaSlice { float S0, S1, Q0, Q1, mn0, mn1, mx0, mx1; };
+__device__ __forceinline__ void pna_slice_add(PnaSlice& a, const float2& x) {
+    a.S0 += x.x; a.S1 += x.y;
+    a.Q0 += x.x * x.x; a.Q1 += x.y * x.y;
+    a.mn0 = __builtin_fminf(x.x, a.mn0); a.mn1 = __builtin_fminf(x.y, a.mn1);  // inputs are never NaN-free-dependent: h is finite
+    a.mx0 = __builtin_fmaxf(x.x, a.mx0); a.mx1 = __builtin_fmaxf(x.y, a.mx1);
+}
+__device__ __forceinline__ void pna_slice_edge(PnaSlice& a, const float* __restrict__ s_h, int u, int col) {
+    pna_slice_add(a, *reinterpret_cast<const float2*>(s_h + u * PNA_FT_STRIDE + col));
+}
+__device__ __forceinline__ void pna_gather_slice(const float* __restrict__ s_h, const uint8_t* __restrict__ s_src, const uint32_t (&srcw)[4],
+                                                 int e_base, int indeg, int col, ds_uint4_t& b_hi, ds_uint4_t& b_lo, float& vmax) {
+    PnaSlice a{0.f, 0.f, 0.f, 0.f, PNA_SENT_MAX, PNA_SENT_MAX, PNA_SENT_MIN, PNA_SENT_MIN};
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+        if (__all(indeg >= 4 * w + 4)) {  // every row of the wave has these four in-edges (kNN graphs): four reads in flight, no masks
+            float2 x[4];
+#pragma unroll
+            for (int b = 0; b < 4; b++) x[b] = *reinterpret_cast<const float2*>(s_h + (int)((srcw[w] >> (8 * b)) & 0xFFu) * PNA_FT_STRIDE + col);
+#pragma unroll
+            for (int b = 0; b < 4; b++) pna_slice_add(a, x[b]);
+        } else if (__any(indeg > 4 * w)) {  // ragged: whole words are skipped when no row of the wave has them
+#pragma unroll
+            for (int b = 0; b < 4; b++)
+                if (indeg > 4 * w + b) pna_slice_edge(a, s_h, (int)((srcw[w] >> (8 * b)) & 0xFFu), col);
+        }
+    }
+    for (int e = 16; __any(e < indeg); e++)  // rows with more than 16 in-edges: the rest comes from the LDS copy of the CSR slice
+        if (e < indeg) pna_slice_edge(a, s_h, (int)s_src[e_base + e], col);
+    // mean = S / indeg (0 -> 1), std = sqrt(relu(Q / indeg - mean^2))   (node_embedding.cc:123,143-145)
+    const float deg = (float)(indeg == 0 ? 1 : indeg);
+    const float m0 = a.S0 / deg, m1 = a.S1 / deg;
+    const float sd0 = sqrtf(relu1(a.Q0 / deg - m0 * m0)), sd1 = sqrtf(relu1(a.Q1 / deg - m1 * m1));
+    // K-slots e = 0..7: (feature f0: mean, min, max, std), (feature f0 + 1: the same)
+    DS_SPLIT2(m0, a.mn0, b_hi.x, b_lo.x);
+    DS_SPLIT2(a.mx0, sd0, b_hi.y, b_lo.y);
+    DS_SPLIT2(m1, a.mn1, b_hi.z, b_lo.z);
+    DS_SPLIT2(a.mx1, sd1, b_hi.w, b_lo.w);
+    vmax = __builtin_fmaxf(__builtin_fmaxf(vmax, __builtin_fabsf(m0)), __builtin_fabsf(m1));
+    vmax = __builtin_fmaxf(__builtin_fmaxf(vmax, sd0), sd1);
+    vmax = __builtin_fmaxf(__builtin_fmaxf(vmax, __builtin_fabsf(a.mn0)), __builtin_fabsf(a.mn1));
+    vmax = __builtin_fmaxf(__builtin_fmaxf(vmax, __builtin_fabsf(a.mx0)), __builtin_fabsf(a.mx1));
+    asm volatile("" : "+v"(vmax));
+}
+
+__global__ __launch_bounds__(PNA_FT_WAVES * 64, 4) void pna_layer_fused_kernel(const float* __restrict__ h, float* __restrict__ hout,
+                                                                  const int* __restrict__ row_ptr, const int* __restrict__ src,
+                                                                  const int* __restrict__ out_deg, const uint8_t* __restrict__ wpk,
+                                                                  const float* __restrict__ bias, float avg_deg, float oscale,
+                                                                  const int* __restrict__ tile_row, int n_tiles, int* __restrict__ range_flag,
+                                                                  int ablate) {
+    __shared__ __attribute__((aligned(16))) char s_a[PNA_CHUNK];  // even K-steps
+    __shared__ __attribute__((aligned(16))) char s_b[PNA_CHUNK];  // odd K-steps
+    __shared__ __attribute__((aligned(16))) float s_h[PNA_FT_ROWS * PNA_FT_STRIDE];
+    __shared__ __attribute__((aligned(4))) uint8_t s_src[2][PNA_FT_EDGES];
+    __shared__ uint16_t s_rp[2][PNA_FT_ROWS + 4];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int j = lane & 15, g = lane >> 4;
+    // Waves 0..7 gather a K-step's slice and then multiply; waves 8..15 multiply first (with the slice they gathered one interval
+    // earlier) and then gather the next one: between two barriers half of the waves of every SIMD are in the matrix pipe while
+    // the other half is in the VALU / LDS gather.
+    const bool late = wave >= PNA_FT_WAVES / 2;
+    float vmax = 0.0f;
+    int tile = blockIdx.x;
+    if (tile >= n_tiles) return;
+    // tile descriptor of the first tile; later ones are fetched one tile ahead
+    int t0 = tile_row[tile], rows = tile_row[tile + 1] - t0;
+    if (rows > PNA_FT_ROWS) rows = PNA_FT_ROWS;
+    int e0 = row_ptr[t0], ne = row_ptr[t0 + rows] - e0;
+    if (ne > PNA_FT_EDGES) ne = PNA_FT_EDGES;  // cannot happen for a validated batch (the host packed by edge count)
+    int buf = 0;
+    for (int i = threadIdx.x; i < ne; i += PNA_FT_WAVES * 64) s_src[0][i] = (uint8_t)((src[e0 + i] - t0) & 255);
+    if ((int)threadIdx.x <= rows) {
+        int o = row_ptr[t0 + threadIdx.x] - e0;
+        s_rp[0][threadIdx.x] = (uint16_t)(o < 0 ? 0 : (o > ne ? ne : o));
+    }
+    pna_issue_rows(h, t0, rows, s_h, wave, lane);
+    while (true) {
+        const int ntile = tile + gridDim.x;
+        const bool has_next = ntile < n_tiles;
+        int nt0 = 0, nrows = 0, ne0 = 0, nne = 0;
+        if (has_next) {
+            nt0 = tile_row[ntile];
+            nrows = tile_row[ntile + 1] - nt0;
+            if (nrows > PNA_FT_ROWS) nrows = PNA_FT_ROWS;
+            ne0 = row_ptr[nt0];
+            nne = row_ptr[nt0 + nrows] - ne0;
+            if (nne > PNA_FT_EDGES) nne = PNA_FT_EDGES;
+        }
+        pna_issue_chunk_asm(wpk, s_a, wave, lane);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this tile's rows and CSR slice, chunk 0
+        __syncthreads();
+        const int r = wave * 16 + j;
+        const bool valid = r < rows;
+        const uint8_t* csrc = s_src[buf];
+        const int e_base = valid ? (int)s_rp[buf][r] : 0;
+        int indeg = valid ? (int)s_rp[buf][r + 1] - e_base : 0;
+        if (ablate & 1) indeg = 0;  // development aid (FLOWGNN_PNA_ABLATE): timing without the gather
+        uint32_t srcw[4];  // the first 16 in-edges, one byte each (re-walked by every K-step)
+#pragma unroll
+        for (int w = 0; w < 4; w++) {
+            uint32_t v = 0;
+#pragma unroll
+            for (int b = 0; b < 4; b++) v |= (4 * w + b < indeg ? (uint32_t)csrc[e_base + 4 * w + b] : 0u) << (8 * b);
+            srcw[w] = v;
+        }
+        // per-node scalars of the epilogue (node_embedding.cc:148-150), requested early
+        const long long node = (long long)t0 + (valid ? r : 0);
+        const int odeg = out_deg[node];
+        float4_t y[PNA_NS * PNA_OT];
+#pragma unroll
+        for (int i = 0; i < PNA_NS * PNA_OT; i++) y[i] = (float4_t){0.f, 0.f, 0.f, 0.f};
+        ds_uint4_t b_hi = {0, 0, 0, 0}, b_lo = {0, 0, 0, 0};
+        if (late) pna_gather_slice(s_h, csrc, srcw, e_base, indeg, 2 * g, b_hi, b_lo, vmax);  // K-step 0's slice, ahead of the first interval
+#pragma unroll 1
+        for (int ks = 0; ks < ((ablate & 2) ? 0 : PNA_KS); ks += 2) {
+            // even K-step from s_a while chunk ks+1 streams into s_b
+            pna_issue_chunk_asm(wpk + (size_t)(ks + 1) * PNA_CHUNK, s_b, wave, lane);
+            if (!late) pna_gather_slice(s_h, csrc, srcw, e_base, indeg, 8 * ks + 2 * g, b_hi, b_lo, vmax);
+            pna_stream_mfma(s_a, lane, b_hi, b_lo, y);
+            if (late) pna_gather_slice(s_h, csrc, srcw, e_base, indeg, 8 * (ks + 1) + 2 * g, b_hi, b_lo, vmax);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (ks + 2 < PNA_KS) pna_issue_chunk_asm(wpk + (size_t)(ks + 2) * PNA_CHUNK, s_a, wave, lane);
+            if (!late) pna_gather_slice(s_h, csrc, srcw, e_base, indeg, 8 * (ks + 1) + 2 * g, b_hi, b_lo, vmax);
+            pna_stream_mfma(s_b, lane, b_hi, b_lo, y);
+            if (late && ks + 2 < PNA_KS) pna_gather_slice(s_h, csrc, srcw, e_base, indeg, 8 * (ks + 2) + 2 * g, b_hi, b_lo, vmax);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+        // ---- epilogue: h' = h + relu(b + Y_0 + t Y_1 + scale Y_2)   (node_embedding.cc:148-150,205-213); the residual rows come
+        // out of the LDS tile, after which the tile is dead and the next one's rows can stream in
+        float4 hv[PNA_OT];
+#pragma unroll
+        for (int t = 0; t < PNA_OT; t++) hv[t] = *reinterpret_cast<const float4*>(s_h + (valid ? r : 0) * PNA_FT_STRIDE + 16 * t + 4 * g);
+        __syncthreads();  // every wave has its residual rows (and is done gathering): s_h may be overwritten
+        if (has_next) {
+            pna_issue_rows(h, nt0, nrows, s_h, wave, lane);
+            // ... and its CSR slice into the other small buffer (the loads return under the stores of this tile's rows)
+            for (int i = threadIdx.x; i < nne; i += PNA_FT_WAVES * 64) s_src[buf ^ 1][i] = (uint8_t)((src[ne0 + i] - nt0) & 255);
+            if ((int)threadIdx.x <= nrows) {
+                const int o = row_ptr[nt0 + threadIdx.x] - ne0;
+                s_rp[buf ^ 1][threadIdx.x] = (uint16_t)(o < 0 ? 0 : (o > nne ? nne : o));
+            }
+        }
+        if (valid) {
+            const float logd = logf((float)(odeg + 1));
+            const float sf_t = logd / avg_deg;
+            const float sf_scale = (logd == 0.0f) ? 1.0f : avg_deg / logd;
+#pragma unroll
+            for (int t = 0; t < PNA_OT; t++) {
+                const float4 b = *reinterpret_cast<const float4*>(bias + 16 * t + 4 * g);
+                float4_t fin = {b.x, b.y, b.z, b.w};
+                fin += y[0 * PNA_OT + t] * oscale;
+                fin += sf_t * (y[1 * PNA_OT + t] * oscale);
+                fin += sf_scale * (y[2 * PNA_OT + t] * oscale);
+                *reinterpret_cast<float4*>(hout + (size_t)node * PNA_D + 16 * t + 4 * g) =
+                    make_float4(hv[t].x + relu1(fin.x), hv[t].y + relu1(fin.y), hv[t].z + relu1(fin.z), hv[t].w + relu1(fin.w));
+            }
+        }
+        if (!has_next) break;
+        tile = ntile; t0 = nt0; rows = nrows; e0 = ne0; ne = nne;
+        buf ^= 1;
+    }
+    if (__any(!(vmax < 6.0e4f))) {
+        if (lane == 0) atomicOr(range_flag, 1);
+    }
+}
+
+// host: conv_w of one layer [80][3][4][80] -> the FEATURE-major weight stream of pna_layer_fused_kernel (same chunk geometry as
+// pna_pack_split_layer: chunk ks = fragments of the 15 (scaler, output tile) pairs, hi then lo, 1 KiB each); K-slot e of lane
+// group gk in K-step ks is (feature 8 ks + 2 gk + (e >> 2), aggregator e & 3).  The scale is the one pna_pack_split_layer returns.
+static void pna_pack_stream_layer(const float* cw, uint8_t* out) {
+    float m = 0.0f;
+    for (size_t i = 0; i < (size_t)PNA_D * PNA_NS * PNA_NA * PNA_D; i++) m = std::fmax(m, std::fabs(cw[i]));
+    const float sc = (m > 0.0f && std::isfinite(m)) ? std::ldexp(1.0f, -std::ilogb(m)) : 1.0f;
+    for (int ks = 0; ks < PNA_KS; ks++)
+        for (int s = 0; s < PNA_NS; s++)
+            for (int t = 0; t < PNA_OT; t++)
+                for (int lane = 0; lane < 64; lane++) {
+                    const int i = lane & 15, gk = lane >> 4, o = 16 * t + i;
+                    uint8_t* f = out + (size_t)ks * PNA_CHUNK + (size_t)((s * PNA_OT + t) * 2) * 1024;
+                    for (int e = 0; e < 8; e++) {
+                        const int feat = 8 * ks + 2 * gk + (e >> 2), a = e & 3;
+                        const float v = cw[(((size_t)o * PNA_NS + s) * PNA_NA + a) * PNA_D + feat] * sc;
+                        const _Float16 hi = (_Float16)v;
+                        const _Float16 lo = (_Float16)(v - (float)hi);
+                        std::memcpy(f + lane * 16 + e * 2, &hi, 2);
+                        std::memcpy(f + 1024 + lane * 16 + e * 2, &lo, 2);
+                    }
+                }
+}
+
 // host: conv_w of one layer [80][3][4][80] -> PNA_SPLIT_LAYER_BYTES; returns 1 / scale
 static float pna_pack_split_layer(const float* cw, uint8_t* out) {
     float m = 0.0f;
@@ -317,8 +575,12 @@ public:
         std::vector<uint8_t> split((size_t)PNA_L * PNA_SPLIT_LAYER_BYTES);
         for (int l = 0; l < PNA_L; l++)
             oscale_[l] = pna_pack_split_layer(cw + (size_t)l * PNA_D * PNA_NS * PNA_NA * PNA_D, split.data() + (size_t)l * PNA_SPLIT_LAYER_BYTES);
+        std::vector<uint8_t> stream((size_t)PNA_L * PNA_SPLIT_LAYER_BYTES);
+        for (int l = 0; l < PNA_L; l++)
+            pna_pack_stream_layer(cw + (size_t)l * PNA_D * PNA_NS * PNA_NA * PNA_D, stream.data() + (size_t)l * PNA_SPLIT_LAYER_BYTES);
         int rc;
         if ((rc = upload(&d_split_, split))) return rc;
+        if ((rc = upload(&d_stream_, stream))) return rc;
         if ((rc = upload(&d_nemb_, v_nemb))) return rc;
         if ((rc = upload(&d_wf_, wf))) return rc;
         if ((rc = upload(&d_cb_, v_cb))) return rc;
@@ -359,6 +621,12 @@ public:
         launch_tiled_aggregate<PnaAggPolicy>(prm, hin, db.scratch, db.csr, nullptr, db.b.n_tot, tiles_.p, tile_nominal_, s);
     }
 
+    // fused layer kernel (pna_layer_fused_kernel): whole graphs packed into tiles of <= 256 rows / 4 608 in-edges by flowgnn_set_batch
+    void graph_tile_limits(int& rows, int& edges) const override {
+        rows = fused_ ? PNA_FT_ROWS : 0;
+        edges = fused_ ? PNA_FT_EDGES : 0;
+    }
+
     int forward(DeviceBatch& db, Profiler& prof, hipStream_t s) override {
         const int n = db.b.n_tot;
         if (n <= 0) return 0;
@@ -370,7 +638,19 @@ public:
         }
         if (int rc = make_tile_bounds(tiles_, db.b.node_off, db.b.num_graphs, n, tile_nominal_, tile_slack_, s)) return rc;
         int cur = 0;
+        // tiles that are mostly empty (graphs of 65..128 nodes) waste MFMA columns: below 40 % full the two-kernel layer is used
+        const bool fused = fused_ && split_ && !exact_ && db.gtiles.ok && db.gtiles.n_tiles > 0 && db.gtiles.fill >= 0.4;
         for (int l = 0; l < PNA_L; l++) {
+            if (fused) {
+                ProfScope p(prof, "pna_layer_fused", s);
+                const int grid = db.gtiles.n_tiles < 256 ? db.gtiles.n_tiles : 256;  // persistent: one 16-wave workgroup per CU (151 KB of LDS)
+                pna_layer_fused_kernel<<<grid, PNA_FT_WAVES * 64, 0, s>>>(db.h[cur], db.h[cur ^ 1], db.csr.row_ptr, db.csr.src, db.csr.out_deg,
+                                                            d_stream_ + (size_t)l * PNA_SPLIT_LAYER_BYTES, d_cb_ + (size_t)l * PNA_D, avg_deg_,
+                                                            oscale_[l], db.gtiles.row_start, db.gtiles.n_tiles, db.range_flag,
+                                                            getenv("FLOWGNN_PNA_ABLATE") ? atoi(getenv("FLOWGNN_PNA_ABLATE")) : 0);
+                cur ^= 1;
+                continue;
+            }
             {
                 ProfScope p(prof, "pna_aggregate", s);
                 launch_aggregate(db, db.h[cur], s);
@@ -413,6 +693,7 @@ private:
         for (auto p : ptrs)
             if (*p) { (void)hipFree(*p); *p = nullptr; }
         if (d_split_) { (void)hipFree(d_split_); d_split_ = nullptr; }
+        if (d_stream_) { (void)hipFree(d_stream_); d_stream_ = nullptr; }
         tiles_.release();
         q_.release();
     }
@@ -424,8 +705,11 @@ private:
     int tile_slack_ = getenv("FLOWGNN_TILE_SLACK") ? atoi(getenv("FLOWGNN_TILE_SLACK")) : 48;
     // FLOWGNN_PNA_MFMA=f32 keeps the dense update on the fp32 matrix pipe (pna_dense_kernel)
     bool split_ = !(getenv("FLOWGNN_PNA_MFMA") && strcmp(getenv("FLOWGNN_PNA_MFMA"), "f32") == 0);
+    // FLOWGNN_PNA_FUSED=0 keeps aggregation and dense update as two kernels per layer (A/B measurements, the aggregation roofline probe)
+    bool fused_ = !(getenv("FLOWGNN_PNA_FUSED") && atoi(getenv("FLOWGNN_PNA_FUSED")) == 0);
     bool exact_ = false;
     uint8_t* d_split_ = nullptr;
+    uint8_t* d_stream_ = nullptr;  // feature-major weight stream of the fused layer kernel
     float oscale_[PNA_L] = {1.f, 1.f, 1.f, 1.f};
     float avg_deg_ = 1.0f;
     float *d_nemb_ = nullptr, *d_wf_ = nullptr, *d_cb_ = nullptr, *d_w1_ = nullptr, *d_b1_ = nullptr, *d_w2_ = nullptr,
