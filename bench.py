@@ -74,8 +74,9 @@ MODELS = {
                 workload="PNA dim=80, hep10k-shaped kNN graphs on MI355X (BASELINE configs[4])"),
     "DGN": dict(metric="graphs/sec on hep10k (DGN, dim=100)", dataset="hep10k", graphs=1 << 15,
                 agg_bytes=lambda n, e: n * 400 * 3 + e * 12, flops=lambda n, e: n * 40000,
-                fused_bytes=lambda n, e: n * (800 + 400 + 400),  # split dense: read both aggregates + h, write h'
-                hbm_kernels=("dgn_aggregate",), mfma_kernels=("dgn_dense",),
+                # unfused split dense: read both aggregates + h, write h'; fused layer: read h (tile rows) + CSR + eigenvector, write h'
+                fused_bytes={"dgn_dense": lambda n, e: n * (800 + 400 + 400), "dgn_layer_fused": lambda n, e: n * (400 + 400 + 12) + e * 4},
+                hbm_kernels=("dgn_aggregate",), mfma_kernels=("dgn_layer_fused", "dgn_dense"),
                 workload="DGN dim=100, hep10k-shaped kNN graphs on MI355X (BASELINE configs[4])"),
 }
 

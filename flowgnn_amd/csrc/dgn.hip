@@ -127,6 +127,253 @@ __global__ __launch_bounds__(256) void dgn_dense_kernel(const float* __restrict_
     }
 }
 
+// ---------------------------------------------------------------- fused layer: aggregation + dense update in one kernel
+// Neither the aggregates z = [a1 | a2] (800 B per node) nor any weight chunk ever crosses a barrier here.  The contraction index
+// is re-ordered FEATURE-major: K-step k (of 7) covers a1 and a2 of features 16k .. 16k+15, lane (j, g) supplying the two
+// quadruples of features 16k + 4g .. +3 of node j (K-slot e: feature 16k + 4g + (e & 3), a1 for e < 4, a2 for e >= 4) -- one
+// 16-byte read per in-edge and eight accumulators per K-step, then the step's 21 MFMAs.  The layer's split weights in that
+// order are 98 KiB: they stay in LDS for the whole kernel, so inside a tile the eight waves of the (persistent, one per CU)
+// workgroup never meet a barrier and drift against each other -- one wave's gather (VALU / LDS) runs under another's MFMAs.
+// Tiles are WHOLE graphs (GraphTiles: <= 128 rows, <= 2 560 in-edges): the tile's rows of h, its CSR slice (bytes) and its
+// eigenvector column live in LDS; the next tile's are fetched into registers while this one is computed and written to LDS
+// between the two barriers that end a tile.  In-edges are summed in CSR order; the directional weights eig1[u] - eig1[v] of a
+// row's first 16 in-edges are kept in registers.
+constexpr int DGN_FT_ROWS = 128;
+constexpr int DGN_FT_EDGES = 2560;
+constexpr int DGN_FT_KS = 7;
+constexpr int DGN_FT_WBYTES = DGN_FT_KS * DGN_OT * 2 * 1024;  // 100 352: [k][t][hi, lo] fragments
+constexpr int DGN_FT_BIAS = DGN_FT_WBYTES;                     // then bias[112] (pre-scaled) and 1 / scale
+constexpr size_t DGN_FT_LAYER_BYTES = DGN_FT_WBYTES + 512;
+
+__global__ __launch_bounds__(512, 2) void dgn_layer_fused_kernel(const float* __restrict__ h, float* __restrict__ hout,
+                                                                  const int* __restrict__ row_ptr, const int* __restrict__ src,
+                                                                  const int* __restrict__ out_deg, const float* __restrict__ eig4,
+                                                                  const uint8_t* __restrict__ wpk, const int* __restrict__ tile_row,
+                                                                  int n_tiles, int* __restrict__ range_flag, int ablate) {
+    __shared__ __attribute__((aligned(16))) char s_w[DGN_FT_LAYER_BYTES];
+    __shared__ __attribute__((aligned(16))) float s_h[DGN_FT_ROWS * DGN_D];
+    __shared__ __attribute__((aligned(4))) uint8_t s_src[DGN_FT_EDGES];
+    __shared__ uint16_t s_rp[DGN_FT_ROWS + 4];
+    __shared__ float s_eig[DGN_FT_ROWS];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 15, g = lane >> 4;
+    int tile = blockIdx.x;
+    if (tile >= n_tiles) return;
+    // the layer's weights: once per workgroup
+    for (int i = tid; i < (int)(DGN_FT_LAYER_BYTES / 16); i += 512)
+        reinterpret_cast<uint4*>(s_w)[i] = reinterpret_cast<const uint4*>(wpk)[i];
+    // first tile straight into LDS
+    int t0 = tile_row[tile], rows = tile_row[tile + 1] - t0;
+    if (rows > DGN_FT_ROWS) rows = DGN_FT_ROWS;
+    int e0 = row_ptr[t0], ne = row_ptr[t0 + rows] - e0;
+    if (ne > DGN_FT_EDGES) ne = DGN_FT_EDGES;  // cannot happen for a validated batch (the host packed by edge count)
+    for (int i = tid; i < rows * (DGN_D / 4); i += 512) reinterpret_cast<float4*>(s_h)[i] = reinterpret_cast<const float4*>(h + (size_t)t0 * DGN_D)[i];
+    for (int i = tid; i < ne; i += 512) s_src[i] = (uint8_t)((src[e0 + i] - t0) & 127);
+    if (tid <= rows) { const int o = row_ptr[t0 + tid] - e0; s_rp[tid] = (uint16_t)(o < 0 ? 0 : (o > ne ? ne : o)); }
+    if (tid < rows) s_eig[tid] = eig4[(size_t)(t0 + tid) * 4 + 1];
+    __syncthreads();
+    const float oscale = *reinterpret_cast<const float*>(s_w + DGN_FT_BIAS + 112 * 4);
+    float vmax = 0.0f;
+    while (true) {
+        const int ntile = tile + gridDim.x;
+        const bool has_next = ntile < n_tiles;
+        // ---- the next tile: requested now into registers (rows: 7 float4 per thread), written to LDS after this tile's work
+        // (unconditional loads from clamped addresses: a conditionally filled array would be kept in scratch memory, and the
+        // store to it would wait for the loads right here)
+        int nt0 = t0, nrows = rows, ne0 = e0, nne = ne;
+        if (has_next) {
+            nt0 = tile_row[ntile];
+            nrows = tile_row[ntile + 1] - nt0;
+            if (nrows > DGN_FT_ROWS) nrows = DGN_FT_ROWS;
+            ne0 = row_ptr[nt0];
+            nne = row_ptr[nt0 + nrows] - ne0;
+            if (nne > DGN_FT_EDGES) nne = DGN_FT_EDGES;
+        }
+        const float4* nb = reinterpret_cast<const float4*>(h + (size_t)nt0 * DGN_D);
+        const int last = nrows * (DGN_D / 4) - 1, elast = nne > 0 ? nne - 1 : 0;
+#define DGN_NXI(P) ((tid + 512 * (P)) < last ? (tid + 512 * (P)) : last)
+#define DGN_NXE(P) (nne > 0 ? src[ne0 + ((tid + 512 * (P)) < elast ? (tid + 512 * (P)) : elast)] : 0)
+        // named scalars, not arrays: hipcc keeps a seven-element float4 array that is filled here and consumed at the loop's end
+        // in scratch memory, and its store would wait for the loads on the spot
+        const float4 nr0 = nb[DGN_NXI(0)], nr1 = nb[DGN_NXI(1)], nr2 = nb[DGN_NXI(2)], nr3 = nb[DGN_NXI(3)], nr4 = nb[DGN_NXI(4)],
+                     nr5 = nb[DGN_NXI(5)], nr6 = nb[DGN_NXI(6)];
+        const int ns0 = DGN_NXE(0), ns1 = DGN_NXE(1), ns2 = DGN_NXE(2), ns3 = DGN_NXE(3), ns4 = DGN_NXE(4);
+#undef DGN_NXI
+#undef DGN_NXE
+        const int nx_rp = row_ptr[nt0 + (tid <= nrows ? tid : nrows)];
+        const float nx_eig = eig4[(size_t)(nt0 + (tid < nrows ? tid : 0)) * 4 + 1];
+        // ---- this wave's 16 rows
+        const int r = wave * 16 + j;
+        const bool valid = r < rows;
+        const int e_base = valid ? (int)s_rp[r] : 0;
+        int indeg = valid ? (int)s_rp[r + 1] - e_base : 0;
+        if (ablate & 1) indeg = 0;  // development aid (FLOWGNN_DGN_ABLATE): timing without the gather
+        const float eig_v = s_eig[valid ? r : 0];
+        const long long node = (long long)t0 + (valid ? r : 0);
+        const int odeg = out_deg[node];
+        // first 16 in-edges: source rows as bytes, directional weights in registers; wsum / abssum over ALL in-edges
+        // (DGN/src/load_inputs.cc:105-110)
+        uint32_t srcw[4];
+        float ew[16];
+        float wsum = 0.0f, abssum = 0.0f;
+#pragma unroll
+        for (int w = 0; w < 4; w++) {
+            uint32_t v = 0;
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                const int e = 4 * w + b;
+                const int u = e < indeg ? (int)s_src[e_base + e] : 0;
+                v |= (uint32_t)u << (8 * b);
+                const float we = e < indeg ? s_eig[u] - eig_v : 0.0f;
+                ew[e] = we;
+                wsum += we;
+                abssum += fabsf(we);
+            }
+            srcw[w] = v;
+        }
+        for (int e = 16; __any(e < indeg); e++)
+            if (e < indeg) { const float we = s_eig[s_src[e_base + e]] - eig_v; wsum += we; abssum += fabsf(we); }
+        const float inv_abs = 1.0f / (abssum == 0.0f ? 1.0f / 8192.0f : abssum);  // epsilon of ap_fixed<16,3> (node_embedding.cc:125-128)
+        float4_t acc[DGN_OT];
+#pragma unroll
+        for (int t = 0; t < DGN_OT; t++) {
+            const float4 bv = *reinterpret_cast<const float4*>(s_w + DGN_FT_BIAS + (16 * t + 4 * g) * 4);
+            acc[t] = (float4_t){bv.x, bv.y, bv.z, bv.w};
+        }
+        const float* hrow = s_h + (valid ? r : 0) * DGN_D;
+#pragma unroll
+        for (int k = 0; k < DGN_FT_KS; k++) {
+            if (ablate & 2) break;
+            // K-step k: features 16k + 4g .. +3 (k = 6: only g = 0 holds real features, 96..99; the others supply zeros)
+            const bool real = k < 6 || g == 0;
+            const int col = real ? 16 * k + 4 * g : 0;
+            float4 m1 = make_float4(0.f, 0.f, 0.f, 0.f), m2 = m1;
+#pragma unroll
+            for (int w = 0; w < 4; w++) {
+                if (__all(indeg >= 4 * w + 4)) {  // every row of the wave has these four in-edges: four reads in flight, no masks
+                    float4 x[4];
+#pragma unroll
+                    for (int b = 0; b < 4; b++) x[b] = *reinterpret_cast<const float4*>(s_h + (int)((srcw[w] >> (8 * b)) & 0xFFu) * DGN_D + col);
+#pragma unroll
+                    for (int b = 0; b < 4; b++) {
+                        const float we = ew[4 * w + b];
+                        m1.x += x[b].x; m1.y += x[b].y; m1.z += x[b].z; m1.w += x[b].w;
+                        m2.x = __builtin_fmaf(x[b].x, we, m2.x); m2.y = __builtin_fmaf(x[b].y, we, m2.y); m2.z = __builtin_fmaf(x[b].z, we, m2.z); m2.w = __builtin_fmaf(x[b].w, we, m2.w);
+                    }
+                } else if (__any(indeg > 4 * w)) {
+#pragma unroll
+                    for (int b = 0; b < 4; b++)
+                        if (indeg > 4 * w + b) {
+                            const float4 x = *reinterpret_cast<const float4*>(s_h + (int)((srcw[w] >> (8 * b)) & 0xFFu) * DGN_D + col);
+                            const float we = ew[4 * w + b];
+                            m1.x += x.x; m1.y += x.y; m1.z += x.z; m1.w += x.w;
+                            m2.x = __builtin_fmaf(x.x, we, m2.x); m2.y = __builtin_fmaf(x.y, we, m2.y); m2.z = __builtin_fmaf(x.z, we, m2.z); m2.w = __builtin_fmaf(x.w, we, m2.w);
+                        }
+                }
+            }
+            for (int e = 16; __any(e < indeg); e++)  // rows with more than 16 in-edges: the rest from the LDS copies
+                if (e < indeg) {
+                    const int u = s_src[e_base + e];
+                    const float we = s_eig[u] - eig_v;
+                    const float4 x = *reinterpret_cast<const float4*>(s_h + u * DGN_D + col);
+                    m1.x += x.x; m1.y += x.y; m1.z += x.z; m1.w += x.w;
+                    m2.x = __builtin_fmaf(x.x, we, m2.x); m2.y = __builtin_fmaf(x.y, we, m2.y); m2.z = __builtin_fmaf(x.z, we, m2.z); m2.w = __builtin_fmaf(x.w, we, m2.w);
+                }
+            // a1 = m1 / outdeg (x / 0 = 0), a2 = |(m2 - wsum h[v]) / abssum|   (node_embedding.cc:143-146)
+            const float4 hv = *reinterpret_cast<const float4*>(hrow + col);
+            const float dg = (float)odeg;
+            float4 a1, a2;
+            a1.x = odeg == 0 ? 0.f : m1.x / dg; a1.y = odeg == 0 ? 0.f : m1.y / dg;
+            a1.z = odeg == 0 ? 0.f : m1.z / dg; a1.w = odeg == 0 ? 0.f : m1.w / dg;
+            // explicit fma: every path a wave can take (all rows full / ragged) rounds alike, so a row's result never depends on its tile mates
+            a2.x = fabsf(__builtin_fmaf(-wsum, hv.x, m2.x) * inv_abs); a2.y = fabsf(__builtin_fmaf(-wsum, hv.y, m2.y) * inv_abs);
+            a2.z = fabsf(__builtin_fmaf(-wsum, hv.z, m2.z) * inv_abs); a2.w = fabsf(__builtin_fmaf(-wsum, hv.w, m2.w) * inv_abs);
+            if (!real) { a1 = make_float4(0.f, 0.f, 0.f, 0.f); a2 = a1; }
+            ds_uint4_t b_hi, b_lo;
+            DS_SPLIT2(a1.x, a1.y, b_hi.x, b_lo.x);
+            DS_SPLIT2(a1.z, a1.w, b_hi.y, b_lo.y);
+            DS_SPLIT2(a2.x, a2.y, b_hi.z, b_lo.z);
+            DS_SPLIT2(a2.z, a2.w, b_hi.w, b_lo.w);
+            vmax = __builtin_fmaxf(__builtin_fmaxf(vmax, __builtin_fabsf(a1.x)), __builtin_fabsf(a1.y));
+            vmax = __builtin_fmaxf(__builtin_fmaxf(vmax, __builtin_fabsf(a1.z)), __builtin_fabsf(a1.w));
+            vmax = __builtin_fmaxf(__builtin_fmaxf(vmax, a2.x), a2.y);
+            vmax = __builtin_fmaxf(__builtin_fmaxf(vmax, a2.z), a2.w);
+            asm volatile("" : "+v"(vmax));
+            const char* wb = s_w + (size_t)k * (DGN_OT * 2 * 1024);
+#pragma unroll
+            for (int t0_ = 0; t0_ < DGN_OT; t0_ += 2) {  // pairs of output tiles, product-major: no MFMA waits for its predecessor
+                const int n = t0_ + 1 < DGN_OT ? 2 : 1;
+                ds_uint4_t f[4];
+#pragma unroll
+                for (int i = 0; i < 2 * n; i++) f[i] = *reinterpret_cast<const ds_uint4_t*>(wb + ((t0_ * 2) + i) * 1024 + lane * 16);
+#pragma unroll
+                for (int i = 0; i < n; i++) acc[t0_ + i] = DS_MFMA16(f[2 * i], b_hi, acc[t0_ + i]);
+#pragma unroll
+                for (int i = 0; i < n; i++) acc[t0_ + i] = DS_MFMA16(f[2 * i], b_lo, acc[t0_ + i]);
+#pragma unroll
+                for (int i = 0; i < n; i++) acc[t0_ + i] = DS_MFMA16(f[2 * i + 1], b_hi, acc[t0_ + i]);
+            }
+        }
+        // ---- epilogue: h' = h + relu(b + W0 a1 + W1 a2)   (node_embedding.cc:176-181)
+        if (valid) {
+#pragma unroll
+            for (int t = 0; t < DGN_OT; t++) {
+                const int c = 16 * t + 4 * g;
+                if (c < DGN_D) {
+                    const float4 hv = *reinterpret_cast<const float4*>(hrow + c);
+                    const float4_t rr = acc[t] * oscale;
+                    *reinterpret_cast<float4*>(hout + (size_t)node * DGN_D + c) =
+                        make_float4(hv.x + relu1(rr.x), hv.y + relu1(rr.y), hv.z + relu1(rr.z), hv.w + relu1(rr.w));
+                }
+            }
+        }
+        if (!has_next) break;
+        __syncthreads();  // every wave is done with this tile's rows, CSR slice and eigenvector column
+#define DGN_PUT(P, V) if (tid + 512 * (P) < nrows * (DGN_D / 4)) reinterpret_cast<float4*>(s_h)[tid + 512 * (P)] = V;
+        DGN_PUT(0, nr0) DGN_PUT(1, nr1) DGN_PUT(2, nr2) DGN_PUT(3, nr3) DGN_PUT(4, nr4) DGN_PUT(5, nr5) DGN_PUT(6, nr6)
+#undef DGN_PUT
+#define DGN_PUTE(P, V) if (tid + 512 * (P) < nne) s_src[tid + 512 * (P)] = (uint8_t)(((V) - nt0) & 127);
+        DGN_PUTE(0, ns0) DGN_PUTE(1, ns1) DGN_PUTE(2, ns2) DGN_PUTE(3, ns3) DGN_PUTE(4, ns4)
+#undef DGN_PUTE
+        if (tid <= nrows) { const int o = nx_rp - ne0; s_rp[tid] = (uint16_t)(o < 0 ? 0 : (o > nne ? nne : o)); }
+        if (tid < nrows) s_eig[tid] = nx_eig;
+        __syncthreads();
+        tile = ntile; t0 = nt0; rows = nrows; e0 = ne0; ne = nne;
+    }
+    if (__any(!(vmax < 6.0e4f))) {
+        if (lane == 0) atomicOr(range_flag, 1);
+    }
+}
+
+// host: W [100][2][100] (out, block, in), b [100] -> DGN_FT_LAYER_BYTES in the feature-major K order of dgn_layer_fused_kernel
+static void dgn_pack_fused_layer(const float* W, const float* b, uint8_t* out) {
+    std::memset(out, 0, DGN_FT_LAYER_BYTES);
+    float m = 0.0f;
+    for (size_t i = 0; i < (size_t)DGN_D * 2 * DGN_D; i++) m = std::fmax(m, std::fabs(W[i]));
+    const float sc = (m > 0.0f && std::isfinite(m)) ? std::ldexp(1.0f, -std::ilogb(m)) : 1.0f;
+    for (int k = 0; k < DGN_FT_KS; k++)
+        for (int t = 0; t < DGN_OT; t++)
+            for (int lane = 0; lane < 64; lane++) {
+                const int i = lane & 15, gk = lane >> 4, o = 16 * t + i;
+                uint8_t* f = out + (size_t)((k * DGN_OT + t) * 2) * 1024;
+                for (int e = 0; e < 8; e++) {
+                    const int feat = 16 * k + 4 * gk + (e & 3), blk = e >> 2;
+                    const float v = (o < DGN_D && feat < DGN_D) ? W[((size_t)o * 2 + blk) * DGN_D + feat] * sc : 0.0f;
+                    const _Float16 hi = (_Float16)v;
+                    const _Float16 lo = (_Float16)(v - (float)hi);
+                    std::memcpy(f + lane * 16 + e * 2, &hi, 2);
+                    std::memcpy(f + 1024 + lane * 16 + e * 2, &lo, 2);
+                }
+            }
+    for (int x = 0; x < 16 * DGN_OT; x++) {
+        const float bb = x < DGN_D ? b[x] * sc : 0.0f;
+        std::memcpy(out + DGN_FT_BIAS + (size_t)x * 4, &bb, 4);
+    }
+    const float os = 1.0f / sc;
+    std::memcpy(out + DGN_FT_BIAS + 112 * 4, &os, 4);
+}
+
 class DgnModel : public Model {
 public:
     ~DgnModel() override { free_all(); }
@@ -162,7 +409,7 @@ public:
         std::vector<float> v_w0(t[3], t[3] + 50 * 100), v_b0(t[4], t[4] + 50), v_w1(t[5], t[5] + 25 * 50), v_b1(t[6], t[6] + 25),
             v_w2(t[7], t[7] + 25), v_b2(t[8], t[8] + 1);
         std::vector<float> wf_all, wt_all, bp_all;
-        std::vector<uint8_t> split_all;
+        std::vector<uint8_t> split_all, fused_all;
         std::vector<float> Wb((size_t)DGN_D * DGN_D), zero(DGN_D, 0.0f);
         for (int l = 0; l < DGN_L; l++) {
             const float* W = t[1] + (size_t)l * DGN_D * 2 * DGN_D;  // [out][2][in]
@@ -183,9 +430,13 @@ public:
             const size_t off = split_all.size();
             split_all.resize(off + dense200_split_bytes(DGN_OT));
             pack_dense200_split(W, t[2] + (size_t)l * DGN_D, DGN_D, DGN_OT, split_all.data() + off);
+            const size_t foff = fused_all.size();
+            fused_all.resize(foff + DGN_FT_LAYER_BYTES);
+            dgn_pack_fused_layer(W, t[2] + (size_t)l * DGN_D, fused_all.data() + foff);
         }
         int rc;
         if ((rc = upload(&d_split_, split_all))) return rc;
+        if ((rc = upload(&d_fused_, fused_all))) return rc;
         if ((rc = upload(&d_emb_, v_emb))) return rc;
         if ((rc = upload(&d_wf_, wf_all))) return rc;
         if ((rc = upload(&d_wt_, wt_all))) return rc;
@@ -226,9 +477,29 @@ public:
         return set_weights(t);
     }
 
+    // row tiles + eig1[src_e] per CSR entry of the standalone aggregation kernel, once per batch pass
+    int prepare_aggregate(DeviceBatch& db, Profiler& prof, hipStream_t s) {
+        const int n = db.b.n_tot;
+        if (int rc = make_tile_bounds(tiles_, db.b.node_off, db.b.num_graphs, n, tile_nominal_, tile_slack_, s)) return rc;
+        if (db.b.e_tot > 0) {
+            if (int rc = esc_.reserve((size_t)db.b.e_tot)) return rc;
+            ProfScope p(prof, "edge_scalar", s);
+            DgnAggPolicy::Params prm{db.node_eigen, db.csr.out_deg, nullptr};
+            edge_scalar_kernel<DgnAggPolicy><<<grid_for(db.b.e_tot, 256, 256 * 8), 256, 0, s>>>(prm, db.csr.src, esc_.p, db.b.e_tot);
+        }
+        agg_ready_ = true;
+        return 0;
+    }
+
     void launch_aggregate(const DeviceBatch& db, const float* hin, hipStream_t s) {
         DgnAggPolicy::Params prm{db.node_eigen, db.csr.out_deg, esc_.p};
         launch_tiled_aggregate<DgnAggPolicy>(prm, hin, db.scratch, db.csr, nullptr, db.b.n_tot, tiles_.p, tile_nominal_, s);
+    }
+
+    // fused layer kernel (dgn_layer_fused_kernel): whole graphs packed into tiles of <= 128 rows / 2 560 in-edges by flowgnn_set_batch
+    void graph_tile_limits(int& rows, int& edges) const override {
+        rows = fused_ ? DGN_FT_ROWS : 0;
+        edges = fused_ ? DGN_FT_EDGES : 0;
     }
 
     int forward(DeviceBatch& db, Profiler& prof, hipStream_t s) override {
@@ -240,15 +511,22 @@ public:
             ProfScope p(prof, "atom_encoder", s);
             atom_encoder_kernel<DGN_D><<<atom_encoder_grid(n, DGN_C), 512, 0, s>>>(db.b.node_feature, d_emb_, db.h[0], n, db.csr.err);
         }
-        if (int rc = make_tile_bounds(tiles_, db.b.node_off, db.b.num_graphs, n, tile_nominal_, tile_slack_, s)) return rc;
-        if (db.b.e_tot > 0) {  // eig1[src_e] per CSR entry, once per pass
-            if (int rc = esc_.reserve((size_t)db.b.e_tot)) return rc;
-            ProfScope p(prof, "edge_scalar", s);
-            DgnAggPolicy::Params prm{db.node_eigen, db.csr.out_deg, nullptr};
-            edge_scalar_kernel<DgnAggPolicy><<<grid_for(db.b.e_tot, 256, 256 * 8), 256, 0, s>>>(prm, db.csr.src, esc_.p, db.b.e_tot);
-        }
+        // tiles that are mostly empty (graphs of 65..128 nodes) waste MFMA columns: below 40 % full the two-kernel layer is used
+        const bool fused = fused_ && split_ && !exact_ && db.gtiles.ok && db.gtiles.n_tiles > 0 && db.gtiles.fill >= 0.4;
+        agg_ready_ = false;
+        if (!fused)  // the fused layer takes eig1[src] from its own LDS tile: only the two-kernel layer needs these
+            if (int rc = prepare_aggregate(db, prof, s)) return rc;
         int cur = 0;
         for (int l = 0; l < DGN_L; l++) {
+            if (fused) {
+                ProfScope p(prof, "dgn_layer_fused", s);
+                const int grid = db.gtiles.n_tiles < 256 ? db.gtiles.n_tiles : 256;  // persistent: one 8-wave workgroup per CU (153 KB of LDS)
+                dgn_layer_fused_kernel<<<grid, 512, 0, s>>>(db.h[cur], db.h[cur ^ 1], db.csr.row_ptr, db.csr.src, db.csr.out_deg, db.node_eigen,
+                                                            d_fused_ + (size_t)l * DGN_FT_LAYER_BYTES, db.gtiles.row_start, db.gtiles.n_tiles,
+                                                            db.range_flag, getenv("FLOWGNN_DGN_ABLATE") ? atoi(getenv("FLOWGNN_DGN_ABLATE")) : 0);
+                cur ^= 1;
+                continue;
+            }
             {
                 ProfScope p(prof, "dgn_aggregate", s);
                 launch_aggregate(db, db.h[cur], s);
@@ -280,6 +558,10 @@ public:
 
     int aggregation_only(DeviceBatch& db, int layer, hipStream_t s) override {
         if (layer < 0 || layer >= DGN_L) return 1;
+        if (!agg_ready_) {  // the last forward ran the fused layers
+            Profiler none;
+            if (int rc = prepare_aggregate(db, none, s)) return rc;
+        }
         launch_aggregate(db, db.h[db.final_h], s);
         return 0;
     }
@@ -293,6 +575,7 @@ private:
         tiles_.release();
         q_.release();
         if (d_split_) { (void)hipFree(d_split_); d_split_ = nullptr; }
+        if (d_fused_) { (void)hipFree(d_fused_); d_fused_ = nullptr; }
     }
     bool ready_ = false;
     bool qmode_ = false;  // flowgnn_set_numeric_mode(FLOWGNN_NUMERIC_Q6_10): ap_fixed<16,3> arithmetic
@@ -302,6 +585,10 @@ private:
     int tile_slack_ = getenv("FLOWGNN_TILE_SLACK") ? atoi(getenv("FLOWGNN_TILE_SLACK")) : 64;
     // FLOWGNN_DGN_MFMA=f32 keeps the dense update on the fp32 matrix pipe (dgn_dense_kernel)
     bool split_ = !(getenv("FLOWGNN_DGN_MFMA") && strcmp(getenv("FLOWGNN_DGN_MFMA"), "f32") == 0);
+    // FLOWGNN_DGN_FUSED=0 keeps aggregation and dense update as two kernels per layer (A/B measurements, the aggregation roofline probe)
+    bool agg_ready_ = false;  // tiles_ / esc_ describe the batch of the last forward
+    bool fused_ = !(getenv("FLOWGNN_DGN_FUSED") && atoi(getenv("FLOWGNN_DGN_FUSED")) == 0);
+    uint8_t* d_fused_ = nullptr;  // feature-major weights of the fused layer kernel
     bool exact_ = false;
     uint8_t* d_split_ = nullptr;
     GrowBuf esc_;

@@ -317,7 +317,7 @@ __device__ __forceinline__ void pna_stream_mfma(const char* wb, int lane, const 
 struct PnaSlice { float S0, S1, Q0, Q1, mn0, mn1, mx0, mx1; };
 __device__ __forceinline__ void pna_slice_add(PnaSlice& a, const float2& x) {
     a.S0 += x.x; a.S1 += x.y;
-    a.Q0 += x.x * x.x; a.Q1 += x.y * x.y;
+    a.Q0 = __builtin_fmaf(x.x, x.x, a.Q0); a.Q1 = __builtin_fmaf(x.y, x.y, a.Q1);  // explicit: the full and the ragged path round alike
     a.mn0 = __builtin_fminf(x.x, a.mn0); a.mn1 = __builtin_fminf(x.y, a.mn1);  // inputs are never NaN-free-dependent: h is finite
     a.mx0 = __builtin_fmaxf(x.x, a.mx0); a.mx1 = __builtin_fmaxf(x.y, a.mx1);
 }
@@ -346,7 +346,7 @@ __device__ __forceinline__ void pna_gather_slice(const float* __restrict__ s_h, 
     // mean = S / indeg (0 -> 1), std = sqrt(relu(Q / indeg - mean^2))   (node_embedding.cc:123,143-145)
     const float deg = (float)(indeg == 0 ? 1 : indeg);
     const float m0 = a.S0 / deg, m1 = a.S1 / deg;
-    const float sd0 = sqrtf(relu1(a.Q0 / deg - m0 * m0)), sd1 = sqrtf(relu1(a.Q1 / deg - m1 * m1));
+    const float sd0 = sqrtf(relu1(__builtin_fmaf(-m0, m0, a.Q0 / deg))), sd1 = sqrtf(relu1(__builtin_fmaf(-m1, m1, a.Q1 / deg)));
     // K-slots e = 0..7: (feature f0: mean, min, max, std), (feature f0 + 1: the same)
     DS_SPLIT2(m0, a.mn0, b_hi.x, b_lo.x);
     DS_SPLIT2(a.mx0, sd0, b_hi.y, b_lo.y);
