@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """profiles/traffic.json from the committed PMC summaries (one FETCH_SIZE pass and one WRITE_SIZE pass per model).
 
-  python profiles/make_traffic.py r01_i
+  python profiles/make_traffic.py r02
 
 bytes per launch = 2 x FETCH_SIZE[KB] x 1000 + WRITE_SIZE[KiB] x 1024:
   * FETCH_SIZE counts the 128-B requests of wide coalesced reads at 64 B on gfx950 (MI355X_MICROARCH.md, HBM) -> doubled;
@@ -15,13 +15,15 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 # bench.py kernel name -> substring of the rocprofv3 kernel name (first match wins; the non-final layer variant is listed first)
 KERNELS = {
-    "GIN": (1 << 18, "gin", {"gin_layer_fused": "gin_layer_split_kernel", "gin_aggregate": "gin_aggregate_tiled_kernel"}),
+    "GIN": (1 << 18, "GIN", {"gin_resident": "gin_resident_kernel", "gin_layer_fused": "gin_layer_split_kernel",
+                             "gin_aggregate": "gin_aggregate_tiled_kernel"}),
     "GCN": (1 << 18, "GCN", {"gcn_layer_fused": "gcn_layer_fused_kernel<false>", "gcn_aggregate": "tiled_aggregate_kernel<fg::GcnAggPolicy"}),
     "GAT": (1 << 18, "GAT", {"gat_layer": "gat_layer_kernel<false, false"}),
-    "PNA": (1 << 15, "PNA", {"pna_aggregate": "tiled_aggregate_kernel<fg::PnaAggPolicy", "pna_dense": "pna_dense_split_kernel"}),
-    "DGN": (1 << 15, "DGN", {"dgn_aggregate": "tiled_aggregate_kernel<fg::DgnAggPolicy", "dgn_dense": "dense200_res_relu_split_kernel"}),
+    "PNA": (1 << 15, "PNA", {"pna_layer_fused": "pna_layer_fused_kernel", "pna_aggregate": "tiled_aggregate_kernel<fg::PnaAggPolicy",
+                             "pna_dense": "pna_dense_split_kernel"}),
+    "DGN": (1 << 15, "DGN", {"dgn_layer_fused": "dgn_layer_fused_kernel", "dgn_aggregate": "tiled_aggregate_kernel<fg::DgnAggPolicy",
+                             "dgn_dense": "dense200_res_relu_split_kernel"}),
 }
-
 
 def table(path):
     out = []
@@ -41,8 +43,10 @@ def main():
         ft, wt = table(os.path.join(HERE, f)), table(os.path.join(HERE, w))
         entry = {"graphs": graphs}
         for name, pat in kernels.items():
-            fk = next(v for k, v in ft if pat in k)
-            wk = next(v for k, v in wt if pat in k)
+            fk = next((v for k, v in ft if pat in k), None)
+            wk = next((v for k, v in wt if pat in k), None)
+            if fk is None or wk is None:  # a kernel of an older or a switched-off path: not launched in this round's default run
+                continue
             entry[name] = {"bytes": int(round(2 * fk * 1000 + wk * 1024, -6)), "fetch_kb": fk, "write_kb": wk,
                            "source": f"profiles/{f}, profiles/{w}"}
         res[model] = entry
