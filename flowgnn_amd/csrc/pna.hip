@@ -318,8 +318,12 @@ struct PnaSlice { float S0, S1, Q0, Q1, mn0, mn1, mx0, mx1; };
 __device__ __forceinline__ void pna_slice_add(PnaSlice& a, const float2& x) {
     a.S0 += x.x; a.S1 += x.y;
     a.Q0 = __builtin_fmaf(x.x, x.x, a.Q0); a.Q1 = __builtin_fmaf(x.y, x.y, a.Q1);  // explicit: the full and the ragged path round alike
-    a.mn0 = __builtin_fminf(x.x, a.mn0); a.mn1 = __builtin_fminf(x.y, a.mn1);  // inputs are never NaN-free-dependent: h is finite
-    a.mx0 = __builtin_fmaxf(x.x, a.mx0); a.mx1 = __builtin_fmaxf(x.y, a.mx1);
+    // min / max as bare instructions: fminf / fmaxf on a value read from memory cost a canonicalising v_max each (the value could be
+    // a signalling NaN); rows of h are finite (the range flag catches what is not)
+    asm("v_min_f32 %0, %1, %0" : "+v"(a.mn0) : "v"(x.x));
+    asm("v_min_f32 %0, %1, %0" : "+v"(a.mn1) : "v"(x.y));
+    asm("v_max_f32 %0, %1, %0" : "+v"(a.mx0) : "v"(x.x));
+    asm("v_max_f32 %0, %1, %0" : "+v"(a.mx1) : "v"(x.y));
 }
 __device__ __forceinline__ void pna_slice_edge(PnaSlice& a, const float* __restrict__ s_h, int u, int col) {
     pna_slice_add(a, *reinterpret_cast<const float2*>(s_h + u * PNA_FT_STRIDE + col));
@@ -334,7 +338,17 @@ __device__ __forceinline__ void pna_gather_slice(const float* __restrict__ s_h, 
 #pragma unroll
             for (int b = 0; b < 4; b++) x[b] = *reinterpret_cast<const float2*>(s_h + (int)((srcw[w] >> (8 * b)) & 0xFFu) * PNA_FT_STRIDE + col);
 #pragma unroll
-            for (int b = 0; b < 4; b++) pna_slice_add(a, x[b]);
+            for (int b = 0; b < 4; b++) {  // sums in CSR order, with the same instructions as pna_slice_add (min / max are order-free: two edges per v_min3 / v_max3)
+                a.S0 += x[b].x; a.S1 += x[b].y;
+                a.Q0 = __builtin_fmaf(x[b].x, x[b].x, a.Q0); a.Q1 = __builtin_fmaf(x[b].y, x[b].y, a.Q1);
+            }
+#pragma unroll
+            for (int b = 0; b < 4; b += 2) {
+                asm("v_min3_f32 %0, %1, %2, %0" : "+v"(a.mn0) : "v"(x[b].x), "v"(x[b + 1].x));
+                asm("v_min3_f32 %0, %1, %2, %0" : "+v"(a.mn1) : "v"(x[b].y), "v"(x[b + 1].y));
+                asm("v_max3_f32 %0, %1, %2, %0" : "+v"(a.mx0) : "v"(x[b].x), "v"(x[b + 1].x));
+                asm("v_max3_f32 %0, %1, %2, %0" : "+v"(a.mx1) : "v"(x[b].y), "v"(x[b + 1].y));
+            }
         } else if (__any(indeg > 4 * w)) {  // ragged: whole words are skipped when no row of the wave has them
 #pragma unroll
             for (int b = 0; b < 4; b++)
@@ -344,18 +358,20 @@ __device__ __forceinline__ void pna_gather_slice(const float* __restrict__ s_h, 
     for (int e = 16; __any(e < indeg); e++)  // rows with more than 16 in-edges: the rest comes from the LDS copy of the CSR slice
         if (e < indeg) pna_slice_edge(a, s_h, (int)s_src[e_base + e], col);
     // mean = S / indeg (0 -> 1), std = sqrt(relu(Q / indeg - mean^2))   (node_embedding.cc:123,143-145)
-    const float deg = (float)(indeg == 0 ? 1 : indeg);
-    const float m0 = a.S0 / deg, m1 = a.S1 / deg;
-    const float sd0 = sqrtf(relu1(__builtin_fmaf(-m0, m0, a.Q0 / deg))), sd1 = sqrtf(relu1(__builtin_fmaf(-m1, m1, a.Q1 / deg)));
+    // 1 / indeg and the square root as single instructions (v_rcp_f32, v_sqrt_f32: 1 ulp): four IEEE divisions and two IEEE square
+    // roots per slice are ~60 dependent VALU instructions, and at two waves per SIMD nothing hides their latency
+    const float rdeg = __builtin_amdgcn_rcpf((float)(indeg == 0 ? 1 : indeg));
+    const float m0 = a.S0 * rdeg, m1 = a.S1 * rdeg;
+    const float sd0 = __builtin_amdgcn_sqrtf(relu1(__builtin_fmaf(-m0, m0, a.Q0 * rdeg))), sd1 = __builtin_amdgcn_sqrtf(relu1(__builtin_fmaf(-m1, m1, a.Q1 * rdeg)));
     // K-slots e = 0..7: (feature f0: mean, min, max, std), (feature f0 + 1: the same)
     DS_SPLIT2(m0, a.mn0, b_hi.x, b_lo.x);
     DS_SPLIT2(a.mx0, sd0, b_hi.y, b_lo.y);
     DS_SPLIT2(m1, a.mn1, b_hi.z, b_lo.z);
     DS_SPLIT2(a.mx1, sd1, b_hi.w, b_lo.w);
-    vmax = __builtin_fmaxf(__builtin_fmaxf(vmax, __builtin_fabsf(m0)), __builtin_fabsf(m1));
-    vmax = __builtin_fmaxf(__builtin_fmaxf(vmax, sd0), sd1);
-    vmax = __builtin_fmaxf(__builtin_fmaxf(vmax, __builtin_fabsf(a.mn0)), __builtin_fabsf(a.mn1));
-    vmax = __builtin_fmaxf(__builtin_fmaxf(vmax, __builtin_fabsf(a.mx0)), __builtin_fabsf(a.mx1));
+    asm("v_max3_f32 %0, |%1|, |%2|, %0" : "+v"(vmax) : "v"(m0), "v"(m1));
+    asm("v_max3_f32 %0, |%1|, |%2|, %0" : "+v"(vmax) : "v"(sd0), "v"(sd1));
+    asm("v_max3_f32 %0, |%1|, |%2|, %0" : "+v"(vmax) : "v"(a.mn0), "v"(a.mn1));
+    asm("v_max3_f32 %0, |%1|, |%2|, %0" : "+v"(vmax) : "v"(a.mx0), "v"(a.mx1));
     asm volatile("" : "+v"(vmax));
 }
 

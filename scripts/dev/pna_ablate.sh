@@ -1,7 +1,7 @@
 #!/bin/bash
 # per-phase timing of the fused PNA / DGN layer kernels: FLOWGNN_<M>_ABLATE bit 0 = no gather loop, bit 1 = no K-steps
 M=${1:-PNA}
-for a in 0 1 2 3; do
+for a in ${ABLATES:-0 1 2 3}; do
   export FLOWGNN_${M}_ABLATE=$a
   python bench.py --model $M --steps 5 --warmup 2 --no-cpu-baseline 2>/dev/null | python -c "
 import json,sys,os
