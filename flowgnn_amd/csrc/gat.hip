@@ -464,6 +464,314 @@ __global__ __launch_bounds__(512, 4) void gat_layer_kernel(const float* __restri
     }
 }
 
+// ---------------------------------------------------------------- graph-resident GAT: all five layers + readout in ONE launch
+// The per-layer kernel above moves ~1.1 KB per node and layer (projection + skip rows in, projection + skip rows out): 1.9x what
+// the layer needs, because o_l = ELU(msg + W_skip skip_l) has to reach the next launch twice (as skip_{l+1} and, projected, as
+// proj_{l+1}).  Here a persistent 16-wave workgroup (one per CU) owns a tile of WHOLE graphs (GraphTiles: <= 256 rows, <= 1 280
+// in-edges; molhiv's largest graph has 222 nodes) across all five layers, as the FPGA keeps one graph in BRAM across its layer loop (GAT/src/GAT_compute.cc:60-100):
+//   * o_l never leaves the registers of the wave that owns the row (it is the B operand of both 64 x 64 contractions);
+//   * proj_l and the attention scores of the tile live in LDS (rows rotated by their index, as above); the gather has no
+//     out-of-tile case at all, because tiles are made of whole graphs;
+//   * the layer's 32 KiB of split weight fragments stream L2 -> LDS under the layer's gather (which does not use them);
+//   * per node the launch reads 36 B of features + 1 B per in-edge + row bounds, and writes 4 B per GRAPH.
+// Two barriers per layer: gathers done -> projections may be overwritten; projections written -> the next gather may start.
+constexpr int GATR_ROWS = 256;
+constexpr int GATR_EDGES = 1280;
+constexpr int GATR_WAVES = 16;
+
+// per layer in device memory (GatModel::d_res_): [W_skip_l 16 KiB][W_lin_{l+1} 16 KiB][score tile 4 KiB], split-f16 fragments.  The
+// score tile is the 16 x 64 matrix whose rows 0..3 are a_src[l+1][h] . W_lin_{l+1} (head h) and rows 4..7 the same with a_tgt: the
+// next layer's attention scores (node_embedding.cc:235-268) come out of the same MFMA chain as the projection, already in the lanes
+// that store them (g = 0: ssrc, g = 1: stgt), instead of 32 multiply-adds and 16 cross-lane shuffles per lane.
+constexpr int GATR_LAYER_BYTES = 36 * 1024;
+struct GatResidentDev {
+    const uint8_t* layers;     // [5][GATR_LAYER_BYTES]
+    const float* scales;       // [3][5]: what undoes the power-of-two scale of W_skip, W_lin, score tile (device memory: a run-time
+                               // index into a kernel argument would go through scratch)
+    const float* a_src;        // [5][16 dim][4 head] (layer 0's scores)
+    const float* a_tgt;
+    const float* lin0;         // [16 dim][9][4 head]
+    const float* pool_w;       // [16]
+    const float* pool_b;
+    int* range_flag;
+};
+
+#define GATR_ABSMAX(v, a, b) asm("v_max3_f32 %0, |%1|, |%2|, %0" : "+v"(v) : "v"(a), "v"(b))
+
+__global__ __launch_bounds__(GATR_WAVES * 64, 4) void gat_resident_kernel(const int* __restrict__ node_feature, const int* __restrict__ feat_row,
+                                                                         const int* __restrict__ row_ptr, const int* __restrict__ src,
+                                                                         const int* __restrict__ tile_row, const int* __restrict__ tile_graph,
+                                                                         const int* __restrict__ node_off, float* __restrict__ out, int n_tiles,
+                                                                         GatResidentDev w, int ablate) {
+    __shared__ __attribute__((aligned(16))) char s_w[GATR_LAYER_BYTES];  // this layer's fragments
+    __shared__ __attribute__((aligned(16))) float4 s_proj[GATR_ROWS * 16];
+    __shared__ __attribute__((aligned(16))) float4 s_sc[GATR_ROWS * 2];
+    __shared__ __attribute__((aligned(16))) float4 s_lin0[GAT_D * ND_FEATURE];
+    __shared__ int s_feat[GATR_ROWS * ND_FEATURE];
+    __shared__ __attribute__((aligned(4))) uint8_t s_src[GATR_EDGES];
+    __shared__ uint16_t s_rp[GATR_ROWS + 2];
+    __shared__ float s_dot[GATR_ROWS];
+    __shared__ __attribute__((aligned(16))) float4 s_att[2 * GAT_D];  // a_src | a_tgt of layer 0 (heads in the float4)
+    __shared__ float s_pw[GAT_D];
+    constexpr int NT = GATR_WAVES * 64;
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int j = lane & 15, g = lane >> 4;
+    for (int i = threadIdx.x; i < GAT_D * ND_FEATURE; i += NT) s_lin0[i] = reinterpret_cast<const float4*>(w.lin0)[i];
+    if (threadIdx.x < 2 * GAT_D) s_att[threadIdx.x] = reinterpret_cast<const float4*>(threadIdx.x < GAT_D ? w.a_src : w.a_tgt)[threadIdx.x & (GAT_D - 1)];
+    if (threadIdx.x < GAT_D) s_pw[threadIdx.x] = w.pool_w[threadIdx.x];
+    float vmax = 0.0f;
+    const uint32_t sw_addr = lds_addr_of(s_w);
+    int tile = blockIdx.x;
+    if (tile >= n_tiles) return;
+    // ---- a tile's inputs travel through registers: requested during the previous tile's layers, stored to LDS when that tile is done
+    int fpre[3] = {0, 0, 0};  // feature words (256 rows x 9)
+    int spre[2] = {0, 0};     // CSR sources (row inside the tile)
+    int rpre = 0;             // row offsets
+    int t0 = tile_row[tile], rows = tile_row[tile + 1] - t0;
+    if (rows > GATR_ROWS) rows = GATR_ROWS;
+    int g0 = tile_graph[tile], g1 = tile_graph[tile + 1];
+    int e0 = row_ptr[t0], ne = row_ptr[t0 + rows] - e0;
+    if (ne > GATR_EDGES) ne = GATR_EDGES;  // cannot happen for a validated batch (the host packed by edge count)
+    auto fetch_tile = [&](int ft0, int frows, int fe0, int fne) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const int i = threadIdx.x + NT * k;
+            if (i < GATR_ROWS * ND_FEATURE) {
+                const int r = i / ND_FEATURE, c = i - r * ND_FEATURE;
+                const long long v = (long long)ft0 + (r < frows ? r : 0);
+                const long long row = feat_row ? (long long)feat_row[v] : v;
+                fpre[k] = node_feature[(size_t)row * ND_FEATURE + c];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            const int i = threadIdx.x + NT * k;
+            if (i < fne) spre[k] = src[fe0 + i] - ft0;
+        }
+        if ((int)threadIdx.x <= frows) {
+            const int o = row_ptr[ft0 + threadIdx.x] - fe0;
+            rpre = o < 0 ? 0 : (o > fne ? fne : o);
+        }
+    };
+    fetch_tile(t0, rows, e0, ne);
+    while (true) {
+        const int ntile = tile + gridDim.x;
+        const bool has_next = ntile < n_tiles;
+        int nt0 = 0, nrows = 0, ng0 = 0, ng1 = 0, ne0 = 0, nne = 0;
+        __syncthreads();  // the previous tile's readout has read s_dot; its LDS state is dead
+#pragma unroll
+        for (int k = 0; k < 3; k++)
+            if (threadIdx.x + NT * k < GATR_ROWS * ND_FEATURE) s_feat[threadIdx.x + NT * k] = fpre[k];
+#pragma unroll
+        for (int k = 0; k < 2; k++)
+            if ((int)threadIdx.x + NT * k < ne) s_src[threadIdx.x + NT * k] = (uint8_t)(spre[k] & 255);
+        if ((int)threadIdx.x <= rows) s_rp[threadIdx.x] = (uint16_t)rpre;
+        __syncthreads();
+        // ---- layer 0: proj_0 of (row, dim) from the row's nine features (load_inputs.cc:184-201), heads in the float4
+        {
+            int tid = threadIdx.x;
+            asm volatile("" : "+v"(tid));  // opaque per tile: this lane's nine W_lin0 rows must not stay in registers across the tile
+            const int d = tid & 15;
+            float4 wl[ND_FEATURE];
+#pragma unroll
+            for (int k = 0; k < ND_FEATURE; k++) wl[k] = s_lin0[d * ND_FEATURE + k];
+#pragma unroll
+            for (int k = 0; k < GATR_ROWS * GAT_D / NT; k++) {
+                const int r = (tid + NT * k) >> 4;
+                s_proj[r * 16 + ((d + r) & 15)] = gat_proj0(&s_feat[r * ND_FEATURE], wl);
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x < GATR_ROWS) {  // layer-0 scores, dims in ascending order (load_inputs.cc:203-224)
+            const int r = threadIdx.x;
+            float4 ss = make_float4(0.f, 0.f, 0.f, 0.f), st = ss;
+#pragma unroll
+            for (int d = 0; d < GAT_D; d++) {
+                const float4 pd = s_proj[r * 16 + ((d + r) & 15)];
+                gat_score_acc(ss, pd, s_att[d]);
+                gat_score_acc(st, pd, s_att[GAT_D + d]);
+            }
+            s_sc[r * 2 + 0] = ss;
+            s_sc[r * 2 + 1] = st;
+        }
+        const int r = wv * 16 + j;
+        const bool valid = r < rows;
+        const int rr = valid ? r : 0;  // rows past the tile's end repeat row 0's self edge (finite values, never used)
+        const int e_begin = valid ? (int)s_rp[r] : 0, e_end = valid && !(ablate & 1) ? (int)s_rp[r + 1] : e_begin;  // ablate: development aid (FLOWGNN_GAT_ABLATE)
+        // the skip input as split B operand; K-slot e of K-step ks <-> feature 16 (2 ks + (e >> 2)) + 4 g + (e & 3).  Layer 0: the raw
+        // features (dims 0..8 of head 0, load_inputs.cc:190-191); later o_{l-1}, whose split for the projection IS this operand
+        ds_uint4_t b_hi[2], b_lo[2];
+        {
+            float bq[16];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int d = 4 * q + g;
+                bq[4 * q + 0] = d < ND_FEATURE ? (float)s_feat[rr * ND_FEATURE + d] : 0.0f;
+                bq[4 * q + 1] = 0.0f; bq[4 * q + 2] = 0.0f; bq[4 * q + 3] = 0.0f;
+            }
+#pragma unroll
+            for (int ks = 0; ks < 2; ks++) {
+                DS_SPLIT2(bq[8 * ks + 0], bq[8 * ks + 1], b_hi[ks].x, b_lo[ks].x);
+                DS_SPLIT2(bq[8 * ks + 2], bq[8 * ks + 3], b_hi[ks].y, b_lo[ks].y);
+                DS_SPLIT2(bq[8 * ks + 4], bq[8 * ks + 5], b_hi[ks].z, b_lo[ks].z);
+                DS_SPLIT2(bq[8 * ks + 6], bq[8 * ks + 7], b_hi[ks].w, b_lo[ks].w);
+            }
+            GATR_ABSMAX(vmax, bq[0], bq[4]);
+            GATR_ABSMAX(vmax, bq[8], bq[12]);
+        }
+        __syncthreads();
+#pragma unroll 1
+        for (int l = 0; l < GAT_L; l++) {
+            // this layer's fragments stream in under the gather, which does not use them: 36 pieces of 1 KiB (last layer: W_skip only)
+            {
+                const int np = l == GAT_L - 1 ? 16 : 36;
+                const uint8_t* gl = w.layers + (size_t)l * GATR_LAYER_BYTES;
+#pragma unroll
+                for (int p = 0; p < 3; p++) {
+                    const int piece = wv + GATR_WAVES * p;
+                    if (piece < np) lds_dma16(gl + piece * 1024, (uint32_t)lane * 16u, sw_addr + piece * 1024);
+                }
+            }
+            if (l == 1 && has_next) {  // the next tile's descriptor (two dependent scalar round trips), used from layer 3 on
+                nt0 = tile_row[ntile];
+                nrows = tile_row[ntile + 1] - nt0;
+                if (nrows > GATR_ROWS) nrows = GATR_ROWS;
+                ng0 = tile_graph[ntile]; ng1 = tile_graph[ntile + 1];
+                ne0 = row_ptr[nt0];
+                nne = row_ptr[nt0 + nrows] - ne0;
+                if (nne > GATR_EDGES) nne = GATR_EDGES;
+            }
+            if (l == 3 && has_next) fetch_tile(nt0, nrows, ne0, nne);  // lands during the last two layers
+            // ---- attention gather (pull): self edge first, then the CSR row (ascending source); everything out of LDS
+            const float4 ssrc = s_sc[rr * 2 + 0];
+            float4 den = make_float4(0.f, 0.f, 0.f, 0.f);
+            float4 num[4];
+#pragma unroll
+            for (int t = 0; t < 4; t++) num[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+            {
+                int e = e_begin;
+                int u = rr;
+                int u_nx = e < e_end ? (int)s_src[e] : 0;
+                bool more = true;
+                while (__any(more)) {
+                    if (more) {
+                        const float4 st = s_sc[u * 2 + 1];
+                        float4 p[4];
+#pragma unroll
+                        for (int t = 0; t < 4; t++) p[t] = s_proj[u * 16 + ((4 * t + g + u) & 15)];
+                        more = e < e_end;
+                        u = u_nx;
+                        e++;
+                        if (e < e_end) u_nx = (int)s_src[e];
+                        float4 sv = make_float4(ssrc.x + st.x, ssrc.y + st.y, ssrc.z + st.z, ssrc.w + st.w);
+                        // leaky_0.2(x) = max(x, 0.2 x)
+                        sv.x = __expf(__builtin_fmaxf(sv.x, sv.x * 0.2f)); sv.y = __expf(__builtin_fmaxf(sv.y, sv.y * 0.2f));
+                        sv.z = __expf(__builtin_fmaxf(sv.z, sv.z * 0.2f)); sv.w = __expf(__builtin_fmaxf(sv.w, sv.w * 0.2f));
+                        den.x += sv.x; den.y += sv.y; den.z += sv.z; den.w += sv.w;
+#pragma unroll
+                        for (int t = 0; t < 4; t++) {
+                            num[t].x += sv.x * p[t].x; num[t].y += sv.y * p[t].y; num[t].z += sv.z * p[t].z; num[t].w += sv.w * p[t].w;
+                        }
+                    }
+                }
+            }
+            float4_t acc[4];  // rows 16 t + 4 g + r' = (dim 4 t + g, head r') of this lane's node
+            {   // msg = num / den: one v_rcp_f32 per head (1 ulp; sixteen IEEE divisions are ~160 dependent instructions per lane and layer)
+                const float4 rd = make_float4(__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y), __builtin_amdgcn_rcpf(den.z), __builtin_amdgcn_rcpf(den.w));
+#pragma unroll
+                for (int t = 0; t < 4; t++) acc[t] = (float4_t){num[t].x * rd.x, num[t].y * rd.y, num[t].z * rd.z, num[t].w * rd.w};
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();  // #1: every gather of this layer is done (s_proj / s_sc may be rewritten); the fragments have landed
+            const char* wb = s_w;
+            const float sk_scale = w.scales[l];
+            if (!(ablate & 2)) {
+#pragma unroll
+                for (int t = 0; t < 4; t++) {
+                    float4_t sk = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int ks = 0; ks < 2; ks++) {
+                        const ds_uint4_t a_hi = *reinterpret_cast<const ds_uint4_t*>(wb + ((t * 2 + ks) * 2 + 0) * 1024 + lane * 16);
+                        const ds_uint4_t a_lo = *reinterpret_cast<const ds_uint4_t*>(wb + ((t * 2 + ks) * 2 + 1) * 1024 + lane * 16);
+                        sk = DS_MFMA16(a_hi, b_hi[ks], sk);
+                        sk = DS_MFMA16(a_hi, b_lo[ks], sk);
+                        sk = DS_MFMA16(a_lo, b_hi[ks], sk);
+                    }
+                    acc[t] += sk * sk_scale;
+                }
+            }
+            if (l == GAT_L - 1) {
+                // emb[v][d] = mean_h(...)[d][h]; the logit is mean_v(emb[v]) . w + b = mean_v(emb[v] . w) + b (finalize.cc:46-112)
+                float part = 0.0f;
+#pragma unroll
+                for (int t = 0; t < 4; t++) part += (acc[t].x + acc[t].y + acc[t].z + acc[t].w) / (float)GAT_H * s_pw[4 * t + g];
+                part += __shfl_xor(part, 16, 64);
+                part += __shfl_xor(part, 32, 64);
+                if (g == 0) s_dot[r] = part;
+                break;
+            }
+            // ---- ELU; o_l split once: B operand of the projection now and of the next layer's skip contraction
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                acc[t].x = acc[t].x <= 0.f ? __expf(acc[t].x) - 1.0f : acc[t].x; acc[t].y = acc[t].y <= 0.f ? __expf(acc[t].y) - 1.0f : acc[t].y;
+                acc[t].z = acc[t].z <= 0.f ? __expf(acc[t].z) - 1.0f : acc[t].z; acc[t].w = acc[t].w <= 0.f ? __expf(acc[t].w) - 1.0f : acc[t].w;
+            }
+#pragma unroll
+            for (int ks = 0; ks < 2; ks++) {  // output tiles 2 ks, 2 ks + 1 of the skip contraction are K-step ks of the next two
+                DS_SPLIT2(acc[2 * ks].x, acc[2 * ks].y, b_hi[ks].x, b_lo[ks].x);
+                DS_SPLIT2(acc[2 * ks].z, acc[2 * ks].w, b_hi[ks].y, b_lo[ks].y);
+                DS_SPLIT2(acc[2 * ks + 1].x, acc[2 * ks + 1].y, b_hi[ks].z, b_lo[ks].z);
+                DS_SPLIT2(acc[2 * ks + 1].z, acc[2 * ks + 1].w, b_hi[ks].w, b_lo[ks].w);
+            }
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                GATR_ABSMAX(vmax, acc[t].x, acc[t].y);
+                GATR_ABSMAX(vmax, acc[t].z, acc[t].w);
+            }
+            // ---- next projection and next scores (five output tiles of one MFMA chain)
+            float4_t pr[5];
+#pragma unroll
+            for (int t2 = 0; t2 < 5; t2++) pr[t2] = (float4_t){0.f, 0.f, 0.f, 0.f};
+            if (!(ablate & 2)) {
+#pragma unroll
+                for (int t2 = 0; t2 < 5; t2++) {
+#pragma unroll
+                    for (int ks = 0; ks < 2; ks++) {
+                        const ds_uint4_t a_hi = *reinterpret_cast<const ds_uint4_t*>(wb + 16384 + ((t2 * 2 + ks) * 2 + 0) * 1024 + lane * 16);
+                        const ds_uint4_t a_lo = *reinterpret_cast<const ds_uint4_t*>(wb + 16384 + ((t2 * 2 + ks) * 2 + 1) * 1024 + lane * 16);
+                        pr[t2] = DS_MFMA16(a_hi, b_hi[ks], pr[t2]);
+                        pr[t2] = DS_MFMA16(a_hi, b_lo[ks], pr[t2]);
+                        pr[t2] = DS_MFMA16(a_lo, b_hi[ks], pr[t2]);
+                    }
+                }
+            }
+            const float lin_scale = w.scales[GAT_L + l], sc_scale = w.scales[2 * GAT_L + l];
+#pragma unroll
+            for (int t2 = 0; t2 < 4; t2++)
+                s_proj[r * 16 + ((4 * t2 + g + r) & 15)] = make_float4(pr[t2].x * lin_scale, pr[t2].y * lin_scale, pr[t2].z * lin_scale, pr[t2].w * lin_scale);
+            if (g < 2) s_sc[r * 2 + g] = make_float4(pr[4].x * sc_scale, pr[4].y * sc_scale, pr[4].z * sc_scale, pr[4].w * sc_scale);
+            __syncthreads();  // #2: the next layer's projections and scores are complete
+        }
+        __syncthreads();  // the per-node readout terms are in s_dot
+        {
+            const int gi = g0 + (int)threadIdx.x;
+            if (gi < g1) {
+                const int n0 = node_off[gi], n1 = node_off[gi + 1];
+                float sum = 0.0f;
+                for (int v = n0; v < n1; v++) sum += s_dot[v - t0];
+                out[gi] = sum / (float)(n1 - n0) + w.pool_b[0];
+            }
+        }
+        if (!has_next) break;
+        tile = ntile; t0 = nt0; rows = nrows; g0 = ng0; g1 = ng1; e0 = ne0; ne = nne;
+    }
+    if (__any(!(vmax < 6.0e4f))) {
+        if (lane == 0) atomicOr(w.range_flag, 1);
+    }
+}
+#undef GATR_ABSMAX
+
 class GatModel : public Model {
 public:
     ~GatModel() override { free_all(); }
@@ -546,6 +854,47 @@ public:
         std::vector<float> v_pw(t[4], t[4] + GAT_D), v_pb(t[5], t[5] + 1);
         int rc;
         if ((rc = upload(&d_wskip_s_, wskip_s))) return rc;
+        {   // the graph-resident kernel's per-layer stream (GATR_LAYER_BYTES): W_skip | W_lin | score tile
+            std::vector<uint8_t> res((size_t)GAT_L * GATR_LAYER_BYTES, 0);
+            std::vector<float> sc(3 * GAT_L, 1.0f);
+            for (int l = 0; l < GAT_L; l++) {
+                uint8_t* base = res.data() + (size_t)l * GATR_LAYER_BYTES;
+                std::memcpy(base, &wskip_s[(size_t)l * 4096], 16384);
+                std::memcpy(base + 16384, &wlin_s[(size_t)l * 4096], 16384);
+                sc[l] = wskip_scale_[l];
+                sc[GAT_L + l] = wlin_scale_[l];
+                if (l + 1 >= GAT_L) continue;
+                // score tile: row h = a_src[l+1][h] . W_lin_{l+1} restricted to head h's outputs, row 4 + h the same with a_tgt
+                double S[16][64] = {};
+                double mx = 0.0;
+                for (int i = 0; i < 8; i++) {
+                    const int h = i & 3;
+                    const float* av = (i < 4 ? srcw : tgt) + ((size_t)(l + 1) * GAT_H + h) * GAT_D;
+                    for (int fi = 0; fi < 64; fi++) {
+                        double a = 0.0;
+                        for (int d = 0; d < GAT_D; d++) a += (double)av[d] * (double)M(lin, l + 1, d * 4 + h, fi);
+                        S[i][fi] = a;
+                        mx = std::fmax(mx, std::fabs(a));
+                    }
+                }
+                const double scl = (mx > 0.0 && std::isfinite(mx)) ? std::ldexp(1.0, -std::ilogb(mx)) : 1.0;
+                sc[2 * GAT_L + l] = (float)(1.0 / scl);
+                uint8_t* outp = base + 32768;
+                for (int ks = 0; ks < 2; ks++)
+                    for (int lane = 0; lane < 64; lane++)
+                        for (int e = 0; e < 8; e++) {
+                            const int i = lane & 15, gk = lane >> 4;
+                            const float v = (float)(S[i][16 * (2 * ks + (e >> 2)) + 4 * gk + (e & 3)] * scl);
+                            const _Float16 hi = (_Float16)v;
+                            const _Float16 lo = (_Float16)(v - (float)hi);
+                            uint8_t* f = outp + (size_t)(ks * 2) * 1024 + lane * 16 + e * 2;
+                            std::memcpy(f, &hi, 2);
+                            std::memcpy(f + 1024, &lo, 2);
+                        }
+            }
+            if ((rc = upload(&d_scales_, sc))) return rc;
+            if ((rc = upload(&d_res_, res))) return rc;
+        }
         if ((rc = upload(&d_wlin_s_, wlin_s))) return rc;
         if ((rc = upload(&d_lin0_, lin0))) return rc;
         if ((rc = upload(&d_asrc_, asrc))) return rc;
@@ -584,6 +933,13 @@ public:
         return set_weights(t);
     }
 
+    // graph-resident kernel (gat_resident_kernel): whole graphs packed into tiles of <= 256 rows / 1 280 in-edges by flowgnn_set_batch
+    void graph_tile_limits(int& rows, int& edges) const override {
+        rows = resident_ ? GATR_ROWS : 0;
+        edges = resident_ ? GATR_EDGES : 0;
+    }
+    void set_keep_h(bool on) override { keep_h_ = on; }
+
     int forward(DeviceBatch& db, Profiler& prof, hipStream_t s) override {
         const int n = db.b.n_tot;
         if (n <= 0) return 0;
@@ -598,6 +954,28 @@ public:
             gat_local_rows_kernel<<<(db.b.num_graphs + 3) / 4, 256, 0, s>>>(db.b.node_off, feat_row, db.b.num_graphs);
         }
         if (qmode_) return gatq_forward(q_, db, feat_row, prof, s);
+        // all five layers in one launch when the batch packs into graph tiles (tiles under half full, e.g. graphs of 65..128
+        // nodes, waste MFMA columns: the per-layer kernels take those); per-node taps (flowgnn_get_h) come from the per-layer path
+        if (resident_ && !keep_h_ && fold_readout_ && split_ && !exact_ && db.gtiles.ok && db.gtiles.n_tiles > 0 && db.gtiles.fill >= 0.5) {
+            GatResidentDev rw;
+            rw.layers = d_res_;
+            rw.scales = d_scales_;
+            rw.a_src = d_asrc_;
+            rw.a_tgt = d_atgt_;
+            rw.lin0 = d_lin0_;
+            rw.pool_w = d_pw_;
+            rw.pool_b = d_pb_;
+            rw.range_flag = db.range_flag;
+            ProfScope p(prof, "gat_resident", s);
+            const int grid = db.gtiles.n_tiles < 256 ? db.gtiles.n_tiles : 256;  // persistent: one 16-wave workgroup per CU (118 KB of LDS)
+            gat_resident_kernel<<<grid, GATR_WAVES * 64, 0, s>>>(db.b.node_feature, feat_row, db.csr.row_ptr, db.csr.src, db.gtiles.row_start,
+                                                               db.gtiles.graph_start, db.b.node_off, db.out, db.gtiles.n_tiles, rw,
+                                                               getenv("FLOWGNN_GAT_ABLATE") ? atoi(getenv("FLOWGNN_GAT_ABLATE")) : 0);
+            db.final_h = 0;
+            db.tap = nullptr;
+            db.h_valid = false;  // no per-node tensor leaves the kernel: flowgnn_get_h repeats the pass on the per-layer kernels
+            return 0;
+        }
         const GatLayer0Dev w0{d_lin0_, d_asrc_, d_atgt_};
         {
             ProfScope p(prof, "gat_scores0", s);
@@ -657,9 +1035,10 @@ public:
 
 private:
     void free_all() {
-        float** ptrs[] = {&d_lin0_, &d_asrc_, &d_atgt_, &d_wskip_, &d_wlin_, &d_pw_, &d_pb_, &d_wskip_s_, &d_wlin_s_};
+        float** ptrs[] = {&d_lin0_, &d_asrc_, &d_atgt_, &d_wskip_, &d_wlin_, &d_pw_, &d_pb_, &d_wskip_s_, &d_wlin_s_, &d_scales_};
         for (auto p : ptrs)
             if (*p) { (void)hipFree(*p); *p = nullptr; }
+        if (d_res_) { (void)hipFree(d_res_); d_res_ = nullptr; }
         q_.release();
     }
     bool ready_ = false;
@@ -670,8 +1049,11 @@ private:
     bool split_ = !(getenv("FLOWGNN_GAT_MFMA") && strcmp(getenv("FLOWGNN_GAT_MFMA"), "f32") == 0);
     bool exact_ = false;
     float wskip_scale_[GAT_L] = {}, wlin_scale_[GAT_L] = {};
-    float *d_wskip_s_ = nullptr, *d_wlin_s_ = nullptr;
+    float *d_wskip_s_ = nullptr, *d_wlin_s_ = nullptr, *d_scales_ = nullptr;
+    uint8_t* d_res_ = nullptr;  // per-layer fragment stream of gat_resident_kernel
     bool fold_readout_ = !(getenv("FLOWGNN_GAT_FOLD_READOUT") && atoi(getenv("FLOWGNN_GAT_FOLD_READOUT")) == 0);
+    bool resident_ = !(getenv("FLOWGNN_GAT_RESIDENT") && atoi(getenv("FLOWGNN_GAT_RESIDENT")) == 0);
+    bool keep_h_ = false;
     float *d_lin0_ = nullptr, *d_asrc_ = nullptr, *d_atgt_ = nullptr, *d_wskip_ = nullptr, *d_wlin_ = nullptr, *d_pw_ = nullptr,
           *d_pb_ = nullptr;
 };
