@@ -323,6 +323,229 @@ __global__ __launch_bounds__(512) void gcn_layer_fused_kernel(const float* __res
     }
 }
 
+// ---------------------------------------------------------------- graph-resident GCN: the five aggregations + four dense layers + readout in ONE launch
+// The counterpart of gin_resident_kernel (gin_split.hip) and of the FPGA keeping one graph in BRAM across its layer loop
+// (GCN/src/GCN_compute.cc): a persistent 12-wave workgroup (one per CU) owns a tile of WHOLE graphs (GraphTiles: <= 192 rows,
+// <= 960 in-edges) and keeps the tile's x rows in LDS across all layers:
+//   * x_l never goes to HBM between layers: the gather reads neighbour rows from LDS, the dense layer writes x_{l+1} in place;
+//   * the tile's CSR slice is staged once per tile as 16-bit words (row inside the tile << 6 | edge code); dinv and 1 / (deg + 1)
+//     of the tile's rows are computed once per tile, so the per-edge norm is two LDS reads and a multiply;
+//   * the two weight regions are never needed at the same time: W_{l+1} (45 KiB of split fragments) streams L2 -> LDS while gather l
+//     runs, the next layer's edge-embedding table + epilogue vectors (25 KiB) while dense l + 1 runs;
+//   * per node the launch reads 400 B (x_0, from gcn_encoder_dense_kernel) + 5 B per in-edge + 8 B of row bounds / degree, and
+//     writes 4 B per GRAPH.
+// LDS: 76 800 (rows) + 46 080 (W) + 25 600 (table + epilogue) + 1 920 (edges) + ~2 700 = 153 KB.
+constexpr int GCNR_ROWS = 192;
+constexpr int GCNR_EDGES = 960;
+constexpr int GCNR_WAVES = 12;
+constexpr int GCNR_W_BYTES = 45 * 1024;     // dense100_split_bytes(GCN_OT) = 45 264, padded to whole 1 KiB DMA pieces
+constexpr int GCNR_BLOB_BYTES = 25 * 1024;  // ecomb [60][100] | root | BN scale | BN shift (25 200 B)
+constexpr int GCNR_LAYER_BYTES = GCNR_W_BYTES + GCNR_BLOB_BYTES;
+static_assert(dense100_split_bytes(GCN_OT) <= (size_t)GCNR_W_BYTES, "weight region");
+static_assert((EDGE_COMBOS + 3) * GCN_D * 4 <= GCNR_BLOB_BYTES, "table region");
+
+__global__ __launch_bounds__(GCNR_WAVES * 64, 3) void gcn_resident_kernel(const float* __restrict__ x0, const int* __restrict__ row_ptr,
+                                                                         const int* __restrict__ src, const uint8_t* __restrict__ ecode,
+                                                                         const int* __restrict__ out_deg, const uint8_t* __restrict__ layers,
+                                                                         const float* __restrict__ pool_w, const float* __restrict__ pool_b,
+                                                                         const int* __restrict__ tile_row, const int* __restrict__ tile_graph,
+                                                                         const int* __restrict__ node_off, float* __restrict__ out, int n_tiles,
+                                                                         int* __restrict__ range_flag) {
+    constexpr int OT = GCN_OT, NT = GCNR_WAVES * 64;
+    constexpr int TAIL_OFF = OT * 6 * 1024, BIAS_OFF = TAIL_OFF + OT * 256, SCALE_OFF = BIAS_OFF + OT * 64;
+    __shared__ __attribute__((aligned(16))) float s_x[GCNR_ROWS * GCN_D + 256];  // + slack: the last DMA piece of a tile may run past its rows
+    __shared__ __attribute__((aligned(16))) char s_w[GCNR_W_BYTES];
+    __shared__ __attribute__((aligned(16))) char s_blob[GCNR_BLOB_BYTES];
+    __shared__ uint16_t s_edge[GCNR_EDGES];
+    __shared__ uint16_t s_rp[GCNR_ROWS + 2];
+    __shared__ float s_dinv[GCNR_ROWS], s_idp1[GCNR_ROWS], s_dot[GCNR_ROWS];
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int j = lane & 15, g = lane >> 4;
+    const float* s_ecomb = reinterpret_cast<const float*>(s_blob);
+    const float* s_ep = s_ecomb + EDGE_COMBOS * GCN_D;
+    const uint32_t x_addr = lds_addr_of(s_x), w_addr = lds_addr_of(s_w), blob_addr = lds_addr_of(s_blob);
+    float vmax = 0.0f;
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int t0 = tile_row[tile];
+        int rows = tile_row[tile + 1] - t0;
+        if (rows > GCNR_ROWS) rows = GCNR_ROWS;
+        const int g0 = tile_graph[tile], g1 = tile_graph[tile + 1];
+        const int e0 = row_ptr[t0];
+        int ne = row_ptr[t0 + rows] - e0;
+        if (ne > GCNR_EDGES) ne = GCNR_EDGES;  // cannot happen for a validated batch (the host packed by edge count)
+        __syncthreads();  // the previous tile's readout has read s_dot; its rows are dead
+        // ---- stage the tile: rows of x_0 and layer 0's table by LDS-DMA, the CSR slice and the degree scalars through registers
+        {
+            const int np = (rows * (GCN_D * 4) + 1023) >> 10;  // <= 75 pieces of 1 KiB
+            const char* gb = reinterpret_cast<const char*>(x0) + (size_t)t0 * (GCN_D * 4);
+#pragma unroll
+            for (int p = 0; p < 7; p++) {
+                const int piece = wv + GCNR_WAVES * p;
+                if (piece < np) lds_dma16(gb + (size_t)piece * 1024, (uint32_t)lane * 16u, x_addr + piece * 1024);
+            }
+#pragma unroll
+            for (int p = 0; p < 3; p++) {
+                const int piece = wv + GCNR_WAVES * p;
+                if (piece < GCNR_BLOB_BYTES / 1024) lds_dma16(layers + GCNR_W_BYTES + piece * 1024, (uint32_t)lane * 16u, blob_addr + piece * 1024);
+            }
+        }
+        for (int i = threadIdx.x; i < ne; i += NT) s_edge[i] = (uint16_t)((((src[e0 + i] - t0) & 255) << 6) | (ecode[e0 + i] & 63));
+        if ((int)threadIdx.x <= rows) {
+            const int o = row_ptr[t0 + threadIdx.x] - e0;
+            s_rp[threadIdx.x] = (uint16_t)(o < 0 ? 0 : (o > ne ? ne : o));
+        }
+        if ((int)threadIdx.x < rows) {
+            const int d = out_deg[t0 + threadIdx.x];
+            s_dinv[threadIdx.x] = d > 0 ? 1.0f / sqrtf((float)(d + 1)) : 0.0f;  // load_inputs.cc:122
+            s_idp1[threadIdx.x] = 1.0f / (float)(d + 1);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const int r = wv * 16 + j;
+        const bool valid = r < rows;
+        const int rr = valid ? r : 0;  // rows past the tile's end repeat row 0 without in-edges (finite values, never stored)
+        const int e_begin = valid ? (int)s_rp[r] : 0, e_end = valid ? (int)s_rp[r + 1] : 0;
+        const float dinv_v = s_dinv[rr], idp1 = s_idp1[rr];
+#pragma unroll 1
+        for (int l = 0; l < GCN_L; l++) {
+            if (l + 1 < GCN_L) {  // W_{l+1} streams in under this layer's gather (45 pieces)
+                const uint8_t* gw = layers + (size_t)(l + 1) * GCNR_LAYER_BYTES;
+#pragma unroll
+                for (int p = 0; p < 4; p++) {
+                    const int piece = wv + GCNR_WAVES * p;
+                    if (piece < GCNR_W_BYTES / 1024) lds_dma16(gw + piece * 1024, (uint32_t)lane * 16u, w_addr + piece * 1024);
+                }
+            }
+            // ---- m_l[v] = sum over in-edges of norm relu(x_l[u] + ecomb[code]) (message_passing.cc:158-167), CSR order, all from LDS
+            const float* xr = s_x + rr * GCN_D + 4 * g;
+            float4 xs[6];
+#pragma unroll
+            for (int q = 0; q < 6; q++) xs[q] = *reinterpret_cast<const float4*>(xr + 16 * q);
+            const float xst = s_x[rr * GCN_D + 96 + g];
+            float m[25];
+#pragma unroll
+            for (int k = 0; k < 25; k++) m[k] = 0.0f;
+            {
+                int e = e_begin;
+                int w_nx = e < e_end ? (int)s_edge[e] : 0;
+                while (__any(e < e_end)) {
+                    if (e < e_end) {
+                        const int u = w_nx >> 6, code = w_nx & 63;
+                        e++;
+                        if (e < e_end) w_nx = (int)s_edge[e];
+                        const float norm = s_dinv[u] * dinv_v;
+                        const float* hr = s_x + u * GCN_D + 4 * g;
+                        const float* er = s_ecomb + code * GCN_D + 4 * g;
+                        float4 xv[6];
+#pragma unroll
+                        for (int q = 0; q < 6; q++) xv[q] = *reinterpret_cast<const float4*>(hr + 16 * q);
+                        const float xt = s_x[u * GCN_D + 96 + g];
+#pragma unroll
+                        for (int q = 0; q < 6; q++) {
+                            const float4 w = *reinterpret_cast<const float4*>(er + 16 * q);
+                            m[4 * q + 0] += norm * relu1(w.x + xv[q].x);
+                            m[4 * q + 1] += norm * relu1(w.y + xv[q].y);
+                            m[4 * q + 2] += norm * relu1(w.z + xv[q].z);
+                            m[4 * q + 3] += norm * relu1(w.w + xv[q].w);
+                        }
+                        m[24] += norm * relu1(s_ecomb[code * GCN_D + 96 + g] + xt);
+                    }
+                }
+            }
+            // ---- a_{l+1} = BN_l(m_l + relu(x_l + root_l) / (deg + 1))   (node_embedding.cc:123-138); folded BatchNorm
+            float a[25];
+#pragma unroll
+            for (int q = 0; q < 6; q++) {
+                const float4 rt = *reinterpret_cast<const float4*>(s_ep + 16 * q + 4 * g);
+                const float4 sc = *reinterpret_cast<const float4*>(s_ep + GCN_D + 16 * q + 4 * g);
+                const float4 sh = *reinterpret_cast<const float4*>(s_ep + 2 * GCN_D + 16 * q + 4 * g);
+                a[4 * q + 0] = (m[4 * q + 0] + relu1(xs[q].x + rt.x) * idp1) * sc.x + sh.x;
+                a[4 * q + 1] = (m[4 * q + 1] + relu1(xs[q].y + rt.y) * idp1) * sc.y + sh.y;
+                a[4 * q + 2] = (m[4 * q + 2] + relu1(xs[q].z + rt.z) * idp1) * sc.z + sh.z;
+                a[4 * q + 3] = (m[4 * q + 3] + relu1(xs[q].w + rt.w) * idp1) * sc.w + sh.w;
+            }
+            a[24] = (m[24] + relu1(xst + s_ep[96 + g]) * idp1) * s_ep[GCN_D + 96 + g] + s_ep[2 * GCN_D + 96 + g];
+            if (l == GCN_L - 1) {
+                // no ReLU after the last BatchNorm; the readout's linear head per node (mean_v(a[v]) . w = mean_v(a[v] . w),
+                // finalize.cc:79-113): 25 terms in the lane, then the node's 4 lanes
+                float part = 0.0f;
+#pragma unroll
+                for (int q = 0; q < 6; q++) {
+                    const float4 pw = *reinterpret_cast<const float4*>(pool_w + 16 * q + 4 * g);
+                    part += a[4 * q + 0] * pw.x; part += a[4 * q + 1] * pw.y; part += a[4 * q + 2] * pw.z; part += a[4 * q + 3] * pw.w;
+                }
+                part += a[24] * pool_w[96 + g];
+                part += __shfl_xor(part, 16, 64);
+                part += __shfl_xor(part, 32, 64);
+                if (g == 0) s_dot[r] = part;
+                break;
+            }
+#pragma unroll
+            for (int k = 0; k < 25; k++) a[k] = relu1(a[k]);
+            ds_uint4_t b_hi[3], b_lo[3];
+#pragma unroll
+            for (int ks = 0; ks < 3; ks++) {
+                DS_SPLIT2(a[8 * ks + 0], a[8 * ks + 1], b_hi[ks].x, b_lo[ks].x);
+                DS_SPLIT2(a[8 * ks + 2], a[8 * ks + 3], b_hi[ks].y, b_lo[ks].y);
+                DS_SPLIT2(a[8 * ks + 4], a[8 * ks + 5], b_hi[ks].z, b_lo[ks].z);
+                DS_SPLIT2(a[8 * ks + 6], a[8 * ks + 7], b_hi[ks].w, b_lo[ks].w);
+            }
+#pragma unroll
+            for (int k = 0; k < 24; k += 2) vmax = __builtin_fmaxf(__builtin_fmaxf(vmax, a[k]), a[k + 1]);  // a >= 0 (ReLU)
+            asm volatile("" : "+v"(vmax));
+            const float a24 = a[24];
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();  // #1: every gather of this layer is done (rows may be rewritten, the table replaced); W_{l+1} has landed
+            {   // the next layer's table + epilogue vectors stream in under the dense layer
+                const uint8_t* gbl = layers + (size_t)(l + 1) * GCNR_LAYER_BYTES + GCNR_W_BYTES;
+#pragma unroll
+                for (int p = 0; p < 3; p++) {
+                    const int piece = wv + GCNR_WAVES * p;
+                    if (piece < GCNR_BLOB_BYTES / 1024) lds_dma16(gbl + piece * 1024, (uint32_t)lane * 16u, blob_addr + piece * 1024);
+                }
+            }
+            // ---- x_{l+1} = b + W a on the f16 matrix pipe (split products, dense_split.h), written over the wave's own rows
+            const float oscale = *reinterpret_cast<const float*>(s_w + SCALE_OFF);
+#pragma unroll
+            for (int t = 0; t < OT; t++) {
+                const float4 bv = *reinterpret_cast<const float4*>(s_w + BIAS_OFF + (16 * t + 4 * g) * 4);
+                float4_t acc = {bv.x, bv.y, bv.z, bv.w};
+#pragma unroll
+                for (int ks = 0; ks < 3; ks++) {
+                    const ds_uint4_t a_hi = *reinterpret_cast<const ds_uint4_t*>(s_w + ((t * 3 + ks) * 2 + 0) * 1024 + lane * 16);
+                    const ds_uint4_t a_lo = *reinterpret_cast<const ds_uint4_t*>(s_w + ((t * 3 + ks) * 2 + 1) * 1024 + lane * 16);
+                    acc = DS_MFMA16(a_hi, b_hi[ks], acc);
+                    acc = DS_MFMA16(a_hi, b_lo[ks], acc);
+                    acc = DS_MFMA16(a_lo, b_hi[ks], acc);
+                }
+                const float at = *reinterpret_cast<const float*>(s_w + TAIL_OFF + t * 256 + lane * 4);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(at, a24, acc, 0, 0, 0);
+                const int col = 16 * t + 4 * g;
+                if (col < GCN_D && valid) {
+                    const float4_t o = acc * oscale;
+                    *reinterpret_cast<float4*>(s_x + r * GCN_D + col) = make_float4(o.x, o.y, o.z, o.w);
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();  // #2: x_{l+1} is complete, the next table has landed
+        }
+        __syncthreads();  // the per-node readout terms are in s_dot
+        {
+            const int gi = g0 + (int)threadIdx.x;
+            if (gi < g1) {
+                const int n0 = node_off[gi], n1 = node_off[gi + 1];
+                float sum = 0.0f;
+                for (int v = n0; v < n1; v++) sum += s_dot[v - t0];
+                out[gi] = sum / (float)(n1 - n0) + pool_b[0];
+            }
+        }
+    }
+    if (__any(!(vmax < 6.0e4f))) {
+        if (lane == 0) atomicOr(range_flag, 1);
+    }
+}
+
 class GcnModel : public Model {
 public:
     ~GcnModel() override { free_all(); }
@@ -385,6 +608,16 @@ public:
             pack_dense100_split(cw + (size_t)l * GCN_D * GCN_D, cb + (size_t)l * GCN_D, GCN_D, GCN_OT, split_all.data() + off);
         }
         int rc;
+        {   // the graph-resident kernel's per-layer stream: [W_l split fragments, 45 KiB][ecomb_l | root_l | BN scale_l | BN shift_l, 25 KiB]
+            std::vector<uint8_t> res((size_t)GCN_L * GCNR_LAYER_BYTES + 4096, 0);
+            for (int l = 0; l < GCN_L; l++) {
+                uint8_t* base = res.data() + (size_t)l * GCNR_LAYER_BYTES;
+                std::memcpy(base, split_all.data() + (size_t)l * dense100_split_bytes(GCN_OT), dense100_split_bytes(GCN_OT));
+                std::memcpy(base + GCNR_W_BYTES, &ecomb[(size_t)l * EDGE_COMBOS * GCN_D], sizeof(float) * EDGE_COMBOS * GCN_D);
+                std::memcpy(base + GCNR_W_BYTES + sizeof(float) * EDGE_COMBOS * GCN_D, &ep[(size_t)l * 3 * GCN_D], sizeof(float) * 3 * GCN_D);
+            }
+            if ((rc = upload(&d_res_, res))) return rc;
+        }
         if ((rc = upload(&d_split_, split_all))) return rc;
         if ((rc = upload(&d_nemb_, v_nemb))) return rc;
         if ((rc = upload(&d_pw_, v_pw))) return rc;
@@ -448,17 +681,51 @@ public:
             GCN_D);
     }
 
-    int forward(DeviceBatch& db, Profiler& prof, hipStream_t s) override {
-        const int n = db.b.n_tot;
-        if (n <= 0) return 0;
-        if (qmode_) return gcnq_forward(q_, db, prof, s);
-        if (int rc = make_tile_bounds(tiles_, db.b.node_off, db.b.num_graphs, n, tile_nominal_, tile_slack_, s)) return rc;
-        if (db.b.e_tot > 0) {  // dinv[src_e] per CSR entry, once per pass
+    // row tiles + dinv[src_e] per CSR entry for the per-layer kernels, once per batch pass
+    int prepare_aggregate(DeviceBatch& db, Profiler& prof, hipStream_t s) {
+        if (int rc = make_tile_bounds(tiles_, db.b.node_off, db.b.num_graphs, db.b.n_tot, tile_nominal_, tile_slack_, s)) return rc;
+        if (db.b.e_tot > 0) {
             if (int rc = esc_.reserve((size_t)db.b.e_tot)) return rc;
             ProfScope p(prof, "edge_scalar", s);
             typename GcnAggPolicy<true>::Params prm{db.csr.out_deg, nullptr, nullptr};
             edge_scalar_kernel<GcnAggPolicy<true>><<<grid_for(db.b.e_tot, 256, 256 * 8), 256, 0, s>>>(prm, db.csr.src, esc_.p, db.b.e_tot);
         }
+        agg_ready_ = true;
+        return 0;
+    }
+
+    // graph-resident kernel (gcn_resident_kernel): whole graphs packed into tiles of <= 192 rows / 960 in-edges by flowgnn_set_batch
+    void graph_tile_limits(int& rows, int& edges) const override {
+        rows = resident_ ? GCNR_ROWS : 0;
+        edges = resident_ ? GCNR_EDGES : 0;
+    }
+    void set_keep_h(bool on) override { keep_h_ = on; }
+
+    int forward(DeviceBatch& db, Profiler& prof, hipStream_t s) override {
+        const int n = db.b.n_tot;
+        if (n <= 0) return 0;
+        if (qmode_) return gcnq_forward(q_, db, prof, s);
+        // x_0 by the encoder + dense kernel, then everything else in one launch when the batch packs into graph tiles (tiles under
+        // half full waste MFMA columns: the per-layer kernels take those; so do per-node taps and the multi-task readout)
+        if (resident_ && !keep_h_ && split_ && !exact_ && fused_ && num_tasks_ == 1 && db.gtiles.ok && db.gtiles.n_tiles > 0 &&
+            db.gtiles.fill >= 0.5) {
+            {
+                ProfScope p(prof, "gcn_encoder_dense", s);
+                const long long wgs = ceil_div_ll(n, 256);
+                gcn_encoder_dense_kernel<<<(int)(wgs < 256 ? wgs : 256), 1024, 0, s>>>(db.b.node_feature, d_nemb_, db.h[0], d_split_, n,
+                                                                                       db.csr.err, db.range_flag);
+            }
+            ProfScope p(prof, "gcn_resident", s);
+            const int grid = db.gtiles.n_tiles < 256 ? db.gtiles.n_tiles : 256;  // persistent: one 12-wave workgroup per CU (153 KB of LDS)
+            gcn_resident_kernel<<<grid, GCNR_WAVES * 64, 0, s>>>(db.h[0], db.csr.row_ptr, db.csr.src, db.csr.ecode, db.csr.out_deg, d_res_, d_pw_,
+                                                               d_pb_, db.gtiles.row_start, db.gtiles.graph_start, db.b.node_off, db.out,
+                                                               db.gtiles.n_tiles, db.range_flag);
+            agg_ready_ = false;
+            db.final_h = 0;
+            db.h_valid = false;  // h[0] holds x_0, not x_4: flowgnn_get_h repeats the pass on the per-layer kernels
+            return 0;
+        }
+        if (int rc = prepare_aggregate(db, prof, s)) return rc;
         int cur = 0;
         if (split_ && !exact_ && fused_) {
             ProfScope p(prof, "gcn_encoder_dense", s);  // x_0 = W_0 (atom encoder) + b_0 in one kernel
@@ -496,6 +763,7 @@ public:
             cur ^= 1;
         }
         db.final_h = cur;
+        db.h_valid = true;
         if (split_ && !exact_ && fused_ && db.b.e_tot > 0 && num_tasks_ == 1) {
             // last stage: aggregation + BatchNorm with the readout's linear head folded in (per-node scores in db.scratch;
             // flowgnn_get_h returns x_4 = db.h[final_h], which is untouched by this)
@@ -539,6 +807,10 @@ public:
 
     int aggregation_only(DeviceBatch& db, int layer, hipStream_t s) override {
         if (layer < 0 || layer >= GCN_L) return 1;
+        if (!agg_ready_) {  // the last forward ran the graph-resident kernel
+            Profiler none;
+            if (int rc = prepare_aggregate(db, none, s)) return rc;
+        }
         launch_aggregate<true>(db, layer, db.h[db.final_h], db.scratch, s);
         return 0;
     }
@@ -549,6 +821,7 @@ private:
         for (auto p : ptrs)
             if (*p) { (void)hipFree(*p); *p = nullptr; }
         if (d_split_) { (void)hipFree(d_split_); d_split_ = nullptr; }
+        if (d_res_) { (void)hipFree(d_res_); d_res_ = nullptr; }
         esc_.release();
         tiles_.release();
         q_.release();
@@ -568,6 +841,10 @@ private:
     // FLOWGNN_GCN_UNFUSED=1 keeps aggregate and dense as two kernels per layer (A/B measurements)
     bool fused_ = !(getenv("FLOWGNN_GCN_UNFUSED") && atoi(getenv("FLOWGNN_GCN_UNFUSED")) != 0);
     uint8_t* d_split_ = nullptr;
+    uint8_t* d_res_ = nullptr;  // per-layer stream of gcn_resident_kernel
+    bool resident_ = !(getenv("FLOWGNN_GCN_RESIDENT") && atoi(getenv("FLOWGNN_GCN_RESIDENT")) == 0);
+    bool keep_h_ = false;
+    bool agg_ready_ = false;  // tiles_ / esc_ describe the batch of the last forward
     float *d_nemb_ = nullptr, *d_pw_ = nullptr, *d_pb_ = nullptr, *d_ecomb_ = nullptr, *d_ep_ = nullptr, *d_wf_ = nullptr,
           *d_wt_ = nullptr, *d_bp_ = nullptr;
 };
