@@ -350,7 +350,7 @@ __global__ __launch_bounds__(GCNR_WAVES * 64, 3) void gcn_resident_kernel(const 
                                                                          const float* __restrict__ pool_w, const float* __restrict__ pool_b,
                                                                          const int* __restrict__ tile_row, const int* __restrict__ tile_graph,
                                                                          const int* __restrict__ node_off, float* __restrict__ out, int n_tiles,
-                                                                         int* __restrict__ range_flag) {
+                                                                         int* __restrict__ range_flag, int ablate) {
     constexpr int OT = GCN_OT, NT = GCNR_WAVES * 64;
     constexpr int TAIL_OFF = OT * 6 * 1024, BIAS_OFF = TAIL_OFF + OT * 256, SCALE_OFF = BIAS_OFF + OT * 64;
     __shared__ __attribute__((aligned(16))) float s_x[GCNR_ROWS * GCN_D + 256];  // + slack: the last DMA piece of a tile may run past its rows
@@ -366,49 +366,72 @@ __global__ __launch_bounds__(GCNR_WAVES * 64, 3) void gcn_resident_kernel(const 
     const float* s_ep = s_ecomb + EDGE_COMBOS * GCN_D;
     const uint32_t x_addr = lds_addr_of(s_x), w_addr = lds_addr_of(s_w), blob_addr = lds_addr_of(s_blob);
     float vmax = 0.0f;
-    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        const int t0 = tile_row[tile];
-        int rows = tile_row[tile + 1] - t0;
-        if (rows > GCNR_ROWS) rows = GCNR_ROWS;
-        const int g0 = tile_graph[tile], g1 = tile_graph[tile + 1];
-        const int e0 = row_ptr[t0];
-        int ne = row_ptr[t0 + rows] - e0;
-        if (ne > GCNR_EDGES) ne = GCNR_EDGES;  // cannot happen for a validated batch (the host packed by edge count)
-        __syncthreads();  // the previous tile's readout has read s_dot; its rows are dead
-        // ---- stage the tile: rows of x_0 and layer 0's table by LDS-DMA, the CSR slice and the degree scalars through registers
-        {
-            const int np = (rows * (GCN_D * 4) + 1023) >> 10;  // <= 75 pieces of 1 KiB
-            const char* gb = reinterpret_cast<const char*>(x0) + (size_t)t0 * (GCN_D * 4);
+    int tile = blockIdx.x;
+    if (tile >= n_tiles) return;
+    int t0 = tile_row[tile], rows = tile_row[tile + 1] - t0;
+    if (rows > GCNR_ROWS) rows = GCNR_ROWS;
+    int g0 = tile_graph[tile], g1 = tile_graph[tile + 1];
+    int e0 = row_ptr[t0], ne = row_ptr[t0 + rows] - e0;
+    if (ne > GCNR_EDGES) ne = GCNR_EDGES;  // cannot happen for a validated batch (the host packed by edge count)
+    // a tile's rows of x_0 and layer 0's table come by LDS-DMA (requested as soon as the previous tile's last gather is done); its CSR
+    // slice and degrees travel through registers: requested during the previous tile's middle layers, stored to LDS when that tile is done
+    auto issue_rows = [&](int ft0, int frows) {
+        const int np = (frows * (GCN_D * 4) + 1023) >> 10;  // <= 75 pieces of 1 KiB
+        const char* gb = reinterpret_cast<const char*>(x0) + (size_t)ft0 * (GCN_D * 4);
 #pragma unroll
-            for (int p = 0; p < 7; p++) {
-                const int piece = wv + GCNR_WAVES * p;
-                if (piece < np) lds_dma16(gb + (size_t)piece * 1024, (uint32_t)lane * 16u, x_addr + piece * 1024);
-            }
+        for (int p = 0; p < 7; p++) {
+            const int piece = wv + GCNR_WAVES * p;
+            if (piece < np) lds_dma16(gb + (size_t)piece * 1024, (uint32_t)lane * 16u, x_addr + piece * 1024);
+        }
 #pragma unroll
-            for (int p = 0; p < 3; p++) {
-                const int piece = wv + GCNR_WAVES * p;
-                if (piece < GCNR_BLOB_BYTES / 1024) lds_dma16(layers + GCNR_W_BYTES + piece * 1024, (uint32_t)lane * 16u, blob_addr + piece * 1024);
-            }
+        for (int p = 0; p < 3; p++) {
+            const int piece = wv + GCNR_WAVES * p;
+            if (piece < GCNR_BLOB_BYTES / 1024) lds_dma16(layers + GCNR_W_BYTES + piece * 1024, (uint32_t)lane * 16u, blob_addr + piece * 1024);
         }
-        for (int i = threadIdx.x; i < ne; i += NT) s_edge[i] = (uint16_t)((((src[e0 + i] - t0) & 255) << 6) | (ecode[e0 + i] & 63));
-        if ((int)threadIdx.x <= rows) {
-            const int o = row_ptr[t0 + threadIdx.x] - e0;
-            s_rp[threadIdx.x] = (uint16_t)(o < 0 ? 0 : (o > ne ? ne : o));
+    };
+    int epre0 = 0, epre1 = 0, rpre = 0, dpre = 0;
+    auto fetch_csr = [&](int ft0, int frows, int fe0, int fne) {
+        if ((int)threadIdx.x < fne) epre0 = (((src[fe0 + threadIdx.x] - ft0) & 255) << 6) | (ecode[fe0 + threadIdx.x] & 63);
+        if ((int)threadIdx.x + NT < fne) epre1 = (((src[fe0 + threadIdx.x + NT] - ft0) & 255) << 6) | (ecode[fe0 + threadIdx.x + NT] & 63);
+        if ((int)threadIdx.x <= frows) {
+            const int o = row_ptr[ft0 + threadIdx.x] - fe0;
+            rpre = o < 0 ? 0 : (o > fne ? fne : o);
         }
+        if ((int)threadIdx.x < frows) dpre = out_deg[ft0 + threadIdx.x];
+    };
+    static_assert(GCNR_EDGES <= 2 * NT, "two CSR words per thread");
+    issue_rows(t0, rows);
+    fetch_csr(t0, rows, e0, ne);
+    while (true) {
+        const int ntile = tile + gridDim.x;
+        const bool has_next = ntile < n_tiles;
+        int nt0 = 0, nrows = 0, ng0 = 0, ng1 = 0, ne0 = 0, nne = 0;
+        if ((int)threadIdx.x < ne) s_edge[threadIdx.x] = (uint16_t)epre0;
+        if ((int)threadIdx.x + NT < ne) s_edge[threadIdx.x + NT] = (uint16_t)epre1;
+        if ((int)threadIdx.x <= rows) s_rp[threadIdx.x] = (uint16_t)rpre;
         if ((int)threadIdx.x < rows) {
-            const int d = out_deg[t0 + threadIdx.x];
-            s_dinv[threadIdx.x] = d > 0 ? 1.0f / sqrtf((float)(d + 1)) : 0.0f;  // load_inputs.cc:122
-            s_idp1[threadIdx.x] = 1.0f / (float)(d + 1);
+            s_dinv[threadIdx.x] = dpre > 0 ? 1.0f / sqrtf((float)(dpre + 1)) : 0.0f;  // load_inputs.cc:122
+            s_idp1[threadIdx.x] = 1.0f / (float)(dpre + 1);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         const int r = wv * 16 + j;
         const bool valid = r < rows;
         const int rr = valid ? r : 0;  // rows past the tile's end repeat row 0 without in-edges (finite values, never stored)
-        const int e_begin = valid ? (int)s_rp[r] : 0, e_end = valid ? (int)s_rp[r + 1] : 0;
+        const int e_begin = valid ? (int)s_rp[r] : 0, e_end = valid && !(ablate & 1) ? (int)s_rp[r + 1] : e_begin;  // ablate: development aid (FLOWGNN_GCN_ABLATE)
         const float dinv_v = s_dinv[rr], idp1 = s_idp1[rr];
 #pragma unroll 1
         for (int l = 0; l < GCN_L; l++) {
+            if (l == 1 && has_next) {  // the next tile's descriptor (two dependent scalar round trips), used from layer 2 on
+                nt0 = tile_row[ntile];
+                nrows = tile_row[ntile + 1] - nt0;
+                if (nrows > GCNR_ROWS) nrows = GCNR_ROWS;
+                ng0 = tile_graph[ntile]; ng1 = tile_graph[ntile + 1];
+                ne0 = row_ptr[nt0];
+                nne = row_ptr[nt0 + nrows] - ne0;
+                if (nne > GCNR_EDGES) nne = GCNR_EDGES;
+            }
+            if (l == 2 && has_next) fetch_csr(nt0, nrows, ne0, nne);
             if (l + 1 < GCN_L) {  // W_{l+1} streams in under this layer's gather (45 pieces)
                 const uint8_t* gw = layers + (size_t)(l + 1) * GCNR_LAYER_BYTES;
 #pragma unroll
@@ -511,6 +534,7 @@ __global__ __launch_bounds__(GCNR_WAVES * 64, 3) void gcn_resident_kernel(const 
             for (int t = 0; t < OT; t++) {
                 const float4 bv = *reinterpret_cast<const float4*>(s_w + BIAS_OFF + (16 * t + 4 * g) * 4);
                 float4_t acc = {bv.x, bv.y, bv.z, bv.w};
+                if (!(ablate & 2)) {
 #pragma unroll
                 for (int ks = 0; ks < 3; ks++) {
                     const ds_uint4_t a_hi = *reinterpret_cast<const ds_uint4_t*>(s_w + ((t * 3 + ks) * 2 + 0) * 1024 + lane * 16);
@@ -521,6 +545,7 @@ __global__ __launch_bounds__(GCNR_WAVES * 64, 3) void gcn_resident_kernel(const 
                 }
                 const float at = *reinterpret_cast<const float*>(s_w + TAIL_OFF + t * 256 + lane * 4);
                 acc = __builtin_amdgcn_mfma_f32_16x16x4f32(at, a24, acc, 0, 0, 0);
+                }
                 const int col = 16 * t + 4 * g;
                 if (col < GCN_D && valid) {
                     const float4_t o = acc * oscale;
@@ -530,7 +555,8 @@ __global__ __launch_bounds__(GCNR_WAVES * 64, 3) void gcn_resident_kernel(const 
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();  // #2: x_{l+1} is complete, the next table has landed
         }
-        __syncthreads();  // the per-node readout terms are in s_dot
+        __syncthreads();  // the per-node readout terms are in s_dot; the rows and the table are dead
+        if (has_next) issue_rows(nt0, nrows);
         {
             const int gi = g0 + (int)threadIdx.x;
             if (gi < g1) {
@@ -540,6 +566,9 @@ __global__ __launch_bounds__(GCNR_WAVES * 64, 3) void gcn_resident_kernel(const 
                 out[gi] = sum / (float)(n1 - n0) + pool_b[0];
             }
         }
+        if (!has_next) break;
+        tile = ntile; t0 = nt0; rows = nrows; g0 = ng0; g1 = ng1; e0 = ne0; ne = nne;
+        __syncthreads();  // the readout has read s_dot and s_rp's neighbours: the small arrays may be rewritten
     }
     if (__any(!(vmax < 6.0e4f))) {
         if (lane == 0) atomicOr(range_flag, 1);
@@ -719,7 +748,8 @@ public:
             const int grid = db.gtiles.n_tiles < 256 ? db.gtiles.n_tiles : 256;  // persistent: one 12-wave workgroup per CU (153 KB of LDS)
             gcn_resident_kernel<<<grid, GCNR_WAVES * 64, 0, s>>>(db.h[0], db.csr.row_ptr, db.csr.src, db.csr.ecode, db.csr.out_deg, d_res_, d_pw_,
                                                                d_pb_, db.gtiles.row_start, db.gtiles.graph_start, db.b.node_off, db.out,
-                                                               db.gtiles.n_tiles, db.range_flag);
+                                                               db.gtiles.n_tiles, db.range_flag,
+                                                               getenv("FLOWGNN_GCN_ABLATE") ? atoi(getenv("FLOWGNN_GCN_ABLATE")) : 0);
             agg_ready_ = false;
             db.final_h = 0;
             db.h_valid = false;  // h[0] holds x_0, not x_4: flowgnn_get_h repeats the pass on the per-layer kernels

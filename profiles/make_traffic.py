@@ -17,8 +17,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 KERNELS = {
     "GIN": (1 << 18, "GIN", {"gin_resident": "gin_resident_kernel", "gin_layer_fused": "gin_layer_split_kernel",
                              "gin_aggregate": "gin_aggregate_tiled_kernel"}),
-    "GCN": (1 << 18, "GCN", {"gcn_layer_fused": "gcn_layer_fused_kernel<false>", "gcn_aggregate": "tiled_aggregate_kernel<fg::GcnAggPolicy"}),
-    "GAT": (1 << 18, "GAT", {"gat_layer": "gat_layer_kernel<false, false"}),
+    "GCN": (1 << 18, "GCN", {"gcn_resident": "gcn_resident_kernel", "gcn_layer_fused": "gcn_layer_fused_kernel<false>", "gcn_aggregate": "tiled_aggregate_kernel<fg::GcnAggPolicy"}),
+    "GAT": (1 << 18, "GAT", {"gat_resident": "gat_resident_kernel", "gat_layer": "gat_layer_kernel<false, false"}),
     "PNA": (1 << 15, "PNA", {"pna_layer_fused": "pna_layer_fused_kernel", "pna_aggregate": "tiled_aggregate_kernel<fg::PnaAggPolicy",
                              "pna_dense": "pna_dense_split_kernel"}),
     "DGN": (1 << 15, "DGN", {"dgn_layer_fused": "dgn_layer_fused_kernel", "dgn_aggregate": "tiled_aggregate_kernel<fg::DgnAggPolicy",
