@@ -18,6 +18,12 @@ constexpr int WAVE = 64;
 constexpr int ERR_EDGE_RANGE = 2;
 constexpr int ERR_EDGE_ATTR = 3;
 constexpr int ERR_NODE_FEAT = 4;
+constexpr int ERR_UNSUPPORTED = 8;
+// The per-row order of the CSR comes from a rank sort that costs indeg^2 per row (graph_build.hip).  Inside the per-graph LDS
+// classes (<= 16 384 edges per graph) that is bounded by the class; on the flat path (graphs beyond every class, i.e. far beyond
+// the reference's own 500-node / 5 500-edge caps, GIN/src/dcl.h:17-18) a row may have at most this many in-edges -- 2.7e8 key
+// comparisons -- before the build refuses the batch with FLOWGNN_ERR_UNSUPPORTED instead of running for minutes.
+constexpr int MAX_FLAT_INDEGREE = 16384;
 
 __host__ __device__ inline long long ceil_div_ll(long long a, long long b) { return (a + b - 1) / b; }
 

@@ -541,7 +541,9 @@ int flowgnn_sync(flowgnn_engine* e) {
         e->prof.collect();
     }
     if (flag) {
-        e->err = "input validation failed on device (edge endpoint / edge attribute / node feature out of range)";
+        e->err = flag == FLOWGNN_ERR_UNSUPPORTED
+                     ? "a node of a graph beyond the per-graph size classes has more than 16384 in-edges (the index build's rank sort is quadratic per row)"
+                     : "input validation failed on device (edge endpoint / edge attribute / node feature out of range)";
         return flag;
     }
     return FLOWGNN_OK;

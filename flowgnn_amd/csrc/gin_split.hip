@@ -14,7 +14,10 @@
 // operands degrade to an ABSOLUTE error of 6e-8, not to zero.  Weights are pre-scaled by a power of two per matrix
 // (exact; undone in the epilogue) so that their largest entry is in [1,2).  Operands beyond the f16 range
 // (|x| > 6e4; the reference's own Q6.10 activations are confined to [-32,32)) set *range_flag, and the engine then
-// repeats the forward pass on the fp32 MFMA kernel (gin.hip), so the result is fp32-accurate for every input.
+// repeats the forward pass on the fp32 MFMA kernel (gin.hip).  The guarantee is therefore: per product a relative error of
+// 2^-20 for operands in the f16 normal range, and an ABSOLUTE error of 6e-8 per operand below it (|x| < 6e-5: nothing flags a
+// model whose activations are uniformly tiny -- FLOWGNN_<M>_MFMA=f32 is the switch for such a model); NaN operands do not raise
+// the flag either (fmax drops them) but propagate to the output.
 //
 // Shape: as gin_layer_fused_kernel (gin.hip) -- transposed product (nodes are MFMA columns), the accumulators of
 // the first linear layer become the B operands of the second without leaving the wave, weights pre-packed in

@@ -10,7 +10,8 @@
 //
 // Integer work only; tests compare it bit-exactly with the oracle's tables.
 //
-// Kernels (all flat over edges / nodes, no per-graph size cap):
+// Kernels (all flat over edges / nodes, no per-graph size cap; the rank sort is quadratic in a row's in-degree, so the flat
+// path refuses rows above MAX_FLAT_INDEGREE = 16 384 in-edges, three times the reference's per-GRAPH edge cap):
 //   globalize_count : wave per graph; local -> global ids, in-degree / out-degree histograms,
 //                     range validation of endpoints and edge attributes
 //   exclusive scan  : in-degree -> row_ptr
@@ -158,6 +159,13 @@ __global__ __launch_bounds__(256) void rank_kernel(CsrView c, int e_tot, const i
     const int e = slot_edge[s];
     const int v = c.gdst[e], u = c.gsrc[e];
     const int beg = c.row_ptr[v], end = c.row_ptr[v + 1];
+    if (end - beg > MAX_FLAT_INDEGREE) {  // quadratic beyond use (common.h): refuse, visibly (flowgnn_sync returns the flag)
+        atomicMax(c.err, ERR_UNSUPPORTED);
+        c.src[s] = u;  // unsorted but in range: the forward pass that is already queued behind this kernel must not read stale indices
+        c.eid[s] = e;
+        if (code_by_edge) c.ecode[s] = (uint8_t)code_by_edge[e];
+        return;
+    }
     int rank = 0;
     for (int t = beg; t < end; t++) {
         const int e2 = slot_edge[t];

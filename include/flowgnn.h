@@ -36,7 +36,7 @@ extern "C" {
 #define FLOWGNN_ERR_HIP 5          /* HIP runtime error (see flowgnn_last_error) */
 #define FLOWGNN_ERR_STATE 6        /* weights or batch not set */
 #define FLOWGNN_ERR_IO 7           /* weight / graph file missing or short */
-#define FLOWGNN_ERR_UNSUPPORTED 8
+#define FLOWGNN_ERR_UNSUPPORTED 8  /* also: a graph larger than 2 048 nodes / 16 384 edges with a node of more than 16 384 in-edges */
 
 /* ---- model ids ---- */
 #define FLOWGNN_MODEL_GIN 0
@@ -227,8 +227,10 @@ int flowgnn_batch_info(const flowgnn_engine* e, long long* num_graphs,
 /*
  * Number of forward passes this engine repeated on its exact-fp32 kernels because
  * an operand left the range in which the default kernels are fp32-accurate (GIN:
- * the dense update runs as three f16 MFMAs per product, accurate to 2^-20 while
- * |activation| < 6e4; the reference's own Q6.10 activations live in [-32,32)).
+ * the dense update runs as three f16 MFMAs per product, accurate to 2^-20 relative
+ * while 6e-5 < |activation| < 6e4 and to 6e-8 ABSOLUTE per operand below that -- no
+ * flag is raised for tiny operands; the reference's own Q6.10 activations live in
+ * [-32,32) on a 2^-10 grid).
  * The check happens in flowgnn_sync / flowgnn_get_results: device-side consumers
  * of flowgnn_results_device must call flowgnn_sync first.  -1 for a null handle.
  */

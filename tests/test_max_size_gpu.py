@@ -46,3 +46,38 @@ def test_graph_at_the_reference_caps(model, oracle):
     assert np.isfinite(want).all() and np.isfinite(got).all()
     scale = max(1.0, float(np.abs(hd).max()))
     assert np.allclose(got, want, rtol=2e-4, atol=2e-4 * scale), (np.abs(got - want).max(), scale)
+
+
+def star(leaves):
+    """leaves -> hub (node 0): a graph beyond every per-graph size class of the index build when leaves > 16 384."""
+    n = leaves + 1
+    nf = np.zeros((n, 9), np.int32)
+    nf[:, 0] = np.arange(n) % 7
+    el = np.stack([np.arange(1, n), np.zeros(leaves, np.int64)], 1).astype(np.int32)
+    ea = np.zeros((leaves, 3), np.int32)
+    return gp.GraphBatch(np.array([n], np.int32), np.array([leaves], np.int32), nf, el, ea)
+
+
+def test_flat_index_build_hub_rows_and_their_cap(oracle):
+    """Graphs beyond the LDS classes take the flat index build, whose per-row rank sort is quadratic: a 3 000-leaf star next to
+    a 2 100-node chain runs (checked against the oracle); a hub above MAX_FLAT_INDEGREE = 16 384 in-edges is refused with
+    FLOWGNN_ERR_UNSUPPORTED instead of running for minutes (flowgnn_amd/csrc/common.h)."""
+    from flowgnn_amd.engine import FlowGNNError
+    w = weights.synth_gcn_weights(seed=7)
+    e = Engine("GCN", device=0)
+    try:
+        e.set_weights(w)
+        n = 2100
+        chain = gp.GraphBatch(np.array([n], np.int32), np.array([n - 1], np.int32), np.zeros((n, 9), np.int32),
+                              np.stack([np.arange(n - 1), np.arange(1, n)], 1).astype(np.int32), np.zeros((n - 1, 3), np.int32))
+        b = gp.concat_batches([star(3000), chain])
+        got = e.forward(b)
+        want = oracle.gcn_forward(b, [w], nthreads=4)
+        assert np.allclose(got, want, rtol=1e-4, atol=1e-4), np.abs(got - want).max()
+        with pytest.raises(FlowGNNError) as ei:
+            e.forward(star(17000))
+        assert ei.value.code == 8, ei.value  # FLOWGNN_ERR_UNSUPPORTED
+        got2 = e.forward(b)  # the engine is usable afterwards
+        assert np.array_equal(got2, got)
+    finally:
+        e.close()
