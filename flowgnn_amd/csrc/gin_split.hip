@@ -690,6 +690,25 @@ __global__ __launch_bounds__(256) void gin_tile_prep_kernel(const int* __restric
         d[GR_DESC_PERM + r] = (uint8_t)r;
         return;
     }
+    if (order == 2) {
+        // Bank-aware order: a column tile takes ONE row of every residue class r mod 16 -- the k-th longest of each class -- so the
+        // 16 rows a gather instruction reads start in 16 different bank groups (row stride 100 dwords = 9 bank groups mod 16), and so do
+        // their self rows and the epilogue's stores; neighbours of rows with distinct residues (atoms are numbered along chains) mostly
+        // have distinct residues too.  Degrees within a column tile stay close (k-th of 16 per class).
+        __shared__ int s_key[GR_ROWS];
+        s_key[r] = key;
+        __syncthreads();
+        const int rho = r & 15;
+        int rank = 0;
+#pragma unroll
+        for (int m = 0; m < 16; m++) {
+            const int r2 = rho + 16 * m, k2 = s_key[r2];
+            rank += (k2 < key) | ((k2 == key) & (r2 < r));
+        }
+        const int wave2 = rank < 8 ? rank : 15 - rank, nt2 = rank < 8 ? 0 : 1;
+        d[GR_DESC_PERM + wave2 * 32 + nt2 * 16 + rho] = (uint8_t)r;
+        return;
+    }
     int below = 0, mine = 0;
     for (int k = 0; k < NKEY; k++) {
         const unsigned long long m = __ballot(key == k);
