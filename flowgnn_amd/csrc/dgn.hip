@@ -150,11 +150,17 @@ __global__ __launch_bounds__(512, 2) void dgn_layer_fused_kernel(const float* __
                                                                   const int* __restrict__ out_deg, const float* __restrict__ eig4,
                                                                   const uint8_t* __restrict__ wpk, const int* __restrict__ tile_row,
                                                                   int n_tiles, int* __restrict__ range_flag, int ablate) {
-    __shared__ __attribute__((aligned(16))) char s_w[DGN_FT_LAYER_BYTES];
-    __shared__ __attribute__((aligned(16))) float s_h[DGN_FT_ROWS * DGN_D];
-    __shared__ __attribute__((aligned(4))) uint8_t s_src[DGN_FT_EDGES];
-    __shared__ uint16_t s_rp[DGN_FT_ROWS + 4];
-    __shared__ float s_eig[DGN_FT_ROWS];
+    // one LDS object with the row tile at offset 0: a neighbour row's byte address (row * 400 + 16 g < 2^16) then packs two to a
+    // register and the K-step's column is the ds_read's immediate offset -- no address arithmetic inside the seven walks
+    constexpr int OFF_W = DGN_FT_ROWS * DGN_D * 4, OFF_SRC = OFF_W + (int)DGN_FT_LAYER_BYTES, OFF_RP = OFF_SRC + DGN_FT_EDGES,
+                  OFF_EIG = OFF_RP + 2 * (DGN_FT_ROWS + 4), LDS_TOTAL = OFF_EIG + 4 * DGN_FT_ROWS;
+    static_assert(OFF_W % 16 == 0 && OFF_SRC % 16 == 0 && OFF_RP % 4 == 0 && OFF_EIG % 4 == 0, "alignment");
+    __shared__ __attribute__((aligned(16))) char s_all[LDS_TOTAL];
+    float* s_h = reinterpret_cast<float*>(s_all);
+    char* s_w = s_all + OFF_W;
+    uint8_t* s_src = reinterpret_cast<uint8_t*>(s_all + OFF_SRC);
+    uint16_t* s_rp = reinterpret_cast<uint16_t*>(s_all + OFF_RP);
+    float* s_eig = reinterpret_cast<float*>(s_all + OFF_EIG);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j = lane & 15, g = lane >> 4;
@@ -214,27 +220,30 @@ __global__ __launch_bounds__(512, 2) void dgn_layer_fused_kernel(const float* __
         const int odeg = out_deg[node];
         // first 16 in-edges: source rows as bytes, directional weights in registers; wsum / abssum over ALL in-edges
         // (DGN/src/load_inputs.cc:105-110)
-        uint32_t srcw[4];
+        uint32_t adr[8];  // byte addresses (row * 400 + 16 g) of the first 16 source rows, two per register
         float ew[16];
         float wsum = 0.0f, abssum = 0.0f;
 #pragma unroll
-        for (int w = 0; w < 4; w++) {
+        for (int w = 0; w < 8; w++) {
             uint32_t v = 0;
 #pragma unroll
-            for (int b = 0; b < 4; b++) {
-                const int e = 4 * w + b;
+            for (int b = 0; b < 2; b++) {
+                const int e = 2 * w + b;
                 const int u = e < indeg ? (int)s_src[e_base + e] : 0;
-                v |= (uint32_t)u << (8 * b);
+                v |= (uint32_t)(u * (DGN_D * 4) + 16 * g) << (16 * b);
                 const float we = e < indeg ? s_eig[u] - eig_v : 0.0f;
                 ew[e] = we;
                 wsum += we;
                 abssum += fabsf(we);
             }
-            srcw[w] = v;
+            adr[w] = v;
         }
         for (int e = 16; __any(e < indeg); e++)
             if (e < indeg) { const float we = s_eig[s_src[e_base + e]] - eig_v; wsum += we; abssum += fabsf(we); }
         const float inv_abs = 1.0f / (abssum == 0.0f ? 1.0f / 8192.0f : abssum);  // epsilon of ap_fixed<16,3> (node_embedding.cc:125-128)
+        // a1 = m1 / outdeg with x / 0 = 0: one reciprocal per row and tile instead of four IEEE divisions (~40 dependent instructions)
+        // per K-step; the row's arithmetic does not depend on its tile mates either way
+        const float inv_dg = odeg == 0 ? 0.0f : 1.0f / (float)odeg;
         float4_t acc[DGN_OT];
 #pragma unroll
         for (int t = 0; t < DGN_OT; t++) {
@@ -246,26 +255,31 @@ __global__ __launch_bounds__(512, 2) void dgn_layer_fused_kernel(const float* __
         for (int k = 0; k < DGN_FT_KS; k++) {
             if (ablate & 2) break;
             // K-step k: features 16k + 4g .. +3 (k = 6: only g = 0 holds real features, 96..99; the others supply zeros)
+            // (k = 6: the address of lane group g > 0 points 16 g bytes past features 96..99 -- inside the next row or the weights;
+            //  the values are discarded below)
             const bool real = k < 6 || g == 0;
             const int col = real ? 16 * k + 4 * g : 0;
+            const char* hk = s_all + 64 * k;
             float4 m1 = make_float4(0.f, 0.f, 0.f, 0.f), m2 = m1;
 #pragma unroll
-            for (int w = 0; w < 4; w++) {
-                if (__all(indeg >= 4 * w + 4)) {  // every row of the wave has these four in-edges: four reads in flight, no masks
-                    float4 x[4];
+            for (int w = 0; w < 4; w += 2) {
+                if (__all(indeg >= 4 * w + 8)) {
+                    // every row of the wave has these eight in-edges (kNN graphs): eight reads in flight, no masks.  The walk is bound by
+                    // LDS round trips, not by instructions: two waves per SIMD hide little, so the reads are batched as deep as registers allow
+                    float4 x[8];
 #pragma unroll
-                    for (int b = 0; b < 4; b++) x[b] = *reinterpret_cast<const float4*>(s_h + (int)((srcw[w] >> (8 * b)) & 0xFFu) * DGN_D + col);
+                    for (int b = 0; b < 8; b++) x[b] = *reinterpret_cast<const float4*>(hk + ((adr[2 * w + (b >> 1)] >> (16 * (b & 1))) & 0xFFFFu));
 #pragma unroll
-                    for (int b = 0; b < 4; b++) {
+                    for (int b = 0; b < 8; b++) {
                         const float we = ew[4 * w + b];
                         m1.x += x[b].x; m1.y += x[b].y; m1.z += x[b].z; m1.w += x[b].w;
                         m2.x = __builtin_fmaf(x[b].x, we, m2.x); m2.y = __builtin_fmaf(x[b].y, we, m2.y); m2.z = __builtin_fmaf(x[b].z, we, m2.z); m2.w = __builtin_fmaf(x[b].w, we, m2.w);
                     }
                 } else if (__any(indeg > 4 * w)) {
 #pragma unroll
-                    for (int b = 0; b < 4; b++)
+                    for (int b = 0; b < 8; b++)
                         if (indeg > 4 * w + b) {
-                            const float4 x = *reinterpret_cast<const float4*>(s_h + (int)((srcw[w] >> (8 * b)) & 0xFFu) * DGN_D + col);
+                            const float4 x = *reinterpret_cast<const float4*>(hk + ((adr[2 * w + (b >> 1)] >> (16 * (b & 1))) & 0xFFFFu));
                             const float we = ew[4 * w + b];
                             m1.x += x.x; m1.y += x.y; m1.z += x.z; m1.w += x.w;
                             m2.x = __builtin_fmaf(x.x, we, m2.x); m2.y = __builtin_fmaf(x.y, we, m2.y); m2.z = __builtin_fmaf(x.z, we, m2.z); m2.w = __builtin_fmaf(x.w, we, m2.w);
@@ -282,10 +296,8 @@ __global__ __launch_bounds__(512, 2) void dgn_layer_fused_kernel(const float* __
                 }
             // a1 = m1 / outdeg (x / 0 = 0), a2 = |(m2 - wsum h[v]) / abssum|   (node_embedding.cc:143-146)
             const float4 hv = *reinterpret_cast<const float4*>(hrow + col);
-            const float dg = (float)odeg;
             float4 a1, a2;
-            a1.x = odeg == 0 ? 0.f : m1.x / dg; a1.y = odeg == 0 ? 0.f : m1.y / dg;
-            a1.z = odeg == 0 ? 0.f : m1.z / dg; a1.w = odeg == 0 ? 0.f : m1.w / dg;
+            a1.x = m1.x * inv_dg; a1.y = m1.y * inv_dg; a1.z = m1.z * inv_dg; a1.w = m1.w * inv_dg;
             // explicit fma: every path a wave can take (all rows full / ragged) rounds alike, so a row's result never depends on its tile mates
             a2.x = fabsf(__builtin_fmaf(-wsum, hv.x, m2.x) * inv_abs); a2.y = fabsf(__builtin_fmaf(-wsum, hv.y, m2.y) * inv_abs);
             a2.z = fabsf(__builtin_fmaf(-wsum, hv.z, m2.z) * inv_abs); a2.w = fabsf(__builtin_fmaf(-wsum, hv.w, m2.w) * inv_abs);
@@ -295,10 +307,10 @@ __global__ __launch_bounds__(512, 2) void dgn_layer_fused_kernel(const float* __
             DS_SPLIT2(a1.z, a1.w, b_hi.y, b_lo.y);
             DS_SPLIT2(a2.x, a2.y, b_hi.z, b_lo.z);
             DS_SPLIT2(a2.z, a2.w, b_hi.w, b_lo.w);
-            vmax = __builtin_fmaxf(__builtin_fmaxf(vmax, __builtin_fabsf(a1.x)), __builtin_fabsf(a1.y));
-            vmax = __builtin_fmaxf(__builtin_fmaxf(vmax, __builtin_fabsf(a1.z)), __builtin_fabsf(a1.w));
-            vmax = __builtin_fmaxf(__builtin_fmaxf(vmax, a2.x), a2.y);
-            vmax = __builtin_fmaxf(__builtin_fmaxf(vmax, a2.z), a2.w);
+            asm("v_max3_f32 %0, |%1|, |%2|, %0" : "+v"(vmax) : "v"(a1.x), "v"(a1.y));
+            asm("v_max3_f32 %0, |%1|, |%2|, %0" : "+v"(vmax) : "v"(a1.z), "v"(a1.w));
+            asm("v_max3_f32 %0, |%1|, |%2|, %0" : "+v"(vmax) : "v"(a2.x), "v"(a2.y));
+            asm("v_max3_f32 %0, |%1|, |%2|, %0" : "+v"(vmax) : "v"(a2.z), "v"(a2.w));
             asm volatile("" : "+v"(vmax));
             const char* wb = s_w + (size_t)k * (DGN_OT * 2 * 1024);
 #pragma unroll
