@@ -202,28 +202,54 @@ def plan_job(dataset: str, graphs: int, world: int, rank: int, scaling: str, mak
 
 class ShardedResults:
     """Result concat of the job: every rank's readout kernel writes its per-graph logits into `pad` (width = widest
-    shard), ONE all_gather_into_tensor per step concatenates them (RCCL over xGMI on GPUs, gloo in the CPU test)."""
+    shard), ONE all_gather_into_tensor per step concatenates them (RCCL over xGMI on GPUs, gloo in the CPU test).
+    Two buffer pairs alternate from step to step and the gather is asynchronous: step i + 1 computes into the other pair
+    while step i's logits travel, and a pair is only reused once its gather has been waited for."""
 
     def __init__(self, ranges, rank, device, dist_mod):
         import torch
         self.ranges, self.rank, self.dist = ranges, rank, dist_mod
         self.world = len(ranges)
         self.width = max(1, max(b - a for a, b in ranges))
-        self.pad = torch.zeros(self.width, dtype=torch.float32, device=device)
-        self.all = torch.empty(self.world * self.width, dtype=torch.float32, device=device) if self.world > 1 else self.pad
+        nbuf = 2 if self.world > 1 else 1
+        self.pads = [torch.zeros(self.width, dtype=torch.float32, device=device) for _ in range(nbuf)]
+        self.alls = [torch.empty(self.world * self.width, dtype=torch.float32, device=device) for _ in range(nbuf)] if self.world > 1 else self.pads
+        self.work = [None] * nbuf
+        self.cur = 0    # the pair the coming step writes
+        self.last = 0   # the pair the last finished step wrote
+
+    @property
+    def pad(self):
+        """Where this rank's readout writes the coming step's logits (waits for the gather that last used the pair)."""
+        if self.work[self.cur] is not None:
+            self.work[self.cur].wait()
+            self.work[self.cur] = None
+        return self.pads[self.cur]
 
     def local_count(self):
         a, b = self.ranges[self.rank]
         return b - a
 
     def gather(self):
+        self.last = self.cur
         if self.world > 1:
-            self.dist.all_gather_into_tensor(self.all, self.pad)
+            self.work[self.cur] = self.dist.all_gather_into_tensor(self.alls[self.cur], self.pads[self.cur], async_op=True)
+            self.cur ^= 1
+
+    def finish(self):
+        for i, w in enumerate(self.work):
+            if w is not None:
+                w.wait()
+                self.work[i] = None
+
+    def local(self):
+        return self.pads[self.last]
 
     def assemble(self):
-        """Logits of the whole job in job order (ragged shards trimmed)."""
+        """Logits of the whole job in job order (ragged shards trimmed), from the last finished step."""
         import torch
-        rows = self.all.view(self.world, self.width)
+        self.finish()
+        rows = self.alls[self.last].view(self.world, self.width)
         return torch.cat([rows[r, : b - a] for r, (a, b) in enumerate(self.ranges)])
 
 
@@ -315,9 +341,9 @@ def main():
     side = torch.cuda.Stream()
     res = ShardedResults(ranges, rank, "cuda", dist)
     eng.set_stream(side.cuda_stream)
-    eng.set_results_buffer(res.pad.data_ptr())
 
     def step():
+        eng.set_results_buffer(res.pad.data_ptr())  # the pair that is free: the previous step's logits may still be travelling
         eng.run()
         res.gather()
 
@@ -333,6 +359,7 @@ def main():
         for _ in range(args.steps):
             step()
         eng.sync()  # inside the clock: stream sync + validation / range flags (an exact-fp32 re-run, if any, is timed too)
+        res.finish()  # ... and the last gathers
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -346,7 +373,7 @@ def main():
         eng.profile_enable(False)
         logits_all = res.assemble()
         ok = bool(torch.isfinite(logits_all).all().item())
-        out_local = res.pad[:G].detach().cpu().numpy()
+        out_local = res.local()[:G].detach().cpu().numpy()
     total_job_graphs = ranges[-1][1]
     if int(logits_all.shape[0]) != total_job_graphs:
         raise SystemExit(f"result concat has {int(logits_all.shape[0])} graphs, the job has {total_job_graphs}")

@@ -28,7 +28,7 @@ def _worker(rank, world, port, scaling, graphs, q):
     w = weights.synth_gin_weights(seed=7)
     res = b.ShardedResults(ranges, rank, "cpu", dist)
     assert res.local_count() == batch.num_graphs
-    for _ in range(2):  # two "steps": buffers are reused
+    for _ in range(3):  # three "steps": both buffer pairs are used and one is reused (asynchronous gathers)
         res.pad[: batch.num_graphs] = torch.from_numpy(oracle.gin_forward(batch, [w]))
         res.gather()
     q.put((rank, res.assemble().numpy(), ranges, balance))
