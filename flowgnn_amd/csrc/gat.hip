@@ -503,6 +503,7 @@ __global__ __launch_bounds__(GATR_WAVES * 64, 4) void gat_resident_kernel(const 
                                                                          const int* __restrict__ tile_row, const int* __restrict__ tile_graph,
                                                                          const int* __restrict__ node_off, float* __restrict__ out, int n_tiles,
                                                                          GatResidentDev w, int ablate) {
+    const bool sort_rows = !(ablate & 4);  // development aid: FLOWGNN_GAT_ABLATE=4 keeps rows in natural order
     __shared__ __attribute__((aligned(16))) char s_w[GATR_LAYER_BYTES];  // this layer's fragments
     __shared__ __attribute__((aligned(16))) float4 s_proj[GATR_ROWS * 16];
     __shared__ __attribute__((aligned(16))) float4 s_sc[GATR_ROWS * 2];
@@ -513,6 +514,11 @@ __global__ __launch_bounds__(GATR_WAVES * 64, 4) void gat_resident_kernel(const 
     __shared__ float s_dot[GATR_ROWS];
     __shared__ __attribute__((aligned(16))) float4 s_att[2 * GAT_D];  // a_src | a_tgt of layer 0 (heads in the float4)
     __shared__ float s_pw[GAT_D];
+    // Column owner table: the walk of a 16-lane group takes as many trips as its LONGEST row, so the tile's rows are dealt to the
+    // groups in order of decreasing in-degree (counting sort per tile; order inside a degree class is whatever the LDS atomics
+    // gave -- placement never changes a row's arithmetic: MFMA columns are independent and a row is summed in CSR order by one lane)
+    __shared__ uint8_t s_perm[GATR_ROWS];
+    __shared__ int s_cnt[16], s_cur[16];
     constexpr int NT = GATR_WAVES * 64;
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -560,6 +566,7 @@ __global__ __launch_bounds__(GATR_WAVES * 64, 4) void gat_resident_kernel(const 
         const bool has_next = ntile < n_tiles;
         int nt0 = 0, nrows = 0, ng0 = 0, ng1 = 0, ne0 = 0, nne = 0;
         __syncthreads();  // the previous tile's readout has read s_dot; its LDS state is dead
+        if (threadIdx.x < 16) { s_cnt[threadIdx.x] = 0; s_cur[threadIdx.x] = 0; }
 #pragma unroll
         for (int k = 0; k < 3; k++)
             if (threadIdx.x + NT * k < GATR_ROWS * ND_FEATURE) s_feat[threadIdx.x + NT * k] = fpre[k];
@@ -568,6 +575,14 @@ __global__ __launch_bounds__(GATR_WAVES * 64, 4) void gat_resident_kernel(const 
             if ((int)threadIdx.x + NT * k < ne) s_src[threadIdx.x + NT * k] = (uint8_t)(spre[k] & 255);
         if ((int)threadIdx.x <= rows) s_rp[threadIdx.x] = (uint16_t)rpre;
         __syncthreads();
+        int skey = 15;  // in-degree class of row threadIdx.x: 0 = longest (>= 14 in-edges) .. 14 = none, 15 = no such row
+        if (threadIdx.x < GATR_ROWS) {
+            if ((int)threadIdx.x < rows) {
+                const int deg = (int)s_rp[threadIdx.x + 1] - (int)s_rp[threadIdx.x];
+                skey = 14 - (deg < 14 ? deg : 14);
+            }
+            if (sort_rows) atomicAdd(&s_cnt[skey], 1);
+        }
         // ---- layer 0: proj_0 of (row, dim) from the row's nine features (load_inputs.cc:184-201), heads in the float4
         {
             int tid = threadIdx.x;
@@ -594,8 +609,15 @@ __global__ __launch_bounds__(GATR_WAVES * 64, 4) void gat_resident_kernel(const 
             }
             s_sc[r * 2 + 0] = ss;
             s_sc[r * 2 + 1] = st;
+            int pos = r;
+            if (sort_rows) {
+                pos = atomicAdd(&s_cur[skey], 1);
+                for (int k = 0; k < skey; k++) pos += s_cnt[k];
+            }
+            s_perm[pos] = (uint8_t)r;
         }
-        const int r = wv * 16 + j;
+        __syncthreads();
+        const int r = s_perm[wv * 16 + j];
         const bool valid = r < rows;
         const int rr = valid ? r : 0;  // rows past the tile's end repeat row 0's self edge (finite values, never used)
         const int e_begin = valid ? (int)s_rp[r] : 0, e_end = valid && !(ablate & 1) ? (int)s_rp[r + 1] : e_begin;  // ablate: development aid (FLOWGNN_GAT_ABLATE)
@@ -620,7 +642,6 @@ __global__ __launch_bounds__(GATR_WAVES * 64, 4) void gat_resident_kernel(const 
             GATR_ABSMAX(vmax, bq[0], bq[4]);
             GATR_ABSMAX(vmax, bq[8], bq[12]);
         }
-        __syncthreads();
 #pragma unroll 1
         for (int l = 0; l < GAT_L; l++) {
             // this layer's fragments stream in under the gather, which does not use them: 36 pieces of 1 KiB (last layer: W_skip only)

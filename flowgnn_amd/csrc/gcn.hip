@@ -359,6 +359,12 @@ __global__ __launch_bounds__(GCNR_WAVES * 64, 3) void gcn_resident_kernel(const 
     __shared__ uint16_t s_edge[GCNR_EDGES];
     __shared__ uint16_t s_rp[GCNR_ROWS + 2];
     __shared__ float s_dinv[GCNR_ROWS], s_idp1[GCNR_ROWS], s_dot[GCNR_ROWS];
+    // Column owner table: the walk of a 16-lane group takes as many trips as its LONGEST row, so the tile's rows are dealt to the
+    // waves in order of decreasing in-degree (counting sort per tile; the order inside a degree class is whatever the LDS atomics
+    // gave -- placement never changes a row's arithmetic: MFMA columns are independent and a row is summed in CSR order by one lane)
+    __shared__ uint8_t s_perm[GCNR_ROWS];
+    __shared__ int s_cnt[16], s_cur[16];
+    const bool sort_rows = !(ablate & 4);  // development aid: FLOWGNN_GCN_ABLATE=4 keeps rows in natural order
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int j = lane & 15, g = lane >> 4;
@@ -413,9 +419,28 @@ __global__ __launch_bounds__(GCNR_WAVES * 64, 3) void gcn_resident_kernel(const 
             s_dinv[threadIdx.x] = dpre > 0 ? 1.0f / sqrtf((float)(dpre + 1)) : 0.0f;  // load_inputs.cc:122
             s_idp1[threadIdx.x] = 1.0f / (float)(dpre + 1);
         }
+        if (threadIdx.x < 16) { s_cnt[threadIdx.x] = 0; s_cur[threadIdx.x] = 0; }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        const int r = wv * 16 + j;
+        int skey = 15;  // in-degree class of row threadIdx.x: 0 = longest (>= 14 in-edges) .. 14 = none, 15 = no such row
+        if (threadIdx.x < GCNR_ROWS) {
+            if ((int)threadIdx.x < rows) {
+                const int deg = (int)s_rp[threadIdx.x + 1] - (int)s_rp[threadIdx.x];
+                skey = 14 - (deg < 14 ? deg : 14);
+            }
+            if (sort_rows) atomicAdd(&s_cnt[skey], 1);
+        }
+        __syncthreads();
+        if (threadIdx.x < GCNR_ROWS) {
+            int pos = threadIdx.x;
+            if (sort_rows) {
+                pos = atomicAdd(&s_cur[skey], 1);
+                for (int k = 0; k < skey; k++) pos += s_cnt[k];
+            }
+            s_perm[pos] = (uint8_t)threadIdx.x;
+        }
+        __syncthreads();
+        const int r = s_perm[wv * 16 + j];
         const bool valid = r < rows;
         const int rr = valid ? r : 0;  // rows past the tile's end repeat row 0 without in-edges (finite values, never stored)
         const int e_begin = valid ? (int)s_rp[r] : 0, e_end = valid && !(ablate & 1) ? (int)s_rp[r + 1] : e_begin;  // ablate: development aid (FLOWGNN_GCN_ABLATE)
