@@ -457,7 +457,7 @@ __global__ __launch_bounds__(GCNR_WAVES * 64, 3) void gcn_resident_kernel(const 
                 if (nne > GCNR_EDGES) nne = GCNR_EDGES;
             }
             if (l == 2 && has_next) fetch_csr(nt0, nrows, ne0, nne);
-            if (l + 1 < GCN_L) {  // W_{l+1} streams in under this layer's gather (45 pieces)
+            if (l + 1 < GCN_L && !(ablate & 16)) {  // W_{l+1} streams in under this layer's gather (45 pieces; ablate 16: timing without it)
                 const uint8_t* gw = layers + (size_t)(l + 1) * GCNR_LAYER_BYTES;
 #pragma unroll
                 for (int p = 0; p < 4; p++) {
@@ -545,7 +545,7 @@ __global__ __launch_bounds__(GCNR_WAVES * 64, 3) void gcn_resident_kernel(const 
             const float a24 = a[24];
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();  // #1: every gather of this layer is done (rows may be rewritten, the table replaced); W_{l+1} has landed
-            {   // the next layer's table + epilogue vectors stream in under the dense layer
+            if (!(ablate & 8)) {  // the next layer's table + epilogue vectors stream in under the dense layer (ablate 8: timing without it)
                 const uint8_t* gbl = layers + (size_t)(l + 1) * GCNR_LAYER_BYTES + GCNR_W_BYTES;
 #pragma unroll
                 for (int p = 0; p < 3; p++) {
