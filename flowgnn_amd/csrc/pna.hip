@@ -453,13 +453,13 @@ __global__ __launch_bounds__(PNA_FT_WAVES * 64, 4) void pna_layer_fused_kernel(c
             pna_stream_mfma(s_a, lane, b_hi, b_lo, y);
             if (late) pna_gather_slice(s_h, csrc, srcw, e_base, indeg, 8 * (ks + 1) + 2 * g, b_hi, b_lo, vmax);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
+            if (!(ablate & 4)) __syncthreads();
             if (ks + 2 < PNA_KS) pna_issue_chunk_asm(wpk + (size_t)(ks + 2) * PNA_CHUNK, s_a, wave, lane);
             if (!late) pna_gather_slice(s_h, csrc, srcw, e_base, indeg, 8 * (ks + 1) + 2 * g, b_hi, b_lo, vmax);
             pna_stream_mfma(s_b, lane, b_hi, b_lo, y);
             if (late && ks + 2 < PNA_KS) pna_gather_slice(s_h, csrc, srcw, e_base, indeg, 8 * (ks + 2) + 2 * g, b_hi, b_lo, vmax);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
+            if (!(ablate & 4)) __syncthreads();  // ablate 4 (development aid): timing without the K-step barriers (results are then wrong)
         }
         // ---- epilogue: h' = h + relu(b + Y_0 + t Y_1 + scale Y_2)   (node_embedding.cc:148-150,205-213); the residual rows come
         // out of the LDS tile, after which the tile is dead and the next one's rows can stream in
