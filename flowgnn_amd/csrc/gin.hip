@@ -728,7 +728,7 @@ public:
                 ProfScope p(prof, "gin_resident", s);
                 launch_gin_resident(db.h[0], rows ? db.h[1] : nullptr, db.csr.row_ptr, db.csr.src, db.csr.ecode, d_ecomb_, d_rsplit_, d_pw_, d_pb_,
                                     db.gtiles.row_start, db.gtiles.graph_start, reinterpret_cast<uint8_t*>(perm_.p), db.b.node_off,
-                                    multi ? nullptr : db.out, db.gtiles.n_tiles, db.range_flag, s);
+                                    multi ? nullptr : db.out, db.gtiles.n_tiles, db.range_flag, s, virtual_node_);
             }
             db.final_h = rows ? 1 : 0;
             db.h_valid = rows;
@@ -849,9 +849,9 @@ private:
     GrowBufI perm_;  // graph-resident path: per-tile descriptors (gin_tile_prep_kernel)
     // FLOWGNN_GIN_FOLD_READOUT=0 keeps the separate mean-pool + linear kernel (and the last layer's 2.7 GB of rows)
     bool fold_readout_ = !(getenv("FLOWGNN_GIN_FOLD_READOUT") && atoi(getenv("FLOWGNN_GIN_FOLD_READOUT")) == 0);
-    // FLOWGNN_GIN_RESIDENT=0 keeps one launch per layer (gin_layer_split_kernel); GIN-VN defaults to that path: its virtual
-    // nodes are hub rows (in-degree = graph size), which the per-layer kernel sums cooperatively and the resident one does not
-    bool resident_ = getenv("FLOWGNN_GIN_RESIDENT") ? atoi(getenv("FLOWGNN_GIN_RESIDENT")) != 0 : !virtual_node_;
+    // FLOWGNN_GIN_RESIDENT=0 keeps one launch per layer (gin_layer_split_kernel).  GIN-VN runs the HUBS form of the resident kernel:
+    // its virtual nodes are hub rows (in-degree = graph size), walked by the 16 lanes of their column tile together
+    bool resident_ = getenv("FLOWGNN_GIN_RESIDENT") ? atoi(getenv("FLOWGNN_GIN_RESIDENT")) != 0 : true;
     double resident_min_fill_ = getenv("FLOWGNN_GIN_RESIDENT_MIN_FILL") ? atof(getenv("FLOWGNN_GIN_RESIDENT_MIN_FILL")) : 0.5;
     uint8_t* d_split_ = nullptr;
     uint8_t* d_rsplit_ = nullptr;  // weight stream of the graph-resident kernel

@@ -42,6 +42,6 @@ constexpr int GIN_RESIDENT_DESC_BYTES = 3584;  // per-tile descriptor built by g
 void launch_gin_resident(const float* h0, float* hout, const int* row_ptr, const int* src, const uint8_t* ecode, const float* ecomb_all,
                          const uint8_t* chunks_all, const float* pool_w, const float* pool_b, const int* tile_row, const int* tile_graph,
                          uint8_t* tile_desc /* scratch, n_tiles x GIN_RESIDENT_DESC_BYTES */, const int* node_off, float* out, int n_tiles,
-                         int* range_flag, hipStream_t s);
+                         int* range_flag, hipStream_t s, bool hubs = false);
 
 }  // namespace fg

@@ -646,6 +646,7 @@ __device__ __forceinline__ GrTile gr_load_tile(const int* __restrict__ tile_row,
 constexpr int GR_DESC_RP = GR_EDGES * 2;
 constexpr int GR_DESC_PERM = GR_DESC_RP + 528;
 constexpr int GR_DESC_BYTES = 3584;  // 3.5 pieces of 1 KiB
+constexpr int GR_HUB_DEG = 8;        // HUBS kernels: rows with more in-edges than this are walked by their whole 16-lane group
 
 // Column owner table: which row of the tile each MFMA column (wave, column tile, lane) owns.  The gather walks the in-edges of
 // the 16 rows of a column tile in lockstep, so a column tile costs as many trips as its LONGEST row: rows are dealt to column
@@ -709,6 +710,46 @@ __global__ __launch_bounds__(256) void gin_tile_prep_kernel(const int* __restric
         d[GR_DESC_PERM + wave2 * 32 + nt2 * 16 + rho] = (uint8_t)r;
         return;
     }
+    if (order == 3) {
+        // Hub order (GIN-VN: one virtual node of in-degree n per graph): rows of more than GR_HUB_DEG in-edges are walked by all 16
+        // lanes of their column tile together (gr_layer), so they are dealt round-robin over the 16 column tiles -- hub i to column
+        // tile i mod 16, lane i / 16 -- and the other rows fill the remaining lanes in order of decreasing in-degree as above.
+        __shared__ int s_hub[4], s_cnt2[4][NKEY];
+        const bool hub = r < rows && deg > GR_HUB_DEG;
+        const unsigned long long hm = __ballot(hub);
+        if (lane == 0) s_hub[wv] = __popcll(hm);
+        const int k2 = hub ? NKEY : key;  // hubs leave the degree classes
+        int mine2 = 0;
+        for (int k = 0; k < NKEY; k++) {
+            const unsigned long long m = __ballot(k2 == k);
+            if (lane == 0) s_cnt2[wv][k] = __popcll(m);
+            if (k2 == k) mine2 = __popcll(m & ((1ull << lane) - 1ull));
+        }
+        __syncthreads();
+        const int H = s_hub[0] + s_hub[1] + s_hub[2] + s_hub[3];
+        int kt, jj;
+        if (hub) {
+            int hr = __popcll(hm & ((1ull << lane) - 1ull));
+            for (int w = 0; w < wv; w++) hr += s_hub[w];
+            kt = hr & 15; jj = hr >> 4;
+        } else {
+            int p = mine2;
+            for (int k = 0; k < NKEY; k++)
+                for (int w = 0; w < 4; w++) {
+                    const int c = s_cnt2[w][k];
+                    if (k < key || (k == key && w < wv)) p += c;
+                }
+            kt = 0; jj = 0;
+            for (int t = 0; t < 16; t++) {  // column tile t has 16 - hubs_in(t) free lanes
+                const int hin = (H >> 4) + (t < (H & 15) ? 1 : 0), cap = 16 - hin;
+                if (p < cap) { kt = t; jj = hin + p; break; }
+                p -= cap;
+            }
+        }
+        const int wave3 = kt < 8 ? kt : 15 - kt, nt3 = kt < 8 ? 0 : 1;
+        d[GR_DESC_PERM + wave3 * 32 + nt3 * 16 + jj] = (uint8_t)r;
+        return;
+    }
     int below = 0, mine = 0;
     for (int k = 0; k < NKEY; k++) {
         const unsigned long long m = __ballot(key == k);
@@ -732,7 +773,7 @@ __device__ __forceinline__ void gr_issue_desc(const uint8_t* __restrict__ desc, 
         lds_dma16(reinterpret_cast<const char*>(desc) + (size_t)tile * GR_DESC_BYTES + wave * 1024, (uint32_t)lane * 16u, lds_addr_of(s_desc) + wave * 1024);
 }
 
-template <bool PROF>
+template <bool PROF, bool HUBS>
 __device__ __forceinline__ void gr_layer(unsigned long long (&tacc)[6], char* bx, char* by, float* s_h, char* s_desc, float* s_dot,
                                          const GrTile& cur, const GrTile& nxt, bool has_next, int next_tile, int l,
                                          const float* __restrict__ h0, const uint8_t* __restrict__ desc, const float* __restrict__ ecomb_all,
@@ -753,6 +794,7 @@ __device__ __forceinline__ void gr_layer(unsigned long long (&tacc)[6], char* bx
     // ---- gather (MP unit) out of LDS: a = h[v] + sum_e relu(h[src_e] + ecomb[code_e]), CSR order
     float bq[NT][25];
     int e_cur[NT], e_end[NT];
+    int hub_beg[NT] = {0, 0}, hub_end[NT] = {0, 0};
     unsigned wd[NT];
     int row[NT];
 #pragma unroll
@@ -763,6 +805,12 @@ __device__ __forceinline__ void gr_layer(unsigned long long (&tacc)[6], char* bx
         e_cur[nt] = s_rp[rr];
         e_end[nt] = s_rp[rr + 1];
         if (!valid) e_end[nt] = e_cur[nt];
+        if constexpr (HUBS) {  // hub rows sit out the per-lane walk (below: the whole 16-lane group walks them)
+            hub_beg[nt] = e_cur[nt];
+            hub_end[nt] = e_end[nt];
+            if (e_end[nt] - e_cur[nt] > GR_HUB_DEG) e_end[nt] = e_cur[nt];
+            else hub_end[nt] = hub_beg[nt];
+        }
 #pragma unroll
         for (int k = 0; k < 25; k++) bq[nt][k] = 0.0f;
     }
@@ -795,6 +843,54 @@ __device__ __forceinline__ void gr_layer(unsigned long long (&tacc)[6], char* bx
                     bq[nt][4 * q + 3] += relu1(w.w + x[q].w);
                 }
                 bq[nt][24] += relu1(s_ecomb[code * GS_D + 96 + g] + xt);
+            }
+        }
+    }
+    if constexpr (HUBS) {
+        // Hub rows (GIN-VN's virtual nodes: in-degree = graph size): one lane walking 26 in-edges would hold its column tile for 26
+        // trips.  Instead every lane j of the column tile takes the hub's in-edges j, j + 16, ... (in CSR order), and the 16 partial
+        // sums are combined with a fixed butterfly -- an association that depends on the row only, so results stay bit-identical
+        // under any batch split or order (as in the per-layer kernel's hub path, gin_split.hip above).
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++) {
+            unsigned long long hm = __ballot(hub_end[nt] > hub_beg[nt] && g == 0);
+            while (hm) {
+                const int jh = __ffsll((long long)hm) - 1;
+                hm &= hm - 1;
+                const int hb = __shfl(hub_beg[nt], jh, 64), he = __shfl(hub_end[nt], jh, 64);
+                float part[25];
+#pragma unroll
+                for (int k = 0; k < 25; k++) part[k] = 0.0f;
+                for (int e = hb + j; __any(e < he); e += 16) {
+                    if (e < he) {
+                        const unsigned w2 = s_edge[e];
+                        const unsigned u = w2 >> 6, code = w2 & 63u;
+                        const float* hr = s_h + u * GS_D + 4 * g;
+                        const float* er = s_ecomb + code * GS_D + 4 * g;
+                        float4 x[6];
+#pragma unroll
+                        for (int q = 0; q < 6; q++) x[q] = *reinterpret_cast<const float4*>(hr + 16 * q);
+                        const float xt = s_h[u * GS_D + 96 + g];
+#pragma unroll
+                        for (int q = 0; q < 6; q++) {
+                            const float4 w = *reinterpret_cast<const float4*>(er + 16 * q);
+                            part[4 * q + 0] += relu1(w.x + x[q].x);
+                            part[4 * q + 1] += relu1(w.y + x[q].y);
+                            part[4 * q + 2] += relu1(w.z + x[q].z);
+                            part[4 * q + 3] += relu1(w.w + x[q].w);
+                        }
+                        part[24] += relu1(s_ecomb[code * GS_D + 96 + g] + xt);
+                    }
+                }
+#pragma unroll
+                for (int m = 1; m < 16; m <<= 1) {
+#pragma unroll
+                    for (int k = 0; k < 25; k++) part[k] += __shfl_xor(part[k], m, 64);
+                }
+                if (j == jh) {
+#pragma unroll
+                    for (int k = 0; k < 25; k++) bq[nt][k] += part[k];
+                }
             }
         }
     }
@@ -922,7 +1018,7 @@ __device__ __forceinline__ void gr_layer(unsigned long long (&tacc)[6], char* bx
     if constexpr (PROF) { const unsigned long long t = wall_clock64(); tacc[3] += t - tp; }
 }
 
-template <bool PROF>
+template <bool PROF, bool HUBS>
 __global__ __launch_bounds__(GR_WAVES * 64, 2) void gin_resident_kernel(const float* __restrict__ h0, float* __restrict__ hout,
                                                                        const float* __restrict__ ecomb_all,
                                                                        const uint8_t* __restrict__ wchunks_all,
@@ -961,9 +1057,9 @@ __global__ __launch_bounds__(GR_WAVES * 64, 2) void gin_resident_kernel(const fl
 #pragma unroll 1
         for (int l = 0; l < 5; l++) {
             if (!flip)
-                gr_layer<PROF>(tacc, s_a, s_b, s_h, s_desc, s_dot, cur, nxt, has_next, ntile, l, h0, desc, ecomb_all, wchunks_all, pool_w, hout, vmax, wave, lane);
+                gr_layer<PROF, HUBS>(tacc, s_a, s_b, s_h, s_desc, s_dot, cur, nxt, has_next, ntile, l, h0, desc, ecomb_all, wchunks_all, pool_w, hout, vmax, wave, lane);
             else
-                gr_layer<PROF>(tacc, s_b, s_a, s_h, s_desc, s_dot, cur, nxt, has_next, ntile, l, h0, desc, ecomb_all, wchunks_all, pool_w, hout, vmax, wave, lane);
+                gr_layer<PROF, HUBS>(tacc, s_b, s_a, s_h, s_desc, s_dot, cur, nxt, has_next, ntile, l, h0, desc, ecomb_all, wchunks_all, pool_w, hout, vmax, wave, lane);
             flip = !flip;
         }
         // readout (GIN/src/finalize.cc:36-113): out[g] = mean_v(h5[v] . w) + b, node order; the terms stay valid until the next
@@ -1151,9 +1247,10 @@ void launch_gin_layer_split(const float* h, float* hout, const int* row_ptr, con
 
 void launch_gin_resident(const float* h0, float* hout, const int* row_ptr, const int* src, const uint8_t* ecode, const float* ecomb_all,
                          const uint8_t* chunks_all, const float* pool_w, const float* pool_b, const int* tile_row, const int* tile_graph,
-                         uint8_t* tile_desc, const int* node_off, float* out, int n_tiles, int* range_flag, hipStream_t s) {
+                         uint8_t* tile_desc, const int* node_off, float* out, int n_tiles, int* range_flag, hipStream_t s, bool hubs) {
     if (n_tiles <= 0) return;
-    static const int order = getenv("FLOWGNN_GIN_RESIDENT_NOSORT") ? atoi(getenv("FLOWGNN_GIN_RESIDENT_NOSORT")) : 0;
+    static const int order_env = getenv("FLOWGNN_GIN_RESIDENT_NOSORT") ? atoi(getenv("FLOWGNN_GIN_RESIDENT_NOSORT")) : 0;
+    const int order = hubs ? 3 : order_env;
     gin_tile_prep_kernel<<<n_tiles, 256, 0, s>>>(row_ptr, src, ecode, tile_row, tile_desc, n_tiles, order);
     const int grid = n_tiles < 256 ? n_tiles : 256;  // persistent: one 8-wave workgroup per CU (157 KB of LDS)
     static const bool prof = getenv("FLOWGNN_GIN_RESIDENT_PROF") && atoi(getenv("FLOWGNN_GIN_RESIDENT_PROF")) != 0;
@@ -1162,7 +1259,11 @@ void launch_gin_resident(const float* h0, float* hout, const int* row_ptr, const
         const size_t cnt = (size_t)grid * GR_WAVES * 7;
         if (hipMalloc((void**)&d, cnt * 8) != hipSuccess) return;
         (void)hipMemsetAsync(d, 0, cnt * 8, s);
-        gin_resident_kernel<true><<<grid, GR_WAVES * 64, 0, s>>>(h0, hout, ecomb_all, chunks_all, pool_w, pool_b, tile_row,
+        if (hubs)
+            gin_resident_kernel<true, true><<<grid, GR_WAVES * 64, 0, s>>>(h0, hout, ecomb_all, chunks_all, pool_w, pool_b, tile_row,
+                                                                           tile_graph, tile_desc, node_off, out, n_tiles, range_flag, d);
+        else
+        gin_resident_kernel<true, false><<<grid, GR_WAVES * 64, 0, s>>>(h0, hout, ecomb_all, chunks_all, pool_w, pool_b, tile_row,
                                                                  tile_graph, tile_desc, node_off, out, n_tiles, range_flag, d);
         std::vector<unsigned long long> hbuf(cnt);
         (void)hipStreamSynchronize(s);
@@ -1175,7 +1276,11 @@ void launch_gin_resident(const float* h0, float* hout, const int* row_ptr, const
                 n_tiles, grid, tot[0] / nw / 100.0, tot[1] / nw / 100.0, tot[2] / nw / 100.0, tot[5] / nw / 100.0, tot[4] / nw / 100.0, tot[3] / nw / 100.0, tot[6] / nw / 100.0);
         return;
     }
-    gin_resident_kernel<false><<<grid, GR_WAVES * 64, 0, s>>>(h0, hout, ecomb_all, chunks_all, pool_w, pool_b, tile_row,
+    if (hubs)
+        gin_resident_kernel<false, true><<<grid, GR_WAVES * 64, 0, s>>>(h0, hout, ecomb_all, chunks_all, pool_w, pool_b, tile_row,
+                                                                        tile_graph, tile_desc, node_off, out, n_tiles, range_flag, nullptr);
+    else
+    gin_resident_kernel<false, false><<<grid, GR_WAVES * 64, 0, s>>>(h0, hout, ecomb_all, chunks_all, pool_w, pool_b, tile_row,
                                                               tile_graph, tile_desc, node_off, out, n_tiles, range_flag, nullptr);
 }
 

@@ -7,7 +7,11 @@ import numpy as np
 from flowgnn_amd import Engine, graphpack as gp, weights
 g = int(sys.argv[1]) if len(sys.argv) > 1 else 1 << 18
 b = gp.synth_molhiv_batch(g, seed=1234)
-e = Engine("GIN", 0)
+vn = "vn" in sys.argv[2:]   # GIN-VN: one virtual node per graph (a hub row of in-degree n), forced through the resident kernel
+if vn:
+    b = gp.add_virtual_nodes(b)
+    os.environ["FLOWGNN_GIN_RESIDENT"] = "1"
+e = Engine("GIN-VN" if vn else "GIN", 0)
 w = weights.synth_gin_weights(7)
 if "zero" in sys.argv[2:]:
     w = {k: np.zeros_like(v) for k, v in w.items()}

@@ -9,7 +9,8 @@ from flowgnn_amd import Engine, graphpack as gp, weights
 
 pytestmark = pytest.mark.gpu
 
-LIMITS = {"GIN": (256, 1280), "GAT": (256, 1280), "GCN": (192, 960)}
+LIMITS = {"GIN": (256, 1280), "GIN-VN": (256, 1280), "GAT": (256, 1280), "GCN": (192, 960)}
+MODELS = ["GIN", "GIN-VN", "GAT", "GCN"]  # GIN-VN: the HUBS form of the resident kernel (rows of more than 8 in-edges are hub rows)
 
 
 def random_graph(n, m, seed):
@@ -28,7 +29,7 @@ def run(model, b, env=None, monkeypatch=None):
     if env:
         for k, v in env.items():
             monkeypatch.setenv(k, v)
-    w = getattr(weights, f"synth_{model.lower()}_weights")(seed=11)
+    w = getattr(weights, f"synth_{model.replace('-VN', '').lower()}_weights")(seed=11)
     e = Engine(model, device=0)
     try:
         e.set_weights(w)
@@ -42,14 +43,14 @@ def run(model, b, env=None, monkeypatch=None):
 
 def check(model, b, oracle, monkeypatch, env=None):
     got, w = run(model, b, env, monkeypatch)
-    want, hd = getattr(oracle, f"{model.lower()}_forward")(b, [w], dump_h=True, nthreads=8)
+    want, hd = getattr(oracle, f"{model.replace('-VN', '').lower()}_forward")(b, [w], dump_h=True, nthreads=8)
     scale = max(1.0, float(np.abs(hd).max()))
     assert np.isfinite(got).all()
     assert np.allclose(got, want, rtol=2e-4, atol=2e-4 * scale), (model, np.abs(got - want).max(), scale)
     return got
 
 
-@pytest.mark.parametrize("model", ["GIN", "GAT", "GCN"])
+@pytest.mark.parametrize("model", MODELS)
 def test_graphs_at_the_tile_limits(model, oracle, monkeypatch):
     rows, edges = LIMITS[model]
     mol = gp.synth_molhiv_batch(40, seed=3)
@@ -58,7 +59,7 @@ def test_graphs_at_the_tile_limits(model, oracle, monkeypatch):
     both = random_graph(rows, edges, seed=4)                  # both at once
     b = gp.concat_batches([mol.slice(0, 13), at_rows, mol.slice(13, 14), at_edges, both, mol.slice(14, 40)])
     resident = check(model, b, oracle, monkeypatch)
-    per_layer = check(model, b, oracle, monkeypatch, env={f"FLOWGNN_{model}_RESIDENT": "0"})
+    per_layer = check(model, b, oracle, monkeypatch, env={f"FLOWGNN_{model.replace('-VN', '')}_RESIDENT": "0"})
     scale = max(1.0, float(np.abs(per_layer).max()))
     assert np.allclose(resident, per_layer, rtol=2e-4, atol=2e-4 * scale)
     # any split of the batch gives the same bits (tiles are re-packed, rows change lanes)
@@ -66,7 +67,7 @@ def test_graphs_at_the_tile_limits(model, oracle, monkeypatch):
     assert np.array_equal(r2, resident[10:20])
 
 
-@pytest.mark.parametrize("model", ["GIN", "GAT", "GCN"])
+@pytest.mark.parametrize("model", MODELS)
 def test_one_graph_beyond_a_limit_sends_the_batch_to_the_per_layer_kernels(model, oracle, monkeypatch):
     rows, edges = LIMITS[model]
     mol = gp.synth_molhiv_batch(30, seed=8)
@@ -74,11 +75,13 @@ def test_one_graph_beyond_a_limit_sends_the_batch_to_the_per_layer_kernels(model
         check(model, gp.concat_batches([mol.slice(0, 20), big, mol.slice(20, 30)]), oracle, monkeypatch)
 
 
-@pytest.mark.parametrize("model", ["GIN", "GAT", "GCN"])
+@pytest.mark.parametrize("model", MODELS)
 def test_many_ragged_tiles(model, oracle, monkeypatch):
     """2 000 molecules: ~200 tiles of different fill on a 256-workgroup grid, and 600 workgroup-strided tiles with 6 000."""
     for g, seed in ((2000, 21), (6000, 22)):
         b = gp.synth_molpcba_batch(g, seed=seed)
+        if model == "GIN-VN":
+            b = gp.add_virtual_nodes(b)
         got, w = run(model, b)
-        want = getattr(oracle, f"{model.lower()}_forward")(b, [w], nthreads=16)
+        want = getattr(oracle, f"{model.replace('-VN', '').lower()}_forward")(b, [w], nthreads=16)
         assert np.allclose(got, want, rtol=2e-4, atol=2e-4 * max(1.0, float(np.abs(want).max()))), np.abs(got - want).max()
