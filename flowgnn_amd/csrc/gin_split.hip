@@ -857,7 +857,7 @@ __device__ __forceinline__ void gr_layer(unsigned long long (&tacc)[6], char* bx
             while (hm) {
                 const int jh = __ffsll((long long)hm) - 1;
                 hm &= hm - 1;
-                const int hb = __shfl(hub_beg[nt], jh, 64), he = __shfl(hub_end[nt], jh, 64);
+                const int hb = __builtin_amdgcn_readlane(hub_beg[nt], jh), he = __builtin_amdgcn_readlane(hub_end[nt], jh);
                 float part[25];
 #pragma unroll
                 for (int k = 0; k < 25; k++) part[k] = 0.0f;
@@ -882,11 +882,13 @@ __device__ __forceinline__ void gr_layer(unsigned long long (&tacc)[6], char* bx
                         part[24] += relu1(s_ecomb[code * GS_D + 96 + g] + xt);
                     }
                 }
-#pragma unroll
-                for (int m = 1; m < 16; m <<= 1) {
-#pragma unroll
-                    for (int k = 0; k < 25; k++) part[k] += __shfl_xor(part[k], m, 64);
-                }
+                // all-reduce over the 16 lanes of the column tile with DPP row rotations (8, 4, 2, 1): every lane adds the same pairs
+                // at every level, so all 16 hold the same bits whichever lane owns the hub
+#define GR_ROR_ADD(CTRL)                                                                                                          \
+    _Pragma("unroll") for (int k = 0; k < 25; k++)                                                                                \
+        part[k] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, part[k]), CTRL, 0xF, 0xF, false));
+                GR_ROR_ADD(0x128) GR_ROR_ADD(0x124) GR_ROR_ADD(0x122) GR_ROR_ADD(0x121)
+#undef GR_ROR_ADD
                 if (j == jh) {
 #pragma unroll
                     for (int k = 0; k < 25; k++) bq[nt][k] += part[k];
