@@ -535,7 +535,7 @@ public:
                 const int grid = db.gtiles.n_tiles < 256 ? db.gtiles.n_tiles : 256;  // persistent: one 8-wave workgroup per CU (153 KB of LDS)
                 dgn_layer_fused_kernel<<<grid, 512, 0, s>>>(db.h[cur], db.h[cur ^ 1], db.csr.row_ptr, db.csr.src, db.csr.out_deg, db.node_eigen,
                                                             d_fused_ + (size_t)l * DGN_FT_LAYER_BYTES, db.gtiles.row_start, db.gtiles.n_tiles,
-                                                            db.range_flag, getenv("FLOWGNN_DGN_ABLATE") ? atoi(getenv("FLOWGNN_DGN_ABLATE")) : 0);
+                                                            db.range_flag, ablate_);
                 cur ^= 1;
                 continue;
             }
@@ -599,6 +599,7 @@ private:
     bool split_ = !(getenv("FLOWGNN_DGN_MFMA") && strcmp(getenv("FLOWGNN_DGN_MFMA"), "f32") == 0);
     // FLOWGNN_DGN_FUSED=0 keeps aggregation and dense update as two kernels per layer (A/B measurements, the aggregation roofline probe)
     bool agg_ready_ = false;  // tiles_ / esc_ describe the batch of the last forward
+    const int ablate_ = getenv("FLOWGNN_DGN_ABLATE") ? atoi(getenv("FLOWGNN_DGN_ABLATE")) : 0;  // development aid: per-phase timing (scripts/dev/pna_ablate.sh)
     bool fused_ = !(getenv("FLOWGNN_DGN_FUSED") && atoi(getenv("FLOWGNN_DGN_FUSED")) == 0);
     uint8_t* d_fused_ = nullptr;  // feature-major weights of the fused layer kernel
     bool exact_ = false;

@@ -991,7 +991,7 @@ public:
             const int grid = db.gtiles.n_tiles < 256 ? db.gtiles.n_tiles : 256;  // persistent: one 16-wave workgroup per CU (118 KB of LDS)
             gat_resident_kernel<<<grid, GATR_WAVES * 64, 0, s>>>(db.b.node_feature, feat_row, db.csr.row_ptr, db.csr.src, db.gtiles.row_start,
                                                                db.gtiles.graph_start, db.b.node_off, db.out, db.gtiles.n_tiles, rw,
-                                                               getenv("FLOWGNN_GAT_ABLATE") ? atoi(getenv("FLOWGNN_GAT_ABLATE")) : 0);
+                                                               ablate_);
             db.final_h = 0;
             db.tap = nullptr;
             db.h_valid = false;  // no per-node tensor leaves the kernel: flowgnn_get_h repeats the pass on the per-layer kernels
@@ -1073,6 +1073,7 @@ private:
     float *d_wskip_s_ = nullptr, *d_wlin_s_ = nullptr, *d_scales_ = nullptr;
     uint8_t* d_res_ = nullptr;  // per-layer fragment stream of gat_resident_kernel
     bool fold_readout_ = !(getenv("FLOWGNN_GAT_FOLD_READOUT") && atoi(getenv("FLOWGNN_GAT_FOLD_READOUT")) == 0);
+    const int ablate_ = getenv("FLOWGNN_GAT_ABLATE") ? atoi(getenv("FLOWGNN_GAT_ABLATE")) : 0;  // development aid: per-phase timing (scripts/dev/pna_ablate.sh)
     bool resident_ = !(getenv("FLOWGNN_GAT_RESIDENT") && atoi(getenv("FLOWGNN_GAT_RESIDENT")) == 0);
     bool keep_h_ = false;
     float *d_lin0_ = nullptr, *d_asrc_ = nullptr, *d_atgt_ = nullptr, *d_wskip_ = nullptr, *d_wlin_ = nullptr, *d_pw_ = nullptr,

@@ -787,7 +787,7 @@ public:
             gcn_resident_kernel<<<grid, GCNR_WAVES * 64, 0, s>>>(db.h[0], db.csr.row_ptr, db.csr.src, db.csr.ecode, db.csr.out_deg, d_res_, d_pw_,
                                                                d_pb_, db.gtiles.row_start, db.gtiles.graph_start, db.b.node_off, db.out,
                                                                db.gtiles.n_tiles, db.range_flag,
-                                                               getenv("FLOWGNN_GCN_ABLATE") ? atoi(getenv("FLOWGNN_GCN_ABLATE")) : 0);
+                                                               ablate_);
             agg_ready_ = false;
             db.final_h = 0;
             db.h_valid = false;  // h[0] holds x_0, not x_4: flowgnn_get_h repeats the pass on the per-layer kernels
@@ -910,6 +910,7 @@ private:
     bool fused_ = !(getenv("FLOWGNN_GCN_UNFUSED") && atoi(getenv("FLOWGNN_GCN_UNFUSED")) != 0);
     uint8_t* d_split_ = nullptr;
     uint8_t* d_res_ = nullptr;  // per-layer stream of gcn_resident_kernel
+    const int ablate_ = getenv("FLOWGNN_GCN_ABLATE") ? atoi(getenv("FLOWGNN_GCN_ABLATE")) : 0;  // development aid: per-phase timing (scripts/dev/pna_ablate.sh)
     bool resident_ = !(getenv("FLOWGNN_GCN_RESIDENT") && atoi(getenv("FLOWGNN_GCN_RESIDENT")) == 0);
     bool keep_h_ = false;
     bool agg_ready_ = false;  // tiles_ / esc_ describe the batch of the last forward

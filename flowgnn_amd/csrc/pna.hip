@@ -663,7 +663,7 @@ public:
                 pna_layer_fused_kernel<<<grid, PNA_FT_WAVES * 64, 0, s>>>(db.h[cur], db.h[cur ^ 1], db.csr.row_ptr, db.csr.src, db.csr.out_deg,
                                                             d_stream_ + (size_t)l * PNA_SPLIT_LAYER_BYTES, d_cb_ + (size_t)l * PNA_D, avg_deg_,
                                                             oscale_[l], db.gtiles.row_start, db.gtiles.n_tiles, db.range_flag,
-                                                            getenv("FLOWGNN_PNA_ABLATE") ? atoi(getenv("FLOWGNN_PNA_ABLATE")) : 0);
+                                                            ablate_);
                 cur ^= 1;
                 continue;
             }
@@ -722,6 +722,7 @@ private:
     // FLOWGNN_PNA_MFMA=f32 keeps the dense update on the fp32 matrix pipe (pna_dense_kernel)
     bool split_ = !(getenv("FLOWGNN_PNA_MFMA") && strcmp(getenv("FLOWGNN_PNA_MFMA"), "f32") == 0);
     // FLOWGNN_PNA_FUSED=0 keeps aggregation and dense update as two kernels per layer (A/B measurements, the aggregation roofline probe)
+    const int ablate_ = getenv("FLOWGNN_PNA_ABLATE") ? atoi(getenv("FLOWGNN_PNA_ABLATE")) : 0;  // development aid: per-phase timing (scripts/dev/pna_ablate.sh)
     bool fused_ = !(getenv("FLOWGNN_PNA_FUSED") && atoi(getenv("FLOWGNN_PNA_FUSED")) == 0);
     bool exact_ = false;
     uint8_t* d_split_ = nullptr;
