@@ -76,7 +76,7 @@ static bool read_eig_txt(const std::string& path, std::vector<float>& eig, size_
 int main(int argc, char** argv) {
     if (argc < 2) {
         fprintf(stderr, "Usage: %s <GIN|GIN-VN|GCN|GAT|PNA|DGN> [--graphs DIR] [--weights DIR] [--num-graphs N] [--trials T] "
-                        "[--out FILE] [--device D] [--numeric f32|q6.10] [XCLBIN File]\n", argv[0]);
+                        "[--out FILE] [--device D] [--numeric f32|q6.10] [--num-tasks T] [XCLBIN File]\n", argv[0]);
         return EXIT_FAILURE;
     }
     const std::string model = argv[1];
@@ -84,7 +84,7 @@ int main(int argc, char** argv) {
     if (mid < 0) { fprintf(stderr, "unknown model %s\n", model.c_str()); return EXIT_FAILURE; }
     std::string graphs = "../graphs", wdir = ".", out_path = "HLS_output.txt", eig_dir = "eig";
     long num_graphs = -1;
-    int trials = 25, device = 0, numeric = FLOWGNN_NUMERIC_F32;
+    int trials = 25, device = 0, numeric = FLOWGNN_NUMERIC_F32, num_tasks = 1;
     for (int i = 2; i < argc; i++) {
         const std::string a = argv[i];
         auto next = [&](const char* what) -> const char* {
@@ -98,6 +98,7 @@ int main(int argc, char** argv) {
         else if (a == "--trials") trials = atoi(next("--trials"));
         else if (a == "--out") out_path = next("--out");
         else if (a == "--device") device = atoi(next("--device"));
+        else if (a == "--num-tasks") num_tasks = atoi(next("--num-tasks"));  // NUM_TASK of the readout (GIN/src/dcl.h:25), GIN / GIN-VN / GCN
         else if (a == "--numeric") numeric = std::string(next("--numeric")) == "q6.10" ? FLOWGNN_NUMERIC_Q6_10 : FLOWGNN_NUMERIC_F32;
         // anything else (e.g. an .xclbin path) is ignored
     }
@@ -109,6 +110,10 @@ int main(int argc, char** argv) {
     flowgnn_engine* eng = nullptr;
     int rc = flowgnn_create(mid, device, &eng);
     if (rc) { fprintf(stderr, "flowgnn_create failed: %d %s\n", rc, flowgnn_last_error(nullptr)); return EXIT_FAILURE; }
+    if (num_tasks != 1) {
+        rc = flowgnn_set_num_tasks(eng, num_tasks);
+        if (rc) { fprintf(stderr, "--num-tasks %d: %d %s\n", num_tasks, rc, flowgnn_last_error(eng)); return EXIT_FAILURE; }
+    }
     rc = flowgnn_load_weights_dir(eng, wdir.c_str());
     if (rc) { fprintf(stderr, "loading weights failed: %d %s\n", rc, flowgnn_last_error(eng)); return EXIT_FAILURE; }
     if (numeric != FLOWGNN_NUMERIC_F32) {  // the reference's ap_fixed<16,6> bit patterns (GIN / GIN-VN)
@@ -181,12 +186,13 @@ int main(int argc, char** argv) {
     printf("%s: %.6f ms per launch, %.6f ms per graph, %.1f graphs/s (%ld graphs, %zu nodes, %zu edges)\n", model.c_str(), ms,
            ms / num_graphs, num_graphs / (ms * 1e-3), num_graphs, N, E);
 
-    std::vector<float> result(num_graphs);
+    std::vector<float> result((size_t)num_graphs * num_tasks);
     rc = flowgnn_get_results(eng, result.data());
     if (rc) { fprintf(stderr, "flowgnn_get_results failed: %d\n", rc); return EXIT_FAILURE; }
     FILE* o = fopen(out_path.c_str(), "w+");
     if (!o) { fprintf(stderr, "cannot write %s\n", out_path.c_str()); return EXIT_FAILURE; }
-    for (long g = 1; g <= num_graphs; g++) fprintf(o, "g%ld: %.8f\n", g, result[g - 1]);  // host.cc:213-222
+    for (long g = 1; g <= num_graphs; g++)  // one line per task, as host.cc:213-222
+        for (int t = 0; t < num_tasks; t++) fprintf(o, "g%ld: %.8f\n", g, result[(size_t)(g - 1) * num_tasks + t]);
     fclose(o);
     flowgnn_destroy(eng);
     return 0;

@@ -45,3 +45,26 @@ def test_host_reports_missing_inputs(tmp_path):
     r = subprocess.run([HOST, "GIN", "--graphs", str(tmp_path), "--weights", str(tmp_path), "--num-graphs", "1"],
                        capture_output=True, text=True, timeout=120)
     assert r.returncode != 0 and "loading weights failed" in r.stderr
+
+
+@pytest.mark.parametrize("model", ["GIN", "GCN"])
+def test_host_multi_task(model, tmp_path, oracle):
+    """--num-tasks: NUM_TASK at run time; HLS_output.txt carries one line per (graph, task), as the reference's host writes it
+    (GIN/src/host.cc:213-222)."""
+    tasks = 5
+    w = weights.SYNTH[model](seed=7, num_tasks=tasks)
+    batch = gp.synth_molpcba_batch(9, seed=4)
+    gdir, wdir, out = tmp_path / "graphs", tmp_path / "weights", tmp_path / "HLS_output.txt"
+    gp.write_pack(batch, str(gdir))
+    weights.SAVERS[model](w, str(wdir))
+    r = subprocess.run([HOST, model, "--graphs", str(gdir), "--weights", str(wdir), "--trials", "1", "--out", str(out), "--num-tasks", str(tasks)],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = open(out).read().strip().splitlines()
+    assert [int(ln.split(":")[0][1:]) for ln in lines] == [g for g in range(1, 10) for _ in range(tasks)]
+    got = np.array([float(ln.split(":")[1]) for ln in lines], dtype=np.float32).reshape(9, tasks)
+    want = getattr(oracle, model.lower() + "_forward")(batch, [w], num_tasks=tasks)
+    assert np.allclose(got, want, rtol=3e-4, atol=3e-4), np.abs(got - want).max()
+    # a model without a multi-task readout refuses
+    r = subprocess.run([HOST, "GAT", "--graphs", str(gdir), "--weights", str(wdir), "--num-tasks", "3"], capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "--num-tasks" in r.stderr
