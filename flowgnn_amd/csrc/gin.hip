@@ -624,6 +624,12 @@ public:
         if ((rc = ginq_upload(qw_, nemb, eemb, w1, b1, w2, b2, pw, pb))) return rc;  // Q6.10 copies (numeric mode 1)
         if ((rc = upload(&d_split_, split))) return rc;
         if ((rc = upload(&d_rsplit_, rsplit))) return rc;
+        {   // the single-task readout folded through the last layer's second linear layer (gin_resident_kernel, gr_layer)
+            std::vector<float> head(GIN_RESIDENT_HEAD_FLOATS);
+            const int l = GIN_L - 1;
+            gin_resident_head_fold(w1 + (size_t)l * GIN_H * GIN_D, w2 + (size_t)l * GIN_D * GIN_H, b2 + (size_t)l * GIN_D, pw, head.data());
+            if ((rc = upload(&d_head_, head))) return rc;
+        }
         if ((rc = upload(&d_chunks_, chunks))) return rc;
         if ((rc = upload(&d_nemb_, v_nemb))) return rc;
         if ((rc = upload(&d_pw_, v_pw))) return rc;
@@ -728,7 +734,8 @@ public:
                 ProfScope p(prof, "gin_resident", s);
                 launch_gin_resident(db.h[0], rows ? db.h[1] : nullptr, db.csr.row_ptr, db.csr.src, db.csr.ecode, d_ecomb_, d_rsplit_, d_pw_, d_pb_,
                                     db.gtiles.row_start, db.gtiles.graph_start, reinterpret_cast<uint8_t*>(perm_.p), db.b.node_off,
-                                    multi ? nullptr : db.out, db.gtiles.n_tiles, db.range_flag, s, virtual_node_);
+                                    multi ? nullptr : db.out, db.gtiles.n_tiles, db.range_flag, s, virtual_node_,
+                                    (!rows && fold_readout_ && head_fold_) ? d_head_ : nullptr);
             }
             db.final_h = rows ? 1 : 0;
             db.h_valid = rows;
@@ -829,6 +836,7 @@ private:
             if (*p) { (void)hipFree(*p); *p = nullptr; }
         if (d_split_) { (void)hipFree(d_split_); d_split_ = nullptr; }
         if (d_rsplit_) { (void)hipFree(d_rsplit_); d_rsplit_ = nullptr; }
+        if (d_head_) { (void)hipFree(d_head_); d_head_ = nullptr; }
         perm_.release();
         qw_.release();
     }
@@ -855,6 +863,8 @@ private:
     double resident_min_fill_ = getenv("FLOWGNN_GIN_RESIDENT_MIN_FILL") ? atof(getenv("FLOWGNN_GIN_RESIDENT_MIN_FILL")) : 0.5;
     uint8_t* d_split_ = nullptr;
     uint8_t* d_rsplit_ = nullptr;  // weight stream of the graph-resident kernel
+    float* d_head_ = nullptr;      // gin_resident_head_fold
+    bool head_fold_ = !(getenv("FLOWGNN_GIN_HEAD_FOLD") && atoi(getenv("FLOWGNN_GIN_HEAD_FOLD")) == 0);
     float* d_chunks_ = nullptr;
     float *d_nemb_ = nullptr, *d_pw_ = nullptr, *d_pb_ = nullptr, *d_ecomb_ = nullptr, *d_w1f_ = nullptr,
           *d_w1tail_ = nullptr, *d_b1p_ = nullptr, *d_w2f_ = nullptr, *d_b2p_ = nullptr;

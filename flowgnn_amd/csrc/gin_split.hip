@@ -482,6 +482,16 @@ __device__ __forceinline__ void grc_issue_chunk(const uint8_t* __restrict__ gchu
     }
 }
 
+// first-layer part of a chunk only (W1 fragments, K-tail, b1: 13 440 B = 13 pieces + 128 B): all the folded last layer reads
+__device__ __forceinline__ void grc_issue_chunk_w1(const uint8_t* __restrict__ gchunk, char* lds_buf, int wave, int lane) {
+    const uint32_t lb = lds_addr_of(lds_buf);
+#pragma unroll
+    for (int p = 0; p < 2; p++) {
+        const int piece = wave + 8 * p;
+        if (piece < 13 || (piece == 13 && lane < 8)) lds_dma16(gchunk + piece * 1024, (uint32_t)lane * 16u, lb + piece * 1024);
+    }
+}
+
 #define GR_LD(off) (*reinterpret_cast<const uint4_t*>(wb + (off) + lane * 16))
 #define GR_SB() __builtin_amdgcn_sched_barrier(0)
 
@@ -491,12 +501,14 @@ __device__ __forceinline__ void grc_issue_chunk(const uint8_t* __restrict__ gchu
 // is always covered by ~120 cycles of matrix pipe, with 16 fragment registers in all.
 // KIND 0: step 0 (first layer's hidden tiles 0,1 only) | 1: steps 1..5 | 2: step 6 (K-step 5 + hidden tile 12, then the packed
 // operand of step 7 is built) | 3: step 7 (packed K-step).
+// KIND 4 / 5: the LAST layer with the readout folded through its second linear layer (head_u, below): hidden tiles only (two / one),
+// each ReLU'd tile is dotted with its slice of u instead of being split for a second layer that is never computed.
 template <int KIND>
 __device__ __forceinline__ void gr_step(const char* wb, int lane, int g, const uint4_t (&in_hi)[2][3], const uint4_t (&in_lo)[2][3],
                                         const uint4_t (&in_tb)[2], uint4_t (&hb_hi)[2], uint4_t (&hb_lo)[2], float4_t (&acc2)[2][GS_T2],
-                                        float& vmax) {
-    constexpr bool DO2 = KIND == 1 || KIND == 2, DO1 = KIND != 3;
-    constexpr int NTL = KIND == 2 ? 1 : 2;
+                                        float& vmax, const float* u_step = nullptr, float* dot = nullptr) {
+    constexpr bool DO2 = KIND == 1 || KIND == 2, DO1 = KIND != 3, DOT = KIND >= 4;
+    constexpr int NTL = (KIND == 2 || KIND == 5) ? 1 : 2;
     uint4_t f0[2], f1[2];  // fragment double buffer: f0 = even units, f1 = odd units
 #define GR_U2_LOAD(F, T) F[0] = GR_LD(GRC_W2_OFF + (2 * (T)) * 1024); F[1] = GR_LD(GRC_W2_OFF + (2 * (T) + 1) * 1024);
 #define GR_U2_MFMA(F, T)                                          \
@@ -529,6 +541,11 @@ __device__ __forceinline__ void gr_step(const char* wb, int lane, int g, const u
     _Pragma("unroll") for (int nt = 0; nt < 2; nt++) {                                                    \
         float4_t r = acc1[nt];                                                                            \
         r.x = gs_relu(r.x); r.y = gs_relu(r.y); r.z = gs_relu(r.z); r.w = gs_relu(r.w);                   \
+        if constexpr (DOT) {                                                                              \
+            const float4 uu = *reinterpret_cast<const float4*>(u_step + 16 * (TL) + 4 * g);              \
+            dot[nt] += r.x * uu.x; dot[nt] += r.y * uu.y; dot[nt] += r.z * uu.z; dot[nt] += r.w * uu.w;   \
+            continue;                                                                                     \
+        }                                                                                                 \
         vmax = __builtin_fmaxf(__builtin_fmaxf(vmax, r.x), r.y);                                          \
         vmax = __builtin_fmaxf(__builtin_fmaxf(vmax, r.z), r.w);                                          \
         if ((TL) == 0) { GS_SPLIT2(r.x, r.y, hb_hi[nt].x, hb_lo[nt].x); GS_SPLIT2(r.z, r.w, hb_hi[nt].y, hb_lo[nt].y); } \
@@ -583,6 +600,8 @@ __device__ __forceinline__ void gr_step(const char* wb, int lane, int g, const u
             acc1[0] = GS_MFMA16(f0[0], in_tb[0], acc1[0]);
             acc1[1] = GS_MFMA16(f0[0], in_tb[1], acc1[1]);
             GR_FINISH(1)
+        } else if constexpr (DOT) {
+            GR_FINISH(0)
         } else {
             GR_FINISH(0)
             // step 6: lanes g = 0 / 1 hold hidden units 192..195 / 196..199 (hi in hb_hi.xy, lo in hb_lo.xy); the packed operand of
@@ -773,15 +792,18 @@ __device__ __forceinline__ void gr_issue_desc(const uint8_t* __restrict__ desc, 
         lds_dma16(reinterpret_cast<const char*>(desc) + (size_t)tile * GR_DESC_BYTES + wave * 1024, (uint32_t)lane * 16u, lds_addr_of(s_desc) + wave * 1024);
 }
 
-template <bool PROF, bool HUBS>
+template <bool PROF, bool HUBS, bool LAST>
 __device__ __forceinline__ void gr_layer(unsigned long long (&tacc)[6], char* bx, char* by, float* s_h, char* s_desc, float* s_dot,
                                          const GrTile& cur, const GrTile& nxt, bool has_next, int next_tile, int l,
                                          const float* __restrict__ h0, const uint8_t* __restrict__ desc, const float* __restrict__ ecomb_all,
                                          const uint8_t* __restrict__ wchunks_all, const float* __restrict__ pool_w,
-                                         float* __restrict__ hout, float& vmax, int wave, int lane) {
+                                         float* __restrict__ hout, float& vmax, int wave, int lane, const float* s_u) {
     constexpr int NT = 2;
     const int j = lane & 15, g = lane >> 4;
-    const bool last = l == 4;
+    constexpr bool last = LAST;  // compile-time: the first four layers carry none of the last layer's code (and registers)
+    // last layer with the readout folded through its second linear layer: h_5 . w = hid . (W2^T w) + b2 . w, so only the hidden tiles
+    // are computed and dotted with u = W2^T w_pred (s_u, pre-divided by the first layer's power-of-two scale)
+    const bool fold = last && s_u != nullptr;
     const uint16_t* s_edge = reinterpret_cast<const uint16_t*>(s_desc);
     const uint16_t* s_rp = reinterpret_cast<const uint16_t*>(s_desc + GR_DESC_RP);
     const uint8_t* s_perm = reinterpret_cast<const uint8_t*>(s_desc + GR_DESC_PERM);
@@ -789,7 +811,8 @@ __device__ __forceinline__ void gr_layer(unsigned long long (&tacc)[6], char* bx
     const int ln = last ? 0 : l + 1;  // the layer whose table is prefetched during step 7 (the next tile starts at layer 0)
     unsigned long long tp = 0;
     if constexpr (PROF) tp = wall_clock64();
-    grc_issue_chunk(wchunks, by, wave, lane);  // chunk 0: lands under the gather
+    if (fold) grc_issue_chunk_w1(wchunks, by, wave, lane);
+    else grc_issue_chunk(wchunks, by, wave, lane);  // chunk 0: lands under the gather
 
     // ---- gather (MP unit) out of LDS: a = h[v] + sum_e relu(h[src_e] + ecomb[code_e]), CSR order
     float bq[NT][25];
@@ -939,14 +962,41 @@ __device__ __forceinline__ void gr_layer(unsigned long long (&tacc)[6], char* bx
 
     // ---- node MLP (NT unit), weights streamed through LDS
     float4_t acc2[NT][GS_T2];
+    uint4_t h_hi[NT], h_lo[NT];
+    float oscale = 1.0f;
+    float dot[NT] = {0.0f, 0.0f};
+    if (fold) {
+        // seven steps of hidden tiles only; the next layer's table (layer 0 of the next tile) lands in bx during step 6, when bx is free
+        // -- the buffers do NOT swap roles after this layer (gin_resident_kernel)
+#pragma unroll 1
+        for (int c = 0; c < GS_STEPS - 1; c++) {
+            char* cb = (c & 1) ? bx : by;
+            char* nb = (c & 1) ? by : bx;
+            if (c + 1 < GS_STEPS - 1) grc_issue_chunk_w1(wchunks + (size_t)(c + 1) * GRC_CHUNK_STRIDE, nb, wave, lane);
+            else gr_issue_ecomb(ecomb_all + (size_t)ln * EDGE_COMBOS * GS_D, nb, wave, lane);
+            if (has_next) {
+                gr_issue_rows(h0, reinterpret_cast<char*>(s_h), nxt, c, wave, lane);
+                if (c == GS_STEPS - 2) gr_issue_rows(h0, reinterpret_cast<char*>(s_h), nxt, c + 1, wave, lane);
+            }
+            if (c < GS_STEPS - 2) gr_step<4>(cb, lane, g, in_hi, in_lo, in_tb, h_hi, h_lo, acc2, vmax, s_u + 32 * c, dot);
+            else gr_step<5>(cb, lane, g, in_hi, in_lo, in_tb, h_hi, h_lo, acc2, vmax, s_u + 32 * c, dot);
+            if (c + 1 < GS_STEPS - 1) {
+                unsigned long long tw = 0;
+                if constexpr (PROF) tw = wall_clock64();
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if constexpr (PROF) { const unsigned long long t = wall_clock64(); tacc[5] += t - tw; tw = t; }
+                __syncthreads();
+                if constexpr (PROF) { const unsigned long long t = wall_clock64(); tacc[4] += t - tw; }
+            }
+        }
+    } else {
 #pragma unroll
     for (int t2 = 0; t2 < GS_T2; t2++) {
         const float4 b = *reinterpret_cast<const float4*>(by + GRC_W2_OFF + (16 * t2 + 4 * g) * 4);
 #pragma unroll
         for (int nt = 0; nt < NT; nt++) acc2[nt][t2] = (float4_t){b.x, b.y, b.z, b.w};
     }
-    const float oscale = *reinterpret_cast<const float*>(by + GRC_W2_OFF + 112 * 4);
-    uint4_t h_hi[NT], h_lo[NT];
+    oscale = *reinterpret_cast<const float*>(by + GRC_W2_OFF + 112 * 4);
 #pragma unroll
     for (int nt = 0; nt < NT; nt++) { h_hi[nt] = (uint4_t){0, 0, 0, 0}; h_lo[nt] = (uint4_t){0, 0, 0, 0}; }
 #pragma unroll 1
@@ -978,6 +1028,7 @@ __device__ __forceinline__ void gr_layer(unsigned long long (&tacc)[6], char* bx
         }
     }
 
+    }
     if constexpr (PROF) { const unsigned long long t = wall_clock64(); tacc[2] += t - tp; tp = t; }
     // ---- epilogue: h' back into the tile (in place: nobody reads the old rows any more), or the readout terms
     if (!last) {
@@ -993,6 +1044,14 @@ __device__ __forceinline__ void gr_layer(unsigned long long (&tacc)[6], char* bx
                     *reinterpret_cast<float4*>(rw + col) = make_float4(r.x, r.y, r.z, r.w);
                 }
             }
+        }
+    } else if (fold) {
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++) {  // 13 hidden tiles x 4 units per lane, then the node's 4 lanes: a fixed order per node
+            float part = dot[nt];
+            part += __shfl_xor(part, 16, 64);
+            part += __shfl_xor(part, 32, 64);
+            if (g == 0) s_dot[row[nt]] = part;
         }
     } else {
 #pragma unroll
@@ -1028,7 +1087,8 @@ __global__ __launch_bounds__(GR_WAVES * 64, 2) void gin_resident_kernel(const fl
                                                                        const int* __restrict__ tile_row, const int* __restrict__ tile_graph,
                                                                        const uint8_t* __restrict__ desc,
                                                                        const int* __restrict__ node_off, float* __restrict__ out, int n_tiles,
-                                                                       int* __restrict__ range_flag, unsigned long long* __restrict__ prof_out) {
+                                                                       int* __restrict__ range_flag, unsigned long long* __restrict__ prof_out,
+                                                                       const float* __restrict__ head_u) {
     __shared__ __attribute__((aligned(16))) char s_a[GRC_CHUNK_BYTES];
     __shared__ __attribute__((aligned(16))) char s_b[GRC_CHUNK_BYTES];
     __shared__ __attribute__((aligned(16))) float s_h[GR_ROWS * GS_D];
@@ -1037,10 +1097,14 @@ __global__ __launch_bounds__(GR_WAVES * 64, 2) void gin_resident_kernel(const fl
     if constexpr (PROF) tk0 = wall_clock64();
     __shared__ __attribute__((aligned(16))) char s_desc[GR_DESC_BYTES];
     __shared__ float s_dot[GR_ROWS];
+    __shared__ __attribute__((aligned(16))) float s_u[208];  // 13 hidden tiles x 16 units  // head_u: the readout folded through the last layer's W2 (gr_layer)
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     int tile = blockIdx.x;
     if (tile >= n_tiles) return;
+    const bool fold_head = head_u != nullptr && out != nullptr && hout == nullptr;
+    if (fold_head && (int)threadIdx.x < 208) s_u[threadIdx.x] = head_u[threadIdx.x];
+    const float head_c = fold_head ? head_u[208] : 0.0f;
     if (wave >= 4) __builtin_amdgcn_s_setprio(1);  // the second-dispatched half loses every arbitration otherwise (MI355X_MICROARCH: static priority)
     GrTile cur = gr_load_tile(tile_row, tile_graph, tile, n_tiles);
     // prologue: this workgroup's first tile (rows, descriptor) and the first table
@@ -1057,12 +1121,20 @@ __global__ __launch_bounds__(GR_WAVES * 64, 2) void gin_resident_kernel(const fl
         const bool has_next = ntile < n_tiles;
         const GrTile nxt = gr_load_tile(tile_row, tile_graph, ntile, n_tiles);  // used five layers from now
 #pragma unroll 1
-        for (int l = 0; l < 5; l++) {
+        for (int l = 0; l < 4; l++) {
             if (!flip)
-                gr_layer<PROF, HUBS>(tacc, s_a, s_b, s_h, s_desc, s_dot, cur, nxt, has_next, ntile, l, h0, desc, ecomb_all, wchunks_all, pool_w, hout, vmax, wave, lane);
+                gr_layer<PROF, HUBS, false>(tacc, s_a, s_b, s_h, s_desc, s_dot, cur, nxt, has_next, ntile, l, h0, desc, ecomb_all, wchunks_all, pool_w, hout, vmax, wave, lane, nullptr);
             else
-                gr_layer<PROF, HUBS>(tacc, s_b, s_a, s_h, s_desc, s_dot, cur, nxt, has_next, ntile, l, h0, desc, ecomb_all, wchunks_all, pool_w, hout, vmax, wave, lane);
+                gr_layer<PROF, HUBS, false>(tacc, s_b, s_a, s_h, s_desc, s_dot, cur, nxt, has_next, ntile, l, h0, desc, ecomb_all, wchunks_all, pool_w, hout, vmax, wave, lane, nullptr);
             flip = !flip;
+        }
+        {
+            const float* su = fold_head ? s_u : nullptr;
+            if (!flip)
+                gr_layer<PROF, HUBS, true>(tacc, s_a, s_b, s_h, s_desc, s_dot, cur, nxt, has_next, ntile, 4, h0, desc, ecomb_all, wchunks_all, pool_w, hout, vmax, wave, lane, su);
+            else
+                gr_layer<PROF, HUBS, true>(tacc, s_b, s_a, s_h, s_desc, s_dot, cur, nxt, has_next, ntile, 4, h0, desc, ecomb_all, wchunks_all, pool_w, hout, vmax, wave, lane, su);
+            if (!fold_head) flip = !flip;  // the folded last layer leaves the next table in its own table buffer
         }
         // readout (GIN/src/finalize.cc:36-113): out[g] = mean_v(h5[v] . w) + b, node order; the terms stay valid until the next
         // tile's last layer rewrites them, so no barrier is needed before the next tile starts
@@ -1072,7 +1144,7 @@ __global__ __launch_bounds__(GR_WAVES * 64, 2) void gin_resident_kernel(const fl
                 const int n0 = node_off[gi], n1 = node_off[gi + 1];
                 float sum = 0.0f;
                 for (int v = n0; v < n1; v++) sum += s_dot[v - cur.t0];
-                out[gi] = sum / (float)(n1 - n0) + pool_b[0];
+                out[gi] = sum / (float)(n1 - n0) + pool_b[0] + head_c;
             }
         }
         if (!has_next) break;
@@ -1156,6 +1228,20 @@ void gin_split_pack_layer(const float* w1, const float* b1, const float* w2, con
 }
 
 size_t gin_resident_layer_bytes() { return (size_t)GS_STEPS * GRC_CHUNK_STRIDE; }
+
+void gin_resident_head_fold(const float* w1_last, const float* w2_last, const float* b2_last, const float* pool_w, float* out) {
+    // the hidden tiles the kernel holds are scaled by s1 (the first layer's weights and bias are pre-scaled by that power of two)
+    const double s1 = (double)pow2_scale(w1_last, (size_t)GS_H * GS_D);
+    for (int k = 0; k < 208; k++) {
+        double a = 0.0;
+        if (k < GS_H)
+            for (int d = 0; d < GS_D; d++) a += (double)w2_last[(size_t)d * GS_H + k] * (double)pool_w[d];
+        out[k] = (float)(a / s1);
+    }
+    double c = 0.0;
+    for (int d = 0; d < GS_D; d++) c += (double)b2_last[d] * (double)pool_w[d];
+    out[208] = (float)c;
+}
 
 void gin_resident_pack_layer(const float* w1, const float* b1, const float* w2, const float* b2, uint8_t* out) {
     std::memset(out, 0, gin_resident_layer_bytes());
@@ -1249,7 +1335,8 @@ void launch_gin_layer_split(const float* h, float* hout, const int* row_ptr, con
 
 void launch_gin_resident(const float* h0, float* hout, const int* row_ptr, const int* src, const uint8_t* ecode, const float* ecomb_all,
                          const uint8_t* chunks_all, const float* pool_w, const float* pool_b, const int* tile_row, const int* tile_graph,
-                         uint8_t* tile_desc, const int* node_off, float* out, int n_tiles, int* range_flag, hipStream_t s, bool hubs) {
+                         uint8_t* tile_desc, const int* node_off, float* out, int n_tiles, int* range_flag, hipStream_t s, bool hubs,
+                         const float* head_u) {
     if (n_tiles <= 0) return;
     static const int order_env = getenv("FLOWGNN_GIN_RESIDENT_NOSORT") ? atoi(getenv("FLOWGNN_GIN_RESIDENT_NOSORT")) : 0;
     const int order = hubs ? 3 : order_env;
@@ -1263,10 +1350,10 @@ void launch_gin_resident(const float* h0, float* hout, const int* row_ptr, const
         (void)hipMemsetAsync(d, 0, cnt * 8, s);
         if (hubs)
             gin_resident_kernel<true, true><<<grid, GR_WAVES * 64, 0, s>>>(h0, hout, ecomb_all, chunks_all, pool_w, pool_b, tile_row,
-                                                                           tile_graph, tile_desc, node_off, out, n_tiles, range_flag, d);
+                                                                           tile_graph, tile_desc, node_off, out, n_tiles, range_flag, d, head_u);
         else
         gin_resident_kernel<true, false><<<grid, GR_WAVES * 64, 0, s>>>(h0, hout, ecomb_all, chunks_all, pool_w, pool_b, tile_row,
-                                                                 tile_graph, tile_desc, node_off, out, n_tiles, range_flag, d);
+                                                                 tile_graph, tile_desc, node_off, out, n_tiles, range_flag, d, head_u);
         std::vector<unsigned long long> hbuf(cnt);
         (void)hipStreamSynchronize(s);
         (void)hipMemcpy(hbuf.data(), d, cnt * 8, hipMemcpyDeviceToHost);
@@ -1280,10 +1367,10 @@ void launch_gin_resident(const float* h0, float* hout, const int* row_ptr, const
     }
     if (hubs)
         gin_resident_kernel<false, true><<<grid, GR_WAVES * 64, 0, s>>>(h0, hout, ecomb_all, chunks_all, pool_w, pool_b, tile_row,
-                                                                        tile_graph, tile_desc, node_off, out, n_tiles, range_flag, nullptr);
+                                                                        tile_graph, tile_desc, node_off, out, n_tiles, range_flag, nullptr, head_u);
     else
     gin_resident_kernel<false, false><<<grid, GR_WAVES * 64, 0, s>>>(h0, hout, ecomb_all, chunks_all, pool_w, pool_b, tile_row,
-                                                              tile_graph, tile_desc, node_off, out, n_tiles, range_flag, nullptr);
+                                                              tile_graph, tile_desc, node_off, out, n_tiles, range_flag, nullptr, head_u);
 }
 
 }  // namespace fg

@@ -6,6 +6,7 @@ behind environment switches (read when a model object is created, e.g. flowgnn_a
     FLOWGNN_GIN_AGG_UNTILED=1    ... with the first, un-tiled aggregation kernel;  FLOWGNN_GIN_AGG_TILE=64|256: other tilings
     FLOWGNN_GIN_MFMA=f32         fp32-MFMA fused layer (the exact fallback)
     FLOWGNN_GIN_SPLIT_NT=1|2     four-wave forms of the split-f16 layer kernel
+    FLOWGNN_GIN_HEAD_FOLD=0      resident kernel with the last layer's second linear layer computed (readout not folded through it)
     FLOWGNN_GIN_RESIDENT=0       per-layer launches instead of the graph-resident multi-layer kernel (FLOWGNN_GAT_RESIDENT=0 likewise)
     FLOWGNN_{GIN,GAT}_FOLD_READOUT=0   separate mean-pool + linear kernel
     FLOWGNN_GCN_UNFUSED=1        tiled_aggregate_kernel<GcnAggPolicy> + dense100_split_kernel
@@ -67,6 +68,7 @@ GIN_VARIANTS = [
     {"FLOWGNN_GIN_UNFUSED": "1", "FLOWGNN_GIN_AGG_TILE": "64"},
     {"FLOWGNN_GIN_UNFUSED": "1", "FLOWGNN_GIN_AGG_TILE": "256"},
     {"FLOWGNN_GIN_MFMA": "f32"},
+    {"FLOWGNN_GIN_HEAD_FOLD": "0"},
     {"FLOWGNN_GIN_RESIDENT": "0"},
     {"FLOWGNN_GIN_RESIDENT": "0", "FLOWGNN_GIN_SPLIT_NT": "1"},
     {"FLOWGNN_GIN_RESIDENT": "0", "FLOWGNN_GIN_SPLIT_NT": "2"},
