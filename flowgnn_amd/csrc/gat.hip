@@ -493,6 +493,9 @@ struct GatResidentDev {
     const float* lin0;         // [16 dim][9][4 head]
     const float* pool_w;       // [16]
     const float* pool_b;
+    // the readout folded through the LAST layer's skip contraction: logit terms are linear in o_3, so sum_{d,h} (pw[d] / 4)
+    // (W_skip_4 o_3)[d][h] = o_3 . u4 with u4 = W_skip_4^T v, v[(d, h)] = pw[d] / 4 -- the last layer needs no MFMA and no weights
+    const float* u4;           // [64]
     int* range_flag;
 };
 
@@ -514,6 +517,7 @@ __global__ __launch_bounds__(GATR_WAVES * 64, 4) void gat_resident_kernel(const 
     __shared__ float s_dot[GATR_ROWS];
     __shared__ __attribute__((aligned(16))) float4 s_att[2 * GAT_D];  // a_src | a_tgt of layer 0 (heads in the float4)
     __shared__ float s_pw[GAT_D];
+    __shared__ __attribute__((aligned(16))) float s_u4[GAT_F];
     // Column owner table: the walk of a 16-lane group takes as many trips as its LONGEST row, so the tile's rows are dealt to the
     // groups in order of decreasing in-degree (counting sort per tile; order inside a degree class is whatever the LDS atomics
     // gave -- placement never changes a row's arithmetic: MFMA columns are independent and a row is summed in CSR order by one lane)
@@ -526,6 +530,7 @@ __global__ __launch_bounds__(GATR_WAVES * 64, 4) void gat_resident_kernel(const 
     for (int i = threadIdx.x; i < GAT_D * ND_FEATURE; i += NT) s_lin0[i] = reinterpret_cast<const float4*>(w.lin0)[i];
     if (threadIdx.x < 2 * GAT_D) s_att[threadIdx.x] = reinterpret_cast<const float4*>(threadIdx.x < GAT_D ? w.a_src : w.a_tgt)[threadIdx.x & (GAT_D - 1)];
     if (threadIdx.x < GAT_D) s_pw[threadIdx.x] = w.pool_w[threadIdx.x];
+    if (threadIdx.x < GAT_F) s_u4[threadIdx.x] = w.u4[threadIdx.x];
     float vmax = 0.0f;
     const uint32_t sw_addr = lds_addr_of(s_w);
     int tile = blockIdx.x;
@@ -623,6 +628,7 @@ __global__ __launch_bounds__(GATR_WAVES * 64, 4) void gat_resident_kernel(const 
         const int e_begin = valid ? (int)s_rp[r] : 0, e_end = valid && !(ablate & 1) ? (int)s_rp[r + 1] : e_begin;  // ablate: development aid (FLOWGNN_GAT_ABLATE)
         // the skip input as split B operand; K-slot e of K-step ks <-> feature 16 (2 ks + (e >> 2)) + 4 g + (e & 3).  Layer 0: the raw
         // features (dims 0..8 of head 0, load_inputs.cc:190-191); later o_{l-1}, whose split for the projection IS this operand
+        float head_pre = 0.0f;
         ds_uint4_t b_hi[2], b_lo[2];
         {
             float bq[16];
@@ -645,13 +651,12 @@ __global__ __launch_bounds__(GATR_WAVES * 64, 4) void gat_resident_kernel(const 
 #pragma unroll 1
         for (int l = 0; l < GAT_L; l++) {
             // this layer's fragments stream in under the gather, which does not use them: 36 pieces of 1 KiB (last layer: W_skip only)
-            {
-                const int np = l == GAT_L - 1 ? 16 : 36;
+            if (l < GAT_L - 1) {  // (the last layer needs none: its skip contraction is folded into the readout, u4)
                 const uint8_t* gl = w.layers + (size_t)l * GATR_LAYER_BYTES;
 #pragma unroll
                 for (int p = 0; p < 3; p++) {
                     const int piece = wv + GATR_WAVES * p;
-                    if (piece < np) lds_dma16(gl + piece * 1024, (uint32_t)lane * 16u, sw_addr + piece * 1024);
+                    if (piece < 36) lds_dma16(gl + piece * 1024, (uint32_t)lane * 16u, sw_addr + piece * 1024);
                 }
             }
             if (l == 1 && has_next) {  // the next tile's descriptor (two dependent scalar round trips), used from layer 3 on
@@ -703,6 +708,17 @@ __global__ __launch_bounds__(GATR_WAVES * 64, 4) void gat_resident_kernel(const 
 #pragma unroll
                 for (int t = 0; t < 4; t++) acc[t] = (float4_t){num[t].x * rd.x, num[t].y * rd.y, num[t].z * rd.z, num[t].w * rd.w};
             }
+            if (l == GAT_L - 1) {
+                // emb[v][d] = mean_h(msg + W_skip_4 o_3)[d][h]; the logit is mean_v(emb[v]) . w + b = mean_v(emb[v] . w) + b
+                // (finalize.cc:46-112), and emb[v] . w = sum (pw[d] / 4) msg[d][h] + o_3 . u4 (head_pre, taken when o_3 was in registers)
+                float part = head_pre;
+#pragma unroll
+                for (int t = 0; t < 4; t++) part += (acc[t].x + acc[t].y + acc[t].z + acc[t].w) / (float)GAT_H * s_pw[4 * t + g];
+                part += __shfl_xor(part, 16, 64);
+                part += __shfl_xor(part, 32, 64);
+                if (g == 0) s_dot[r] = part;
+                break;
+            }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();  // #1: every gather of this layer is done (s_proj / s_sc may be rewritten); the fragments have landed
             const char* wb = s_w;
@@ -722,21 +738,19 @@ __global__ __launch_bounds__(GATR_WAVES * 64, 4) void gat_resident_kernel(const 
                     acc[t] += sk * sk_scale;
                 }
             }
-            if (l == GAT_L - 1) {
-                // emb[v][d] = mean_h(...)[d][h]; the logit is mean_v(emb[v]) . w + b = mean_v(emb[v] . w) + b (finalize.cc:46-112)
-                float part = 0.0f;
-#pragma unroll
-                for (int t = 0; t < 4; t++) part += (acc[t].x + acc[t].y + acc[t].z + acc[t].w) / (float)GAT_H * s_pw[4 * t + g];
-                part += __shfl_xor(part, 16, 64);
-                part += __shfl_xor(part, 32, 64);
-                if (g == 0) s_dot[r] = part;
-                break;
-            }
             // ---- ELU; o_l split once: B operand of the projection now and of the next layer's skip contraction
 #pragma unroll
             for (int t = 0; t < 4; t++) {
                 acc[t].x = acc[t].x <= 0.f ? __expf(acc[t].x) - 1.0f : acc[t].x; acc[t].y = acc[t].y <= 0.f ? __expf(acc[t].y) - 1.0f : acc[t].y;
                 acc[t].z = acc[t].z <= 0.f ? __expf(acc[t].z) - 1.0f : acc[t].z; acc[t].w = acc[t].w <= 0.f ? __expf(acc[t].w) - 1.0f : acc[t].w;
+            }
+            if (l == GAT_L - 2) {  // o_3 . u4: this lane's 16 features (16 t + 4 g + r'), the node's 4 lanes are summed with the message part
+                head_pre = 0.0f;
+#pragma unroll
+                for (int t = 0; t < 4; t++) {
+                    const float4 uu = *reinterpret_cast<const float4*>(s_u4 + 16 * t + 4 * g);
+                    head_pre += acc[t].x * uu.x; head_pre += acc[t].y * uu.y; head_pre += acc[t].z * uu.z; head_pre += acc[t].w * uu.w;
+                }
             }
 #pragma unroll
             for (int ks = 0; ks < 2; ks++) {  // output tiles 2 ks, 2 ks + 1 of the skip contraction are K-step ks of the next two
@@ -915,6 +929,13 @@ public:
             }
             if ((rc = upload(&d_scales_, sc))) return rc;
             if ((rc = upload(&d_res_, res))) return rc;
+            std::vector<float> u4(GAT_F);
+            for (int fi = 0; fi < GAT_F; fi++) {
+                double a = 0.0;
+                for (int fo = 0; fo < GAT_F; fo++) a += (double)t[4][fo >> 2] / (double)GAT_H * (double)M(skip, GAT_L - 1, fo, fi);
+                u4[fi] = (float)a;
+            }
+            if ((rc = upload(&d_u4_, u4))) return rc;
         }
         if ((rc = upload(&d_wlin_s_, wlin_s))) return rc;
         if ((rc = upload(&d_lin0_, lin0))) return rc;
@@ -986,6 +1007,7 @@ public:
             rw.lin0 = d_lin0_;
             rw.pool_w = d_pw_;
             rw.pool_b = d_pb_;
+            rw.u4 = d_u4_;
             rw.range_flag = db.range_flag;
             ProfScope p(prof, "gat_resident", s);
             const int grid = db.gtiles.n_tiles < 256 ? db.gtiles.n_tiles : 256;  // persistent: one 16-wave workgroup per CU (118 KB of LDS)
@@ -1056,7 +1078,7 @@ public:
 
 private:
     void free_all() {
-        float** ptrs[] = {&d_lin0_, &d_asrc_, &d_atgt_, &d_wskip_, &d_wlin_, &d_pw_, &d_pb_, &d_wskip_s_, &d_wlin_s_, &d_scales_};
+        float** ptrs[] = {&d_lin0_, &d_asrc_, &d_atgt_, &d_wskip_, &d_wlin_, &d_pw_, &d_pb_, &d_wskip_s_, &d_wlin_s_, &d_scales_, &d_u4_};
         for (auto p : ptrs)
             if (*p) { (void)hipFree(*p); *p = nullptr; }
         if (d_res_) { (void)hipFree(d_res_); d_res_ = nullptr; }
@@ -1070,7 +1092,7 @@ private:
     bool split_ = !(getenv("FLOWGNN_GAT_MFMA") && strcmp(getenv("FLOWGNN_GAT_MFMA"), "f32") == 0);
     bool exact_ = false;
     float wskip_scale_[GAT_L] = {}, wlin_scale_[GAT_L] = {};
-    float *d_wskip_s_ = nullptr, *d_wlin_s_ = nullptr, *d_scales_ = nullptr;
+    float *d_wskip_s_ = nullptr, *d_wlin_s_ = nullptr, *d_scales_ = nullptr, *d_u4_ = nullptr;
     uint8_t* d_res_ = nullptr;  // per-layer fragment stream of gat_resident_kernel
     bool fold_readout_ = !(getenv("FLOWGNN_GAT_FOLD_READOUT") && atoi(getenv("FLOWGNN_GAT_FOLD_READOUT")) == 0);
     const int ablate_ = getenv("FLOWGNN_GAT_ABLATE") ? atoi(getenv("FLOWGNN_GAT_ABLATE")) : 0;  // development aid: per-phase timing (scripts/dev/pna_ablate.sh)
