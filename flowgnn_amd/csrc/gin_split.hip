@@ -792,7 +792,7 @@ __device__ __forceinline__ void gr_issue_desc(const uint8_t* __restrict__ desc, 
         lds_dma16(reinterpret_cast<const char*>(desc) + (size_t)tile * GR_DESC_BYTES + wave * 1024, (uint32_t)lane * 16u, lds_addr_of(s_desc) + wave * 1024);
 }
 
-template <bool PROF, bool HUBS, bool LAST>
+template <bool PROF, bool HUBS, bool LAST, bool FOLD>
 __device__ __forceinline__ void gr_layer(unsigned long long (&tacc)[6], char* bx, char* by, float* s_h, char* s_desc, float* s_dot,
                                          const GrTile& cur, const GrTile& nxt, bool has_next, int next_tile, int l,
                                          const float* __restrict__ h0, const uint8_t* __restrict__ desc, const float* __restrict__ ecomb_all,
@@ -803,7 +803,7 @@ __device__ __forceinline__ void gr_layer(unsigned long long (&tacc)[6], char* bx
     constexpr bool last = LAST;  // compile-time: the first four layers carry none of the last layer's code (and registers)
     // last layer with the readout folded through its second linear layer: h_5 . w = hid . (W2^T w) + b2 . w, so only the hidden tiles
     // are computed and dotted with u = W2^T w_pred (s_u, pre-divided by the first layer's power-of-two scale)
-    const bool fold = last && s_u != nullptr;
+    constexpr bool fold = LAST && FOLD;  // compile-time as well: the folded kernel carries no second linear layer for its last layer
     const uint16_t* s_edge = reinterpret_cast<const uint16_t*>(s_desc);
     const uint16_t* s_rp = reinterpret_cast<const uint16_t*>(s_desc + GR_DESC_RP);
     const uint8_t* s_perm = reinterpret_cast<const uint8_t*>(s_desc + GR_DESC_PERM);
@@ -1079,7 +1079,7 @@ __device__ __forceinline__ void gr_layer(unsigned long long (&tacc)[6], char* bx
     if constexpr (PROF) { const unsigned long long t = wall_clock64(); tacc[3] += t - tp; }
 }
 
-template <bool PROF, bool HUBS>
+template <bool PROF, bool HUBS, bool FOLD>
 __global__ __launch_bounds__(GR_WAVES * 64, 2) void gin_resident_kernel(const float* __restrict__ h0, float* __restrict__ hout,
                                                                        const float* __restrict__ ecomb_all,
                                                                        const uint8_t* __restrict__ wchunks_all,
@@ -1102,7 +1102,7 @@ __global__ __launch_bounds__(GR_WAVES * 64, 2) void gin_resident_kernel(const fl
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     int tile = blockIdx.x;
     if (tile >= n_tiles) return;
-    const bool fold_head = head_u != nullptr && out != nullptr && hout == nullptr;
+    constexpr bool fold_head = FOLD;  // the launcher instantiates FOLD only with head_u, a single-task readout and no per-node tap
     if (fold_head && (int)threadIdx.x < 208) s_u[threadIdx.x] = head_u[threadIdx.x];
     const float head_c = fold_head ? head_u[208] : 0.0f;
     if (wave >= 4) __builtin_amdgcn_s_setprio(1);  // the second-dispatched half loses every arbitration otherwise (MI355X_MICROARCH: static priority)
@@ -1123,17 +1123,17 @@ __global__ __launch_bounds__(GR_WAVES * 64, 2) void gin_resident_kernel(const fl
 #pragma unroll 1
         for (int l = 0; l < 4; l++) {
             if (!flip)
-                gr_layer<PROF, HUBS, false>(tacc, s_a, s_b, s_h, s_desc, s_dot, cur, nxt, has_next, ntile, l, h0, desc, ecomb_all, wchunks_all, pool_w, hout, vmax, wave, lane, nullptr);
+                gr_layer<PROF, HUBS, false, FOLD>(tacc, s_a, s_b, s_h, s_desc, s_dot, cur, nxt, has_next, ntile, l, h0, desc, ecomb_all, wchunks_all, pool_w, hout, vmax, wave, lane, nullptr);
             else
-                gr_layer<PROF, HUBS, false>(tacc, s_b, s_a, s_h, s_desc, s_dot, cur, nxt, has_next, ntile, l, h0, desc, ecomb_all, wchunks_all, pool_w, hout, vmax, wave, lane, nullptr);
+                gr_layer<PROF, HUBS, false, FOLD>(tacc, s_b, s_a, s_h, s_desc, s_dot, cur, nxt, has_next, ntile, l, h0, desc, ecomb_all, wchunks_all, pool_w, hout, vmax, wave, lane, nullptr);
             flip = !flip;
         }
         {
             const float* su = fold_head ? s_u : nullptr;
             if (!flip)
-                gr_layer<PROF, HUBS, true>(tacc, s_a, s_b, s_h, s_desc, s_dot, cur, nxt, has_next, ntile, 4, h0, desc, ecomb_all, wchunks_all, pool_w, hout, vmax, wave, lane, su);
+                gr_layer<PROF, HUBS, true, FOLD>(tacc, s_a, s_b, s_h, s_desc, s_dot, cur, nxt, has_next, ntile, 4, h0, desc, ecomb_all, wchunks_all, pool_w, hout, vmax, wave, lane, su);
             else
-                gr_layer<PROF, HUBS, true>(tacc, s_b, s_a, s_h, s_desc, s_dot, cur, nxt, has_next, ntile, 4, h0, desc, ecomb_all, wchunks_all, pool_w, hout, vmax, wave, lane, su);
+                gr_layer<PROF, HUBS, true, FOLD>(tacc, s_b, s_a, s_h, s_desc, s_dot, cur, nxt, has_next, ntile, 4, h0, desc, ecomb_all, wchunks_all, pool_w, hout, vmax, wave, lane, su);
             if (!fold_head) flip = !flip;  // the folded last layer leaves the next table in its own table buffer
         }
         // readout (GIN/src/finalize.cc:36-113): out[g] = mean_v(h5[v] . w) + b, node order; the terms stay valid until the next
@@ -1343,17 +1343,25 @@ void launch_gin_resident(const float* h0, float* hout, const int* row_ptr, const
     gin_tile_prep_kernel<<<n_tiles, 256, 0, s>>>(row_ptr, src, ecode, tile_row, tile_desc, n_tiles, order);
     const int grid = n_tiles < 256 ? n_tiles : 256;  // persistent: one 8-wave workgroup per CU (157 KB of LDS)
     static const bool prof = getenv("FLOWGNN_GIN_RESIDENT_PROF") && atoi(getenv("FLOWGNN_GIN_RESIDENT_PROF")) != 0;
+    const bool fold = head_u != nullptr && out != nullptr && hout == nullptr;  // single-task readout, no per-node tap
+    unsigned long long* d = nullptr;
+    const size_t cnt = (size_t)grid * GR_WAVES * 7;
     if (prof) {  // development aid: phase breakdown from s_memrealtime stamps, printed per launch (synchronises!)
-        unsigned long long* d = nullptr;
-        const size_t cnt = (size_t)grid * GR_WAVES * 7;
         if (hipMalloc((void**)&d, cnt * 8) != hipSuccess) return;
         (void)hipMemsetAsync(d, 0, cnt * 8, s);
-        if (hubs)
-            gin_resident_kernel<true, true><<<grid, GR_WAVES * 64, 0, s>>>(h0, hout, ecomb_all, chunks_all, pool_w, pool_b, tile_row,
-                                                                           tile_graph, tile_desc, node_off, out, n_tiles, range_flag, d, head_u);
-        else
-        gin_resident_kernel<true, false><<<grid, GR_WAVES * 64, 0, s>>>(h0, hout, ecomb_all, chunks_all, pool_w, pool_b, tile_row,
-                                                                 tile_graph, tile_desc, node_off, out, n_tiles, range_flag, d, head_u);
+    }
+#define GR_LAUNCH(P, H, F)                                                                                                        \
+    gin_resident_kernel<P, H, F><<<grid, GR_WAVES * 64, 0, s>>>(h0, hout, ecomb_all, chunks_all, pool_w, pool_b, tile_row, tile_graph, \
+                                                                tile_desc, node_off, out, n_tiles, range_flag, d, head_u)
+    if (prof) {
+        if (hubs) { if (fold) GR_LAUNCH(true, true, true); else GR_LAUNCH(true, true, false); }
+        else { if (fold) GR_LAUNCH(true, false, true); else GR_LAUNCH(true, false, false); }
+    } else {
+        if (hubs) { if (fold) GR_LAUNCH(false, true, true); else GR_LAUNCH(false, true, false); }
+        else { if (fold) GR_LAUNCH(false, false, true); else GR_LAUNCH(false, false, false); }
+    }
+#undef GR_LAUNCH
+    if (prof) {
         std::vector<unsigned long long> hbuf(cnt);
         (void)hipStreamSynchronize(s);
         (void)hipMemcpy(hbuf.data(), d, cnt * 8, hipMemcpyDeviceToHost);
@@ -1363,14 +1371,7 @@ void launch_gin_resident(const float* h0, float* hout, const int* row_ptr, const
         const double nw = (double)grid * GR_WAVES;
         fprintf(stderr, "[gin_resident prof] tiles %d grid %d | per wave, us: gather %.1f  wait+barrier %.1f  mlp %.1f (of which step-end DMA wait %.1f, barrier %.1f)  epilogue+barrier %.1f  kernel %.1f\n",
                 n_tiles, grid, tot[0] / nw / 100.0, tot[1] / nw / 100.0, tot[2] / nw / 100.0, tot[5] / nw / 100.0, tot[4] / nw / 100.0, tot[3] / nw / 100.0, tot[6] / nw / 100.0);
-        return;
     }
-    if (hubs)
-        gin_resident_kernel<false, true><<<grid, GR_WAVES * 64, 0, s>>>(h0, hout, ecomb_all, chunks_all, pool_w, pool_b, tile_row,
-                                                                        tile_graph, tile_desc, node_off, out, n_tiles, range_flag, nullptr, head_u);
-    else
-    gin_resident_kernel<false, false><<<grid, GR_WAVES * 64, 0, s>>>(h0, hout, ecomb_all, chunks_all, pool_w, pool_b, tile_row,
-                                                              tile_graph, tile_desc, node_off, out, n_tiles, range_flag, nullptr, head_u);
 }
 
 }  // namespace fg
