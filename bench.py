@@ -9,7 +9,9 @@ head, for G graphs per GPU (weak scaling, default) or G graphs in the whole job 
 (strong scaling), followed for N > 1 by the RCCL all-gather that concatenates the per-graph results.
 Inputs are resident in HBM when the timed region starts (the reference also times kernel execution
 only: run_experiments.sh:44).  Rank 0 prints ONE JSON line, which carries `roofline`, `cpu_baseline`
-(N = 1) and `parity` (GPU logits of the timed batch vs the oracle).
+(N = 1) and `parity` (GPU logits of the timed batch vs the oracle); the default single-GPU GIN run also measures the other
+BASELINE configs after the timed region and reports them as `configs`.  A failed parity check -- headline or any config --
+is exit code 3 after the line is printed.
 
 Run plainly with --gpus N > 1 it starts the N ranks itself (one process per GPU, 127.0.0.1
 rendezvous); under torchrun it uses the launcher's RANK / LOCAL_RANK / WORLD_SIZE.  It refuses to
@@ -46,12 +48,15 @@ MODELS = {
                 # its bound is the f16 matrix pipe (5 layers x 3 x 80 000 flop per node)
                 fused_bytes={"gin_layer_fused": lambda n, e: n * 400 * 2 + n * 4 + e * 5, "gin_resident": lambda n, e: n * 400 + n * 4 + e * 5},
                 layers_per_launch={"gin_resident": 5}, mfma_bound_kernels=("gin_resident",),
+                # dense layers' worth of products one launch EXECUTES: the single-task readout is folded through the last layer's
+                # second linear layer (never computed), so 4.5 of the 5 layers count
+                dense_layers_per_launch={"gin_resident": 4.5},
                 hbm_kernels=("gin_aggregate",), mfma_kernels=("gin_resident", "gin_layer_fused", "gin_mlp"),
                 workload="GIN dim=100, batched ogbg-molhiv-shaped graphs on MI355X (BASELINE configs[1])"),
     "GIN-VN": dict(metric="graphs/sec on ogbg-molhiv (GIN-VN, dim=100)", dataset="molhiv-vn", graphs=1 << 18,
                    agg_bytes=lambda n, e: n * 400 * 2 + e * 20, flops=lambda n, e: n * 80000,
                    fused_bytes={"gin_layer_fused": lambda n, e: n * 400 * 2 + n * 4 + e * 5, "gin_resident": lambda n, e: n * 400 + n * 4 + e * 5},
-                   layers_per_launch={"gin_resident": 5}, mfma_bound_kernels=("gin_resident",),
+                   layers_per_launch={"gin_resident": 5}, mfma_bound_kernels=("gin_resident",), dense_layers_per_launch={"gin_resident": 4.5},
                    hbm_kernels=("gin_aggregate",), mfma_kernels=("gin_resident", "gin_layer_fused", "gin_mlp"),
                    workload="GIN-VN dim=100 (virtual node per graph), ogbg-molhiv-shaped graphs"),
     "GCN": dict(metric="graphs/sec on ogbg-molpcba (GCN, dim=100)", dataset="molpcba", graphs=1 << 18,
@@ -177,6 +182,133 @@ def parity_record(model, got, want, numeric="f32"):
             "ok": bool((err <= bound).all() and np.isfinite(got).all())}
 
 
+def rooflines(model, M, prof, kern, G, N, E, steps, split, qmode):
+    """(roofline of the dominant kernel, roofline of the stand-alone aggregation kernel) from the HIP-event profile of the timed
+    region: algorithmic bytes / flops per launch over the kernel's average launch duration."""
+    agg_bytes, mlp_flops = M["agg_bytes"](N, E), M["flops"](N, E)
+    layer = {k: v for k, v in prof.items() if k in M["hbm_kernels"] + M["mfma_kernels"]}
+    dominant = max(layer.items(), key=lambda kv: kv[1]["total_ms"])[0] if layer else None
+    agg_name = next((k for k in M["hbm_kernels"] if k in kern), M["hbm_kernels"][0])
+    traffic_db = {}
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+        if tj.get(model, {}).get("graphs") == G:
+            traffic_db = tj[model]
+    except (OSError, ValueError):
+        pass
+
+    def traffic_of(name):  # PMC-measured HBM bytes per launch of the same batch (committed profile), or None
+        return (traffic_db.get(name) or {}).get("bytes")
+
+    def tag(obj):  # where `traffic` comes from: a committed rocprofv3 --pmc pass of the same batch, not this run
+        if obj is not None and obj.get("traffic") is not None:
+            obj["traffic_source"] = "profiles/traffic.json: committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the same batch, not this run"
+        return obj
+
+    def hbm_obj(name):
+        if name not in kern:
+            return None
+        nbytes = agg_bytes * M.get("layers_per_launch", {}).get(name, 1)
+        ach = nbytes / (kern[name] * 1e-3) / 1e9
+        obj = {"kernel": name, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+               "frac": ach / HBM_PEAK_GBS, "traffic": traffic_of(name), "avg_ms": kern[name], "bytes_per_launch": nbytes}
+        if name in M.get("moved_bytes", {}):
+            obj["hbm_bytes_moved"] = M["moved_bytes"][name](N, E)
+        return tag(obj)
+
+    roof = None
+    if dominant in M["hbm_kernels"]:
+        roof = hbm_obj(dominant)
+    elif dominant is not None:
+        launches_per_step = prof[dominant]["launches"] / max(steps, 1)
+        t_s = kern[dominant] * 1e-3
+        # dense layers one launch really executes (GIN resident: the folded readout removes the last layer's second linear layer,
+        # so 4.5 of the 5 layers' products are computed and counted)
+        work_flops = mlp_flops * M.get("dense_layers_per_launch", M.get("layers_per_launch", {})).get(dominant, 1)
+        if split:
+            # three f16 products per algorithmic fp32 product, priced against the f16 pipe the kernel uses
+            ach, peak = 3 * work_flops / t_s / 1e12, F16_MFMA_PEAK_TF
+            mfma = {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
+                    "pipe": "f16 (3 products per fp32 product, fp32 accumulate)", "flops_per_launch": 3 * work_flops,
+                    "fp32_equivalent_tflops": work_flops / t_s / 1e12}
+        else:
+            ach = work_flops / t_s / 1e12
+            mfma = {"bound": "mfma", "achieved": ach, "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s",
+                    "frac": ach / FP32_MFMA_PEAK_TF, "pipe": "f32", "flops_per_launch": work_flops}
+        fbf = M.get("fused_bytes")
+        fbf = fbf.get(dominant) if isinstance(fbf, dict) else fbf
+        if split and fbf is not None and dominant not in M.get("mfma_bound_kernels", ()):
+            fb = fbf(N, E)
+            ach = fb / t_s / 1e9
+            roof = {"kernel": dominant, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": ach / HBM_PEAK_GBS, "traffic": traffic_of(dominant), "avg_ms": kern[dominant],
+                    "bytes_per_launch": fb, "mfma": mfma}
+            if dominant in M.get("moved_bytes", {}):
+                roof["hbm_bytes_moved"] = M["moved_bytes"][dominant](N, E)
+        else:
+            roof = dict({"kernel": dominant, "traffic": traffic_of(dominant), "avg_ms": kern[dominant],
+                         "launches_per_step": launches_per_step}, **mfma)
+            if fbf is not None:
+                roof["hbm_bytes_per_launch"] = fbf(N, E)
+        tag(roof)
+        lim = issue_limits(model, dominant)
+        if lim is not None:
+            roof["issue_limit"] = lim
+    agg = hbm_obj(agg_name) if not qmode else None
+    if qmode:
+        roof = None  # integer VALU work (one truncated product at a time): neither of the two rooflines applies
+    return roof, agg
+
+
+def issue_limits(model, kernel):
+    """What the kernel is really limited by, from the committed SQ counter pass of the same batch (profiles/limits.json, made by
+    profiles/make_limits.py from profiles/rNN_<M>_pmc_SQ*.txt): busy share of the matrix pipe, the LDS and VALU issue."""
+    try:
+        lj = json.load(open(os.path.join(ROOT, "profiles", "limits.json")))
+        rec = lj.get(model, {}).get(kernel)
+        return dict(rec, source="profiles/limits.json (committed rocprofv3 --pmc SQ pass of the same batch, not this run)") if rec else None
+    except (OSError, ValueError):
+        return None
+
+
+def measure_config(model, batch, steps, warmup, device, sample_graphs=512):
+    """One of the non-headline configurations in the same process: a few timed steps of the resident batch, the HIP-event
+    profile, the dominant kernel's roofline fraction and a parity check of the first `sample_graphs` graphs against the oracle.
+    Compact on purpose (one JSON line carries all of them)."""
+    from flowgnn_amd import Engine, weights
+    M = MODELS[model]
+    w = weights.SYNTH[model](seed=7)
+    eng = Engine(model, device=device)
+    try:
+        eng.set_weights(w)
+        eng.set_batch(batch)
+        for _ in range(warmup):
+            eng.run()
+        eng.sync()
+        eng.profile_enable(True)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            eng.run()
+        eng.sync()
+        dt = time.perf_counter() - t0
+        prof = eng.profile_read()
+        eng.profile_enable(False)
+        out = eng.results()
+        reruns = eng.exact_reruns()
+    finally:
+        eng.close()
+    G, N, E = batch.num_graphs, batch.total_nodes, batch.total_edges
+    kern = {k: (v["total_ms"] / max(v["launches"], 1)) for k, v in prof.items()}
+    roof, _ = rooflines(model, M, prof, kern, G, N, E, steps, True, False)
+    n = min(G, sample_graphs)
+    want = np.asarray(oracle_forward(model, batch.slice(0, n), w, effective_cpus()), np.float32)
+    par = parity_record(model, out[:n], want)
+    rec = {"value": G * steps / dt, "ms_per_step": dt / steps * 1e3, "graphs": G, "kernel": roof["kernel"] if roof else None,
+           "avg_ms": roof["avg_ms"] if roof else None, "bound": roof["bound"] if roof else None, "frac": roof["frac"] if roof else None,
+           "parity_ok": par["ok"], "max_abs_err": par["max_abs_err"], "exact_reruns": reruns}
+    return {k: (round(v, 4) if isinstance(v, float) and k not in ("value", "max_abs_err") else v) for k, v in rec.items()}
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # multi-GPU plumbing: one process per GPU, graphs are the only parallel dimension (SURVEY 8e)
 # ---------------------------------------------------------------------------------------------------------------------
@@ -296,6 +428,9 @@ def main():
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak: fixed graphs per GPU; strong: ONE job batch cut by sum(N+E) with flowgnn_amd.dist.shard_ranges")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--configs", default="auto", choices=["auto", "on", "off"],
+                    help="also measure the other BASELINE configs (GIN at dataset size, GIN-VN, GCN, GAT, PNA, DGN) in the same run and "
+                         "report them in a compact `configs` object; auto = on for the default single-GPU GIN run")
     ap.add_argument("--numeric", default="f32", choices=["f32", "q6.10"],
                     help="q6.10: the reference's ap_fixed<16,6> bit-faithful mode (a fidelity mode, ~10x slower)")
     args = ap.parse_args()
@@ -339,11 +474,17 @@ def main():
     # no host synchronisation: the gather waits for the readout kernel on the device, and the next step's readout for the
     # gather (flowgnn_set_stream).
     side = torch.cuda.Stream()
-    res = ShardedResults(ranges, rank, "cuda", dist)
+    with torch.cuda.stream(side):  # the pads are zero-filled on the stream that later writes them
+        res = ShardedResults(ranges, rank, "cuda", dist)
+    torch.cuda.synchronize()
     eng.set_stream(side.cuda_stream)
+    bound = [0]
 
     def step():
-        eng.set_results_buffer(res.pad.data_ptr())  # the pair that is free: the previous step's logits may still be travelling
+        ptr = res.pad.data_ptr()  # the pair that is free: the previous step's logits may still be travelling
+        if ptr != bound[0]:       # one GPU: set once; N GPUs: the two pairs alternate (the call itself never waits for the device)
+            eng.set_results_buffer(ptr)
+            bound[0] = ptr
         eng.run()
         res.gather()
 
@@ -380,10 +521,7 @@ def main():
 
     if rank == 0:
         value = total_job_graphs * args.steps / elapsed
-        agg_bytes, mlp_flops = M["agg_bytes"](N, E), M["flops"](N, E)
         kern = {k: (v["total_ms"] / max(v["launches"], 1)) for k, v in prof.items()}
-        layer = {k: v for k, v in prof.items() if k in M["hbm_kernels"] + M["mfma_kernels"]}
-        dominant = max(layer.items(), key=lambda kv: kv[1]["total_ms"])[0] if layer else None
         agg_name = next((k for k in M["hbm_kernels"] if k in kern), M["hbm_kernels"][0])
         qmode = args.numeric != "f32"
         if agg_name not in kern and not qmode:  # fused layer: measure the message-passing unit alone as well
@@ -392,69 +530,9 @@ def main():
             except Exception:  # a model without a standalone aggregation kernel
                 pass
 
-        traffic_db = {}
-        try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
-            if tj.get(args.model, {}).get("graphs") == G:
-                traffic_db = tj[args.model]
-        except (OSError, ValueError):
-            pass
-
-        def traffic_of(name):  # PMC-measured HBM bytes per launch of the same batch (committed profile), or None
-            return (traffic_db.get(name) or {}).get("bytes")
-
-        def hbm_obj(name):
-            if name not in kern:
-                return None
-            nbytes = agg_bytes * M.get("layers_per_launch", {}).get(name, 1)
-            ach = nbytes / (kern[name] * 1e-3) / 1e9
-            obj = {"kernel": name, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                   "frac": ach / HBM_PEAK_GBS, "traffic": traffic_of(name), "avg_ms": kern[name], "bytes_per_launch": nbytes}
-            if name in M.get("moved_bytes", {}):
-                obj["hbm_bytes_moved"] = M["moved_bytes"][name](N, E)
-            return obj
-
-        # the dense updates of every model run as three f16 MFMAs per fp32 product unless FLOWGNN_<M>_MFMA=f32
-        env = {"GIN": "FLOWGNN_GIN_MFMA", "GIN-VN": "FLOWGNN_GIN_MFMA", "GCN": "FLOWGNN_GCN_MFMA", "PNA": "FLOWGNN_PNA_MFMA",
-               "DGN": "FLOWGNN_DGN_MFMA", "GAT": "FLOWGNN_GAT_MFMA"}.get(args.model)
-        split = env is not None and os.environ.get(env, "") != "f32"
-        roof = None
-        if dominant in M["hbm_kernels"]:
-            roof = hbm_obj(dominant)
-        elif dominant is not None:
-            launches_per_step = prof[dominant]["launches"] / max(args.steps, 1)
-            layers_per_launch = M.get("layers_per_launch", {}).get(dominant, 1)
-            t_s = kern[dominant] * 1e-3
-            work_flops = mlp_flops * layers_per_launch
-            if split:
-                # three f16 products per algorithmic fp32 product, priced against the f16 pipe the kernel uses
-                ach, peak = 3 * work_flops / t_s / 1e12, F16_MFMA_PEAK_TF
-                mfma = {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
-                        "pipe": "f16 (3 products per fp32 product, fp32 accumulate)", "flops_per_launch": 3 * work_flops,
-                        "fp32_equivalent_tflops": work_flops / t_s / 1e12}
-            else:
-                ach = work_flops / t_s / 1e12
-                mfma = {"bound": "mfma", "achieved": ach, "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s",
-                        "frac": ach / FP32_MFMA_PEAK_TF, "pipe": "f32", "flops_per_launch": work_flops}
-            fbf = M.get("fused_bytes")
-            fbf = fbf.get(dominant) if isinstance(fbf, dict) else fbf
-            if split and fbf is not None and dominant not in M.get("mfma_bound_kernels", ()):
-                # with the f16 pipe the fused layer's HBM floor (0.7 ms) is above its MFMA floor (0.6 ms): HBM-bound
-                fb = fbf(N, E)
-                ach = fb / t_s / 1e9
-                roof = {"kernel": dominant, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": ach / HBM_PEAK_GBS, "traffic": traffic_of(dominant), "avg_ms": kern[dominant],
-                        "bytes_per_launch": fb, "mfma": mfma}
-                if dominant in M.get("moved_bytes", {}):
-                    roof["hbm_bytes_moved"] = M["moved_bytes"][dominant](N, E)
-            else:
-                roof = dict({"kernel": dominant, "traffic": traffic_of(dominant), "avg_ms": kern[dominant],
-                             "launches_per_step": launches_per_step}, **mfma)
-                if fbf is not None:
-                    roof["hbm_bytes_per_launch"] = fbf(N, E)
-        agg = hbm_obj(agg_name) if not qmode else None
-        if qmode:
-            roof = None  # integer VALU work (one truncated product at a time): neither of the two rooflines applies
+        # the dense updates of every model run as three f16 MFMAs per fp32 product unless option <m>_mfma = 32 ("f32")
+        split = eng.get_option({"GIN-VN": "gin"}.get(args.model, args.model.lower()) + "_mfma") != 32
+        roof, agg = rooflines(args.model, M, prof, kern, G, N, E, args.steps, split, qmode)
         par = f"batch-sharded x{world}, RCCL all-gather of logits" if world > 1 else "single GPU"
         line = {
             "metric": M["metric"],
@@ -481,8 +559,34 @@ def main():
             n = min(G, 4096)
             want = np.asarray(oracle_forward(args.model, batch.slice(0, n), w, effective_cpus(), args.numeric), np.float32)
         line["parity"] = parity_record(args.model, out_local[: want.shape[0]], want, args.numeric)
+        parity_ok = bool(line["parity"]["ok"])
+        do_configs = args.configs == "on" or (args.configs == "auto" and world == 1 and args.model == "GIN" and not args.graphs and not qmode)
+        if do_configs and world == 1:
+            # every BASELINE config in the driver's one run: after the headline's timed region, same process, same GPU
+            eng.close()
+            eng = None
+            from flowgnn_amd import graphpack as gp
+            cfgs = {}
+            csteps, cwarm = max(3, min(args.steps, 10)), 2
+            mol = batch  # the headline's molhiv batch is reused for GAT and (plus virtual nodes) for GIN-VN
+            cfgs["GIN@4113"] = measure_config("GIN", make_batch("molhiv", 4113, 99), 50, 5, local_rank)  # the dataset-sized batch
+            cfgs["GAT"] = measure_config("GAT", mol, csteps, cwarm, local_rank)
+            cfgs["GIN-VN"] = measure_config("GIN-VN", gp.add_virtual_nodes(mol), csteps, cwarm, local_rank)
+            del mol
+            cfgs["GCN"] = measure_config("GCN", make_batch("molpcba", MODELS["GCN"]["graphs"], 1234), csteps, cwarm, local_rank)
+            hep = make_batch("hep10k", MODELS["PNA"]["graphs"], 1234)
+            cfgs["PNA"] = measure_config("PNA", hep, csteps, cwarm, local_rank)
+            cfgs["DGN"] = measure_config("DGN", hep, csteps, cwarm, local_rank)
+            line["configs"] = cfgs
+            parity_ok = parity_ok and all(c["parity_ok"] for c in cfgs.values())
         print(json.dumps(line), flush=True)
-    eng.close()
+        if not parity_ok:
+            sys.stderr.write("bench.py: PARITY FAILURE against the oracle -- the throughput above is not a valid measurement\n")
+            if eng is not None:
+                eng.close()
+            sys.exit(3)
+    if eng is not None:
+        eng.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -56,6 +56,34 @@ def _declare(lib):
     lib.flowgnn_run_aggregation_only.argtypes = [eng, C.c_int, C.c_int, p_float]
     lib.flowgnn_get_aggregate.argtypes = [eng, C.c_int, p_float, p_int, p_float, p_int]
     lib.flowgnn_set_stream.argtypes = [eng, C.c_void_p, C.c_int]
+    grp = C.c_void_p
+    lib.flowgnn_set_option.argtypes = [eng, C.c_char_p, C.c_double]
+    lib.flowgnn_get_option.argtypes = [eng, C.c_char_p, C.POINTER(C.c_double)]
+    lib.flowgnn_option_count.argtypes = []
+    lib.flowgnn_option_name.argtypes = [C.c_int]
+    lib.flowgnn_option_name.restype = C.c_char_p
+    lib.flowgnn_entry_set_devices.argtypes = [C.c_int, p_int]
+    lib.flowgnn_entry_set_option.argtypes = [C.c_int, C.c_char_p, C.c_double]
+    lib.flowgnn_shard_ranges.argtypes = [C.c_int, p_int, p_int, C.c_int, p_int]
+    lib.flowgnn_create_multi.argtypes = [C.c_int, C.c_int, p_int, C.POINTER(grp)]
+    lib.flowgnn_group_destroy.argtypes = [grp]
+    lib.flowgnn_group_size.argtypes = [grp]
+    lib.flowgnn_group_engine.argtypes = [grp, C.c_int]
+    lib.flowgnn_group_engine.restype = C.c_void_p
+    lib.flowgnn_group_last_error.argtypes = [grp]
+    lib.flowgnn_group_last_error.restype = C.c_char_p
+    lib.flowgnn_group_set_weights.argtypes = [grp, C.c_int, C.POINTER(p_float)]
+    lib.flowgnn_group_load_weights_dir.argtypes = [grp, C.c_char_p]
+    lib.flowgnn_group_set_option.argtypes = [grp, C.c_char_p, C.c_double]
+    lib.flowgnn_group_set_num_tasks.argtypes = [grp, C.c_int]
+    lib.flowgnn_group_set_numeric_mode.argtypes = [grp, C.c_int]
+    lib.flowgnn_group_set_batch.argtypes = [grp, C.c_int, p_int, p_int, p_int, p_int, p_int, p_float]
+    lib.flowgnn_group_shards.argtypes = [grp, p_int]
+    lib.flowgnn_group_run.argtypes = [grp]
+    lib.flowgnn_group_sync.argtypes = [grp]
+    lib.flowgnn_group_get_results.argtypes = [grp, p_float]
+    lib.GIN_compute_graphs_mt.argtypes = [C.c_int, p_int, p_int, p_int, p_float, p_int, p_int, p_int] + [p_float] * 8 + [C.c_int]
+    lib.GCN_compute_graphs_mt.argtypes = [C.c_int, p_int, p_int, p_int, p_float, p_int, p_int, p_int] + [p_float] * 11 + [C.c_int]
     lib.GIN_compute_graphs.argtypes = [C.c_int, p_int, p_int, p_int, p_float, p_int, p_int, p_int] + [p_float] * 8
     lib.PNA_compute_graphs.argtypes = [C.c_int, p_int, p_int, p_int, p_float, p_int, p_int] + [p_float] * 10
     lib.DGN_compute_graphs.argtypes = [C.c_int, p_int, p_int, p_int, p_float, p_int, p_float, p_int] + [p_float] * 9
@@ -65,7 +93,12 @@ def _declare(lib):
                  "flowgnn_set_batch", "flowgnn_run", "flowgnn_sync", "flowgnn_get_results",
                  "flowgnn_results_device", "flowgnn_set_results_buffer", "flowgnn_stream", "flowgnn_batch_info", "flowgnn_exact_reruns", "flowgnn_set_numeric_mode", "flowgnn_set_num_tasks", "flowgnn_num_tasks", "flowgnn_get_csr",
                  "flowgnn_get_h", "flowgnn_profile_enable", "flowgnn_profile_read",
-                 "flowgnn_run_aggregation_only", "flowgnn_get_aggregate", "flowgnn_set_stream", "GIN_compute_graphs", "GCN_compute_graphs", "PNA_compute_graphs", "DGN_compute_graphs", "GAT_compute_graphs"):
+                 "flowgnn_run_aggregation_only", "flowgnn_get_aggregate", "flowgnn_set_stream",
+                 "flowgnn_set_option", "flowgnn_get_option", "flowgnn_option_count", "flowgnn_entry_set_devices", "flowgnn_entry_set_option",
+                 "flowgnn_shard_ranges", "flowgnn_create_multi", "flowgnn_group_destroy", "flowgnn_group_size", "flowgnn_group_set_weights",
+                 "flowgnn_group_load_weights_dir", "flowgnn_group_set_option", "flowgnn_group_set_num_tasks", "flowgnn_group_set_numeric_mode",
+                 "flowgnn_group_set_batch", "flowgnn_group_shards", "flowgnn_group_run", "flowgnn_group_sync", "flowgnn_group_get_results",
+                 "GIN_compute_graphs_mt", "GCN_compute_graphs_mt", "GIN_compute_graphs", "GCN_compute_graphs", "PNA_compute_graphs", "DGN_compute_graphs", "GAT_compute_graphs"):
         getattr(lib, name).restype = C.c_int
 
 

@@ -143,9 +143,35 @@ struct DeviceBatch {
     int* range_flag;          // [1] set by a reduced-range kernel whose operands left its accurate range (see Model::set_exact)
 };
 
+// Run-time switches of an engine (flowgnn_set_option / flowgnn_get_option).  Keys and defaults: the table in engine.hip.
+// The environment is consulted in exactly ONE place -- Options::Options(), i.e. once per flowgnn_create -- as
+// FLOWGNN_<KEY IN UPPER CASE> (e.g. gin_resident <- FLOWGNN_GIN_RESIDENT; "f32" reads as 32); flowgnn_set_option overrides.
+// Switches that can change RESULTS (the ablation hooks of the resident / fused kernels) exist only in a -DFLOWGNN_DEV build.
+class Options {
+public:
+    Options();
+    bool set(const char* key, double v);         // false: unknown key
+    bool get(const char* key, double* v) const;  // false: unknown key
+    double num(const char* key) const;           // known keys only (0 for an unknown one)
+    int i(const char* key) const { return (int)num(key); }
+    bool on(const char* key) const { return num(key) != 0.0; }
+private:
+    std::vector<double> v_;
+};
+
+// Development-only ablation bits of the hot kernels: compiled out of the shipped library (the kernels see a constant 0, so the
+// branches and the wrong-result modes behind them do not exist in it); `make DEV=1` builds them in.
+#ifdef FLOWGNN_DEV
+#define FG_ABLATE(x) (x)
+#else
+#define FG_ABLATE(x) 0
+#endif
+
 class Model {
 public:
     virtual ~Model() {}
+    // pull this model's switches out of the engine's options (called at create and after every flowgnn_set_option)
+    virtual void configure(const Options&) {}
     // A model whose default kernels are fp32-accurate only inside an operand range (GIN: split-f16 MFMA) raises
     // DeviceBatch::range_flag when an input leaves it; the engine then calls set_exact(true) and repeats forward().
     virtual void set_exact(bool) {}

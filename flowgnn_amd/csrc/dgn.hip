@@ -149,7 +149,9 @@ __global__ __launch_bounds__(512, 2) void dgn_layer_fused_kernel(const float* __
                                                                   const int* __restrict__ row_ptr, const int* __restrict__ src,
                                                                   const int* __restrict__ out_deg, const float* __restrict__ eig4,
                                                                   const uint8_t* __restrict__ wpk, const int* __restrict__ tile_row,
-                                                                  int n_tiles, int* __restrict__ range_flag, int ablate) {
+                                                                  int n_tiles, int* __restrict__ range_flag, int ablate_arg) {
+    const int ablate = FG_ABLATE(ablate_arg);  // 0 in the shipped build: the branches below fold away (common.h)
+    (void)ablate_arg;
     // one LDS object with the row tile at offset 0: a neighbour row's byte address (row * 400 + 16 g < 2^16) then packs two to a
     // register and the K-step's column is the ds_read's immediate offset -- no address arithmetic inside the seven walks
     constexpr int OFF_W = DGN_FT_ROWS * DGN_D * 4, OFF_SRC = OFF_W + (int)DGN_FT_LAYER_BYTES, OFF_RP = OFF_SRC + DGN_FT_EDGES,
@@ -214,7 +216,7 @@ __global__ __launch_bounds__(512, 2) void dgn_layer_fused_kernel(const float* __
         const bool valid = r < rows;
         const int e_base = valid ? (int)s_rp[r] : 0;
         int indeg = valid ? (int)s_rp[r + 1] - e_base : 0;
-        if (ablate & 1) indeg = 0;  // development aid (FLOWGNN_DGN_ABLATE): timing without the gather
+        if (ablate & 1) indeg = 0;  // development aid (dgn_ablate, -DFLOWGNN_DEV builds): timing without the gather
         const float eig_v = s_eig[valid ? r : 0];
         const long long node = (long long)t0 + (valid ? r : 0);
         const int odeg = out_deg[node];
@@ -391,7 +393,7 @@ public:
     ~DgnModel() override { free_all(); }
     int emb_dim() const override { return DGN_D; }
     int scratch_dim() const override { return 2 * DGN_D; }
-    int aggregate_dim() const override { return 2 * DGN_D; }
+    int aggregate_dim() const override { return qmode_ ? 0 : 2 * DGN_D; }  // fixed-point modes have no float aggregation kernel
     bool has_edge_attr() const override { return false; }
     int num_weight_tensors() const override { return 9; }
     bool weights_ready() const override { return ready_; }
@@ -518,6 +520,7 @@ public:
         const int n = db.b.n_tot;
         if (n <= 0) return 0;
         if (!db.node_eigen) return 1;
+        agg_ready_ = false;  // tiles_ / esc_ are rebuilt by whichever float path runs below; a fixed-point pass leaves none
         if (qmode_) return dgnq_forward(q_, db, prof, s);
         {
             ProfScope p(prof, "atom_encoder", s);
@@ -566,9 +569,18 @@ public:
         return 0;
     }
 
+    void configure(const Options& o) override {
+        if (o.i("tile_nominal") > 0) tile_nominal_ = o.i("tile_nominal");
+        if (o.i("tile_slack") >= 0) tile_slack_ = o.i("tile_slack");
+        split_ = o.i("dgn_mfma") != 32;
+        fused_ = o.on("dgn_fused");
+        ablate_ = FG_ABLATE(o.i("dgn_ablate"));
+        agg_ready_ = false;
+    }
     void set_exact(bool on) override { exact_ = on; }
 
     int aggregation_only(DeviceBatch& db, int layer, hipStream_t s) override {
+        if (qmode_) return 8;  // FLOWGNN_ERR_UNSUPPORTED: the fixed-point forward never builds the float kernels\' inputs (tiles, h rows)
         if (layer < 0 || layer >= DGN_L) return 1;
         if (!agg_ready_) {  // the last forward ran the fused layers
             Profiler none;
@@ -593,14 +605,13 @@ private:
     bool qmode_ = false;  // flowgnn_set_numeric_mode(FLOWGNN_NUMERIC_Q6_10): ap_fixed<16,3> arithmetic
     QPack q_;
     GrowBufI tiles_;  // graph-aligned tile starts of the resident batch (tile_bounds_kernel)
-    int tile_nominal_ = getenv("FLOWGNN_TILE_NOMINAL") ? atoi(getenv("FLOWGNN_TILE_NOMINAL")) : 64;
-    int tile_slack_ = getenv("FLOWGNN_TILE_SLACK") ? atoi(getenv("FLOWGNN_TILE_SLACK")) : 64;
-    // FLOWGNN_DGN_MFMA=f32 keeps the dense update on the fp32 matrix pipe (dgn_dense_kernel)
-    bool split_ = !(getenv("FLOWGNN_DGN_MFMA") && strcmp(getenv("FLOWGNN_DGN_MFMA"), "f32") == 0);
-    // FLOWGNN_DGN_FUSED=0 keeps aggregation and dense update as two kernels per layer (A/B measurements, the aggregation roofline probe)
+    int tile_nominal_ = 64, tile_slack_ = 64;  // options tile_nominal / tile_slack (< 0: these defaults)
+    // dgn_mfma=32 keeps the dense update on the fp32 matrix pipe (dgn_dense_kernel)
+    bool split_ = true;
+    // dgn_fused=0 keeps aggregation and dense update as two kernels per layer (A/B measurements, the aggregation roofline probe)
     bool agg_ready_ = false;  // tiles_ / esc_ describe the batch of the last forward
-    const int ablate_ = getenv("FLOWGNN_DGN_ABLATE") ? atoi(getenv("FLOWGNN_DGN_ABLATE")) : 0;  // development aid: per-phase timing (scripts/dev/pna_ablate.sh)
-    bool fused_ = !(getenv("FLOWGNN_DGN_FUSED") && atoi(getenv("FLOWGNN_DGN_FUSED")) == 0);
+    int ablate_ = 0;  // development aid (-DFLOWGNN_DEV builds only, option dgn_ablate): per-phase timing (scripts/dev/pna_ablate.sh)
+    bool fused_ = true;
     uint8_t* d_fused_ = nullptr;  // feature-major weights of the fused layer kernel
     bool exact_ = false;
     uint8_t* d_split_ = nullptr;

@@ -10,7 +10,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <cctype>
 #include <mutex>
+#include <thread>
 
 namespace fg {
 
@@ -83,6 +85,86 @@ void Profiler::reset() {
     for (auto& x : launches) x = 0;
 }
 
+// ------------------------------------------------------------------ options
+// Every run-time switch of the library, with its default.  Keys ending in _ablate exist only in -DFLOWGNN_DEV builds.
+struct OptionDef { const char* key; double dflt; };
+static const OptionDef kOptionTable[] = {
+    {"hipgraph", 0},              // 1: replay the launch sequence of resident batches of up to 2^20 nodes; 2: of any size
+    {"csr_flat", 0},              // 1: global-memory index build for every graph (A/B)
+    {"tile_nominal", -1},         // rows per tile of the tiled aggregation kernels (< 0: the model's default)
+    {"tile_slack", -1},
+    {"gin_resident", 1}, {"gin_resident_min_fill", 0.5}, {"gin_resident_nosort", 0}, {"gin_resident_prof", 0},
+    {"gin_unfused", 0}, {"gin_mfma", 16}, {"gin_split_nt", 4}, {"gin_fold_readout", 1}, {"gin_head_fold", 1},
+    {"gin_agg_untiled", 0}, {"gin_agg_tile", 128},
+    {"gcn_resident", 1}, {"gcn_unfused", 0}, {"gcn_mfma", 16},
+    {"gat_resident", 1}, {"gat_mfma", 16}, {"gat_fold_readout", 1}, {"gat_reference_quirk", 0},
+    {"pna_fused", 1}, {"pna_mfma", 16}, {"pna_mfma_agg", -1},
+    {"dgn_fused", 1}, {"dgn_mfma", 16}, {"dgn_mfma_agg", -1},
+#ifdef FLOWGNN_DEV
+    {"gcn_ablate", 0}, {"gat_ablate", 0}, {"pna_ablate", 0}, {"dgn_ablate", 0},
+#endif
+};
+constexpr int kNumOptions = (int)(sizeof(kOptionTable) / sizeof(kOptionTable[0]));
+
+static int option_index(const char* key) {
+    if (!key) return -1;
+    for (int i = 0; i < kNumOptions; i++)
+        if (strcmp(kOptionTable[i].key, key) == 0) return i;
+    return -1;
+}
+
+// THE place where the library reads its environment: FLOWGNN_<KEY> seeds option <key> of every engine created afterwards
+// ("f32" reads as 32, for the *_mfma switches); FLOWGNN_DEVICES / FLOWGNN_DEVICE seed the device list of the
+// <M>_compute_graphs entry points (entry_devices below).
+static double env_number(const char* text) {
+    if (strcmp(text, "f32") == 0) return 32.0;
+    if (strcmp(text, "f16") == 0) return 16.0;
+    return atof(text);
+}
+static void read_environment(std::vector<double>* option_values, std::vector<int>* devices) {
+    if (option_values) {
+        option_values->resize(kNumOptions);
+        for (int i = 0; i < kNumOptions; i++) {
+            (*option_values)[i] = kOptionTable[i].dflt;
+            std::string name = "FLOWGNN_";
+            for (const char* c = kOptionTable[i].key; *c; c++) name += (char)toupper((unsigned char)*c);
+            const char* v = getenv(name.c_str());
+            if (v && *v) (*option_values)[i] = env_number(v);
+        }
+    }
+    if (devices) {
+        devices->clear();
+        const char* v = getenv("FLOWGNN_DEVICES");
+        if (!v || !*v) v = getenv("FLOWGNN_DEVICE");
+        if (v && *v) {
+            for (const char* c = v; *c;) {
+                devices->push_back(atoi(c));
+                while (*c && *c != ',') c++;
+                if (*c == ',') c++;
+            }
+        }
+        if (devices->empty()) devices->push_back(0);
+    }
+}
+
+Options::Options() { read_environment(&v_, nullptr); }
+bool Options::set(const char* key, double v) {
+    const int i = option_index(key);
+    if (i < 0) return false;
+    v_[i] = v;
+    return true;
+}
+bool Options::get(const char* key, double* v) const {
+    const int i = option_index(key);
+    if (i < 0) return false;
+    if (v) *v = v_[i];
+    return true;
+}
+double Options::num(const char* key) const {
+    const int i = option_index(key);
+    return i < 0 ? 0.0 : v_[i];
+}
+
 }  // namespace fg
 
 using namespace fg;
@@ -94,6 +176,7 @@ struct flowgnn_engine {
     hipStream_t stream = nullptr;      // the stream every launch goes to
     hipStream_t own_stream = nullptr;  // the engine's own stream (stream == own_stream unless flowgnn_set_stream redirected it)
     Model* model = nullptr;
+    Options opts;   // defaults <- environment (read once, here) <- flowgnn_set_option
     Profiler prof;
     std::string err;
 
@@ -130,7 +213,7 @@ struct flowgnn_engine {
     const float* graph_tap = nullptr;
     int graph_tap_dim = 0, graph_final_h = 0;
     int plain_runs = 0;
-    int graph_mode = getenv("FLOWGNN_HIPGRAPH") ? atoi(getenv("FLOWGNN_HIPGRAPH")) : 0;
+    int graph_mode = 0;  // option hipgraph
     long long graph_replays = 0;
     void drop_graph() {
         if (gexec) (void)hipGraphExecDestroy(gexec);
@@ -199,6 +282,8 @@ int flowgnn_create(int model, int device_id, flowgnn_engine** out) {
     e->model_id = model;
     e->device = device_id;
     e->model = m;
+    e->graph_mode = e->opts.i("hipgraph");
+    m->configure(e->opts);
     int rc = use_device(e);
     if (!rc) {
         hipError_t he = hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking);
@@ -461,7 +546,7 @@ int flowgnn_run(flowgnn_engine* e) {
     int frc = FLOWGNN_OK;
     {
         ProfScope p(e->prof, "build_csr", e->stream);
-        const bool flat = getenv("FLOWGNN_CSR_FLAT") && atoi(getenv("FLOWGNN_CSR_FLAT")) != 0;  // A/B: force the global path
+        const bool flat = e->opts.on("csr_flat");  // A/B: force the global path
         launch_build_csr(e->db.b, e->db.csr, e->has_attr, flat ? (1 << 30) : e->max_nodes, flat ? (1 << 30) : e->max_edges, e->stream);
     }
     e->db.tap = nullptr;
@@ -575,9 +660,9 @@ int flowgnn_results_device(flowgnn_engine* e, void** d_out) {
 int flowgnn_set_results_buffer(flowgnn_engine* e, void* device_ptr) {
     if (!e) return FLOWGNN_ERR_ARG;
     if (!e->batch_ready) return FLOWGNN_ERR_STATE;
-    ENGINE_TRY(e, use_device(e));
-    e->drop_graph();
-    EHIP_TRY(e, hipStreamSynchronize(e->stream));
+    // no device synchronisation: launches are stream-ordered, the pointer only matters to launches enqueued after this call
+    // (a recorded launch sequence bakes the old pointer in, so that is dropped)
+    if (e->gexec) { ENGINE_TRY(e, use_device(e)); e->drop_graph(); }
     e->db.out = device_ptr ? (float*)device_ptr : e->d_out;
     return FLOWGNN_OK;
 }
@@ -632,6 +717,31 @@ int flowgnn_set_numeric_mode(flowgnn_engine* e, int mode) {
     if (rc) e->err = "flowgnn_set_numeric_mode: unknown mode, or the fixed-point readout is single-task and NUM_TASK != 1";
     return rc;
 }
+
+int flowgnn_set_option(flowgnn_engine* e, const char* key, double value) {
+    if (!e || !key) return FLOWGNN_ERR_ARG;
+    ENGINE_TRY(e, use_device(e));
+    e->drop_graph();
+    if (e->stream) EHIP_TRY(e, hipStreamSynchronize(e->stream));
+    if (!e->opts.set(key, value)) {
+        e->err = std::string("flowgnn_set_option: unknown option '") + key + "'";
+        return FLOWGNN_ERR_UNSUPPORTED;
+    }
+    e->graph_mode = e->opts.i("hipgraph");
+    e->model->configure(e->opts);
+    // the batch's graph tiles were packed for the limits the model asked for under the old options: set the batch again
+    e->batch_ready = false;
+    e->ran = false;
+    return FLOWGNN_OK;
+}
+
+int flowgnn_get_option(const flowgnn_engine* e, const char* key, double* value) {
+    if (!e || !key) return FLOWGNN_ERR_ARG;
+    return e->opts.get(key, value) ? FLOWGNN_OK : FLOWGNN_ERR_UNSUPPORTED;
+}
+
+int flowgnn_option_count(void) { return kNumOptions; }
+const char* flowgnn_option_name(int i) { return (i >= 0 && i < kNumOptions) ? kOptionTable[i].key : nullptr; }
 
 int flowgnn_get_csr(flowgnn_engine* e, int* row_ptr, int* src, int* eid, int* out_deg) {
     if (!e) return FLOWGNN_ERR_ARG;
@@ -703,7 +813,7 @@ int flowgnn_run_aggregation_only(flowgnn_engine* e, int layer, int iters, float*
     e->drop_graph();
     int rc = e->model->aggregation_only(e->db, layer, e->stream);  // warm-up; also the model's verdict on `layer`
     if (rc) {
-        e->err = rc == FLOWGNN_ERR_UNSUPPORTED ? "this model has no standalone aggregation kernel" : "flowgnn_run_aggregation_only: bad layer";
+        e->err = rc == FLOWGNN_ERR_UNSUPPORTED ? "no standalone aggregation kernel for this model / numeric mode (the fixed-point modes have none)" : "flowgnn_run_aggregation_only: bad layer";
         return rc;
     }
     hipEvent_t a = nullptr, b = nullptr;
@@ -736,10 +846,10 @@ int flowgnn_get_aggregate(flowgnn_engine* e, int layer, float* h_in_host, int* i
     const int D = e->model->emb_dim(), AD = e->model->aggregate_dim();
     if (in_dim) *in_dim = D;
     if (agg_dim) *agg_dim = AD;
-    if (AD <= 0) { e->err = "this model has no standalone aggregation kernel"; return FLOWGNN_ERR_UNSUPPORTED; }
+    if (AD <= 0) { e->err = "no standalone aggregation kernel for this model / numeric mode (the fixed-point modes have none)"; return FLOWGNN_ERR_UNSUPPORTED; }
     if (e->N == 0 || (!h_in_host && !agg_host)) return FLOWGNN_OK;
     rc = e->model->aggregation_only(e->db, layer, e->stream);
-    if (rc) { e->err = "flowgnn_get_aggregate: bad layer"; return rc; }
+    if (rc) { e->err = rc == FLOWGNN_ERR_UNSUPPORTED ? "flowgnn_get_aggregate: not available in this numeric mode" : "flowgnn_get_aggregate: bad layer"; return rc; }
     EHIP_TRY(e, hipStreamSynchronize(e->stream));
     if (h_in_host)
         EHIP_TRY(e, hipMemcpy(h_in_host, e->db.h[e->db.final_h], sizeof(float) * (size_t)e->N * D, hipMemcpyDeviceToHost));
@@ -748,55 +858,254 @@ int flowgnn_get_aggregate(flowgnn_engine* e, int layer, float* h_in_host, int* i
     return FLOWGNN_OK;
 }
 
-// ------------------------------------------------------------------ reference-compatible entry points
-// Split the batch into runs of constant weight set (reload_weights semantics of
-// GIN/src/GIN_compute.cc:44,51-53) and run each through a process-wide engine per model.
-static std::mutex g_entry_mutex;
-static flowgnn_engine* g_entry_engine[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-// FNV-1a over the tensors of the weight set an entry-point engine holds: a caller that reloads the SAME set on every graph
-// (reload_weights = 1 everywhere is legal in the reference and cheap there) must not pay a repack + upload per graph
-static unsigned long long g_entry_whash[6] = {0, 0, 0, 0, 0, 0};
-static bool g_entry_whash_valid[6] = {false, false, false, false, false, false};
-static unsigned long long hash_tensors(int ntens, const float* const* t, const size_t* elems) {
-    unsigned long long h = 1469598103934665603ull;
-    for (int i = 0; i < ntens; i++) {
-        const unsigned* p = reinterpret_cast<const unsigned*>(t[i]);
-        for (size_t k = 0; k < elems[i]; k++) { h ^= p[k]; h *= 1099511628211ull; }
-        h ^= 0x9e3779b97f4a7c15ull + i;
-        h *= 1099511628211ull;
+// ------------------------------------------------------------------ several devices behind one handle
+// north_star: "that batch dimension is partitioned across the 8 GPUs of one node".  A group = one engine (own stream, own
+// resident shard) per listed device + one host thread per engine for every call that touches the device; the batch is cut
+// into contiguous graph ranges balanced by sum(N + E) (flowgnn_shard_ranges, the C counterpart of flowgnn_amd/dist.py) and
+// the results are written into the caller's buffer in job order.  A device may be listed more than once (two engines on
+// one GPU: what the 1-GPU tests do) -- graphs are independent, so results are bit-identical to the single-engine run.
+}  // extern "C"
+
+struct flowgnn_group {
+    int model_id = 0;
+    std::vector<flowgnn_engine*> eng;
+    std::vector<int> cut;  // [n + 1] graph cuts of the resident batch
+    int num_tasks = 1;
+    std::string err;
+};
+
+namespace {
+template <typename F>
+int group_each(flowgnn_group* g, F fn) {  // fn(i) on every engine, one host thread per engine; first failure wins
+    const int n = (int)g->eng.size();
+    std::vector<int> rc((size_t)n, 0);
+    if (n == 1) {
+        rc[0] = fn(0);
+    } else {
+        std::vector<std::thread> th;
+        th.reserve((size_t)n);
+        for (int i = 0; i < n; i++) th.emplace_back([&, i] { rc[(size_t)i] = fn(i); });
+        for (auto& t : th) t.join();
     }
-    return h;
+    for (int i = 0; i < n; i++)
+        if (rc[(size_t)i]) {
+            g->err = "engine " + std::to_string(i) + " (device " + std::to_string(g->eng[(size_t)i]->device) + "): " + flowgnn_last_error(g->eng[(size_t)i]);
+            return rc[(size_t)i];
+        }
+    return FLOWGNN_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int flowgnn_shard_ranges(int num_graphs, const int* nums_of_nodes, const int* nums_of_edges, int parts, int* cuts) {
+    if (num_graphs < 0 || parts < 1 || !cuts || (num_graphs > 0 && (!nums_of_nodes || !nums_of_edges))) return FLOWGNN_ERR_ARG;
+    long long total = 0;
+    for (int g = 0; g < num_graphs; g++) total += (long long)nums_of_nodes[g] + nums_of_edges[g];
+    // cut r = the first graph index whose cumulative work reaches r / parts of the total (exact integer comparison)
+    cuts[0] = 0;
+    long long cum = 0;
+    int g = 0;
+    for (int r = 1; r < parts; r++) {
+        while (g < num_graphs && cum * parts < total * r) { cum += (long long)nums_of_nodes[g] + nums_of_edges[g]; g++; }
+        cuts[r] = g;
+    }
+    cuts[parts] = num_graphs;
+    return FLOWGNN_OK;
 }
 
-// NUM_TASK of the GIN / GCN entry points: a compile-time constant of the reference build (GIN/src/dcl.h:25, 1 as shipped); a
-// caller whose build uses another value says so with FLOWGNN_NUM_TASK (out is then [num_graphs][NUM_TASK], as in the reference)
-static int entry_num_tasks() {
-    const char* v = getenv("FLOWGNN_NUM_TASK");
-    const int t = v ? atoi(v) : 1;
-    return t >= 1 ? t : 1;
+int flowgnn_create_multi(int model, int n_devices, const int* device_ids, flowgnn_group** out) {
+    if (!out || n_devices < 1 || !device_ids) return FLOWGNN_ERR_ARG;
+    *out = nullptr;
+    flowgnn_group* g = new flowgnn_group();
+    g->model_id = model;
+    for (int i = 0; i < n_devices; i++) {
+        flowgnn_engine* e = nullptr;
+        const int rc = flowgnn_create(model, device_ids[i], &e);
+        if (rc) {
+            for (auto* p : g->eng) flowgnn_destroy(p);
+            delete g;
+            return rc;
+        }
+        g->eng.push_back(e);
+    }
+    g->cut.assign((size_t)n_devices + 1, 0);
+    *out = g;
+    return FLOWGNN_OK;
+}
+
+int flowgnn_group_destroy(flowgnn_group* g) {
+    if (!g) return FLOWGNN_ERR_ARG;
+    for (auto* e : g->eng) flowgnn_destroy(e);
+    delete g;
+    return FLOWGNN_OK;
+}
+
+int flowgnn_group_size(const flowgnn_group* g) { return g ? (int)g->eng.size() : -1; }
+flowgnn_engine* flowgnn_group_engine(flowgnn_group* g, int i) { return (g && i >= 0 && i < (int)g->eng.size()) ? g->eng[(size_t)i] : nullptr; }
+const char* flowgnn_group_last_error(const flowgnn_group* g) { return (g && !g->err.empty()) ? g->err.c_str() : fg::last_error_text(); }
+
+int flowgnn_group_set_weights(flowgnn_group* g, int count, const float* const* tensors) {
+    if (!g) return FLOWGNN_ERR_ARG;
+    return group_each(g, [&](int i) { return flowgnn_set_weights(g->eng[(size_t)i], count, tensors); });
+}
+int flowgnn_group_load_weights_dir(flowgnn_group* g, const char* dir) {
+    if (!g) return FLOWGNN_ERR_ARG;
+    return group_each(g, [&](int i) { return flowgnn_load_weights_dir(g->eng[(size_t)i], dir); });
+}
+int flowgnn_group_set_option(flowgnn_group* g, const char* key, double value) {
+    if (!g) return FLOWGNN_ERR_ARG;
+    return group_each(g, [&](int i) { return flowgnn_set_option(g->eng[(size_t)i], key, value); });
+}
+int flowgnn_group_set_num_tasks(flowgnn_group* g, int num_tasks) {
+    if (!g) return FLOWGNN_ERR_ARG;
+    const int rc = group_each(g, [&](int i) { return flowgnn_set_num_tasks(g->eng[(size_t)i], num_tasks); });
+    if (!rc) g->num_tasks = num_tasks;
+    return rc;
+}
+int flowgnn_group_set_numeric_mode(flowgnn_group* g, int mode) {
+    if (!g) return FLOWGNN_ERR_ARG;
+    return group_each(g, [&](int i) { return flowgnn_set_numeric_mode(g->eng[(size_t)i], mode); });
+}
+
+int flowgnn_group_set_batch(flowgnn_group* g, int num_graphs, const int* nums_of_nodes, const int* nums_of_edges,
+                            const int* node_feature, const int* edge_list, const int* edge_attr, const float* node_eigen) {
+    if (!g || num_graphs < 0) return FLOWGNN_ERR_ARG;
+    if (num_graphs > 0 && (!nums_of_nodes || !nums_of_edges)) return FLOWGNN_ERR_ARG;
+    const int n = (int)g->eng.size();
+    int rc = flowgnn_shard_ranges(num_graphs, nums_of_nodes, nums_of_edges, n, g->cut.data());
+    if (rc) return rc;
+    // node / edge offsets of every cut (the reference's running nodes_offset / edges_offset, GIN/src/GIN_compute.cc:96-97)
+    std::vector<long long> noff((size_t)n + 1, 0), eoff((size_t)n + 1, 0);
+    {
+        long long N = 0, E = 0;
+        int r = 0;
+        for (int gi = 0; gi <= num_graphs; gi++) {
+            while (r <= n && g->cut[(size_t)r] == gi) { noff[(size_t)r] = N; eoff[(size_t)r] = E; r++; }
+            if (gi < num_graphs) { N += nums_of_nodes[gi]; E += nums_of_edges[gi]; }
+        }
+    }
+    return group_each(g, [&](int i) {
+        const int g0 = g->cut[(size_t)i], g1 = g->cut[(size_t)i + 1];
+        const long long n0 = noff[(size_t)i], e0 = eoff[(size_t)i];
+        return flowgnn_set_batch(g->eng[(size_t)i], g1 - g0, nums_of_nodes ? nums_of_nodes + g0 : nullptr,
+                                 nums_of_edges ? nums_of_edges + g0 : nullptr, node_feature ? node_feature + n0 * 9 : nullptr,
+                                 edge_list ? edge_list + e0 * 2 : nullptr, edge_attr ? edge_attr + e0 * 3 : nullptr,
+                                 node_eigen ? node_eigen + n0 * 4 : nullptr);
+    });
+}
+
+int flowgnn_group_shards(const flowgnn_group* g, int* cuts) {
+    if (!g || !cuts) return FLOWGNN_ERR_ARG;
+    for (size_t i = 0; i < g->cut.size(); i++) cuts[i] = g->cut[i];
+    return FLOWGNN_OK;
+}
+
+int flowgnn_group_run(flowgnn_group* g) {
+    if (!g) return FLOWGNN_ERR_ARG;
+    return group_each(g, [&](int i) { return flowgnn_run(g->eng[(size_t)i]); });
+}
+int flowgnn_group_sync(flowgnn_group* g) {
+    if (!g) return FLOWGNN_ERR_ARG;
+    return group_each(g, [&](int i) { return flowgnn_sync(g->eng[(size_t)i]); });
+}
+int flowgnn_group_get_results(flowgnn_group* g, float* out_host) {
+    if (!g) return FLOWGNN_ERR_ARG;
+    if (!out_host && g->cut.back() > 0) return FLOWGNN_ERR_ARG;
+    return group_each(g, [&](int i) {
+        flowgnn_engine* e = g->eng[(size_t)i];
+        if (e->G == 0) return flowgnn_sync(e);
+        return flowgnn_get_results(e, out_host + (size_t)g->cut[(size_t)i] * g->num_tasks);
+    });
+}
+
+// ------------------------------------------------------------------ reference-compatible entry points
+// Split the batch into runs of constant weight set (reload_weights semantics of
+// GIN/src/GIN_compute.cc:44,51-53) and run each through a process-wide group of engines per model: one engine on device 0
+// unless flowgnn_entry_set_devices (or FLOWGNN_DEVICES=0,1,.. at the first call) lists more.
+static std::mutex g_entry_mutex;
+static flowgnn_group* g_entry_group[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+static std::vector<int> g_entry_devices;  // empty: not decided yet (the environment is asked at the first call)
+static std::vector<std::pair<std::string, double>> g_entry_options[6];
+// The weight set an entry-point group holds, kept on the host: a caller that reloads the SAME set on every graph
+// (reload_weights = 1 everywhere is legal in the reference and cheap there) must not pay a repack + upload per graph.
+// Compared with memcmp -- no hash, no collision to reason about.
+static std::vector<float> g_entry_wcopy[6];
+static bool same_weights(int model, int ntens, const float* const* t, const size_t* elems) {
+    size_t total = 0;
+    for (int i = 0; i < ntens; i++) total += elems[i];
+    const std::vector<float>& c = g_entry_wcopy[model];
+    if (c.size() != total) return false;
+    size_t off = 0;
+    for (int i = 0; i < ntens; i++) {
+        if (memcmp(c.data() + off, t[i], elems[i] * sizeof(float)) != 0) return false;
+        off += elems[i];
+    }
+    return true;
+}
+static void remember_weights(int model, int ntens, const float* const* t, const size_t* elems) {
+    std::vector<float>& c = g_entry_wcopy[model];
+    c.clear();
+    for (int i = 0; i < ntens; i++) c.insert(c.end(), t[i], t[i] + elems[i]);
+}
+
+static void entry_drop_groups() {
+    for (int m = 0; m < 6; m++) {
+        if (g_entry_group[m]) flowgnn_group_destroy(g_entry_group[m]);
+        g_entry_group[m] = nullptr;
+        g_entry_wcopy[m].clear();
+    }
+}
+
+int flowgnn_entry_set_devices(int n_devices, const int* device_ids) {
+    if (n_devices < 1 || !device_ids) return FLOWGNN_ERR_ARG;
+    std::lock_guard<std::mutex> lock(g_entry_mutex);
+    entry_drop_groups();
+    g_entry_devices.assign(device_ids, device_ids + n_devices);
+    return FLOWGNN_OK;
+}
+
+int flowgnn_entry_set_option(int model, const char* key, double value) {
+    if (model < 0 || model >= 6 || !key) return FLOWGNN_ERR_ARG;
+    if (option_index(key) < 0) return FLOWGNN_ERR_UNSUPPORTED;
+    std::lock_guard<std::mutex> lock(g_entry_mutex);
+    bool found = false;
+    for (auto& kv : g_entry_options[model])
+        if (kv.first == key) { kv.second = value; found = true; }
+    if (!found) g_entry_options[model].emplace_back(key, value);
+    if (g_entry_group[model]) {
+        g_entry_wcopy[model].clear();
+        return flowgnn_group_set_option(g_entry_group[model], key, value);
+    }
+    return FLOWGNN_OK;
 }
 
 static int compute_graphs_generic(int model, int num_graphs, const int* nums_of_nodes, const int* nums_of_edges,
                                   const int* reload_weights, float* out, const int* node_feature, const float* node_eigen,
                                   const int* edge_list, const int* edge_attr, int ntens, const float* const* tens,
                                   const size_t* tens_elems, int num_tasks = 1) {
-    if (num_graphs < 0) return FLOWGNN_ERR_ARG;
+    if (num_graphs < 0 || num_tasks < 1) return FLOWGNN_ERR_ARG;
     if (num_graphs == 0) return FLOWGNN_OK;
     if (!nums_of_nodes || !nums_of_edges || !reload_weights || !out || !node_feature) return FLOWGNN_ERR_ARG;
     for (int i = 0; i < ntens; i++)
         if (!tens[i]) return FLOWGNN_ERR_ARG;
     if (!reload_weights[0]) return FLOWGNN_ERR_ARG;  // the reference would index weight set -1
     std::lock_guard<std::mutex> lock(g_entry_mutex);
-    flowgnn_engine*& eng = g_entry_engine[model];
-    if (!eng) {
-        const char* dev = getenv("FLOWGNN_DEVICE");
-        int rc = flowgnn_create(model, dev ? atoi(dev) : 0, &eng);
+    flowgnn_group*& grp = g_entry_group[model];
+    if (!grp) {
+        if (g_entry_devices.empty()) read_environment(nullptr, &g_entry_devices);
+        int rc = flowgnn_create_multi(model, (int)g_entry_devices.size(), g_entry_devices.data(), &grp);
         if (rc) return rc;
+        for (auto& kv : g_entry_options[model]) {
+            rc = flowgnn_group_set_option(grp, kv.first.c_str(), kv.second);
+            if (rc) return rc;
+        }
+        g_entry_wcopy[model].clear();
     }
-    if (eng->num_tasks != num_tasks) {
-        int rc = flowgnn_set_num_tasks(eng, num_tasks);
+    if (grp->num_tasks != num_tasks) {
+        int rc = flowgnn_group_set_num_tasks(grp, num_tasks);
         if (rc) return rc;
-        g_entry_whash_valid[model] = false;
+        g_entry_wcopy[model].clear();
     }
     long long noff = 0, eoff = 0;
     int set = -1, g = 0;
@@ -809,21 +1118,19 @@ static int compute_graphs_generic(int model, int num_graphs, const int* nums_of_
         for (int i = g; i < g1; i++) { n += nums_of_nodes[i]; m += nums_of_edges[i]; }
         for (int i = 0; i < ntens; i++) cur[i] = tens[i] + (size_t)set * tens_elems[i];
         int rc = FLOWGNN_OK;
-        const unsigned long long wh = hash_tensors(ntens, cur, tens_elems);
-        if (!g_entry_whash_valid[model] || g_entry_whash[model] != wh) {
-            g_entry_whash_valid[model] = false;
-            rc = flowgnn_set_weights(eng, ntens, cur);
+        if (!same_weights(model, ntens, cur, tens_elems)) {
+            g_entry_wcopy[model].clear();
+            rc = flowgnn_group_set_weights(grp, ntens, cur);
             if (rc) return rc;
-            g_entry_whash[model] = wh;
-            g_entry_whash_valid[model] = true;
+            remember_weights(model, ntens, cur, tens_elems);
         }
-        rc = flowgnn_set_batch(eng, g1 - g, nums_of_nodes + g, nums_of_edges + g, node_feature + noff * 9,
-                               edge_list ? edge_list + eoff * 2 : nullptr, edge_attr ? edge_attr + eoff * 3 : nullptr,
-                               node_eigen ? node_eigen + noff * 4 : nullptr);
+        rc = flowgnn_group_set_batch(grp, g1 - g, nums_of_nodes + g, nums_of_edges + g, node_feature + noff * 9,
+                                     edge_list ? edge_list + eoff * 2 : nullptr, edge_attr ? edge_attr + eoff * 3 : nullptr,
+                                     node_eigen ? node_eigen + noff * 4 : nullptr);
         if (rc) return rc;
-        rc = flowgnn_run(eng);
+        rc = flowgnn_group_run(grp);
         if (rc) return rc;
-        rc = flowgnn_get_results(eng, out + (size_t)g * num_tasks);
+        rc = flowgnn_group_get_results(grp, out + (size_t)g * num_tasks);
         if (rc) return rc;
         noff += n;
         eoff += m;
@@ -832,17 +1139,43 @@ static int compute_graphs_generic(int model, int num_graphs, const int* nums_of_
     return FLOWGNN_OK;
 }
 
+int GIN_compute_graphs_mt(int num_graphs, int* nums_of_nodes, int* nums_of_edges, int* reload_weights, float* out,
+                          int* node_feature_in, int* edge_list_in, int* edge_attr_in, float* node_embedding_weight_in,
+                          float* edge_embedding_weight_in, float* node_mlp_1_weights, float* node_mlp_1_bias,
+                          float* node_mlp_2_weights, float* node_mlp_2_bias, float* graph_pred_weights_in,
+                          float* graph_pred_bias_in, int num_tasks) {
+    const float* t[8] = {node_embedding_weight_in, edge_embedding_weight_in, node_mlp_1_weights, node_mlp_1_bias,
+                         node_mlp_2_weights,       node_mlp_2_bias,          graph_pred_weights_in, graph_pred_bias_in};
+    if (num_tasks < 1) return FLOWGNN_ERR_ARG;
+    const int T = num_tasks;
+    const size_t sz[8] = {173 * 100, 5 * 13 * 100, 5 * 200 * 100, 5 * 200, 5 * 100 * 200, 5 * 100, (size_t)T * 100, (size_t)T};
+    return compute_graphs_generic(FLOWGNN_MODEL_GIN, num_graphs, nums_of_nodes, nums_of_edges, reload_weights, out,
+                                  node_feature_in, nullptr, edge_list_in, edge_attr_in, 8, t, sz, T);
+}
+
 int GIN_compute_graphs(int num_graphs, int* nums_of_nodes, int* nums_of_edges, int* reload_weights, float* out,
                        int* node_feature_in, int* edge_list_in, int* edge_attr_in, float* node_embedding_weight_in,
                        float* edge_embedding_weight_in, float* node_mlp_1_weights, float* node_mlp_1_bias,
                        float* node_mlp_2_weights, float* node_mlp_2_bias, float* graph_pred_weights_in,
                        float* graph_pred_bias_in) {
-    const float* t[8] = {node_embedding_weight_in, edge_embedding_weight_in, node_mlp_1_weights, node_mlp_1_bias,
-                         node_mlp_2_weights,       node_mlp_2_bias,          graph_pred_weights_in, graph_pred_bias_in};
-    const int T = entry_num_tasks();
-    const size_t sz[8] = {173 * 100, 5 * 13 * 100, 5 * 200 * 100, 5 * 200, 5 * 100 * 200, 5 * 100, (size_t)T * 100, (size_t)T};
-    return compute_graphs_generic(FLOWGNN_MODEL_GIN, num_graphs, nums_of_nodes, nums_of_edges, reload_weights, out,
-                                  node_feature_in, nullptr, edge_list_in, edge_attr_in, 8, t, sz, T);
+    return GIN_compute_graphs_mt(num_graphs, nums_of_nodes, nums_of_edges, reload_weights, out, node_feature_in, edge_list_in,
+                                 edge_attr_in, node_embedding_weight_in, edge_embedding_weight_in, node_mlp_1_weights, node_mlp_1_bias,
+                                 node_mlp_2_weights, node_mlp_2_bias, graph_pred_weights_in, graph_pred_bias_in, 1);
+}
+
+int GCN_compute_graphs_mt(int num_graphs, int* nums_of_nodes, int* nums_of_edges, int* reload_weights, float* out,
+                          int* node_feature_in, int* edge_list_in, int* edge_attr_in, float* node_embedding_weight_in,
+                          float* edge_embedding_weight_in, float* convs_weight_in, float* convs_bias_in,
+                          float* convs_root_emb_weight_in, float* bn_weight_in, float* bn_bias_in, float* bn_mean_in,
+                          float* bn_var_in, float* graph_pred_weights_in, float* graph_pred_bias_in, int num_tasks) {
+    if (num_tasks < 1) return FLOWGNN_ERR_ARG;
+    const float* t[11] = {node_embedding_weight_in, edge_embedding_weight_in, convs_weight_in, convs_bias_in,
+                          convs_root_emb_weight_in, bn_weight_in, bn_bias_in, bn_mean_in, bn_var_in,
+                          graph_pred_weights_in, graph_pred_bias_in};
+    const int T = num_tasks;
+    const size_t sz[11] = {173 * 100, 5 * 13 * 100, 5 * 100 * 100, 500, 500, 500, 500, 500, 500, (size_t)T * 100, (size_t)T};
+    return compute_graphs_generic(FLOWGNN_MODEL_GCN, num_graphs, nums_of_nodes, nums_of_edges, reload_weights, out,
+                                  node_feature_in, nullptr, edge_list_in, edge_attr_in, 11, t, sz, T);
 }
 
 int GCN_compute_graphs(int num_graphs, int* nums_of_nodes, int* nums_of_edges, int* reload_weights, float* out,
@@ -850,13 +1183,10 @@ int GCN_compute_graphs(int num_graphs, int* nums_of_nodes, int* nums_of_edges, i
                        float* edge_embedding_weight_in, float* convs_weight_in, float* convs_bias_in,
                        float* convs_root_emb_weight_in, float* bn_weight_in, float* bn_bias_in, float* bn_mean_in,
                        float* bn_var_in, float* graph_pred_weights_in, float* graph_pred_bias_in) {
-    const float* t[11] = {node_embedding_weight_in, edge_embedding_weight_in, convs_weight_in, convs_bias_in,
-                          convs_root_emb_weight_in, bn_weight_in, bn_bias_in, bn_mean_in, bn_var_in,
-                          graph_pred_weights_in, graph_pred_bias_in};
-    const int T = entry_num_tasks();
-    const size_t sz[11] = {173 * 100, 5 * 13 * 100, 5 * 100 * 100, 500, 500, 500, 500, 500, 500, (size_t)T * 100, (size_t)T};
-    return compute_graphs_generic(FLOWGNN_MODEL_GCN, num_graphs, nums_of_nodes, nums_of_edges, reload_weights, out,
-                                  node_feature_in, nullptr, edge_list_in, edge_attr_in, 11, t, sz, T);
+    return GCN_compute_graphs_mt(num_graphs, nums_of_nodes, nums_of_edges, reload_weights, out, node_feature_in, edge_list_in,
+                                 edge_attr_in, node_embedding_weight_in, edge_embedding_weight_in, convs_weight_in, convs_bias_in,
+                                 convs_root_emb_weight_in, bn_weight_in, bn_bias_in, bn_mean_in, bn_var_in, graph_pred_weights_in,
+                                 graph_pred_bias_in, 1);
 }
 
 int PNA_compute_graphs(int num_graphs, int* nums_of_nodes, int* nums_of_edges, int* reload_weights, float* out,

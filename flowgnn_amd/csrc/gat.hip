@@ -505,8 +505,10 @@ __global__ __launch_bounds__(GATR_WAVES * 64, 4) void gat_resident_kernel(const 
                                                                          const int* __restrict__ row_ptr, const int* __restrict__ src,
                                                                          const int* __restrict__ tile_row, const int* __restrict__ tile_graph,
                                                                          const int* __restrict__ node_off, float* __restrict__ out, int n_tiles,
-                                                                         GatResidentDev w, int ablate) {
-    const bool sort_rows = !(ablate & 4);  // development aid: FLOWGNN_GAT_ABLATE=4 keeps rows in natural order
+                                                                         GatResidentDev w, int ablate_arg) {
+    const int ablate = FG_ABLATE(ablate_arg);  // 0 in the shipped build: the branches below fold away (common.h)
+    (void)ablate_arg;
+    const bool sort_rows = !(ablate & 4);  // development aid: gat_ablate, -DFLOWGNN_DEV builds=4 keeps rows in natural order
     __shared__ __attribute__((aligned(16))) char s_w[GATR_LAYER_BYTES];  // this layer's fragments
     __shared__ __attribute__((aligned(16))) float4 s_proj[GATR_ROWS * 16];
     __shared__ __attribute__((aligned(16))) float4 s_sc[GATR_ROWS * 2];
@@ -625,7 +627,7 @@ __global__ __launch_bounds__(GATR_WAVES * 64, 4) void gat_resident_kernel(const 
         const int r = s_perm[wv * 16 + j];
         const bool valid = r < rows;
         const int rr = valid ? r : 0;  // rows past the tile's end repeat row 0's self edge (finite values, never used)
-        const int e_begin = valid ? (int)s_rp[r] : 0, e_end = valid && !(ablate & 1) ? (int)s_rp[r + 1] : e_begin;  // ablate: development aid (FLOWGNN_GAT_ABLATE)
+        const int e_begin = valid ? (int)s_rp[r] : 0, e_end = valid && !(ablate & 1) ? (int)s_rp[r + 1] : e_begin;  // ablate: development aid (gat_ablate, -DFLOWGNN_DEV builds)
         // the skip input as split B operand; K-slot e of K-step ks <-> feature 16 (2 ks + (e >> 2)) + 4 g + (e & 3).  Layer 0: the raw
         // features (dims 0..8 of head 0, load_inputs.cc:190-191); later o_{l-1}, whose split for the projection IS this operand
         float head_pre = 0.0f;
@@ -815,6 +817,13 @@ public:
     bool has_edge_attr() const override { return false; }
     int num_weight_tensors() const override { return 6; }
     bool weights_ready() const override { return ready_; }
+    void configure(const Options& o) override {
+        split_ = o.i("gat_mfma") != 32;
+        reference_quirk_ = o.on("gat_reference_quirk");
+        fold_readout_ = o.on("gat_fold_readout");
+        resident_ = o.on("gat_resident");
+        ablate_ = FG_ABLATE(o.i("gat_ablate"));
+    }
     void set_exact(bool on) override { exact_ = on; }
 
     // host tensors (GAT/src/dcl.h:86-93): scoring_fn_target[5][4][16], scoring_fn_source[5][4][16],
@@ -989,9 +998,8 @@ public:
         float* scoreb[2] = {db.scratch + (size_t)n * 2 * GAT_F, db.scratch + (size_t)n * (2 * GAT_F + 8)};
         float* emb = db.scratch + (size_t)n * (2 * GAT_F + 16);
         int* feat_row = nullptr;
-        // FLOWGNN_GAT_REFERENCE_QUIRK=1: node features read without the per-graph offset (GAT_compute.cc:72)
-        const char* q = getenv("FLOWGNN_GAT_REFERENCE_QUIRK");
-        if (q && atoi(q) != 0) {
+        // gat_reference_quirk=1: node features read without the per-graph offset (GAT_compute.cc:72)
+        if (reference_quirk_) {
             feat_row = reinterpret_cast<int*>(db.scratch + (size_t)n * (2 * GAT_F + 16 + GAT_D));
             gat_local_rows_kernel<<<(db.b.num_graphs + 3) / 4, 256, 0, s>>>(db.b.node_off, feat_row, db.b.num_graphs);
         }
@@ -1089,14 +1097,15 @@ private:
     QPack q_;
     // the two 64 x 64 contractions per layer as split-f16 products unless FLOWGNN_GAT_MFMA=f32; exact_ = the engine asked for the
     // fp32 pipe after an operand left the split's accurate range (flowgnn_sync)
-    bool split_ = !(getenv("FLOWGNN_GAT_MFMA") && strcmp(getenv("FLOWGNN_GAT_MFMA"), "f32") == 0);
+    bool split_ = true;
+    bool reference_quirk_ = false;
     bool exact_ = false;
     float wskip_scale_[GAT_L] = {}, wlin_scale_[GAT_L] = {};
     float *d_wskip_s_ = nullptr, *d_wlin_s_ = nullptr, *d_scales_ = nullptr, *d_u4_ = nullptr;
     uint8_t* d_res_ = nullptr;  // per-layer fragment stream of gat_resident_kernel
-    bool fold_readout_ = !(getenv("FLOWGNN_GAT_FOLD_READOUT") && atoi(getenv("FLOWGNN_GAT_FOLD_READOUT")) == 0);
-    const int ablate_ = getenv("FLOWGNN_GAT_ABLATE") ? atoi(getenv("FLOWGNN_GAT_ABLATE")) : 0;  // development aid: per-phase timing (scripts/dev/pna_ablate.sh)
-    bool resident_ = !(getenv("FLOWGNN_GAT_RESIDENT") && atoi(getenv("FLOWGNN_GAT_RESIDENT")) == 0);
+    bool fold_readout_ = true;
+    int ablate_ = 0;  // development aid (-DFLOWGNN_DEV builds only, option gat_ablate): per-phase timing (scripts/dev/pna_ablate.sh)
+    bool resident_ = true;
     bool keep_h_ = false;
     float *d_lin0_ = nullptr, *d_asrc_ = nullptr, *d_atgt_ = nullptr, *d_wskip_ = nullptr, *d_wlin_ = nullptr, *d_pw_ = nullptr,
           *d_pb_ = nullptr;

@@ -350,7 +350,9 @@ __global__ __launch_bounds__(GCNR_WAVES * 64, 3) void gcn_resident_kernel(const 
                                                                          const float* __restrict__ pool_w, const float* __restrict__ pool_b,
                                                                          const int* __restrict__ tile_row, const int* __restrict__ tile_graph,
                                                                          const int* __restrict__ node_off, float* __restrict__ out, int n_tiles,
-                                                                         int* __restrict__ range_flag, int ablate) {
+                                                                         int* __restrict__ range_flag, int ablate_arg) {
+    const int ablate = FG_ABLATE(ablate_arg);  // 0 in the shipped build: the branches below fold away (common.h)
+    (void)ablate_arg;
     constexpr int OT = GCN_OT, NT = GCNR_WAVES * 64;
     constexpr int TAIL_OFF = OT * 6 * 1024, BIAS_OFF = TAIL_OFF + OT * 256, SCALE_OFF = BIAS_OFF + OT * 64;
     __shared__ __attribute__((aligned(16))) float s_x[GCNR_ROWS * GCN_D + 256];  // + slack: the last DMA piece of a tile may run past its rows
@@ -364,7 +366,7 @@ __global__ __launch_bounds__(GCNR_WAVES * 64, 3) void gcn_resident_kernel(const 
     // gave -- placement never changes a row's arithmetic: MFMA columns are independent and a row is summed in CSR order by one lane)
     __shared__ uint8_t s_perm[GCNR_ROWS];
     __shared__ int s_cnt[16], s_cur[16];
-    const bool sort_rows = !(ablate & 4);  // development aid: FLOWGNN_GCN_ABLATE=4 keeps rows in natural order
+    const bool sort_rows = !(ablate & 4);  // development aid: gcn_ablate, -DFLOWGNN_DEV builds=4 keeps rows in natural order
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int j = lane & 15, g = lane >> 4;
@@ -443,7 +445,7 @@ __global__ __launch_bounds__(GCNR_WAVES * 64, 3) void gcn_resident_kernel(const 
         const int r = s_perm[wv * 16 + j];
         const bool valid = r < rows;
         const int rr = valid ? r : 0;  // rows past the tile's end repeat row 0 without in-edges (finite values, never stored)
-        const int e_begin = valid ? (int)s_rp[r] : 0, e_end = valid && !(ablate & 1) ? (int)s_rp[r + 1] : e_begin;  // ablate: development aid (FLOWGNN_GCN_ABLATE)
+        const int e_begin = valid ? (int)s_rp[r] : 0, e_end = valid && !(ablate & 1) ? (int)s_rp[r + 1] : e_begin;  // ablate: development aid (gcn_ablate, -DFLOWGNN_DEV builds)
         const float dinv_v = s_dinv[rr], idp1 = s_idp1[rr];
 #pragma unroll 1
         for (int l = 0; l < GCN_L; l++) {
@@ -605,7 +607,7 @@ public:
     ~GcnModel() override { free_all(); }
     int emb_dim() const override { return GCN_D; }
     int scratch_dim() const override { return GCN_D; }
-    int aggregate_dim() const override { return GCN_D; }
+    int aggregate_dim() const override { return qmode_ ? 0 : GCN_D; }  // fixed-point modes have no float aggregation kernel
     bool has_edge_attr() const override { return true; }
     int num_weight_tensors() const override { return 11; }
     bool weights_ready() const override { return ready_; }
@@ -773,6 +775,7 @@ public:
     int forward(DeviceBatch& db, Profiler& prof, hipStream_t s) override {
         const int n = db.b.n_tot;
         if (n <= 0) return 0;
+        agg_ready_ = false;  // tiles_ / esc_ are rebuilt by whichever float path runs below; a fixed-point pass leaves none
         if (qmode_) return gcnq_forward(q_, db, prof, s);
         // x_0 by the encoder + dense kernel, then everything else in one launch when the batch packs into graph tiles (tiles under
         // half full waste MFMA columns: the per-layer kernels take those; so do per-node taps and the multi-task readout)
@@ -871,9 +874,19 @@ public:
         return 0;
     }
 
+    void configure(const Options& o) override {
+        if (o.i("tile_nominal") > 0) tile_nominal_ = o.i("tile_nominal");
+        if (o.i("tile_slack") >= 0) tile_slack_ = o.i("tile_slack");
+        split_ = o.i("gcn_mfma") != 32;
+        fused_ = !o.on("gcn_unfused");
+        resident_ = o.on("gcn_resident");
+        ablate_ = FG_ABLATE(o.i("gcn_ablate"));
+        agg_ready_ = false;
+    }
     void set_exact(bool on) override { exact_ = on; }
 
     int aggregation_only(DeviceBatch& db, int layer, hipStream_t s) override {
+        if (qmode_) return 8;  // FLOWGNN_ERR_UNSUPPORTED: the fixed-point forward never builds the float kernels\' inputs (tiles, h rows)
         if (layer < 0 || layer >= GCN_L) return 1;
         if (!agg_ready_) {  // the last forward ran the graph-resident kernel
             Profiler none;
@@ -900,18 +913,17 @@ private:
     int num_tasks_ = 1;  // NUM_TASK (GCN/src/dcl.h) as a run-time dimension
     GrowBuf esc_;
     GrowBufI tiles_;  // graph-aligned tile starts of the resident batch (tile_bounds_kernel)
-    int tile_nominal_ = getenv("FLOWGNN_TILE_NOMINAL") ? atoi(getenv("FLOWGNN_TILE_NOMINAL")) : 96;
-    int tile_slack_ = getenv("FLOWGNN_TILE_SLACK") ? atoi(getenv("FLOWGNN_TILE_SLACK")) : 32;
-    // FLOWGNN_GCN_MFMA=f32 keeps the dense layers on the fp32 matrix pipe (dense100_kernel); the default runs them as three
+    int tile_nominal_ = 96, tile_slack_ = 32;  // options tile_nominal / tile_slack (< 0: these defaults)
+    // gcn_mfma=32 keeps the dense layers on the fp32 matrix pipe (dense100_kernel); the default runs them as three
     // f16 MFMAs per product (dense_split.h), with the engine falling back to fp32 when the range flag trips
-    bool split_ = !(getenv("FLOWGNN_GCN_MFMA") && strcmp(getenv("FLOWGNN_GCN_MFMA"), "f32") == 0);
+    bool split_ = true;
     bool exact_ = false;
-    // FLOWGNN_GCN_UNFUSED=1 keeps aggregate and dense as two kernels per layer (A/B measurements)
-    bool fused_ = !(getenv("FLOWGNN_GCN_UNFUSED") && atoi(getenv("FLOWGNN_GCN_UNFUSED")) != 0);
+    // gcn_unfused=1 keeps aggregate and dense as two kernels per layer (A/B measurements)
+    bool fused_ = true;
     uint8_t* d_split_ = nullptr;
     uint8_t* d_res_ = nullptr;  // per-layer stream of gcn_resident_kernel
-    const int ablate_ = getenv("FLOWGNN_GCN_ABLATE") ? atoi(getenv("FLOWGNN_GCN_ABLATE")) : 0;  // development aid: per-phase timing (scripts/dev/pna_ablate.sh)
-    bool resident_ = !(getenv("FLOWGNN_GCN_RESIDENT") && atoi(getenv("FLOWGNN_GCN_RESIDENT")) == 0);
+    int ablate_ = 0;  // development aid (-DFLOWGNN_DEV builds only, option gcn_ablate): per-phase timing (scripts/dev/pna_ablate.sh)
+    bool resident_ = true;  // gcn_resident=0: one launch per layer
     bool keep_h_ = false;
     bool agg_ready_ = false;  // tiles_ / esc_ describe the batch of the last forward
     float* d_nemb_proj_ = nullptr;  // W_0 applied to the node-embedding table (+ b_0 in feature 0's rows): x_0 by lookups alone

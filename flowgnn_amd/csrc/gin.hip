@@ -537,7 +537,7 @@ public:
     ~GinModel() override { free_all(); }
     int emb_dim() const override { return GIN_D; }
     int scratch_dim() const override { return GIN_D; }
-    int aggregate_dim() const override { return GIN_D; }
+    int aggregate_dim() const override { return qmode_ ? 0 : GIN_D; }  // fixed-point modes have no float aggregation kernel
     bool has_edge_attr() const override { return true; }
     int num_weight_tensors() const override { return 8; }
     bool weights_ready() const override { return ready_; }
@@ -678,14 +678,14 @@ public:
         const long long items = (long long)db.b.n_tot * GIN_C;
         const int grid = grid_for(items, 256, 256 * 6);
         const size_t lds = sizeof(float) * EDGE_COMBOS * GIN_D;
-        // FLOWGNN_GIN_AGG_UNTILED=1 selects the first (un-tiled) kernel for A/B measurements
-        if (!(getenv("FLOWGNN_GIN_AGG_UNTILED") && atoi(getenv("FLOWGNN_GIN_AGG_UNTILED")) != 0)) {
+        // gin_agg_untiled=1 selects the first (un-tiled) kernel for A/B measurements
+        if (!agg_untiled_) {
             const int n_tiles = (int)ceil_div_ll(db.b.n_tot, GIN_TR);
             int g2 = 256 * 3;  // persistent: three workgroups per CU (52 KB of LDS each)
             if (g2 > n_tiles) g2 = n_tiles;
             // tile = 128 rows per 512-thread workgroup, 2 workgroups per CU (78 KB of LDS each): 1.17 ms at 2^18
-            // molhiv graphs vs 1.26-1.30 ms for 64 rows x 256 threads x 3 per CU (FLOWGNN_GIN_AGG_TILE=64 / 256)
-            const int tv = getenv("FLOWGNN_GIN_AGG_TILE") ? atoi(getenv("FLOWGNN_GIN_AGG_TILE")) : 128;
+            // molhiv graphs vs 1.26-1.30 ms for 64 rows x 256 threads x 3 per CU (gin_agg_tile=64 / 256)
+            const int tv = agg_tile_;
             if (tv == 128 || tv == 256) {
                 const int nt2 = (int)ceil_div_ll(db.b.n_tot, tv);
                 int g4 = tv == 128 ? 256 * 2 : 256;
@@ -735,7 +735,7 @@ public:
                 launch_gin_resident(db.h[0], rows ? db.h[1] : nullptr, db.csr.row_ptr, db.csr.src, db.csr.ecode, d_ecomb_, d_rsplit_, d_pw_, d_pb_,
                                     db.gtiles.row_start, db.gtiles.graph_start, reinterpret_cast<uint8_t*>(perm_.p), db.b.node_off,
                                     multi ? nullptr : db.out, db.gtiles.n_tiles, db.range_flag, s, virtual_node_,
-                                    (!rows && fold_readout_ && head_fold_) ? d_head_ : nullptr);
+                                    (!rows && fold_readout_ && head_fold_) ? d_head_ : nullptr, resident_order_, resident_prof_);
             }
             db.final_h = rows ? 1 : 0;
             db.h_valid = rows;
@@ -808,6 +808,19 @@ public:
                                                                                       num_tasks_);
     }
 
+    void configure(const Options& o) override {
+        fused_ = !o.on("gin_unfused");
+        split_ = o.i("gin_mfma") != 32;
+        split_nt_ = o.i("gin_split_nt");
+        agg_untiled_ = o.on("gin_agg_untiled");
+        agg_tile_ = o.i("gin_agg_tile");
+        resident_order_ = o.i("gin_resident_nosort");
+        resident_prof_ = o.on("gin_resident_prof");
+        fold_readout_ = o.on("gin_fold_readout");
+        resident_ = o.on("gin_resident");
+        resident_min_fill_ = o.num("gin_resident_min_fill");
+        head_fold_ = o.on("gin_head_fold");
+    }
     void set_exact(bool on) override { exact_ = on; }
     void set_keep_h(bool on) override { keep_h_ = on; }
     int set_numeric_mode(int mode) override {
@@ -824,6 +837,7 @@ public:
     }
 
     int aggregation_only(DeviceBatch& db, int layer, hipStream_t s) override {
+        if (qmode_) return 8;  // FLOWGNN_ERR_UNSUPPORTED: the fixed-point forward never builds the float kernels\' inputs (tiles, h rows)
         if (layer < 0 || layer >= GIN_L) return 1;
         launch_aggregate(db, layer, db.h[db.final_h], db.scratch, s);
         return 0;
@@ -842,29 +856,33 @@ private:
     }
     bool ready_ = false;
     const bool virtual_node_;  // FLOWGNN_MODEL_GIN_VN: the batch carries one virtual node per graph
-    // FLOWGNN_GIN_UNFUSED=1 keeps the two-kernel layer (aggregate + mlp) for A/B measurements
-    bool fused_ = !(getenv("FLOWGNN_GIN_UNFUSED") && atoi(getenv("FLOWGNN_GIN_UNFUSED")) != 0);
-    // FLOWGNN_GIN_MFMA=f32 keeps the dense update on the fp32 matrix pipe (gin_layer_fused_kernel); the default runs it
+    // gin_unfused=1 keeps the two-kernel layer (aggregate + mlp) for A/B measurements
+    bool fused_ = true;
+    // gin_mfma=32 keeps the dense update on the fp32 matrix pipe (gin_layer_fused_kernel); the default (16) runs it
     // as three f16 MFMAs per product (gin_split.hip), with the engine falling back to fp32 when the range flag trips
-    bool split_ = !(getenv("FLOWGNN_GIN_MFMA") && strcmp(getenv("FLOWGNN_GIN_MFMA"), "f32") == 0);
+    bool split_ = true;
     // 4 = eight-wave workgroups of 128 nodes (default), 1 / 2 = four waves x 1 / 2 node tiles
-    int split_nt_ = getenv("FLOWGNN_GIN_SPLIT_NT") ? atoi(getenv("FLOWGNN_GIN_SPLIT_NT")) : 4;
+    int split_nt_ = 4;
+    bool agg_untiled_ = false;  // gin_agg_untiled=1: the first (un-tiled) aggregation kernel, A/B measurements
+    int agg_tile_ = 128;        // gin_agg_tile: 64 | 128 | 256 rows per tile of the stand-alone aggregation kernel
+    int resident_order_ = 0;    // gin_resident_nosort: column order of the resident kernel's tiles (0 degree-sorted, 1 natural, 2 bank-aware)
+    bool resident_prof_ = false;  // gin_resident_prof: phase stamps printed per launch (synchronises)
     bool exact_ = false;
     bool keep_h_ = false;
     bool qmode_ = false;  // flowgnn_set_numeric_mode(FLOWGNN_NUMERIC_Q6_10)
     int num_tasks_ = 1;   // NUM_TASK (GIN/src/dcl.h:25) as a run-time dimension
     GinQWeights qw_;
     GrowBufI perm_;  // graph-resident path: per-tile descriptors (gin_tile_prep_kernel)
-    // FLOWGNN_GIN_FOLD_READOUT=0 keeps the separate mean-pool + linear kernel (and the last layer's 2.7 GB of rows)
-    bool fold_readout_ = !(getenv("FLOWGNN_GIN_FOLD_READOUT") && atoi(getenv("FLOWGNN_GIN_FOLD_READOUT")) == 0);
-    // FLOWGNN_GIN_RESIDENT=0 keeps one launch per layer (gin_layer_split_kernel).  GIN-VN runs the HUBS form of the resident kernel:
+    // gin_fold_readout=0 keeps the separate mean-pool + linear kernel (and the last layer's 2.7 GB of rows)
+    bool fold_readout_ = true;
+    // gin_resident=0 keeps one launch per layer (gin_layer_split_kernel).  GIN-VN runs the HUBS form of the resident kernel:
     // its virtual nodes are hub rows (in-degree = graph size), walked by the 16 lanes of their column tile together
-    bool resident_ = getenv("FLOWGNN_GIN_RESIDENT") ? atoi(getenv("FLOWGNN_GIN_RESIDENT")) != 0 : true;
-    double resident_min_fill_ = getenv("FLOWGNN_GIN_RESIDENT_MIN_FILL") ? atof(getenv("FLOWGNN_GIN_RESIDENT_MIN_FILL")) : 0.5;
+    bool resident_ = true;
+    double resident_min_fill_ = 0.5;
     uint8_t* d_split_ = nullptr;
     uint8_t* d_rsplit_ = nullptr;  // weight stream of the graph-resident kernel
     float* d_head_ = nullptr;      // gin_resident_head_fold
-    bool head_fold_ = !(getenv("FLOWGNN_GIN_HEAD_FOLD") && atoi(getenv("FLOWGNN_GIN_HEAD_FOLD")) == 0);
+    bool head_fold_ = true;  // gin_head_fold=0: the last layer's second linear layer is computed (readout not folded through it)
     float* d_chunks_ = nullptr;
     float *d_nemb_ = nullptr, *d_pw_ = nullptr, *d_pb_ = nullptr, *d_ecomb_ = nullptr, *d_w1f_ = nullptr,
           *d_w1tail_ = nullptr, *d_b1p_ = nullptr, *d_w2f_ = nullptr, *d_b2p_ = nullptr;

@@ -42,7 +42,7 @@ constexpr int GIN_RESIDENT_DESC_BYTES = 3584;  // per-tile descriptor built by g
 void launch_gin_resident(const float* h0, float* hout, const int* row_ptr, const int* src, const uint8_t* ecode, const float* ecomb_all,
                          const uint8_t* chunks_all, const float* pool_w, const float* pool_b, const int* tile_row, const int* tile_graph,
                          uint8_t* tile_desc /* scratch, n_tiles x GIN_RESIDENT_DESC_BYTES */, const int* node_off, float* out, int n_tiles,
-                         int* range_flag, hipStream_t s, bool hubs = false, const float* head_u = nullptr);
+                         int* range_flag, hipStream_t s, bool hubs = false, const float* head_u = nullptr, int col_order = 0, bool prof = false);
 // head_u for launch_gin_resident (GIN_RESIDENT_HEAD_FLOATS floats): the single-task readout folded through the LAST layer's second
 // linear layer -- u = W2^T w_pred divided by the first layer's power-of-two weight scale, padded to 208, then c = b2 . w_pred
 constexpr int GIN_RESIDENT_HEAD_FLOATS = 209;

@@ -1336,13 +1336,11 @@ void launch_gin_layer_split(const float* h, float* hout, const int* row_ptr, con
 void launch_gin_resident(const float* h0, float* hout, const int* row_ptr, const int* src, const uint8_t* ecode, const float* ecomb_all,
                          const uint8_t* chunks_all, const float* pool_w, const float* pool_b, const int* tile_row, const int* tile_graph,
                          uint8_t* tile_desc, const int* node_off, float* out, int n_tiles, int* range_flag, hipStream_t s, bool hubs,
-                         const float* head_u) {
+                         const float* head_u, int col_order, bool prof) {
     if (n_tiles <= 0) return;
-    static const int order_env = getenv("FLOWGNN_GIN_RESIDENT_NOSORT") ? atoi(getenv("FLOWGNN_GIN_RESIDENT_NOSORT")) : 0;
-    const int order = hubs ? 3 : order_env;
+    const int order = hubs ? 3 : col_order;
     gin_tile_prep_kernel<<<n_tiles, 256, 0, s>>>(row_ptr, src, ecode, tile_row, tile_desc, n_tiles, order);
     const int grid = n_tiles < 256 ? n_tiles : 256;  // persistent: one 8-wave workgroup per CU (157 KB of LDS)
-    static const bool prof = getenv("FLOWGNN_GIN_RESIDENT_PROF") && atoi(getenv("FLOWGNN_GIN_RESIDENT_PROF")) != 0;
     const bool fold = head_u != nullptr && out != nullptr && hout == nullptr;  // single-task readout, no per-node tap
     unsigned long long* d = nullptr;
     const size_t cnt = (size_t)grid * GR_WAVES * 7;

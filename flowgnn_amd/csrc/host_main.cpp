@@ -2,7 +2,7 @@
 // OpenCL host (GIN/src/host.cc): load the model's .bin weights, read a graph pack in the reference's on-disk
 // layout, run the whole dataset as ONE batched launch NUM_TRIALS times, write HLS_output.txt.
 //
-//   host <MODEL> [--graphs DIR] [--weights DIR] [--num-graphs N] [--trials T] [--out FILE] [--device D] [--numeric f32|q6.10] [XCLBIN]
+//   host <MODEL> [--graphs DIR] [--weights DIR] [--num-graphs N] [--trials T] [--out FILE] [--device D | --devices D0,D1,..] [--option key=value] [--numeric f32|q6.10] [XCLBIN]
 //
 //   MODEL        GIN | GIN-VN | GCN | GAT | PNA | DGN
 //   --graphs     directory holding graph_info/ and graph_bin/      (default ../graphs, host.cc:14-15)
@@ -76,7 +76,7 @@ static bool read_eig_txt(const std::string& path, std::vector<float>& eig, size_
 int main(int argc, char** argv) {
     if (argc < 2) {
         fprintf(stderr, "Usage: %s <GIN|GIN-VN|GCN|GAT|PNA|DGN> [--graphs DIR] [--weights DIR] [--num-graphs N] [--trials T] "
-                        "[--out FILE] [--device D] [--numeric f32|q6.10] [--num-tasks T] [XCLBIN File]\n", argv[0]);
+                        "[--out FILE] [--device D | --devices D0,D1,..] [--option key=value] [--numeric f32|q6.10] [--num-tasks T] [XCLBIN File]\n", argv[0]);
         return EXIT_FAILURE;
     }
     const std::string model = argv[1];
@@ -84,7 +84,9 @@ int main(int argc, char** argv) {
     if (mid < 0) { fprintf(stderr, "unknown model %s\n", model.c_str()); return EXIT_FAILURE; }
     std::string graphs = "../graphs", wdir = ".", out_path = "HLS_output.txt", eig_dir = "eig";
     long num_graphs = -1;
-    int trials = 25, device = 0, numeric = FLOWGNN_NUMERIC_F32, num_tasks = 1;
+    int trials = 25, numeric = FLOWGNN_NUMERIC_F32, num_tasks = 1;
+    std::vector<int> devices;
+    std::vector<std::pair<std::string, double>> options;
     for (int i = 2; i < argc; i++) {
         const std::string a = argv[i];
         auto next = [&](const char* what) -> const char* {
@@ -97,7 +99,21 @@ int main(int argc, char** argv) {
         else if (a == "--num-graphs") num_graphs = atol(next("--num-graphs"));
         else if (a == "--trials") trials = atoi(next("--trials"));
         else if (a == "--out") out_path = next("--out");
-        else if (a == "--device") device = atoi(next("--device"));
+        else if (a == "--device") { devices.clear(); devices.push_back(atoi(next("--device"))); }
+        else if (a == "--devices") {  // e.g. 0,1,2,3,4,5,6,7: the batch is cut by sum(N + E), one engine + host thread per device
+            devices.clear();
+            for (const char* c = next("--devices"); *c;) {
+                devices.push_back(atoi(c));
+                while (*c && *c != ',') c++;
+                if (*c == ',') c++;
+            }
+        }
+        else if (a == "--option") {  // key=value, flowgnn_set_option (e.g. gin_resident=0)
+            const std::string kv = next("--option");
+            const size_t eq = kv.find('=');
+            if (eq == std::string::npos) { fprintf(stderr, "--option wants key=value\n"); return EXIT_FAILURE; }
+            options.emplace_back(kv.substr(0, eq), atof(kv.c_str() + eq + 1));
+        }
         else if (a == "--num-tasks") num_tasks = atoi(next("--num-tasks"));  // NUM_TASK of the readout (GIN/src/dcl.h:25), GIN / GIN-VN / GCN
         else if (a == "--numeric") numeric = std::string(next("--numeric")) == "q6.10" ? FLOWGNN_NUMERIC_Q6_10 : FLOWGNN_NUMERIC_F32;
         // anything else (e.g. an .xclbin path) is ignored
@@ -107,18 +123,23 @@ int main(int argc, char** argv) {
     if (num_graphs < 0) { fprintf(stderr, "graph count unknown: pass --num-graphs or provide dataset_size.txt\n"); return EXIT_FAILURE; }
 
     printf("\n******* This is the MI355X host for the %s model *******\n", model.c_str());
-    flowgnn_engine* eng = nullptr;
-    int rc = flowgnn_create(mid, device, &eng);
-    if (rc) { fprintf(stderr, "flowgnn_create failed: %d %s\n", rc, flowgnn_last_error(nullptr)); return EXIT_FAILURE; }
-    if (num_tasks != 1) {
-        rc = flowgnn_set_num_tasks(eng, num_tasks);
-        if (rc) { fprintf(stderr, "--num-tasks %d: %d %s\n", num_tasks, rc, flowgnn_last_error(eng)); return EXIT_FAILURE; }
+    if (devices.empty()) devices.push_back(0);
+    flowgnn_group* eng = nullptr;  // one engine per listed device behind one handle (a single device is the common case)
+    int rc = flowgnn_create_multi(mid, (int)devices.size(), devices.data(), &eng);
+    if (rc) { fprintf(stderr, "flowgnn_create_multi failed: %d %s\n", rc, flowgnn_group_last_error(nullptr)); return EXIT_FAILURE; }
+    for (auto& kv : options) {
+        rc = flowgnn_group_set_option(eng, kv.first.c_str(), kv.second);
+        if (rc) { fprintf(stderr, "--option %s: %d %s\n", kv.first.c_str(), rc, flowgnn_group_last_error(eng)); return EXIT_FAILURE; }
     }
-    rc = flowgnn_load_weights_dir(eng, wdir.c_str());
-    if (rc) { fprintf(stderr, "loading weights failed: %d %s\n", rc, flowgnn_last_error(eng)); return EXIT_FAILURE; }
+    if (num_tasks != 1) {
+        rc = flowgnn_group_set_num_tasks(eng, num_tasks);
+        if (rc) { fprintf(stderr, "--num-tasks %d: %d %s\n", num_tasks, rc, flowgnn_group_last_error(eng)); return EXIT_FAILURE; }
+    }
+    rc = flowgnn_group_load_weights_dir(eng, wdir.c_str());
+    if (rc) { fprintf(stderr, "loading weights failed: %d %s\n", rc, flowgnn_group_last_error(eng)); return EXIT_FAILURE; }
     if (numeric != FLOWGNN_NUMERIC_F32) {  // the reference's ap_fixed<16,6> bit patterns (GIN / GIN-VN)
-        rc = flowgnn_set_numeric_mode(eng, numeric);
-        if (rc) { fprintf(stderr, "numeric mode: %d %s\n", rc, flowgnn_last_error(eng)); return EXIT_FAILURE; }
+        rc = flowgnn_group_set_numeric_mode(eng, numeric);
+        if (rc) { fprintf(stderr, "numeric mode: %d %s\n", rc, flowgnn_group_last_error(eng)); return EXIT_FAILURE; }
     }
     printf("\n******* Weights loading done *******\n");
 
@@ -165,21 +186,21 @@ int main(int argc, char** argv) {
     }
     printf("\n******* Graphs loading done *******\n");
 
-    rc = flowgnn_set_batch(eng, (int)num_graphs, nn.data(), ne.data(), nf.data(), el.data(), ea.data(), dgn ? eig.data() : nullptr);
-    if (rc) { fprintf(stderr, "flowgnn_set_batch failed: %d %s\n", rc, flowgnn_last_error(eng)); return EXIT_FAILURE; }
-    rc = flowgnn_run(eng);  // warm-up (first-touch, code load)
-    if (!rc) rc = flowgnn_sync(eng);
-    if (rc) { fprintf(stderr, "run failed: %d %s\n", rc, flowgnn_last_error(eng)); return EXIT_FAILURE; }
+    rc = flowgnn_group_set_batch(eng, (int)num_graphs, nn.data(), ne.data(), nf.data(), el.data(), ea.data(), dgn ? eig.data() : nullptr);
+    if (rc) { fprintf(stderr, "flowgnn_set_batch failed: %d %s\n", rc, flowgnn_group_last_error(eng)); return EXIT_FAILURE; }
+    rc = flowgnn_group_run(eng);  // warm-up (first-touch, code load)
+    if (!rc) rc = flowgnn_group_sync(eng);
+    if (rc) { fprintf(stderr, "run failed: %d %s\n", rc, flowgnn_group_last_error(eng)); return EXIT_FAILURE; }
     const auto t0 = std::chrono::steady_clock::now();
     for (int i = 0; i < trials; i++) {
         printf("(%d/%d) Computing %s ...\r", i + 1, trials, model.c_str());
         fflush(stdout);
-        rc = flowgnn_run(eng);
+        rc = flowgnn_group_run(eng);
         if (rc) break;
     }
-    if (!rc) rc = flowgnn_sync(eng);
+    if (!rc) rc = flowgnn_group_sync(eng);
     const auto t1 = std::chrono::steady_clock::now();
-    if (rc) { fprintf(stderr, "run failed: %d %s\n", rc, flowgnn_last_error(eng)); return EXIT_FAILURE; }
+    if (rc) { fprintf(stderr, "run failed: %d %s\n", rc, flowgnn_group_last_error(eng)); return EXIT_FAILURE; }
     const double ms = std::chrono::duration<double, std::milli>(t1 - t0).count() / (trials > 0 ? trials : 1);
     printf("\n******* Computation done *******\n");
     // the figure run_experiments.sh derives: kernel ms for the whole dataset / graphs (run_experiments.sh:44-46)
@@ -187,13 +208,13 @@ int main(int argc, char** argv) {
            ms / num_graphs, num_graphs / (ms * 1e-3), num_graphs, N, E);
 
     std::vector<float> result((size_t)num_graphs * num_tasks);
-    rc = flowgnn_get_results(eng, result.data());
+    rc = flowgnn_group_get_results(eng, result.data());
     if (rc) { fprintf(stderr, "flowgnn_get_results failed: %d\n", rc); return EXIT_FAILURE; }
     FILE* o = fopen(out_path.c_str(), "w+");
     if (!o) { fprintf(stderr, "cannot write %s\n", out_path.c_str()); return EXIT_FAILURE; }
     for (long g = 1; g <= num_graphs; g++)  // one line per task, as host.cc:213-222
         for (int t = 0; t < num_tasks; t++) fprintf(o, "g%ld: %.8f\n", g, result[(size_t)(g - 1) * num_tasks + t]);
     fclose(o);
-    flowgnn_destroy(eng);
+    flowgnn_group_destroy(eng);
     return 0;
 }

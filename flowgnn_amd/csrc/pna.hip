@@ -380,7 +380,9 @@ __global__ __launch_bounds__(PNA_FT_WAVES * 64, 4) void pna_layer_fused_kernel(c
                                                                   const int* __restrict__ out_deg, const uint8_t* __restrict__ wpk,
                                                                   const float* __restrict__ bias, float avg_deg, float oscale,
                                                                   const int* __restrict__ tile_row, int n_tiles, int* __restrict__ range_flag,
-                                                                  int ablate) {
+                                                                  int ablate_arg) {
+    const int ablate = FG_ABLATE(ablate_arg);  // 0 in the shipped build: the branches below fold away (common.h)
+    (void)ablate_arg;
     __shared__ __attribute__((aligned(16))) char s_a[PNA_CHUNK];  // even K-steps
     __shared__ __attribute__((aligned(16))) char s_b[PNA_CHUNK];  // odd K-steps
     __shared__ __attribute__((aligned(16))) float s_h[PNA_FT_ROWS * PNA_FT_STRIDE];
@@ -428,7 +430,7 @@ __global__ __launch_bounds__(PNA_FT_WAVES * 64, 4) void pna_layer_fused_kernel(c
         const uint8_t* csrc = s_src[buf];
         const int e_base = valid ? (int)s_rp[buf][r] : 0;
         int indeg = valid ? (int)s_rp[buf][r + 1] - e_base : 0;
-        if (ablate & 1) indeg = 0;  // development aid (FLOWGNN_PNA_ABLATE): timing without the gather
+        if (ablate & 1) indeg = 0;  // development aid (pna_ablate, -DFLOWGNN_DEV builds): timing without the gather
         uint32_t srcw[4];  // the first 16 in-edges, one byte each (re-walked by every K-step)
 #pragma unroll
         for (int w = 0; w < 4; w++) {
@@ -552,7 +554,7 @@ public:
     ~PnaModel() override { free_all(); }
     int emb_dim() const override { return PNA_D; }
     int scratch_dim() const override { return PNA_D * PNA_NA; }
-    int aggregate_dim() const override { return PNA_D * PNA_NA; }
+    int aggregate_dim() const override { return qmode_ ? 0 : PNA_D * PNA_NA; }  // fixed-point modes have no float aggregation kernel
     bool has_edge_attr() const override { return false; }
     int num_weight_tensors() const override { return 10; }
     bool weights_ready() const override { return ready_; }
@@ -695,9 +697,17 @@ public:
         return 0;
     }
 
+    void configure(const Options& o) override {
+        if (o.i("tile_nominal") > 0) tile_nominal_ = o.i("tile_nominal");
+        if (o.i("tile_slack") >= 0) tile_slack_ = o.i("tile_slack");
+        split_ = o.i("pna_mfma") != 32;
+        fused_ = o.on("pna_fused");
+        ablate_ = FG_ABLATE(o.i("pna_ablate"));
+    }
     void set_exact(bool on) override { exact_ = on; }
 
     int aggregation_only(DeviceBatch& db, int layer, hipStream_t s) override {
+        if (qmode_) return 8;  // FLOWGNN_ERR_UNSUPPORTED: the fixed-point forward never builds the float kernels\' inputs (tiles, h rows)
         if (layer < 0 || layer >= PNA_L) return 1;
         launch_aggregate(db, db.h[db.final_h], s);
         return 0;
@@ -717,13 +727,12 @@ private:
     bool qmode_ = false;  // flowgnn_set_numeric_mode(FLOWGNN_NUMERIC_Q6_10)
     QPack q_;
     GrowBufI tiles_;  // graph-aligned tile starts of the resident batch (tile_bounds_kernel)
-    int tile_nominal_ = getenv("FLOWGNN_TILE_NOMINAL") ? atoi(getenv("FLOWGNN_TILE_NOMINAL")) : 112;
-    int tile_slack_ = getenv("FLOWGNN_TILE_SLACK") ? atoi(getenv("FLOWGNN_TILE_SLACK")) : 48;
-    // FLOWGNN_PNA_MFMA=f32 keeps the dense update on the fp32 matrix pipe (pna_dense_kernel)
-    bool split_ = !(getenv("FLOWGNN_PNA_MFMA") && strcmp(getenv("FLOWGNN_PNA_MFMA"), "f32") == 0);
-    // FLOWGNN_PNA_FUSED=0 keeps aggregation and dense update as two kernels per layer (A/B measurements, the aggregation roofline probe)
-    const int ablate_ = getenv("FLOWGNN_PNA_ABLATE") ? atoi(getenv("FLOWGNN_PNA_ABLATE")) : 0;  // development aid: per-phase timing (scripts/dev/pna_ablate.sh)
-    bool fused_ = !(getenv("FLOWGNN_PNA_FUSED") && atoi(getenv("FLOWGNN_PNA_FUSED")) == 0);
+    int tile_nominal_ = 112, tile_slack_ = 48;  // options tile_nominal / tile_slack (< 0: these defaults)
+    // pna_mfma=32 keeps the dense update on the fp32 matrix pipe (pna_dense_kernel)
+    bool split_ = true;
+    // pna_fused=0 keeps aggregation and dense update as two kernels per layer (A/B measurements, the aggregation roofline probe)
+    int ablate_ = 0;  // development aid (-DFLOWGNN_DEV builds only, option pna_ablate): per-phase timing (scripts/dev/pna_ablate.sh)
+    bool fused_ = true;
     bool exact_ = false;
     uint8_t* d_split_ = nullptr;
     uint8_t* d_stream_ = nullptr;  // feature-major weight stream of the fused layer kernel

@@ -22,8 +22,8 @@ def shard_ranges(batch: GraphBatch, world_size: int) -> List[Tuple[int, int]]:
     total = int(cum[-1])
     cuts = [0]
     for r in range(1, world_size):
-        target = total * r / world_size
-        g = int(np.searchsorted(cum, target, side="left"))
+        # first g with cum[g] * world_size >= total * r: exact integers, the same rule as the C ABI's flowgnn_shard_ranges
+        g = int(np.searchsorted(cum * world_size, total * r, side="left"))
         cuts.append(min(max(g, cuts[-1]), G))
     cuts.append(G)
     return [(cuts[r], cuts[r + 1]) for r in range(world_size)]

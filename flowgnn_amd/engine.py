@@ -37,10 +37,18 @@ def _pf(a: Optional[np.ndarray]):
     return None if a is None else a.ctypes.data_as(_lib.p_float)
 
 
-class Engine:
-    """One engine = one GPU, one stream, one model's weights, one resident batch."""
+def option_value(v) -> float:
+    """Option values are numbers; "f32" / "f16" (the *_mfma switches) read as 32 / 16."""
+    if isinstance(v, str) and v in ("f32", "f16"):
+        return 32.0 if v == "f32" else 16.0
+    return float(v)
 
-    def __init__(self, model: str = "GIN", device: int = 0):
+
+class Engine:
+    """One engine = one GPU, one stream, one model's weights, one resident batch.
+    `options`: {key: value} passed to flowgnn_set_option right after creation (e.g. {"gin_resident": 0})."""
+
+    def __init__(self, model: str = "GIN", device: int = 0, options: Optional[Dict[str, float]] = None):
         self.lib = _lib.load()
         self.model = model.upper()
         if self.model not in _lib.MODEL_IDS:
@@ -49,6 +57,17 @@ class Engine:
         self._check(self.lib.flowgnn_create(_lib.MODEL_IDS[self.model], device, C.byref(self._h)), "flowgnn_create")
         self._keep = []
         self.num_tasks = 1
+        for k, v in (options or {}).items():
+            self.set_option(k, v)
+
+    def set_option(self, key: str, value):
+        """Run-time switch by name (flowgnn.h: flowgnn_set_option); call before set_batch."""
+        self._check(self.lib.flowgnn_set_option(self._h, key.encode(), option_value(value)), f"flowgnn_set_option({key})")
+
+    def get_option(self, key: str) -> float:
+        v = C.c_double()
+        self._check(self.lib.flowgnn_get_option(self._h, key.encode(), C.byref(v)), f"flowgnn_get_option({key})")
+        return float(v.value)
 
     def _check(self, rc: int, where: str):
         if rc != 0:
@@ -184,6 +203,109 @@ class Engine:
             self._check(self.lib.flowgnn_set_stream(self._h, C.c_void_p(stream_handle), 1), "flowgnn_set_stream")
 
 
+class EngineGroup:
+    """Several engines behind one handle (flowgnn.h: flowgnn_create_multi): the batch is cut into contiguous graph ranges
+    balanced by sum(N + E), one engine + host thread per listed device; results come back in job order."""
+
+    def __init__(self, model: str, devices, options: Optional[Dict[str, float]] = None):
+        self.lib = _lib.load()
+        self.model = model.upper()
+        self.devices = [int(d) for d in devices]
+        self._h = C.c_void_p()
+        ids = _i32(self.devices)
+        rc = self.lib.flowgnn_create_multi(_lib.MODEL_IDS[self.model], len(self.devices), _pi(ids), C.byref(self._h))
+        if rc:
+            raise FlowGNNError(rc, "flowgnn_create_multi")
+        self.num_tasks = 1
+        self.num_graphs = 0
+        for k, v in (options or {}).items():
+            self._check(self.lib.flowgnn_group_set_option(self._h, k.encode(), option_value(v)), f"flowgnn_group_set_option({k})")
+
+    def _check(self, rc: int, where: str):
+        if rc != 0:
+            raise FlowGNNError(rc, where, (self.lib.flowgnn_group_last_error(self._h) or b"").decode(errors="replace"))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.flowgnn_group_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_weights(self, w: Dict[str, np.ndarray]):
+        arrs = [_f32(v) for v in w.values()]
+        ptrs = (_lib.p_float * len(arrs))(*[_pf(a) for a in arrs])
+        self._check(self.lib.flowgnn_group_set_weights(self._h, len(arrs), ptrs), "flowgnn_group_set_weights")
+
+    def load_weights_dir(self, directory: str):
+        self._check(self.lib.flowgnn_group_load_weights_dir(self._h, directory.encode()), "flowgnn_group_load_weights_dir")
+
+    def set_num_tasks(self, num_tasks: int):
+        self._check(self.lib.flowgnn_group_set_num_tasks(self._h, int(num_tasks)), "flowgnn_group_set_num_tasks")
+        self.num_tasks = int(num_tasks)
+
+    def set_numeric_mode(self, mode: str = "f32"):
+        self._check(self.lib.flowgnn_group_set_numeric_mode(self._h, {"f32": 0, "q6.10": 1}[mode]), "flowgnn_group_set_numeric_mode")
+
+    def set_batch(self, batch: GraphBatch):
+        nn, ne = _i32(batch.nums_of_nodes), _i32(batch.nums_of_edges)
+        nf, el, ea = _i32(batch.node_feature), _i32(batch.edge_list), _i32(batch.edge_attr)
+        eig = None if batch.node_eigen is None else _f32(batch.node_eigen)
+        self._check(self.lib.flowgnn_group_set_batch(self._h, batch.num_graphs, _pi(nn), _pi(ne), _pi(nf), _pi(el), _pi(ea), _pf(eig)),
+                    "flowgnn_group_set_batch")
+        self.num_graphs = batch.num_graphs
+
+    def shards(self):
+        cuts = np.zeros(len(self.devices) + 1, dtype=np.int32)
+        self._check(self.lib.flowgnn_group_shards(self._h, _pi(cuts)), "flowgnn_group_shards")
+        return [(int(cuts[i]), int(cuts[i + 1])) for i in range(len(self.devices))]
+
+    def run(self):
+        self._check(self.lib.flowgnn_group_run(self._h), "flowgnn_group_run")
+
+    def sync(self):
+        self._check(self.lib.flowgnn_group_sync(self._h), "flowgnn_group_sync")
+
+    def results(self) -> np.ndarray:
+        out = np.empty(self.num_graphs * self.num_tasks, dtype=np.float32)
+        self._check(self.lib.flowgnn_group_get_results(self._h, _pf(out)), "flowgnn_group_get_results")
+        return out.reshape(self.num_graphs, self.num_tasks) if self.num_tasks > 1 else out
+
+    def forward(self, batch: GraphBatch) -> np.ndarray:
+        self.set_batch(batch)
+        self.run()
+        return self.results()
+
+
+def shard_ranges_c(nums_of_nodes, nums_of_edges, parts: int):
+    """flowgnn_shard_ranges (the C ABI's cut by cumulative node + edge count); pure host code, no GPU needed."""
+    lib = _lib.load()
+    nn, ne = _i32(nums_of_nodes), _i32(nums_of_edges)
+    cuts = np.zeros(parts + 1, dtype=np.int32)
+    rc = lib.flowgnn_shard_ranges(len(nn), _pi(nn), _pi(ne), parts, _pi(cuts))
+    if rc:
+        raise FlowGNNError(rc, "flowgnn_shard_ranges")
+    return [(int(cuts[i]), int(cuts[i + 1])) for i in range(parts)]
+
+
+def entry_set_devices(devices):
+    """Devices of the <M>_compute_graphs entry points (flowgnn.h: flowgnn_entry_set_devices)."""
+    ids = _i32(list(devices))
+    rc = _lib.load().flowgnn_entry_set_devices(len(ids), _pi(ids))
+    if rc:
+        raise FlowGNNError(rc, "flowgnn_entry_set_devices")
+
+
+def entry_set_option(model: str, key: str, value):
+    rc = _lib.load().flowgnn_entry_set_option(_lib.MODEL_IDS[model.upper()], key.encode(), option_value(value))
+    if rc:
+        raise FlowGNNError(rc, f"flowgnn_entry_set_option({key})")
+
+
 def compute_graphs(model: str, batch: GraphBatch, weight_sets, reload_weights=None, num_tasks: int = 1) -> np.ndarray:
     """Call the reference-compatible C symbol <M>_compute_graphs (e.g. GIN/src/dcl.h:75-94) with host
     arrays.  `weight_sets` is a list of weight dicts: the leading [S] dimension of every weight pointer,
@@ -198,16 +320,21 @@ def compute_graphs(model: str, batch: GraphBatch, weight_sets, reload_weights=No
     stacked = [np.ascontiguousarray(np.stack([np.asarray(ws[k], dtype=np.float32) for ws in weight_sets]))
                for k in weight_sets[0].keys()]  # [S, ...] per tensor (avg_deg: [S, 1] == float[S])
     out = np.zeros(G * num_tasks, dtype=np.float32)
-    if num_tasks != 1:  # the entry points take NUM_TASK (a compile-time constant of the reference build) from the environment
-        import os
-        os.environ["FLOWGNN_NUM_TASK"] = str(num_tasks)
+    if num_tasks != 1 and model not in ("GIN", "GIN-VN", "GCN"):
+        raise FlowGNNError(8, f"{model}_compute_graphs", "this model's readout is a single-task MLP head (NUM_TASK != 1 exists for GIN / GIN-VN / GCN)")
     nn, ne, rw = _i32(batch.nums_of_nodes), _i32(batch.nums_of_edges), _i32(reload_weights)
     nf, el, ea = _i32(batch.node_feature), _i32(batch.edge_list), _i32(batch.edge_attr)
     wp = [_pf(a) for a in stacked]
     if model in ("GIN", "GIN-VN"):
-        rc = lib.GIN_compute_graphs(G, _pi(nn), _pi(ne), _pi(rw), _pf(out), _pi(nf), _pi(el), _pi(ea), *wp)
+        if num_tasks == 1:
+            rc = lib.GIN_compute_graphs(G, _pi(nn), _pi(ne), _pi(rw), _pf(out), _pi(nf), _pi(el), _pi(ea), *wp)
+        else:  # NUM_TASK, a compile-time constant of the reference build, is an explicit argument here
+            rc = lib.GIN_compute_graphs_mt(G, _pi(nn), _pi(ne), _pi(rw), _pf(out), _pi(nf), _pi(el), _pi(ea), *wp, num_tasks)
     elif model == "GCN":
-        rc = lib.GCN_compute_graphs(G, _pi(nn), _pi(ne), _pi(rw), _pf(out), _pi(nf), _pi(el), _pi(ea), *wp)
+        if num_tasks == 1:
+            rc = lib.GCN_compute_graphs(G, _pi(nn), _pi(ne), _pi(rw), _pf(out), _pi(nf), _pi(el), _pi(ea), *wp)
+        else:
+            rc = lib.GCN_compute_graphs_mt(G, _pi(nn), _pi(ne), _pi(rw), _pf(out), _pi(nf), _pi(el), _pi(ea), *wp, num_tasks)
     elif model == "PNA":
         rc = lib.PNA_compute_graphs(G, _pi(nn), _pi(ne), _pi(rw), _pf(out), _pi(nf), _pi(el), *wp)
     elif model == "GAT":
@@ -217,8 +344,6 @@ def compute_graphs(model: str, batch: GraphBatch, weight_sets, reload_weights=No
         rc = lib.DGN_compute_graphs(G, _pi(nn), _pi(ne), _pi(rw), _pf(out), _pi(nf), _pf(eig), _pi(el), *wp)
     else:
         raise ValueError(model)
-    if num_tasks != 1:
-        os.environ.pop("FLOWGNN_NUM_TASK", None)
     if rc:
         raise FlowGNNError(rc, f"{model}_compute_graphs")
     return out.reshape(G, num_tasks) if num_tasks > 1 else out

@@ -79,6 +79,20 @@ int GIN_compute_graphs(int num_graphs, int* nums_of_nodes, int* nums_of_edges,
                        float* graph_pred_weights_in, float* graph_pred_bias_in);
 
 /*
+ * NUM_TASK (a compile-time constant of the reference build, GIN/src/dcl.h:25, 1 as shipped; ogbg-molpcba has 128) as an explicit
+ * last argument: graph_pred_weights_in is then [S][num_tasks][100], graph_pred_bias_in [S][num_tasks], out [num_graphs][num_tasks]
+ * (`FM_TYPE out[][NUM_TASK]`, GIN/src/dcl.h:80).  GIN_compute_graphs(...) == GIN_compute_graphs_mt(..., 1); nothing about the
+ * shape of `out` is ever taken from the environment.
+ */
+int GIN_compute_graphs_mt(int num_graphs, int* nums_of_nodes, int* nums_of_edges,
+                          int* reload_weights, float* out,
+                          int* node_feature_in, int* edge_list_in, int* edge_attr_in,
+                          float* node_embedding_weight_in, float* edge_embedding_weight_in,
+                          float* node_mlp_1_weights, float* node_mlp_1_bias,
+                          float* node_mlp_2_weights, float* node_mlp_2_bias,
+                          float* graph_pred_weights_in, float* graph_pred_bias_in, int num_tasks);
+
+/*
  * Replaces GCN_compute_graphs, GCN/src/dcl.h:75-97 (def. GCN/src/GCN_compute.cc:7-112).
  *   out [num_graphs]; graph arrays as for GIN
  *   convs_weight_in [S][5][100][100]  convs_bias_in [S][5][100]  convs_root_emb_weight_in [S][5][100]
@@ -91,6 +105,15 @@ int GCN_compute_graphs(int num_graphs, int* nums_of_nodes, int* nums_of_edges,
                        float* convs_weight_in, float* convs_bias_in, float* convs_root_emb_weight_in,
                        float* bn_weight_in, float* bn_bias_in, float* bn_mean_in, float* bn_var_in,
                        float* graph_pred_weights_in, float* graph_pred_bias_in);
+
+/* GCN with NUM_TASK as an explicit last argument (see GIN_compute_graphs_mt). */
+int GCN_compute_graphs_mt(int num_graphs, int* nums_of_nodes, int* nums_of_edges,
+                          int* reload_weights, float* out,
+                          int* node_feature_in, int* edge_list_in, int* edge_attr_in,
+                          float* node_embedding_weight_in, float* edge_embedding_weight_in,
+                          float* convs_weight_in, float* convs_bias_in, float* convs_root_emb_weight_in,
+                          float* bn_weight_in, float* bn_bias_in, float* bn_mean_in, float* bn_var_in,
+                          float* graph_pred_weights_in, float* graph_pred_bias_in, int num_tasks);
 
 /*
  * Replaces PNA_compute_graphs, PNA/src/dcl.h:91-111 (def. PNA/src/PNA_compute.cc:7-101).  No edge features.
@@ -134,8 +157,8 @@ int DGN_compute_graphs(int num_graphs, int* nums_of_nodes, int* nums_of_edges,
  *   linear_proj_weights_in / skip_proj_weights_in [S][5][4][16][4][16]  (layer, head_out, dim_out, head_in, dim_in);
  *       layer 0 uses only [head_out][dim_out][0][dim_in < 9] (GAT/src/host_load.cc:69-78)
  *   graph_pred_weights_in [S][1][16], graph_pred_bias_in [S][1]
- * Per-graph node-feature offsets ARE applied (the reference omits them, GAT_compute.cc:72); set the environment
- * variable FLOWGNN_GAT_REFERENCE_QUIRK=1 to reproduce the reference behaviour.
+ * Per-graph node-feature offsets ARE applied (the reference omits them, GAT_compute.cc:72); option
+ * gat_reference_quirk = 1 (flowgnn_set_option / flowgnn_entry_set_option) reproduces the reference behaviour.
  */
 int GAT_compute_graphs(int num_graphs, int* nums_of_nodes, int* nums_of_edges,
                        int* reload_weights, float* out,
@@ -143,6 +166,17 @@ int GAT_compute_graphs(int num_graphs, int* nums_of_nodes, int* nums_of_edges,
                        float* scoring_fn_target_in, float* scoring_fn_source_in,
                        float* linear_proj_weights_in, float* skip_proj_weights_in,
                        float* graph_pred_weights_in, float* graph_pred_bias_in);
+
+/*
+ * Devices and options of the entry points above (they have no handle to carry them).
+ *  flowgnn_entry_set_devices: the HIP devices the six entry points run on.  With more than one, every run of constant weight
+ *     set is cut into contiguous graph ranges balanced by sum(N + E) and the ranges run concurrently, one engine and one host
+ *     thread per listed device (a device may be listed twice); `out` is filled in job order.  Default: device 0, or the list in
+ *     the environment variable FLOWGNN_DEVICES (e.g. "0,1,2,3,4,5,6,7") read at the first call.
+ *  flowgnn_entry_set_option: flowgnn_set_option for the engines behind the entry points of `model` (FLOWGNN_MODEL_*).
+ */
+int flowgnn_entry_set_devices(int n_devices, const int* device_ids);
+int flowgnn_entry_set_option(int model, const char* key, double value);
 
 /* =====================================================================
  * (2) Handle API
@@ -206,7 +240,8 @@ int flowgnn_results_device(flowgnn_engine* e, void** d_out);
 /*
  * Redirect results into a caller-owned DEVICE buffer of at least num_graphs floats (e.g. a
  * torch tensor's data_ptr(), so RCCL can all-gather it without a copy); NULL restores the
- * engine's own buffer.  Applies to the resident batch and is reset by flowgnn_set_batch.
+ * engine's own buffer.  Applies to the resident batch and is reset by flowgnn_set_batch.  Does not wait for the device: it
+ * affects the runs enqueued after it (a caller alternating two buffers from step to step pays no host synchronisation).
  */
 int flowgnn_set_results_buffer(flowgnn_engine* e, void* device_ptr);
 /* The engine's hipStream_t as an opaque pointer (for event timing by a caller). */
@@ -237,7 +272,7 @@ int flowgnn_batch_info(const flowgnn_engine* e, long long* num_graphs,
 int flowgnn_exact_reruns(const flowgnn_engine* e);
 
 /*
- * Launch-sequence replay (opt-in: FLOWGNN_HIPGRAPH=1 for resident batches of up to 2^20 nodes, 2 for any size).
+ * Launch-sequence replay (opt-in: option hipgraph = 1 for resident batches of up to 2^20 nodes, 2 for any size).
  * flowgnn_run then records its launch sequence (index build + forward pass) into a hipGraph on the second run of a
  * batch and replays it afterwards; any call that changes what the kernels read or write (weights, batch, result
  * buffer, numeric mode, an exact-fp32 re-run) drops the recording, and runs with the profiler enabled are never
@@ -252,8 +287,8 @@ long long flowgnn_graph_replays(const flowgnn_engine* e);
  * the results are [num_graphs][NUM_TASK] (out[g][t], as `FM_TYPE out[][NUM_TASK]`, GIN/src/dcl.h:80) -- every buffer that
  * receives results (flowgnn_get_results, flowgnn_set_results_buffer) holds num_graphs * NUM_TASK floats.  Call it before
  * setting weights and batch (both must be set again afterwards).  GIN / GIN-VN / GCN; the other models' readouts are
- * single-task MLP heads and return FLOWGNN_ERR_UNSUPPORTED for NUM_TASK != 1.  The <M>_compute_graphs entry points take their
- * NUM_TASK from the environment variable FLOWGNN_NUM_TASK (default 1).
+ * single-task MLP heads and return FLOWGNN_ERR_UNSUPPORTED for NUM_TASK != 1.  The entry points take NUM_TASK as an explicit
+ * argument (GIN_compute_graphs_mt / GCN_compute_graphs_mt).
  */
 int flowgnn_set_num_tasks(flowgnn_engine* e, int num_tasks);
 int flowgnn_num_tasks(const flowgnn_engine* e);
@@ -266,10 +301,57 @@ int flowgnn_num_tasks(const flowgnn_engine* e);
  * does, and the outputs are pattern / 2^F (exact in float).  The rules assumed for ap_fixed division and the hls:: math
  * functions are written down in oracle/ginq_oracle.c and oracle/q_oracle.c.  A fidelity mode, one to two orders of
  * magnitude slower than the default path: products are truncated one at a time, as the reference does.
+ * NOT validated against Vitis: the rules are taken from the published ap_fixed / hls_math semantics and the tests prove that
+ * the GPU kernels and the CPU restatement agree bit for bit with EACH OTHER; no Vitis header or C-simulation output exists in
+ * this repository's build environment to pin them to the reference's real bit patterns.
  */
 #define FLOWGNN_NUMERIC_F32 0
 #define FLOWGNN_NUMERIC_Q6_10 1
 int flowgnn_set_numeric_mode(flowgnn_engine* e, int mode);
+
+/*
+ * Run-time switches, by name (the full list with defaults: the option table in flowgnn_amd/csrc/engine.hip, or
+ * flowgnn_option_count / flowgnn_option_name).  They select between kernels that compute the SAME results -- e.g.
+ * "gin_resident" 0 = one launch per layer, "gin_mfma" 32 = fp32 matrix pipe instead of three f16 products, "pna_fused" 0 =
+ * separate aggregation and dense kernels, "hipgraph" 1 -- and exist for A/B measurements and parity tests.  Defaults come from the
+ * table; the environment is read in exactly one place, when flowgnn_create builds an engine (FLOWGNN_<KEY IN UPPER CASE>, "f32"
+ * reads as 32), and flowgnn_set_option overrides it.  Call it before flowgnn_set_batch: it invalidates the resident batch.
+ * Unknown key: FLOWGNN_ERR_UNSUPPORTED.  No option changes the shape of any buffer, and the shipped library has no option
+ * that changes results (the kernels' ablation hooks are compiled in only with -DFLOWGNN_DEV).
+ */
+int flowgnn_set_option(flowgnn_engine* e, const char* key, double value);
+int flowgnn_get_option(const flowgnn_engine* e, const char* key, double* value);
+int flowgnn_option_count(void);
+const char* flowgnn_option_name(int i);
+
+/*
+ * Several devices behind one handle (north_star: the batch dimension partitioned across the GPUs of a node; the reference has
+ * one compute unit, GIN/config_slr.cfg:1-2).  One engine + one host thread per listed device; flowgnn_group_set_batch cuts the
+ * batch into contiguous graph ranges balanced by sum(N + E) (flowgnn_shard_ranges: cuts[0..parts], cuts[r] = the first graph
+ * whose cumulative node + edge count reaches r / parts of the total) and flowgnn_group_get_results writes [num_graphs][NUM_TASK]
+ * in job order.  Graphs are independent, so the results are bit-identical to a single engine's.  A device may appear more than
+ * once in the list.  flowgnn_group_engine(g, i) exposes member i for per-engine calls (profiling, taps).
+ */
+typedef struct flowgnn_group flowgnn_group;
+int flowgnn_shard_ranges(int num_graphs, const int* nums_of_nodes, const int* nums_of_edges, int parts, int* cuts);
+int flowgnn_create_multi(int model, int n_devices, const int* device_ids, flowgnn_group** out);
+int flowgnn_group_destroy(flowgnn_group* g);
+int flowgnn_group_size(const flowgnn_group* g);
+flowgnn_engine* flowgnn_group_engine(flowgnn_group* g, int i);
+const char* flowgnn_group_last_error(const flowgnn_group* g);
+int flowgnn_group_set_weights(flowgnn_group* g, int count, const float* const* tensors);
+int flowgnn_group_load_weights_dir(flowgnn_group* g, const char* dir);
+int flowgnn_group_set_option(flowgnn_group* g, const char* key, double value);
+int flowgnn_group_set_num_tasks(flowgnn_group* g, int num_tasks);
+int flowgnn_group_set_numeric_mode(flowgnn_group* g, int mode);
+int flowgnn_group_set_batch(flowgnn_group* g, int num_graphs,
+                            const int* nums_of_nodes, const int* nums_of_edges,
+                            const int* node_feature, const int* edge_list, const int* edge_attr,
+                            const float* node_eigen);
+int flowgnn_group_shards(const flowgnn_group* g, int* cuts /* [size + 1] */);
+int flowgnn_group_run(flowgnn_group* g);
+int flowgnn_group_sync(flowgnn_group* g);
+int flowgnn_group_get_results(flowgnn_group* g, float* out_host);
 
 /*
  * Debug / parity taps (device -> host copies; synchronise first).

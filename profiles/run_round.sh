@@ -13,13 +13,13 @@ OUT=$R/gpurun_out; mkdir -p $OUT
 STEPS=5; WARM=2
 cd /tmp && export TMPDIR=/tmp
 for M in $MODELS; do
-  python $R/bench.py --model $M --steps 10 --warmup 2 > $OUT/${TAG}_bench_$M.json 2> $OUT/${TAG}_bench_$M.err
-  rocprofv3 --kernel-trace --output-format csv -d $OUT/${TAG}_${M}_kt -o kt -- python $R/bench.py --model $M --steps $STEPS --warmup $WARM --no-cpu-baseline > $OUT/${TAG}_${M}_kt.log 2>&1
+  python $R/bench.py --model $M --steps 10 --warmup 2 --configs off > $OUT/${TAG}_bench_$M.json 2> $OUT/${TAG}_bench_$M.err
+  rocprofv3 --kernel-trace --output-format csv -d $OUT/${TAG}_${M}_kt -o kt -- python $R/bench.py --model $M --steps $STEPS --warmup $WARM --no-cpu-baseline --configs off > $OUT/${TAG}_${M}_kt.log 2>&1
   f=$(find $OUT/${TAG}_${M}_kt -name '*kernel_trace.csv' | head -1)
   [ -n "$f" ] && python $R/profiles/summarize.py stats $f $STEPS $WARM > $OUT/${TAG}_${M}_kernel_trace_summary.txt
   rm -rf $OUT/${TAG}_${M}_kt
   for C in FETCH_SIZE WRITE_SIZE; do
-    rocprofv3 --pmc $C --output-format csv -d $OUT/${TAG}_${M}_$C -o pmc -- python $R/bench.py --model $M --steps 2 --warmup 1 --no-cpu-baseline > $OUT/${TAG}_${M}_$C.log 2>&1
+    rocprofv3 --pmc $C --output-format csv -d $OUT/${TAG}_${M}_$C -o pmc -- python $R/bench.py --model $M --steps 2 --warmup 1 --no-cpu-baseline --configs off > $OUT/${TAG}_${M}_$C.log 2>&1
     f=$(find $OUT/${TAG}_${M}_$C -name '*counter_collection.csv' | head -1)
     [ -n "$f" ] && python $R/profiles/summarize.py pmc $f $C > $OUT/${TAG}_${M}_pmc_$C.txt
     rm -rf $OUT/${TAG}_${M}_$C

@@ -14,7 +14,7 @@ HEADER = os.path.join(ROOT, "include", "flowgnn.h")
 def declared_functions():
     src = open(HEADER).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    names = re.findall(r"^\s*(?:const\s+char\*|int)\s+([A-Za-z_][A-Za-z0-9_]*)\s*\(", src, flags=re.M)
+    names = re.findall(r"^\s*(?:const\s+char\*|flowgnn_engine\*|int)\s+([A-Za-z_][A-Za-z0-9_]*)\s*\(", src, flags=re.M)
     return sorted(set(names))
 
 
@@ -38,3 +38,43 @@ def test_bad_arguments_are_rejected_without_a_gpu():
     assert lib.flowgnn_destroy(None) == 1
     assert lib.GIN_compute_graphs(-1, *([None] * 15)) == 1
     assert lib.GIN_compute_graphs(0, *([None] * 15)) == 0  # empty batch is a no-op
+
+
+@pytest.mark.skipif(not os.path.exists(LIB), reason="libflowgnn_hip.so not built")
+def test_shipped_library_has_no_ablation_hooks_and_one_env_reader():
+    """The kernels' ablation hooks (some give wrong results on purpose) exist only in a -DFLOWGNN_DEV build; NUM_TASK is an
+    argument, not an environment variable; every option name is reachable through the API."""
+    blob = open(LIB, "rb").read()
+    assert b"ABLATE" not in blob and b"_ablate" not in blob
+    assert b"FLOWGNN_NUM_TASK" not in blob
+    lib = ctypes.CDLL(LIB)
+    lib.flowgnn_option_name.restype = ctypes.c_char_p
+    names = [lib.flowgnn_option_name(i).decode() for i in range(lib.flowgnn_option_count())]
+    assert "gin_resident" in names and "hipgraph" in names and "pna_fused" in names
+    assert not [n for n in names if n.endswith("ablate")]
+    assert lib.flowgnn_option_name(len(names)) is None
+    # the library reads its environment in one function: every getenv call site sits in engine.hip's read_environment
+    import glob
+    hits = []
+    for f in glob.glob(os.path.join(ROOT, "flowgnn_amd", "csrc", "*")):
+        if f.endswith((".hip", ".h", ".cpp")):
+            for i, line in enumerate(open(f, errors="replace"), 1):
+                code = line.split("//")[0]
+                if "getenv(" in code:
+                    hits.append((os.path.basename(f), i))
+    assert hits and all(f == "engine.hip" for f, _ in hits) and len(hits) <= 3, hits
+
+
+@pytest.mark.skipif(not os.path.exists(LIB), reason="libflowgnn_hip.so not built")
+def test_shard_ranges_c_equals_python():
+    """flowgnn_shard_ranges (host code of the multi-device path) cuts exactly where flowgnn_amd.dist.shard_ranges does."""
+    import numpy as np
+    from flowgnn_amd import graphpack as gp, shard_ranges_c
+    from flowgnn_amd.dist import shard_ranges
+    rng = np.random.default_rng(0)
+    for trial in range(20):
+        G = int(rng.integers(1, 200))
+        b = gp.synth_hep10k_batch(G, seed=trial, with_eigen=False) if trial % 2 else gp.synth_molhiv_batch(G, seed=trial)
+        for parts in (1, 2, 3, 8, 17, 256):
+            assert shard_ranges_c(b.nums_of_nodes, b.nums_of_edges, parts) == shard_ranges(b, parts), (trial, parts)
+    assert shard_ranges_c(np.zeros(0, np.int32), np.zeros(0, np.int32), 4) == [(0, 0)] * 4

@@ -1,0 +1,137 @@
+"""Several engines behind one handle (flowgnn_create_multi; north_star: the batch dimension partitioned across the GPUs of a
+node).  The 1-GPU box lists device 0 more than once -- two / three engines on one GPU, each with its own stream and host thread,
+which an RCCL rank-per-GPU launch cannot do: the sharding (cut by sum(N + E)), the per-engine threads and the job-order result
+assembly are exactly what runs on eight devices.  Graphs are independent, so the results must be BIT-identical to the
+single-engine run, for every model, ragged shards, empty shards, weight-set runs that span a cut, and through the `host` binary."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from flowgnn_amd import Engine, EngineGroup, compute_graphs, entry_set_devices, graphpack as gp, shard_ranges_c, weights
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HOST = os.path.join(ROOT, "flowgnn_amd", "host")
+MODELS = ["GIN", "GIN-VN", "GCN", "GAT", "PNA", "DGN"]
+
+
+def batch_for(model, n=61):
+    if model in ("GIN", "GAT"):
+        return gp.synth_molhiv_batch(n, seed=41)
+    if model == "GIN-VN":
+        return gp.add_virtual_nodes(gp.synth_molhiv_batch(n, seed=42))
+    if model == "GCN":
+        return gp.synth_molpcba_batch(n, seed=43)
+    return gp.synth_hep10k_batch(n // 2, seed=44, with_eigen=(model == "DGN"))  # sizes vary: cuts by work differ from cuts by count
+
+
+def single(model, b, w):
+    e = Engine(model, device=0)
+    try:
+        e.set_weights(w)
+        return e.forward(b)
+    finally:
+        e.close()
+
+
+@pytest.mark.parametrize("devices", [[0, 0], [0, 0, 0]], ids=["2x", "3x"])
+@pytest.mark.parametrize("model", MODELS)
+def test_group_is_bit_identical_to_one_engine(model, devices):
+    b, w = batch_for(model), weights.SYNTH[model](seed=7)
+    want = single(model, b, w)
+    g = EngineGroup(model, devices)
+    try:
+        g.set_weights(w)
+        got = g.forward(b)
+        cuts = g.shards()
+        assert cuts == shard_ranges_c(b.nums_of_nodes, b.nums_of_edges, len(devices))
+        assert cuts[0][0] == 0 and cuts[-1][1] == b.num_graphs and all(a < c for a, c in cuts)  # ragged, non-empty
+        assert np.array_equal(got, want)
+        # the resident shards re-run (the timed loop of `host`), then a different batch on the same group
+        g.run()
+        assert np.array_equal(g.results(), want)
+        b2 = b.slice(3, 17)
+        assert np.array_equal(g.forward(b2), want[3:17])
+    finally:
+        g.close()
+
+
+def test_more_engines_than_graphs_and_empty_batch():
+    b, w = gp.synth_molhiv_batch(2, seed=5), weights.synth_gin_weights(seed=7)
+    want = single("GIN", b, w)
+    g = EngineGroup("GIN", [0, 0, 0, 0])
+    try:
+        g.set_weights(w)
+        assert np.array_equal(g.forward(b), want)  # two shards are empty
+        assert sum(1 for a, c in g.shards() if a == c) == 2
+        assert g.forward(b.slice(0, 0)).shape == (0,)
+    finally:
+        g.close()
+
+
+def test_group_options_num_tasks_and_fixed_point(oracle):
+    b = gp.synth_molpcba_batch(40, seed=8)
+    w = weights.synth_gin_weights(seed=7, num_tasks=6)
+    g = EngineGroup("GIN", [0, 0], options={"gin_resident": 0})
+    try:
+        g.set_num_tasks(6)
+        g.set_weights(w)
+        got = g.forward(b)
+        want = oracle.gin_forward(b, [w], num_tasks=6, nthreads=8)
+        assert got.shape == (40, 6) and np.allclose(got, want, rtol=1e-4, atol=1e-4)
+        g.set_num_tasks(1)
+        w1 = weights.synth_gin_weights(seed=7)
+        g.set_weights(w1)
+        g.set_numeric_mode("q6.10")
+        _, want_q = oracle.gin_forward_q(b, [w1], nthreads=8)
+        assert np.array_equal(np.round(g.forward(b) * 1024.0).astype(np.int64), want_q.astype(np.int64))
+    finally:
+        g.close()
+
+
+@pytest.mark.parametrize("model", ["GIN", "DGN"])
+def test_entry_points_on_two_engines_with_reloads_spanning_a_cut(model, oracle):
+    """<M>_compute_graphs with flowgnn_entry_set_devices({0, 0}): every run of constant weight set is sharded on its own, so a
+    reload in the middle of what would be one shard is honoured; same bits as the one-device entry point."""
+    b = batch_for(model, 40)
+    G = b.num_graphs
+    w1, w2 = weights.SYNTH[model](seed=7), weights.SYNTH[model](seed=8)
+    rw = np.zeros(G, np.int32)
+    rw[0] = 1
+    rw[G // 2 - 1] = 1  # just before the middle cut
+    rw[G - 2] = 1       # a two-graph run at the end: one graph per engine
+    sets = [w1, w2, w1]
+    try:
+        entry_set_devices([0])
+        one = compute_graphs(model, b, sets, rw)
+        entry_set_devices([0, 0])
+        two = compute_graphs(model, b, sets, rw)
+    finally:
+        entry_set_devices([0])
+    assert np.array_equal(one, two)
+    want = getattr(oracle, model.lower() + "_forward")(b, sets, reload_weights=rw, nthreads=8)
+    assert np.allclose(two, want, rtol=2e-4, atol=2e-3), np.abs(two - want).max()
+
+
+@pytest.mark.parametrize("model", ["GIN", "PNA"])
+def test_host_binary_devices_flag(model, tmp_path, oracle):
+    """`host <MODEL> --devices 0,0` (the C++ host of north_star on two engines): HLS_output.txt equals the one-device run's and
+    matches the oracle."""
+    w = weights.SYNTH[model](seed=7)
+    batch = gp.synth_hep10k_batch(7, seed=3, with_eigen=False) if model == "PNA" else gp.synth_molhiv_batch(23, seed=3)
+    gdir, wdir = tmp_path / "graphs", tmp_path / "weights"
+    gp.write_pack(batch, str(gdir))
+    weights.SAVERS[model](w, str(wdir))
+    outs = []
+    for devs in ("0", "0,0"):
+        out = tmp_path / f"out_{devs.replace(',', '_')}.txt"
+        r = subprocess.run([HOST, model, "--graphs", str(gdir), "--weights", str(wdir), "--trials", "2", "--out", str(out), "--devices", devs],
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout + r.stderr
+        outs.append(open(out).read())
+    assert outs[0] == outs[1]
+    got = np.array([float(ln.split(":")[1]) for ln in outs[1].strip().splitlines()], dtype=np.float32)
+    want = getattr(oracle, model.lower() + "_forward")(batch, [w])
+    assert np.allclose(got, want, rtol=3e-4, atol=3e-4 * max(1.0, np.abs(want).max()))

@@ -14,13 +14,11 @@ def close(a, b):
 
 
 @pytest.mark.parametrize("tasks", [128, 3])
-@pytest.mark.parametrize("env", [{}, {"FLOWGNN_GIN_RESIDENT": "0"}, {"FLOWGNN_GIN_MFMA": "f32"}], ids=["resident", "per-layer", "f32"])
-def test_gin_multi_task(monkeypatch, oracle, tasks, env):
-    for k, v in env.items():
-        monkeypatch.setenv(k, v)
+@pytest.mark.parametrize("env", [{}, {"gin_resident": 0}, {"gin_mfma": "f32"}], ids=["resident", "per-layer", "f32"])
+def test_gin_multi_task(oracle, tasks, env):
     w = weights.synth_gin_weights(seed=7, num_tasks=tasks)
     b = gp.synth_molpcba_batch(300, seed=5)
-    e = Engine("GIN", device=0)
+    e = Engine("GIN", device=0, options=env)
     e.set_num_tasks(tasks)
     e.set_weights(w)
     got = e.forward(b)
@@ -49,14 +47,12 @@ def test_gin_vn_multi_task(oracle):
     e.close()
 
 
-@pytest.mark.parametrize("env", [{}, {"FLOWGNN_GCN_UNFUSED": "1"}, {"FLOWGNN_GCN_MFMA": "f32"}], ids=["fused", "unfused", "f32"])
-def test_gcn_multi_task(monkeypatch, tmp_path, oracle, env):
-    for k, v in env.items():
-        monkeypatch.setenv(k, v)
+@pytest.mark.parametrize("env", [{}, {"gcn_unfused": 1}, {"gcn_mfma": "f32"}], ids=["fused", "unfused", "f32"])
+def test_gcn_multi_task(tmp_path, oracle, env):
     tasks = 128
     w = weights.synth_gcn_weights(seed=7, num_tasks=tasks)
     b = gp.synth_molpcba_batch(300, seed=8)
-    e = Engine("GCN", device=0)
+    e = Engine("GCN", device=0, options=env)
     e.set_num_tasks(tasks)
     e.set_weights(w)
     got, want = e.forward(b), oracle.gcn_forward(b, [w], num_tasks=tasks, nthreads=8)
@@ -79,7 +75,14 @@ def test_entry_points_and_refusals(oracle):
     # the entry-point engine goes back to NUM_TASK = 1 afterwards
     w1 = weights.synth_gin_weights(seed=7)
     assert close(compute_graphs("GIN", b, [w1]), oracle.gin_forward(b, [w1]))
+    # GCN through its _mt entry point as well
+    wg = weights.synth_gcn_weights(seed=7, num_tasks=tasks)
+    gotg = compute_graphs("GCN", b, [wg], num_tasks=tasks)
+    assert gotg.shape == (9, tasks) and close(gotg, oracle.gcn_forward(b, [wg], num_tasks=tasks))
     for model in ("PNA", "DGN", "GAT"):
+        with pytest.raises(FlowGNNError) as ei:  # single-task MLP heads: refused, never a half-written [G][T] array
+            compute_graphs(model, b, [weights.SYNTH[model](seed=1)], num_tasks=4)
+        assert ei.value.code == 8
         e = Engine(model, device=0)
         with pytest.raises(FlowGNNError) as ei:
             e.set_num_tasks(4)

@@ -26,19 +26,13 @@ def random_graph(n, m, seed):
 
 
 def run(model, b, env=None, monkeypatch=None):
-    if env:
-        for k, v in env.items():
-            monkeypatch.setenv(k, v)
     w = getattr(weights, f"synth_{model.replace('-VN', '').lower()}_weights")(seed=11)
-    e = Engine(model, device=0)
+    e = Engine(model, device=0, options=env or {})
     try:
         e.set_weights(w)
         return e.forward(b), w
     finally:
         e.close()
-        if env:
-            for k in env:
-                monkeypatch.delenv(k)
 
 
 def check(model, b, oracle, monkeypatch, env=None):
@@ -59,7 +53,7 @@ def test_graphs_at_the_tile_limits(model, oracle, monkeypatch):
     both = random_graph(rows, edges, seed=4)                  # both at once
     b = gp.concat_batches([mol.slice(0, 13), at_rows, mol.slice(13, 14), at_edges, both, mol.slice(14, 40)])
     resident = check(model, b, oracle, monkeypatch)
-    per_layer = check(model, b, oracle, monkeypatch, env={f"FLOWGNN_{model.replace('-VN', '')}_RESIDENT": "0"})
+    per_layer = check(model, b, oracle, monkeypatch, env={f"{model.replace('-VN', '').lower()}_resident": 0})
     scale = max(1.0, float(np.abs(per_layer).max()))
     assert np.allclose(resident, per_layer, rtol=2e-4, atol=2e-4 * scale)
     # any split of the batch gives the same bits (tiles are re-packed, rows change lanes)

@@ -15,7 +15,7 @@ import make_modes_golden as mk  # noqa: E402  (fixture_batch)
 
 MODELS = ["GIN", "GCN", "GAT", "PNA", "DGN"]
 FRAC = {"GIN": 10, "GCN": 10, "GAT": 10, "PNA": 10, "DGN": 13}
-SWITCH = {"GIN": "FLOWGNN_GIN_RESIDENT", "GCN": "FLOWGNN_GCN_RESIDENT", "GAT": "FLOWGNN_GAT_RESIDENT", "PNA": "FLOWGNN_PNA_FUSED", "DGN": "FLOWGNN_DGN_FUSED"}
+SWITCH = {"GIN": "gin_resident", "GCN": "gcn_resident", "GAT": "gat_resident", "PNA": "pna_fused", "DGN": "dgn_fused"}
 
 
 def trained(model):
@@ -49,11 +49,9 @@ def test_fixture_is_the_shipped_set_and_the_oracle_reproduces_its_logits(model, 
 @pytest.mark.gpu
 @pytest.mark.parametrize("per_layer", [False, True], ids=["resident-or-fused", "per-layer"])
 @pytest.mark.parametrize("model", MODELS)
-def test_gpu_matches_the_oracle_on_trained_weights(model, per_layer, monkeypatch):
+def test_gpu_matches_the_oracle_on_trained_weights(model, per_layer):
     from flowgnn_amd import Engine
-    if per_layer:
-        monkeypatch.setenv(SWITCH[model], "0")
-    e = Engine(model, device=0)
+    e = Engine(model, device=0, options={SWITCH[model]: 0} if per_layer else {})
     try:
         e.set_weights(trained(model))
         got = e.forward(mk.fixture_batch(model))
@@ -96,3 +94,70 @@ def test_fixed_point_mode_bit_exact_on_trained_weights(model, oracle):
     finally:
         e.close()
     assert np.array_equal(np.round(got * float(1 << FRAC[model])).astype(np.int64), want_q.astype(np.int64))
+
+
+# ---------------------------------------------------------------- trained weights beyond the models' own dataset shapes
+def _big_graph(n, m, seed):
+    """One connected graph at the reference's caps (GIN/src/dcl.h:17-18: 500 nodes / 5 500 edges)."""
+    from flowgnn_amd import graphpack as gp
+    rng = np.random.default_rng(seed)
+    dims = np.array([119, 4, 12, 12, 10, 6, 6, 2, 2])
+    nf = (rng.integers(0, 1 << 30, (n, 9)) % dims).astype(np.int32)
+    ring = np.stack([np.arange(n), (np.arange(n) + 1) % n], 1)
+    el = np.concatenate([ring, rng.integers(0, n, (m - n, 2))]).astype(np.int32)
+    ea = np.stack([rng.integers(0, 5, m), rng.integers(0, 6, m), rng.integers(0, 2, m)], 1).astype(np.int32)
+    return gp.GraphBatch(np.array([n], np.int32), np.array([m], np.int32), nf, el, ea)
+
+
+def _shape_batch(shape):
+    from flowgnn_amd import graphpack as gp
+    if shape == "hep10k":      # kNN graphs: every node sums 16 messages (SURVEY 0.1: the case that wraps on the FPGA)
+        return gp.synth_hep10k_batch(96, seed=71, with_eigen=False)
+    if shape == "caps":        # the reference's MAX_NODE / MAX_EDGE, next to ordinary molecules
+        mol = gp.synth_molhiv_batch(40, seed=72)
+        return gp.concat_batches([mol.slice(0, 20), _big_graph(500, 5500, 73), mol.slice(20, 40), _big_graph(183, 378, 74)])
+    if shape == "molpcba":     # a full-size sample of GCN's own dataset shape
+        return gp.synth_molpcba_batch(4096, seed=75)
+    raise ValueError(shape)
+
+
+# measured on MI355X (the flag trips where the oracle's activations say it must; trained GIN on kNN graphs grows ~6x per layer)
+EXPECT_RERUN = {("GIN", "hep10k"): True, ("GIN", "caps"): False, ("GIN-VN", "hep10k"): True, ("GIN-VN", "caps"): True,
+                ("GCN", "molpcba"): False, ("GCN", "caps"): False}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("per_layer", [False, True], ids=["resident", "per-layer"])
+@pytest.mark.parametrize("model,shape", [("GIN", "hep10k"), ("GIN", "caps"), ("GIN-VN", "hep10k"), ("GIN-VN", "caps"), ("GCN", "molpcba"), ("GCN", "caps")])
+def test_trained_weights_on_other_graph_shapes(model, shape, per_layer, oracle):
+    """Trained GIN / GIN-VN on dense (degree-16) graphs and on graphs at the reference's caps, trained GCN on a full-size molpcba
+    sample.  Trained GIN grows ~6x per layer on degree-16 graphs (h_5 up to 2.7e4, GIN-VN 1.7e5; the reference's Q6.10 wraps there,
+    SURVEY 0.1), so some of these batches DO leave the split-f16 range: the flag must then trip and the fp32 re-run must match the
+    oracle; exact_reruns is asserted either way (EXPECT_RERUN)."""
+    from flowgnn_amd import Engine, graphpack as gp
+    base = model.replace("-VN", "")
+    w = trained(base)
+    b = _shape_batch(shape)
+    if model == "GIN-VN":
+        b = gp.add_virtual_nodes(b)
+    fwd = getattr(oracle, base.lower() + "_forward")
+    want, hd = fwd(b, [w], dump_h=True, nthreads=8)
+    assert np.isfinite(want).all()
+    e = Engine(model, device=0, options={SWITCH[base]: 0} if per_layer else {})
+    try:
+        e.set_weights(w)
+        got = e.forward(b)
+        reruns = e.exact_reruns()
+    finally:
+        e.close()
+    hmax = [float(np.abs(np.asarray(h)).max()) for h in hd]
+    scale = max(1.0, max(hmax))
+    assert np.allclose(got, want, rtol=2e-4, atol=2e-4 * scale), (model, shape, np.abs(got - want).max(), scale)
+    # The range flag, either way.  h_1..h_4 are operands of the next layer's products (a = h + sum of ReLU'd terms >= h): beyond 6e4
+    # the split-f16 kernels MUST have raised the flag and the engine repeated the pass on the fp32 pipe; where every activation
+    # (aggregates and hidden units included: bounded here by 64 x the largest row entry) stays below it, they must NOT have.
+    if max(hmax[1:5]) > 6.0e4:
+        assert reruns >= 1, (model, shape, hmax)
+    elif 64.0 * max(hmax) < 6.0e4:
+        assert reruns == 0, (model, shape, hmax)
+    assert EXPECT_RERUN[(model, shape)] == (reruns > 0), (model, shape, reruns, hmax)

@@ -1,19 +1,19 @@
 """Every kernel variant that carries a reported number, checked against the oracle.
 
 The default forward of each model is covered by tests/test_<model>_gpu.py.  The engine also ships alternative kernels
-behind environment switches (read when a model object is created, e.g. flowgnn_amd/csrc/gin.hip `fused_`, `split_`):
-    FLOWGNN_GIN_UNFUSED=1        gin_aggregate_tiled_kernel + gin_mlp_kernel (the kernel behind `aggregation_roofline`)
-    FLOWGNN_GIN_AGG_UNTILED=1    ... with the first, un-tiled aggregation kernel;  FLOWGNN_GIN_AGG_TILE=64|256: other tilings
-    FLOWGNN_GIN_MFMA=f32         fp32-MFMA fused layer (the exact fallback)
-    FLOWGNN_GIN_SPLIT_NT=1|2     four-wave forms of the split-f16 layer kernel
-    FLOWGNN_GIN_HEAD_FOLD=0      resident kernel with the last layer's second linear layer computed (readout not folded through it)
-    FLOWGNN_GIN_RESIDENT=0       per-layer launches instead of the graph-resident multi-layer kernel (FLOWGNN_GAT_RESIDENT=0 likewise)
-    FLOWGNN_{GIN,GAT}_FOLD_READOUT=0   separate mean-pool + linear kernel
-    FLOWGNN_GCN_UNFUSED=1        tiled_aggregate_kernel<GcnAggPolicy> + dense100_split_kernel
-    FLOWGNN_<M>_MFMA=f32         fp32 matrix pipe for every model
-    FLOWGNN_CSR_FLAT=1           global-memory index build
-    FLOWGNN_HIPGRAPH             covered by tests/test_hipgraph_gpu.py
-Each variant gets a fresh Engine (fresh model object) with the switch set and must match the CPU oracle to the same
+behind named options (flowgnn_set_option; include/flowgnn.h, table in flowgnn_amd/csrc/engine.hip):
+    gin_unfused=1        gin_aggregate_tiled_kernel + gin_mlp_kernel (the kernel behind `aggregation_roofline`)
+    gin_agg_untiled=1    ... with the first, un-tiled aggregation kernel;  gin_agg_tile=64|256: other tilings
+    gin_mfma=32 ("f32")         fp32-MFMA fused layer (the exact fallback)
+    gin_split_nt=1|2     four-wave forms of the split-f16 layer kernel
+    gin_head_fold=0      resident kernel with the last layer's second linear layer computed (readout not folded through it)
+    gin_resident=0       per-layer launches instead of the graph-resident multi-layer kernel (gat_resident=0 likewise)
+    {gin,gat}_fold_readout=0   separate mean-pool + linear kernel
+    gcn_unfused=1        tiled_aggregate_kernel<GcnAggPolicy> + dense100_split_kernel
+    <m>_mfma=32         fp32 matrix pipe for every model
+    csr_flat=1           global-memory index build
+    hipgraph             covered by tests/test_hipgraph_gpu.py
+Each variant gets a fresh Engine with the option set through the API and must match the CPU oracle to the same
 tolerance as the default path.  The standalone aggregation kernels timed by flowgnn_run_aggregation_only are read back
 through flowgnn_get_aggregate and compared with the message-passing equations evaluated on the rows they read
 (GIN/src/message_passing.cc:136-145 + node_embedding.cc:117; GCN/src/message_passing.cc:158-167 +
@@ -28,19 +28,17 @@ from tests.numpy_ref import ED_OFF
 pytestmark = pytest.mark.gpu
 
 
-def fresh_forward(monkeypatch, model, env, batch, w, want_h=False):
-    for k, v in env.items():
-        monkeypatch.setenv(k, v)
-    e = Engine(model, device=0)
+def fresh_forward(model, options, batch, w, want_h=False):
+    e = Engine(model, device=0, options=options)  # flowgnn_set_option per entry, before weights and batch
     try:
+        for k, v in options.items():
+            assert e.get_option(k) == (32.0 if v == "f32" else float(v))
         e.set_weights(w)
         out = e.forward(batch)
         h = e.final_h() if want_h else None
         reruns = e.exact_reruns()
     finally:
         e.close()
-        for k in env:
-            monkeypatch.delenv(k, raising=False)
     return out, h, reruns
 
 
@@ -63,27 +61,27 @@ def oracle_fn(oracle, model):
 TOL = {"GIN": (1e-4, 1e-4), "GIN-VN": (2e-4, 1e-3), "GCN": (1e-4, 1e-4), "GAT": (2e-4, 2e-4), "PNA": (2e-4, 2e-3), "DGN": (2e-4, 2e-3)}
 
 GIN_VARIANTS = [
-    {"FLOWGNN_GIN_UNFUSED": "1"},
-    {"FLOWGNN_GIN_UNFUSED": "1", "FLOWGNN_GIN_AGG_UNTILED": "1"},
-    {"FLOWGNN_GIN_UNFUSED": "1", "FLOWGNN_GIN_AGG_TILE": "64"},
-    {"FLOWGNN_GIN_UNFUSED": "1", "FLOWGNN_GIN_AGG_TILE": "256"},
-    {"FLOWGNN_GIN_MFMA": "f32"},
-    {"FLOWGNN_GIN_HEAD_FOLD": "0"},
-    {"FLOWGNN_GIN_RESIDENT": "0"},
-    {"FLOWGNN_GIN_RESIDENT": "0", "FLOWGNN_GIN_SPLIT_NT": "1"},
-    {"FLOWGNN_GIN_RESIDENT": "0", "FLOWGNN_GIN_SPLIT_NT": "2"},
-    {"FLOWGNN_GIN_RESIDENT": "0", "FLOWGNN_GIN_FOLD_READOUT": "0"},
-    {"FLOWGNN_GIN_FOLD_READOUT": "0"},
-    {"FLOWGNN_CSR_FLAT": "1"},
+    {"gin_unfused": 1},
+    {"gin_unfused": 1, "gin_agg_untiled": 1},
+    {"gin_unfused": 1, "gin_agg_tile": 64},
+    {"gin_unfused": 1, "gin_agg_tile": 256},
+    {"gin_mfma": "f32"},
+    {"gin_head_fold": 0},
+    {"gin_resident": 0},
+    {"gin_resident": 0, "gin_split_nt": 1},
+    {"gin_resident": 0, "gin_split_nt": 2},
+    {"gin_resident": 0, "gin_fold_readout": 0},
+    {"gin_fold_readout": 0},
+    {"csr_flat": 1},
 ]
 
 
-@pytest.mark.parametrize("env", GIN_VARIANTS, ids=lambda e: ",".join(f"{k[8:]}={v}" for k, v in e.items()))
+@pytest.mark.parametrize("env", GIN_VARIANTS, ids=lambda e: ",".join(f"{k}={v}" for k, v in e.items()))
 @pytest.mark.parametrize("model", ["GIN", "GIN-VN"])
-def test_gin_variants_match_oracle(monkeypatch, oracle, model, env):
+def test_gin_variants_match_oracle(oracle, model, env):
     b = batch_for(model)
     w = weights.synth_gin_weights(seed=7)
-    got, h, reruns = fresh_forward(monkeypatch, model, env, b, w, want_h=True)
+    got, h, reruns = fresh_forward(model, env, b, w, want_h=True)
     want, hd = oracle.gin_forward(b, [w], dump_h=True, nthreads=8)
     rtol, atol = TOL[model]
     assert np.isfinite(got).all()
@@ -93,29 +91,29 @@ def test_gin_variants_match_oracle(monkeypatch, oracle, model, env):
 
 
 OTHER_VARIANTS = [
-    ("GCN", {"FLOWGNN_GCN_RESIDENT": "0"}),
-    ("GCN", {"FLOWGNN_GCN_UNFUSED": "1"}),
-    ("GCN", {"FLOWGNN_GCN_MFMA": "f32"}),
-    ("GCN", {"FLOWGNN_GCN_UNFUSED": "1", "FLOWGNN_GCN_MFMA": "f32"}),
-    ("GCN", {"FLOWGNN_CSR_FLAT": "1"}),
-    ("GAT", {"FLOWGNN_GAT_MFMA": "f32"}),
-    ("GAT", {"FLOWGNN_GAT_RESIDENT": "0"}),
-    ("GAT", {"FLOWGNN_GAT_FOLD_READOUT": "0"}),
-    ("GAT", {"FLOWGNN_GAT_MFMA": "f32", "FLOWGNN_GAT_FOLD_READOUT": "0"}),
-    ("PNA", {"FLOWGNN_PNA_MFMA": "f32"}),
-    ("PNA", {"FLOWGNN_PNA_FUSED": "0"}),
-    ("DGN", {"FLOWGNN_DGN_MFMA": "f32"}),
-    ("DGN", {"FLOWGNN_DGN_FUSED": "0"}),
-    ("PNA", {"FLOWGNN_TILE_NOMINAL": "64", "FLOWGNN_TILE_SLACK": "0"}),
-    ("DGN", {"FLOWGNN_TILE_NOMINAL": "128", "FLOWGNN_TILE_SLACK": "0"}),
+    ("GCN", {"gcn_resident": 0}),
+    ("GCN", {"gcn_unfused": 1}),
+    ("GCN", {"gcn_mfma": "f32"}),
+    ("GCN", {"gcn_unfused": 1, "gcn_mfma": "f32"}),
+    ("GCN", {"csr_flat": 1}),
+    ("GAT", {"gat_mfma": "f32"}),
+    ("GAT", {"gat_resident": 0}),
+    ("GAT", {"gat_fold_readout": 0}),
+    ("GAT", {"gat_mfma": "f32", "gat_fold_readout": 0}),
+    ("PNA", {"pna_mfma": "f32"}),
+    ("PNA", {"pna_fused": 0}),
+    ("DGN", {"dgn_mfma": "f32"}),
+    ("DGN", {"dgn_fused": 0}),
+    ("PNA", {"tile_nominal": 64, "tile_slack": 0}),
+    ("DGN", {"tile_nominal": 128, "tile_slack": 0}),
 ]
 
 
-@pytest.mark.parametrize("model,env", OTHER_VARIANTS, ids=lambda x: x if isinstance(x, str) else ",".join(f"{k[8:]}={v}" for k, v in x.items()))
-def test_other_model_variants_match_oracle(monkeypatch, oracle, model, env):
+@pytest.mark.parametrize("model,env", OTHER_VARIANTS, ids=lambda x: x if isinstance(x, str) else ",".join(f"{k}={v}" for k, v in x.items()))
+def test_other_model_variants_match_oracle(oracle, model, env):
     b = batch_for(model)
     w = weights.SYNTH[model](seed=7)
-    got, _, _ = fresh_forward(monkeypatch, model, env, b, w)
+    got, _, _ = fresh_forward(model, env, b, w)
     want = oracle_fn(oracle, model)(b, [w], nthreads=8)
     rtol, atol = TOL[model]
     scale = max(1.0, float(np.abs(want).max()))
@@ -140,16 +138,14 @@ def gin_aggregate_reference(h, batch, row_ptr, src, eid, eemb_l):
     return acc + h
 
 
-@pytest.mark.parametrize("env", [{}, {"FLOWGNN_GIN_AGG_UNTILED": "1"}, {"FLOWGNN_GIN_AGG_TILE": "64"}, {"FLOWGNN_GIN_AGG_TILE": "256"}],
+@pytest.mark.parametrize("env", [{}, {"gin_agg_untiled": 1}, {"gin_agg_tile": 64}, {"gin_agg_tile": 256}],
                          ids=["tiled128", "untiled", "tiled64", "tiled256"])
-def test_gin_aggregation_probe_is_bit_exact(monkeypatch, oracle, env):
+def test_gin_aggregation_probe_is_bit_exact(oracle, env):
     """gin_aggregate_tiled_kernel, the kernel `aggregation_roofline` in bench.py is measured on."""
-    for k, v in env.items():
-        monkeypatch.setenv(k, v)
     b = gp.concat_batches([gp.synth_molhiv_batch(500, seed=51), gp.add_virtual_nodes(gp.synth_molhiv_batch(20, seed=52)),
                            gp.synth_hep10k_batch(6, seed=53, with_eigen=False)])
     w = weights.synth_gin_weights(seed=7)
-    e = Engine("GIN", device=0)
+    e = Engine("GIN", device=0, options=env)
     e.set_weights(w)
     out = e.forward(b)
     row_ptr, src, eid, _ = e.csr()
@@ -206,3 +202,49 @@ def test_entry_point_skips_identical_weight_reloads(oracle):
     got = GIN_compute_graphs(b, [w1, w1, w1, w2, w2, w1], rw)
     want = oracle.gin_forward(b, [w1, w1, w1, w2, w2, w1], reload_weights=rw)
     assert np.allclose(got, want, rtol=1e-4, atol=1e-4), np.abs(got - want).max()
+
+
+def test_options_api_and_fixed_point_aggregate_guard(oracle):
+    """flowgnn_set_option: unknown keys are refused; an option invalidates the resident batch; the aggregation taps are refused
+    (not run on stale or missing inputs) while a fixed-point mode is selected."""
+    from flowgnn_amd import FlowGNNError
+    b = gp.synth_hep10k_batch(8, seed=3, with_eigen=False)
+    e = Engine("PNA", device=0)
+    with pytest.raises(FlowGNNError) as ei:
+        e.set_option("no_such_switch", 1)
+    assert ei.value.code == 8
+    with pytest.raises(FlowGNNError):
+        e.set_option("pna_ablate", 1)  # development hooks do not exist in the shipped library
+    e.set_weights(weights.SYNTH["PNA"](seed=7))
+    ref = e.forward(b)
+    e.set_option("pna_fused", 0)
+    with pytest.raises(FlowGNNError) as ei:
+        e.run()  # the batch must be set again after an option change
+    assert ei.value.code == 6
+    two_kernel = e.forward(b)
+    assert np.allclose(two_kernel, ref, rtol=2e-4, atol=2e-3)
+    e.aggregate(0)  # float mode: available
+    e.set_numeric_mode("q6.10")
+    e.forward(b)
+    with pytest.raises(FlowGNNError) as ei:
+        e.aggregate(0)
+    assert ei.value.code == 8
+    with pytest.raises(FlowGNNError) as ei:
+        e.aggregation_only_ms(0, 1)
+    assert ei.value.code == 8
+    e.close()
+    for model, mk in (("GCN", gp.synth_molpcba_batch), ("DGN", lambda n, seed: gp.synth_hep10k_batch(n, seed=seed, with_eigen=True))):
+        e = Engine(model, device=0)
+        e.set_weights(weights.SYNTH[model](seed=7))
+        e.forward(mk(4, seed=1))
+        e.aggregate(0)
+        e.set_numeric_mode("q6.10")
+        e.forward(mk(40, seed=2))  # a LARGER batch: stale tiles of the float run must not be used
+        with pytest.raises(FlowGNNError) as ei:
+            e.aggregate(0)
+        assert ei.value.code == 8
+        e.set_numeric_mode("f32")
+        out = e.forward(mk(40, seed=2))
+        e.aggregate(0)
+        assert np.isfinite(out).all()
+        e.close()
