@@ -139,6 +139,8 @@ struct DeviceBatch {
     int tap_dim;
     bool h_valid;             // h[final_h] holds the last stage's node embeddings (false: the model folded the readout into its last
                               // layer and never wrote them; flowgnn_get_h then repeats the pass with Model::set_keep_h(true))
+    bool csr_built;           // csr.* describe this batch (set by the engine when the index build has run; kernels that work from the
+                              // caller's arrays directly -- Model::needs_csr() == false -- leave it as it is)
     GraphTiles gtiles;        // graph-aligned tiles (GraphTiles above), n_tiles == 0 if the model did not ask for them
     int* range_flag;          // [1] set by a reduced-range kernel whose operands left its accurate range (see Model::set_exact)
 };
@@ -190,6 +192,9 @@ public:
     virtual int set_weights(const float* const* host_tensors) = 0;
     virtual int load_weights_dir(const char* dir) = 0;
     virtual bool weights_ready() const = 0;
+    // false: the next forward() of this batch (under the current exact / keep_h / numeric state) reads the caller's arrays itself and
+    // needs no destination-major CSR in HBM; the engine then skips the index build for that run (taps build it on demand)
+    virtual bool needs_csr(const DeviceBatch&) const { return true; }
     virtual int forward(DeviceBatch& db, Profiler& prof, hipStream_t s) = 0;
     virtual int aggregation_only(DeviceBatch& db, int layer, hipStream_t s) { (void)db; (void)layer; (void)s; return 8; }
     // floats per node that aggregation_only() writes to db.scratch (0: the model has no standalone aggregation kernel)

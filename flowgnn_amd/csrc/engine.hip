@@ -93,7 +93,7 @@ static const OptionDef kOptionTable[] = {
     {"csr_flat", 0},              // 1: global-memory index build for every graph (A/B)
     {"tile_nominal", -1},         // rows per tile of the tiled aggregation kernels (< 0: the model's default)
     {"tile_slack", -1},
-    {"gin_resident", 1}, {"gin_resident_min_fill", 0.5}, {"gin_resident_nosort", 0}, {"gin_resident_prof", 0},
+    {"gin_resident", 1}, {"gin_tile_build", -1}, {"gin_resident_min_fill", 0.5}, {"gin_resident_nosort", 0}, {"gin_resident_prof", 0},
     {"gin_unfused", 0}, {"gin_mfma", 16}, {"gin_split_nt", 4}, {"gin_fold_readout", 1}, {"gin_head_fold", 1},
     {"gin_agg_untiled", 0}, {"gin_agg_tile", 128},
     {"gcn_resident", 1}, {"gcn_unfused", 0}, {"gcn_mfma", 16},
@@ -261,6 +261,24 @@ struct flowgnn_engine {
 static int use_device(flowgnn_engine* e) {
     FG_HIP_TRY(hipSetDevice(e->device));
     return 0;
+}
+
+// index build (when the model's next forward needs the CSR) + forward pass, on the engine's stream; the state the model decides
+// on (exact / keep_h / numeric mode) must be set before
+static int engine_forward(flowgnn_engine* e) {
+    if (e->model->needs_csr(e->db)) {
+        ProfScope p(e->prof, "build_csr", e->stream);
+        const bool flat = e->opts.on("csr_flat");  // A/B: force the global path
+        launch_build_csr(e->db.b, e->db.csr, e->has_attr, flat ? (1 << 30) : e->max_nodes, flat ? (1 << 30) : e->max_edges, e->stream);
+        e->db.csr_built = true;
+    }
+    return e->model->forward(e->db, e->prof, e->stream);
+}
+// taps that read the CSR (flowgnn_get_csr, the stand-alone aggregation kernels): build it if no run of this batch has
+static void ensure_csr(flowgnn_engine* e) {
+    if (e->db.csr_built || e->G == 0) return;
+    launch_build_csr(e->db.b, e->db.csr, e->has_attr, e->max_nodes, e->max_edges, e->stream);
+    e->db.csr_built = true;
 }
 
 extern "C" {
@@ -508,6 +526,7 @@ int flowgnn_set_batch(flowgnn_engine* e, int num_graphs, const int* nums_of_node
     db.final_h = 0;
     db.tap = nullptr;
     db.tap_dim = 0;
+    db.csr_built = false;
     EHIP_TRY(e, hipMemset(e->d_err, 0, 2 * sizeof(int)));
     e->db.range_flag = e->d_err + 1;
     e->force_exact = false;
@@ -544,16 +563,11 @@ int flowgnn_run(flowgnn_engine* e) {
         }
     }
     int frc = FLOWGNN_OK;
-    {
-        ProfScope p(e->prof, "build_csr", e->stream);
-        const bool flat = e->opts.on("csr_flat");  // A/B: force the global path
-        launch_build_csr(e->db.b, e->db.csr, e->has_attr, flat ? (1 << 30) : e->max_nodes, flat ? (1 << 30) : e->max_edges, e->stream);
-    }
     e->db.tap = nullptr;
     e->db.tap_dim = 0;
     e->db.h_valid = true;
     e->model->set_exact(e->force_exact);
-    frc = e->model->forward(e->db, e->prof, e->stream);
+    frc = engine_forward(e);
     if (capture) {
         hipGraph_t g = nullptr;
         hipError_t hc = hipStreamEndCapture(e->stream, &g);
@@ -616,7 +630,7 @@ int flowgnn_sync(flowgnn_engine* e) {
         e->drop_graph();  // the captured launches are the split-f16 ones
         EHIP_TRY(e, hipMemsetAsync(e->d_err + 1, 0, sizeof(int), e->stream));
         e->model->set_exact(true);
-        ENGINE_TRY(e, e->model->forward(e->db, e->prof, e->stream));
+        ENGINE_TRY(e, engine_forward(e));
         he = hipStreamSynchronize(e->stream);
         if (he != hipSuccess) {
             set_hip_error("hipStreamSynchronize (exact re-run)", he, __FILE__, __LINE__);
@@ -746,6 +760,8 @@ const char* flowgnn_option_name(int i) { return (i >= 0 && i < kNumOptions) ? kO
 int flowgnn_get_csr(flowgnn_engine* e, int* row_ptr, int* src, int* eid, int* out_deg) {
     if (!e) return FLOWGNN_ERR_ARG;
     if (!e->ran) return FLOWGNN_ERR_STATE;
+    ENGINE_TRY(e, use_device(e));
+    ensure_csr(e);  // the last run may have worked from the caller's arrays directly
     int rc = flowgnn_sync(e);
     if (rc) return rc;
     if (row_ptr && e->N == 0) row_ptr[0] = 0;  // empty batch: nothing was built (and nothing may have been allocated)
@@ -764,7 +780,7 @@ int flowgnn_get_h(flowgnn_engine* e, float* h_host, int* dim) {
     if (!e->db.h_valid && !e->db.tap) {  // the readout was folded into the last layer: repeat the pass with the tap on
         e->model->set_keep_h(true);
         e->model->set_exact(e->force_exact);
-        rc = e->model->forward(e->db, e->prof, e->stream);
+        rc = engine_forward(e);
         e->model->set_keep_h(false);
         if (rc) { e->err = fg::last_error_text(); return rc; }
         rc = flowgnn_sync(e);
@@ -811,6 +827,7 @@ int flowgnn_run_aggregation_only(flowgnn_engine* e, int layer, int iters, float*
     if (!e->ran) { e->err = "flowgnn_run_aggregation_only needs a prior flowgnn_run"; return FLOWGNN_ERR_STATE; }
     ENGINE_TRY(e, use_device(e));
     e->drop_graph();
+    ensure_csr(e);
     int rc = e->model->aggregation_only(e->db, layer, e->stream);  // warm-up; also the model's verdict on `layer`
     if (rc) {
         e->err = rc == FLOWGNN_ERR_UNSUPPORTED ? "no standalone aggregation kernel for this model / numeric mode (the fixed-point modes have none)" : "flowgnn_run_aggregation_only: bad layer";
@@ -848,6 +865,7 @@ int flowgnn_get_aggregate(flowgnn_engine* e, int layer, float* h_in_host, int* i
     if (agg_dim) *agg_dim = AD;
     if (AD <= 0) { e->err = "no standalone aggregation kernel for this model / numeric mode (the fixed-point modes have none)"; return FLOWGNN_ERR_UNSUPPORTED; }
     if (e->N == 0 || (!h_in_host && !agg_host)) return FLOWGNN_OK;
+    ensure_csr(e);
     rc = e->model->aggregation_only(e->db, layer, e->stream);
     if (rc) { e->err = rc == FLOWGNN_ERR_UNSUPPORTED ? "flowgnn_get_aggregate: not available in this numeric mode" : "flowgnn_get_aggregate: bad layer"; return rc; }
     EHIP_TRY(e, hipStreamSynchronize(e->stream));

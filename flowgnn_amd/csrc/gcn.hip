@@ -886,7 +886,7 @@ public:
     void set_exact(bool on) override { exact_ = on; }
 
     int aggregation_only(DeviceBatch& db, int layer, hipStream_t s) override {
-        if (qmode_) return 8;  // FLOWGNN_ERR_UNSUPPORTED: the fixed-point forward never builds the float kernels\' inputs (tiles, h rows)
+        if (qmode_) return 8;  // FLOWGNN_ERR_UNSUPPORTED: the fixed-point forward never builds the float kernels' inputs (tiles, h rows)
         if (layer < 0 || layer >= GCN_L) return 1;
         if (!agg_ready_) {  // the last forward ran the graph-resident kernel
             Profiler none;

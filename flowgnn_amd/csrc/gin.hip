@@ -630,6 +630,11 @@ public:
             gin_resident_head_fold(w1 + (size_t)l * GIN_H * GIN_D, w2 + (size_t)l * GIN_D * GIN_H, b2 + (size_t)l * GIN_D, pw, head.data());
             if ((rc = upload(&d_head_, head))) return rc;
         }
+        {   // pre-combined encoder table of the one-pass tile loader (gin_tile_build_kernel + the resident kernel's ENC form)
+            std::vector<float> etab(gin_resident_enc_table_floats());
+            gin_resident_pack_enc_table(nemb, etab.data());
+            if ((rc = upload(&d_enc_tab_, etab))) return rc;
+        }
         if ((rc = upload(&d_chunks_, chunks))) return rc;
         if ((rc = upload(&d_nemb_, v_nemb))) return rc;
         if ((rc = upload(&d_pw_, v_pw))) return rc;
@@ -717,10 +722,43 @@ public:
         return resident_ && fused_ && split_ && !exact_ && db.gtiles.ok && db.gtiles.n_tiles > 0 && db.gtiles.fill >= resident_min_fill_;
     }
 
+    // One-pass form of the graph-resident path (default): gin_tile_build_kernel turns the caller's edge list / attributes / node
+    // features of each tile into the tile descriptor + four table-row numbers per node, and the resident kernel's tile loader
+    // computes h_0 itself -- no CSR, no h_0 rows and no separate encoder / index-build launches in HBM.  Needs the folded
+    // single-task readout (the loader rides on the folded last layer's steps); gin_tile_build = 0 restores the three-kernel front end.
+    bool one_pass(const DeviceBatch& db) const {
+        // measured (2^18 molhiv graphs): the tile build costs what index build + tile prep cost (0.27 ms) and the encoder
+        // inside the last layer's steps costs the resident kernel 0.57 ms (VALU issue at two waves per SIMD) where the separate,
+        // store-bound encoder launch costs 0.51 -- so on large batches the one-pass form does not pay (9.61 vs 9.47 ms per step);
+        // on dataset-sized batches it does (two launches instead of four: 0.229 vs 0.246 ms at 4 113 graphs).  -1 = choose by size.
+        const bool want = tile_build_ < 0 ? db.gtiles.n_tiles <= 2048 : tile_build_ != 0;
+        return want && use_resident(db) && !qmode_ && !keep_h_ && num_tasks_ == 1 && fold_readout_ && head_fold_ && db.b.edge_attr != nullptr;
+    }
+    bool needs_csr(const DeviceBatch& db) const override { return !one_pass(db); }
+
     int forward(DeviceBatch& db, Profiler& prof, hipStream_t s) override {
         const int n = db.b.n_tot;
         if (n <= 0) return 0;
         if (qmode_) return ginq_forward(qw_, db, prof, s);
+        if (one_pass(db)) {
+            if (int rc = perm_.reserve((size_t)db.gtiles.n_tiles * (GIN_RESIDENT_DESC_BYTES / 4))) return rc;
+            if (int rc = enc_idx_.reserve((size_t)n * 2)) return rc;
+            GinTileBuild tb{db.b, enc_idx_.p, d_enc_tab_, db.csr.err};
+            {
+                ProfScope p(prof, "gin_tile_build", s);
+                launch_gin_tile_build(tb, db.gtiles.row_start, db.gtiles.graph_start, reinterpret_cast<uint8_t*>(perm_.p), db.gtiles.n_tiles,
+                                      virtual_node_, resident_order_, s);
+            }
+            ProfScope p(prof, "gin_resident", s);  // the whole model
+            launch_gin_resident(nullptr, nullptr, nullptr, nullptr, nullptr, d_ecomb_, d_rsplit_, d_pw_, d_pb_, db.gtiles.row_start,
+                                db.gtiles.graph_start, reinterpret_cast<uint8_t*>(perm_.p), db.b.node_off, db.out, db.gtiles.n_tiles,
+                                db.range_flag, s, virtual_node_, d_head_, resident_order_, resident_prof_, &tb);
+            db.final_h = 0;
+            db.h_valid = false;
+            h0_in_hbm_ = false;  // the tile loader computed h_0 on chip
+            return 0;
+        }
+        h0_in_hbm_ = true;
         {
             ProfScope p(prof, "atom_encoder", s);
             atom_encoder_kernel<GIN_D><<<atom_encoder_grid(n, GIN_C), 512, 0, s>>>(db.b.node_feature, d_nemb_, db.h[0], n, db.csr.err);
@@ -819,6 +857,7 @@ public:
         fold_readout_ = o.on("gin_fold_readout");
         resident_ = o.on("gin_resident");
         resident_min_fill_ = o.num("gin_resident_min_fill");
+        tile_build_ = o.i("gin_tile_build");
         head_fold_ = o.on("gin_head_fold");
     }
     void set_exact(bool on) override { exact_ = on; }
@@ -837,8 +876,12 @@ public:
     }
 
     int aggregation_only(DeviceBatch& db, int layer, hipStream_t s) override {
-        if (qmode_) return 8;  // FLOWGNN_ERR_UNSUPPORTED: the fixed-point forward never builds the float kernels\' inputs (tiles, h rows)
+        if (qmode_) return 8;  // FLOWGNN_ERR_UNSUPPORTED: the fixed-point forward never builds the float kernels' inputs (tiles, h rows)
         if (layer < 0 || layer >= GIN_L) return 1;
+        if (!h0_in_hbm_) {  // the last run was the one-pass resident path: the probe's input rows (h_0) were never written to HBM
+            atom_encoder_kernel<GIN_D><<<atom_encoder_grid(db.b.n_tot, GIN_C), 512, 0, s>>>(db.b.node_feature, d_nemb_, db.h[0], db.b.n_tot, db.csr.err);
+            h0_in_hbm_ = true;
+        }
         launch_aggregate(db, layer, db.h[db.final_h], db.scratch, s);
         return 0;
     }
@@ -851,6 +894,8 @@ private:
         if (d_split_) { (void)hipFree(d_split_); d_split_ = nullptr; }
         if (d_rsplit_) { (void)hipFree(d_rsplit_); d_rsplit_ = nullptr; }
         if (d_head_) { (void)hipFree(d_head_); d_head_ = nullptr; }
+        if (d_enc_tab_) { (void)hipFree(d_enc_tab_); d_enc_tab_ = nullptr; }
+        enc_idx_.release();
         perm_.release();
         qw_.release();
     }
@@ -872,7 +917,11 @@ private:
     bool qmode_ = false;  // flowgnn_set_numeric_mode(FLOWGNN_NUMERIC_Q6_10)
     int num_tasks_ = 1;   // NUM_TASK (GIN/src/dcl.h:25) as a run-time dimension
     GinQWeights qw_;
-    GrowBufI perm_;  // graph-resident path: per-tile descriptors (gin_tile_prep_kernel)
+    GrowBufI perm_;  // graph-resident path: per-tile descriptors (gin_tile_prep_kernel / gin_tile_build_kernel)
+    GrowBufI enc_idx_;  // one-pass path: four table-row numbers per node (8 B), written by gin_tile_build_kernel
+    float* d_enc_tab_ = nullptr;  // ... and the pre-combined encoder table they index
+    bool h0_in_hbm_ = false;      // db.h[0] holds h_0 of the resident batch (false after a one-pass run)
+    int tile_build_ = -1;         // gin_tile_build: 1 = one-pass front end, 0 = CSR build + atom encoder + tile prep as separate launches, -1 = by batch size
     // gin_fold_readout=0 keeps the separate mean-pool + linear kernel (and the last layer's 2.7 GB of rows)
     bool fold_readout_ = true;
     // gin_resident=0 keeps one launch per layer (gin_layer_split_kernel).  GIN-VN runs the HUBS form of the resident kernel:

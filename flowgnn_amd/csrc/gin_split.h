@@ -3,6 +3,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include "common.h"
+
 #include <cstddef>
 #include <cstdint>
 
@@ -39,10 +41,24 @@ void gin_resident_pack_layer(const float* w1, const float* b1, const float* w2, 
 constexpr int GIN_RESIDENT_ROWS = 256;
 constexpr int GIN_RESIDENT_EDGES = 1280;
 constexpr int GIN_RESIDENT_DESC_BYTES = 3584;  // per-tile descriptor built by gin_tile_prep_kernel (CSR slice as 16-bit words, row offsets, column owners)
+// what the one-pass tile loader needs (launch_gin_resident, tb != null): the caller's arrays, the per-node table-row numbers it writes
+// (8 B per node) and the pre-combined encoder table (gin_resident_pack_enc_table); err = the engine's validation flag
+struct GinTileBuild {
+    BatchView batch;
+    void* enc_idx;         // device, [n_tot] x 8 B, written by gin_tile_build_kernel
+    const float* enc_tab;  // device, gin_resident_enc_table_floats() floats
+    int* err;
+};
+size_t gin_resident_enc_table_floats();
+void gin_resident_pack_enc_table(const float* node_embedding /* [173][100] */, float* out);
+// the one-pass front end: descriptors + encoder row numbers of every tile from the caller's arrays (then launch_gin_resident with tb)
+void launch_gin_tile_build(const GinTileBuild& tb, const int* tile_row, const int* tile_graph, uint8_t* tile_desc, int n_tiles, bool hubs,
+                           int col_order, hipStream_t s);
 void launch_gin_resident(const float* h0, float* hout, const int* row_ptr, const int* src, const uint8_t* ecode, const float* ecomb_all,
                          const uint8_t* chunks_all, const float* pool_w, const float* pool_b, const int* tile_row, const int* tile_graph,
                          uint8_t* tile_desc /* scratch, n_tiles x GIN_RESIDENT_DESC_BYTES */, const int* node_off, float* out, int n_tiles,
-                         int* range_flag, hipStream_t s, bool hubs = false, const float* head_u = nullptr, int col_order = 0, bool prof = false);
+                         int* range_flag, hipStream_t s, bool hubs = false, const float* head_u = nullptr, int col_order = 0, bool prof = false,
+                         const GinTileBuild* tb = nullptr);
 // head_u for launch_gin_resident (GIN_RESIDENT_HEAD_FLOATS floats): the single-task readout folded through the LAST layer's second
 // linear layer -- u = W2^T w_pred divided by the first layer's power-of-two weight scale, padded to 208, then c = b2 . w_pred
 constexpr int GIN_RESIDENT_HEAD_FLOATS = 209;

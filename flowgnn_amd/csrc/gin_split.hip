@@ -673,39 +673,13 @@ constexpr int GR_HUB_DEG = 8;        // HUBS kernels: rows with more in-edges th
 // that every wave gets a long and a short one.  Placement never changes a row's arithmetic (MFMA columns are independent, a
 // row's in-edges are summed in CSR order whoever owns it): results are identical for any permutation.  Rows beyond the tile's
 // last sort last.   slot = wave * 32 + nt * 16 + j  ->  row inside the tile (0..255)
-__global__ __launch_bounds__(256) void gin_tile_prep_kernel(const int* __restrict__ row_ptr, const int* __restrict__ src,
-                                                            const uint8_t* __restrict__ ecode, const int* __restrict__ tile_row,
-                                                            uint8_t* __restrict__ desc, int n_tiles, int order) {
+// Column owner table of a tile (desc + GR_DESC_PERM) from every row's in-degree; thread r = row r of a 256-thread workgroup.
+__device__ __forceinline__ void gr_write_column_order(uint8_t* d, int r, int rows, int deg, int order) {
     constexpr int NKEY = 18;
     __shared__ int s_cnt[4][NKEY];
-    const int tile = blockIdx.x;
-    if (tile >= n_tiles) return;
-    const int t0 = tile_row[tile];
-    int rows = tile_row[tile + 1] - t0;
-    if (rows > GR_ROWS) rows = GR_ROWS;
-    const int e0 = row_ptr[t0];
-    int ne = row_ptr[t0 + rows] - e0;
-    if (ne > GR_EDGES) ne = GR_EDGES;  // cannot happen for a validated batch (the host packed by edge count); never overrun LDS
-    uint8_t* d = desc + (size_t)tile * GR_DESC_BYTES;
-    uint16_t* d_edge = reinterpret_cast<uint16_t*>(d);
-    uint16_t* d_rp = reinterpret_cast<uint16_t*>(d + GR_DESC_RP);
-    const int r = threadIdx.x, lane = r & 63, wv = r >> 6;
-    for (int i = r; i < ne; i += 256)
-        d_edge[i] = (uint16_t)((((unsigned)(src[e0 + i] - t0) & 0xFFu) << 6) | ((unsigned)ecode[e0 + i] & 63u));
+    const int lane = r & 63, wv = r >> 6;
     int key = NKEY - 1;  // absent row
-    int deg = 0;
-    {
-        const int lo = r <= rows ? row_ptr[t0 + r] - e0 : ne;
-        const int lo_c = lo < 0 ? 0 : (lo > ne ? ne : lo);
-        d_rp[r] = (uint16_t)lo_c;
-        if (r == 255) d_rp[256] = (uint16_t)ne;
-        if (r < rows) {
-            const int hi = row_ptr[t0 + r + 1] - e0;
-            deg = (hi > ne ? ne : hi) - lo_c;
-            if (deg < 0) deg = 0;
-            key = 16 - (deg < 16 ? deg : 16);  // ascending key = descending in-degree
-        }
-    }
+    if (r < rows) key = 16 - (deg < 16 ? deg : 16);  // ascending key = descending in-degree
     if (order == 1) {  // development switch: natural order (column tile k = rows 16k..16k+15)
         d[GR_DESC_PERM + r] = (uint8_t)r;
         return;
@@ -787,17 +761,230 @@ __global__ __launch_bounds__(256) void gin_tile_prep_kernel(const int* __restric
     d[GR_DESC_PERM + wave * 32 + nt * 16 + j] = (uint8_t)r;
 }
 
+__global__ __launch_bounds__(256) void gin_tile_prep_kernel(const int* __restrict__ row_ptr, const int* __restrict__ src,
+                                                            const uint8_t* __restrict__ ecode, const int* __restrict__ tile_row,
+                                                            uint8_t* __restrict__ desc, int n_tiles, int order) {
+    const int tile = blockIdx.x;
+    if (tile >= n_tiles) return;
+    const int t0 = tile_row[tile];
+    int rows = tile_row[tile + 1] - t0;
+    if (rows > GR_ROWS) rows = GR_ROWS;
+    const int e0 = row_ptr[t0];
+    int ne = row_ptr[t0 + rows] - e0;
+    if (ne > GR_EDGES) ne = GR_EDGES;  // cannot happen for a validated batch (the host packed by edge count); never overrun LDS
+    uint8_t* d = desc + (size_t)tile * GR_DESC_BYTES;
+    uint16_t* d_edge = reinterpret_cast<uint16_t*>(d);
+    uint16_t* d_rp = reinterpret_cast<uint16_t*>(d + GR_DESC_RP);
+    const int r = threadIdx.x;
+    for (int i = r; i < ne; i += 256)
+        d_edge[i] = (uint16_t)((((unsigned)(src[e0 + i] - t0) & 0xFFu) << 6) | ((unsigned)ecode[e0 + i] & 63u));
+    int deg = 0;
+    {
+        const int lo = r <= rows ? row_ptr[t0 + r] - e0 : ne;
+        const int lo_c = lo < 0 ? 0 : (lo > ne ? ne : lo);
+        d_rp[r] = (uint16_t)lo_c;
+        if (r == 255) d_rp[256] = (uint16_t)ne;
+        if (r < rows) {
+            const int hi = row_ptr[t0 + r + 1] - e0;
+            deg = (hi > ne ? ne : hi) - lo_c;
+            if (deg < 0) deg = 0;
+        }
+    }
+    gr_write_column_order(d, r, rows, deg, order);
+}
+
+// ---------------------------------------------------------------- the tile's descriptor straight from the caller's arrays
+// gin_tile_build_kernel = load_graph (GIN/src/load_inputs.cc:87-172) + the index part of the atom encoder (:174-220) for ONE tile of
+// whole graphs, with no global CSR in between: what build_csr_graph_kernel + gin_tile_prep_kernel + the encoder's feature validation
+// did in three passes over HBM.  One 256-thread workgroup per tile:
+//   * the tile's raw edges (a contiguous slice of edge_list / edge_attr: graphs are stored in batch order) are validated, turned
+//     into (source row, destination row, edge code) and counting-sorted by destination in LDS; inside a row they are rank-sorted by
+//     (source row, input index) -- unique keys, so the order is the CSR's (graph_build.hip) whatever order the LDS atomics landed in;
+//   * the descriptor is written in gin_tile_prep_kernel's format (edge words, row offsets, column owner table);
+//   * every node's nine features are validated and turned into four row numbers of the pre-combined encoder table (below), 8 B per
+//     node: what the resident kernel's tile loader reads instead of a 400 B row of h_0.
+// Pre-combined encoder table (GinModel::set_weights; rows of 100 floats; GRB_* = first row of each part):
+//   T01[f0][f1] = E0[f0] + E1[f1]   E2[f2]   T34[f3][f4] = E3[f3] + E4[f4]   T5678[f5][f6][f7][f8] = ((E5 + E6) + E7) + E8
+//   h_0 = ((T01 + E2) + T34) + T5678: the reference's nine-term sum (load_inputs.cc:207-214) re-associated -- it differs from the
+//   sequential order by fp32 rounding only (<= 4 ulp of a sum of magnitude ~1; the stated parity tolerance is 1e-4).
+constexpr int GRB_T01 = 0, GRB_E2 = 476, GRB_T34 = 488, GRB_T5678 = 608, GRB_ROWS = 752;
+
+__device__ __forceinline__ int gr_wave_inclusive_scan(int x, int lane) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int y = __shfl_up(x, d, 64);
+        if (lane >= d) x += y;
+    }
+    return x;
+}
+
+__global__ __launch_bounds__(256) void gin_tile_build_kernel(BatchView b, const int* __restrict__ tile_row, const int* __restrict__ tile_graph,
+                                                             uint8_t* __restrict__ desc, uint2* __restrict__ enc_idx, int n_tiles, int order,
+                                                             int* __restrict__ err) {
+    constexpr int EPT = GR_EDGES / 256;  // edges per thread
+    __shared__ int s_eoff[GR_ROWS + 1], s_noff[GR_ROWS + 1];  // edge / row offsets of the tile's graphs, relative to the tile
+    __shared__ int s_cnt[GR_ROWS + 1], s_cur[GR_ROWS];
+    __shared__ unsigned s_bucket[GR_EDGES];
+    __shared__ int s_feat[GR_ROWS * ND_FEATURE];
+    __shared__ int s_wtot[4];
+    const int tile = blockIdx.x;
+    if (tile >= n_tiles) return;
+    const int r = threadIdx.x, lane = r & 63, wv = r >> 6;
+    const int t0 = tile_row[tile];
+    int rows = tile_row[tile + 1] - t0;
+    if (rows > GR_ROWS) rows = GR_ROWS;
+    const int g0 = tile_graph[tile];
+    int ng = tile_graph[tile + 1] - g0;
+    if (ng > GR_ROWS) ng = GR_ROWS;  // every graph has at least one node, so a validated tile never has more graphs than rows
+    const int e0 = b.edge_off[g0];
+    int ne = b.edge_off[g0 + ng] - e0;
+    if (ne > GR_EDGES) ne = GR_EDGES;  // cannot happen for a batch packed by flowgnn_set_batch; never overrun LDS
+    for (int i = r; i <= ng; i += 256) {
+        s_eoff[i] = b.edge_off[g0 + i] - e0;
+        s_noff[i] = b.node_off[g0 + i] - t0;
+    }
+    s_cnt[r] = 0;
+    s_cur[r] = 0;
+    if (r == 0) s_cnt[GR_ROWS] = 0;
+#pragma unroll
+    for (int p = 0; p < ND_FEATURE; p++) {  // the tile's node features, coalesced
+        const int i = r + 256 * p;
+        s_feat[i] = i < rows * ND_FEATURE ? b.node_feature[(size_t)t0 * ND_FEATURE + i] : 0;
+    }
+    __syncthreads();
+    unsigned ekey[EPT];  // (source row << 17) | (edge index inside the tile << 6) | edge code
+    int edst[EPT];       // destination row, -1 = no edge
+#pragma unroll
+    for (int k = 0; k < EPT; k++) {
+        const int i = r + 256 * k;
+        edst[k] = -1;
+        ekey[k] = 0;
+        if (i < ne) {
+            const int2 uv = reinterpret_cast<const int2*>(b.edge_list)[e0 + i];
+            const int a0 = b.edge_attr[3 * (size_t)(e0 + i)], a1 = b.edge_attr[3 * (size_t)(e0 + i) + 1], a2 = b.edge_attr[3 * (size_t)(e0 + i) + 2];
+            int lo = 0, hi = ng - 1;  // the graph of edge i: the last one whose first edge is <= i
+            while (lo < hi) {
+                const int mid = (lo + hi + 1) >> 1;
+                if (s_eoff[mid] <= i) lo = mid; else hi = mid - 1;
+            }
+            const int base = s_noff[lo], n = s_noff[lo + 1] - base;
+            int u = uv.x, v = uv.y;
+            if (!((u >= 0) & (u < n) & (v >= 0) & (v < n))) {  // flag it, then treat as a self-loop on node 0 (as build_csr does)
+                atomicMax(err, ERR_EDGE_RANGE);
+                u = 0;
+                v = 0;
+            }
+            const bool aok = (a0 >= 0) & (a0 < 5) & (a1 >= 0) & (a1 < 6) & (a2 >= 0) & (a2 < 2);  // cardinalities {5,6,2}: GIN/src/host_load.cc:6
+            if (!aok) atomicMax(err, ERR_EDGE_ATTR);
+            const unsigned code = aok ? (unsigned)((a0 * 6 + a1) * 2 + a2) : 0u;
+            edst[k] = base + v;
+            ekey[k] = ((unsigned)(base + u) << 17) | ((unsigned)i << 6) | code;
+            atomicAdd(&s_cnt[base + v], 1);
+        }
+    }
+    __syncthreads();
+    const int deg = s_cnt[r];  // rows beyond the tile's last have none
+    {
+        const int incl = gr_wave_inclusive_scan(deg, lane);
+        if (lane == 63) s_wtot[wv] = incl;
+        __syncthreads();
+        int start = incl - deg;
+        for (int w = 0; w < wv; w++) start += s_wtot[w];
+        s_cnt[r] = start;
+        if (r == 255) s_cnt[GR_ROWS] = start + deg;  // = ne
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < EPT; k++)
+        if (edst[k] >= 0) s_bucket[s_cnt[edst[k]] + atomicAdd(&s_cur[edst[k]], 1)] = ekey[k];
+    __syncthreads();
+    uint8_t* d = desc + (size_t)tile * GR_DESC_BYTES;
+    uint16_t* d_edge = reinterpret_cast<uint16_t*>(d);
+    uint16_t* d_rp = reinterpret_cast<uint16_t*>(d + GR_DESC_RP);
+#pragma unroll
+    for (int k = 0; k < EPT; k++)
+        if (edst[k] >= 0) {
+            const int beg = s_cnt[edst[k]], end = s_cnt[edst[k] + 1];
+            const unsigned mine = ekey[k] >> 6;
+            int rank = 0;
+            for (int t = beg; t < end; t++) rank += (s_bucket[t] >> 6) < mine;
+            d_edge[beg + rank] = (uint16_t)(((ekey[k] >> 17) << 6) | (ekey[k] & 63u));
+        }
+    d_rp[r] = (uint16_t)s_cnt[r];
+    if (r == 255) d_rp[256] = (uint16_t)s_cnt[GR_ROWS];
+    if (r < rows) {  // the node's rows of the pre-combined encoder table (validated: table cardinalities, GIN/src/host_load.cc:5)
+        int f[ND_FEATURE];
+#pragma unroll
+        for (int k = 0; k < ND_FEATURE; k++) {
+            f[k] = s_feat[r * ND_FEATURE + k];
+            if (f[k] < 0 || f[k] >= c_nd_card[k]) {
+                atomicMax(err, ERR_NODE_FEAT);
+                f[k] = 0;
+            }
+        }
+        const unsigned i0 = GRB_T01 + f[0] * 4 + f[1], i1 = GRB_E2 + f[2], i2 = GRB_T34 + f[3] * 10 + f[4],
+                       i3 = GRB_T5678 + ((f[5] * 6 + f[6]) * 2 + f[7]) * 2 + f[8];
+        enc_idx[(size_t)t0 + r] = make_uint2(i0 | (i1 << 16), i2 | (i3 << 16));
+    }
+    gr_write_column_order(d, r, rows, r < rows ? (deg < ne ? deg : ne) : 0, order);
+}
+
+// ---- the tile loader's atom encoder (resident kernel, ENC form): rows of h_0 computed straight into the tile's LDS rows
+// A tile's rows are encoded in GRE_PARTS parts of GRE_PART rows, one part per MLP step of the folded last layer (the rows of the
+// CURRENT tile are dead by then).  In a part, wave w owns row slots 5w .. 5w + 4 as three groups of two rows: lanes 0..31 the even
+// slot, lanes 32..63 the odd one, lane & 31 = float4 chunk (25 of 32 lanes active: one contiguous 400 B row per half wave).
+constexpr int GRE_PART = 37, GRE_PARTS = 7;  // 7 x 37 = 259 >= GR_ROWS
+struct GrEncIdx { uint2 k0, k1, k2; };
+struct GrEncVal { float4 a0, a1, a2, a3, b0, b1, b2, b3, c0, c1, c2, c3; };
+
+__device__ __forceinline__ int gre_row(int part, int wave, int lane, int k, int rows) {
+    const int q = 2 * k + (lane >> 5), slot = 5 * wave + q;
+    const int row = GRE_PART * part + slot;
+    return (q < 5 && slot < GRE_PART && row < rows && (lane & 31) < 25) ? row : -1;
+}
+__device__ __forceinline__ GrEncIdx gre_issue_idx(const uint2* __restrict__ enc_idx, const GrTile& t, int part, int wave, int lane) {
+    GrEncIdx x;
+    const int r0 = gre_row(part, wave, lane, 0, t.rows), r1 = gre_row(part, wave, lane, 1, t.rows), r2 = gre_row(part, wave, lane, 2, t.rows);
+    x.k0 = r0 >= 0 ? enc_idx[(size_t)t.t0 + r0] : make_uint2(0u, 0u);
+    x.k1 = r1 >= 0 ? enc_idx[(size_t)t.t0 + r1] : make_uint2(0u, 0u);
+    x.k2 = r2 >= 0 ? enc_idx[(size_t)t.t0 + r2] : make_uint2(0u, 0u);
+    return x;
+}
+#define GRE_LD4(V0, V1, V2, V3, K)                                          \
+    V0 = tab[((K).x & 0xFFFFu) * 25u + c]; V1 = tab[((K).x >> 16) * 25u + c]; \
+    V2 = tab[((K).y & 0xFFFFu) * 25u + c]; V3 = tab[((K).y >> 16) * 25u + c];
+__device__ __forceinline__ GrEncVal gre_issue_tab(const float4* __restrict__ tab, const GrEncIdx& x, int lane) {
+    GrEncVal v;
+    const unsigned c = (unsigned)(lane & 31) < 25u ? (unsigned)(lane & 31) : 0u;  // idle lanes re-read chunk 0 of row 0 (in range)
+    GRE_LD4(v.a0, v.a1, v.a2, v.a3, x.k0)
+    GRE_LD4(v.b0, v.b1, v.b2, v.b3, x.k1)
+    GRE_LD4(v.c0, v.c1, v.c2, v.c3, x.k2)
+    return v;
+}
+#undef GRE_LD4
+#define GRE_SUM(V0, V1, V2, V3) \
+    make_float4(((V0.x + V1.x) + V2.x) + V3.x, ((V0.y + V1.y) + V2.y) + V3.y, ((V0.z + V1.z) + V2.z) + V3.z, ((V0.w + V1.w) + V2.w) + V3.w)
+__device__ __forceinline__ void gre_finish(float* s_h, const GrEncVal& v, const GrTile& t, int part, int wave, int lane) {
+    const int r0 = gre_row(part, wave, lane, 0, t.rows), r1 = gre_row(part, wave, lane, 1, t.rows), r2 = gre_row(part, wave, lane, 2, t.rows);
+    const int c = lane & 31;
+    if (r0 >= 0) *reinterpret_cast<float4*>(s_h + r0 * GS_D + 4 * c) = GRE_SUM(v.a0, v.a1, v.a2, v.a3);
+    if (r1 >= 0) *reinterpret_cast<float4*>(s_h + r1 * GS_D + 4 * c) = GRE_SUM(v.b0, v.b1, v.b2, v.b3);
+    if (r2 >= 0) *reinterpret_cast<float4*>(s_h + r2 * GS_D + 4 * c) = GRE_SUM(v.c0, v.c1, v.c2, v.c3);
+}
+#undef GRE_SUM
+
 __device__ __forceinline__ void gr_issue_desc(const uint8_t* __restrict__ desc, int tile, char* s_desc, int wave, int lane) {
     if (wave < 4 && (wave < 3 || lane < 32))
         lds_dma16(reinterpret_cast<const char*>(desc) + (size_t)tile * GR_DESC_BYTES + wave * 1024, (uint32_t)lane * 16u, lds_addr_of(s_desc) + wave * 1024);
 }
 
-template <bool PROF, bool HUBS, bool LAST, bool FOLD>
+template <bool PROF, bool HUBS, bool LAST, bool FOLD, bool ENC>
 __device__ __forceinline__ void gr_layer(unsigned long long (&tacc)[6], char* bx, char* by, float* s_h, char* s_desc, float* s_dot,
                                          const GrTile& cur, const GrTile& nxt, bool has_next, int next_tile, int l,
                                          const float* __restrict__ h0, const uint8_t* __restrict__ desc, const float* __restrict__ ecomb_all,
                                          const uint8_t* __restrict__ wchunks_all, const float* __restrict__ pool_w,
-                                         float* __restrict__ hout, float& vmax, int wave, int lane, const float* s_u) {
+                                         float* __restrict__ hout, float& vmax, int wave, int lane, const float* s_u,
+                                         const uint2* __restrict__ enc_idx, const float4* __restrict__ enc_tab) {
     constexpr int NT = 2;
     const int j = lane & 15, g = lane >> 4;
     constexpr bool last = LAST;  // compile-time: the first four layers carry none of the last layer's code (and registers)
@@ -813,6 +1000,12 @@ __device__ __forceinline__ void gr_layer(unsigned long long (&tacc)[6], char* bx
     if constexpr (PROF) tp = wall_clock64();
     if (fold) grc_issue_chunk_w1(wchunks, by, wave, lane);
     else grc_issue_chunk(wchunks, by, wave, lane);  // chunk 0: lands under the gather
+    // ENC (the tile loader computes h_0 itself): the next tile's rows are encoded during this layer's MLP steps, a part per step;
+    // the table-row numbers of part 0 are requested here, a whole gather ahead of their use
+    GrEncIdx enc_ix{};
+    if constexpr (ENC && LAST) {
+        if (has_next) enc_ix = gre_issue_idx(enc_idx, nxt, 0, wave, lane);
+    }
 
     // ---- gather (MP unit) out of LDS: a = h[v] + sum_e relu(h[src_e] + ecomb[code_e]), CSR order
     float bq[NT][25];
@@ -974,19 +1167,30 @@ __device__ __forceinline__ void gr_layer(unsigned long long (&tacc)[6], char* bx
             char* nb = (c & 1) ? by : bx;
             if (c + 1 < GS_STEPS - 1) grc_issue_chunk_w1(wchunks + (size_t)(c + 1) * GRC_CHUNK_STRIDE, nb, wave, lane);
             else gr_issue_ecomb(ecomb_all + (size_t)ln * EDGE_COMBOS * GS_D, nb, wave, lane);
-            if (has_next) {
+            GrEncVal enc_v{};
+            if constexpr (ENC) {
+                if (has_next) {  // part c of the next tile: its table rows are requested now and summed at the end of the step
+                    enc_v = gre_issue_tab(enc_tab, enc_ix, lane);
+                    if (c + 1 < GRE_PARTS) enc_ix = gre_issue_idx(enc_idx, nxt, c + 1, wave, lane);
+                }
+            } else if (has_next) {
                 gr_issue_rows(h0, reinterpret_cast<char*>(s_h), nxt, c, wave, lane);
                 if (c == GS_STEPS - 2) gr_issue_rows(h0, reinterpret_cast<char*>(s_h), nxt, c + 1, wave, lane);
             }
             if (c < GS_STEPS - 2) gr_step<4>(cb, lane, g, in_hi, in_lo, in_tb, h_hi, h_lo, acc2, vmax, s_u + 32 * c, dot);
             else gr_step<5>(cb, lane, g, in_hi, in_lo, in_tb, h_hi, h_lo, acc2, vmax, s_u + 32 * c, dot);
-            if (c + 1 < GS_STEPS - 1) {
+            if (ENC || c + 1 < GS_STEPS - 1) {
                 unsigned long long tw = 0;
                 if constexpr (PROF) tw = wall_clock64();
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 if constexpr (PROF) { const unsigned long long t = wall_clock64(); tacc[5] += t - tw; tw = t; }
-                __syncthreads();
-                if constexpr (PROF) { const unsigned long long t = wall_clock64(); tacc[4] += t - tw; }
+                if constexpr (ENC) {
+                    if (has_next) gre_finish(s_h, enc_v, nxt, c, wave, lane);
+                }
+                if (c + 1 < GS_STEPS - 1) {
+                    __syncthreads();
+                    if constexpr (PROF) { const unsigned long long t = wall_clock64(); tacc[4] += t - tw; }
+                }
             }
         }
     } else {
@@ -1079,7 +1283,7 @@ __device__ __forceinline__ void gr_layer(unsigned long long (&tacc)[6], char* bx
     if constexpr (PROF) { const unsigned long long t = wall_clock64(); tacc[3] += t - tp; }
 }
 
-template <bool PROF, bool HUBS, bool FOLD>
+template <bool PROF, bool HUBS, bool FOLD, bool ENC>
 __global__ __launch_bounds__(GR_WAVES * 64, 2) void gin_resident_kernel(const float* __restrict__ h0, float* __restrict__ hout,
                                                                        const float* __restrict__ ecomb_all,
                                                                        const uint8_t* __restrict__ wchunks_all,
@@ -1088,7 +1292,9 @@ __global__ __launch_bounds__(GR_WAVES * 64, 2) void gin_resident_kernel(const fl
                                                                        const uint8_t* __restrict__ desc,
                                                                        const int* __restrict__ node_off, float* __restrict__ out, int n_tiles,
                                                                        int* __restrict__ range_flag, unsigned long long* __restrict__ prof_out,
-                                                                       const float* __restrict__ head_u) {
+                                                                       const float* __restrict__ head_u, const uint2* __restrict__ enc_idx,
+                                                                       const float4* __restrict__ enc_tab) {
+    static_assert(!ENC || FOLD, "the in-kernel encoder rides on the folded last layer's steps");
     __shared__ __attribute__((aligned(16))) char s_a[GRC_CHUNK_BYTES];
     __shared__ __attribute__((aligned(16))) char s_b[GRC_CHUNK_BYTES];
     __shared__ __attribute__((aligned(16))) float s_h[GR_ROWS * GS_D];
@@ -1110,8 +1316,17 @@ __global__ __launch_bounds__(GR_WAVES * 64, 2) void gin_resident_kernel(const fl
     // prologue: this workgroup's first tile (rows, descriptor) and the first table
     gr_issue_ecomb(ecomb_all, s_a, wave, lane);
     gr_issue_desc(desc, tile, s_desc, wave, lane);
+    if constexpr (ENC) {  // this workgroup's first tile is encoded on the spot (later ones under the previous tile's last layer)
 #pragma unroll 1
-    for (int part = 0; part < 8; part++) gr_issue_rows(h0, reinterpret_cast<char*>(s_h), cur, part, wave, lane);
+        for (int part = 0; part < GRE_PARTS; part++) {
+            const GrEncIdx ix = gre_issue_idx(enc_idx, cur, part, wave, lane);
+            const GrEncVal v = gre_issue_tab(enc_tab, ix, lane);
+            gre_finish(s_h, v, cur, part, wave, lane);
+        }
+    } else {
+#pragma unroll 1
+        for (int part = 0; part < 8; part++) gr_issue_rows(h0, reinterpret_cast<char*>(s_h), cur, part, wave, lane);
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     float vmax = 0.0f;
@@ -1123,17 +1338,17 @@ __global__ __launch_bounds__(GR_WAVES * 64, 2) void gin_resident_kernel(const fl
 #pragma unroll 1
         for (int l = 0; l < 4; l++) {
             if (!flip)
-                gr_layer<PROF, HUBS, false, FOLD>(tacc, s_a, s_b, s_h, s_desc, s_dot, cur, nxt, has_next, ntile, l, h0, desc, ecomb_all, wchunks_all, pool_w, hout, vmax, wave, lane, nullptr);
+                gr_layer<PROF, HUBS, false, FOLD, ENC>(tacc, s_a, s_b, s_h, s_desc, s_dot, cur, nxt, has_next, ntile, l, h0, desc, ecomb_all, wchunks_all, pool_w, hout, vmax, wave, lane, nullptr, enc_idx, enc_tab);
             else
-                gr_layer<PROF, HUBS, false, FOLD>(tacc, s_b, s_a, s_h, s_desc, s_dot, cur, nxt, has_next, ntile, l, h0, desc, ecomb_all, wchunks_all, pool_w, hout, vmax, wave, lane, nullptr);
+                gr_layer<PROF, HUBS, false, FOLD, ENC>(tacc, s_b, s_a, s_h, s_desc, s_dot, cur, nxt, has_next, ntile, l, h0, desc, ecomb_all, wchunks_all, pool_w, hout, vmax, wave, lane, nullptr, enc_idx, enc_tab);
             flip = !flip;
         }
         {
             const float* su = fold_head ? s_u : nullptr;
             if (!flip)
-                gr_layer<PROF, HUBS, true, FOLD>(tacc, s_a, s_b, s_h, s_desc, s_dot, cur, nxt, has_next, ntile, 4, h0, desc, ecomb_all, wchunks_all, pool_w, hout, vmax, wave, lane, su);
+                gr_layer<PROF, HUBS, true, FOLD, ENC>(tacc, s_a, s_b, s_h, s_desc, s_dot, cur, nxt, has_next, ntile, 4, h0, desc, ecomb_all, wchunks_all, pool_w, hout, vmax, wave, lane, su, enc_idx, enc_tab);
             else
-                gr_layer<PROF, HUBS, true, FOLD>(tacc, s_b, s_a, s_h, s_desc, s_dot, cur, nxt, has_next, ntile, 4, h0, desc, ecomb_all, wchunks_all, pool_w, hout, vmax, wave, lane, su);
+                gr_layer<PROF, HUBS, true, FOLD, ENC>(tacc, s_b, s_a, s_h, s_desc, s_dot, cur, nxt, has_next, ntile, 4, h0, desc, ecomb_all, wchunks_all, pool_w, hout, vmax, wave, lane, su, enc_idx, enc_tab);
             if (!fold_head) flip = !flip;  // the folded last layer leaves the next table in its own table buffer
         }
         // readout (GIN/src/finalize.cc:36-113): out[g] = mean_v(h5[v] . w) + b, node order; the terms stay valid until the next
@@ -1336,28 +1551,36 @@ void launch_gin_layer_split(const float* h, float* hout, const int* row_ptr, con
 void launch_gin_resident(const float* h0, float* hout, const int* row_ptr, const int* src, const uint8_t* ecode, const float* ecomb_all,
                          const uint8_t* chunks_all, const float* pool_w, const float* pool_b, const int* tile_row, const int* tile_graph,
                          uint8_t* tile_desc, const int* node_off, float* out, int n_tiles, int* range_flag, hipStream_t s, bool hubs,
-                         const float* head_u, int col_order, bool prof) {
+                         const float* head_u, int col_order, bool prof, const GinTileBuild* tb) {
     if (n_tiles <= 0) return;
     const int order = hubs ? 3 : col_order;
-    gin_tile_prep_kernel<<<n_tiles, 256, 0, s>>>(row_ptr, src, ecode, tile_row, tile_desc, n_tiles, order);
-    const int grid = n_tiles < 256 ? n_tiles : 256;  // persistent: one 8-wave workgroup per CU (157 KB of LDS)
     const bool fold = head_u != nullptr && out != nullptr && hout == nullptr;  // single-task readout, no per-node tap
+    const bool enc = tb != nullptr && fold;  // descriptor + encoder indices straight from the caller's arrays, h_0 computed by the tile loader
+    if (!enc) gin_tile_prep_kernel<<<n_tiles, 256, 0, s>>>(row_ptr, src, ecode, tile_row, tile_desc, n_tiles, order);
+    const int grid = n_tiles < 256 ? n_tiles : 256;  // persistent: one 8-wave workgroup per CU (157 KB of LDS)
     unsigned long long* d = nullptr;
     const size_t cnt = (size_t)grid * GR_WAVES * 7;
     if (prof) {  // development aid: phase breakdown from s_memrealtime stamps, printed per launch (synchronises!)
         if (hipMalloc((void**)&d, cnt * 8) != hipSuccess) return;
         (void)hipMemsetAsync(d, 0, cnt * 8, s);
     }
-#define GR_LAUNCH(P, H, F)                                                                                                        \
-    gin_resident_kernel<P, H, F><<<grid, GR_WAVES * 64, 0, s>>>(h0, hout, ecomb_all, chunks_all, pool_w, pool_b, tile_row, tile_graph, \
-                                                                tile_desc, node_off, out, n_tiles, range_flag, d, head_u)
+    const uint2* eidx = enc ? reinterpret_cast<const uint2*>(tb->enc_idx) : nullptr;
+    const float4* etab = enc ? reinterpret_cast<const float4*>(tb->enc_tab) : nullptr;
+#define GR_LAUNCH(P, H, F, E)                                                                                                        \
+    gin_resident_kernel<P, H, F, E><<<grid, GR_WAVES * 64, 0, s>>>(h0, hout, ecomb_all, chunks_all, pool_w, pool_b, tile_row, tile_graph, \
+                                                                   tile_desc, node_off, out, n_tiles, range_flag, d, head_u, eidx, etab)
+#define GR_LAUNCH_FE(P, H)                                    \
+    do {                                                      \
+        if (enc) GR_LAUNCH(P, H, true, true);                 \
+        else if (fold) GR_LAUNCH(P, H, true, false);          \
+        else GR_LAUNCH(P, H, false, false);                   \
+    } while (0)
     if (prof) {
-        if (hubs) { if (fold) GR_LAUNCH(true, true, true); else GR_LAUNCH(true, true, false); }
-        else { if (fold) GR_LAUNCH(true, false, true); else GR_LAUNCH(true, false, false); }
+        if (hubs) GR_LAUNCH_FE(true, true); else GR_LAUNCH_FE(true, false);
     } else {
-        if (hubs) { if (fold) GR_LAUNCH(false, true, true); else GR_LAUNCH(false, true, false); }
-        else { if (fold) GR_LAUNCH(false, false, true); else GR_LAUNCH(false, false, false); }
+        if (hubs) GR_LAUNCH_FE(false, true); else GR_LAUNCH_FE(false, false);
     }
+#undef GR_LAUNCH_FE
 #undef GR_LAUNCH
     if (prof) {
         std::vector<unsigned long long> hbuf(cnt);
@@ -1370,6 +1593,35 @@ void launch_gin_resident(const float* h0, float* hout, const int* row_ptr, const
         fprintf(stderr, "[gin_resident prof] tiles %d grid %d | per wave, us: gather %.1f  wait+barrier %.1f  mlp %.1f (of which step-end DMA wait %.1f, barrier %.1f)  epilogue+barrier %.1f  kernel %.1f\n",
                 n_tiles, grid, tot[0] / nw / 100.0, tot[1] / nw / 100.0, tot[2] / nw / 100.0, tot[5] / nw / 100.0, tot[4] / nw / 100.0, tot[3] / nw / 100.0, tot[6] / nw / 100.0);
     }
+}
+
+void launch_gin_tile_build(const GinTileBuild& tb, const int* tile_row, const int* tile_graph, uint8_t* tile_desc, int n_tiles, bool hubs,
+                           int col_order, hipStream_t s) {
+    if (n_tiles <= 0) return;
+    gin_tile_build_kernel<<<n_tiles, 256, 0, s>>>(tb.batch, tile_row, tile_graph, tile_desc, reinterpret_cast<uint2*>(tb.enc_idx), n_tiles,
+                                                  hubs ? 3 : col_order, tb.err);
+}
+
+// the pre-combined encoder table of gin_tile_build_kernel / the resident kernel's tile loader (GRB_* layout above)
+size_t gin_resident_enc_table_floats() { return (size_t)GRB_ROWS * GS_D; }
+void gin_resident_pack_enc_table(const float* nemb /* [173][100] */, float* out) {
+    static const int off[ND_FEATURE] = {0, 119, 123, 135, 147, 157, 163, 169, 171};  // load_inputs.cc:5
+    static const int card[ND_FEATURE] = {119, 4, 12, 12, 10, 6, 6, 2, 2};            // host_load.cc:5
+    auto E = [&](int k, int f, int d) { return nemb[(size_t)(off[k] + f) * GS_D + d]; };
+    for (int f0 = 0; f0 < card[0]; f0++)
+        for (int f1 = 0; f1 < card[1]; f1++)
+            for (int d = 0; d < GS_D; d++) { float s = 0.0f; s += E(0, f0, d); s += E(1, f1, d); out[(size_t)(GRB_T01 + f0 * 4 + f1) * GS_D + d] = s; }
+    for (int f2 = 0; f2 < card[2]; f2++)
+        for (int d = 0; d < GS_D; d++) out[(size_t)(GRB_E2 + f2) * GS_D + d] = E(2, f2, d);
+    for (int f3 = 0; f3 < card[3]; f3++)
+        for (int f4 = 0; f4 < card[4]; f4++)
+            for (int d = 0; d < GS_D; d++) out[(size_t)(GRB_T34 + f3 * 10 + f4) * GS_D + d] = E(3, f3, d) + E(4, f4, d);
+    for (int f5 = 0; f5 < card[5]; f5++)
+        for (int f6 = 0; f6 < card[6]; f6++)
+            for (int f7 = 0; f7 < card[7]; f7++)
+                for (int f8 = 0; f8 < card[8]; f8++)
+                    for (int d = 0; d < GS_D; d++)
+                        out[(size_t)(GRB_T5678 + ((f5 * 6 + f6) * 2 + f7) * 2 + f8) * GS_D + d] = ((E(5, f5, d) + E(6, f6, d)) + E(7, f7, d)) + E(8, f8, d);
 }
 
 }  // namespace fg

@@ -707,7 +707,7 @@ public:
     void set_exact(bool on) override { exact_ = on; }
 
     int aggregation_only(DeviceBatch& db, int layer, hipStream_t s) override {
-        if (qmode_) return 8;  // FLOWGNN_ERR_UNSUPPORTED: the fixed-point forward never builds the float kernels\' inputs (tiles, h rows)
+        if (qmode_) return 8;  // FLOWGNN_ERR_UNSUPPORTED: the fixed-point forward never builds the float kernels' inputs (tiles, h rows)
         if (layer < 0 || layer >= PNA_L) return 1;
         launch_aggregate(db, db.h[db.final_h], s);
         return 0;

@@ -7,6 +7,7 @@ behind named options (flowgnn_set_option; include/flowgnn.h, table in flowgnn_am
     gin_mfma=32 ("f32")         fp32-MFMA fused layer (the exact fallback)
     gin_split_nt=1|2     four-wave forms of the split-f16 layer kernel
     gin_head_fold=0      resident kernel with the last layer's second linear layer computed (readout not folded through it)
+    gin_tile_build=1|0   graph-resident GIN with the one-pass front end (gin_tile_build_kernel + in-kernel encoder) / with the three-kernel one
     gin_resident=0       per-layer launches instead of the graph-resident multi-layer kernel (gat_resident=0 likewise)
     {gin,gat}_fold_readout=0   separate mean-pool + linear kernel
     gcn_unfused=1        tiled_aggregate_kernel<GcnAggPolicy> + dense100_split_kernel
@@ -61,6 +62,8 @@ def oracle_fn(oracle, model):
 TOL = {"GIN": (1e-4, 1e-4), "GIN-VN": (2e-4, 1e-3), "GCN": (1e-4, 1e-4), "GAT": (2e-4, 2e-4), "PNA": (2e-4, 2e-3), "DGN": (2e-4, 2e-3)}
 
 GIN_VARIANTS = [
+    {"gin_tile_build": 1},   # one-pass front end: tile descriptors + encoder row numbers from the caller's arrays, h_0 computed by the tile loader
+    {"gin_tile_build": 0},   # index build + atom encoder + tile prep as separate launches
     {"gin_unfused": 1},
     {"gin_unfused": 1, "gin_agg_untiled": 1},
     {"gin_unfused": 1, "gin_agg_tile": 64},
@@ -248,3 +251,46 @@ def test_options_api_and_fixed_point_aggregate_guard(oracle):
         e.aggregate(0)
         assert np.isfinite(out).all()
         e.close()
+
+
+def test_one_pass_front_end_is_the_same_index_build(oracle):
+    """gin_tile_build_kernel orders a tile's edges exactly as build_csr + gin_tile_prep do (same descriptors), so the two front ends
+    differ only by the encoder's re-associated table sum: logits agree to a few ulp, and each is bit-identical under batch splits
+    (duplicates, self loops, a hub row and kNN-dense graphs included); validation errors are reported the same way."""
+    from flowgnn_amd import FlowGNNError
+    rng = np.random.default_rng(5)
+    b = gp.concat_batches([gp.synth_molhiv_batch(300, seed=51), gp.synth_hep10k_batch(3, seed=53, with_eigen=False), gp.synth_molhiv_batch(50, seed=54)])
+    el = b.edge_list.copy()
+    el[5] = el[4]                      # duplicate edge
+    el[11, 1] = el[11, 0]              # self loop
+    b = gp.GraphBatch(b.nums_of_nodes, b.nums_of_edges, b.node_feature, el, b.edge_attr)
+    w = weights.synth_gin_weights(seed=7)
+    outs = {}
+    for tb in (1, 0):
+        e = Engine("GIN", device=0, options={"gin_tile_build": tb, "gin_resident_min_fill": 0})
+        e.set_weights(w)
+        outs[tb] = e.forward(b)
+        assert np.array_equal(e.forward(b.slice(40, 300)), outs[tb][40:300])
+        row_ptr, src, eid, _ = e.csr()  # the tap builds the CSR on demand after a one-pass run
+        assert row_ptr[-1] == b.total_edges and len(src) == b.total_edges
+        e.close()
+    want = oracle.gin_forward(b, [w], nthreads=8)
+    assert np.allclose(outs[1], want, rtol=1e-4, atol=1e-4)
+    assert np.abs(outs[1] - outs[0]).max() < 2e-5
+    bad = gp.GraphBatch(b.nums_of_nodes, b.nums_of_edges, b.node_feature, el.copy(), b.edge_attr.copy())
+    bad.edge_list[7, 0] = 10 ** 6
+    for tb in (1, 0):
+        e = Engine("GIN", device=0, options={"gin_tile_build": tb})
+        e.set_weights(w)
+        with pytest.raises(FlowGNNError) as ei:
+            e.forward(bad)
+        assert ei.value.code == 2, ei.value
+        e.close()
+    bad2 = gp.GraphBatch(b.nums_of_nodes, b.nums_of_edges, b.node_feature.copy(), el, b.edge_attr)
+    bad2.node_feature[3, 2] = 99
+    e = Engine("GIN", device=0, options={"gin_tile_build": 1})
+    e.set_weights(w)
+    with pytest.raises(FlowGNNError) as ei:
+        e.forward(bad2)
+    assert ei.value.code == 4, ei.value
+    e.close()
