@@ -123,6 +123,17 @@ struct GraphTiles {
     int rows = 0, edges = 0;           // the limits it was built for
     bool ok = false;                   // every graph of the batch fits a tile
     double fill = 0.0;                 // n_tot / (n_tiles * rows)
+    // Second packing for kernels that run two half-tiles per CU out of phase (Model::sub_tile_limits): runs of consecutive
+    // graphs of at most sub_rows rows / sub_edges in-edges, {first row, rows, first graph, one past the last graph} each; a graph
+    // beyond those limits (but within rows / edges above) ends the run and is listed in big_* instead -- pairs
+    // (start, end) in the row_start / graph_start format read with stride 2, one graph per tile.
+    const int* sub = nullptr;          // device [n_sub][4]
+    int n_sub = 0, sub_rows = 0, sub_edges = 0;
+    const int* big_row = nullptr;      // device [2 n_big]
+    const int* big_graph = nullptr;    // device [2 n_big]
+    int n_big = 0;
+    bool sub_ok = false;
+    double sub_fill = 0.0;             // rows of the sub-tiles' graphs / (n_sub * sub_rows)
 };
 
 // Everything a model's forward needs about the resident batch.
@@ -185,6 +196,8 @@ public:
     virtual int set_num_tasks(int t) { return t == 1 ? 0 : 8; }
     // rows > 0: flowgnn_set_batch packs whole graphs into tiles of at most rows rows / edges in-edges (DeviceBatch::gtiles)
     virtual void graph_tile_limits(int& rows, int& edges) const { rows = 0; edges = 0; }
+    // rows > 0: flowgnn_set_batch also packs the half-tile lists of GraphTiles (sub / big_*)
+    virtual void sub_tile_limits(int& rows, int& edges) const { rows = 0; edges = 0; }
     virtual int emb_dim() const = 0;
     virtual int scratch_dim() const = 0;          // floats per node of scratch the forward needs
     virtual bool has_edge_attr() const = 0;

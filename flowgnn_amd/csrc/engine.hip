@@ -93,7 +93,7 @@ static const OptionDef kOptionTable[] = {
     {"csr_flat", 0},              // 1: global-memory index build for every graph (A/B)
     {"tile_nominal", -1},         // rows per tile of the tiled aggregation kernels (< 0: the model's default)
     {"tile_slack", -1},
-    {"gin_resident", 1}, {"gin_tile_build", -1}, {"gin_resident_min_fill", 0.5}, {"gin_resident_nosort", 0}, {"gin_resident_prof", 0},
+    {"gin_resident", 1}, {"gin_tile_build", -1}, {"gin_pingpong", 0}, {"gin_resident_min_fill", 0.5}, {"gin_resident_nosort", 0}, {"gin_resident_prof", 0},
     {"gin_unfused", 0}, {"gin_mfma", 16}, {"gin_split_nt", 4}, {"gin_fold_readout", 1}, {"gin_head_fold", 1},
     {"gin_agg_untiled", 0}, {"gin_agg_tile", 128},
     {"gcn_resident", 1}, {"gcn_unfused", 0}, {"gcn_mfma", 16},
@@ -198,6 +198,8 @@ struct flowgnn_engine {
     float *d_h0 = nullptr, *d_h1 = nullptr, *d_scratch = nullptr, *d_out = nullptr;
     int *d_trow = nullptr, *d_tgraph = nullptr;  // graph-aligned tiles (GraphTiles)
     size_t cap_tiles = 0;
+    int* d_sub = nullptr;                        // GraphTiles::sub | big_row | big_graph in one allocation
+    size_t cap_sub = 0;
     bool has_attr = false, has_eig = false;
     DeviceBatch db{};
 
@@ -236,6 +238,9 @@ struct flowgnn_engine {
         if (d_tgraph) (void)hipFree(d_tgraph);
         d_trow = d_tgraph = nullptr;
         cap_tiles = 0;
+        if (d_sub) (void)hipFree(d_sub);
+        d_sub = nullptr;
+        cap_sub = 0;
         capG = capN = capE = 0;
     }
 };
@@ -505,6 +510,47 @@ int flowgnn_set_batch(flowgnn_engine* e, int num_graphs, const int* nums_of_node
                 gt.n_tiles = (int)cnt - 1; gt.rows = t_rows; gt.edges = t_edges; gt.ok = true;
                 gt.fill = (double)N / ((double)gt.n_tiles * t_rows);
             }
+        }
+        int s_rows = 0, s_edges = 0;
+        e->model->sub_tile_limits(s_rows, s_edges);
+        if (e->db.gtiles.ok && s_rows > 0) {  // half-tile runs + the graphs beyond the half-tile limits (GraphTiles::sub / big_*)
+            std::vector<int> sub, brow, bgraph;
+            int cr = 0, ce = 0, g0 = -1;
+            long long sub_rows_total = 0;
+            auto close_run = [&](int g_end) {
+                if (g0 >= 0) { sub.push_back(noff[g0]); sub.push_back(cr); sub.push_back(g0); sub.push_back(g_end); }
+                g0 = -1; cr = 0; ce = 0;
+            };
+            for (int g = 0; g < num_graphs; g++) {
+                const int n = nums_of_nodes[g], m = nums_of_edges[g];
+                if (n > s_rows || m > s_edges) {  // within the full-tile limits (gtiles.ok), beyond the half tile: its own full tile
+                    close_run(g);
+                    brow.push_back(noff[g]); brow.push_back(noff[g] + n);
+                    bgraph.push_back(g); bgraph.push_back(g + 1);
+                    continue;
+                }
+                if (g0 >= 0 && (cr + n > s_rows || ce + m > s_edges)) close_run(g);
+                if (g0 < 0) g0 = g;
+                cr += n; ce += m;
+                sub_rows_total += n;
+            }
+            close_run(num_graphs);
+            const size_t cnt = sub.size() + brow.size() + bgraph.size();
+            if (cnt > e->cap_sub) {
+                if (e->d_sub) (void)hipFree(e->d_sub);
+                e->d_sub = nullptr;
+                e->cap_sub = 0;
+                EHIP_TRY(e, hipMalloc((void**)&e->d_sub, sizeof(int) * (cnt ? cnt : 1)));
+                e->cap_sub = cnt;
+            }
+            ENGINE_TRY(e, h2d(e->d_sub, sub.data(), sizeof(int) * sub.size()));
+            ENGINE_TRY(e, h2d(e->d_sub + sub.size(), brow.data(), sizeof(int) * brow.size()));
+            ENGINE_TRY(e, h2d(e->d_sub + sub.size() + brow.size(), bgraph.data(), sizeof(int) * bgraph.size()));
+            GraphTiles& gt = e->db.gtiles;
+            gt.sub = e->d_sub; gt.n_sub = (int)(sub.size() / 4); gt.sub_rows = s_rows; gt.sub_edges = s_edges;
+            gt.big_row = e->d_sub + sub.size(); gt.big_graph = e->d_sub + sub.size() + brow.size(); gt.n_big = (int)(brow.size() / 2);
+            gt.sub_ok = true;
+            gt.sub_fill = gt.n_sub ? (double)sub_rows_total / ((double)gt.n_sub * s_rows) : 0.0;
         }
     }
 

@@ -620,7 +620,15 @@ public:
         for (int l = 0; l < GIN_L; l++)
             gin_resident_pack_layer(w1 + (size_t)l * GIN_H * GIN_D, b1 + (size_t)l * GIN_H, w2 + (size_t)l * GIN_D * GIN_H,
                                     b2 + (size_t)l * GIN_D, rsplit.data() + (size_t)l * gin_resident_layer_bytes());
+        // ... re-cut into the ping-pong kernel's pieces, with the edge-embedding tables as half tables
+        std::vector<uint8_t> pp_pieces((size_t)GIN_L * gin_pp_layer_bytes());
+        for (int l = 0; l < GIN_L; l++)
+            gin_pp_pack_layer(rsplit.data() + (size_t)l * gin_resident_layer_bytes(), pp_pieces.data() + (size_t)l * gin_pp_layer_bytes());
+        std::vector<float> pp_tables(gin_pp_table_floats());
+        gin_pp_pack_tables(ecomb.data(), pp_tables.data());
         int rc;
+        if ((rc = upload(&d_pp_pieces_, pp_pieces))) return rc;
+        if ((rc = upload(&d_pp_tables_, pp_tables))) return rc;
         if ((rc = ginq_upload(qw_, nemb, eemb, w1, b1, w2, b2, pw, pb))) return rc;  // Q6.10 copies (numeric mode 1)
         if ((rc = upload(&d_split_, split))) return rc;
         if ((rc = upload(&d_rsplit_, rsplit))) return rc;
@@ -716,6 +724,16 @@ public:
         rows = resident_ ? GIN_RESIDENT_ROWS : 0;
         edges = resident_ ? GIN_RESIDENT_EDGES : 0;
     }
+    void sub_tile_limits(int& rows, int& edges) const override {
+        const bool on = resident_ && pingpong_ && !virtual_node_;
+        rows = on ? GIN_PP_ROWS : 0;
+        edges = on ? GIN_PP_EDGES : 0;
+    }
+    // ping-pong form (gin_pp_kernel): the batch's half-tiles on it, the few graphs beyond the half-tile limits on gin_resident_kernel
+    bool use_pingpong(const DeviceBatch& db) const {
+        return pingpong_ && !virtual_node_ && use_resident(db) && !keep_h_ && num_tasks_ == 1 && fold_readout_ && head_fold_ && db.gtiles.sub_ok &&
+               db.gtiles.n_sub > 0 && db.gtiles.sub_fill >= resident_min_fill_;
+    }
     bool use_resident(const DeviceBatch& db) const {
         // tiles that are mostly empty (graphs of 130..256 nodes, or dense graphs that hit the edge limit first) waste the
         // MFMA columns of the absent rows: below half full the per-layer kernels are the better choice
@@ -764,6 +782,25 @@ public:
             atom_encoder_kernel<GIN_D><<<atom_encoder_grid(n, GIN_C), 512, 0, s>>>(db.b.node_feature, d_nemb_, db.h[0], n, db.csr.err);
         }
         const bool multi = num_tasks_ > 1;  // NUM_TASK > 1: the layers leave h_5 in HBM and a multi-task readout kernel follows
+        if (use_pingpong(db)) {
+            const GraphTiles& gt = db.gtiles;
+            const size_t sub_words = ((size_t)gt.n_sub * gin_pp_desc_bytes() + 3) / 4, big_words = (size_t)gt.n_big * (GIN_RESIDENT_DESC_BYTES / 4);
+            if (int rc = perm_.reserve(sub_words + big_words)) return rc;
+            {
+                ProfScope p(prof, "gin_resident", s);  // all five layers + readout of every half-tile
+                launch_gin_pp(db.h[0], db.csr.row_ptr, db.csr.src, db.csr.ecode, d_pp_tables_, d_pp_pieces_, d_pb_, gt.sub,
+                              reinterpret_cast<uint8_t*>(perm_.p), db.b.node_off, db.out, gt.n_sub, db.range_flag, d_head_, s, resident_prof_);
+            }
+            if (gt.n_big > 0) {  // graphs of 129..256 nodes (or 641..1280 edges): one full tile each on the eight-wave resident kernel
+                ProfScope p(prof, "gin_resident_big", s);
+                launch_gin_resident(db.h[0], nullptr, db.csr.row_ptr, db.csr.src, db.csr.ecode, d_ecomb_, d_rsplit_, d_pw_, d_pb_, gt.big_row,
+                                    gt.big_graph, reinterpret_cast<uint8_t*>(perm_.p + sub_words), db.b.node_off, db.out, gt.n_big,
+                                    db.range_flag, s, false, d_head_, resident_order_, false, nullptr, 2);
+            }
+            db.final_h = 0;
+            db.h_valid = false;
+            return 0;
+        }
         if (use_resident(db)) {
             // all five layers and the readout in one launch; h_5 rows are written (to h[1]) only for the flowgnn_get_h tap
             if (int rc = perm_.reserve((size_t)db.gtiles.n_tiles * (GIN_RESIDENT_DESC_BYTES / 4))) return rc;
@@ -858,6 +895,7 @@ public:
         resident_ = o.on("gin_resident");
         resident_min_fill_ = o.num("gin_resident_min_fill");
         tile_build_ = o.i("gin_tile_build");
+        pingpong_ = o.on("gin_pingpong");
         head_fold_ = o.on("gin_head_fold");
     }
     void set_exact(bool on) override { exact_ = on; }
@@ -895,6 +933,8 @@ private:
         if (d_rsplit_) { (void)hipFree(d_rsplit_); d_rsplit_ = nullptr; }
         if (d_head_) { (void)hipFree(d_head_); d_head_ = nullptr; }
         if (d_enc_tab_) { (void)hipFree(d_enc_tab_); d_enc_tab_ = nullptr; }
+        if (d_pp_pieces_) { (void)hipFree(d_pp_pieces_); d_pp_pieces_ = nullptr; }
+        if (d_pp_tables_) { (void)hipFree(d_pp_tables_); d_pp_tables_ = nullptr; }
         enc_idx_.release();
         perm_.release();
         qw_.release();
@@ -921,6 +961,9 @@ private:
     GrowBufI enc_idx_;  // one-pass path: four table-row numbers per node (8 B), written by gin_tile_build_kernel
     float* d_enc_tab_ = nullptr;  // ... and the pre-combined encoder table they index
     bool h0_in_hbm_ = false;      // db.h[0] holds h_0 of the resident batch (false after a one-pass run)
+    bool pingpong_ = false;       // gin_pingpong = 1: gin_pp_kernel (two half-tiles per CU half a layer out of phase; measured slower)
+    uint8_t* d_pp_pieces_ = nullptr;  // weight pieces of gin_pp_kernel
+    float* d_pp_tables_ = nullptr;    // ... and its half tables
     int tile_build_ = -1;         // gin_tile_build: 1 = one-pass front end, 0 = CSR build + atom encoder + tile prep as separate launches, -1 = by batch size
     // gin_fold_readout=0 keeps the separate mean-pool + linear kernel (and the last layer's 2.7 GB of rows)
     bool fold_readout_ = true;

@@ -41,6 +41,19 @@ void gin_resident_pack_layer(const float* w1, const float* b1, const float* w2, 
 constexpr int GIN_RESIDENT_ROWS = 256;
 constexpr int GIN_RESIDENT_EDGES = 1280;
 constexpr int GIN_RESIDENT_DESC_BYTES = 3584;  // per-tile descriptor built by gin_tile_prep_kernel (CSR slice as 16-bit words, row offsets, column owners)
+// ping-pong form of the graph-resident kernel (gin_pp_kernel): two half-tiles of <= 128 rows / 640 in-edges per CU, half a layer out
+// of phase -- one half multiplies while the other gathers and loads.  Single-task folded readout only; graphs beyond the half-tile
+// limits go to launch_gin_resident with the (start, end) pair lists (tstride 2).
+constexpr int GIN_PP_ROWS = 128, GIN_PP_EDGES = 640;
+size_t gin_pp_layer_bytes();
+size_t gin_pp_table_floats();
+int gin_pp_desc_bytes();
+void gin_pp_pack_layer(const uint8_t* resident_layer /* gin_resident_pack_layer's output */, uint8_t* out);
+void gin_pp_pack_tables(const float* ecomb_all /* [5][60][100] */, float* out);
+void launch_gin_pp(const float* h0, const int* row_ptr, const int* src, const uint8_t* ecode, const float* tables, const uint8_t* pieces,
+                   const float* pool_b, const int* sub_tiles /* [n_sub][4] */, uint8_t* sub_desc, const int* node_off, float* out, int n_sub,
+                   int* range_flag, const float* head_u, hipStream_t s, bool prof = false);
+
 // what the one-pass tile loader needs (launch_gin_resident, tb != null): the caller's arrays, the per-node table-row numbers it writes
 // (8 B per node) and the pre-combined encoder table (gin_resident_pack_enc_table); err = the engine's validation flag
 struct GinTileBuild {
@@ -58,7 +71,7 @@ void launch_gin_resident(const float* h0, float* hout, const int* row_ptr, const
                          const uint8_t* chunks_all, const float* pool_w, const float* pool_b, const int* tile_row, const int* tile_graph,
                          uint8_t* tile_desc /* scratch, n_tiles x GIN_RESIDENT_DESC_BYTES */, const int* node_off, float* out, int n_tiles,
                          int* range_flag, hipStream_t s, bool hubs = false, const float* head_u = nullptr, int col_order = 0, bool prof = false,
-                         const GinTileBuild* tb = nullptr);
+                         const GinTileBuild* tb = nullptr, int tstride = 1);
 // head_u for launch_gin_resident (GIN_RESIDENT_HEAD_FLOATS floats): the single-task readout folded through the LAST layer's second
 // linear layer -- u = W2^T w_pred divided by the first layer's power-of-two weight scale, padded to 208, then c = b2 . w_pred
 constexpr int GIN_RESIDENT_HEAD_FLOATS = 209;

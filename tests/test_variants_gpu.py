@@ -64,6 +64,7 @@ TOL = {"GIN": (1e-4, 1e-4), "GIN-VN": (2e-4, 1e-3), "GCN": (1e-4, 1e-4), "GAT": 
 GIN_VARIANTS = [
     {"gin_tile_build": 1},   # one-pass front end: tile descriptors + encoder row numbers from the caller's arrays, h_0 computed by the tile loader
     {"gin_tile_build": 0},   # index build + atom encoder + tile prep as separate launches
+    {"gin_pingpong": 1, "gin_tile_build": 0},  # gin_pp_kernel: two half-tiles per CU half a layer out of phase (GIN only; GIN-VN ignores it)
     {"gin_unfused": 1},
     {"gin_unfused": 1, "gin_agg_untiled": 1},
     {"gin_unfused": 1, "gin_agg_tile": 64},
@@ -294,3 +295,26 @@ def test_one_pass_front_end_is_the_same_index_build(oracle):
         e.forward(bad2)
     assert ei.value.code == 4, ei.value
     e.close()
+
+
+def test_pingpong_kernel_is_bit_identical_to_the_lock_step_one(oracle):
+    """gin_pp_kernel (gin_pingpong=1: one half of the workgroup multiplies while the other gathers and loads) does exactly the
+    arithmetic of gin_resident_kernel per row -- same bits -- on ragged half-tiles, on graphs beyond the half-tile limits (129..256
+    nodes: routed to the eight-wave kernel, one tile each) and when one half runs out of half-tiles before the other."""
+    from tests.test_resident_limits_gpu import random_graph
+    w = weights.synth_gin_weights(seed=7)
+    mol = gp.synth_molhiv_batch(700, seed=61)
+    b = gp.concat_batches([mol.slice(0, 100), random_graph(128, 640, seed=1), random_graph(150, 330, seed=2), mol.slice(100, 101),
+                           random_graph(256, 1280, seed=3), random_graph(100, 700, seed=4), mol.slice(101, 700)])
+    outs = {}
+    for pp in (1, 0):
+        e = Engine("GIN", device=0, options={"gin_pingpong": pp, "gin_tile_build": 0, "gin_resident_min_fill": 0})
+        e.set_weights(w)
+        outs[pp] = e.forward(b)
+        for lo, hi in ((0, 1), (3, 4), (50, 53), (0, 705)):  # one graph, an odd number of half-tiles, the lot
+            assert np.array_equal(e.forward(b.slice(lo, hi)), outs[pp][lo:hi]), (pp, lo, hi)
+        assert e.exact_reruns() == 0
+        e.close()
+    assert np.array_equal(outs[1], outs[0])
+    want = oracle.gin_forward(b, [w], nthreads=8)
+    assert np.allclose(outs[1], want, rtol=1e-4, atol=1e-4 * max(1.0, float(np.abs(want).max())))
