@@ -360,6 +360,302 @@ __global__ __launch_bounds__(512, 2) void dgn_layer_fused_kernel(const float* __
     }
 }
 
+// ---------------------------------------------------------------- fused layer, aggregation on the MATRIX pipe (kNN-dense tiles)
+// In dgn_layer_fused_kernel a K-step's operand is a walk over the row's in-edges: 16 LDS reads + 128 VALU instructions per lane,
+// seven times per tile -- the walk, not the 21 MFMAs behind it, is where the layer's time goes (wait share 0.61, MFMA busy 14 %).
+// Both aggregates are LINEAR in h, and a tile of whole graphs is a block-diagonal adjacency matrix A (v, u) of 0 / 1 entries:
+//     m1[v] = sum_u A[v][u] h[u]                     P[v] = sum_u A[v][u] eig[u] h[u]
+//     m2[v] = sum_u A[v][u] (eig[u] - eig[v]) h[u] = P[v] - eig[v] m1[v]           (DGN/src/message_passing.cc:148-149)
+// so for K-step k (features 16k .. 16k+15) the two aggregates of the wave's 16 rows are  H^T[16 features][128 sources] x A^T[128][16]
+// -- MFMAs with the TRANSPOSED, f16-split rows of the tile as the A operand (s_ht: [feature][source] hi and lo, built by the tile
+// loader) and, as the B operand, the row's adjacency: lane (j, g) holds A[v_j][32 s + 8 g .. + 7] for the four 32-source blocks s as
+// f16 -- ones (exact: m1 = two products, H_hi A + H_lo A) and eig[u] split hi / lo (P = three products).  The adjacency operands
+// are built ONCE per tile from a 32-bit mask per lane (the row's sources that fall into this lane's slots): ~160 VALU instructions
+// per tile instead of 896 for the seven walks; source blocks that are empty for the whole wave are skipped (block diagonal: a
+// 16-row group sees two or three of the four).  The result lands in the lanes that need it: D[feature 4g + r][v_j] -> lane (j, g).
+// Order of summation differs from the CSR order of the walk (and depends on where the graph sits in its tile), so this path is
+// toleranced, not bit-identical under batch splits (tests/test_dgn_gpu.py says so); duplicate edges (multiplicity > 1: not a 0 / 1
+// matrix) are added by a correction walk over just those edges.  h[v] (self term, residual) is read from HBM / L2, not from LDS:
+// the fp32 rows are not kept on chip.
+constexpr int DGN_HT_STRIDE = 136;                           // f16 per feature row of s_ht (128 sources + 8: 68 banks, conflict-free)
+constexpr int DGN_HT_BYTES = DGN_D * DGN_HT_STRIDE * 2;      // 27 200 per half (hi | lo)
+
+__global__ __launch_bounds__(512, 2) void dgn_layer_mfma_kernel(const float* __restrict__ h, float* __restrict__ hout,
+                                                                 const int* __restrict__ row_ptr, const int* __restrict__ src,
+                                                                 const int* __restrict__ out_deg, const float* __restrict__ eig4,
+                                                                 const uint8_t* __restrict__ wpk, const int* __restrict__ tile_row,
+                                                                 int n_tiles, int* __restrict__ range_flag, int ablate_arg) {
+    const int ablate = FG_ABLATE(ablate_arg);  // development aid (dgn_ablate, -DFLOWGNN_DEV builds): 1 no aggregation MFMAs, 2 no dense
+    (void)ablate_arg;                          // MFMAs, 4 no transposing stores of the next tile, 8 no in-edge pass, 16 no h[v] loads
+    constexpr int OFF_W = 2 * DGN_HT_BYTES, OFF_SRC = OFF_W + (int)DGN_FT_LAYER_BYTES, OFF_RP = OFF_SRC + DGN_FT_EDGES,
+                  OFF_EIG = OFF_RP + 2 * (DGN_FT_ROWS + 8), OFF_EH = OFF_EIG + 4 * DGN_FT_ROWS, LDS_TOTAL = OFF_EH + 4 * DGN_FT_ROWS;
+    static_assert(OFF_W % 16 == 0 && OFF_SRC % 16 == 0 && OFF_RP % 4 == 0 && OFF_EIG % 16 == 0 && OFF_EH % 16 == 0, "alignment");
+    __shared__ __attribute__((aligned(16))) char s_all[LDS_TOTAL];
+    uint16_t* s_ht_hi = reinterpret_cast<uint16_t*>(s_all);
+    uint16_t* s_ht_lo = reinterpret_cast<uint16_t*>(s_all + DGN_HT_BYTES);
+    char* s_w = s_all + OFF_W;
+    uint8_t* s_src = reinterpret_cast<uint8_t*>(s_all + OFF_SRC);
+    uint16_t* s_rp = reinterpret_cast<uint16_t*>(s_all + OFF_RP);
+    float* s_eig = reinterpret_cast<float*>(s_all + OFF_EIG);
+    uint16_t* s_eh = reinterpret_cast<uint16_t*>(s_all + OFF_EH);            // eig split: [128] hi, then [128] lo (f16)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 15, g = lane >> 4;
+    int tile = blockIdx.x;
+    if (tile >= n_tiles) return;
+    for (int i = tid; i < (int)(DGN_FT_LAYER_BYTES / 16); i += 512)
+        reinterpret_cast<uint4*>(s_w)[i] = reinterpret_cast<const uint4*>(wpk)[i];
+    // loader geometry: wave w owns rows 16 w .. 16 w + 15; its p-th load covers chunks 4 p .. 4 p + 3 of them -- lane = (row lane & 15,
+    // chunk lane >> 4): a wave instruction reads sixteen 64-byte row segments (lanes along rows alone would touch 64 different lines
+    // per instruction: measured +0.23 ms per layer), and the 2-byte stores of the transposition fall into 32 different banks
+    const int lr = 16 * wave + (lane & 15), cg = lane >> 4;
+    auto put_row_piece = [&](int c, const float4& v, bool real) {
+        if (c >= DGN_C) return;
+        const float4 x = real ? v : make_float4(0.f, 0.f, 0.f, 0.f);  // rows beyond the tile's last: zeros (never NaN under a zero mask)
+        uint32_t h01, l01, h23, l23;
+        DS_SPLIT2(x.x, x.y, h01, l01);
+        DS_SPLIT2(x.z, x.w, h23, l23);
+        uint16_t* ph = s_ht_hi + (4 * c) * DGN_HT_STRIDE + lr;
+        uint16_t* pl = s_ht_lo + (4 * c) * DGN_HT_STRIDE + lr;
+        ph[0] = (uint16_t)h01; ph[DGN_HT_STRIDE] = (uint16_t)(h01 >> 16); ph[2 * DGN_HT_STRIDE] = (uint16_t)h23; ph[3 * DGN_HT_STRIDE] = (uint16_t)(h23 >> 16);
+        pl[0] = (uint16_t)l01; pl[DGN_HT_STRIDE] = (uint16_t)(l01 >> 16); pl[2 * DGN_HT_STRIDE] = (uint16_t)l23; pl[3 * DGN_HT_STRIDE] = (uint16_t)(l23 >> 16);
+    };
+    auto put_eig = [&](int r, float e, bool real) {
+        const float x = real ? e : 0.0f;
+        uint32_t hh, ll;
+        DS_SPLIT2(x, 0.0f, hh, ll);
+        s_eig[r] = x;
+        s_eh[r] = (uint16_t)hh;
+        s_eh[DGN_FT_ROWS + r] = (uint16_t)ll;
+    };
+    int t0 = tile_row[tile], rows = tile_row[tile + 1] - t0;
+    if (rows > DGN_FT_ROWS) rows = DGN_FT_ROWS;
+    int e0 = row_ptr[t0], ne = row_ptr[t0 + rows] - e0;
+    if (ne > DGN_FT_EDGES) ne = DGN_FT_EDGES;
+    {
+        const float4* hb = reinterpret_cast<const float4*>(h + (size_t)(t0 + (lr < rows ? lr : 0)) * DGN_D);
+#pragma unroll
+        for (int p = 0; p < 7; p++) {
+            const int c = 4 * p + cg;
+            put_row_piece(c, hb[c < DGN_C ? c : 0], lr < rows);
+        }
+    }
+    for (int i = tid; i < ne; i += 512) s_src[i] = (uint8_t)((src[e0 + i] - t0) & 127);
+    if (tid <= rows) { const int o = row_ptr[t0 + tid] - e0; s_rp[tid] = (uint16_t)(o < 0 ? 0 : (o > ne ? ne : o)); }
+    if (tid < DGN_FT_ROWS) put_eig(tid, eig4[(size_t)(t0 + (tid < rows ? tid : 0)) * 4 + 1], tid < rows);
+    __syncthreads();
+    const float oscale = *reinterpret_cast<const float*>(s_w + DGN_FT_BIAS + 112 * 4);
+    float vmax = 0.0f;
+    while (true) {
+        const int ntile = tile + gridDim.x;
+        const bool has_next = ntile < n_tiles;
+        int nt0 = t0, nrows = rows, ne0 = e0, nne = ne;
+        if (has_next) {
+            nt0 = tile_row[ntile];
+            nrows = tile_row[ntile + 1] - nt0;
+            if (nrows > DGN_FT_ROWS) nrows = DGN_FT_ROWS;
+            ne0 = row_ptr[nt0];
+            nne = row_ptr[nt0 + nrows] - ne0;
+            if (nne > DGN_FT_EDGES) nne = DGN_FT_EDGES;
+        }
+        // the next tile, requested now into registers (named scalars: an array filled here and consumed at the loop's end goes to scratch)
+        const float4* nb = reinterpret_cast<const float4*>(h + (size_t)(nt0 + (lr < nrows ? lr : 0)) * DGN_D);
+#define DGN_NC(P) ((4 * (P) + cg) < DGN_C ? (4 * (P) + cg) : 0)
+        const float4 nr0 = nb[DGN_NC(0)], nr1 = nb[DGN_NC(1)], nr2 = nb[DGN_NC(2)], nr3 = nb[DGN_NC(3)], nr4 = nb[DGN_NC(4)], nr5 = nb[DGN_NC(5)],
+                     nr6 = nb[DGN_NC(6)];
+#undef DGN_NC
+        const int elast = nne > 0 ? nne - 1 : 0;
+#define DGN_NXE(P) (nne > 0 ? src[ne0 + ((tid + 512 * (P)) < elast ? (tid + 512 * (P)) : elast)] : 0)
+        const int ns0 = DGN_NXE(0), ns1 = DGN_NXE(1), ns2 = DGN_NXE(2), ns3 = DGN_NXE(3), ns4 = DGN_NXE(4);
+#undef DGN_NXE
+        const int nx_rp = row_ptr[nt0 + (tid <= nrows ? tid : nrows)];
+        const float nx_eig = eig4[(size_t)(nt0 + (tid < nrows ? tid : 0)) * 4 + 1];
+        // ---- this wave's 16 rows
+        const int r = wave * 16 + j;
+        const bool valid = r < rows;
+        const int e_base = valid ? (int)s_rp[r] : 0;
+        const int indeg = (valid && !(ablate & 8)) ? (int)s_rp[r + 1] - e_base : 0;
+        const float eig_v = s_eig[valid ? r : 0];
+        const long long node = (long long)t0 + (valid ? r : 0);
+        const int odeg = out_deg[node];
+        // one pass over the row's in-edges: wsum, abssum (DGN/src/load_inputs.cc:105-110), this lane's slice of the adjacency row as a
+        // bit mask (bit 8 s + e <-> source 32 s + 8 g + e), and the number of duplicate edges (CSR rows are sorted by source)
+        float wsum = 0.0f, abssum = 0.0f;
+        uint32_t bits = 0;
+        int ndup = 0;
+        {
+            // the first 16 in-edges (kNN rows have exactly 16) as two batches of independent LDS reads -- source bytes, then their
+            // eigenvector entries: two round trips instead of 32 dependent ones
+            int us[16];
+            float es[16];
+#pragma unroll
+            for (int e = 0; e < 16; e++) us[e] = e < indeg ? (int)s_src[e_base + e] : 0;
+#pragma unroll
+            for (int e = 0; e < 16; e++) es[e] = s_eig[us[e]];
+            int prev = -1;
+#pragma unroll
+            for (int e = 0; e < 16; e++) {
+                const bool on = e < indeg;
+                const int u = us[e];
+                const float we = on ? es[e] - eig_v : 0.0f;
+                wsum += we;
+                abssum += fabsf(we);
+                if (on && ((u >> 3) & 3) == g) bits |= 1u << (((u >> 5) << 3) | (u & 7));
+                ndup += (on && u == prev);
+                prev = on ? u : prev;
+            }
+            for (int e = 16; __any(e < indeg); e++)
+                if (e < indeg) {
+                    const int u = s_src[e_base + e];
+                    const float we = s_eig[u] - eig_v;
+                    wsum += we;
+                    abssum += fabsf(we);
+                    if (((u >> 3) & 3) == g) bits |= 1u << (((u >> 5) << 3) | (u & 7));
+                    ndup += (u == prev);
+                    prev = u;
+                }
+        }
+        const float inv_abs = 1.0f / (abssum == 0.0f ? 1.0f / 8192.0f : abssum);  // epsilon of ap_fixed<16,3> (node_embedding.cc:125-128)
+        const float inv_dg = odeg == 0 ? 0.0f : 1.0f / (float)odeg;
+        // adjacency operands of the four source blocks: 16-bit lane masks, then ones / eig_hi / eig_lo under the mask
+        ds_uint4_t b_one[4], b_eh[4], b_el[4];
+        bool blk[4];
+#pragma unroll
+        for (int sb = 0; sb < 4; sb++) {
+            ds_uint4_t m;
+#pragma unroll
+            for (int pr = 0; pr < 4; pr++) {
+                const uint32_t lo16 = (uint32_t)(-(int)((bits >> (8 * sb + 2 * pr)) & 1u)) & 0xFFFFu;
+                const uint32_t hi16 = (uint32_t)(-(int)((bits >> (8 * sb + 2 * pr + 1)) & 1u)) & 0xFFFF0000u;
+                m[pr] = lo16 | hi16;
+            }
+            const ds_uint4_t eh = *reinterpret_cast<const ds_uint4_t*>(s_eh + 32 * sb + 8 * g);
+            const ds_uint4_t el = *reinterpret_cast<const ds_uint4_t*>(s_eh + DGN_FT_ROWS + 32 * sb + 8 * g);
+            b_one[sb] = m & (ds_uint4_t){0x3C003C00u, 0x3C003C00u, 0x3C003C00u, 0x3C003C00u};
+            b_eh[sb] = m & eh;
+            b_el[sb] = m & el;
+            blk[sb] = __any(((bits >> (8 * sb)) & 0xFFu) != 0);  // wave-uniform: a source block none of the 16 rows touches is skipped
+        }
+        float4_t acc[DGN_OT];
+#pragma unroll
+        for (int t = 0; t < DGN_OT; t++) {
+            const float4 bv = *reinterpret_cast<const float4*>(s_w + DGN_FT_BIAS + (16 * t + 4 * g) * 4);
+            acc[t] = (float4_t){bv.x, bv.y, bv.z, bv.w};
+        }
+        const float* hrow = h + (size_t)node * DGN_D;  // the row itself: from HBM / L2 (the tile's fp32 rows are not kept in LDS)
+        if (ablate & 16) hrow = reinterpret_cast<const float*>(s_w);
+        float4 hv_next = *reinterpret_cast<const float4*>(hrow + 4 * g);
+        const bool dups = __any(ndup > 0);
+#pragma unroll
+        for (int k = 0; k < DGN_FT_KS; k++) {
+            const bool real = k < 6 || g == 0;
+            const float4 hv = hv_next;
+            if (k + 1 < DGN_FT_KS) hv_next = *reinterpret_cast<const float4*>(hrow + ((k + 1 < 6 || g == 0) ? 16 * (k + 1) + 4 * g : 0));
+            // A operand: lane (i = j, g) reads feature row 16 k + j of s_ht, sources 32 sb + 8 g .. + 7 (k = 6: rows 96 + (j & 3); the
+            // other output rows of that step are discarded below)
+            const int frow = k < 6 ? 16 * k + j : 96 + (j & 3);
+            const uint16_t* ah = s_ht_hi + frow * DGN_HT_STRIDE + 8 * g;
+            const uint16_t* al = s_ht_lo + frow * DGN_HT_STRIDE + 8 * g;
+            float4_t m1 = (float4_t){0.f, 0.f, 0.f, 0.f}, pp = m1;
+#pragma unroll
+            for (int sb = 0; sb < 4; sb++) {
+                if (blk[sb] && !(ablate & 1)) {
+                    const ds_uint4_t fh = *reinterpret_cast<const ds_uint4_t*>(ah + 32 * sb);
+                    const ds_uint4_t fl = *reinterpret_cast<const ds_uint4_t*>(al + 32 * sb);
+                    m1 = DS_MFMA16(fh, b_one[sb], m1);
+                    pp = DS_MFMA16(fh, b_eh[sb], pp);
+                    m1 = DS_MFMA16(fl, b_one[sb], m1);
+                    pp = DS_MFMA16(fl, b_eh[sb], pp);
+                    pp = DS_MFMA16(fh, b_el[sb], pp);
+                }
+            }
+            if (dups) {  // multiplicity > 1: the extra copies of a duplicate edge, from the split rows (hi + lo)
+                int prev = -1;
+                for (int e = 0; __any(e < indeg); e++)
+                    if (e < indeg) {
+                        const int u = s_src[e_base + e];
+                        if (u == prev && real) {
+                            const float eu = s_eig[u];
+#pragma unroll
+                            for (int c = 0; c < 4; c++) {
+                                const int f = (k < 6 ? 16 * k : 96) + 4 * g + c;
+                                const float x = (float)__builtin_bit_cast(_Float16, s_ht_hi[f * DGN_HT_STRIDE + u]) +
+                                                (float)__builtin_bit_cast(_Float16, s_ht_lo[f * DGN_HT_STRIDE + u]);
+                                m1[c] += x;
+                                pp[c] = __builtin_fmaf(x, eu, pp[c]);
+                            }
+                        }
+                        prev = u;
+                    }
+            }
+            // a1 = m1 / outdeg (x / 0 = 0), a2 = |(m2 - wsum h[v]) / abssum| with m2 = P - eig[v] m1   (node_embedding.cc:143-146)
+            float4 a1, a2;
+            a1.x = m1.x * inv_dg; a1.y = m1.y * inv_dg; a1.z = m1.z * inv_dg; a1.w = m1.w * inv_dg;
+            a2.x = fabsf(__builtin_fmaf(-wsum, hv.x, __builtin_fmaf(-eig_v, m1.x, pp.x)) * inv_abs);
+            a2.y = fabsf(__builtin_fmaf(-wsum, hv.y, __builtin_fmaf(-eig_v, m1.y, pp.y)) * inv_abs);
+            a2.z = fabsf(__builtin_fmaf(-wsum, hv.z, __builtin_fmaf(-eig_v, m1.z, pp.z)) * inv_abs);
+            a2.w = fabsf(__builtin_fmaf(-wsum, hv.w, __builtin_fmaf(-eig_v, m1.w, pp.w)) * inv_abs);
+            if (!real || !valid) { a1 = make_float4(0.f, 0.f, 0.f, 0.f); a2 = a1; }
+            ds_uint4_t b_hi, b_lo;
+            DS_SPLIT2(a1.x, a1.y, b_hi.x, b_lo.x);
+            DS_SPLIT2(a1.z, a1.w, b_hi.y, b_lo.y);
+            DS_SPLIT2(a2.x, a2.y, b_hi.z, b_lo.z);
+            DS_SPLIT2(a2.z, a2.w, b_hi.w, b_lo.w);
+            asm("v_max3_f32 %0, |%1|, |%2|, %0" : "+v"(vmax) : "v"(a1.x), "v"(a1.y));
+            asm("v_max3_f32 %0, |%1|, |%2|, %0" : "+v"(vmax) : "v"(a1.z), "v"(a1.w));
+            asm("v_max3_f32 %0, |%1|, |%2|, %0" : "+v"(vmax) : "v"(a2.x), "v"(a2.y));
+            asm("v_max3_f32 %0, |%1|, |%2|, %0" : "+v"(vmax) : "v"(a2.z), "v"(a2.w));
+            asm volatile("" : "+v"(vmax));
+            const char* wb = s_w + (size_t)k * (DGN_OT * 2 * 1024);
+            if (!(ablate & 2)) {
+#pragma unroll
+            for (int t0_ = 0; t0_ < DGN_OT; t0_ += 2) {
+                const int n = t0_ + 1 < DGN_OT ? 2 : 1;
+                ds_uint4_t f[4];
+#pragma unroll
+                for (int i = 0; i < 2 * n; i++) f[i] = *reinterpret_cast<const ds_uint4_t*>(wb + ((t0_ * 2) + i) * 1024 + lane * 16);
+#pragma unroll
+                for (int i = 0; i < n; i++) acc[t0_ + i] = DS_MFMA16(f[2 * i], b_hi, acc[t0_ + i]);
+#pragma unroll
+                for (int i = 0; i < n; i++) acc[t0_ + i] = DS_MFMA16(f[2 * i], b_lo, acc[t0_ + i]);
+#pragma unroll
+                for (int i = 0; i < n; i++) acc[t0_ + i] = DS_MFMA16(f[2 * i + 1], b_hi, acc[t0_ + i]);
+            }
+            } else { acc[0].x += b_hi.x + b_lo.y; }
+        }
+        // ---- epilogue: h' = h + relu(b + W0 a1 + W1 a2)   (node_embedding.cc:176-181)
+        if (valid) {
+#pragma unroll
+            for (int t = 0; t < DGN_OT; t++) {
+                const int c = 16 * t + 4 * g;
+                if (c < DGN_D) {
+                    const float4 hv = *reinterpret_cast<const float4*>(hrow + c);
+                    const float4_t rr = acc[t] * oscale;
+                    *reinterpret_cast<float4*>(hout + (size_t)node * DGN_D + c) =
+                        make_float4(hv.x + relu1(rr.x), hv.y + relu1(rr.y), hv.z + relu1(rr.z), hv.w + relu1(rr.w));
+                }
+            }
+        }
+        if (!has_next) break;
+        __syncthreads();  // every wave is done with this tile's transposed rows, CSR slice and eigenvector column
+        if (!(ablate & 4)) {
+        put_row_piece(cg, nr0, lr < nrows); put_row_piece(4 + cg, nr1, lr < nrows); put_row_piece(8 + cg, nr2, lr < nrows);
+        put_row_piece(12 + cg, nr3, lr < nrows); put_row_piece(16 + cg, nr4, lr < nrows); put_row_piece(20 + cg, nr5, lr < nrows);
+        put_row_piece(24 + cg, nr6, lr < nrows);
+        } else { s_ht_hi[tid] = (uint16_t)(nr0.x + nr1.x + nr2.x + nr3.x + nr4.x + nr5.x + nr6.x); }
+#define DGN_PUTE(P, V) if (tid + 512 * (P) < nne) s_src[tid + 512 * (P)] = (uint8_t)(((V) - nt0) & 127);
+        DGN_PUTE(0, ns0) DGN_PUTE(1, ns1) DGN_PUTE(2, ns2) DGN_PUTE(3, ns3) DGN_PUTE(4, ns4)
+#undef DGN_PUTE
+        if (tid <= nrows) { const int o = nx_rp - ne0; s_rp[tid] = (uint16_t)(o < 0 ? 0 : (o > nne ? nne : o)); }
+        if (tid < DGN_FT_ROWS) put_eig(tid, nx_eig, tid < nrows);
+        __syncthreads();
+        tile = ntile; t0 = nt0; rows = nrows; e0 = ne0; ne = nne;
+    }
+    if (__any(!(vmax < 6.0e4f))) {
+        if (lane == 0) atomicOr(range_flag, 1);
+    }
+}
+
 // host: W [100][2][100] (out, block, in), b [100] -> DGN_FT_LAYER_BYTES in the feature-major K order of dgn_layer_fused_kernel
 static void dgn_pack_fused_layer(const float* W, const float* b, uint8_t* out) {
     std::memset(out, 0, DGN_FT_LAYER_BYTES);
@@ -536,6 +832,16 @@ public:
             if (fused) {
                 ProfScope p(prof, "dgn_layer_fused", s);
                 const int grid = db.gtiles.n_tiles < 256 ? db.gtiles.n_tiles : 256;  // persistent: one 8-wave workgroup per CU (153 KB of LDS)
+                // dense tiles (kNN graphs: 16 in-edges per row, a third of a graph's block filled): both aggregates as MFMAs with the
+                // tile's adjacency; sparse ones (molecules, ~2 in-edges per row): the in-edge walk is cheaper than 20 MFMAs per K-step
+                const bool mfma_agg = mfma_agg_ < 0 ? (double)db.b.e_tot >= 8.0 * (double)n : mfma_agg_ != 0;
+                if (mfma_agg) {
+                    dgn_layer_mfma_kernel<<<grid, 512, 0, s>>>(db.h[cur], db.h[cur ^ 1], db.csr.row_ptr, db.csr.src, db.csr.out_deg, db.node_eigen,
+                                                               d_fused_ + (size_t)l * DGN_FT_LAYER_BYTES, db.gtiles.row_start, db.gtiles.n_tiles,
+                                                               db.range_flag, ablate_);
+                    cur ^= 1;
+                    continue;
+                }
                 dgn_layer_fused_kernel<<<grid, 512, 0, s>>>(db.h[cur], db.h[cur ^ 1], db.csr.row_ptr, db.csr.src, db.csr.out_deg, db.node_eigen,
                                                             d_fused_ + (size_t)l * DGN_FT_LAYER_BYTES, db.gtiles.row_start, db.gtiles.n_tiles,
                                                             db.range_flag, ablate_);
@@ -574,6 +880,7 @@ public:
         if (o.i("tile_slack") >= 0) tile_slack_ = o.i("tile_slack");
         split_ = o.i("dgn_mfma") != 32;
         fused_ = o.on("dgn_fused");
+        mfma_agg_ = o.i("dgn_mfma_agg");
         ablate_ = FG_ABLATE(o.i("dgn_ablate"));
         agg_ready_ = false;
     }
@@ -610,6 +917,7 @@ private:
     bool split_ = true;
     // dgn_fused=0 keeps aggregation and dense update as two kernels per layer (A/B measurements, the aggregation roofline probe)
     bool agg_ready_ = false;  // tiles_ / esc_ describe the batch of the last forward
+    int mfma_agg_ = -1;  // dgn_mfma_agg: 1 = aggregation on the matrix pipe (dgn_layer_mfma_kernel), 0 = in-edge walk, -1 = by density
     int ablate_ = 0;  // development aid (-DFLOWGNN_DEV builds only, option dgn_ablate): per-phase timing (scripts/dev/pna_ablate.sh)
     bool fused_ = true;
     uint8_t* d_fused_ = nullptr;  // feature-major weights of the fused layer kernel

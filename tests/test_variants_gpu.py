@@ -108,6 +108,8 @@ OTHER_VARIANTS = [
     ("PNA", {"pna_fused": 0}),
     ("DGN", {"dgn_mfma": "f32"}),
     ("DGN", {"dgn_fused": 0}),
+    ("DGN", {"dgn_mfma_agg": 0}),   # fused layer with the in-edge walk (the default for sparse tiles)
+    ("DGN", {"dgn_mfma_agg": 1}),   # ... with both aggregates as MFMAs over the tile's adjacency (the default for kNN-dense tiles)
     ("PNA", {"tile_nominal": 64, "tile_slack": 0}),
     ("DGN", {"tile_nominal": 128, "tile_slack": 0}),
 ]
@@ -318,3 +320,34 @@ def test_pingpong_kernel_is_bit_identical_to_the_lock_step_one(oracle):
     assert np.array_equal(outs[1], outs[0])
     want = oracle.gin_forward(b, [w], nthreads=8)
     assert np.allclose(outs[1], want, rtol=1e-4, atol=1e-4 * max(1.0, float(np.abs(want).max())))
+
+
+def test_dgn_mfma_aggregation_on_awkward_tiles(oracle):
+    """dgn_layer_mfma_kernel forced on (dgn_mfma_agg = 1) where its special cases live: duplicate edges (multiplicity > 1 is not a
+    0 / 1 adjacency: the correction walk), self loops, rows without in-edges, rows with far more than 16 in-edges, sparse molecule
+    tiles (most source blocks empty) and a graph that fills the 128-row tile."""
+    from tests.test_resident_limits_gpu import random_graph
+    rng = np.random.default_rng(3)
+    hep = gp.synth_hep10k_batch(12, seed=7, with_eigen=True)
+    el = hep.edge_list.copy()
+    el[3] = el[2]; el[4] = el[2]      # a triple edge
+    el[40, 1] = el[40, 0]             # a self loop
+    hep = gp.GraphBatch(hep.nums_of_nodes, hep.nums_of_edges, hep.node_feature, el, hep.edge_attr, hep.node_eigen)
+    def with_eig(b, seed):
+        e = np.zeros((b.total_nodes, 4), np.float32)
+        e[:, 1] = np.random.default_rng(seed).uniform(-1, 1, b.total_nodes)
+        return gp.GraphBatch(b.nums_of_nodes, b.nums_of_edges, b.node_feature, b.edge_list, b.edge_attr, e)
+    b = gp.concat_batches([hep, with_eig(gp.synth_molhiv_batch(30, seed=8), 1), with_eig(random_graph(128, 2560, seed=5), 2),
+                           with_eig(random_graph(40, 900, seed=6), 3)])
+    w = weights.SYNTH["DGN"](seed=7)
+    want = oracle.dgn_forward(b, [w], nthreads=8)
+    scale = max(1.0, float(np.abs(want).max()))
+    outs = {}
+    for mode in (1, 0):
+        e = Engine("DGN", device=0, options={"dgn_mfma_agg": mode})
+        e.set_weights(w)
+        outs[mode] = e.forward(b)
+        e.close()
+        assert np.isfinite(outs[mode]).all()
+        assert np.allclose(outs[mode], want, rtol=2e-4, atol=2e-3 * scale), (mode, np.abs(outs[mode] - want).max(), scale)
+    assert np.allclose(outs[1], outs[0], rtol=1e-4, atol=1e-4 * scale)
