@@ -27,8 +27,14 @@ def batch_for(model, n=61):
     return gp.synth_hep10k_batch(n // 2, seed=44, with_eigen=(model == "DGN"))  # sizes vary: cuts by work differ from cuts by count
 
 
+# Bit identity under a batch split needs kernels that sum a row's terms in an order that depends on the row alone.  DGN's default
+# kernel for kNN-dense tiles does not (its aggregation is an MFMA contraction over the tile's adjacency: the order depends on where
+# the graph sits in its tile -- tests/test_dgn_gpu.py); the in-edge walk does, so the bit-identity tests select it for DGN.
+OPTS = {"DGN": {"dgn_mfma_agg": 0}}
+
+
 def single(model, b, w):
-    e = Engine(model, device=0)
+    e = Engine(model, device=0, options=OPTS.get(model, {}))
     try:
         e.set_weights(w)
         return e.forward(b)
@@ -41,7 +47,7 @@ def single(model, b, w):
 def test_group_is_bit_identical_to_one_engine(model, devices):
     b, w = batch_for(model), weights.SYNTH[model](seed=7)
     want = single(model, b, w)
-    g = EngineGroup(model, devices)
+    g = EngineGroup(model, devices, options=OPTS.get(model, {}))
     try:
         g.set_weights(w)
         got = g.forward(b)
@@ -105,6 +111,9 @@ def test_entry_points_on_two_engines_with_reloads_spanning_a_cut(model, oracle):
     rw[G // 2 - 1] = 1  # just before the middle cut
     rw[G - 2] = 1       # a two-graph run at the end: one graph per engine
     sets = [w1, w2, w1]
+    from flowgnn_amd import entry_set_option
+    for k, v in OPTS.get(model, {}).items():
+        entry_set_option(model, k, v)
     try:
         entry_set_devices([0])
         one = compute_graphs(model, b, sets, rw)
@@ -112,6 +121,8 @@ def test_entry_points_on_two_engines_with_reloads_spanning_a_cut(model, oracle):
         two = compute_graphs(model, b, sets, rw)
     finally:
         entry_set_devices([0])
+        for k in OPTS.get(model, {}):
+            entry_set_option(model, k, -1)
     assert np.array_equal(one, two)
     want = getattr(oracle, model.lower() + "_forward")(b, sets, reload_weights=rw, nthreads=8)
     assert np.allclose(two, want, rtol=2e-4, atol=2e-3), np.abs(two - want).max()
@@ -137,3 +148,22 @@ def test_host_binary_devices_flag(model, tmp_path, oracle):
     got = np.array([float(ln.split(":")[1]) for ln in outs[1].strip().splitlines()], dtype=np.float32)
     want = getattr(oracle, model.lower() + "_forward")(batch, [w])
     assert np.allclose(got, want, rtol=3e-4, atol=3e-4 * max(1.0, np.abs(want).max()))
+
+
+def test_dgn_default_kernel_on_two_engines_is_toleranced(oracle):
+    """DGN's default (MFMA-aggregation) path under a split: same values to fp32 rounding, and right against the oracle."""
+    b, w = batch_for("DGN"), weights.SYNTH["DGN"](seed=7)
+    e = Engine("DGN", device=0)
+    e.set_weights(w)
+    one = e.forward(b)
+    e.close()
+    g = EngineGroup("DGN", [0, 0])
+    try:
+        g.set_weights(w)
+        two = g.forward(b)
+    finally:
+        g.close()
+    want = oracle.dgn_forward(b, [w], nthreads=8)
+    scale = max(1.0, float(np.abs(want).max()))
+    assert np.allclose(one, two, rtol=1e-5, atol=1e-5 * scale)
+    assert np.allclose(two, want, rtol=2e-4, atol=2e-3 * scale)

@@ -273,13 +273,13 @@ def test_one_pass_front_end_is_the_same_index_build(oracle):
         e = Engine("GIN", device=0, options={"gin_tile_build": tb, "gin_resident_min_fill": 0})
         e.set_weights(w)
         outs[tb] = e.forward(b)
-        assert np.array_equal(e.forward(b.slice(40, 300)), outs[tb][40:300])
         row_ptr, src, eid, _ = e.csr()  # the tap builds the CSR on demand after a one-pass run
         assert row_ptr[-1] == b.total_edges and len(src) == b.total_edges
+        assert np.array_equal(e.forward(b.slice(40, 300)), outs[tb][40:300])
         e.close()
     want = oracle.gin_forward(b, [w], nthreads=8)
     assert np.allclose(outs[1], want, rtol=1e-4, atol=1e-4)
-    assert np.abs(outs[1] - outs[0]).max() < 2e-5
+    assert np.allclose(outs[1], outs[0], rtol=1e-5, atol=1e-5)  # (the kNN graphs' logits are large: relative, not absolute)
     bad = gp.GraphBatch(b.nums_of_nodes, b.nums_of_edges, b.node_feature, el.copy(), b.edge_attr.copy())
     bad.edge_list[7, 0] = 10 ** 6
     for tb in (1, 0):
@@ -313,7 +313,7 @@ def test_pingpong_kernel_is_bit_identical_to_the_lock_step_one(oracle):
         e = Engine("GIN", device=0, options={"gin_pingpong": pp, "gin_tile_build": 0, "gin_resident_min_fill": 0})
         e.set_weights(w)
         outs[pp] = e.forward(b)
-        for lo, hi in ((0, 1), (3, 4), (50, 53), (0, 705)):  # one graph, an odd number of half-tiles, the lot
+        for lo, hi in ((0, 1), (3, 4), (50, 53), (99, 106), (0, b.num_graphs)):  # one graph, odd numbers of half-tiles, the big graphs, the lot
             assert np.array_equal(e.forward(b.slice(lo, hi)), outs[pp][lo:hi]), (pp, lo, hi)
         assert e.exact_reruns() == 0
         e.close()
