@@ -21,7 +21,7 @@ KERNELS = {
     "GAT": (1 << 18, "GAT", {"gat_resident": "gat_resident_kernel", "gat_layer": "gat_layer_kernel<false, false"}),
     "PNA": (1 << 15, "PNA", {"pna_layer_fused": "pna_layer_fused_kernel", "pna_aggregate": "tiled_aggregate_kernel<fg::PnaAggPolicy",
                              "pna_dense": "pna_dense_split_kernel"}),
-    "DGN": (1 << 15, "DGN", {"dgn_layer_fused": "dgn_layer_fused_kernel", "dgn_aggregate": "tiled_aggregate_kernel<fg::DgnAggPolicy",
+    "DGN": (1 << 15, "DGN", {"dgn_layer_fused": "dgn_layer_mfma_kernel", "dgn_aggregate": "tiled_aggregate_kernel<fg::DgnAggPolicy",
                              "dgn_dense": "dense200_res_relu_split_kernel"}),
 }
 

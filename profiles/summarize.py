@@ -6,6 +6,7 @@
       the averages are those of the timed region (a kernel with c calls runs c / (steps + warmup) times per step; its first
       warmup x that many calls, in time order, are dropped)
   python profiles/summarize.py pmc    <counter_collection.csv> COUNTER       > profiles/rNN_*.txt
+  python profiles/summarize.py pmcall <counter_collection.csv>               > profiles/rNN_*_pmc_SQ.txt   (all counters of a pass)
 """
 import csv
 import sys
@@ -60,8 +61,29 @@ def pmc(path, counter):
         print(f"{k[:70]:<70} {c:>10} {t/c:>16.1f} {t:>18.1f}")
 
 
+def pmcall(path):
+    """every counter of a multi-counter pass, per kernel (averages per dispatch) + the kernel's average duration"""
+    agg = defaultdict(lambda: defaultdict(lambda: [0, 0.0]))
+    rows = list(csv.DictReader(open(path)))
+    print("# columns:", ",".join(rows[0].keys()) if rows else "")
+    for r in rows:
+        a = agg[r["Kernel_Name"]][r["Counter_Name"]]
+        a[0] += 1
+        a[1] += float(r["Counter_Value"])
+        if "Start_Timestamp" in r and "End_Timestamp" in r:
+            d = agg[r["Kernel_Name"]]["(duration_ns)"]
+            d[0] += 1
+            d[1] += float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
+    for k, cs in agg.items():
+        print(k[:90])
+        for c, (n, t) in sorted(cs.items()):
+            print(f"    {c:<34} dispatches={n:<5} avg={t/n:,.1f}")
+
+
 if __name__ == "__main__":
     if sys.argv[1] == "stats":
         stats(sys.argv[2], *(int(a) for a in sys.argv[3:5]))
+    elif sys.argv[1] == "pmcall":
+        pmcall(sys.argv[2])
     else:
         pmc(sys.argv[2], sys.argv[3])
