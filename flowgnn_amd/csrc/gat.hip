@@ -501,6 +501,9 @@ struct GatResidentDev {
 
 #define GATR_ABSMAX(v, a, b) asm("v_max3_f32 %0, |%1|, |%2|, %0" : "+v"(v) : "v"(a), "v"(b))
 
+constexpr int GATR_PS = 17;
+constexpr float GATR_LOG2E = 1.4426950408889634f;
+
 __global__ __launch_bounds__(GATR_WAVES * 64, 4) void gat_resident_kernel(const int* __restrict__ node_feature, const int* __restrict__ feat_row,
                                                                          const int* __restrict__ row_ptr, const int* __restrict__ src,
                                                                          const int* __restrict__ tile_row, const int* __restrict__ tile_graph,
@@ -510,7 +513,10 @@ __global__ __launch_bounds__(GATR_WAVES * 64, 4) void gat_resident_kernel(const 
     (void)ablate_arg;
     const bool sort_rows = !(ablate & 4);  // development aid: gat_ablate, -DFLOWGNN_DEV builds=4 keeps rows in natural order
     __shared__ __attribute__((aligned(16))) char s_w[GATR_LAYER_BYTES];  // this layer's fragments
-    __shared__ __attribute__((aligned(16))) float4 s_proj[GATR_ROWS * 16];
+    // projections: 16 float4 (dims, heads in the float4) per row at a stride of GATR_PS = 17 float4 -- row u starts in bank group
+    // u mod 16, so the sixteen rows a gather instruction reads spread over the groups as the former per-row rotation did, but the
+    // dim index is a compile-time offset (the rotation cost ~10 VALU instructions per edge and lane in a VALU-issue-bound kernel)
+    __shared__ __attribute__((aligned(16))) float4 s_proj[GATR_ROWS * GATR_PS];
     __shared__ __attribute__((aligned(16))) float4 s_sc[GATR_ROWS * 2];
     __shared__ __attribute__((aligned(16))) float4 s_lin0[GAT_D * ND_FEATURE];
     __shared__ int s_feat[GATR_ROWS * ND_FEATURE];
@@ -601,7 +607,7 @@ __global__ __launch_bounds__(GATR_WAVES * 64, 4) void gat_resident_kernel(const 
 #pragma unroll
             for (int k = 0; k < GATR_ROWS * GAT_D / NT; k++) {
                 const int r = (tid + NT * k) >> 4;
-                s_proj[r * 16 + ((d + r) & 15)] = gat_proj0(&s_feat[r * ND_FEATURE], wl);
+                s_proj[r * GATR_PS + d] = gat_proj0(&s_feat[r * ND_FEATURE], wl);
             }
         }
         __syncthreads();
@@ -610,12 +616,14 @@ __global__ __launch_bounds__(GATR_WAVES * 64, 4) void gat_resident_kernel(const 
             float4 ss = make_float4(0.f, 0.f, 0.f, 0.f), st = ss;
 #pragma unroll
             for (int d = 0; d < GAT_D; d++) {
-                const float4 pd = s_proj[r * 16 + ((d + r) & 15)];
+                const float4 pd = s_proj[r * GATR_PS + d];
                 gat_score_acc(ss, pd, s_att[d]);
                 gat_score_acc(st, pd, s_att[GAT_D + d]);
             }
-            s_sc[r * 2 + 0] = ss;
-            s_sc[r * 2 + 1] = st;
+            // scores are kept pre-multiplied by log2(e): leaky-ReLU is positively homogeneous, so exp(leaky(s)) = exp2(leaky(s log2 e))
+            // and the gather's exponentials are bare v_exp_f32 (one multiply less per head, edge and lane)
+            s_sc[r * 2 + 0] = make_float4(ss.x * GATR_LOG2E, ss.y * GATR_LOG2E, ss.z * GATR_LOG2E, ss.w * GATR_LOG2E);
+            s_sc[r * 2 + 1] = make_float4(st.x * GATR_LOG2E, st.y * GATR_LOG2E, st.z * GATR_LOG2E, st.w * GATR_LOG2E);
             int pos = r;
             if (sort_rows) {
                 pos = atomicAdd(&s_cur[skey], 1);
@@ -687,15 +695,15 @@ __global__ __launch_bounds__(GATR_WAVES * 64, 4) void gat_resident_kernel(const 
                         const float4 st = s_sc[u * 2 + 1];
                         float4 p[4];
 #pragma unroll
-                        for (int t = 0; t < 4; t++) p[t] = s_proj[u * 16 + ((4 * t + g + u) & 15)];
+                        for (int t = 0; t < 4; t++) p[t] = s_proj[u * GATR_PS + 4 * t + g];
                         more = e < e_end;
                         u = u_nx;
                         e++;
                         if (e < e_end) u_nx = (int)s_src[e];
                         float4 sv = make_float4(ssrc.x + st.x, ssrc.y + st.y, ssrc.z + st.z, ssrc.w + st.w);
                         // leaky_0.2(x) = max(x, 0.2 x)
-                        sv.x = __expf(__builtin_fmaxf(sv.x, sv.x * 0.2f)); sv.y = __expf(__builtin_fmaxf(sv.y, sv.y * 0.2f));
-                        sv.z = __expf(__builtin_fmaxf(sv.z, sv.z * 0.2f)); sv.w = __expf(__builtin_fmaxf(sv.w, sv.w * 0.2f));
+                        sv.x = __builtin_amdgcn_exp2f(__builtin_fmaxf(sv.x, sv.x * 0.2f)); sv.y = __builtin_amdgcn_exp2f(__builtin_fmaxf(sv.y, sv.y * 0.2f));
+                        sv.z = __builtin_amdgcn_exp2f(__builtin_fmaxf(sv.z, sv.z * 0.2f)); sv.w = __builtin_amdgcn_exp2f(__builtin_fmaxf(sv.w, sv.w * 0.2f));
                         den.x += sv.x; den.y += sv.y; den.z += sv.z; den.w += sv.w;
 #pragma unroll
                         for (int t = 0; t < 4; t++) {
@@ -786,8 +794,11 @@ __global__ __launch_bounds__(GATR_WAVES * 64, 4) void gat_resident_kernel(const 
             const float lin_scale = w.scales[GAT_L + l], sc_scale = w.scales[2 * GAT_L + l];
 #pragma unroll
             for (int t2 = 0; t2 < 4; t2++)
-                s_proj[r * 16 + ((4 * t2 + g + r) & 15)] = make_float4(pr[t2].x * lin_scale, pr[t2].y * lin_scale, pr[t2].z * lin_scale, pr[t2].w * lin_scale);
-            if (g < 2) s_sc[r * 2 + g] = make_float4(pr[4].x * sc_scale, pr[4].y * sc_scale, pr[4].z * sc_scale, pr[4].w * sc_scale);
+                s_proj[r * GATR_PS + 4 * t2 + g] = make_float4(pr[t2].x * lin_scale, pr[t2].y * lin_scale, pr[t2].z * lin_scale, pr[t2].w * lin_scale);
+            if (g < 2) {
+                const float sl = sc_scale * GATR_LOG2E;  // (scores pre-multiplied by log2 e, see the layer-0 scores above)
+                s_sc[r * 2 + g] = make_float4(pr[4].x * sl, pr[4].y * sl, pr[4].z * sl, pr[4].w * sl);
+            }
             __syncthreads();  // #2: the next layer's projections and scores are complete
         }
         __syncthreads();  // the per-node readout terms are in s_dot
