@@ -494,6 +494,12 @@ __device__ __forceinline__ void grc_issue_chunk_w1(const uint8_t* __restrict__ g
 
 #define GR_LD(off) (*reinterpret_cast<const uint4_t*>(wb + (off) + lane * 16))
 #define GR_SB() __builtin_amdgcn_sched_barrier(0)
+// GR_DEFER (compile-time, -DGR_DEFER=true): finish a step's last hidden tile at the top of the NEXT step (gr_step, PEND_IN / PEND_OUT).
+// Measured on MI355X: 8.95 ms per launch against 8.70 -- eight more live registers across the barrier cost 16 B of scratch per lane,
+// and VALU work at the head of a segment is exactly what MI355X_MICROARCH.md says not to put there.  Off.
+#ifndef GR_DEFER
+#define GR_DEFER false
+#endif
 
 // One step of the node MLP for TWO column tiles per wave.  The work is a chain of "units" -- two fragments (hi, lo of one
 // 16-row weight tile and one K-step) feeding six MFMAs (w_hi x_hi, w_hi x_lo, w_lo x_hi for both column tiles) -- and the
@@ -503,10 +509,13 @@ __device__ __forceinline__ void grc_issue_chunk_w1(const uint8_t* __restrict__ g
 // operand of step 7 is built) | 3: step 7 (packed K-step).
 // KIND 4 / 5: the LAST layer with the readout folded through its second linear layer (head_u, below): hidden tiles only (two / one),
 // each ReLU'd tile is dotted with its slice of u instead of being split for a second layer that is never computed.
-template <int KIND>
+// PEND_OUT: the step's LAST hidden tile is left un-finished in `pend` (its accumulators); PEND_IN: the previous step did that, and this
+// step finishes it AFTER requesting its own first fragments -- the ReLU + split VALU work then covers the LDS round trip every step
+// otherwise starts with (both waves of a SIMD sit behind the step barrier waiting ~200 clocks for their first fragment).
+template <int KIND, bool PEND_IN = false, bool PEND_OUT = false>
 __device__ __forceinline__ void gr_step(const char* wb, int lane, int g, const uint4_t (&in_hi)[2][3], const uint4_t (&in_lo)[2][3],
                                         const uint4_t (&in_tb)[2], uint4_t (&hb_hi)[2], uint4_t (&hb_lo)[2], float4_t (&acc2)[2][GS_T2],
-                                        float& vmax, const float* u_step = nullptr, float* dot = nullptr) {
+                                        float& vmax, float4_t (&pend)[2], const float* u_step = nullptr, float* dot = nullptr) {
     constexpr bool DO2 = KIND == 1 || KIND == 2, DO1 = KIND != 3, DOT = KIND >= 4;
     constexpr int NTL = (KIND == 2 || KIND == 5) ? 1 : 2;
     uint4_t f0[2], f1[2];  // fragment double buffer: f0 = even units, f1 = odd units
@@ -537,9 +546,16 @@ __device__ __forceinline__ void gr_step(const char* wb, int lane, int g, const u
 #define GR_TAIL_LOAD(F, TL) F[0] = *reinterpret_cast<const uint4_t*>(wb + GRC_TAIL_OFF + (TL) * 512 + (lane & 31) * 16);
 #define GR_BIAS(TL) acc1[0] = *reinterpret_cast<const float4_t*>(wb + GRC_B1_OFF + (TL) * 64 + g * 16);
     // ReLU, range watch, split of hidden tile TL into its half (.xy / .zw) of the next step's B operands
-#define GR_FINISH(TL)                                                                                     \
+#define GR_PACK_STEP7()                                                                                                   \
+    _Pragma("unroll") for (int nt = 0; nt < 2; nt++) {                                                                    \
+        const uint32_t ox = __shfl(hb_hi[nt].x, lane & 31, 64), oy = __shfl(hb_hi[nt].y, lane & 31, 64);                  \
+        const bool own = g < 2;                                                                                          \
+        hb_hi[nt] = own ? (uint4_t){hb_hi[nt].x, hb_hi[nt].y, hb_lo[nt].x, hb_lo[nt].y} : (uint4_t){ox, oy, 0u, 0u};      \
+    }
+#define GR_FINISH(TL) GR_FINISH_FROM(acc1, TL)
+#define GR_FINISH_FROM(SRC, TL)                                                                           \
     _Pragma("unroll") for (int nt = 0; nt < 2; nt++) {                                                    \
-        float4_t r = acc1[nt];                                                                            \
+        float4_t r = SRC[nt];                                                                             \
         r.x = gs_relu(r.x); r.y = gs_relu(r.y); r.z = gs_relu(r.z); r.w = gs_relu(r.w);                   \
         if constexpr (DOT) {                                                                              \
             const float4 uu = *reinterpret_cast<const float4*>(u_step + 16 * (TL) + 4 * g);              \
@@ -554,7 +570,9 @@ __device__ __forceinline__ void gr_step(const char* wb, int lane, int g, const u
     if constexpr (DO2) {  // second linear layer, K-step s-1: acc2[nt][t] += W2 frag(t) x relu(hidden) of the previous step
         GR_U2_LOAD(f0, 0)
         GR_SB();
-        GR_U2_LOAD(f1, 1) GR_SB(); GR_U2_MFMA(f0, 0) GR_SB();
+        GR_U2_LOAD(f1, 1) GR_SB();
+        if constexpr (PEND_IN) { GR_FINISH_FROM(pend, 1) GR_SB(); }  // the previous step's second hidden tile -> hb_*.zw, under the two requests
+        GR_U2_MFMA(f0, 0) GR_SB();
         GR_U2_LOAD(f0, 2) GR_SB(); GR_U2_MFMA(f1, 1) GR_SB();
         GR_U2_LOAD(f1, 3) GR_SB(); GR_U2_MFMA(f0, 2) GR_SB();
         GR_U2_LOAD(f0, 4) GR_SB(); GR_U2_MFMA(f1, 3) GR_SB();
@@ -571,6 +589,7 @@ __device__ __forceinline__ void gr_step(const char* wb, int lane, int g, const u
         uint4_t p[GS_T2];
 #pragma unroll
         for (int t = 0; t < GS_T2; t++) p[t] = GR_LD(GRC_W2_OFF + t * 1024);
+        if constexpr (PEND_IN) { GR_SB(); GR_FINISH_FROM(pend, 0) GR_PACK_STEP7() GR_SB(); }  // hidden tile 12 of step 6, under the seven requests
 #pragma unroll
         for (int t = 0; t < GS_T2; t++) {
             acc2[0][t] = GS_MFMA16(p[t], hb_hi[0], acc2[0][t]);
@@ -599,19 +618,15 @@ __device__ __forceinline__ void gr_step(const char* wb, int lane, int g, const u
             GR_TAIL_LOAD(f0, 1) GR_SB(); GR_U1_MFMA1(f1, 2) GR_SB();
             acc1[0] = GS_MFMA16(f0[0], in_tb[0], acc1[0]);
             acc1[1] = GS_MFMA16(f0[0], in_tb[1], acc1[1]);
-            GR_FINISH(1)
+            if constexpr (PEND_OUT) { pend[0] = acc1[0]; pend[1] = acc1[1]; }
+            else { GR_FINISH(1) }
         } else if constexpr (DOT) {
             GR_FINISH(0)
         } else {
-            GR_FINISH(0)
             // step 6: lanes g = 0 / 1 hold hidden units 192..195 / 196..199 (hi in hb_hi.xy, lo in hb_lo.xy); the packed operand of
             // step 7 is  g = 0, 1: [hi, lo] (own)   g = 2, 3: [hi of lane - 32, 0]
-#pragma unroll
-            for (int nt = 0; nt < 2; nt++) {
-                const uint32_t ox = __shfl(hb_hi[nt].x, lane & 31, 64), oy = __shfl(hb_hi[nt].y, lane & 31, 64);
-                const bool own = g < 2;
-                hb_hi[nt] = own ? (uint4_t){hb_hi[nt].x, hb_hi[nt].y, hb_lo[nt].x, hb_lo[nt].y} : (uint4_t){ox, oy, 0u, 0u};
-            }
+            if constexpr (PEND_OUT) { pend[0] = acc1[0]; pend[1] = acc1[1]; }
+            else { GR_FINISH(0) GR_PACK_STEP7() }
         }
         asm volatile("" : "+v"(vmax));
     }
@@ -619,6 +634,8 @@ __device__ __forceinline__ void gr_step(const char* wb, int lane, int g, const u
 #undef GR_TAIL_LOAD
 #undef GR_BIAS
 #undef GR_FINISH
+#undef GR_FINISH_FROM
+#undef GR_PACK_STEP7
 #undef GR_U2_LOAD
 #undef GR_U2_MFMA
 #undef GR_U1_LOAD
@@ -1182,6 +1199,7 @@ __device__ __forceinline__ void gr_layer(unsigned long long (&tacc)[6], char* bx
     uint4_t h_hi[NT], h_lo[NT];
     float oscale = 1.0f;
     float dot[NT] = {0.0f, 0.0f};
+    float4_t pend[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};  // a step's last hidden tile, finished at the top of the next step (gr_step)
     if (fold) {
         // seven steps of hidden tiles only; the next layer's table (layer 0 of the next tile) lands in bx during step 6, when bx is free
         // -- the buffers do NOT swap roles after this layer (gin_resident_kernel)
@@ -1201,8 +1219,8 @@ __device__ __forceinline__ void gr_layer(unsigned long long (&tacc)[6], char* bx
                 gr_issue_rows(h0, reinterpret_cast<char*>(s_h), nxt, c, wave, lane);
                 if (c == GS_STEPS - 2) gr_issue_rows(h0, reinterpret_cast<char*>(s_h), nxt, c + 1, wave, lane);
             }
-            if (c < GS_STEPS - 2) gr_step<4>(cb, lane, g, in_hi, in_lo, in_tb, h_hi, h_lo, acc2, vmax, s_u + 32 * c, dot);
-            else gr_step<5>(cb, lane, g, in_hi, in_lo, in_tb, h_hi, h_lo, acc2, vmax, s_u + 32 * c, dot);
+            if (c < GS_STEPS - 2) gr_step<4>(cb, lane, g, in_hi, in_lo, in_tb, h_hi, h_lo, acc2, vmax, pend, s_u + 32 * c, dot);
+            else gr_step<5>(cb, lane, g, in_hi, in_lo, in_tb, h_hi, h_lo, acc2, vmax, pend, s_u + 32 * c, dot);
             if (ENC || c + 1 < GS_STEPS - 1) {
                 unsigned long long tw = 0;
                 if constexpr (PROF) tw = wall_clock64();
@@ -1232,9 +1250,9 @@ __device__ __forceinline__ void gr_layer(unsigned long long (&tacc)[6], char* bx
         // even step: compute from by while chunk c+1 streams into bx
         grc_issue_chunk(wchunks + (size_t)(c + 1) * GRC_CHUNK_STRIDE, bx, wave, lane);
         if (last && has_next) gr_issue_rows(h0, reinterpret_cast<char*>(s_h), nxt, c, wave, lane);
-        if (c == 0) gr_step<0>(by, lane, g, in_hi, in_lo, in_tb, h_hi, h_lo, acc2, vmax);
-        else if (c == 6) gr_step<2>(by, lane, g, in_hi, in_lo, in_tb, h_hi, h_lo, acc2, vmax);
-        else gr_step<1>(by, lane, g, in_hi, in_lo, in_tb, h_hi, h_lo, acc2, vmax);
+        if (c == 0) gr_step<0, false, GR_DEFER>(by, lane, g, in_hi, in_lo, in_tb, h_hi, h_lo, acc2, vmax, pend);
+        else if (c == 6) gr_step<2, GR_DEFER, GR_DEFER>(by, lane, g, in_hi, in_lo, in_tb, h_hi, h_lo, acc2, vmax, pend);
+        else gr_step<1, GR_DEFER, GR_DEFER>(by, lane, g, in_hi, in_lo, in_tb, h_hi, h_lo, acc2, vmax, pend);
         unsigned long long tw = 0;
         if constexpr (PROF) tw = wall_clock64();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of chunk c+1 (and of the next tile) have landed
@@ -1245,8 +1263,8 @@ __device__ __forceinline__ void gr_layer(unsigned long long (&tacc)[6], char* bx
         if (c + 2 < GS_STEPS) grc_issue_chunk(wchunks + (size_t)(c + 2) * GRC_CHUNK_STRIDE, by, wave, lane);
         else gr_issue_ecomb(ecomb_all + (size_t)ln * EDGE_COMBOS * GS_D, by, wave, lane);
         if (last && has_next) gr_issue_rows(h0, reinterpret_cast<char*>(s_h), nxt, c + 1, wave, lane);
-        if (c == 6) gr_step<3>(bx, lane, g, in_hi, in_lo, in_tb, h_hi, h_lo, acc2, vmax);
-        else gr_step<1>(bx, lane, g, in_hi, in_lo, in_tb, h_hi, h_lo, acc2, vmax);
+        if (c == 6) gr_step<3, GR_DEFER, false>(bx, lane, g, in_hi, in_lo, in_tb, h_hi, h_lo, acc2, vmax, pend);
+        else gr_step<1, GR_DEFER, GR_DEFER>(bx, lane, g, in_hi, in_lo, in_tb, h_hi, h_lo, acc2, vmax, pend);
         if (c + 2 < GS_STEPS) {
             if constexpr (PROF) tw = wall_clock64();
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

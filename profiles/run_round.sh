@@ -11,10 +11,10 @@ TAG=${1:-r02}; shift || true
 MODELS=${@:-GIN GIN-VN GCN GAT PNA DGN}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out; mkdir -p $OUT
-STEPS=5; WARM=2
+STEPS=10; WARM=8
 cd /tmp && export TMPDIR=/tmp
 for M in $MODELS; do
-  python $R/bench.py --model $M --steps 10 --warmup 2 --configs off > $OUT/${TAG}_bench_$M.json 2> $OUT/${TAG}_bench_$M.err
+  python $R/bench.py --model $M --steps 20 --warmup 8 --configs off > $OUT/${TAG}_bench_$M.json 2> $OUT/${TAG}_bench_$M.err
   rocprofv3 --kernel-trace --output-format csv -d $OUT/${TAG}_${M}_kt -o kt -- python $R/bench.py --model $M --steps $STEPS --warmup $WARM --no-cpu-baseline --configs off > $OUT/${TAG}_${M}_kt.log 2>&1
   f=$(find $OUT/${TAG}_${M}_kt -name '*kernel_trace.csv' | head -1)
   [ -n "$f" ] && python $R/profiles/summarize.py stats $f $STEPS $WARM > $OUT/${TAG}_${M}_kernel_trace_summary.txt
