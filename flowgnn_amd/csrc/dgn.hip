@@ -380,11 +380,16 @@ __global__ __launch_bounds__(512, 2) void dgn_layer_fused_kernel(const float* __
 constexpr int DGN_HT_STRIDE = 136;                           // f16 per feature row of s_ht (128 sources + 8: 68 banks, conflict-free)
 constexpr int DGN_HT_BYTES = DGN_D * DGN_HT_STRIDE * 2;      // 27 200 per half (hi | lo)
 
+// INFO: what a row's in-edge pass produces -- this lane's adjacency mask, wsum, abssum, the duplicate count -- depends on the graph and
+// the eigenvector only, not on the layer: the first layer's launch (INFO 1) stores it, 32 B per row, the later ones (INFO 2) load it
+// (requested a tile ahead) instead of walking the row's in-edges again (0.10-0.12 ms per launch).  INFO 0: neither.
+template <int INFO>
 __global__ __launch_bounds__(512, 2) void dgn_layer_mfma_kernel(const float* __restrict__ h, float* __restrict__ hout,
                                                                  const int* __restrict__ row_ptr, const int* __restrict__ src,
                                                                  const int* __restrict__ out_deg, const float* __restrict__ eig4,
                                                                  const uint8_t* __restrict__ wpk, const int* __restrict__ tile_row,
-                                                                 int n_tiles, int* __restrict__ range_flag, int ablate_arg) {
+                                                                 int n_tiles, int* __restrict__ range_flag, int ablate_arg,
+                                                                 uint32_t* __restrict__ rowinfo /* [n_tot][8] */) {
     const int ablate = FG_ABLATE(ablate_arg);  // development aid (dgn_ablate, -DFLOWGNN_DEV builds): 1 no aggregation MFMAs, 2 no dense
     (void)ablate_arg;                          // MFMAs, 4 no transposing stores of the next tile, 8 no in-edge pass, 16 no h[v] loads
     constexpr int OFF_W = 2 * DGN_HT_BYTES, OFF_SRC = OFF_W + (int)DGN_FT_LAYER_BYTES, OFF_RP = OFF_SRC + DGN_FT_EDGES,
@@ -440,12 +445,23 @@ __global__ __launch_bounds__(512, 2) void dgn_layer_mfma_kernel(const float* __r
             put_row_piece(c, hb[c < DGN_C ? c : 0], lr < rows);
         }
     }
-    for (int i = tid; i < ne; i += 512) s_src[i] = (uint8_t)((src[e0 + i] - t0) & 127);
-    if (tid <= rows) { const int o = row_ptr[t0 + tid] - e0; s_rp[tid] = (uint16_t)(o < 0 ? 0 : (o > ne ? ne : o)); }
+    constexpr bool STAGE_CSR = INFO != 2;  // INFO 2 never walks a row's in-edges (the rare duplicate edges: from global memory)
+    if constexpr (STAGE_CSR) {
+        for (int i = tid; i < ne; i += 512) s_src[i] = (uint8_t)((src[e0 + i] - t0) & 127);
+        if (tid <= rows) { const int o = row_ptr[t0 + tid] - e0; s_rp[tid] = (uint16_t)(o < 0 ? 0 : (o > ne ? ne : o)); }
+    }
     if (tid < DGN_FT_ROWS) put_eig(tid, eig4[(size_t)(t0 + (tid < rows ? tid : 0)) * 4 + 1], tid < rows);
     __syncthreads();
     const float oscale = *reinterpret_cast<const float*>(s_w + DGN_FT_BIAS + 112 * 4);
     float vmax = 0.0f;
+    uint32_t cur_bits = 0;
+    uint4 cur_info = make_uint4(0u, 0u, 0u, 0u);
+    if constexpr (INFO == 2) {  // the first tile's stored pass results (later tiles': requested a tile ahead, below)
+        const int r1 = wave * 16 + j;
+        const size_t n1 = (size_t)t0 + (r1 < rows ? r1 : 0);
+        cur_bits = rowinfo[n1 * 8 + g];
+        cur_info = *reinterpret_cast<const uint4*>(rowinfo + n1 * 8 + 4);
+    }
     while (true) {
         const int ntile = tile + gridDim.x;
         const bool has_next = ntile < n_tiles;
@@ -465,16 +481,23 @@ __global__ __launch_bounds__(512, 2) void dgn_layer_mfma_kernel(const float* __r
                      nr6 = nb[DGN_NC(6)];
 #undef DGN_NC
         const int elast = nne > 0 ? nne - 1 : 0;
-#define DGN_NXE(P) (nne > 0 ? src[ne0 + ((tid + 512 * (P)) < elast ? (tid + 512 * (P)) : elast)] : 0)
+#define DGN_NXE(P) ((STAGE_CSR && nne > 0) ? src[ne0 + ((tid + 512 * (P)) < elast ? (tid + 512 * (P)) : elast)] : 0)
         const int ns0 = DGN_NXE(0), ns1 = DGN_NXE(1), ns2 = DGN_NXE(2), ns3 = DGN_NXE(3), ns4 = DGN_NXE(4);
 #undef DGN_NXE
-        const int nx_rp = row_ptr[nt0 + (tid <= nrows ? tid : nrows)];
+        const int nx_rp = STAGE_CSR ? row_ptr[nt0 + (tid <= nrows ? tid : nrows)] : 0;
         const float nx_eig = eig4[(size_t)(nt0 + (tid < nrows ? tid : 0)) * 4 + 1];
         // ---- this wave's 16 rows
         const int r = wave * 16 + j;
         const bool valid = r < rows;
-        const int e_base = valid ? (int)s_rp[r] : 0;
-        const int indeg = (valid && !(ablate & 8)) ? (int)s_rp[r + 1] - e_base : 0;
+        uint32_t nx_bits = 0;
+        uint4 nx_info = make_uint4(0u, 0u, 0u, 0u);
+        if constexpr (INFO == 2) {  // the stored pass results of this lane's row in the NEXT tile
+            const size_t nn = (size_t)nt0 + (r < nrows ? r : 0);
+            nx_bits = rowinfo[nn * 8 + g];
+            nx_info = *reinterpret_cast<const uint4*>(rowinfo + nn * 8 + 4);
+        }
+        const int e_base = (STAGE_CSR && valid) ? (int)s_rp[r] : 0;
+        const int indeg = (STAGE_CSR && valid && !(ablate & 8)) ? (int)s_rp[r + 1] - e_base : 0;
         const float eig_v = s_eig[valid ? r : 0];
         const long long node = (long long)t0 + (valid ? r : 0);
         const int odeg = out_deg[node];
@@ -483,7 +506,12 @@ __global__ __launch_bounds__(512, 2) void dgn_layer_mfma_kernel(const float* __r
         float wsum = 0.0f, abssum = 0.0f;
         uint32_t bits = 0;
         int ndup = 0;
-        {
+        if constexpr (INFO == 2) {
+            bits = valid ? cur_bits : 0u;
+            wsum = valid ? __builtin_bit_cast(float, cur_info.x) : 0.0f;
+            abssum = valid ? __builtin_bit_cast(float, cur_info.y) : 0.0f;
+            ndup = valid ? (int)cur_info.z : 0;
+        } else {
             // the first 16 in-edges (kNN rows have exactly 16) as two batches of independent LDS reads -- source bytes, then their
             // eigenvector entries: two round trips instead of 32 dependent ones
             int us[16];
@@ -514,6 +542,13 @@ __global__ __launch_bounds__(512, 2) void dgn_layer_mfma_kernel(const float* __r
                     ndup += (u == prev);
                     prev = u;
                 }
+            if constexpr (INFO == 1) {
+                if (valid) {
+                    rowinfo[(size_t)node * 8 + g] = bits;
+                    if (g == 0) *reinterpret_cast<uint4*>(rowinfo + (size_t)node * 8 + 4) =
+                        make_uint4(__builtin_bit_cast(uint32_t, wsum), __builtin_bit_cast(uint32_t, abssum), (uint32_t)ndup, 0u);
+                }
+            }
         }
         const float inv_abs = 1.0f / (abssum == 0.0f ? 1.0f / 8192.0f : abssum);  // epsilon of ap_fixed<16,3> (node_embedding.cc:125-128)
         const float inv_dg = odeg == 0 ? 0.0f : 1.0f / (float)odeg;
@@ -571,9 +606,11 @@ __global__ __launch_bounds__(512, 2) void dgn_layer_mfma_kernel(const float* __r
             }
             if (dups) {  // multiplicity > 1: the extra copies of a duplicate edge, from the split rows (hi + lo)
                 int prev = -1;
-                for (int e = 0; __any(e < indeg); e++)
-                    if (e < indeg) {
-                        const int u = s_src[e_base + e];
+                const int gb = (!STAGE_CSR && valid) ? row_ptr[node] : 0;             // INFO 2: the row's in-edges straight from the CSR
+                const int cnt = STAGE_CSR ? indeg : ((valid && ndup > 0) ? row_ptr[node + 1] - gb : 0);
+                for (int e = 0; __any(e < cnt); e++)
+                    if (e < cnt) {
+                        const int u = STAGE_CSR ? (int)s_src[e_base + e] : ((src[gb + e] - t0) & 127);
                         if (u == prev && real) {
                             const float eu = s_eig[u];
 #pragma unroll
@@ -643,13 +680,14 @@ __global__ __launch_bounds__(512, 2) void dgn_layer_mfma_kernel(const float* __r
         put_row_piece(12 + cg, nr3, lr < nrows); put_row_piece(16 + cg, nr4, lr < nrows); put_row_piece(20 + cg, nr5, lr < nrows);
         put_row_piece(24 + cg, nr6, lr < nrows);
         } else { s_ht_hi[tid] = (uint16_t)(nr0.x + nr1.x + nr2.x + nr3.x + nr4.x + nr5.x + nr6.x); }
-#define DGN_PUTE(P, V) if (tid + 512 * (P) < nne) s_src[tid + 512 * (P)] = (uint8_t)(((V) - nt0) & 127);
+#define DGN_PUTE(P, V) if (STAGE_CSR && tid + 512 * (P) < nne) s_src[tid + 512 * (P)] = (uint8_t)(((V) - nt0) & 127);
         DGN_PUTE(0, ns0) DGN_PUTE(1, ns1) DGN_PUTE(2, ns2) DGN_PUTE(3, ns3) DGN_PUTE(4, ns4)
 #undef DGN_PUTE
-        if (tid <= nrows) { const int o = nx_rp - ne0; s_rp[tid] = (uint16_t)(o < 0 ? 0 : (o > nne ? nne : o)); }
+        if (STAGE_CSR && tid <= nrows) { const int o = nx_rp - ne0; s_rp[tid] = (uint16_t)(o < 0 ? 0 : (o > nne ? nne : o)); }
         if (tid < DGN_FT_ROWS) put_eig(tid, nx_eig, tid < nrows);
         __syncthreads();
         tile = ntile; t0 = nt0; rows = nrows; e0 = ne0; ne = nne;
+        cur_bits = nx_bits; cur_info = nx_info;
     }
     if (__any(!(vmax < 6.0e4f))) {
         if (lane == 0) atomicOr(range_flag, 1);
@@ -836,9 +874,15 @@ public:
                 // tile's adjacency; sparse ones (molecules, ~2 in-edges per row): the in-edge walk is cheaper than 20 MFMAs per K-step
                 const bool mfma_agg = mfma_agg_ < 0 ? (double)db.b.e_tot >= 8.0 * (double)n : mfma_agg_ != 0;
                 if (mfma_agg) {
-                    dgn_layer_mfma_kernel<<<grid, 512, 0, s>>>(db.h[cur], db.h[cur ^ 1], db.csr.row_ptr, db.csr.src, db.csr.out_deg, db.node_eigen,
-                                                               d_fused_ + (size_t)l * DGN_FT_LAYER_BYTES, db.gtiles.row_start, db.gtiles.n_tiles,
-                                                               db.range_flag, ablate_);
+                    if (int rc = rowinfo_.reserve((size_t)n * 8)) return rc;
+                    uint32_t* ri = reinterpret_cast<uint32_t*>(rowinfo_.p);
+#define DGN_MFMA_LAUNCH(I)                                                                                                                    \
+    dgn_layer_mfma_kernel<I><<<grid, 512, 0, s>>>(db.h[cur], db.h[cur ^ 1], db.csr.row_ptr, db.csr.src, db.csr.out_deg, db.node_eigen,          \
+                                                  d_fused_ + (size_t)l * DGN_FT_LAYER_BYTES, db.gtiles.row_start, db.gtiles.n_tiles, db.range_flag, \
+                                                  ablate_, ri)
+                    // the first layer stores what its in-edge pass found per row (adjacency mask, wsum, abssum), the others load it
+                    if (l == 0) DGN_MFMA_LAUNCH(1); else DGN_MFMA_LAUNCH(2);
+#undef DGN_MFMA_LAUNCH
                     cur ^= 1;
                     continue;
                 }
@@ -904,6 +948,7 @@ private:
             if (*p) { (void)hipFree(*p); *p = nullptr; }
         esc_.release();
         tiles_.release();
+        rowinfo_.release();
         q_.release();
         if (d_split_) { (void)hipFree(d_split_); d_split_ = nullptr; }
         if (d_fused_) { (void)hipFree(d_fused_); d_fused_ = nullptr; }
@@ -917,6 +962,7 @@ private:
     bool split_ = true;
     // dgn_fused=0 keeps aggregation and dense update as two kernels per layer (A/B measurements, the aggregation roofline probe)
     bool agg_ready_ = false;  // tiles_ / esc_ describe the batch of the last forward
+    GrowBufI rowinfo_;   // dgn_layer_mfma_kernel: 32 B per row of layer-independent in-edge pass results
     int mfma_agg_ = -1;  // dgn_mfma_agg: 1 = aggregation on the matrix pipe (dgn_layer_mfma_kernel), 0 = in-edge walk, -1 = by density
     int ablate_ = 0;  // development aid (-DFLOWGNN_DEV builds only, option dgn_ablate): per-phase timing (scripts/dev/pna_ablate.sh)
     bool fused_ = true;

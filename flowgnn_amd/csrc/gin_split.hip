@@ -500,6 +500,9 @@ __device__ __forceinline__ void grc_issue_chunk_w1(const uint8_t* __restrict__ g
 #ifndef GR_DEFER
 #define GR_DEFER false
 #endif
+#ifndef GR_PRIO_BY_PHASE
+#define GR_PRIO_BY_PHASE true
+#endif
 
 // One step of the node MLP for TWO column tiles per wave.  The work is a chain of "units" -- two fragments (hi, lo of one
 // 16-row weight tile and one K-step) feeding six MFMAs (w_hi x_hi, w_hi x_lo, w_lo x_hi for both column tiles) -- and the
@@ -1016,6 +1019,12 @@ __device__ __forceinline__ void gr_layer(unsigned long long (&tacc)[6], char* bx
     const int ln = last ? 0 : l + 1;  // the layer whose table is prefetched during step 7 (the next tile starts at layer 0)
     unsigned long long tp = 0;
     if constexpr (PROF) tp = wall_clock64();
+    // Static priority for the second-dispatched half (waves 4-7) pays in the MLP (they lose every arbitration otherwise), but in the
+    // gather it makes their SIMD partners (waves 0-3) the phase's stragglers -- 2 331 us against 1 799 per wave by phase stamps, and
+    // the phase ends with its slowest wave: equal priority while gathering, raised again behind the gather's barrier (then age
+    // decides and waves 4-7 trail by less: 2 305 against 1 959; launch 8.70 -> 8.60 ms.  Priorities alternating trip by trip even the
+    // halves out but cost more than they return: 8.69 ms).
+    if (GR_PRIO_BY_PHASE) __builtin_amdgcn_s_setprio(0);
     if (fold) grc_issue_chunk_w1(wchunks, by, wave, lane);
     else grc_issue_chunk(wchunks, by, wave, lane);  // chunk 0: lands under the gather
     // ENC (the tile loader computes h_0 itself): the next tile's rows are encoded during this layer's MLP steps, a part per step;
@@ -1189,6 +1198,7 @@ __device__ __forceinline__ void gr_layer(unsigned long long (&tacc)[6], char* bx
     if constexpr (PROF) { const unsigned long long t = wall_clock64(); tacc[0] += t - tp; tp = t; }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of chunk 0
     __syncthreads();  // chunk 0 resident; every wave is done with the table (bx), with the tile's rows and with its CSR slice
+    if (GR_PRIO_BY_PHASE && wave >= 4) __builtin_amdgcn_s_setprio(1);
     if constexpr (PROF) { const unsigned long long t = wall_clock64(); tacc[1] += t - tp; tp = t; }
 
     // last layer: the rows and the descriptor of this tile are dead -- bring in the next tile's (rows: an eighth per MLP step)
@@ -2193,6 +2203,15 @@ void launch_gin_resident(const float* h0, float* hout, const int* row_ptr, const
         const double nw = (double)grid * GR_WAVES;
         fprintf(stderr, "[gin_resident prof] tiles %d grid %d | per wave, us: gather %.1f  wait+barrier %.1f  mlp %.1f (of which step-end DMA wait %.1f, barrier %.1f)  epilogue+barrier %.1f  kernel %.1f\n",
                 n_tiles, grid, tot[0] / nw / 100.0, tot[1] / nw / 100.0, tot[2] / nw / 100.0, tot[5] / nw / 100.0, tot[4] / nw / 100.0, tot[3] / nw / 100.0, tot[6] / nw / 100.0);
+        {   // the same by wave index (0..7: which of the eight waves of a workgroup), gather and the wait behind it
+            double gw[GR_WAVES] = {0}, ww[GR_WAVES] = {0};
+            for (size_t i = 0; i < cnt; i += 7) { const int wi = (int)((i / 7) % GR_WAVES); gw[wi] += (double)hbuf[i]; ww[wi] += (double)hbuf[i + 1]; }
+            fprintf(stderr, "[gin_resident prof] by wave index, us: gather");
+            for (int wi = 0; wi < GR_WAVES; wi++) fprintf(stderr, " %.0f", gw[wi] / grid / 100.0);
+            fprintf(stderr, " | wait behind it");
+            for (int wi = 0; wi < GR_WAVES; wi++) fprintf(stderr, " %.0f", ww[wi] / grid / 100.0);
+            fprintf(stderr, "\n");
+        }
     }
 }
 
