@@ -473,21 +473,32 @@ constexpr int GRC_W2_OFF = 13440;
 constexpr int GRC_CHUNK_BYTES = 27776;
 constexpr int GRC_CHUNK_STRIDE = 28672;  // 28 pieces of 1 KiB in global memory (the last one: 128 B = 8 lanes)
 
+// GR_DEALERS: how many of the workgroup's eight waves issue the LDS-DMA of the weight / table / row streams.  An LDS-DMA instruction
+// costs its wave 100-150 cycles of issue; with all eight dealing, both waves of every SIMD stall on their pieces at the top of a
+// step and the matrix pipe idles; with waves 0-3 dealing (one per SIMD, the half WITHOUT the static priority), each SIMD's other
+// wave multiplies meanwhile.
+#ifndef GR_DEALERS
+#define GR_DEALERS 4
+#endif
+template <int DEAL = GR_DEALERS>
 __device__ __forceinline__ void grc_issue_chunk(const uint8_t* __restrict__ gchunk, char* lds_buf, int wave, int lane) {
+    if (wave >= DEAL) return;
     const uint32_t lb = lds_addr_of(lds_buf);
 #pragma unroll
-    for (int p = 0; p < 4; p++) {
-        const int piece = wave + 8 * p;  // 27 full pieces + 128 B
+    for (int p = 0; p < (28 + DEAL - 1) / DEAL; p++) {
+        const int piece = wave + DEAL * p;  // 27 full pieces + 128 B
         if (piece < 27 || (piece == 27 && lane < 8)) lds_dma16(gchunk + piece * 1024, (uint32_t)lane * 16u, lb + piece * 1024);
     }
 }
 
 // first-layer part of a chunk only (W1 fragments, K-tail, b1: 13 440 B = 13 pieces + 128 B): all the folded last layer reads
+template <int DEAL = GR_DEALERS>
 __device__ __forceinline__ void grc_issue_chunk_w1(const uint8_t* __restrict__ gchunk, char* lds_buf, int wave, int lane) {
+    if (wave >= DEAL) return;
     const uint32_t lb = lds_addr_of(lds_buf);
 #pragma unroll
-    for (int p = 0; p < 2; p++) {
-        const int piece = wave + 8 * p;
+    for (int p = 0; p < (14 + DEAL - 1) / DEAL; p++) {
+        const int piece = wave + DEAL * p;
         if (piece < 13 || (piece == 13 && lane < 8)) lds_dma16(gchunk + piece * 1024, (uint32_t)lane * 16u, lb + piece * 1024);
     }
 }
@@ -649,19 +660,21 @@ __device__ __forceinline__ void gr_step(const char* wb, int lane, int g, const u
 struct GrTile { int t0, rows, g0, g1; };
 
 __device__ __forceinline__ void gr_issue_ecomb(const float* __restrict__ ecomb, char* lds_buf, int wave, int lane) {
+    if (wave >= GR_DEALERS) return;
 #pragma unroll
-    for (int r = 0; r < 3; r++) {
-        const int piece = wave + GR_WAVES * r;
+    for (int r = 0; r < (24 + GR_DEALERS - 1) / GR_DEALERS; r++) {
+        const int piece = wave + GR_DEALERS * r;
         if (piece < 23 || (piece == 23 && lane < 28)) lds_dma16(reinterpret_cast<const char*>(ecomb) + piece * 1024, (uint32_t)lane * 16u, lds_addr_of(lds_buf) + piece * 1024);
     }
 }
 // pieces [13 part, 13 part + 13) of the tile's rows (<= 100 pieces of 1 KiB; a piece may run past the tile's last row: the
 // rows array has 4 KiB of slack and the surplus lands in unused rows of the buffer)
 __device__ __forceinline__ void gr_issue_rows(const float* __restrict__ h0, char* s_rows, const GrTile& t, int part, int wave, int lane) {
+    if (wave >= GR_DEALERS) return;
     const int np = (t.rows * (GS_D * 4) + 1023) >> 10;
 #pragma unroll
-    for (int r = 0; r < 2; r++) {
-        const int piece = 13 * part + wave + GR_WAVES * r;
+    for (int r = 0; r < (13 + GR_DEALERS - 1) / GR_DEALERS; r++) {
+        const int piece = 13 * part + wave + GR_DEALERS * r;
         if (piece < 13 * part + 13 && piece < np)
             lds_dma16(reinterpret_cast<const char*>(h0) + (size_t)t.t0 * (GS_D * 4) + (size_t)piece * 1024, (uint32_t)lane * 16u, lds_addr_of(s_rows) + piece * 1024);
     }
@@ -1025,8 +1038,8 @@ __device__ __forceinline__ void gr_layer(unsigned long long (&tacc)[6], char* bx
     // decides and waves 4-7 trail by less: 2 305 against 1 959; launch 8.70 -> 8.60 ms.  Priorities alternating trip by trip even the
     // halves out but cost more than they return: 8.69 ms).
     if (GR_PRIO_BY_PHASE) __builtin_amdgcn_s_setprio(0);
-    if (fold) grc_issue_chunk_w1(wchunks, by, wave, lane);
-    else grc_issue_chunk(wchunks, by, wave, lane);  // chunk 0: lands under the gather
+    if (fold) grc_issue_chunk_w1<8>(wchunks, by, wave, lane);
+    else grc_issue_chunk<8>(wchunks, by, wave, lane);  // chunk 0: lands under the gather (dealt by all eight waves: nobody multiplies now)
     // ENC (the tile loader computes h_0 itself): the next tile's rows are encoded during this layer's MLP steps, a part per step;
     // the table-row numbers of part 0 are requested here, a whole gather ahead of their use
     GrEncIdx enc_ix{};
