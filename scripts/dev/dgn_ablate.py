@@ -7,7 +7,7 @@ from flowgnn_amd import Engine, weights
 model = sys.argv[1] if len(sys.argv) > 1 else "DGN"
 b = bench.make_batch("hep10k", 1 << 15, 1234)
 w = weights.SYNTH[model](seed=7)
-for ab in [0, 1, 2, 3, 4, 8, 16, 31] + ([] if model == "DGN" else []):
+for ab in ([0, 1, 2, 3, 4, 8, 16, 31] if model == "DGN" else [0, 1, 2, 3, 4, 5, 7]):
     e = Engine(model, 0, options={model.lower() + "_ablate": ab})
     e.set_weights(w); e.set_batch(b)
     for _ in range(2): e.run()
