@@ -431,6 +431,8 @@ def main():
     ap.add_argument("--configs", default="auto", choices=["auto", "on", "off"],
                     help="also measure the other BASELINE configs (GIN at dataset size, GIN-VN, GCN, GAT, PNA, DGN) in the same run and "
                          "report them in a compact `configs` object; auto = on for the default single-GPU GIN run")
+    ap.add_argument("--inject-parity-failure", action="store_true",
+                    help="test hook: perturb the GPU logits before they are compared with the oracle (the run must then exit with code 3)")
     ap.add_argument("--numeric", default="f32", choices=["f32", "q6.10"],
                     help="q6.10: the reference's ap_fixed<16,6> bit-faithful mode (a fidelity mode, ~10x slower)")
     args = ap.parse_args()
@@ -519,6 +521,7 @@ def main():
     if int(logits_all.shape[0]) != total_job_graphs:
         raise SystemExit(f"result concat has {int(logits_all.shape[0])} graphs, the job has {total_job_graphs}")
 
+    exit_code = 0
     if rank == 0:
         value = total_job_graphs * args.steps / elapsed
         kern = {k: (v["total_ms"] / max(v["launches"], 1)) for k, v in prof.items()}
@@ -558,6 +561,8 @@ def main():
         else:  # no timed CPU leg: still check a slice of rank 0's shard of the timed batch against the oracle
             n = min(G, 4096)
             want = np.asarray(oracle_forward(args.model, batch.slice(0, n), w, effective_cpus(), args.numeric), np.float32)
+        if args.inject_parity_failure:
+            out_local = out_local + np.float32(1.0)
         line["parity"] = parity_record(args.model, out_local[: want.shape[0]], want, args.numeric)
         parity_ok = bool(line["parity"]["ok"])
         do_configs = args.configs == "on" or (args.configs == "auto" and world == 1 and args.model == "GIN" and not args.graphs and not qmode)
@@ -584,14 +589,14 @@ def main():
         print(json.dumps(line), flush=True)
         if not parity_ok:
             sys.stderr.write("bench.py: PARITY FAILURE against the oracle -- the throughput above is not a valid measurement\n")
-            if eng is not None:
-                eng.close()
-            sys.exit(3)
+            exit_code = 3
     if eng is not None:
         eng.close()
-    if world > 1:
+    if world > 1:  # (rank 0 leaves through the same barrier as the others even when it is about to report a failure)
         dist.barrier()
         dist.destroy_process_group()
+    if exit_code:
+        sys.exit(exit_code)
 
 
 if __name__ == "__main__":

@@ -81,3 +81,20 @@ def test_usage_and_unknown_experiment(tmp_path):
     assert r.returncode != 0 and "Unknown dataset or model" in r.stderr
     r = run(tmp_path, "molhiv:GIN")  # known names, but no archive and nothing unpacked
     assert r.returncode != 0 and "molhiv.zip" in r.stderr
+
+
+@pytest.mark.gpu
+def test_bench_exits_with_code_3_on_a_parity_failure():
+    """bench.py prints its line and exits with code 3 when the GPU logits of the timed batch disagree with the oracle:
+    a wrong-answer run must not hand anyone a throughput number with rc 0."""
+    import json
+    import sys
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--graphs", "96", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--configs", "off"]
+    ok = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert ok.returncode == 0, ok.stderr[-2000:]
+    line = json.loads(ok.stdout.strip().splitlines()[-1])
+    assert line["parity"]["ok"] is True and line["roofline"]["kernel"] == "gin_resident"
+    bad = subprocess.run(cmd + ["--inject-parity-failure"], capture_output=True, text=True, timeout=600)
+    assert bad.returncode == 3, (bad.returncode, bad.stderr[-2000:])
+    assert json.loads(bad.stdout.strip().splitlines()[-1])["parity"]["ok"] is False
+    assert "PARITY FAILURE" in bad.stderr
