@@ -10,6 +10,7 @@ static __constant__ int c_nd_off[ND_FEATURE] = {0, 119, 123, 135, 147, 157, 163,
 static __constant__ int c_nd_card[ND_FEATURE] = {119, 4, 12, 12, 10, 6, 6, 2, 2};            // host_load.cc:5
 
 typedef float float4_t __attribute__((ext_vector_type(4)));
+typedef float float2_t __attribute__((ext_vector_type(2)));
 
 // A global load that hipcc's wait-count tracking does not see: issued and waited for inside one asm statement.
 // For RARE fall-back paths inside hot loops -- an ordinary load in a branch makes the compiler put an unconditional

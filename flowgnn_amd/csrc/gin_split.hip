@@ -699,6 +699,7 @@ __device__ __forceinline__ GrTile gr_load_tile(const int* __restrict__ tile_row,
 constexpr int GR_DESC_RP = GR_EDGES * 2;
 constexpr int GR_DESC_PERM = GR_DESC_RP + 528;
 constexpr int GR_DESC_BYTES = 3584;  // 3.5 pieces of 1 KiB
+constexpr unsigned GR_NO_EDGE = (unsigned)GR_ROWS << 6;  // edge word of "no in-edge left": source row GR_ROWS (all -1e30), code 0
 constexpr int GR_HUB_DEG = 8;        // HUBS kernels: rows with more in-edges than this are walked by their whole 16-lane group
 
 // Column owner table: which row of the tile each MFMA column (wave, column tile, lane) owns.  The gather walks the in-edges of
@@ -1067,63 +1068,100 @@ __device__ __forceinline__ void gr_layer(unsigned long long (&tacc)[6], char* bx
             if (e_end[nt] - e_cur[nt] > GR_HUB_DEG) e_end[nt] = e_cur[nt];
             else hub_end[nt] = hub_beg[nt];
         }
-#pragma unroll
-        for (int k = 0; k < 25; k++) bq[nt][k] = 0.0f;
     }
 #pragma unroll
-    for (int nt = 0; nt < NT; nt++) wd[nt] = s_edge[e_cur[nt] < e_end[nt] ? e_cur[nt] : 0];
+    for (int nt = 0; nt < NT; nt++) wd[nt] = e_cur[nt] < e_end[nt] ? (unsigned)s_edge[e_cur[nt]] : GR_NO_EDGE;
     const float* s_ecomb = reinterpret_cast<const float*>(bx);
-    // Both column tiles' LDS reads of a trip are requested BEFORE either is folded (the per-lane guards below keep hipcc from doing
-    // that itself: it emits read -> wait -> fold once per column tile, two exposed LDS round trips per trip instead of one): the
-    // second tile's 14 reads are in flight while the first one's 75 VALU instructions issue.  Same sums, same order.
-    while (true) {
-        const bool a0 = e_cur[0] < e_end[0], a1 = e_cur[1] < e_end[1];
-        const bool any0 = __any(a0), any1 = __any(a1);
-        if (!(any0 || any1)) break;
-        float4 x0[6], w0[6], x1[6], w1[6];
-        float xt0 = 0.f, wt0 = 0.f, xt1 = 0.f, wt1 = 0.f;
-        if (any0) {  // wave-uniform: a column tile whose 16 rows are all done costs nothing
-            const unsigned u = wd[0] >> 6, code = wd[0] & 63u;
-            const float* hr = s_h + u * GS_D + 4 * g;
-            const float* er = s_ecomb + code * GS_D + 4 * g;
+    // A lane whose row has no in-edge left walks the NO-EDGE word: source row GR_ROWS of the tile (-1e30 in every feature, written
+    // once per workgroup), so its message is relu(-1e30 + e) = +0 and the accumulation needs no per-lane guard.  (With the guard,
+    // `if (lane active) bq += ...`, hipcc keeps two copies of the 25 accumulators and moves them back and forth: 54 v_mov per trip
+    // beside the 48 packed adds and 50 max that are the work.)  Adding +0 leaves every sum's bits as they were.
+    // Trip counts are wave-uniform and known up front (the column tile's largest in-degree), so the walk is three branch-free
+    // loops -- both column tiles, then whichever one has rows left -- and in the first both tiles' LDS reads of a trip are requested
+    // BEFORE either is folded: the second tile's 14 reads are in flight while the first one's VALU instructions issue.  (A single
+    // `while (any lane active)` loop with per-tile guards costs the same moves again: the accumulators become loop phis that hipcc
+    // copies on every path.)  Same sums, same order.
+    int trips[NT];
 #pragma unroll
-            for (int q = 0; q < 6; q++) { x0[q] = *reinterpret_cast<const float4*>(hr + 16 * q); w0[q] = *reinterpret_cast<const float4*>(er + 16 * q); }
-            xt0 = s_h[u * GS_D + 96 + g];
-            wt0 = s_ecomb[code * GS_D + 96 + g];
-        }
-        if (any1) {
-            const unsigned u = wd[1] >> 6, code = wd[1] & 63u;
-            const float* hr = s_h + u * GS_D + 4 * g;
-            const float* er = s_ecomb + code * GS_D + 4 * g;
+    for (int nt = 0; nt < NT; nt++) {
+        int d = e_end[nt] - e_cur[nt];
 #pragma unroll
-            for (int q = 0; q < 6; q++) { x1[q] = *reinterpret_cast<const float4*>(hr + 16 * q); w1[q] = *reinterpret_cast<const float4*>(er + 16 * q); }
-            xt1 = s_h[u * GS_D + 96 + g];
-            wt1 = s_ecomb[code * GS_D + 96 + g];
-        }
-        if (a0) {
-            e_cur[0]++;
-            if (e_cur[0] < e_end[0]) wd[0] = s_edge[e_cur[0]];
+        for (int m = 1; m < 64; m <<= 1) d = max(d, __shfl_xor(d, m, 64));
+        trips[nt] = __builtin_amdgcn_readfirstlane(d);
+    }
+#define GR_READ(NTI, X, W, XT, WT)                                                                                                \
+    {                                                                                                                             \
+        const unsigned u = wd[NTI] >> 6, code = wd[NTI] & 63u;                                                                    \
+        const float* hr = s_h + u * GS_D + 4 * g;                                                                                 \
+        const float* er = s_ecomb + code * GS_D + 4 * g;                                                                          \
+        _Pragma("unroll") for (int q = 0; q < 6; q++) {                                                                           \
+            X[q] = *reinterpret_cast<const float4_t*>(hr + 16 * q);                                                               \
+            W[q] = *reinterpret_cast<const float4_t*>(er + 16 * q);                                                               \
+        }                                                                                                                         \
+        XT = s_h[u * GS_D + 96 + g];                                                                                              \
+        WT = s_ecomb[code * GS_D + 96 + g];                                                                                       \
+    }
+#define GR_NEXT(NTI)                                                                                                              \
+    {                                                                                                                             \
+        e_cur[NTI]++;                                                                                                             \
+        const bool more = e_cur[NTI] < e_end[NTI];                                                                                \
+        const unsigned nw = s_edge[more ? e_cur[NTI] : 0];                                                                        \
+        wd[NTI] = more ? nw : GR_NO_EDGE;                                                                                         \
+    }
+#define GR_FOLD(NTI, X, W, XT, WT)                                                                                                \
+    {                                                                                                                             \
+        _Pragma("unroll") for (int q = 0; q < 6; q++) {                                                                           \
+            const float2_t a = __builtin_elementwise_max(W[q].lo + X[q].lo, (float2_t){0.0f, 0.0f});                              \
+            const float2_t b = __builtin_elementwise_max(W[q].hi + X[q].hi, (float2_t){0.0f, 0.0f});                              \
+            aq[NTI][2 * q + 0] += a;                                                                                              \
+            aq[NTI][2 * q + 1] += b;                                                                                              \
+        }                                                                                                                         \
+        at[NTI] += relu1(WT + XT);                                                                                                \
+    }
+    // the 24 + 1 sums of a row as 12 register PAIRS: v_pk_add_f32 for the message and for the accumulation (two v_max between)
+    float2_t aq[NT][12];
+    float at[NT] = {0.0f, 0.0f};
 #pragma unroll
-            for (int q = 0; q < 6; q++) {
-                bq[0][4 * q + 0] += relu1(w0[q].x + x0[q].x);
-                bq[0][4 * q + 1] += relu1(w0[q].y + x0[q].y);
-                bq[0][4 * q + 2] += relu1(w0[q].z + x0[q].z);
-                bq[0][4 * q + 3] += relu1(w0[q].w + x0[q].w);
-            }
-            bq[0][24] += relu1(wt0 + xt0);
-        }
-        if (a1) {
-            e_cur[1]++;
-            if (e_cur[1] < e_end[1]) wd[1] = s_edge[e_cur[1]];
+    for (int nt = 0; nt < NT; nt++) {
 #pragma unroll
-            for (int q = 0; q < 6; q++) {
-                bq[1][4 * q + 0] += relu1(w1[q].x + x1[q].x);
-                bq[1][4 * q + 1] += relu1(w1[q].y + x1[q].y);
-                bq[1][4 * q + 2] += relu1(w1[q].z + x1[q].z);
-                bq[1][4 * q + 3] += relu1(w1[q].w + x1[q].w);
-            }
-            bq[1][24] += relu1(wt1 + xt1);
-        }
+        for (int k = 0; k < 12; k++) aq[nt][k] = (float2_t){0.0f, 0.0f};
+    }
+    const int tboth = min(trips[0], trips[1]);
+#pragma unroll 1
+    for (int t = 0; t < tboth; t++) {
+        float4_t x0[6], w0[6], x1[6], w1[6];
+        float xt0, wt0, xt1, wt1;
+        GR_READ(0, x0, w0, xt0, wt0)
+        GR_READ(1, x1, w1, xt1, wt1)
+        GR_NEXT(0)
+        GR_NEXT(1)
+        GR_FOLD(0, x0, w0, xt0, wt0)
+        GR_FOLD(1, x1, w1, xt1, wt1)
+    }
+#pragma unroll 1
+    for (int t = tboth; t < trips[0]; t++) {
+        float4_t x0[6], w0[6];
+        float xt0, wt0;
+        GR_READ(0, x0, w0, xt0, wt0)
+        GR_NEXT(0)
+        GR_FOLD(0, x0, w0, xt0, wt0)
+    }
+#pragma unroll 1
+    for (int t = tboth; t < trips[1]; t++) {
+        float4_t x1[6], w1[6];
+        float xt1, wt1;
+        GR_READ(1, x1, w1, xt1, wt1)
+        GR_NEXT(1)
+        GR_FOLD(1, x1, w1, xt1, wt1)
+    }
+#undef GR_READ
+#undef GR_NEXT
+#undef GR_FOLD
+#pragma unroll
+    for (int nt = 0; nt < NT; nt++) {
+#pragma unroll
+        for (int k = 0; k < 12; k++) { bq[nt][2 * k] = aq[nt][k].x; bq[nt][2 * k + 1] = aq[nt][k].y; }
+        bq[nt][24] = at[nt];
     }
     if constexpr (HUBS) {
         // Hub rows (GIN-VN's virtual nodes: in-degree = graph size): one lane walking 26 in-edges would hold its column tile for 26
@@ -1362,7 +1400,7 @@ __global__ __launch_bounds__(GR_WAVES * 64, 2) void gin_resident_kernel(const fl
     static_assert(!ENC || FOLD, "the in-kernel encoder rides on the folded last layer's steps");
     __shared__ __attribute__((aligned(16))) char s_a[GRC_CHUNK_BYTES];
     __shared__ __attribute__((aligned(16))) char s_b[GRC_CHUNK_BYTES];
-    __shared__ __attribute__((aligned(16))) float s_h[GR_ROWS * GS_D];
+    __shared__ __attribute__((aligned(16))) float s_h[(GR_ROWS + 1) * GS_D];  // + the no-edge row (GR_NO_EDGE)
     unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0};
     unsigned long long tk0 = 0;
     if constexpr (PROF) tk0 = wall_clock64();
@@ -1375,6 +1413,7 @@ __global__ __launch_bounds__(GR_WAVES * 64, 2) void gin_resident_kernel(const fl
     if (tile >= n_tiles) return;
     constexpr bool fold_head = FOLD;  // the launcher instantiates FOLD only with head_u, a single-task readout and no per-node tap
     if (fold_head && (int)threadIdx.x < 208) s_u[threadIdx.x] = head_u[threadIdx.x];
+    if ((int)threadIdx.x < GS_D) s_h[GR_ROWS * GS_D + threadIdx.x] = -1.0e30f;
     const float head_c = fold_head ? head_u[208] : 0.0f;
     if (wave >= 4) __builtin_amdgcn_s_setprio(1);  // the second-dispatched half loses every arbitration otherwise (MI355X_MICROARCH: static priority)
     GrTile cur = gr_load_tile(tile_row, tile_graph, tile, n_tiles, tstride);
