@@ -1178,26 +1178,27 @@ __device__ __forceinline__ void gr_layer(unsigned long long (&tacc)[6], char* bx
                 float part[25];
 #pragma unroll
                 for (int k = 0; k < 25; k++) part[k] = 0.0f;
-                for (int e = hb + j; __any(e < he); e += 16) {
-                    if (e < he) {
-                        const unsigned w2 = s_edge[e];
-                        const unsigned u = w2 >> 6, code = w2 & 63u;
-                        const float* hr = s_h + u * GS_D + 4 * g;
-                        const float* er = s_ecomb + code * GS_D + 4 * g;
-                        float4 x[6];
+                const int hub_trips = (he - hb + 15) >> 4;  // wave-uniform; lanes past the hub's last in-edge walk the no-edge word
+#pragma unroll 1
+                for (int t = 0; t < hub_trips; t++) {
+                    const int e = hb + j + 16 * t;
+                    const unsigned w2 = e < he ? (unsigned)s_edge[e < he ? e : 0] : GR_NO_EDGE;
+                    const unsigned u = w2 >> 6, code = w2 & 63u;
+                    const float* hr = s_h + u * GS_D + 4 * g;
+                    const float* er = s_ecomb + code * GS_D + 4 * g;
+                    float4 x[6];
 #pragma unroll
-                        for (int q = 0; q < 6; q++) x[q] = *reinterpret_cast<const float4*>(hr + 16 * q);
-                        const float xt = s_h[u * GS_D + 96 + g];
+                    for (int q = 0; q < 6; q++) x[q] = *reinterpret_cast<const float4*>(hr + 16 * q);
+                    const float xt = s_h[u * GS_D + 96 + g];
 #pragma unroll
-                        for (int q = 0; q < 6; q++) {
-                            const float4 w = *reinterpret_cast<const float4*>(er + 16 * q);
-                            part[4 * q + 0] += relu1(w.x + x[q].x);
-                            part[4 * q + 1] += relu1(w.y + x[q].y);
-                            part[4 * q + 2] += relu1(w.z + x[q].z);
-                            part[4 * q + 3] += relu1(w.w + x[q].w);
-                        }
-                        part[24] += relu1(s_ecomb[code * GS_D + 96 + g] + xt);
+                    for (int q = 0; q < 6; q++) {
+                        const float4 w = *reinterpret_cast<const float4*>(er + 16 * q);
+                        part[4 * q + 0] += relu1(w.x + x[q].x);
+                        part[4 * q + 1] += relu1(w.y + x[q].y);
+                        part[4 * q + 2] += relu1(w.z + x[q].z);
+                        part[4 * q + 3] += relu1(w.w + x[q].w);
                     }
+                    part[24] += relu1(s_ecomb[code * GS_D + 96 + g] + xt);
                 }
                 // all-reduce over the 16 lanes of the column tile with DPP row rotations (8, 4, 2, 1): every lane adds the same pairs
                 // at every level, so all 16 hold the same bits whichever lane owns the hub
