@@ -383,13 +383,21 @@ constexpr int DGN_HT_BYTES = DGN_D * DGN_HT_STRIDE * 2;      // 27 200 per half 
 // INFO: what a row's in-edge pass produces -- this lane's adjacency mask, wsum, abssum, the duplicate count -- depends on the graph and
 // the eigenvector only, not on the layer: the first layer's launch (INFO 1) stores it, 32 B per row, the later ones (INFO 2) load it
 // (requested a tile ahead) instead of walking the row's in-edges again (0.10-0.12 ms per launch).  INFO 0: neither.
-template <int INFO>
+// POOL (the last layer when nothing asks for its rows): h' does not leave the kernel.  Every wave sums its 16 rows per graph (fixed
+// DPP butterfly over the 16 lanes that share a feature slice) and writes one partial row per (graph, wave): pool_part[graph][rel][100],
+// rel = the wave's index counted from the graph's first one (a graph of <= 128 rows spans <= 8 waves); the graph's first wave also
+// writes how many there are.  dgn_pool_part_mlp3_kernel adds them in order and runs the head: the 400 B per node of h' are neither
+// written nor read back (2 x 0.64 GB per step at 2^15 hep10k graphs).  The association depends on where the graph sits in its tile
+// -- toleranced like the rest of this path.  ginfo[node] = (graph, (node - first) | (end - node) << 8), dgn_graph_info_kernel.
+template <int INFO, bool POOL>
 __global__ __launch_bounds__(512, 2) void dgn_layer_mfma_kernel(const float* __restrict__ h, float* __restrict__ hout,
                                                                  const int* __restrict__ row_ptr, const int* __restrict__ src,
                                                                  const int* __restrict__ out_deg, const float* __restrict__ eig4,
                                                                  const uint8_t* __restrict__ wpk, const int* __restrict__ tile_row,
                                                                  int n_tiles, int* __restrict__ range_flag, int ablate_arg,
-                                                                 uint32_t* __restrict__ rowinfo /* [n_tot][8] */) {
+                                                                 uint32_t* __restrict__ rowinfo /* [n_tot][8] */,
+                                                                 const int2* __restrict__ ginfo, float* __restrict__ pool_part,
+                                                                 int* __restrict__ pool_cnt) {
     const int ablate = FG_ABLATE(ablate_arg);  // development aid (dgn_ablate, -DFLOWGNN_DEV builds): 1 no aggregation MFMAs, 2 no dense
     (void)ablate_arg;                          // MFMAs, 4 no transposing stores of the next tile, 8 no in-edge pass, 16 no h[v] loads
     constexpr int OFF_W = 2 * DGN_HT_BYTES, OFF_SRC = OFF_W + (int)DGN_FT_LAYER_BYTES, OFF_RP = OFF_SRC + DGN_FT_EDGES,
@@ -501,6 +509,8 @@ __global__ __launch_bounds__(512, 2) void dgn_layer_mfma_kernel(const float* __r
         const float eig_v = s_eig[valid ? r : 0];
         const long long node = (long long)t0 + (valid ? r : 0);
         const int odeg = out_deg[node];
+        int2 gi = make_int2(0, 0);
+        if constexpr (POOL) gi = ginfo[node];  // requested here, used in the epilogue
         // one pass over the row's in-edges: wsum, abssum (DGN/src/load_inputs.cc:105-110), this lane's slice of the adjacency row as a
         // bit mask (bit 8 s + e <-> source 32 s + 8 g + e), and the number of duplicate edges (CSR rows are sorted by source)
         float wsum = 0.0f, abssum = 0.0f;
@@ -661,15 +671,67 @@ __global__ __launch_bounds__(512, 2) void dgn_layer_mfma_kernel(const float* __r
             } else { acc[0].x += b_hi.x + b_lo.y; }
         }
         // ---- epilogue: h' = h + relu(b + W0 a1 + W1 a2)   (node_embedding.cc:176-181)
-        if (valid) {
+        if constexpr (!POOL) {
+            if (valid) {
+#pragma unroll
+                for (int t = 0; t < DGN_OT; t++) {
+                    const int c = 16 * t + 4 * g;
+                    if (c < DGN_D) {
+                        const float4 hv = *reinterpret_cast<const float4*>(hrow + c);
+                        const float4_t rr = acc[t] * oscale;
+                        *reinterpret_cast<float4*>(hout + (size_t)node * DGN_D + c) =
+                            make_float4(hv.x + relu1(rr.x), hv.y + relu1(rr.y), hv.z + relu1(rr.z), hv.w + relu1(rr.w));
+                    }
+                }
+            }
+        } else if (16 * wave < rows) {  // wave-uniform: this wave owns rows of the tile
+            float4_t hp[DGN_OT];
 #pragma unroll
             for (int t = 0; t < DGN_OT; t++) {
                 const int c = 16 * t + 4 * g;
-                if (c < DGN_D) {
-                    const float4 hv = *reinterpret_cast<const float4*>(hrow + c);
-                    const float4_t rr = acc[t] * oscale;
-                    *reinterpret_cast<float4*>(hout + (size_t)node * DGN_D + c) =
-                        make_float4(hv.x + relu1(rr.x), hv.y + relu1(rr.y), hv.z + relu1(rr.z), hv.w + relu1(rr.w));
+                const float4 hv = *reinterpret_cast<const float4*>(hrow + (c < DGN_D ? c : 0));
+                const float4_t rr = acc[t] * oscale;
+                hp[t] = (float4_t){hv.x + relu1(rr.x), hv.y + relu1(rr.y), hv.z + relu1(rr.z), hv.w + relu1(rr.w)};
+            }
+            const int last = rows - 16 * wave < 16 ? rows - 16 * wave - 1 : 15;  // the wave's last row of the tile (lane = its j)
+            const int g_lo = __builtin_amdgcn_readlane(gi.x, 0), g_hi = __builtin_amdgcn_readlane(gi.x, last);
+            for (int G = g_lo; G <= g_hi; G++) {  // the graphs this wave has rows of (one or two; more only for tiny graphs)
+                const bool in = valid && gi.x == G;
+                float4_t sum[DGN_OT];
+#pragma unroll
+                for (int t = 0; t < DGN_OT; t++) sum[t] = in ? hp[t] : (float4_t){0.f, 0.f, 0.f, 0.f};
+                // all-reduce over the 16 lanes of a feature slice (DPP row rotations 8, 4, 2, 1: the same pairs at every level in every lane)
+                // (on scalar copies: with the DPP source an element of a float4_t, sum[t][i], hipcc 7.2 produced wrong sums here)
+                float sv[4 * DGN_OT];
+#pragma unroll
+                for (int t = 0; t < DGN_OT; t++) {
+#pragma unroll
+                    for (int i = 0; i < 4; i++) sv[4 * t + i] = sum[t][i];
+                }
+#define DGN_ROR_ADD(CTRL)                                                                                                         \
+    _Pragma("unroll") for (int k = 0; k < 4 * DGN_OT; k++)                                                                        \
+        sv[k] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sv[k]), CTRL, 0xF, 0xF, false));
+                DGN_ROR_ADD(0x128) DGN_ROR_ADD(0x124) DGN_ROR_ADD(0x122) DGN_ROR_ADD(0x121)
+#undef DGN_ROR_ADD
+#pragma unroll
+                for (int t = 0; t < DGN_OT; t++) sum[t] = (float4_t){sv[4 * t], sv[4 * t + 1], sv[4 * t + 2], sv[4 * t + 3]};
+                // the lane of the graph's first row held by this wave writes, in every feature slice
+                const unsigned long long inm = __ballot(in && g == 0);
+                if (inm == 0ull) continue;  // (cannot happen: a graph's rows are contiguous)
+                const int jf = __ffsll((long long)inm) - 1;
+                const int first_rel = __builtin_amdgcn_readlane(gi.y & 0xFF, jf);        // (row of jf) - (graph's first row)
+                const int to_end = __builtin_amdgcn_readlane((gi.y >> 8) & 0xFFF, jf);   // (graph's end) - (row of jf)
+                const int row_jf = 16 * wave + jf;                                        // inside the tile
+                const int gstart = row_jf - first_rel, gend = row_jf + to_end;            // the graph's rows inside the tile: [gstart, gend)
+                const int rel = wave - (gstart >> 4);
+                if (j == jf) {
+                    float* dst = pool_part + ((size_t)G * 8 + rel) * DGN_D;
+#pragma unroll
+                    for (int t = 0; t < DGN_OT; t++) {
+                        const int c = 16 * t + 4 * g;
+                        if (c < DGN_D) *reinterpret_cast<float4*>(dst + c) = make_float4(sum[t].x, sum[t].y, sum[t].z, sum[t].w);
+                    }
+                    if (rel == 0 && g == 0) pool_cnt[G] = ((gend - 1) >> 4) - (gstart >> 4) + 1;
                 }
             }
         }
@@ -691,6 +753,62 @@ __global__ __launch_bounds__(512, 2) void dgn_layer_mfma_kernel(const float* __r
     }
     if (__any(!(vmax < 6.0e4f))) {
         if (lane == 0) atomicOr(range_flag, 1);
+    }
+}
+
+// ginfo[node] = (graph, (node - graph's first node) | (graph's end - node) << 8) for the POOL epilogue above: one thread per graph
+// (graphs of this path have <= 128 nodes)
+__global__ __launch_bounds__(256) void dgn_graph_info_kernel(const int* __restrict__ node_off, int num_graphs, int2* __restrict__ ginfo) {
+    const int gph = blockIdx.x * 256 + threadIdx.x;
+    if (gph >= num_graphs) return;
+    const int n0 = node_off[gph], n1 = node_off[gph + 1];
+    for (int v = n0; v < n1; v++) ginfo[v] = make_int2(gph, ((v - n0) & 0xFF) | ((n1 - v) << 8));
+}
+
+// readout of the POOL form: mean over the graph's nodes from the per-wave partial sums (added in wave order), then the 3-layer head
+// of pool_mlp3_kernel (device_common.h) with the same arithmetic per graph.  Persistent workgroups, one wavefront per graph at a
+// time; W1 and W2 are staged once per workgroup in LDS, transposed (unit along the lanes: conflict-free) -- read from global memory
+// in [unit][input] order every lane of a step touches another cache line, and the head then costs more than the pooling it follows.
+__global__ __launch_bounds__(256) void dgn_pool_part_mlp3_kernel(const float* __restrict__ part /* [G][8][100] */, const int* __restrict__ cnt,
+                                                                 const int* __restrict__ node_off, const float* __restrict__ w1,
+                                                                 const float* __restrict__ b1, const float* __restrict__ w2,
+                                                                 const float* __restrict__ b2, const float* __restrict__ w3,
+                                                                 const float* __restrict__ b3, float* __restrict__ out, int num_graphs) {
+    constexpr int D = DGN_D, H1 = 50, H2 = 25, P1 = H1 + 1, P2 = H2 + 2;
+    __shared__ float s_w1t[D * P1];   // [input][unit]
+    __shared__ float s_w2t[H1 * P2];  // [input][unit]
+    __shared__ float s_hg[4][D];
+    __shared__ float s_o1[4][H1];
+    for (int i = threadIdx.x; i < H1 * D; i += 256) s_w1t[(i % D) * P1 + i / D] = w1[i];
+    for (int i = threadIdx.x; i < H2 * H1; i += 256) s_w2t[(i % H1) * P2 + i / H1] = w2[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const float bias1 = lane < H1 ? b1[lane] : 0.0f, bias2 = lane < H2 ? b2[lane] : 0.0f, w3l = lane < H2 ? w3[lane] : 0.0f, bias3 = b3[0];
+    for (int gph = blockIdx.x * 4 + wv; gph < num_graphs; gph += gridDim.x * 4) {
+        const int nw = cnt[gph];
+        const float n = (float)(node_off[gph + 1] - node_off[gph]);
+        for (int c = lane; c < D; c += 64) {
+            float sum = 0.0f;
+            for (int k = 0; k < nw; k++) sum += part[((size_t)gph * 8 + k) * D + c];
+            s_hg[wv][c] = sum / n;
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (lane < H1) {
+            float s = bias1;
+            for (int i = 0; i < D; i++) s += s_hg[wv][i] * s_w1t[i * P1 + lane];
+            s_o1[wv][lane] = relu1(s);
+        }
+        __builtin_amdgcn_wave_barrier();
+        float p = 0.f;
+        if (lane < H2) {
+            float s = bias2;
+            for (int i = 0; i < H1; i++) s += s_o1[wv][i] * s_w2t[i * P2 + lane];
+            p = relu1(s) * w3l;
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) p += __shfl_down(p, d, 64);
+        if (lane == 0) out[gph] = bias3 + p;
+        __builtin_amdgcn_wave_barrier();  // s_hg / s_o1 are rewritten for the wave's next graph
     }
 }
 
@@ -866,6 +984,7 @@ public:
         if (!fused)  // the fused layer takes eig1[src] from its own LDS tile: only the two-kernel layer needs these
             if (int rc = prepare_aggregate(db, prof, s)) return rc;
         int cur = 0;
+        bool pooled = false;  // the last layer left per-wave partial sums instead of its rows
         for (int l = 0; l < DGN_L; l++) {
             if (fused) {
                 ProfScope p(prof, "dgn_layer_fused", s);
@@ -876,12 +995,23 @@ public:
                 if (mfma_agg) {
                     if (int rc = rowinfo_.reserve((size_t)n * 8)) return rc;
                     uint32_t* ri = reinterpret_cast<uint32_t*>(rowinfo_.p);
-#define DGN_MFMA_LAUNCH(I)                                                                                                                    \
-    dgn_layer_mfma_kernel<I><<<grid, 512, 0, s>>>(db.h[cur], db.h[cur ^ 1], db.csr.row_ptr, db.csr.src, db.csr.out_deg, db.node_eigen,          \
-                                                  d_fused_ + (size_t)l * DGN_FT_LAYER_BYTES, db.gtiles.row_start, db.gtiles.n_tiles, db.range_flag, \
-                                                  ablate_, ri)
-                    // the first layer stores what its in-edge pass found per row (adjacency mask, wsum, abssum), the others load it
-                    if (l == 0) DGN_MFMA_LAUNCH(1); else DGN_MFMA_LAUNCH(2);
+#define DGN_MFMA_LAUNCH(I, P)                                                                                                                 \
+    dgn_layer_mfma_kernel<I, P><<<grid, 512, 0, s>>>(db.h[cur], db.h[cur ^ 1], db.csr.row_ptr, db.csr.src, db.csr.out_deg, db.node_eigen,       \
+                                                     d_fused_ + (size_t)l * DGN_FT_LAYER_BYTES, db.gtiles.row_start, db.gtiles.n_tiles,       \
+                                                     db.range_flag, ablate_, ri, reinterpret_cast<const int2*>(ginfo_.p), pool_part_.p,      \
+                                                     pool_cnt_.p)
+                    // the first layer stores what its in-edge pass found per row (adjacency mask, wsum, abssum), the others load it;
+                    // the last one keeps h' on chip and hands the readout per-wave partial sums (POOL) unless the rows are asked for
+                    const bool pool = l == DGN_L - 1 && fold_readout_ && !keep_h_ && DGN_L > 1;
+                    if (pool) {
+                        if (int rc = ginfo_.reserve((size_t)n * 2)) return rc;
+                        if (int rc = pool_part_.reserve((size_t)db.b.num_graphs * 8 * DGN_D)) return rc;
+                        if (int rc = pool_cnt_.reserve((size_t)db.b.num_graphs)) return rc;
+                        dgn_graph_info_kernel<<<(db.b.num_graphs + 255) / 256, 256, 0, s>>>(db.b.node_off, db.b.num_graphs,
+                                                                                          reinterpret_cast<int2*>(ginfo_.p));
+                        pooled = true;
+                    }
+                    if (l == 0) DGN_MFMA_LAUNCH(1, false); else if (pool) DGN_MFMA_LAUNCH(2, true); else DGN_MFMA_LAUNCH(2, false);
 #undef DGN_MFMA_LAUNCH
                     cur ^= 1;
                     continue;
@@ -911,10 +1041,15 @@ public:
             cur ^= 1;
         }
         db.final_h = cur;
+        db.h_valid = !pooled;  // pooled: h[cur] was never written; flowgnn_get_h repeats the pass with the rows kept
         {
             ProfScope p(prof, "pool_mlp3", s);
-            pool_mlp3_kernel<DGN_D, 50, 25><<<(db.b.num_graphs + 3) / 4, 256, 0, s>>>(db.h[cur], db.b.node_off, d_w0_, d_b0_, d_w1_,
-                                                                                      d_b1_, d_w2_, d_b2_, db.out, db.b.num_graphs);
+            if (pooled)
+                dgn_pool_part_mlp3_kernel<<<grid_for(db.b.num_graphs, 4, 256 * 4), 256, 0, s>>>(pool_part_.p, pool_cnt_.p, db.b.node_off, d_w0_, d_b0_, d_w1_,
+                                                                                    d_b1_, d_w2_, d_b2_, db.out, db.b.num_graphs);
+            else
+                pool_mlp3_kernel<DGN_D, 50, 25><<<(db.b.num_graphs + 3) / 4, 256, 0, s>>>(db.h[cur], db.b.node_off, d_w0_, d_b0_, d_w1_,
+                                                                                          d_b1_, d_w2_, d_b2_, db.out, db.b.num_graphs);
         }
         return 0;
     }
@@ -925,10 +1060,12 @@ public:
         split_ = o.i("dgn_mfma") != 32;
         fused_ = o.on("dgn_fused");
         mfma_agg_ = o.i("dgn_mfma_agg");
+        fold_readout_ = o.on("dgn_fold_readout");
         ablate_ = FG_ABLATE(o.i("dgn_ablate"));
         agg_ready_ = false;
     }
     void set_exact(bool on) override { exact_ = on; }
+    void set_keep_h(bool on) override { keep_h_ = on; }
 
     int aggregation_only(DeviceBatch& db, int layer, hipStream_t s) override {
         if (qmode_) return 8;  // FLOWGNN_ERR_UNSUPPORTED: the fixed-point forward never builds the float kernels' inputs (tiles, h rows)
@@ -949,6 +1086,9 @@ private:
         esc_.release();
         tiles_.release();
         rowinfo_.release();
+        ginfo_.release();
+        pool_cnt_.release();
+        pool_part_.release();
         q_.release();
         if (d_split_) { (void)hipFree(d_split_); d_split_ = nullptr; }
         if (d_fused_) { (void)hipFree(d_fused_); d_fused_ = nullptr; }
@@ -963,6 +1103,9 @@ private:
     // dgn_fused=0 keeps aggregation and dense update as two kernels per layer (A/B measurements, the aggregation roofline probe)
     bool agg_ready_ = false;  // tiles_ / esc_ describe the batch of the last forward
     GrowBufI rowinfo_;   // dgn_layer_mfma_kernel: 32 B per row of layer-independent in-edge pass results
+    GrowBufI ginfo_, pool_cnt_;  // POOL form of the last layer: (graph, position) per node; partial rows per graph
+    GrowBuf pool_part_;          //   [G][8][100] per-wave partial sums of h_4
+    bool fold_readout_ = true, keep_h_ = false;
     int mfma_agg_ = -1;  // dgn_mfma_agg: 1 = aggregation on the matrix pipe (dgn_layer_mfma_kernel), 0 = in-edge walk, -1 = by density
     int ablate_ = 0;  // development aid (-DFLOWGNN_DEV builds only, option dgn_ablate): per-phase timing (scripts/dev/pna_ablate.sh)
     bool fused_ = true;

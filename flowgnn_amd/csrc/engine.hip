@@ -99,7 +99,7 @@ static const OptionDef kOptionTable[] = {
     {"gcn_resident", 1}, {"gcn_unfused", 0}, {"gcn_mfma", 16},
     {"gat_resident", 1}, {"gat_mfma", 16}, {"gat_fold_readout", 1}, {"gat_reference_quirk", 0},
     {"pna_fused", 1}, {"pna_mfma", 16}, {"pna_mfma_agg", -1},
-    {"dgn_fused", 1}, {"dgn_mfma", 16}, {"dgn_mfma_agg", -1},
+    {"dgn_fused", 1}, {"dgn_mfma", 16}, {"dgn_mfma_agg", -1}, {"dgn_fold_readout", 1},
 #ifdef FLOWGNN_DEV
     {"gcn_ablate", 0}, {"gat_ablate", 0}, {"pna_ablate", 0}, {"dgn_ablate", 0},
 #endif

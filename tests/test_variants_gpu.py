@@ -351,3 +351,35 @@ def test_dgn_mfma_aggregation_on_awkward_tiles(oracle):
         assert np.isfinite(outs[mode]).all()
         assert np.allclose(outs[mode], want, rtol=2e-4, atol=2e-3 * scale), (mode, np.abs(outs[mode] - want).max(), scale)
     assert np.allclose(outs[1], outs[0], rtol=1e-4, atol=1e-4 * scale)
+
+
+def test_dgn_pooled_last_layer(oracle):
+    """dgn_fold_readout: the last MFMA layer hands the readout per-wave partial sums instead of its rows.  Same logits (the mean over
+    a graph's nodes is added in another order: tolerance), on kNN tiles, on tiles of many tiny graphs (several graphs per wave), on a
+    graph that fills the tile; flowgnn_get_h afterwards repeats the pass with the rows kept and leaves the engine as it was."""
+    from tests.test_resident_limits_gpu import random_graph
+
+    def with_eig(b, seed):
+        e = np.zeros((b.total_nodes, 4), np.float32)
+        e[:, 1] = np.random.default_rng(seed).uniform(-1, 1, b.total_nodes)
+        return gp.GraphBatch(b.nums_of_nodes, b.nums_of_edges, b.node_feature, b.edge_list, b.edge_attr, e)
+    tiny = gp.concat_batches([with_eig(random_graph(n, 3 * n, seed=100 + n), n) for n in (1, 2, 3, 5, 1, 17, 2, 33, 4, 1, 1, 64, 7)])
+    batches = [gp.synth_hep10k_batch(301, seed=12),
+               gp.concat_batches([tiny, with_eig(gp.synth_molhiv_batch(120, seed=9), 4), with_eig(random_graph(128, 2560, seed=5), 2), tiny])]
+    w = weights.SYNTH["DGN"](seed=7)
+    for b in batches:
+        want, hd = oracle.dgn_forward(b, [w], dump_h=True, nthreads=8)
+        scale = max(1.0, float(np.abs(hd).max()))
+        e1 = Engine("DGN", device=0, options={"dgn_mfma_agg": 1, "dgn_fold_readout": 1})
+        e0 = Engine("DGN", device=0, options={"dgn_mfma_agg": 1, "dgn_fold_readout": 0})
+        for e in (e1, e0):
+            e.set_weights(w)
+        o1, o0 = e1.forward(b), e0.forward(b)
+        assert np.isfinite(o1).all()
+        assert np.allclose(o1, want, rtol=2e-4, atol=2e-3 * scale), (np.abs(o1 - want).max(), scale)
+        assert np.allclose(o1, o0, rtol=1e-5, atol=1e-5 * scale), np.abs(o1 - o0).max()
+        h1, h0 = e1.final_h(), e0.final_h()  # e1: the pass is repeated with the rows kept (the same kernels as e0)
+        assert np.array_equal(h1, h0)
+        assert np.allclose(h1, hd[4], rtol=2e-4, atol=2e-3 * scale)
+        assert np.array_equal(e1.forward(b), o1)  # and the pooled form is back afterwards
+        e1.close(); e0.close()
