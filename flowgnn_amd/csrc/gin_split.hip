@@ -511,6 +511,12 @@ __device__ __forceinline__ void grc_issue_chunk_w1(const uint8_t* __restrict__ g
 #ifndef GR_DEFER
 #define GR_DEFER false
 #endif
+// At equal priority the SIMD's older wave (0-3) wins the arbitration and the younger one (4-7) is the gather's straggler by 20 %
+// (2 330 us against 1 950 per wave by phase stamps); with the priority on 4-7 for the whole gather it is the other way round.  So
+// waves 4-7 hold it for the first half of their trips: 2 280 against 2 050, wait behind the gather 483 -> 418 us, launch -0.4 %.
+#ifndef GR_PRIO_HALF
+#define GR_PRIO_HALF true
+#endif
 #ifndef GR_PRIO_BY_PHASE
 #define GR_PRIO_BY_PHASE true
 #endif
@@ -1038,7 +1044,7 @@ __device__ __forceinline__ void gr_layer(unsigned long long (&tacc)[6], char* bx
     // the phase ends with its slowest wave: equal priority while gathering, raised again behind the gather's barrier (then age
     // decides and waves 4-7 trail by less: 2 305 against 1 959; launch 8.70 -> 8.60 ms.  Priorities alternating trip by trip even the
     // halves out but cost more than they return: 8.69 ms).
-    if (GR_PRIO_BY_PHASE) __builtin_amdgcn_s_setprio(0);
+    if (GR_PRIO_BY_PHASE) { if (GR_PRIO_HALF && wave >= 4) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
     if (fold) grc_issue_chunk_w1<8>(wchunks, by, wave, lane);
     else grc_issue_chunk<8>(wchunks, by, wave, lane);  // chunk 0: lands under the gather (dealt by all eight waves: nobody multiplies now)
     // ENC (the tile loader computes h_0 itself): the next tile's rows are encoded during this layer's MLP steps, a part per step;
@@ -1131,6 +1137,7 @@ __device__ __forceinline__ void gr_layer(unsigned long long (&tacc)[6], char* bx
     for (int t = 0; t < tboth; t++) {
         float4_t x0[6], w0[6], x1[6], w1[6];
         float xt0, wt0, xt1, wt1;
+        if (GR_PRIO_HALF && wave >= 4 && t == (tboth >> 1)) __builtin_amdgcn_s_setprio(0);
         GR_READ(0, x0, w0, xt0, wt0)
         GR_READ(1, x1, w1, xt1, wt1)
         GR_NEXT(0)
