@@ -7,7 +7,7 @@ importing it does not load the library, using an Engine does, and fails loudly i
 from .graphpack import (GraphBatch, synth_molhiv_batch, synth_molpcba_batch, synth_hep10k_batch,  # noqa: F401
                         add_virtual_nodes, read_pack, write_pack, concat_batches)
 from .engine import (Engine, EngineGroup, FlowGNNError, compute_graphs, GIN_compute_graphs, GCN_compute_graphs,  # noqa: F401
-                     entry_set_devices, entry_set_option, shard_ranges_c)
+                     entry_set_devices, entry_set_option, entry_set_pipeline, shard_ranges_c)
 from . import weights  # noqa: F401
 
 __all__ = ["Engine", "EngineGroup", "FlowGNNError", "GIN_compute_graphs", "GraphBatch", "weights"]

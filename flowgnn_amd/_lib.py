@@ -64,6 +64,7 @@ def _declare(lib):
     lib.flowgnn_option_name.restype = C.c_char_p
     lib.flowgnn_entry_set_devices.argtypes = [C.c_int, p_int]
     lib.flowgnn_entry_set_option.argtypes = [C.c_int, C.c_char_p, C.c_double]
+    lib.flowgnn_entry_set_pipeline.argtypes = [C.c_int]
     lib.flowgnn_shard_ranges.argtypes = [C.c_int, p_int, p_int, C.c_int, p_int]
     lib.flowgnn_create_multi.argtypes = [C.c_int, C.c_int, p_int, C.POINTER(grp)]
     lib.flowgnn_group_destroy.argtypes = [grp]
@@ -82,6 +83,7 @@ def _declare(lib):
     lib.flowgnn_group_run.argtypes = [grp]
     lib.flowgnn_group_sync.argtypes = [grp]
     lib.flowgnn_group_get_results.argtypes = [grp, p_float]
+    lib.flowgnn_group_compute.argtypes = [grp, C.c_int, p_int, p_int, p_int, p_int, p_int, p_float, p_float, C.c_int]
     lib.GIN_compute_graphs_mt.argtypes = [C.c_int, p_int, p_int, p_int, p_float, p_int, p_int, p_int] + [p_float] * 8 + [C.c_int]
     lib.GCN_compute_graphs_mt.argtypes = [C.c_int, p_int, p_int, p_int, p_float, p_int, p_int, p_int] + [p_float] * 11 + [C.c_int]
     lib.GIN_compute_graphs.argtypes = [C.c_int, p_int, p_int, p_int, p_float, p_int, p_int, p_int] + [p_float] * 8
@@ -98,6 +100,7 @@ def _declare(lib):
                  "flowgnn_shard_ranges", "flowgnn_create_multi", "flowgnn_group_destroy", "flowgnn_group_size", "flowgnn_group_set_weights",
                  "flowgnn_group_load_weights_dir", "flowgnn_group_set_option", "flowgnn_group_set_num_tasks", "flowgnn_group_set_numeric_mode",
                  "flowgnn_group_set_batch", "flowgnn_group_shards", "flowgnn_group_run", "flowgnn_group_sync", "flowgnn_group_get_results",
+                 "flowgnn_group_compute", "flowgnn_entry_set_pipeline",
                  "GIN_compute_graphs_mt", "GCN_compute_graphs_mt", "GIN_compute_graphs", "GCN_compute_graphs", "PNA_compute_graphs", "DGN_compute_graphs", "GAT_compute_graphs"):
         getattr(lib, name).restype = C.c_int
 

@@ -13,6 +13,7 @@
 #include <cctype>
 #include <mutex>
 #include <thread>
+#include <memory>
 
 namespace fg {
 
@@ -386,6 +387,14 @@ static int alloc_batch(flowgnn_engine* e, size_t G, size_t N, size_t E, bool att
     const int D = e->model->emb_dim(), SD = e->model->scratch_dim();
     G *= (size_t)e->num_tasks;  // capG counts result slots (only d_out and the small per-graph arrays scale with it)
     if (G > e->capG || N > e->capN || E > e->capE || (attr && !e->d_ea) || (eig && !e->d_eig)) {
+        // Capacities only grow, each on its own, and a regrow leaves an eighth of headroom: an engine that is handed the ranges of
+        // a cut job one after the other (flowgnn_group_compute) sees counts that differ by a few percent from range to range, and
+        // every reallocation is two dozen hipFree / hipMalloc pairs that wait for the device.
+        const bool regrow = e->capN > 0 || e->capE > 0;
+        if (G < e->capG) G = e->capG;
+        if (N < e->capN) N = e->capN;
+        if (E < e->capE) E = e->capE;
+        if (regrow) { G += G / 8; N += N / 8; E += E / 8; }
         e->free_batch();
         const size_t g1 = G ? G : 1, n1 = N ? N : 1, e1 = E ? E : 1;
         EHIP_TRY(e, hipMalloc((void**)&e->d_nn, sizeof(int) * g1));
@@ -934,6 +943,8 @@ struct flowgnn_group {
     int model_id = 0;
     std::vector<flowgnn_engine*> eng;
     std::vector<int> cut;  // [n + 1] graph cuts of the resident batch
+    std::vector<std::unique_ptr<std::mutex>> copy_mu;  // flowgnn_group_compute: one copier per device ...
+    std::vector<int> copy_of;                          // ... engine i uses copy_mu[copy_of[i]] (the first engine on its device)
     int num_tasks = 1;
     std::string err;
 };
@@ -994,6 +1005,13 @@ int flowgnn_create_multi(int model, int n_devices, const int* device_ids, flowgn
         g->eng.push_back(e);
     }
     g->cut.assign((size_t)n_devices + 1, 0);
+    for (int i = 0; i < n_devices; i++) {
+        int first = i;
+        for (int k = 0; k < i; k++)
+            if (device_ids[k] == device_ids[i]) { first = k; break; }
+        g->copy_of.push_back(first);
+        g->copy_mu.emplace_back(new std::mutex());
+    }
     *out = g;
     return FLOWGNN_OK;
 }
@@ -1083,6 +1101,54 @@ int flowgnn_group_get_results(flowgnn_group* g, float* out_host) {
     });
 }
 
+// One call for a batch that lives in HOST memory: the job is cut into size x chunks_per_engine ranges (same rule), and engine i
+// takes ranges i, i + size, ... one after the other -- set_batch (validation, tile packing, host -> device), run, results into
+// out_host at the range's place.  While one engine's kernels run, the other engines' copies are in flight: with two engines on ONE
+// device the PCIe transfer of range j + 1 hides under the kernels of range j (the entry points do exactly that).  The engines are
+// left holding their last range.
+int flowgnn_group_compute(flowgnn_group* g, int num_graphs, const int* nums_of_nodes, const int* nums_of_edges,
+                          const int* node_feature, const int* edge_list, const int* edge_attr, const float* node_eigen,
+                          float* out_host, int chunks_per_engine) {
+    if (!g || num_graphs < 0 || chunks_per_engine < 1) return FLOWGNN_ERR_ARG;
+    if (num_graphs > 0 && (!nums_of_nodes || !nums_of_edges || !out_host)) return FLOWGNN_ERR_ARG;
+    const int n = (int)g->eng.size();
+    const int S = n * chunks_per_engine;
+    std::vector<int> cut((size_t)S + 1, 0);
+    int rc = flowgnn_shard_ranges(num_graphs, nums_of_nodes, nums_of_edges, S, cut.data());
+    if (rc) return rc;
+    std::vector<long long> noff((size_t)S + 1, 0), eoff((size_t)S + 1, 0);
+    {
+        long long N = 0, E = 0;
+        int r = 0;
+        for (int gi = 0; gi <= num_graphs; gi++) {
+            while (r <= S && cut[(size_t)r] == gi) { noff[(size_t)r] = N; eoff[(size_t)r] = E; r++; }
+            if (gi < num_graphs) { N += nums_of_nodes[gi]; E += nums_of_edges[gi]; }
+        }
+    }
+    const int T = g->num_tasks;
+    return group_each(g, [&](int i) {
+        flowgnn_engine* e = g->eng[(size_t)i];
+        for (int j = i; j < S; j += n) {
+            const int g0 = cut[(size_t)j], g1 = cut[(size_t)j + 1];
+            if (g1 == g0) continue;
+            const long long n0 = noff[(size_t)j], e0 = eoff[(size_t)j];
+            int r;
+            {   // one host -> device copy per DEVICE at a time: two threads copying from pageable memory to the same GPU get a
+                // quarter of the rate each (6.0 ms against 1.4 for a 67 MB range), and the ranges would then march in lockstep
+                // instead of alternating copy / kernels
+                std::lock_guard<std::mutex> lk(*g->copy_mu[(size_t)g->copy_of[(size_t)i]]);
+                r = flowgnn_set_batch(e, g1 - g0, nums_of_nodes + g0, nums_of_edges + g0, node_feature ? node_feature + n0 * 9 : nullptr,
+                                      edge_list ? edge_list + e0 * 2 : nullptr, edge_attr ? edge_attr + e0 * 3 : nullptr,
+                                      node_eigen ? node_eigen + n0 * 4 : nullptr);
+            }
+            if (!r) r = flowgnn_run(e);
+            if (!r) r = flowgnn_get_results(e, out_host + (size_t)g0 * T);
+            if (r) return r;
+        }
+        return (int)FLOWGNN_OK;
+    });
+}
+
 // ------------------------------------------------------------------ reference-compatible entry points
 // Split the batch into runs of constant weight set (reload_weights semantics of
 // GIN/src/GIN_compute.cc:44,51-53) and run each through a process-wide group of engines per model: one engine on device 0
@@ -1090,6 +1156,7 @@ int flowgnn_group_get_results(flowgnn_group* g, float* out_host) {
 static std::mutex g_entry_mutex;
 static flowgnn_group* g_entry_group[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 static std::vector<int> g_entry_devices;  // empty: not decided yet (the environment is asked at the first call)
+static int g_entry_pipeline = 0;          // flowgnn_entry_set_pipeline: ranges per engine (0: by the size of the host arrays, 1: off)
 static std::vector<std::pair<std::string, double>> g_entry_options[6];
 // The weight set an entry-point group holds, kept on the host: a caller that reloads the SAME set on every graph
 // (reload_weights = 1 everywhere is legal in the reference and cheap there) must not pay a repack + upload per graph.
@@ -1129,6 +1196,14 @@ int flowgnn_entry_set_devices(int n_devices, const int* device_ids) {
     return FLOWGNN_OK;
 }
 
+int flowgnn_entry_set_pipeline(int chunks_per_engine) {
+    if (chunks_per_engine < 0 || chunks_per_engine > 64) return FLOWGNN_ERR_ARG;
+    std::lock_guard<std::mutex> lock(g_entry_mutex);
+    if ((g_entry_pipeline == 1) != (chunks_per_engine == 1)) entry_drop_groups();  // the engine count of a one-device list changes
+    g_entry_pipeline = chunks_per_engine;
+    return FLOWGNN_OK;
+}
+
 int flowgnn_entry_set_option(int model, const char* key, double value) {
     if (model < 0 || model >= 6 || !key) return FLOWGNN_ERR_ARG;
     if (option_index(key) < 0) return FLOWGNN_ERR_UNSUPPORTED;
@@ -1158,7 +1233,10 @@ static int compute_graphs_generic(int model, int num_graphs, const int* nums_of_
     flowgnn_group*& grp = g_entry_group[model];
     if (!grp) {
         if (g_entry_devices.empty()) read_environment(nullptr, &g_entry_devices);
-        int rc = flowgnn_create_multi(model, (int)g_entry_devices.size(), g_entry_devices.data(), &grp);
+        // one listed device: TWO engines on it, so that a large batch's host -> device copies run under the other engine's kernels
+        std::vector<int> devs = g_entry_devices;
+        if (devs.size() == 1 && g_entry_pipeline != 1) devs.push_back(devs[0]);
+        int rc = flowgnn_create_multi(model, (int)devs.size(), devs.data(), &grp);
         if (rc) return rc;
         for (auto& kv : g_entry_options[model]) {
             rc = flowgnn_group_set_option(grp, kv.first.c_str(), kv.second);
@@ -1188,14 +1266,33 @@ static int compute_graphs_generic(int model, int num_graphs, const int* nums_of_
             if (rc) return rc;
             remember_weights(model, ntens, cur, tens_elems);
         }
-        rc = flowgnn_group_set_batch(grp, g1 - g, nums_of_nodes + g, nums_of_edges + g, node_feature + noff * 9,
-                                     edge_list ? edge_list + eoff * 2 : nullptr, edge_attr ? edge_attr + eoff * 3 : nullptr,
-                                     node_eigen ? node_eigen + noff * 4 : nullptr);
-        if (rc) return rc;
-        rc = flowgnn_group_run(grp);
-        if (rc) return rc;
-        rc = flowgnn_group_get_results(grp, out + (size_t)g * num_tasks);
-        if (rc) return rc;
+        // ranges per engine: by the size of the host arrays (~48 MB per range, at most 8 per engine); a small batch is ONE range on
+        // one engine (cutting it would only add launches and half-empty tiles)
+        const int n_eng = flowgnn_group_size(grp);
+        int chunks = g_entry_pipeline;
+        bool whole = false;
+        if (chunks == 0) {
+            const double bytes = (double)n * (36.0 + (node_eigen ? 16.0 : 0.0)) + (double)m * (8.0 + (edge_attr ? 12.0 : 0.0));
+            const int want = (int)(bytes / 48.0e6);  // ranges in all
+            whole = want < 2 && (int)g_entry_devices.size() == 1;
+            chunks = (want + n_eng - 1) / n_eng;
+            if (chunks < 1) chunks = 1;
+            if (chunks > 8) chunks = 8;
+        }
+        if (whole) {  // everything on engine 0
+            flowgnn_engine* e0 = flowgnn_group_engine(grp, 0);
+            rc = flowgnn_set_batch(e0, g1 - g, nums_of_nodes + g, nums_of_edges + g, node_feature + noff * 9,
+                                   edge_list ? edge_list + eoff * 2 : nullptr, edge_attr ? edge_attr + eoff * 3 : nullptr,
+                                   node_eigen ? node_eigen + noff * 4 : nullptr);
+            if (!rc) rc = flowgnn_run(e0);
+            if (!rc) rc = flowgnn_get_results(e0, out + (size_t)g * num_tasks);
+            if (rc) { grp->err = flowgnn_last_error(e0); return rc; }
+        } else {
+            rc = flowgnn_group_compute(grp, g1 - g, nums_of_nodes + g, nums_of_edges + g, node_feature + noff * 9,
+                                       edge_list ? edge_list + eoff * 2 : nullptr, edge_attr ? edge_attr + eoff * 3 : nullptr,
+                                       node_eigen ? node_eigen + noff * 4 : nullptr, out + (size_t)g * num_tasks, chunks);
+            if (rc) return rc;
+        }
         noff += n;
         eoff += m;
         g = g1;

@@ -280,6 +280,17 @@ class EngineGroup:
         self.run()
         return self.results()
 
+    def compute(self, batch: GraphBatch, chunks_per_engine: int = 1) -> np.ndarray:
+        """flowgnn_group_compute: the host batch cut into size x chunks_per_engine ranges, engine i taking ranges i, i + size, ...
+        (set_batch, run, results) so that one engine's host -> device copies overlap the others' kernels."""
+        nn, ne = _i32(batch.nums_of_nodes), _i32(batch.nums_of_edges)
+        nf, el, ea = _i32(batch.node_feature), _i32(batch.edge_list), _i32(batch.edge_attr)
+        eig = None if batch.node_eigen is None else _f32(batch.node_eigen)
+        out = np.empty(batch.num_graphs * self.num_tasks, dtype=np.float32)
+        self._check(self.lib.flowgnn_group_compute(self._h, batch.num_graphs, _pi(nn), _pi(ne), _pi(nf), _pi(el), _pi(ea), _pf(eig), _pf(out),
+                                                   int(chunks_per_engine)), "flowgnn_group_compute")
+        return out.reshape(batch.num_graphs, self.num_tasks) if self.num_tasks > 1 else out
+
 
 def shard_ranges_c(nums_of_nodes, nums_of_edges, parts: int):
     """flowgnn_shard_ranges (the C ABI's cut by cumulative node + edge count); pure host code, no GPU needed."""
@@ -298,6 +309,13 @@ def entry_set_devices(devices):
     rc = _lib.load().flowgnn_entry_set_devices(len(ids), _pi(ids))
     if rc:
         raise FlowGNNError(rc, "flowgnn_entry_set_devices")
+
+
+def entry_set_pipeline(chunks_per_engine: int):
+    """Ranges per engine of the entry points' host-array pipeline (flowgnn.h: flowgnn_entry_set_pipeline; 0 = by size, 1 = off)."""
+    rc = _lib.load().flowgnn_entry_set_pipeline(int(chunks_per_engine))
+    if rc:
+        raise FlowGNNError(rc, "flowgnn_entry_set_pipeline")
 
 
 def entry_set_option(model: str, key: str, value):

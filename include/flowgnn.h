@@ -174,8 +174,13 @@ int GAT_compute_graphs(int num_graphs, int* nums_of_nodes, int* nums_of_edges,
  *     thread per listed device (a device may be listed twice); `out` is filled in job order.  Default: device 0, or the list in
  *     the environment variable FLOWGNN_DEVICES (e.g. "0,1,2,3,4,5,6,7") read at the first call.
  *  flowgnn_entry_set_option: flowgnn_set_option for the engines behind the entry points of `model` (FLOWGNN_MODEL_*).
+ *  flowgnn_entry_set_pipeline: the entry points take HOST arrays, so a large batch is cut into several ranges per engine and an
+ *     engine's host -> device copy of its next range runs under the other engines' kernels (flowgnn_group_compute); with ONE listed
+ *     device the entry points keep two engines on it for that.  0 (default): ranges of ~48 MB of host arrays, at most 8 per
+ *     engine, small batches uncut on one engine; k >= 1: exactly k ranges per engine (1 = no pipelining, one engine per device).
  */
 int flowgnn_entry_set_devices(int n_devices, const int* device_ids);
+int flowgnn_entry_set_pipeline(int chunks_per_engine);
 int flowgnn_entry_set_option(int model, const char* key, double value);
 
 /* =====================================================================
@@ -352,6 +357,11 @@ int flowgnn_group_shards(const flowgnn_group* g, int* cuts /* [size + 1] */);
 int flowgnn_group_run(flowgnn_group* g);
 int flowgnn_group_sync(flowgnn_group* g);
 int flowgnn_group_get_results(flowgnn_group* g, float* out_host);
+/* set_batch + run + get_results for a batch in HOST memory, cut into size x chunks_per_engine ranges; engine i takes ranges
+ * i, i + size, ... in turn, so that one engine's copies overlap the others' kernels.  out_host: [num_graphs][NUM_TASK]. */
+int flowgnn_group_compute(flowgnn_group* g, int num_graphs, const int* nums_of_nodes, const int* nums_of_edges,
+                          const int* node_feature, const int* edge_list, const int* edge_attr, const float* node_eigen,
+                          float* out_host, int chunks_per_engine);
 
 /*
  * Debug / parity taps (device -> host copies; synchronise first).

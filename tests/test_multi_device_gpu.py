@@ -167,3 +167,32 @@ def test_dgn_default_kernel_on_two_engines_is_toleranced(oracle):
     scale = max(1.0, float(np.abs(want).max()))
     assert np.allclose(one, two, rtol=1e-5, atol=1e-5 * scale)
     assert np.allclose(two, want, rtol=2e-4, atol=2e-3 * scale)
+
+
+def test_group_compute_pipelines_ranges_and_matches_the_single_engine(oracle):
+    """flowgnn_group_compute: the host batch cut into size x chunks ranges, engine i taking ranges i, i + size, ... (copy of one
+    range under the kernels of another).  Same logits as one engine on the whole batch -- bit for bit on GIN (graphs are
+    independent and every range stays on the resident kernel), in job order, for ragged cuts, for more ranges than graphs, and
+    through the entry points with every pipeline setting."""
+    from flowgnn_amd import EngineGroup, compute_graphs, entry_set_pipeline
+    w = weights.synth_gin_weights(7)
+    b = gp.synth_molhiv_batch(6000, seed=77)
+    ref = Engine("GIN", device=0)
+    ref.set_weights(w)
+    want = ref.forward(b).copy()
+    ref.close()
+    for engines, chunks in ((1, 3), (2, 1), (2, 4), (3, 2)):
+        grp = EngineGroup("GIN", [0] * engines)
+        grp.set_weights(w)
+        got = grp.compute(b, chunks)
+        assert np.array_equal(got, want), (engines, chunks, np.abs(got - want).max())
+        small = b.slice(0, 3)  # fewer graphs than ranges: empty ranges are skipped (one-graph ranges pack below the resident kernel's
+        assert np.allclose(grp.compute(small, chunks), want[:3], rtol=1e-5, atol=1e-5)  # fill threshold: per-layer kernels, last-bit differences)
+        assert np.array_equal(grp.compute(b, chunks), want)  # engines re-used with other sizes
+        grp.close()
+    try:
+        for setting in (0, 1, 2, 5):
+            entry_set_pipeline(setting)
+            assert np.array_equal(compute_graphs("GIN", b, [w]), want), setting
+    finally:
+        entry_set_pipeline(0)
