@@ -554,6 +554,18 @@ def main():
         }
         if balance is not None:
             line["shard_balance"] = balance
+        if world == 1 and not qmode:
+            # the drop-in symbol itself with HOST arrays in the clock (validation, tile packing, PCIe copies, kernels, logits back):
+            # reported beside `value`, never as `value`
+            from flowgnn_amd import compute_graphs
+            ts = []
+            for _ in range(3):
+                t0 = time.perf_counter()
+                out_entry = compute_graphs(args.model, batch, [w])
+                ts.append(time.perf_counter() - t0)
+            line["entry_point_host_arrays"] = {"symbol": ("GIN" if args.model == "GIN-VN" else args.model) + "_compute_graphs", "ms": min(ts) * 1e3,
+                                               "value": G / min(ts), "unit": "graphs/s",
+                                               "matches_timed_logits": bool(np.allclose(out_entry, out_local, rtol=1e-5, atol=1e-5))}
         want = None
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"], want = cpu_baseline(args.model, batch, w, numeric=args.numeric)
