@@ -789,7 +789,8 @@ public:
             {
                 ProfScope p(prof, "gin_resident", s);  // all five layers + readout of every half-tile
                 launch_gin_pp(db.h[0], db.csr.row_ptr, db.csr.src, db.csr.ecode, d_pp_tables_, d_pp_pieces_, d_pb_, gt.sub,
-                              reinterpret_cast<uint8_t*>(perm_.p), db.b.node_off, db.out, gt.n_sub, db.range_flag, d_head_, s, resident_prof_);
+                              reinterpret_cast<uint8_t*>(perm_.p), db.b.node_off, db.out, gt.n_sub, db.range_flag, d_head_, s, resident_prof_,
+                              pingpong_waves_);
             }
             if (gt.n_big > 0) {  // graphs of 129..256 nodes (or 641..1280 edges): one full tile each on the eight-wave resident kernel
                 ProfScope p(prof, "gin_resident_big", s);
@@ -896,6 +897,7 @@ public:
         resident_min_fill_ = o.num("gin_resident_min_fill");
         tile_build_ = o.i("gin_tile_build");
         pingpong_ = o.on("gin_pingpong");
+        pingpong_waves_ = o.i("gin_pingpong") == 2 ? 16 : 8;  // 2: the sixteen-wave form (eight waves per half, one column tile each)
         head_fold_ = o.on("gin_head_fold");
     }
     void set_exact(bool on) override { exact_ = on; }
@@ -961,6 +963,7 @@ private:
     GrowBufI enc_idx_;  // one-pass path: four table-row numbers per node (8 B), written by gin_tile_build_kernel
     float* d_enc_tab_ = nullptr;  // ... and the pre-combined encoder table they index
     bool h0_in_hbm_ = false;      // db.h[0] holds h_0 of the resident batch (false after a one-pass run)
+    int pingpong_waves_ = 8;
     bool pingpong_ = false;       // gin_pingpong = 1: gin_pp_kernel (two half-tiles per CU half a layer out of phase; measured slower)
     uint8_t* d_pp_pieces_ = nullptr;  // weight pieces of gin_pp_kernel
     float* d_pp_tables_ = nullptr;    // ... and its half tables

@@ -52,7 +52,7 @@ void gin_pp_pack_layer(const uint8_t* resident_layer /* gin_resident_pack_layer'
 void gin_pp_pack_tables(const float* ecomb_all /* [5][60][100] */, float* out);
 void launch_gin_pp(const float* h0, const int* row_ptr, const int* src, const uint8_t* ecode, const float* tables, const uint8_t* pieces,
                    const float* pool_b, const int* sub_tiles /* [n_sub][4] */, uint8_t* sub_desc, const int* node_off, float* out, int n_sub,
-                   int* range_flag, const float* head_u, hipStream_t s, bool prof = false);
+                   int* range_flag, const float* head_u, hipStream_t s, bool prof = false, int waves = 8);
 
 // what the one-pass tile loader needs (launch_gin_resident, tb != null): the caller's arrays, the per-node table-row numbers it writes
 // (8 B per node) and the pre-combined encoder table (gin_resident_pack_enc_table); err = the engine's validation flag

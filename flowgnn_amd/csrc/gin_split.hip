@@ -1520,7 +1520,7 @@ constexpr int PP_SUB = 7;                     // sub-steps per gather pass (2 pa
 // descriptor of a half-tile (as gin_tile_prep_kernel's, for 128 rows / 8 column tiles over the 4 waves of a half): thread r = row r
 __global__ __launch_bounds__(128) void gin_pp_prep_kernel(const int* __restrict__ row_ptr, const int* __restrict__ src,
                                                           const uint8_t* __restrict__ ecode, const int4* __restrict__ tiles,
-                                                          uint8_t* __restrict__ desc, int n_tiles) {
+                                                          uint8_t* __restrict__ desc, int n_tiles, int ntc) {
     constexpr int NKEY = 18;
     __shared__ int s_cnt[2][NKEY];
     const int tile = blockIdx.x;
@@ -1565,14 +1565,19 @@ __global__ __launch_bounds__(128) void gin_pp_prep_kernel(const int* __restrict_
         }
     const int pos = below + mine;           // rank in (decreasing in-degree, row) order, 0..127
     const int kt = pos >> 4, j = pos & 15;  // column tile kt (0 = longest rows)
+    if (ntc == 1) {  // eight waves per half, one column tile each: wave kt owns column tile kt
+        d[PP_DESC_PERM + pos] = (uint8_t)r;
+        return;
+    }
     const int w4 = kt < 4 ? kt : 7 - kt, nt = kt < 4 ? 0 : 1;  // snake over the half's four waves
     d[PP_DESC_PERM + w4 * 32 + nt * 16 + j] = (uint8_t)r;
 }
 
 #define PP_LD(off) (*reinterpret_cast<const uint4_t*>(wb + (off) + lane * 16))
 // one W2 piece: acc2[nt][t] += W2 frag(t) x relu(hidden) of the W1 piece before it (7 units of 6 MFMAs, fragments one unit ahead)
-template <bool PACKED>
-__device__ __forceinline__ void pp_w2(const char* wb, int lane, const uint4_t (&hb_hi)[2], const uint4_t (&hb_lo)[2], float4_t (&acc2)[2][GS_T2]) {
+// NTC = column tiles (of 16 rows) per wave: 2 in the eight-wave workgroup (four waves per half), 1 in the sixteen-wave one (eight per half)
+template <bool PACKED, int NTC>
+__device__ __forceinline__ void pp_w2(const char* wb, int lane, const uint4_t (&hb_hi)[NTC], const uint4_t (&hb_lo)[NTC], float4_t (&acc2)[NTC][GS_T2]) {
     if constexpr (PACKED) {  // hidden units 192..199: one MFMA per output tile and column tile (hb_hi holds the packed operand)
         uint4_t p[GS_T2];
 #pragma unroll
@@ -1580,18 +1585,18 @@ __device__ __forceinline__ void pp_w2(const char* wb, int lane, const uint4_t (&
 #pragma unroll
         for (int t = 0; t < GS_T2; t++) {
             acc2[0][t] = GS_MFMA16(p[t], hb_hi[0], acc2[0][t]);
-            acc2[1][t] = GS_MFMA16(p[t], hb_hi[1], acc2[1][t]);
+            if constexpr (NTC == 2) acc2[NTC - 1][t] = GS_MFMA16(p[t], hb_hi[NTC - 1], acc2[NTC - 1][t]);
         }
     } else {
         uint4_t f0[2], f1[2];
 #define PP_U2_LOAD(F, T) F[0] = PP_LD((2 * (T)) * 1024); F[1] = PP_LD((2 * (T) + 1) * 1024);
-#define PP_U2_MFMA(F, T)                                          \
-    acc2[0][T] = GS_MFMA16(F[0], hb_hi[0], acc2[0][T]);           \
-    acc2[1][T] = GS_MFMA16(F[0], hb_hi[1], acc2[1][T]);           \
-    acc2[0][T] = GS_MFMA16(F[0], hb_lo[0], acc2[0][T]);           \
-    acc2[1][T] = GS_MFMA16(F[0], hb_lo[1], acc2[1][T]);           \
-    acc2[0][T] = GS_MFMA16(F[1], hb_hi[0], acc2[0][T]);           \
-    acc2[1][T] = GS_MFMA16(F[1], hb_hi[1], acc2[1][T]);
+#define PP_U2_MFMA(F, T)                                                                                    \
+    acc2[0][T] = GS_MFMA16(F[0], hb_hi[0], acc2[0][T]);                                                     \
+    if constexpr (NTC == 2) acc2[NTC - 1][T] = GS_MFMA16(F[0], hb_hi[NTC - 1], acc2[NTC - 1][T]);           \
+    acc2[0][T] = GS_MFMA16(F[0], hb_lo[0], acc2[0][T]);                                                     \
+    if constexpr (NTC == 2) acc2[NTC - 1][T] = GS_MFMA16(F[0], hb_lo[NTC - 1], acc2[NTC - 1][T]);           \
+    acc2[0][T] = GS_MFMA16(F[1], hb_hi[0], acc2[0][T]);                                                     \
+    if constexpr (NTC == 2) acc2[NTC - 1][T] = GS_MFMA16(F[1], hb_hi[NTC - 1], acc2[NTC - 1][T]);
         PP_U2_LOAD(f0, 0) GR_SB();
         PP_U2_LOAD(f1, 1) GR_SB(); PP_U2_MFMA(f0, 0) GR_SB();
         PP_U2_LOAD(f0, 2) GR_SB(); PP_U2_MFMA(f1, 1) GR_SB();
@@ -1608,24 +1613,24 @@ __device__ __forceinline__ void pp_w2(const char* wb, int lane, const uint4_t (&
 // one W1 piece: hidden tiles 2s (, 2s+1) = b1 + W1 a (K = 96 as three K-steps + the packed tail), then ReLU + split into the next W2
 // piece's B operands -- or (DOT: the folded last layer) dotted with their slice of u.  NTL 1, !DOT = the last W1 piece (hidden tile
 // 12): the packed operand of the packed W2 piece is built.
-template <int NTL, bool DOT>
-__device__ __forceinline__ void pp_w1(const char* wb, int lane, int g, const uint4_t (&in_hi)[2][3], const uint4_t (&in_lo)[2][3],
-                                      const uint4_t (&in_tb)[2], uint4_t (&hb_hi)[2], uint4_t (&hb_lo)[2], float& vmax,
-                                      const float* u_step, float (&dot)[2]) {
+template <int NTL, bool DOT, int NTC>
+__device__ __forceinline__ void pp_w1(const char* wb, int lane, int g, const uint4_t (&in_hi)[NTC][3], const uint4_t (&in_lo)[NTC][3],
+                                      const uint4_t (&in_tb)[NTC], uint4_t (&hb_hi)[NTC], uint4_t (&hb_lo)[NTC], float& vmax,
+                                      const float* u_step, float (&dot)[NTC]) {
     uint4_t f0[2], f1[2];
-    float4_t acc1[2];
+    float4_t acc1[NTC];
 #define PP_U1_LOAD(F, TL, KS) F[0] = PP_LD((TL) * 6144 + (2 * (KS)) * 1024); F[1] = PP_LD((TL) * 6144 + (2 * (KS) + 1) * 1024);
-#define PP_U1_MFMA1(F, KS)                                        \
-    acc1[0] = GS_MFMA16(F[0], in_hi[0][KS], acc1[0]);             \
-    acc1[1] = GS_MFMA16(F[0], in_hi[1][KS], acc1[1]);             \
-    acc1[0] = GS_MFMA16(F[0], in_lo[0][KS], acc1[0]);             \
-    acc1[1] = GS_MFMA16(F[0], in_lo[1][KS], acc1[1]);             \
-    acc1[0] = GS_MFMA16(F[1], in_hi[0][KS], acc1[0]);             \
-    acc1[1] = GS_MFMA16(F[1], in_hi[1][KS], acc1[1]);
+#define PP_U1_MFMA1(F, KS)                                                                                  \
+    acc1[0] = GS_MFMA16(F[0], in_hi[0][KS], acc1[0]);                                                       \
+    if constexpr (NTC == 2) acc1[NTC - 1] = GS_MFMA16(F[0], in_hi[NTC - 1][KS], acc1[NTC - 1]);             \
+    acc1[0] = GS_MFMA16(F[0], in_lo[0][KS], acc1[0]);                                                       \
+    if constexpr (NTC == 2) acc1[NTC - 1] = GS_MFMA16(F[0], in_lo[NTC - 1][KS], acc1[NTC - 1]);             \
+    acc1[0] = GS_MFMA16(F[1], in_hi[0][KS], acc1[0]);                                                       \
+    if constexpr (NTC == 2) acc1[NTC - 1] = GS_MFMA16(F[1], in_hi[NTC - 1][KS], acc1[NTC - 1]);
 #define PP_TAIL_LOAD(F, TL) F[0] = *reinterpret_cast<const uint4_t*>(wb + GRC_TAIL_OFF + (TL) * 512 + (lane & 31) * 16);
 #define PP_BIAS(TL) acc1[0] = *reinterpret_cast<const float4_t*>(wb + GRC_B1_OFF + (TL) * 64 + g * 16);
 #define PP_FINISH(TL)                                                                                     \
-    _Pragma("unroll") for (int nt = 0; nt < 2; nt++) {                                                    \
+    _Pragma("unroll") for (int nt = 0; nt < NTC; nt++) {                                                    \
         float4_t r = acc1[nt];                                                                            \
         r.x = gs_relu(r.x); r.y = gs_relu(r.y); r.z = gs_relu(r.z); r.w = gs_relu(r.w);                   \
         if constexpr (DOT) {                                                                              \
@@ -1641,22 +1646,22 @@ __device__ __forceinline__ void pp_w1(const char* wb, int lane, int g, const uin
     PP_U1_LOAD(f1, 0, 0)
     PP_BIAS(0)
     GR_SB();
-    acc1[1] = acc1[0];
+    if constexpr (NTC == 2) acc1[NTC - 1] = acc1[0];
     PP_U1_LOAD(f0, 0, 1) GR_SB(); PP_U1_MFMA1(f1, 0) GR_SB();
     PP_U1_LOAD(f1, 0, 2) GR_SB(); PP_U1_MFMA1(f0, 1) GR_SB();
     PP_TAIL_LOAD(f0, 0) GR_SB(); PP_U1_MFMA1(f1, 2) GR_SB();
     if constexpr (NTL == 2) { PP_U1_LOAD(f1, 1, 0) GR_SB(); }
     acc1[0] = GS_MFMA16(f0[0], in_tb[0], acc1[0]);
-    acc1[1] = GS_MFMA16(f0[0], in_tb[1], acc1[1]);
+    if constexpr (NTC == 2) acc1[NTC - 1] = GS_MFMA16(f0[0], in_tb[NTC - 1], acc1[NTC - 1]);
     if constexpr (NTL == 2) {
         PP_FINISH(0)
         PP_BIAS(1)
-        acc1[1] = acc1[0];
+        if constexpr (NTC == 2) acc1[NTC - 1] = acc1[0];
         PP_U1_LOAD(f0, 1, 1) GR_SB(); PP_U1_MFMA1(f1, 0) GR_SB();
         PP_U1_LOAD(f1, 1, 2) GR_SB(); PP_U1_MFMA1(f0, 1) GR_SB();
         PP_TAIL_LOAD(f0, 1) GR_SB(); PP_U1_MFMA1(f1, 2) GR_SB();
         acc1[0] = GS_MFMA16(f0[0], in_tb[0], acc1[0]);
-        acc1[1] = GS_MFMA16(f0[0], in_tb[1], acc1[1]);
+        if constexpr (NTC == 2) acc1[NTC - 1] = GS_MFMA16(f0[0], in_tb[NTC - 1], acc1[NTC - 1]);
         PP_FINISH(1)
     } else if constexpr (DOT) {
         PP_FINISH(0)
@@ -1665,7 +1670,7 @@ __device__ __forceinline__ void pp_w1(const char* wb, int lane, int g, const uin
         // lanes g = 0 / 1 hold hidden units 192..195 / 196..199 (hi in hb_hi.xy, lo in hb_lo.xy); the packed operand of the packed
         // W2 piece is  g = 0, 1: [hi, lo] (own)   g = 2, 3: [hi of lane - 32, 0]
 #pragma unroll
-        for (int nt = 0; nt < 2; nt++) {
+        for (int nt = 0; nt < NTC; nt++) {
             const uint32_t ox = __shfl(hb_hi[nt].x, lane & 31, 64), oy = __shfl(hb_hi[nt].y, lane & 31, 64);
             const bool own = g < 2;
             hb_hi[nt] = own ? (uint4_t){hb_hi[nt].x, hb_hi[nt].y, hb_lo[nt].x, hb_lo[nt].y} : (uint4_t){ox, oy, 0u, 0u};
@@ -1703,12 +1708,15 @@ __device__ __forceinline__ void pp_dma_slice(const void* gsrc, void* ldst, int b
 // One pass (features 0..47 or 48..99) of the gather slot: PP_SUB sub-steps, each = loader duties, then up to `tps` in-edges of each of
 // this wave's 2 x 16 rows (CSR order), then the sub-step's barrier.
 #define PP_STAMP(K) if constexpr (PROF) { const unsigned long long t_ = clock64(); tacc[K] += t_ - tp; tp = t_; }
-template <int PASS, bool PROF>
-__device__ __forceinline__ void pp_gather_pass(float (&bq)[2][25], const int (&e_beg)[2], const int (&e_end)[2], const uint16_t* s_edge,
+template <int PASS, bool PROF, int NTC>
+__device__ __forceinline__ void pp_gather_pass(float (&bq)[NTC][25], const int (&e_beg)[NTC], const int (&e_end)[NTC], const uint16_t* s_edge,
                                                const float* s_h, const float* s_tab, int tps, int p, int lm, const uint8_t* pieces_m,
                                                const uint8_t* pieces_n, const float* tbl_h2, const float* tbl_h1n, char* s_cb0, char* s_cb1,
                                                char* s_tb0, char* s_tb1, int w4, int lane, int g, unsigned long long (&tacc)[8], unsigned long long& tp) {
-    int e_cur[2] = {e_beg[0], e_beg[1]};
+    constexpr int NWH = 8 / NTC;  // waves per half: the loader's pieces are dealt over them
+    int e_cur[NTC];
+#pragma unroll
+    for (int nt = 0; nt < NTC; nt++) e_cur[nt] = e_beg[nt];
 #pragma unroll 1
     for (int ss = 0; ss < PP_SUB; ss++) {
         const int i = PASS * PP_SUB + ss;
@@ -1716,18 +1724,18 @@ __device__ __forceinline__ void pp_gather_pass(float (&bq)[2][25], const int (&e
         // loader: the multiplying half's next piece (the folded last layer reads its W1 pieces only: the even ones) ...
         if (i + 1 < PP_PIECES) {
             if (p > 0 && (lm != 4 || ((i + 1) & 1) == 0))
-                pp_dma(pieces_m + (size_t)(i + 1) * PP_PIECE, ((i + 1) & 1) ? s_cb1 : s_cb0, ((i + 1) & 1) ? PP_PIECE : PP_HDR_OFF + 512, w4, 4, lane);
+                pp_dma(pieces_m + (size_t)(i + 1) * PP_PIECE, ((i + 1) & 1) ? s_cb1 : s_cb0, ((i + 1) & 1) ? PP_PIECE : PP_HDR_OFF + 512, w4, NWH, lane);
         } else {
-            pp_dma(pieces_n, s_cb0, PP_HDR_OFF + 512, w4, 4, lane);  // piece 0 of the next phase's layer
+            pp_dma(pieces_n, s_cb0, PP_HDR_OFF + 512, w4, NWH, lane);  // piece 0 of the next phase's layer
         }
         // ... and the half tables: even phases bring in the second half of this layer's table during pass 0 (needed in pass 1 of this
         // phase and of the next), odd phases the first half of the NEXT layer's table during pass 1
-        if (PASS == 0 && (p & 1) == 0) pp_dma_slice(tbl_h2, s_tb1, PP_TBL_BYTES, 2 * ss, 2, w4, 4, lane);
-        if (PASS == 1 && (p & 1) == 1) pp_dma_slice(tbl_h1n, s_tb0, PP_TBL_BYTES, 2 * ss, 2, w4, 4, lane);
+        if (PASS == 0 && (p & 1) == 0) pp_dma_slice(tbl_h2, s_tb1, PP_TBL_BYTES, 2 * ss, 2, w4, NWH, lane);
+        if (PASS == 1 && (p & 1) == 1) pp_dma_slice(tbl_h1n, s_tb0, PP_TBL_BYTES, 2 * ss, 2, w4, NWH, lane);
         PP_STAMP(0)
         for (int t = 0; t < tps; t++) {
 #pragma unroll
-            for (int nt = 0; nt < 2; nt++) {
+            for (int nt = 0; nt < NTC; nt++) {
                 if (e_cur[nt] < e_end[nt]) {
                     const unsigned wd = s_edge[e_cur[nt]];
                     const unsigned u = wd >> 6, code = wd & 63u;
@@ -1761,35 +1769,37 @@ __device__ __forceinline__ void pp_gather_pass(float (&bq)[2][25], const int (&e
 
 #define PP_SUBSTEP_END() PP_STAMP(4) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); PP_STAMP(5) __syncthreads(); PP_STAMP(6)
 // multiply slot of layers 0..3: 14 pieces through the two piece buffers (even pieces s_cb0, odd s_cb1), then h' in place
-template <bool PROF>
-__device__ __forceinline__ void pp_multiply(const char* s_cb0, const char* s_cb1, float* s_h, const int (&row)[2], const uint4_t (&in_hi)[2][3],
-                                            const uint4_t (&in_lo)[2][3], const uint4_t (&in_tb)[2], float& vmax, int lane, int g,
+template <bool PROF, int NTC>
+__device__ __forceinline__ void pp_multiply(const char* s_cb0, const char* s_cb1, float* s_h, const int (&row)[NTC], const uint4_t (&in_hi)[NTC][3],
+                                            const uint4_t (&in_lo)[NTC][3], const uint4_t (&in_tb)[NTC], float& vmax, int lane, int g,
                                             unsigned long long (&tacc)[8], unsigned long long& tp) {
-    float4_t acc2[2][GS_T2];
-    uint4_t hb_hi[2], hb_lo[2];
-    float dot[2] = {0.0f, 0.0f};
+    float4_t acc2[NTC][GS_T2];
+    uint4_t hb_hi[NTC], hb_lo[NTC];
+    float dot[NTC];
+#pragma unroll
+    for (int nt = 0; nt < NTC; nt++) dot[nt] = 0.0f;
 #pragma unroll
     for (int t2 = 0; t2 < GS_T2; t2++) {
         const float4 b = *reinterpret_cast<const float4*>(s_cb0 + PP_HDR_OFF + (16 * t2 + 4 * g) * 4);
 #pragma unroll
-        for (int nt = 0; nt < 2; nt++) acc2[nt][t2] = (float4_t){b.x, b.y, b.z, b.w};
+        for (int nt = 0; nt < NTC; nt++) acc2[nt][t2] = (float4_t){b.x, b.y, b.z, b.w};
     }
     const float oscale = *reinterpret_cast<const float*>(s_cb0 + PP_HDR_OFF + 112 * 4);
 #pragma unroll
-    for (int nt = 0; nt < 2; nt++) { hb_hi[nt] = (uint4_t){0, 0, 0, 0}; hb_lo[nt] = (uint4_t){0, 0, 0, 0}; }
+    for (int nt = 0; nt < NTC; nt++) { hb_hi[nt] = (uint4_t){0, 0, 0, 0}; hb_lo[nt] = (uint4_t){0, 0, 0, 0}; }
 #pragma unroll
     for (int st = 0; st < 6; st++) {
-        pp_w1<2, false>(s_cb0, lane, g, in_hi, in_lo, in_tb, hb_hi, hb_lo, vmax, nullptr, dot);
+        pp_w1<2, false, NTC>(s_cb0, lane, g, in_hi, in_lo, in_tb, hb_hi, hb_lo, vmax, nullptr, dot);
         PP_SUBSTEP_END()
-        pp_w2<false>(s_cb1, lane, hb_hi, hb_lo, acc2);
+        pp_w2<false, NTC>(s_cb1, lane, hb_hi, hb_lo, acc2);
         PP_SUBSTEP_END()
     }
-    pp_w1<1, false>(s_cb0, lane, g, in_hi, in_lo, in_tb, hb_hi, hb_lo, vmax, nullptr, dot);
+    pp_w1<1, false, NTC>(s_cb0, lane, g, in_hi, in_lo, in_tb, hb_hi, hb_lo, vmax, nullptr, dot);
     PP_SUBSTEP_END()
-    pp_w2<true>(s_cb1, lane, hb_hi, hb_lo, acc2);
+    pp_w2<true, NTC>(s_cb1, lane, hb_hi, hb_lo, acc2);
     // h' back into the half-tile, in place (this half's next gather reads it after the barrier)
 #pragma unroll
-    for (int nt = 0; nt < 2; nt++) {
+    for (int nt = 0; nt < NTC; nt++) {
         float* rw = s_h + row[nt] * GS_D;
 #pragma unroll
         for (int t2 = 0; t2 < GS_T2; t2++) {
@@ -1806,26 +1816,27 @@ __device__ __forceinline__ void pp_multiply(const char* s_cb0, const char* s_cb1
 
 // multiply slot of the last layer, readout folded through its second linear layer: the seven W1 pieces only (hidden tiles dotted with
 // u = W2^T w), every other sub-step empty; the next half-tile's rows and descriptor come in, a slice per sub-step
-template <bool PROF>
-__device__ __forceinline__ void pp_multiply_last(const char* s_cb0, const char* s_cb1, float* s_dot, const float* s_u, const int (&row)[2],
-                                                 const uint4_t (&in_hi)[2][3], const uint4_t (&in_lo)[2][3], const uint4_t (&in_tb)[2], float& vmax,
+template <bool PROF, int NTC>
+__device__ __forceinline__ void pp_multiply_last(const char* s_cb0, const char* s_cb1, float* s_dot, const float* s_u, const int (&row)[NTC],
+                                                 const uint4_t (&in_hi)[NTC][3], const uint4_t (&in_lo)[NTC][3], const uint4_t (&in_tb)[NTC], float& vmax,
                                                  int lane, int g, bool has_next, const float* next_rows, float* s_h, int next_bytes,
                                                  const uint8_t* next_desc, char* s_desc, int w4, unsigned long long (&tacc)[8], unsigned long long& tp) {
     (void)s_cb1;
-    uint4_t hb_hi[2], hb_lo[2];
-    float dot[2] = {0.0f, 0.0f};
+    constexpr int NWH = 8 / NTC;
+    uint4_t hb_hi[NTC], hb_lo[NTC];
+    float dot[NTC];
 #pragma unroll
-    for (int nt = 0; nt < 2; nt++) { hb_hi[nt] = (uint4_t){0, 0, 0, 0}; hb_lo[nt] = (uint4_t){0, 0, 0, 0}; }
+    for (int nt = 0; nt < NTC; nt++) { dot[nt] = 0.0f; hb_hi[nt] = (uint4_t){0, 0, 0, 0}; hb_lo[nt] = (uint4_t){0, 0, 0, 0}; }
 #pragma unroll
     for (int st = 0; st < 7; st++) {
         // the rows and the descriptor of this half-tile are dead: the next one's come in (the descriptor not in the very first sub-step:
         // a wave of this half that is a few cycles behind may still be reading its column owners from it)
-        if (has_next) pp_dma_slice(next_rows, s_h, next_bytes, 8 * st, 4, w4, 4, lane);
-        if (st < 6) pp_w1<2, true>(s_cb0, lane, g, in_hi, in_lo, in_tb, hb_hi, hb_lo, vmax, s_u + 32 * st, dot);
-        else pp_w1<1, true>(s_cb0, lane, g, in_hi, in_lo, in_tb, hb_hi, hb_lo, vmax, s_u + 32 * st, dot);
+        if (has_next) pp_dma_slice(next_rows, s_h, next_bytes, 8 * st, 4, w4, NWH, lane);
+        if (st < 6) pp_w1<2, true, NTC>(s_cb0, lane, g, in_hi, in_lo, in_tb, hb_hi, hb_lo, vmax, s_u + 32 * st, dot);
+        else pp_w1<1, true, NTC>(s_cb0, lane, g, in_hi, in_lo, in_tb, hb_hi, hb_lo, vmax, s_u + 32 * st, dot);
         if (st == 6) {
 #pragma unroll
-            for (int nt = 0; nt < 2; nt++) {
+            for (int nt = 0; nt < NTC; nt++) {
                 float part = dot[nt];
                 part += __shfl_xor(part, 16, 64);
                 part += __shfl_xor(part, 32, 64);
@@ -1834,8 +1845,8 @@ __device__ __forceinline__ void pp_multiply_last(const char* s_cb0, const char* 
         }
         PP_SUBSTEP_END()
         if (has_next) {
-            pp_dma_slice(next_rows, s_h, next_bytes, 8 * st + 4, 4, w4, 4, lane);
-            if (st == 0) pp_dma(next_desc, s_desc, PP_DESC_BYTES, w4, 4, lane);
+            pp_dma_slice(next_rows, s_h, next_bytes, 8 * st + 4, 4, w4, NWH, lane);
+            if (st == 0) pp_dma(next_desc, s_desc, PP_DESC_BYTES, w4, NWH, lane);
         }
         PP_SUBSTEP_END()
     }
@@ -1852,8 +1863,8 @@ __device__ __forceinline__ PpTile pp_load_tile(const int4* __restrict__ tiles, i
     return t;
 }
 
-template <bool PROF>
-__global__ __launch_bounds__(512, 2) void gin_pp_kernel(const float* __restrict__ h0, const float* __restrict__ tbl_all /* [5][2][60][52] */,
+template <bool PROF, int NTC>
+__global__ __launch_bounds__(1024 / NTC) void gin_pp_kernel(const float* __restrict__ h0, const float* __restrict__ tbl_all /* [5][2][60][52] */,
                                                         const uint8_t* __restrict__ pieces_all /* [5][14][14336] */,
                                                         const float* __restrict__ pool_b, const int4* __restrict__ tiles,
                                                         const uint8_t* __restrict__ desc, const int* __restrict__ node_off,
@@ -1875,7 +1886,8 @@ __global__ __launch_bounds__(512, 2) void gin_pp_kernel(const float* __restrict_
     __shared__ __attribute__((aligned(16))) float s_u[208];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int half = wave >> 2, w4 = wave & 3;
+    constexpr int NWH = 8 / NTC;  // waves per half; w4 = this wave's index inside its half
+    const int half = wave / NWH, w4 = wave % NWH;
     const int j = lane & 15, g = lane >> 4;
     float* s_h = half ? s_hB : s_hA;
     char* s_desc = half ? s_descB : s_descA;
@@ -1893,17 +1905,17 @@ __global__ __launch_bounds__(512, 2) void gin_pp_kernel(const float* __restrict_
     PpTile cur = pp_load_tile(tiles, T_mine > 0 ? tile_of(0) : -1, n_tiles);
     // prologue: every half brings in its first half-tile (rows + descriptor); half A the first half table of layer 0
     if (T_mine > 0) {
-        pp_dma(h0 + (size_t)cur.t0 * GS_D, s_h, ((cur.rows * GS_D * 4 + 15) >> 4) << 4, w4, 4, lane);
-        pp_dma(desc + (size_t)tile_of(0) * PP_DESC_BYTES, s_desc, PP_DESC_BYTES, w4, 4, lane);
+        pp_dma(h0 + (size_t)cur.t0 * GS_D, s_h, ((cur.rows * GS_D * 4 + 15) >> 4) << 4, w4, NWH, lane);
+        pp_dma(desc + (size_t)tile_of(0) * PP_DESC_BYTES, s_desc, PP_DESC_BYTES, w4, NWH, lane);
     }
-    if (half == 0) pp_dma(tbl_all, s_tb0, PP_TBL_BYTES, w4, 4, lane);
+    if (half == 0) pp_dma(tbl_all, s_tb0, PP_TBL_BYTES, w4, NWH, lane);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
     float vmax = 0.0f;
-    uint4_t in_hi[2][3], in_lo[2][3], in_tb[2];
+    uint4_t in_hi[NTC][3], in_lo[NTC][3], in_tb[NTC];
 #pragma unroll
-    for (int nt = 0; nt < 2; nt++) {
+    for (int nt = 0; nt < NTC; nt++) {
         in_tb[nt] = (uint4_t){0, 0, 0, 0};
 #pragma unroll
         for (int ks = 0; ks < 3; ks++) { in_hi[nt][ks] = (uint4_t){0, 0, 0, 0}; in_lo[nt][ks] = (uint4_t){0, 0, 0, 0}; }
@@ -1921,8 +1933,9 @@ __global__ __launch_bounds__(512, 2) void gin_pp_kernel(const float* __restrict_
         const int lm = p > 0 ? ((p - 1 + (p & 1)) % 10) >> 1 : 0;  // the layer multiplied in this phase (by half 1 - (p & 1)); p = 0: nobody multiplies
         if (readout_due) {
             // readout of the half-tile finished in the previous phase (GIN/src/finalize.cc:36-113): out[g] = mean_v(h5[v] . w) + b, node order
-            const int gi = done_tile.g0 + (int)(threadIdx.x & 255);
-            if ((threadIdx.x & 255) < PP_ROWS && gi < done_tile.g1) {
+            const int ti = (int)threadIdx.x - half * (NWH * 64);  // thread inside the half
+            const int gi = done_tile.g0 + ti;
+            if (ti < PP_ROWS && gi < done_tile.g1) {
                 const int n0 = node_off[gi], n1 = node_off[gi + 1];
                 float sum = 0.0f;
                 for (int v = n0; v < n1; v++) sum += s_dot[v - done_tile.t0];
@@ -1936,12 +1949,12 @@ __global__ __launch_bounds__(512, 2) void gin_pp_kernel(const float* __restrict_
             const uint16_t* s_rp = reinterpret_cast<const uint16_t*>(s_desc + PP_DESC_RP);
             const uint8_t* s_perm = reinterpret_cast<const uint8_t*>(s_desc + PP_DESC_PERM);
             const int rows_here = active ? cur.rows : 0;  // an idle half walks no edges and produces zero operands
-            float bq[2][25];
-            int e_beg[2], e_end[2], row[2];
+            float bq[NTC][25];
+            int e_beg[NTC], e_end[NTC], row[NTC];
             int dmax = 0;
 #pragma unroll
-            for (int nt = 0; nt < 2; nt++) {
-                row[nt] = s_perm[w4 * 32 + nt * 16 + j];
+            for (int nt = 0; nt < NTC; nt++) {
+                row[nt] = s_perm[w4 * (16 * NTC) + nt * 16 + j];
                 const bool valid = row[nt] < rows_here;
                 const int rr = valid ? row[nt] : 0;
                 e_beg[nt] = s_rp[rr];
@@ -1958,14 +1971,14 @@ __global__ __launch_bounds__(512, 2) void gin_pp_kernel(const float* __restrict_
             const float* tbl_h2 = tbl_all + ((size_t)lg * 2 + 1) * (PP_TBL_BYTES / 4);
             const float* tbl_h1n = tbl_all + ((size_t)((lg + 1) % 5) * 2) * (PP_TBL_BYTES / 4);
             PP_STAMP(7)
-            pp_gather_pass<0, PROF>(bq, e_beg, e_end, s_edge, s_h, reinterpret_cast<const float*>(s_tb0), tps, p, lm, pieces_m, pieces_n, tbl_h2, tbl_h1n,
+            pp_gather_pass<0, PROF, NTC>(bq, e_beg, e_end, s_edge, s_h, reinterpret_cast<const float*>(s_tb0), tps, p, lm, pieces_m, pieces_n, tbl_h2, tbl_h1n,
                                     s_cb0, s_cb1, s_tb0, s_tb1, w4, lane, g, tacc, tp);
-            pp_gather_pass<1, PROF>(bq, e_beg, e_end, s_edge, s_h, reinterpret_cast<const float*>(s_tb1), tps, p, lm, pieces_m, pieces_n, tbl_h2, tbl_h1n,
+            pp_gather_pass<1, PROF, NTC>(bq, e_beg, e_end, s_edge, s_h, reinterpret_cast<const float*>(s_tb1), tps, p, lm, pieces_m, pieces_n, tbl_h2, tbl_h1n,
                                     s_cb0, s_cb1, s_tb0, s_tb1, w4, lane, g, tacc, tp);
             // + (1 + eps) h[v], eps == 0, then the B operands of the first linear layer (as gr_layer) -- inside the phase's last sub-step:
             // after its barrier this half's other waves may already be overwriting the rows (next half-tile's DMA, h' in place)
 #pragma unroll
-            for (int nt = 0; nt < 2; nt++) {
+            for (int nt = 0; nt < NTC; nt++) {
                 if (row[nt] < rows_here) {
                     const float* hr = s_h + row[nt] * GS_D + 4 * g;
 #pragma unroll
@@ -2004,11 +2017,11 @@ __global__ __launch_bounds__(512, 2) void gin_pp_kernel(const float* __restrict_
             const int next_ord = q / 10 + 1;
             const bool has_next = active && last && next_ord < T_mine;
             const PpTile nxt = pp_load_tile(tiles, has_next ? tile_of(next_ord) : -1, n_tiles);
-            int row[2];
+            int row[NTC];
             {
                 const uint8_t* s_perm = reinterpret_cast<const uint8_t*>(s_desc + PP_DESC_PERM);
 #pragma unroll
-                for (int nt = 0; nt < 2; nt++) row[nt] = s_perm[w4 * 32 + nt * 16 + j];
+                for (int nt = 0; nt < NTC; nt++) row[nt] = s_perm[w4 * (16 * NTC) + nt * 16 + j];
             }
             PP_STAMP(7)
             if (!active) {
@@ -2016,10 +2029,10 @@ __global__ __launch_bounds__(512, 2) void gin_pp_kernel(const float* __restrict_
                 for (int i = 0; i < PP_PIECES; i++) __syncthreads();
                 PP_STAMP(6)
             } else if (!last) {
-                pp_multiply<PROF>(s_cb0, s_cb1, s_h, row, in_hi, in_lo, in_tb, vmax, lane, g, tacc, tp);
+                pp_multiply<PROF, NTC>(s_cb0, s_cb1, s_h, row, in_hi, in_lo, in_tb, vmax, lane, g, tacc, tp);
             } else {
                 const int nb = ((nxt.rows * GS_D * 4 + 15) >> 4) << 4;
-                pp_multiply_last<PROF>(s_cb0, s_cb1, s_dot, s_u, row, in_hi, in_lo, in_tb, vmax, lane, g, has_next, h0 + (size_t)nxt.t0 * GS_D, s_h, nb,
+                pp_multiply_last<PROF, NTC>(s_cb0, s_cb1, s_dot, s_u, row, in_hi, in_lo, in_tb, vmax, lane, g, has_next, h0 + (size_t)nxt.t0 * GS_D, s_h, nb,
                                        desc + (size_t)(has_next ? tile_of(next_ord) : 0) * PP_DESC_BYTES, s_desc, w4, tacc, tp);
                 readout_due = true;
                 done_tile = cur;
@@ -2028,8 +2041,9 @@ __global__ __launch_bounds__(512, 2) void gin_pp_kernel(const float* __restrict_
         }
     }
     if (readout_due) {  // (the barrier that closed the last phase made the terms visible)
-        const int gi = done_tile.g0 + (int)(threadIdx.x & 255);
-        if ((threadIdx.x & 255) < PP_ROWS && gi < done_tile.g1) {
+        const int ti = (int)threadIdx.x - half * (NWH * 64);
+        const int gi = done_tile.g0 + ti;
+        if (ti < PP_ROWS && gi < done_tile.g1) {
             const int n0 = node_off[gi], n1 = node_off[gi + 1];
             float sum = 0.0f;
             for (int v = n0; v < n1; v++) sum += s_dot[v - done_tile.t0];
@@ -2041,8 +2055,8 @@ __global__ __launch_bounds__(512, 2) void gin_pp_kernel(const float* __restrict_
     }
     if constexpr (PROF) {  // per-wave totals in shader cycles (s_memtime)
         if (lane == 0) {
-            for (int i = 0; i < 8; i++) prof_out[((size_t)blockIdx.x * 8 + wave) * 9 + i] = tacc[i];
-            prof_out[((size_t)blockIdx.x * 8 + wave) * 9 + 8] = clock64() - tk0;
+            for (int i = 0; i < 8; i++) prof_out[((size_t)blockIdx.x * (2 * NWH) + wave) * 9 + i] = tacc[i];
+            prof_out[((size_t)blockIdx.x * (2 * NWH) + wave) * 9 + 8] = clock64() - tk0;
         }
     }
 }
@@ -2301,30 +2315,34 @@ void gin_pp_pack_tables(const float* ecomb_all, float* out) {
 int gin_pp_desc_bytes() { return PP_DESC_BYTES; }
 void launch_gin_pp(const float* h0, const int* row_ptr, const int* src, const uint8_t* ecode, const float* tables, const uint8_t* pieces,
                    const float* pool_b, const int* sub_tiles, uint8_t* sub_desc, const int* node_off, float* out, int n_sub, int* range_flag,
-                   const float* head_u, hipStream_t s, bool prof) {
+                   const float* head_u, hipStream_t s, bool prof, int waves) {
     if (n_sub <= 0) return;
     const int4* tiles = reinterpret_cast<const int4*>(sub_tiles);
-    gin_pp_prep_kernel<<<n_sub, 128, 0, s>>>(row_ptr, src, ecode, tiles, sub_desc, n_sub);
-    const int grid = n_sub < 256 ? n_sub : 256;  // persistent: one 8-wave workgroup (two halves) per CU
+    const int ntc = waves == 16 ? 1 : 2;  // sixteen waves: eight per half, one column tile each; eight: four per half, two each
+    gin_pp_prep_kernel<<<n_sub, 128, 0, s>>>(row_ptr, src, ecode, tiles, sub_desc, n_sub, ntc);
+    const int grid = n_sub < 256 ? n_sub : 256;  // persistent: one workgroup (two halves) per CU
     if (!prof) {
-        gin_pp_kernel<false><<<grid, 512, 0, s>>>(h0, tables, pieces, pool_b, tiles, sub_desc, node_off, out, n_sub, range_flag, head_u, nullptr);
+        if (ntc == 1) gin_pp_kernel<false, 1><<<grid, 1024, 0, s>>>(h0, tables, pieces, pool_b, tiles, sub_desc, node_off, out, n_sub, range_flag, head_u, nullptr);
+        else gin_pp_kernel<false, 2><<<grid, 512, 0, s>>>(h0, tables, pieces, pool_b, tiles, sub_desc, node_off, out, n_sub, range_flag, head_u, nullptr);
         return;
     }
     // development aid (option gin_resident_prof): where the waves' cycles go, printed per launch (synchronises!)
     unsigned long long* d = nullptr;
-    const size_t cnt = (size_t)grid * 8 * 9;
+    const int nwv = ntc == 1 ? 16 : 8;
+    const size_t cnt = (size_t)grid * nwv * 9;
     if (hipMalloc((void**)&d, cnt * 8) != hipSuccess) return;
     (void)hipMemsetAsync(d, 0, cnt * 8, s);
-    gin_pp_kernel<true><<<grid, 512, 0, s>>>(h0, tables, pieces, pool_b, tiles, sub_desc, node_off, out, n_sub, range_flag, head_u, d);
+    if (ntc == 1) gin_pp_kernel<true, 1><<<grid, 1024, 0, s>>>(h0, tables, pieces, pool_b, tiles, sub_desc, node_off, out, n_sub, range_flag, head_u, d);
+    else gin_pp_kernel<true, 2><<<grid, 512, 0, s>>>(h0, tables, pieces, pool_b, tiles, sub_desc, node_off, out, n_sub, range_flag, head_u, d);
     std::vector<unsigned long long> hbuf(cnt);
     (void)hipStreamSynchronize(s);
     (void)hipMemcpy(hbuf.data(), d, cnt * 8, hipMemcpyDeviceToHost);
     (void)hipFree(d);
     double tot[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     for (size_t i = 0; i < cnt; i++) tot[i % 9] += (double)hbuf[i];
-    const double nw = (double)grid * 8;
-    fprintf(stderr, "[gin_pp prof] half-tiles %d grid %d | per wave, kcycles: gather slot: loader %.0f  walk+finish %.0f  dma wait %.0f  barrier %.0f | multiply slot: compute %.0f  dma wait %.0f  barrier %.0f | other %.0f | kernel %.0f\n",
-            n_sub, grid, tot[0] / nw / 1e3, tot[1] / nw / 1e3, tot[2] / nw / 1e3, tot[3] / nw / 1e3, tot[4] / nw / 1e3, tot[5] / nw / 1e3, tot[6] / nw / 1e3,
+    const double nw = (double)grid * nwv;
+    fprintf(stderr, "[gin_pp prof] half-tiles %d grid %d waves %d | per wave, kcycles: gather slot: loader %.0f  walk+finish %.0f  dma wait %.0f  barrier %.0f | multiply slot: compute %.0f  dma wait %.0f  barrier %.0f | other %.0f | kernel %.0f\n",
+            n_sub, grid, nwv, tot[0] / nw / 1e3, tot[1] / nw / 1e3, tot[2] / nw / 1e3, tot[3] / nw / 1e3, tot[4] / nw / 1e3, tot[5] / nw / 1e3, tot[6] / nw / 1e3,
             tot[7] / nw / 1e3, tot[8] / nw / 1e3);
 }
 

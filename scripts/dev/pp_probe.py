@@ -7,7 +7,7 @@ w = weights.synth_gin_weights(7)
 for g in [int(a) for a in sys.argv[1:]] or [40, 300, 5000]:
     b = gp.synth_molhiv_batch(g, seed=1234)
     outs = {}
-    for pp in (1, 0):
+    for pp in (2, 1, 0):
         e = Engine("GIN", 0, options={"gin_pingpong": pp, "gin_tile_build": 0, "gin_resident_min_fill": 0})
         e.set_weights(w)
         e.set_batch(b)
@@ -23,5 +23,6 @@ for g in [int(a) for a in sys.argv[1:]] or [40, 300, 5000]:
         k = {a: round(v["total_ms"] / max(v["launches"], 1), 4) for a, v in e.profile_read().items()}
         print(f"graphs={g} pingpong={pp}: {dt:.4f} ms/step {k}", flush=True)
         e.close()
-    d = np.abs(outs[1] - outs[0])
-    print(f"   bit-identical: {np.array_equal(outs[1], outs[0])}  max|diff| {d.max():.3e}  finite {np.isfinite(outs[1]).all()}  first {outs[1][:3]} {outs[0][:3]}", flush=True)
+    for pp in (2, 1):
+        d = np.abs(outs[pp] - outs[0])
+        print(f"   pingpong={pp} bit-identical: {np.array_equal(outs[pp], outs[0])}  max|diff| {d.max():.3e}  finite {np.isfinite(outs[pp]).all()}  first {outs[pp][:3]} {outs[0][:3]}", flush=True)

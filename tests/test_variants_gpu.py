@@ -300,7 +300,8 @@ def test_one_pass_front_end_is_the_same_index_build(oracle):
 
 
 def test_pingpong_kernel_is_bit_identical_to_the_lock_step_one(oracle):
-    """gin_pp_kernel (gin_pingpong=1: one half of the workgroup multiplies while the other gathers and loads) does exactly the
+    """gin_pp_kernel (gin_pingpong=1: one half of the workgroup multiplies while the other gathers and loads; =2: the same with
+    sixteen waves, eight per half and one column tile each) does exactly the
     arithmetic of gin_resident_kernel per row -- same bits -- on ragged half-tiles, on graphs beyond the half-tile limits (129..256
     nodes: routed to the eight-wave kernel, one tile each) and when one half runs out of half-tiles before the other."""
     from tests.test_resident_limits_gpu import random_graph
@@ -309,7 +310,7 @@ def test_pingpong_kernel_is_bit_identical_to_the_lock_step_one(oracle):
     b = gp.concat_batches([mol.slice(0, 100), random_graph(128, 640, seed=1), random_graph(150, 330, seed=2), mol.slice(100, 101),
                            random_graph(256, 1280, seed=3), random_graph(100, 700, seed=4), mol.slice(101, 700)])
     outs = {}
-    for pp in (1, 0):
+    for pp in (2, 1, 0):
         e = Engine("GIN", device=0, options={"gin_pingpong": pp, "gin_tile_build": 0, "gin_resident_min_fill": 0})
         e.set_weights(w)
         outs[pp] = e.forward(b)
@@ -318,6 +319,7 @@ def test_pingpong_kernel_is_bit_identical_to_the_lock_step_one(oracle):
         assert e.exact_reruns() == 0
         e.close()
     assert np.array_equal(outs[1], outs[0])
+    assert np.array_equal(outs[2], outs[0])
     want = oracle.gin_forward(b, [w], nthreads=8)
     assert np.allclose(outs[1], want, rtol=1e-4, atol=1e-4 * max(1.0, float(np.abs(want).max())))
 
