@@ -88,7 +88,7 @@ MODELS = {
     "DGN": dict(metric="graphs/sec on hep10k (DGN, dim=100)", dataset="hep10k", graphs=1 << 15,
                 agg_bytes=lambda n, e: n * 400 * 3 + e * 12, flops=lambda n, e: n * 40000,
                 # unfused split dense: read both aggregates + h, write h'; fused layer: read h (tile rows) + CSR + eigenvector, write h'
-                fused_bytes={"dgn_dense": lambda n, e: n * (800 + 400 + 400), "dgn_layer_fused": lambda n, e: n * (400 + 300 + 12) + e * 4},  # average of 4 launches: the last one writes no rows (dgn_fold_readout)
+                fused_bytes={"dgn_dense": lambda n, e: n * (800 + 400 + 400), "dgn_layer_fused": lambda n, e: n * (400 + 300 + 44)},  # rows in, rows out (average of 4 launches: the last one writes none, dgn_fold_readout), 32 B of stored in-edge pass + eigenvector entry + out-degree per row
                 hbm_kernels=("dgn_aggregate",), mfma_kernels=("dgn_layer_fused", "dgn_dense"),
                 workload="DGN dim=100, hep10k-shaped kNN graphs on MI355X (BASELINE configs[4])"),
 }

@@ -60,7 +60,7 @@ struct CsrView {
 
 // graph_build.hip
 // max_nodes / max_edges: largest graph of the batch (selects the per-graph LDS build or the flat global build)
-void launch_build_csr(const BatchView& b, const CsrView& c, bool has_edge_attr, int max_nodes, int max_edges, hipStream_t s);
+void launch_build_csr(const BatchView& b, const CsrView& c, bool has_edge_attr, int max_nodes, int max_edges, hipStream_t s, const int* only_if = nullptr);
 
 }  // namespace fg
 
@@ -152,6 +152,7 @@ struct DeviceBatch {
                               // layer and never wrote them; flowgnn_get_h then repeats the pass with Model::set_keep_h(true))
     bool csr_built;           // csr.* describe this batch (set by the engine when the index build has run; kernels that work from the
                               // caller's arrays directly -- Model::needs_csr() == false -- leave it as it is)
+    int max_nodes, max_edges; // largest graph of the batch (what launch_build_csr selects its per-graph class by)
     GraphTiles gtiles;        // graph-aligned tiles (GraphTiles above), n_tiles == 0 if the model did not ask for them
     int* range_flag;          // [1] set by a reduced-range kernel whose operands left its accurate range (see Model::set_exact)
 };

@@ -756,6 +756,95 @@ __global__ __launch_bounds__(512, 2) void dgn_layer_mfma_kernel(const float* __r
     }
 }
 
+// The in-edge pass of dgn_layer_mfma_kernel<1> -- adjacency mask, wsum, abssum, duplicate count per row -- and the out-degrees,
+// straight from the caller's edge list: what the matrix-pipe path needs of load_graph (DGN/src/load_inputs.cc:87-172) WITHOUT the
+// CSR.  One 256-thread workgroup per tile of whole graphs (<= 128 rows): the tile's edges are a contiguous slice of edge_list;
+// each is validated, turned into (source row, destination row) of the tile and ORed into a 128 x 128 bit matrix in LDS (an
+// atomicOr that finds its bit set has found a duplicate edge).  Thread v then walks the set bits of row v in ascending order --
+// the CSR's order (sources ascending), so wsum and abssum add the same terms in the same order as the walk over the CSR row and
+// rowinfo is bit-identical to what INFO = 1 stores.  Rows with duplicate in-edges (multiplicity is not in the mask) count the
+// copies by a scan over the tile's edges -- rare -- and raise *dup_flag: the launching model then also builds the CSR (on the
+// device's say-so: launch_build_csr(..., only_if)), because the layer kernels' correction walk for duplicates reads it.
+__global__ __launch_bounds__(256) void dgn_rowinfo_kernel(BatchView b, const int* __restrict__ tile_row, const int* __restrict__ tile_graph,
+                                                          int n_tiles, const float* __restrict__ eig4, uint32_t* __restrict__ rowinfo,
+                                                          int* __restrict__ out_deg, int* __restrict__ err, int* __restrict__ dup_flag) {
+    __shared__ uint32_t s_adj[DGN_FT_ROWS][4];
+    __shared__ int s_odeg[DGN_FT_ROWS], s_ndup[DGN_FT_ROWS];
+    __shared__ float s_eig[DGN_FT_ROWS];
+    const int tile = blockIdx.x, tid = threadIdx.x;
+    if (tile >= n_tiles) return;
+    const int t0 = tile_row[tile];
+    int rows = tile_row[tile + 1] - t0;
+    if (rows > DGN_FT_ROWS) rows = DGN_FT_ROWS;
+    const int g0 = tile_graph[tile], g1 = tile_graph[tile + 1];
+    if (tid < DGN_FT_ROWS) {
+        s_adj[tid][0] = 0u; s_adj[tid][1] = 0u; s_adj[tid][2] = 0u; s_adj[tid][3] = 0u;
+        s_odeg[tid] = 0; s_ndup[tid] = 0;
+        s_eig[tid] = tid < rows ? eig4[(size_t)(t0 + tid) * 4 + 1] : 0.0f;
+    }
+    __syncthreads();
+    for (int gph = g0; gph < g1; gph++) {  // (a handful of graphs per tile; their headers are wave-uniform scalar loads)
+        const int n = b.nums_of_nodes[gph], base = b.node_off[gph] - t0, e0 = b.edge_off[gph], ne = b.edge_off[gph + 1] - e0;
+        for (int e = tid; e < ne; e += 256) {
+            const int2 uv = reinterpret_cast<const int2*>(b.edge_list)[e0 + e];
+            int u = uv.x, v = uv.y;
+            if (!((u >= 0) & (u < n) & (v >= 0) & (v < n))) {  // as the index build: flag it, then a self-loop on the graph's node 0
+                atomicMax(err, ERR_EDGE_RANGE);
+                u = 0;
+                v = 0;
+            }
+            u += base; v += base;
+            if (u >= DGN_FT_ROWS || v >= DGN_FT_ROWS) continue;  // (cannot happen: the host packed whole graphs into <= 128 rows)
+            const uint32_t bit = 1u << (u & 31);
+            const uint32_t old = atomicOr(&s_adj[v][u >> 5], bit);
+            if (old & bit) atomicAdd(&s_ndup[v], 1);
+            atomicAdd(&s_odeg[u], 1);
+        }
+    }
+    __syncthreads();
+    if (tid < rows) {
+        const int v = tid;
+        const float eig_v = s_eig[v];
+        const int nd = s_ndup[v];
+        float wsum = 0.0f, abssum = 0.0f;
+        for (int sb = 0; sb < 4; sb++) {
+            uint32_t w = s_adj[v][sb];
+            while (w) {
+                const int u = 32 * sb + __ffs((int)w) - 1;
+                w &= w - 1;
+                int mult = 1;
+                if (nd > 0) {  // how many copies of (u -> v) the caller listed: a scan over the tile's edges (rows with duplicates only)
+                    mult = 0;
+                    for (int gph = g0; gph < g1; gph++) {
+                        const int n = b.nums_of_nodes[gph], base = b.node_off[gph] - t0, e0 = b.edge_off[gph], ne = b.edge_off[gph + 1] - e0;
+                        if (v < base || v >= base + n) continue;
+                        for (int e = 0; e < ne; e++) {
+                            const int2 uv = reinterpret_cast<const int2*>(b.edge_list)[e0 + e];
+                            int uu = uv.x, vv = uv.y;
+                            if (!((uu >= 0) & (uu < n) & (vv >= 0) & (vv < n))) { uu = 0; vv = 0; }
+                            mult += (uu + base == u) & (vv + base == v);
+                        }
+                    }
+                }
+                const float we = s_eig[u] - eig_v;
+                for (int k = 0; k < mult; k++) { wsum += we; abssum += fabsf(we); }
+            }
+        }
+        // this lane group's byte of every 32-source block: bit 8 s + e <-> source 32 s + 8 g + e (dgn_layer_mfma_kernel)
+        uint32_t* ri = rowinfo + (size_t)(t0 + v) * 8;
+#pragma unroll
+        for (int gq = 0; gq < 4; gq++) {
+            uint32_t wg = 0;
+#pragma unroll
+            for (int sb = 0; sb < 4; sb++) wg |= ((s_adj[v][sb] >> (8 * gq)) & 0xFFu) << (8 * sb);
+            ri[gq] = wg;
+        }
+        *reinterpret_cast<uint4*>(ri + 4) = make_uint4(__builtin_bit_cast(uint32_t, wsum), __builtin_bit_cast(uint32_t, abssum), (uint32_t)nd, 0u);
+        out_deg[t0 + v] = s_odeg[v];
+        if (nd > 0) atomicOr(dup_flag, 1);
+    }
+}
+
 // ginfo[node] = (graph, (node - graph's first node) | (graph's end - node) << 8) for the POOL epilogue above: one thread per graph
 // (graphs of this path have <= 128 nodes)
 __global__ __launch_bounds__(256) void dgn_graph_info_kernel(const int* __restrict__ node_off, int num_graphs, int2* __restrict__ ginfo) {
@@ -968,6 +1057,18 @@ public:
         edges = fused_ ? DGN_FT_EDGES : 0;
     }
 
+    bool use_fused(const DeviceBatch& db) const {
+        // tiles that are mostly empty (graphs of 65..128 nodes) waste MFMA columns: below 40 % full the two-kernel layer is used
+        return fused_ && split_ && !exact_ && db.gtiles.ok && db.gtiles.n_tiles > 0 && db.gtiles.fill >= 0.4;
+    }
+    bool use_mfma_agg(const DeviceBatch& db) const {
+        return mfma_agg_ < 0 ? (double)db.b.e_tot >= 8.0 * (double)db.b.n_tot : mfma_agg_ != 0;
+    }
+    // the matrix-pipe path takes what it needs of the graph structure from the caller's edge list (dgn_rowinfo_kernel): no index build
+    bool needs_csr(const DeviceBatch& db) const override {
+        return !(rowinfo_direct_ && !qmode_ && db.b.n_tot > 0 && db.node_eigen && use_fused(db) && use_mfma_agg(db));
+    }
+
     int forward(DeviceBatch& db, Profiler& prof, hipStream_t s) override {
         const int n = db.b.n_tot;
         if (n <= 0) return 0;
@@ -978,30 +1079,44 @@ public:
             ProfScope p(prof, "atom_encoder", s);
             atom_encoder_kernel<DGN_D><<<atom_encoder_grid(n, DGN_C), 512, 0, s>>>(db.b.node_feature, d_emb_, db.h[0], n, db.csr.err);
         }
-        // tiles that are mostly empty (graphs of 65..128 nodes) waste MFMA columns: below 40 % full the two-kernel layer is used
-        const bool fused = fused_ && split_ && !exact_ && db.gtiles.ok && db.gtiles.n_tiles > 0 && db.gtiles.fill >= 0.4;
+        const bool fused = use_fused(db);
         agg_ready_ = false;
         if (!fused)  // the fused layer takes eig1[src] from its own LDS tile: only the two-kernel layer needs these
             if (int rc = prepare_aggregate(db, prof, s)) return rc;
         int cur = 0;
         bool pooled = false;  // the last layer left per-wave partial sums instead of its rows
+        // matrix-pipe path without a CSR of this batch: the in-edge pass (adjacency masks, wsum, abssum, out-degrees) from the caller's
+        // edge list, once per forward
+        const bool direct = fused && use_mfma_agg(db) && rowinfo_direct_ && !db.csr_built;
+        if (direct) {
+            if (int rc = rowinfo_.reserve((size_t)n * 8)) return rc;
+            if (int rc = dupflag_.reserve(1)) return rc;
+            ProfScope p(prof, "dgn_rowinfo", s);
+            FG_HIP_TRY(hipMemsetAsync(dupflag_.p, 0, sizeof(int), s));
+            dgn_rowinfo_kernel<<<db.gtiles.n_tiles, 256, 0, s>>>(db.b, db.gtiles.row_start, db.gtiles.graph_start, db.gtiles.n_tiles, db.node_eigen,
+                                                                 reinterpret_cast<uint32_t*>(rowinfo_.p), db.csr.out_deg, db.csr.err, dupflag_.p);
+            // the layer kernels' correction walk for duplicate edges reads the CSR: built only if the pass found one (device-side test)
+            launch_build_csr(db.b, db.csr, false, db.max_nodes, db.max_edges, s, dupflag_.p);
+        }
         for (int l = 0; l < DGN_L; l++) {
             if (fused) {
                 ProfScope p(prof, "dgn_layer_fused", s);
                 const int grid = db.gtiles.n_tiles < 256 ? db.gtiles.n_tiles : 256;  // persistent: one 8-wave workgroup per CU (153 KB of LDS)
                 // dense tiles (kNN graphs: 16 in-edges per row, a third of a graph's block filled): both aggregates as MFMAs with the
                 // tile's adjacency; sparse ones (molecules, ~2 in-edges per row): the in-edge walk is cheaper than 20 MFMAs per K-step
-                const bool mfma_agg = mfma_agg_ < 0 ? (double)db.b.e_tot >= 8.0 * (double)n : mfma_agg_ != 0;
+                const bool mfma_agg = use_mfma_agg(db);
                 if (mfma_agg) {
                     if (int rc = rowinfo_.reserve((size_t)n * 8)) return rc;
                     uint32_t* ri = reinterpret_cast<uint32_t*>(rowinfo_.p);
+                    const bool stored = direct || l > 0;  // rowinfo of this batch exists: every layer loads it
 #define DGN_MFMA_LAUNCH(I, P)                                                                                                                 \
     dgn_layer_mfma_kernel<I, P><<<grid, 512, 0, s>>>(db.h[cur], db.h[cur ^ 1], db.csr.row_ptr, db.csr.src, db.csr.out_deg, db.node_eigen,       \
                                                      d_fused_ + (size_t)l * DGN_FT_LAYER_BYTES, db.gtiles.row_start, db.gtiles.n_tiles,       \
                                                      db.range_flag, ablate_, ri, reinterpret_cast<const int2*>(ginfo_.p), pool_part_.p,      \
                                                      pool_cnt_.p)
-                    // the first layer stores what its in-edge pass found per row (adjacency mask, wsum, abssum), the others load it;
-                    // the last one keeps h' on chip and hands the readout per-wave partial sums (POOL) unless the rows are asked for
+                    // without a stored pass the first layer's launch makes and stores it (adjacency mask, wsum, abssum per row), the
+                    // others load it; the last one keeps h' on chip and hands the readout per-wave partial sums (POOL) unless the rows
+                    // are asked for
                     const bool pool = l == DGN_L - 1 && fold_readout_ && !keep_h_ && DGN_L > 1;
                     if (pool) {
                         if (int rc = ginfo_.reserve((size_t)n * 2)) return rc;
@@ -1011,7 +1126,7 @@ public:
                                                                                           reinterpret_cast<int2*>(ginfo_.p));
                         pooled = true;
                     }
-                    if (l == 0) DGN_MFMA_LAUNCH(1, false); else if (pool) DGN_MFMA_LAUNCH(2, true); else DGN_MFMA_LAUNCH(2, false);
+                    if (!stored) DGN_MFMA_LAUNCH(1, false); else if (pool) DGN_MFMA_LAUNCH(2, true); else DGN_MFMA_LAUNCH(2, false);
 #undef DGN_MFMA_LAUNCH
                     cur ^= 1;
                     continue;
@@ -1061,6 +1176,7 @@ public:
         fused_ = o.on("dgn_fused");
         mfma_agg_ = o.i("dgn_mfma_agg");
         fold_readout_ = o.on("dgn_fold_readout");
+        rowinfo_direct_ = o.on("dgn_rowinfo_direct");
         ablate_ = FG_ABLATE(o.i("dgn_ablate"));
         agg_ready_ = false;
     }
@@ -1087,6 +1203,7 @@ private:
         tiles_.release();
         rowinfo_.release();
         ginfo_.release();
+        dupflag_.release();
         pool_cnt_.release();
         pool_part_.release();
         q_.release();
@@ -1103,6 +1220,8 @@ private:
     // dgn_fused=0 keeps aggregation and dense update as two kernels per layer (A/B measurements, the aggregation roofline probe)
     bool agg_ready_ = false;  // tiles_ / esc_ describe the batch of the last forward
     GrowBufI rowinfo_;   // dgn_layer_mfma_kernel: 32 B per row of layer-independent in-edge pass results
+    GrowBufI dupflag_;           // dgn_rowinfo_kernel: set on the device when the batch has duplicate edges
+    bool rowinfo_direct_ = true;
     GrowBufI ginfo_, pool_cnt_;  // POOL form of the last layer: (graph, position) per node; partial rows per graph
     GrowBuf pool_part_;          //   [G][8][100] per-wave partial sums of h_4
     bool fold_readout_ = true, keep_h_ = false;

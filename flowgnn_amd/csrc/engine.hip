@@ -100,7 +100,7 @@ static const OptionDef kOptionTable[] = {
     {"gcn_resident", 1}, {"gcn_unfused", 0}, {"gcn_mfma", 16},
     {"gat_resident", 1}, {"gat_mfma", 16}, {"gat_fold_readout", 1}, {"gat_reference_quirk", 0},
     {"pna_fused", 1}, {"pna_mfma", 16}, {"pna_mfma_agg", -1},
-    {"dgn_fused", 1}, {"dgn_mfma", 16}, {"dgn_mfma_agg", -1}, {"dgn_fold_readout", 1},
+    {"dgn_fused", 1}, {"dgn_mfma", 16}, {"dgn_mfma_agg", -1}, {"dgn_fold_readout", 1}, {"dgn_rowinfo_direct", 1},
 #ifdef FLOWGNN_DEV
     {"gcn_ablate", 0}, {"gat_ablate", 0}, {"pna_ablate", 0}, {"dgn_ablate", 0},
 #endif
@@ -582,6 +582,7 @@ int flowgnn_set_batch(flowgnn_engine* e, int num_graphs, const int* nums_of_node
     db.tap = nullptr;
     db.tap_dim = 0;
     db.csr_built = false;
+    db.max_nodes = mx_n; db.max_edges = mx_e;
     EHIP_TRY(e, hipMemset(e->d_err, 0, 2 * sizeof(int)));
     e->db.range_flag = e->d_err + 1;
     e->force_exact = false;

@@ -192,8 +192,9 @@ __global__ __launch_bounds__(256) void rank_kernel(CsrView c, int e_tot, const i
 // 10 KB and twice as many graphs are in flight per CU (0.32 -> 0.19 ms).  The multi-wave classes keep static arrays of the
 // class size: sized by the batch they measured slower on the kNN graphs (0.23 -> 0.26 ms).
 template <int NT, int NMAX, int EMAX, typename IdxT, bool DYN>
-__global__ __launch_bounds__(NT) void build_csr_graph_kernel(BatchView b, CsrView c, bool has_attr, int nmax, int emax) {
+__global__ __launch_bounds__(NT) void build_csr_graph_kernel(BatchView b, CsrView c, bool has_attr, int nmax, int emax, const int* only_if) {
     extern __shared__ __attribute__((aligned(16))) char s_dyn[];
+    if (only_if != nullptr && *only_if == 0) return;  // a build that the launching model needs only when a device-side flag says so
     __shared__ int st_cnt[DYN ? 1 : NMAX + 1];
     __shared__ int st_cur[DYN ? 1 : NMAX];
     __shared__ int st_odeg[DYN ? 1 : NMAX];
@@ -293,26 +294,28 @@ __global__ __launch_bounds__(NT) void build_csr_graph_kernel(BatchView b, CsrVie
     }
 }
 
-void launch_build_csr(const BatchView& b, const CsrView& c, bool has_edge_attr, int max_nodes, int max_edges, hipStream_t s) {
+// only_if (device int, or null): per-graph classes only -- every workgroup returns at once when *only_if == 0 (DGN's matrix-pipe path
+// needs the CSR only for batches with duplicate edges, which its own index pass finds on the device)
+void launch_build_csr(const BatchView& b, const CsrView& c, bool has_edge_attr, int max_nodes, int max_edges, hipStream_t s, const int* only_if) {
     if (b.num_graphs > 0 && max_nodes <= 256 && max_edges <= 1024) {
         // dynamic LDS of one graph: 3 nmax + 1 + NT / 64 ints, 3 emax indices, emax codes
         const int nmax = (max_nodes + 1) & ~1, emax = (max_edges + 3) & ~3;
         const size_t lds = (size_t)(3 * nmax + 1 + 1 + 1) * 4 + (size_t)emax * (3 * sizeof(uint16_t) + 1);
-        build_csr_graph_kernel<64, 256, 1024, uint16_t, true><<<b.num_graphs, 64, lds, s>>>(b, c, has_edge_attr, nmax, emax);
+        build_csr_graph_kernel<64, 256, 1024, uint16_t, true><<<b.num_graphs, 64, lds, s>>>(b, c, has_edge_attr, nmax, emax, only_if);
         return;
     }
     // kNN graphs of the hep10k shape (<= ~100 nodes x 16 in-edges): 18 KB of LDS per graph, so nine workgroups share a CU;
     // in the class below one graph claims 139 KB and a CU holds a single 4-wave workgroup (0.93 -> 0.22 ms for 2^15 graphs)
     if (b.num_graphs > 0 && max_nodes <= 256 && max_edges <= 2048) {
-        build_csr_graph_kernel<128, 256, 2048, uint16_t, false><<<b.num_graphs, 128, 0, s>>>(b, c, has_edge_attr, 256, 2048);
+        build_csr_graph_kernel<128, 256, 2048, uint16_t, false><<<b.num_graphs, 128, 0, s>>>(b, c, has_edge_attr, 256, 2048, only_if);
         return;
     }
     if (b.num_graphs > 0 && max_nodes <= 512 && max_edges <= 6144) {  // the reference's own caps: 500 nodes / 5500 edges
-        build_csr_graph_kernel<256, 512, 6144, uint16_t, false><<<b.num_graphs, 256, 0, s>>>(b, c, has_edge_attr, 512, 6144);
+        build_csr_graph_kernel<256, 512, 6144, uint16_t, false><<<b.num_graphs, 256, 0, s>>>(b, c, has_edge_attr, 512, 6144, only_if);
         return;
     }
     if (b.num_graphs > 0 && max_nodes <= 2048 && max_edges <= 16384) {
-        build_csr_graph_kernel<256, 2048, 16384, uint16_t, false><<<b.num_graphs, 256, 0, s>>>(b, c, has_edge_attr, 2048, 16384);
+        build_csr_graph_kernel<256, 2048, 16384, uint16_t, false><<<b.num_graphs, 256, 0, s>>>(b, c, has_edge_attr, 2048, 16384, only_if);
         return;
     }
     // flat global path: any graph size

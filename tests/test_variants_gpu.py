@@ -385,3 +385,35 @@ def test_dgn_pooled_last_layer(oracle):
         assert np.allclose(h1, hd[4], rtol=2e-4, atol=2e-3 * scale)
         assert np.array_equal(e1.forward(b), o1)  # and the pooled form is back afterwards
         e1.close(); e0.close()
+
+
+def test_dgn_in_edge_pass_from_the_edge_list_is_the_csr_one():
+    """dgn_rowinfo_direct: the matrix-pipe path's per-row pass (adjacency mask, wsum, abssum, duplicate count, out-degree) made from
+    the caller's edge list, no index build.  Same bits as the pass over the CSR (sources ascending = set bits ascending), also with
+    duplicate edges (the device then builds the CSR after all, for the layer kernels' correction walk), self loops and rows without
+    in-edges; the CSR tap still answers afterwards."""
+    from tests.test_resident_limits_gpu import random_graph
+    hep = gp.synth_hep10k_batch(40, seed=7, with_eigen=True)
+    el = hep.edge_list.copy()
+    el[3] = el[2]; el[4] = el[2]; el[700] = el[699]  # a triple and a double edge
+    el[40, 1] = el[40, 0]                              # a self loop
+    dup = gp.GraphBatch(hep.nums_of_nodes, hep.nums_of_edges, hep.node_feature, el, hep.edge_attr, hep.node_eigen)
+
+    def with_eig(b, seed):
+        e = np.zeros((b.total_nodes, 4), np.float32)
+        e[:, 1] = np.random.default_rng(seed).uniform(-1, 1, b.total_nodes)
+        return gp.GraphBatch(b.nums_of_nodes, b.nums_of_edges, b.node_feature, b.edge_list, b.edge_attr, e)
+    w = weights.SYNTH["DGN"](seed=7)
+    for b in (gp.synth_hep10k_batch(257, seed=3), dup, gp.concat_batches([dup, with_eig(random_graph(128, 2560, seed=5), 2), with_eig(gp.synth_molhiv_batch(60, seed=8), 1)])):
+        outs = {}
+        for direct in (1, 0):
+            e = Engine("DGN", device=0, options={"dgn_mfma_agg": 1, "dgn_rowinfo_direct": direct})
+            e.set_weights(w)
+            outs[direct] = e.forward(b)
+            assert np.array_equal(e.forward(b), outs[direct])
+            if direct:
+                row_ptr, src, eid, out_deg = e.csr()  # built on demand
+                assert row_ptr[-1] == b.total_edges and np.array_equal(np.bincount(b.global_edges()[:, 0], minlength=b.total_nodes), out_deg)
+                assert np.array_equal(e.forward(b), outs[direct])
+            e.close()
+        assert np.array_equal(outs[1], outs[0])
