@@ -428,6 +428,7 @@ def main():
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak: fixed graphs per GPU; strong: ONE job batch cut by sum(N+E) with flowgnn_amd.dist.shard_ranges")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-entry-point", action="store_true", help="skip the timing of the drop-in symbol with host arrays (profiling runs: its launches would mix into the kernel trace)")
     ap.add_argument("--configs", default="auto", choices=["auto", "on", "off"],
                     help="also measure the other BASELINE configs (GIN at dataset size, GIN-VN, GCN, GAT, PNA, DGN) in the same run and "
                          "report them in a compact `configs` object; auto = on for the default single-GPU GIN run")
@@ -554,7 +555,7 @@ def main():
         }
         if balance is not None:
             line["shard_balance"] = balance
-        if world == 1 and not qmode:
+        if world == 1 and not qmode and not args.no_entry_point:
             # the drop-in symbol itself with HOST arrays in the clock (validation, tile packing, PCIe copies, kernels, logits back):
             # reported beside `value`, never as `value`
             from flowgnn_amd import compute_graphs

@@ -15,12 +15,12 @@ STEPS=10; WARM=8
 cd /tmp && export TMPDIR=/tmp
 for M in $MODELS; do
   python $R/bench.py --model $M --steps 20 --warmup 8 --configs off > $OUT/${TAG}_bench_$M.json 2> $OUT/${TAG}_bench_$M.err
-  rocprofv3 --kernel-trace --output-format csv -d $OUT/${TAG}_${M}_kt -o kt -- python $R/bench.py --model $M --steps $STEPS --warmup $WARM --no-cpu-baseline --configs off > $OUT/${TAG}_${M}_kt.log 2>&1
+  rocprofv3 --kernel-trace --output-format csv -d $OUT/${TAG}_${M}_kt -o kt -- python $R/bench.py --model $M --steps $STEPS --warmup $WARM --no-cpu-baseline --no-entry-point --configs off > $OUT/${TAG}_${M}_kt.log 2>&1
   f=$(find $OUT/${TAG}_${M}_kt -name '*kernel_trace.csv' | head -1)
   [ -n "$f" ] && python $R/profiles/summarize.py stats $f $STEPS $WARM > $OUT/${TAG}_${M}_kernel_trace_summary.txt
   rm -rf $OUT/${TAG}_${M}_kt
   for C in FETCH_SIZE WRITE_SIZE; do
-    rocprofv3 --pmc $C --output-format csv -d $OUT/${TAG}_${M}_$C -o pmc -- python $R/bench.py --model $M --steps 2 --warmup 1 --no-cpu-baseline --configs off > $OUT/${TAG}_${M}_$C.log 2>&1
+    rocprofv3 --pmc $C --output-format csv -d $OUT/${TAG}_${M}_$C -o pmc -- python $R/bench.py --model $M --steps 2 --warmup 1 --no-cpu-baseline --no-entry-point --configs off > $OUT/${TAG}_${M}_$C.log 2>&1
     f=$(find $OUT/${TAG}_${M}_$C -name '*counter_collection.csv' | head -1)
     [ -n "$f" ] && python $R/profiles/summarize.py pmc $f $C > $OUT/${TAG}_${M}_pmc_$C.txt
     rm -rf $OUT/${TAG}_${M}_$C
@@ -29,7 +29,7 @@ for M in $MODELS; do
   for P in 1 2; do
     if [ $P = 1 ]; then CT="GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_INSTS_MFMA SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAVE_CYCLES"; SUF=SQ;
     else CT="GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY"; SUF=SQ2; fi
-    rocprofv3 --pmc $CT --output-format csv -d $OUT/${TAG}_${M}_$SUF -o pmc -- python $R/bench.py --model $M --steps 2 --warmup 1 --no-cpu-baseline --configs off > $OUT/${TAG}_${M}_$SUF.log 2>&1
+    rocprofv3 --pmc $CT --output-format csv -d $OUT/${TAG}_${M}_$SUF -o pmc -- python $R/bench.py --model $M --steps 2 --warmup 1 --no-cpu-baseline --no-entry-point --configs off > $OUT/${TAG}_${M}_$SUF.log 2>&1
     f=$(find $OUT/${TAG}_${M}_$SUF -name '*counter_collection.csv' | head -1)
     [ -n "$f" ] && python $R/profiles/summarize.py pmcall $f > $OUT/${TAG}_${M}_pmc_$SUF.txt
     rm -rf $OUT/${TAG}_${M}_$SUF
