@@ -2284,7 +2284,9 @@ void launch_gin_resident(const float* h0, float* hout, const int* row_ptr, const
             for (int wi = 0; wi < GR_WAVES; wi++) fprintf(stderr, " %.0f", gw[wi] / grid / 100.0);
             fprintf(stderr, " | wait behind it");
             for (int wi = 0; wi < GR_WAVES; wi++) fprintf(stderr, " %.0f", ww[wi] / grid / 100.0);
-            fprintf(stderr, "\n");
+            double kmin = 1e300, kmax = 0.0;  // workgroup lifetimes (wave 0's): how long the launch waits for its last workgroup
+            for (size_t i = 0; i < cnt; i += 7 * GR_WAVES) { const double k = (double)hbuf[i + 6]; kmin = k < kmin ? k : kmin; kmax = k > kmax ? k : kmax; }
+            fprintf(stderr, " | workgroup lifetime min %.0f max %.0f\n", kmin / 100.0, kmax / 100.0);
         }
     }
 }
