@@ -642,6 +642,9 @@ __global__ __launch_bounds__(512, 2) void dgn_layer_mfma_kernel(const float* __r
             a2.y = fabsf(__builtin_fmaf(-wsum, hv.y, __builtin_fmaf(-eig_v, m1.y, pp.y)) * inv_abs);
             a2.z = fabsf(__builtin_fmaf(-wsum, hv.z, __builtin_fmaf(-eig_v, m1.z, pp.z)) * inv_abs);
             a2.w = fabsf(__builtin_fmaf(-wsum, hv.w, __builtin_fmaf(-eig_v, m1.w, pp.w)) * inv_abs);
+            // abssum == 0: every in-edge has eig[u] == eig[v] exactly (self loops, equal entries), so m2 and wsum are exactly 0 -- but
+            // P - eig_v m1 leaves the rounding of two separately accumulated sums, which 1 / epsilon (8192) would amplify into the result
+            if (abssum == 0.0f) a2 = make_float4(0.f, 0.f, 0.f, 0.f);
             if (!real || !valid) { a1 = make_float4(0.f, 0.f, 0.f, 0.f); a2 = a1; }
             ds_uint4_t b_hi, b_lo;
             DS_SPLIT2(a1.x, a1.y, b_hi.x, b_lo.x);

@@ -1,0 +1,74 @@
+"""Differential fuzz: random batches (graph sizes 1..500, sparse to dense, duplicate edges, self loops, isolated nodes, tiny and huge
+graphs mixed) through the HIP path vs the CPU oracle, plus consistency under a batch split and through the entry point.
+usage: fuzz.py MODEL [seconds] [seed]      (dev tool; imports oracle/ like the tests do)"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import numpy as np
+import oracle
+from flowgnn_amd import Engine, compute_graphs, graphpack as gp, weights
+
+model = sys.argv[1] if len(sys.argv) > 1 else "GIN"
+budget = float(sys.argv[2]) if len(sys.argv) > 2 else 60.0
+seed0 = int(sys.argv[3]) if len(sys.argv) > 3 else 1
+base = model.replace("-VN", "").lower()
+w = getattr(weights, f"synth_{base}_weights")(seed=11)
+ofn = getattr(oracle, f"{base}_forward")
+
+
+def rand_graph(rng):
+    kind = rng.integers(0, 6)
+    n = int(rng.choice([1, 2, 3, 5, 17, 33, 64, 65, 100, 128, 129, 200, 256, 257, 400, 500])) if kind == 0 else int(rng.integers(1, 60))
+    dens = rng.choice([0.0, 0.5, 1.0, 2.2, 4.0, 16.0])
+    m = int(min(5500, max(0, round(n * dens + rng.integers(0, 3)))))
+    if model in ("PNA", "DGN") and rng.random() < 0.5:
+        m = int(min(5500, n * min(16, max(n - 1, 0))))
+    el = rng.integers(0, n, (m, 2)).astype(np.int32)
+    if m and rng.random() < 0.3:
+        el[rng.integers(0, m, max(1, m // 10))] = el[rng.integers(0, m)]  # duplicates
+    nf = np.stack([rng.integers(0, c, n) for c in (119, 4, 12, 12, 10, 6, 6, 2, 2)], 1).astype(np.int32)
+    ea = np.stack([rng.integers(0, 5, m), rng.integers(0, 6, m), rng.integers(0, 2, m)], 1).astype(np.int32).reshape(m, 3)
+    eig = None
+    if model == "DGN":
+        eig = np.zeros((n, 4), np.float32)
+        eig[:, 1] = rng.uniform(-1, 1, n)
+    return gp.GraphBatch(np.array([n], np.int32), np.array([m], np.int32), nf, el, ea, eig)
+
+
+e = Engine(model, 0)
+e.set_weights(w)
+t_end = time.time() + budget
+it = 0
+worst = 0.0
+while time.time() < t_end:
+    rng = np.random.default_rng(seed0 * 100003 + it)
+    graphs = [rand_graph(rng) for _ in range(int(rng.integers(1, 40)))]
+    if rng.random() < 0.3:
+        mol = gp.synth_molhiv_batch(int(rng.integers(1, 300)), seed=int(rng.integers(1 << 30)))
+        if model == "DGN":
+            eg = np.zeros((mol.total_nodes, 4), np.float32); eg[:, 1] = rng.uniform(-1, 1, mol.total_nodes)
+            mol = gp.GraphBatch(mol.nums_of_nodes, mol.nums_of_edges, mol.node_feature, mol.edge_list, mol.edge_attr, eg)
+        graphs.insert(int(rng.integers(0, len(graphs) + 1)), mol)
+    b = gp.concat_batches(graphs)
+    if model == "GIN-VN":
+        b = gp.add_virtual_nodes(b)
+    got = e.forward(b)
+    want, hd = ofn(b, [w], dump_h=True, nthreads=8)
+    scale = max(1.0, float(np.abs(hd).max()))
+    ok = np.isfinite(got).all() and np.allclose(got, want, rtol=2e-4, atol=2e-3 * scale if model in ("PNA", "DGN", "GAT") else 2e-4 * scale)
+    cut = int(rng.integers(0, b.num_graphs + 1))
+    parts = [e.forward(b.slice(a, c)) for a, c in ((0, cut), (cut, b.num_graphs)) if c > a]
+    split = np.concatenate(parts) if parts else got[:0]
+    ok_split = np.allclose(split, got, rtol=1e-4, atol=1e-4 * scale)
+    ent = compute_graphs(model, b, [w])
+    ok_ent = np.allclose(ent, got, rtol=1e-4, atol=1e-4 * scale)
+    err = float(np.abs(got - want).max() / scale) if got.size else 0.0
+    worst = max(worst, err)
+    if not (ok and ok_split and ok_ent):
+        print(f"FAIL {model} seed {seed0} iter {it}: graphs {b.num_graphs} nodes {b.total_nodes} edges {b.total_edges} oracle_ok {ok} split_ok {ok_split} entry_ok {ok_ent} "
+              f"max|d| {np.abs(got - want).max():.3e} scale {scale:.3e} exact_reruns {e.exact_reruns()}", flush=True)
+        np.savez(os.path.join(ROOT, "gpurun_out", f"fuzz_fail_{model}_{seed0}_{it}.npz"), nn=b.nums_of_nodes, ne=b.nums_of_edges, nf=b.node_feature, el=b.edge_list, ea=b.edge_attr)
+        sys.exit(1)
+    it += 1
+print(f"{model}: {it} random batches ok, worst |gpu - oracle| / scale = {worst:.2e}, exact_reruns {e.exact_reruns()}", flush=True)
