@@ -364,15 +364,16 @@ __global__ __launch_bounds__(512, 2) void dgn_layer_fused_kernel(const float* __
 // In dgn_layer_fused_kernel a K-step's operand is a walk over the row's in-edges: 16 LDS reads + 128 VALU instructions per lane,
 // seven times per tile -- the walk, not the 21 MFMAs behind it, is where the layer's time goes (wait share 0.61, MFMA busy 14 %).
 // Both aggregates are LINEAR in h, and a tile of whole graphs is a block-diagonal adjacency matrix A (v, u) of 0 / 1 entries:
-//     m1[v] = sum_u A[v][u] h[u]                     P[v] = sum_u A[v][u] eig[u] h[u]
-//     m2[v] = sum_u A[v][u] (eig[u] - eig[v]) h[u] = P[v] - eig[v] m1[v]           (DGN/src/message_passing.cc:148-149)
-// so for K-step k (features 16k .. 16k+15) the two aggregates of the wave's 16 rows are  H^T[16 features][128 sources] x A^T[128][16]
+//     m1[v] = sum_u A[v][u] h[u]                     m2[v] = sum_u A[v][u] (eig[u] - eig[v]) h[u]      (DGN/src/message_passing.cc:148-149)
+// so for K-step k (features 16k .. 16k+15) the two aggregates of the wave's 16 rows are  H^T[16 features][128 sources] x B[128][16]
 // -- MFMAs with the TRANSPOSED, f16-split rows of the tile as the A operand (s_ht: [feature][source] hi and lo, built by the tile
-// loader) and, as the B operand, the row's adjacency: lane (j, g) holds A[v_j][32 s + 8 g .. + 7] for the four 32-source blocks s as
-// f16 -- ones (exact: m1 = two products, H_hi A + H_lo A) and eig[u] split hi / lo (P = three products).  The adjacency operands
-// are built ONCE per tile from a 32-bit mask per lane (the row's sources that fall into this lane's slots): ~160 VALU instructions
-// per tile instead of 896 for the seven walks; source blocks that are empty for the whole wave are skipped (block diagonal: a
-// 16-row group sees two or three of the four).  The result lands in the lanes that need it: D[feature 4g + r][v_j] -> lane (j, g).
+// loader) and, as the B operand, the row's adjacency: lane (j, g) holds its row's entries for sources 32 s + 8 g .. + 7 of the four
+// 32-source blocks s as f16 -- ones (exact: m1 = two products, H_hi A + H_lo A) and the row's WEIGHTS w = eig[u] - eig[v], formed in
+// fp32 as the reference forms them, scaled by the power of two that brings sum |w| into [1, 2) and split hi / lo (m2 = three
+// products).  The operands are built ONCE per tile from a 32-bit mask per lane (the row's sources that fall into this lane's slots)
+// and 32 differences: ~260 VALU instructions per tile instead of 896 for the seven walks; source blocks that are empty for the whole
+// wave are skipped (block diagonal: a 16-row group sees two or three of the four).  The result lands in the lanes that need it:
+// D[feature 4g + r][v_j] -> lane (j, g).
 // Order of summation differs from the CSR order of the walk (and depends on where the graph sits in its tile), so this path is
 // toleranced, not bit-identical under batch splits (tests/test_dgn_gpu.py says so); duplicate edges (multiplicity > 1: not a 0 / 1
 // matrix) are added by a correction walk over just those edges.  h[v] (self term, residual) is read from HBM / L2, not from LDS:
@@ -401,8 +402,8 @@ __global__ __launch_bounds__(512, 2) void dgn_layer_mfma_kernel(const float* __r
     const int ablate = FG_ABLATE(ablate_arg);  // development aid (dgn_ablate, -DFLOWGNN_DEV builds): 1 no aggregation MFMAs, 2 no dense
     (void)ablate_arg;                          // MFMAs, 4 no transposing stores of the next tile, 8 no in-edge pass, 16 no h[v] loads
     constexpr int OFF_W = 2 * DGN_HT_BYTES, OFF_SRC = OFF_W + (int)DGN_FT_LAYER_BYTES, OFF_RP = OFF_SRC + DGN_FT_EDGES,
-                  OFF_EIG = OFF_RP + 2 * (DGN_FT_ROWS + 8), OFF_EH = OFF_EIG + 4 * DGN_FT_ROWS, LDS_TOTAL = OFF_EH + 4 * DGN_FT_ROWS;
-    static_assert(OFF_W % 16 == 0 && OFF_SRC % 16 == 0 && OFF_RP % 4 == 0 && OFF_EIG % 16 == 0 && OFF_EH % 16 == 0, "alignment");
+                  OFF_EIG = OFF_RP + 2 * (DGN_FT_ROWS + 8), LDS_TOTAL = OFF_EIG + 4 * DGN_FT_ROWS;
+    static_assert(OFF_W % 16 == 0 && OFF_SRC % 16 == 0 && OFF_RP % 4 == 0 && OFF_EIG % 16 == 0, "alignment");
     __shared__ __attribute__((aligned(16))) char s_all[LDS_TOTAL];
     uint16_t* s_ht_hi = reinterpret_cast<uint16_t*>(s_all);
     uint16_t* s_ht_lo = reinterpret_cast<uint16_t*>(s_all + DGN_HT_BYTES);
@@ -410,7 +411,6 @@ __global__ __launch_bounds__(512, 2) void dgn_layer_mfma_kernel(const float* __r
     uint8_t* s_src = reinterpret_cast<uint8_t*>(s_all + OFF_SRC);
     uint16_t* s_rp = reinterpret_cast<uint16_t*>(s_all + OFF_RP);
     float* s_eig = reinterpret_cast<float*>(s_all + OFF_EIG);
-    uint16_t* s_eh = reinterpret_cast<uint16_t*>(s_all + OFF_EH);            // eig split: [128] hi, then [128] lo (f16)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j = lane & 15, g = lane >> 4;
@@ -433,14 +433,7 @@ __global__ __launch_bounds__(512, 2) void dgn_layer_mfma_kernel(const float* __r
         ph[0] = (uint16_t)h01; ph[DGN_HT_STRIDE] = (uint16_t)(h01 >> 16); ph[2 * DGN_HT_STRIDE] = (uint16_t)h23; ph[3 * DGN_HT_STRIDE] = (uint16_t)(h23 >> 16);
         pl[0] = (uint16_t)l01; pl[DGN_HT_STRIDE] = (uint16_t)(l01 >> 16); pl[2 * DGN_HT_STRIDE] = (uint16_t)l23; pl[3 * DGN_HT_STRIDE] = (uint16_t)(l23 >> 16);
     };
-    auto put_eig = [&](int r, float e, bool real) {
-        const float x = real ? e : 0.0f;
-        uint32_t hh, ll;
-        DS_SPLIT2(x, 0.0f, hh, ll);
-        s_eig[r] = x;
-        s_eh[r] = (uint16_t)hh;
-        s_eh[DGN_FT_ROWS + r] = (uint16_t)ll;
-    };
+    auto put_eig = [&](int r, float e, bool real) { s_eig[r] = real ? e : 0.0f; };
     int t0 = tile_row[tile], rows = tile_row[tile + 1] - t0;
     if (rows > DGN_FT_ROWS) rows = DGN_FT_ROWS;
     int e0 = row_ptr[t0], ne = row_ptr[t0 + rows] - e0;
@@ -562,7 +555,17 @@ __global__ __launch_bounds__(512, 2) void dgn_layer_mfma_kernel(const float* __r
         }
         const float inv_abs = 1.0f / (abssum == 0.0f ? 1.0f / 8192.0f : abssum);  // epsilon of ap_fixed<16,3> (node_embedding.cc:125-128)
         const float inv_dg = odeg == 0 ? 0.0f : 1.0f / (float)odeg;
-        // adjacency operands of the four source blocks: 16-bit lane masks, then ones / eig_hi / eig_lo under the mask
+        // adjacency operands of the four source blocks: 16-bit lane masks, then ones and the row's WEIGHTS w = eig[u] - eig[v] (split
+        // hi / lo) under the mask.  The weights are formed per (row, source) in fp32 exactly as the reference forms them, and scaled by
+        // the power of two that brings the row's sum |w| into [1, 2) before they are split into f16 pairs: the directional sum then
+        // comes out of the matrix pipe as m2 = sum w h[u] itself, accurate relative to sum |w| |h| whatever the size of the weights.
+        // (The first version multiplied by eig[u] and subtracted eig[v] m1 afterwards: two separately rounded sums whose difference a
+        // row of nearly equal eigenvector entries -- sum |w| = 1e-5 -- turned into a 1.6 % error of its aggregate; found by the fuzzer.)
+        const int ae = (int)((__builtin_bit_cast(uint32_t, abssum) >> 23) & 0xFFu) - 127;  // abssum in [2^ae, 2^(ae+1))
+        const int aec = ae < -100 ? -100 : ae;
+        const float wscale = __builtin_bit_cast(float, (uint32_t)(127 - aec) << 23);        // 2^-ae: w wscale in (-2, 2)
+        const float inv_abs_s = inv_abs * __builtin_bit_cast(float, (uint32_t)(127 + aec) << 23);  // inv_abs / wscale (exact)
+        const float wsum_s = wsum * wscale;
         ds_uint4_t b_one[4], b_eh[4], b_el[4];
         bool blk[4];
 #pragma unroll
@@ -574,8 +577,12 @@ __global__ __launch_bounds__(512, 2) void dgn_layer_mfma_kernel(const float* __r
                 const uint32_t hi16 = (uint32_t)(-(int)((bits >> (8 * sb + 2 * pr + 1)) & 1u)) & 0xFFFF0000u;
                 m[pr] = lo16 | hi16;
             }
-            const ds_uint4_t eh = *reinterpret_cast<const ds_uint4_t*>(s_eh + 32 * sb + 8 * g);
-            const ds_uint4_t el = *reinterpret_cast<const ds_uint4_t*>(s_eh + DGN_FT_ROWS + 32 * sb + 8 * g);
+            const float4 ea = *reinterpret_cast<const float4*>(s_eig + 32 * sb + 8 * g), eb = *reinterpret_cast<const float4*>(s_eig + 32 * sb + 8 * g + 4);
+            ds_uint4_t eh, el;
+            DS_SPLIT2((ea.x - eig_v) * wscale, (ea.y - eig_v) * wscale, eh.x, el.x);
+            DS_SPLIT2((ea.z - eig_v) * wscale, (ea.w - eig_v) * wscale, eh.y, el.y);
+            DS_SPLIT2((eb.x - eig_v) * wscale, (eb.y - eig_v) * wscale, eh.z, el.z);
+            DS_SPLIT2((eb.z - eig_v) * wscale, (eb.w - eig_v) * wscale, eh.w, el.w);
             b_one[sb] = m & (ds_uint4_t){0x3C003C00u, 0x3C003C00u, 0x3C003C00u, 0x3C003C00u};
             b_eh[sb] = m & eh;
             b_el[sb] = m & el;
@@ -622,7 +629,7 @@ __global__ __launch_bounds__(512, 2) void dgn_layer_mfma_kernel(const float* __r
                     if (e < cnt) {
                         const int u = STAGE_CSR ? (int)s_src[e_base + e] : ((src[gb + e] - t0) & 127);
                         if (u == prev && real) {
-                            const float eu = s_eig[u];
+                            const float eu = (s_eig[u] - eig_v) * wscale;  // the copy's (scaled) weight
 #pragma unroll
                             for (int c = 0; c < 4; c++) {
                                 const int f = (k < 6 ? 16 * k : 96) + 4 * g + c;
@@ -635,16 +642,13 @@ __global__ __launch_bounds__(512, 2) void dgn_layer_mfma_kernel(const float* __r
                         prev = u;
                     }
             }
-            // a1 = m1 / outdeg (x / 0 = 0), a2 = |(m2 - wsum h[v]) / abssum| with m2 = P - eig[v] m1   (node_embedding.cc:143-146)
+            // a1 = m1 / outdeg (x / 0 = 0), a2 = |(m2 - wsum h[v]) / abssum|   (node_embedding.cc:143-146); pp = m2 wscale
             float4 a1, a2;
             a1.x = m1.x * inv_dg; a1.y = m1.y * inv_dg; a1.z = m1.z * inv_dg; a1.w = m1.w * inv_dg;
-            a2.x = fabsf(__builtin_fmaf(-wsum, hv.x, __builtin_fmaf(-eig_v, m1.x, pp.x)) * inv_abs);
-            a2.y = fabsf(__builtin_fmaf(-wsum, hv.y, __builtin_fmaf(-eig_v, m1.y, pp.y)) * inv_abs);
-            a2.z = fabsf(__builtin_fmaf(-wsum, hv.z, __builtin_fmaf(-eig_v, m1.z, pp.z)) * inv_abs);
-            a2.w = fabsf(__builtin_fmaf(-wsum, hv.w, __builtin_fmaf(-eig_v, m1.w, pp.w)) * inv_abs);
-            // abssum == 0: every in-edge has eig[u] == eig[v] exactly (self loops, equal entries), so m2 and wsum are exactly 0 -- but
-            // P - eig_v m1 leaves the rounding of two separately accumulated sums, which 1 / epsilon (8192) would amplify into the result
-            if (abssum == 0.0f) a2 = make_float4(0.f, 0.f, 0.f, 0.f);
+            a2.x = fabsf(__builtin_fmaf(-wsum_s, hv.x, pp.x) * inv_abs_s);
+            a2.y = fabsf(__builtin_fmaf(-wsum_s, hv.y, pp.y) * inv_abs_s);
+            a2.z = fabsf(__builtin_fmaf(-wsum_s, hv.z, pp.z) * inv_abs_s);
+            a2.w = fabsf(__builtin_fmaf(-wsum_s, hv.w, pp.w) * inv_abs_s);
             if (!real || !valid) { a1 = make_float4(0.f, 0.f, 0.f, 0.f); a2 = a1; }
             ds_uint4_t b_hi, b_lo;
             DS_SPLIT2(a1.x, a1.y, b_hi.x, b_lo.x);
