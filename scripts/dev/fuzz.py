@@ -1,6 +1,7 @@
 """Differential fuzz: random batches (graph sizes 1..500, sparse to dense, duplicate edges, self loops, isolated nodes, tiny and huge
 graphs mixed) through the HIP path vs the CPU oracle, plus consistency under a batch split and through the entry point.
-usage: fuzz.py MODEL [seconds] [seed]      (dev tool; imports oracle/ like the tests do)"""
+usage: fuzz.py MODEL [seconds] [seed] [mode]      (dev tool; imports oracle/ like the tests do)
+mode: f32 (default) | q (the fixed-point mode, BIT-exact against the Q oracle) | variants (random option sets against the default path)"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
@@ -12,6 +13,7 @@ from flowgnn_amd import Engine, compute_graphs, graphpack as gp, weights
 model = sys.argv[1] if len(sys.argv) > 1 else "GIN"
 budget = float(sys.argv[2]) if len(sys.argv) > 2 else 60.0
 seed0 = int(sys.argv[3]) if len(sys.argv) > 3 else 1
+mode = sys.argv[4] if len(sys.argv) > 4 else "f32"
 base = model.replace("-VN", "").lower()
 w = getattr(weights, f"synth_{base}_weights")(seed=11)
 ofn = getattr(oracle, f"{base}_forward")
@@ -36,8 +38,20 @@ def rand_graph(rng):
     return gp.GraphBatch(np.array([n], np.int32), np.array([m], np.int32), nf, el, ea, eig)
 
 
+VARIANTS = {
+    "GIN": [{"gin_tile_build": 1}, {"gin_tile_build": 0}, {"gin_pingpong": 1, "gin_tile_build": 0}, {"gin_pingpong": 2, "gin_tile_build": 0}, {"gin_resident": 0},
+            {"gin_resident": 0, "gin_unfused": 1}, {"gin_fold_readout": 0}, {"gin_head_fold": 0}, {"gin_resident_min_fill": 0}, {"hipgraph": 0}],
+    "GIN-VN": [{"gin_tile_build": 1}, {"gin_tile_build": 0}, {"gin_resident": 0}, {"gin_resident": 0, "gin_unfused": 1}, {"gin_resident_min_fill": 0}],
+    "GCN": [{"gcn_resident": 0}, {"gcn_resident": 0, "gcn_unfused": 1}, {"hipgraph": 0}],
+    "GAT": [{"gat_resident": 0}, {"gat_fold_readout": 0}, {"hipgraph": 0}],
+    "PNA": [{"pna_fused": 0}, {"hipgraph": 0}],
+    "DGN": [{"dgn_fused": 0}, {"dgn_mfma_agg": 0}, {"dgn_mfma_agg": 1}, {"dgn_mfma_agg": 1, "dgn_rowinfo_direct": 0}, {"dgn_mfma_agg": 1, "dgn_fold_readout": 0}],
+}[model]
+
 e = Engine(model, 0)
 e.set_weights(w)
+if mode == "q":
+    e.set_numeric_mode("q6.10")
 t_end = time.time() + budget
 it = 0
 worst = 0.0
@@ -54,21 +68,37 @@ while time.time() < t_end:
     if model == "GIN-VN":
         b = gp.add_virtual_nodes(b)
     got = e.forward(b)
-    want, hd = ofn(b, [w], dump_h=True, nthreads=8)
-    scale = max(1.0, float(np.abs(hd).max()))
-    ok = np.isfinite(got).all() and np.allclose(got, want, rtol=2e-4, atol=2e-3 * scale if model in ("PNA", "DGN", "GAT") else 2e-4 * scale)
-    cut = int(rng.integers(0, b.num_graphs + 1))
-    parts = [e.forward(b.slice(a, c)) for a, c in ((0, cut), (cut, b.num_graphs)) if c > a]
-    split = np.concatenate(parts) if parts else got[:0]
-    ok_split = np.allclose(split, got, rtol=1e-4, atol=1e-4 * scale)
-    ent = compute_graphs(model, b, [w])
-    ok_ent = np.allclose(ent, got, rtol=1e-4, atol=1e-4 * scale)
-    err = float(np.abs(got - want).max() / scale) if got.size else 0.0
+    if mode == "q":
+        want = oracle.gin_forward_q(b, [w], nthreads=8) if base == "gin" else oracle.q_forward(model, b, [w], nthreads=8)[0]
+        want = want[0] if isinstance(want, tuple) else want
+        ok = np.array_equal(got, want)
+        cut = int(rng.integers(0, b.num_graphs + 1))
+        parts = [e.forward(b.slice(a, c)) for a, c in ((0, cut), (cut, b.num_graphs)) if c > a]
+        ok_split = np.array_equal(np.concatenate(parts) if parts else got[:0], got)
+        ok_ent, scale, err = True, 1.0, float(np.abs(got - want).max()) if got.size else 0.0
+    else:
+        want, hd = ofn(b, [w], dump_h=True, nthreads=8)
+        scale = max(1.0, float(np.abs(hd).max()))
+        ok = np.isfinite(got).all() and np.allclose(got, want, rtol=2e-4, atol=2e-3 * scale if model in ("PNA", "DGN", "GAT") else 2e-4 * scale)
+        cut = int(rng.integers(0, b.num_graphs + 1))
+        parts = [e.forward(b.slice(a, c)) for a, c in ((0, cut), (cut, b.num_graphs)) if c > a]
+        split = np.concatenate(parts) if parts else got[:0]
+        ok_split = np.allclose(split, got, rtol=1e-4, atol=1e-4 * scale)
+        if mode == "variants":
+            opts = VARIANTS[int(rng.integers(0, len(VARIANTS)))]
+            e2 = Engine(model, 0, options=opts)
+            e2.set_weights(w)
+            ent = e2.forward(b)
+            e2.close()
+        else:
+            opts = "entry point"
+            ent = compute_graphs(model, b, [w])
+        ok_ent = np.isfinite(ent).all() and np.allclose(ent, got, rtol=1e-4, atol=1e-4 * scale)
+        err = float(np.abs(got - want).max() / scale) if got.size else 0.0
     worst = max(worst, err)
     if not (ok and ok_split and ok_ent):
-        print(f"FAIL {model} seed {seed0} iter {it}: graphs {b.num_graphs} nodes {b.total_nodes} edges {b.total_edges} oracle_ok {ok} split_ok {ok_split} entry_ok {ok_ent} "
-              f"max|d| {np.abs(got - want).max():.3e} scale {scale:.3e} exact_reruns {e.exact_reruns()}", flush=True)
-        np.savez(os.path.join(ROOT, "gpurun_out", f"fuzz_fail_{model}_{seed0}_{it}.npz"), nn=b.nums_of_nodes, ne=b.nums_of_edges, nf=b.node_feature, el=b.edge_list, ea=b.edge_attr)
+        print(f"FAIL {model} mode {mode} seed {seed0} iter {it}: graphs {b.num_graphs} nodes {b.total_nodes} edges {b.total_edges} oracle_ok {ok} split_ok {ok_split} "
+              f"other_ok {ok_ent} ({opts if mode != 'q' else ''}) max|d| {np.abs(got - want).max():.3e} scale {scale:.3e} exact_reruns {e.exact_reruns()}", flush=True)
         sys.exit(1)
     it += 1
-print(f"{model}: {it} random batches ok, worst |gpu - oracle| / scale = {worst:.2e}, exact_reruns {e.exact_reruns()}", flush=True)
+print(f"{model} [{mode}]: {it} random batches ok, worst |gpu - oracle| / scale = {worst:.2e}, exact_reruns {e.exact_reruns()}", flush=True)

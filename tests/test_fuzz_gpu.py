@@ -15,10 +15,15 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+@pytest.mark.parametrize("mode", ["f32", "q", "variants"])
 @pytest.mark.parametrize("model", ["GIN", "GIN-VN", "GCN", "GAT", "PNA", "DGN"])
-def test_short_fuzz(model):
-    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "dev", "fuzz.py"), model, "5", "7"], capture_output=True, text=True, timeout=300)
+def test_short_fuzz(model, mode):
+    """f32: against the float oracle (tolerance), a batch split and the entry point; q: the fixed-point mode, BIT-exact against the Q
+    oracle and under a split; variants: a random option set (per-layer kernels, unfused paths, ping-pong, ...) against the default."""
+    if mode == "q" and model == "GIN-VN":
+        pytest.skip("the GIN fixed-point oracle has no virtual-node entry of its own (GIN-VN runs as GIN on augmented graphs)")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "dev", "fuzz.py"), model, "5" if mode == "f32" else "3", "7", mode],
+                       capture_output=True, text=True, timeout=300)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
     assert "random batches ok" in p.stdout
 
