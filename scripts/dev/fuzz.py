@@ -1,7 +1,9 @@
 """Differential fuzz: random batches (graph sizes 1..500, sparse to dense, duplicate edges, self loops, isolated nodes, tiny and huge
 graphs mixed) through the HIP path vs the CPU oracle, plus consistency under a batch split and through the entry point.
 usage: fuzz.py MODEL [seconds] [seed] [mode]      (dev tool; imports oracle/ like the tests do)
-mode: f32 (default) | q (the fixed-point mode, BIT-exact against the Q oracle) | variants (random option sets against the default path)"""
+mode: f32 (default) | q (the fixed-point mode, BIT-exact against the Q oracle) | variants (random option sets against the default path)
+      | entry (the drop-in symbol with two or three weight sets switched by reload_weights, NUM_TASK 1..5 where the model has it, every
+        pipeline setting, against the oracle)"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
@@ -67,6 +69,30 @@ while time.time() < t_end:
     b = gp.concat_batches(graphs)
     if model == "GIN-VN":
         b = gp.add_virtual_nodes(b)
+    if mode == "entry":
+        from flowgnn_amd import entry_set_pipeline
+        T = int(rng.integers(1, 6)) if base in ("gin", "gcn") else 1
+        mk = getattr(weights, f"synth_{base}_weights")
+        sets = [mk(seed=11 + k, num_tasks=T) if base in ("gin", "gcn") else mk(seed=11 + k) for k in range(int(rng.integers(1, 4)))]
+        rw = np.zeros(b.num_graphs, np.int32)
+        rw[0] = 1
+        for k in range(1, len(sets)):
+            if b.num_graphs > 1:
+                rw[int(rng.integers(1, b.num_graphs))] = 1
+        rw[0] = 1
+        sets = sets[: int(rw.sum())]
+        entry_set_pipeline(int(rng.choice([0, 1, 2, 3])))
+        got = compute_graphs(model, b, sets, rw, **({"num_tasks": T} if T > 1 else {}))
+        kw = {"num_tasks": T} if base in ("gin", "gcn") else {}
+        want = ofn(b, sets, rw, nthreads=8, **kw)
+        scale = max(1.0, float(np.abs(want).max()))
+        ok = got.shape == want.shape and np.isfinite(got).all() and np.allclose(got, want, rtol=2e-4, atol=2e-3 * scale if model in ("PNA", "DGN", "GAT") else 2e-4 * scale)
+        worst = max(worst, float(np.abs(got - want).max() / scale) if got.size else 0.0)
+        if not ok:
+            print(f"FAIL {model} mode entry seed {seed0} iter {it}: graphs {b.num_graphs} sets {len(sets)} tasks {T} rw {np.nonzero(rw)[0]} max|d| {np.abs(got - want).max():.3e} scale {scale:.3e}", flush=True)
+            sys.exit(1)
+        it += 1
+        continue
     got = e.forward(b)
     if mode == "q":
         want = oracle.gin_forward_q(b, [w], nthreads=8) if base == "gin" else oracle.q_forward(model, b, [w], nthreads=8)[0]
