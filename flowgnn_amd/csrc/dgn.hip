@@ -577,16 +577,20 @@ __global__ __launch_bounds__(512, 2) void dgn_layer_mfma_kernel(const float* __r
                 const uint32_t hi16 = (uint32_t)(-(int)((bits >> (8 * sb + 2 * pr + 1)) & 1u)) & 0xFFFF0000u;
                 m[pr] = lo16 | hi16;
             }
-            const float4 ea = *reinterpret_cast<const float4*>(s_eig + 32 * sb + 8 * g), eb = *reinterpret_cast<const float4*>(s_eig + 32 * sb + 8 * g + 4);
-            ds_uint4_t eh, el;
-            DS_SPLIT2((ea.x - eig_v) * wscale, (ea.y - eig_v) * wscale, eh.x, el.x);
-            DS_SPLIT2((ea.z - eig_v) * wscale, (ea.w - eig_v) * wscale, eh.y, el.y);
-            DS_SPLIT2((eb.x - eig_v) * wscale, (eb.y - eig_v) * wscale, eh.z, el.z);
-            DS_SPLIT2((eb.z - eig_v) * wscale, (eb.w - eig_v) * wscale, eh.w, el.w);
-            b_one[sb] = m & (ds_uint4_t){0x3C003C00u, 0x3C003C00u, 0x3C003C00u, 0x3C003C00u};
-            b_eh[sb] = m & eh;
-            b_el[sb] = m & el;
             blk[sb] = __any(((bits >> (8 * sb)) & 0xFFu) != 0);  // wave-uniform: a source block none of the 16 rows touches is skipped
+            b_one[sb] = m & (ds_uint4_t){0x3C003C00u, 0x3C003C00u, 0x3C003C00u, 0x3C003C00u};
+            b_eh[sb] = (ds_uint4_t){0u, 0u, 0u, 0u};
+            b_el[sb] = b_eh[sb];
+            if (blk[sb]) {  // (block diagonal: a 16-row group sees two or three of the four blocks)
+                const float4 ea = *reinterpret_cast<const float4*>(s_eig + 32 * sb + 8 * g), eb = *reinterpret_cast<const float4*>(s_eig + 32 * sb + 8 * g + 4);
+                ds_uint4_t eh, el;
+                DS_SPLIT2((ea.x - eig_v) * wscale, (ea.y - eig_v) * wscale, eh.x, el.x);
+                DS_SPLIT2((ea.z - eig_v) * wscale, (ea.w - eig_v) * wscale, eh.y, el.y);
+                DS_SPLIT2((eb.x - eig_v) * wscale, (eb.y - eig_v) * wscale, eh.z, el.z);
+                DS_SPLIT2((eb.z - eig_v) * wscale, (eb.w - eig_v) * wscale, eh.w, el.w);
+                b_eh[sb] = m & eh;
+                b_el[sb] = m & el;
+            }
         }
         float4_t acc[DGN_OT];
 #pragma unroll
