@@ -18,6 +18,9 @@ seed0 = int(sys.argv[3]) if len(sys.argv) > 3 else 1
 mode = sys.argv[4] if len(sys.argv) > 4 else "f32"
 base = model.replace("-VN", "").lower()
 w = getattr(weights, f"synth_{base}_weights")(seed=11)
+wscale = float(os.environ.get("FUZZ_WEIGHT_SCALE", "1"))  # > 1: activations grow layer by layer -- the f16 range flag and the exact-fp32 re-run get exercised
+if wscale != 1.0:
+    w = {k: (v * np.float32(wscale) if ("weight" in k.lower() or "mlp" in k.lower() or "conv" in k.lower()) and "emb" not in k.lower() and "bn" not in k.lower() else v) for k, v in w.items()}
 ofn = getattr(oracle, f"{base}_forward")
 
 
@@ -104,12 +107,17 @@ while time.time() < t_end:
         ok_ent, scale, err = True, 1.0, float(np.abs(got - want).max()) if got.size else 0.0
     else:
         want, hd = ofn(b, [w], dump_h=True, nthreads=8)
+        if not np.isfinite(want).all() or not np.isfinite(hd).all():
+            it += 1  # the reference arithmetic itself overflowed on this batch: nothing to compare
+            continue
         scale = max(1.0, float(np.abs(hd).max()))
         ok = np.isfinite(got).all() and np.allclose(got, want, rtol=2e-4, atol=2e-3 * scale if model in ("PNA", "DGN", "GAT") else 2e-4 * scale)
         cut = int(rng.integers(0, b.num_graphs + 1))
         parts = [e.forward(b.slice(a, c)) for a, c in ((0, cut), (cut, b.num_graphs)) if c > a]
         split = np.concatenate(parts) if parts else got[:0]
-        ok_split = np.allclose(split, got, rtol=1e-4, atol=1e-4 * scale)
+        # (PNA: a shard may pack below the fused kernel's fill threshold and run the two-kernel layers, whose std = sqrt(Q/n - mean^2)
+        # rounds differently -- and that difference of squares amplifies roundings when the variance is small against the mean)
+        ok_split = np.allclose(split, got, rtol=1e-4, atol=(5e-4 if model == "PNA" else 1e-4) * scale)
         if mode == "variants":
             opts = VARIANTS[int(rng.integers(0, len(VARIANTS)))]
             e2 = Engine(model, 0, options=opts)
@@ -119,7 +127,7 @@ while time.time() < t_end:
         else:
             opts = "entry point"
             ent = compute_graphs(model, b, [w])
-        ok_ent = np.isfinite(ent).all() and np.allclose(ent, got, rtol=1e-4, atol=1e-4 * scale)
+        ok_ent = np.isfinite(ent).all() and np.allclose(ent, got, rtol=1e-4, atol=(5e-4 if model == "PNA" else 1e-4) * scale)
         err = float(np.abs(got - want).max() / scale) if got.size else 0.0
     worst = max(worst, err)
     if not (ok and ok_split and ok_ent):
