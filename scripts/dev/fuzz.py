@@ -110,7 +110,7 @@ while time.time() < t_end:
         if not np.isfinite(want).all() or not np.isfinite(hd).all():
             it += 1  # the reference arithmetic itself overflowed on this batch: nothing to compare
             continue
-        scale = max(1.0, float(np.abs(hd).max()))
+        scale = max(1.0, float(np.abs(hd).max()), float(np.abs(want).max()))  # (scaled head weights: the logits can be larger than any activation)
         ok = np.isfinite(got).all() and np.allclose(got, want, rtol=2e-4, atol=2e-3 * scale if model in ("PNA", "DGN", "GAT") else 2e-4 * scale)
         cut = int(rng.integers(0, b.num_graphs + 1))
         parts = [e.forward(b.slice(a, c)) for a, c in ((0, cut), (cut, b.num_graphs)) if c > a]

@@ -36,3 +36,10 @@ for opts in ({}, {"dgn_mfma_agg": 0}):
         eig = b.node_eigen[:, 1]
         print("  node", v, "of graph", gi, "in-edges from", np.sort(ins)[:20], "eig_v", eig[v], "weights", (eig[ins] - eig[v])[:20], "sum|w|", np.abs(eig[ins] - eig[v]).sum())
     e.close()
+if model == "PNA":
+    for opts in ({"pna_fused": 0}, {"pna_mfma": 32}, {"pna_fused": 0, "pna_mfma": 32}):
+        e = Engine(model, 0, options=opts); e.set_weights(w)
+        got = e.forward(b); h = e.final_h()
+        print(opts, "logits max err", np.abs(got - want).max(), "rows max err", np.abs(h - hd[-1]).max(), "max|h|", np.abs(h).max(), "exact_reruns", e.exact_reruns())
+        e.close()
+    print("oracle max|h| per layer", [float(np.abs(x).max()) for x in hd])
