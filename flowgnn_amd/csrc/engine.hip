@@ -176,6 +176,7 @@ struct flowgnn_engine {
     int device = 0;
     hipStream_t stream = nullptr;      // the stream every launch goes to
     hipStream_t own_stream = nullptr;  // the engine's own stream (stream == own_stream unless flowgnn_set_stream redirected it)
+    hipStream_t copy_stream = nullptr; // flowgnn_set_batch's host -> device copies: the engine's own queue, not the process's null stream
     Model* model = nullptr;
     Options opts;   // defaults <- environment (read once, here) <- flowgnn_set_option
     Profiler prof;
@@ -226,7 +227,7 @@ struct flowgnn_engine {
     }
 
     void free_batch() {
-        void* ptrs[] = {d_nn, d_ne, d_noff, d_eoff, d_nf, d_el, d_ea, d_eig, d_rowptr, d_src, d_eid, d_outdeg, d_gsrc,
+        void* ptrs[] = {d_nn /* base of d_ne, d_noff, d_eoff too */, d_nf, d_el, d_ea, d_eig, d_rowptr, d_src, d_eid, d_outdeg, d_gsrc,
                         d_gdst, d_cursor, d_tmp, d_bsums, d_ecode, d_h0, d_h1, d_scratch, d_out};
         for (void* p : ptrs)
             if (p) (void)hipFree(p);
@@ -235,8 +236,7 @@ struct flowgnn_engine {
         d_rowptr = d_src = d_eid = d_outdeg = d_gsrc = d_gdst = d_cursor = d_tmp = d_bsums = nullptr;
         d_ecode = nullptr;
         d_h0 = d_h1 = d_scratch = d_out = nullptr;
-        if (d_trow) (void)hipFree(d_trow);
-        if (d_tgraph) (void)hipFree(d_tgraph);
+        if (d_trow) (void)hipFree(d_trow);  // (base of d_tgraph too)
         d_trow = d_tgraph = nullptr;
         cap_tiles = 0;
         if (d_sub) (void)hipFree(d_sub);
@@ -312,6 +312,14 @@ int flowgnn_create(int model, int device_id, flowgnn_engine** out) {
     if (!rc) {
         hipError_t he = hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking);
         e->stream = e->own_stream;
+        // Copies on a stream of their own, at the highest priority (priorities have their own hardware queues): through the null stream
+        // a copy can share a queue with ANOTHER engine's kernels -- which queue a stream lands on depends on how many streams the
+        // process has had -- and then waits for them: the entry points' copy / kernel pipeline ran at 31 ms instead of 13 in such runs.
+        if (he == hipSuccess) {
+            int lo = 0, hi = 0;
+            (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+            if (hipStreamCreateWithPriority(&e->copy_stream, hipStreamNonBlocking, hi) != hipSuccess) { (void)hipGetLastError(); e->copy_stream = nullptr; }
+        }
         if (he == hipSuccess) he = hipMalloc((void**)&e->d_err, 2 * sizeof(int));  // [0] validation, [1] range flag
         if (he == hipSuccess) he = hipMemset(e->d_err, 0, 2 * sizeof(int));
         if (he != hipSuccess) {
@@ -338,6 +346,7 @@ int flowgnn_destroy(flowgnn_engine* e) {
     if (e->d_err) (void)hipFree(e->d_err);
     delete e->model;
     if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
+    if (e->copy_stream) (void)hipStreamDestroy(e->copy_stream);
     delete e;
     return FLOWGNN_OK;
 }
@@ -397,10 +406,11 @@ static int alloc_batch(flowgnn_engine* e, size_t G, size_t N, size_t E, bool att
         if (regrow) { G += G / 8; N += N / 8; E += E / 8; }
         e->free_batch();
         const size_t g1 = G ? G : 1, n1 = N ? N : 1, e1 = E ? E : 1;
-        EHIP_TRY(e, hipMalloc((void**)&e->d_nn, sizeof(int) * g1));
-        EHIP_TRY(e, hipMalloc((void**)&e->d_ne, sizeof(int) * g1));
-        EHIP_TRY(e, hipMalloc((void**)&e->d_noff, sizeof(int) * (g1 + 1)));
-        EHIP_TRY(e, hipMalloc((void**)&e->d_eoff, sizeof(int) * (g1 + 1)));
+        // the four per-graph arrays share ONE allocation (d_nn is its base; flowgnn_set_batch places the other three behind it and
+        // fills all four with one copy: every host -> device copy costs ~20 us whatever its size, which is what a dataset-sized
+        // batch's flowgnn_set_batch is made of)
+        EHIP_TRY(e, hipMalloc((void**)&e->d_nn, sizeof(int) * (4 * g1 + 2)));
+        e->d_ne = e->d_noff = e->d_eoff = nullptr;
         EHIP_TRY(e, hipMalloc((void**)&e->d_nf, sizeof(int) * n1 * ND_FEATURE));
         EHIP_TRY(e, hipMalloc((void**)&e->d_el, sizeof(int) * e1 * 2));
         if (attr) EHIP_TRY(e, hipMalloc((void**)&e->d_ea, sizeof(int) * e1 * EDGE_ATTR));
@@ -466,13 +476,23 @@ int flowgnn_set_batch(flowgnn_engine* e, int num_graphs, const int* nums_of_node
     ENGINE_TRY(e, alloc_batch(e, (size_t)num_graphs, (size_t)N, (size_t)E, attr, eig));
     auto h2d = [&](void* dst, const void* src, size_t bytes) -> int {
         if (bytes == 0) return 0;
-        EHIP_TRY(e, hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
+        if (e->copy_stream) {  // (the source is the caller's pageable memory: the call returns when the data has left it)
+            EHIP_TRY(e, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, e->copy_stream));
+            EHIP_TRY(e, hipStreamSynchronize(e->copy_stream));
+        } else {
+            EHIP_TRY(e, hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
+        }
         return 0;
     };
-    ENGINE_TRY(e, h2d(e->d_nn, nums_of_nodes, sizeof(int) * (size_t)num_graphs));
-    ENGINE_TRY(e, h2d(e->d_ne, nums_of_edges, sizeof(int) * (size_t)num_graphs));
-    ENGINE_TRY(e, h2d(e->d_noff, noff.data(), sizeof(int) * ((size_t)num_graphs + 1)));
-    ENGINE_TRY(e, h2d(e->d_eoff, eoff.data(), sizeof(int) * ((size_t)num_graphs + 1)));
+    {   // counts and offsets: one staging vector, one copy
+        const size_t G = (size_t)num_graphs;
+        std::vector<int> meta(4 * G + 2);
+        if (G) { memcpy(meta.data(), nums_of_nodes, sizeof(int) * G); memcpy(meta.data() + G, nums_of_edges, sizeof(int) * G); }
+        memcpy(meta.data() + 2 * G, noff.data(), sizeof(int) * (G + 1));
+        memcpy(meta.data() + 3 * G + 1, eoff.data(), sizeof(int) * (G + 1));
+        e->d_ne = e->d_nn + G; e->d_noff = e->d_nn + 2 * G; e->d_eoff = e->d_nn + 3 * G + 1;
+        ENGINE_TRY(e, h2d(e->d_nn, meta.data(), sizeof(int) * meta.size()));
+    }
     ENGINE_TRY(e, h2d(e->d_nf, node_feature, sizeof(int) * (size_t)N * ND_FEATURE));
     ENGINE_TRY(e, h2d(e->d_el, edge_list, sizeof(int) * (size_t)E * 2));
     if (attr) ENGINE_TRY(e, h2d(e->d_ea, edge_attr, sizeof(int) * (size_t)E * EDGE_ATTR));
@@ -505,15 +525,15 @@ int flowgnn_set_batch(flowgnn_engine* e, int num_graphs, const int* nums_of_node
                 const size_t cnt = trow.size();
                 if (cnt > e->cap_tiles) {
                     if (e->d_trow) (void)hipFree(e->d_trow);
-                    if (e->d_tgraph) (void)hipFree(e->d_tgraph);
                     e->d_trow = e->d_tgraph = nullptr;
                     e->cap_tiles = 0;
-                    EHIP_TRY(e, hipMalloc((void**)&e->d_trow, sizeof(int) * cnt));
-                    EHIP_TRY(e, hipMalloc((void**)&e->d_tgraph, sizeof(int) * cnt));
-                    e->cap_tiles = cnt;
+                    const size_t cap = cnt + cnt / 8;  // (ranges of a cut job differ by a few tiles)
+                    EHIP_TRY(e, hipMalloc((void**)&e->d_trow, sizeof(int) * 2 * cap));
+                    e->cap_tiles = cap;
                 }
-                ENGINE_TRY(e, h2d(e->d_trow, trow.data(), sizeof(int) * cnt));
-                ENGINE_TRY(e, h2d(e->d_tgraph, tgraph.data(), sizeof(int) * cnt));
+                e->d_tgraph = e->d_trow + cnt;  // one allocation, one copy
+                trow.insert(trow.end(), tgraph.begin(), tgraph.end());
+                ENGINE_TRY(e, h2d(e->d_trow, trow.data(), sizeof(int) * 2 * cnt));
                 GraphTiles& gt = e->db.gtiles;
                 gt.row_start = e->d_trow; gt.graph_start = e->d_tgraph;
                 gt.n_tiles = (int)cnt - 1; gt.rows = t_rows; gt.edges = t_edges; gt.ok = true;
@@ -552,9 +572,12 @@ int flowgnn_set_batch(flowgnn_engine* e, int num_graphs, const int* nums_of_node
                 EHIP_TRY(e, hipMalloc((void**)&e->d_sub, sizeof(int) * (cnt ? cnt : 1)));
                 e->cap_sub = cnt;
             }
-            ENGINE_TRY(e, h2d(e->d_sub, sub.data(), sizeof(int) * sub.size()));
-            ENGINE_TRY(e, h2d(e->d_sub + sub.size(), brow.data(), sizeof(int) * brow.size()));
-            ENGINE_TRY(e, h2d(e->d_sub + sub.size() + brow.size(), bgraph.data(), sizeof(int) * bgraph.size()));
+            {
+                std::vector<int> all(sub);
+                all.insert(all.end(), brow.begin(), brow.end());
+                all.insert(all.end(), bgraph.begin(), bgraph.end());
+                ENGINE_TRY(e, h2d(e->d_sub, all.data(), sizeof(int) * all.size()));
+            }
             GraphTiles& gt = e->db.gtiles;
             gt.sub = e->d_sub; gt.n_sub = (int)(sub.size() / 4); gt.sub_rows = s_rows; gt.sub_edges = s_edges;
             gt.big_row = e->d_sub + sub.size(); gt.big_graph = e->d_sub + sub.size() + brow.size(); gt.n_big = (int)(brow.size() / 2);
@@ -671,7 +694,12 @@ int flowgnn_sync(flowgnn_engine* e) {
     }
     e->prof.collect();
     int flags[2] = {0, 0};
-    he = hipMemcpy(flags, e->d_err, sizeof(flags), hipMemcpyDeviceToHost);
+    if (e->copy_stream) {  // (on the engine's own copy queue: the null stream may share a hardware queue with another engine's kernels)
+        he = hipMemcpyAsync(flags, e->d_err, sizeof(flags), hipMemcpyDeviceToHost, e->copy_stream);
+        if (he == hipSuccess) he = hipStreamSynchronize(e->copy_stream);
+    } else {
+        he = hipMemcpy(flags, e->d_err, sizeof(flags), hipMemcpyDeviceToHost);
+    }
     if (he != hipSuccess) {
         set_hip_error("read error flag", he, __FILE__, __LINE__);
         e->err = fg::last_error_text();
@@ -710,7 +738,13 @@ int flowgnn_get_results(flowgnn_engine* e, float* out_host) {
     int rc = flowgnn_sync(e);
     if (rc) return rc;
     if (e->G > 0) {
-        hipError_t he = hipMemcpy(out_host, e->db.out, sizeof(float) * (size_t)e->G * e->num_tasks, hipMemcpyDeviceToHost);
+        hipError_t he;
+        if (e->copy_stream) {
+            he = hipMemcpyAsync(out_host, e->db.out, sizeof(float) * (size_t)e->G * e->num_tasks, hipMemcpyDeviceToHost, e->copy_stream);
+            if (he == hipSuccess) he = hipStreamSynchronize(e->copy_stream);
+        } else {
+            he = hipMemcpy(out_host, e->db.out, sizeof(float) * (size_t)e->G * e->num_tasks, hipMemcpyDeviceToHost);
+        }
         if (he != hipSuccess) {
             set_hip_error("copy results", he, __FILE__, __LINE__);
             e->err = fg::last_error_text();
