@@ -684,11 +684,16 @@ __global__ __launch_bounds__(512, 2) void dgn_layer_mfma_kernel(const float* __r
         // ---- epilogue: h' = h + relu(b + W0 a1 + W1 a2)   (node_embedding.cc:176-181)
         if constexpr (!POOL) {
             if (valid) {
+                // the row's own slices are requested TOGETHER, ahead of the stores: a load issued between two stores is waited for with
+                // vmcnt(0), i.e. together with the store before it -- seven serialized global round trips per tile
+                float4 hvv[DGN_OT];
+#pragma unroll
+                for (int t = 0; t < DGN_OT; t++) hvv[t] = *reinterpret_cast<const float4*>(hrow + (16 * t + 4 * g < DGN_D ? 16 * t + 4 * g : 0));
 #pragma unroll
                 for (int t = 0; t < DGN_OT; t++) {
                     const int c = 16 * t + 4 * g;
                     if (c < DGN_D) {
-                        const float4 hv = *reinterpret_cast<const float4*>(hrow + c);
+                        const float4 hv = hvv[t];
                         const float4_t rr = acc[t] * oscale;
                         *reinterpret_cast<float4*>(hout + (size_t)node * DGN_D + c) =
                             make_float4(hv.x + relu1(rr.x), hv.y + relu1(rr.y), hv.z + relu1(rr.z), hv.w + relu1(rr.w));

@@ -482,9 +482,14 @@ __global__ __launch_bounds__(PNA_FT_WAVES * 64, 4) void pna_layer_fused_kernel(c
             const float logd = logf((float)(odeg + 1));
             const float sf_t = logd / avg_deg;
             const float sf_scale = (logd == 0.0f) ? 1.0f : avg_deg / logd;
+            // the bias slices are requested TOGETHER, ahead of the stores: a load issued between two stores is waited for with
+            // vmcnt(0), i.e. together with the store before it -- five serialized global round trips per tile
+            float4 bb[PNA_OT];
+#pragma unroll
+            for (int t = 0; t < PNA_OT; t++) bb[t] = *reinterpret_cast<const float4*>(bias + 16 * t + 4 * g);
 #pragma unroll
             for (int t = 0; t < PNA_OT; t++) {
-                const float4 b = *reinterpret_cast<const float4*>(bias + 16 * t + 4 * g);
+                const float4 b = bb[t];
                 float4_t fin = {b.x, b.y, b.z, b.w};
                 fin += y[0 * PNA_OT + t] * oscale;
                 fin += sf_t * (y[1 * PNA_OT + t] * oscale);
