@@ -3,7 +3,8 @@ graphs mixed) through the HIP path vs the CPU oracle, plus consistency under a b
 usage: fuzz.py MODEL [seconds] [seed] [mode]      (dev tool; imports oracle/ like the tests do)
 mode: f32 (default) | q (the fixed-point mode, BIT-exact against the Q oracle) | variants (random option sets against the default path)
       | entry (the drop-in symbol with two or three weight sets switched by reload_weights, NUM_TASK 1..5 where the model has it, every
-        pipeline setting, against the oracle)"""
+        pipeline setting, against the oracle)
+environment: FUZZ_WEIGHT_SCALE=x (layer weights scaled: range flags, exact re-runs), FUZZ_WEIGHTS=trained (the reference's trained set)"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
@@ -18,6 +19,9 @@ seed0 = int(sys.argv[3]) if len(sys.argv) > 3 else 1
 mode = sys.argv[4] if len(sys.argv) > 4 else "f32"
 base = model.replace("-VN", "").lower()
 w = getattr(weights, f"synth_{base}_weights")(seed=11)
+if os.environ.get("FUZZ_WEIGHTS", "") == "trained":  # the reference's own trained set (a data fixture of the tests) instead of synthetic weights
+    z = np.load(os.path.join(ROOT, "tests", "golden", f"ref_weights_{base}.npz"))
+    w = {k: z[k] for k in z.files}
 wscale = float(os.environ.get("FUZZ_WEIGHT_SCALE", "1"))  # > 1: activations grow layer by layer -- the f16 range flag and the exact-fp32 re-run get exercised
 if wscale != 1.0:
     w = {k: (v * np.float32(wscale) if ("weight" in k.lower() or "mlp" in k.lower() or "conv" in k.lower()) and "emb" not in k.lower() and "bn" not in k.lower() else v) for k, v in w.items()}
