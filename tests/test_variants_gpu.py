@@ -417,3 +417,48 @@ def test_dgn_in_edge_pass_from_the_edge_list_is_the_csr_one():
                 assert np.array_equal(e.forward(b), outs[direct])
             e.close()
         assert np.array_equal(outs[1], outs[0])
+
+
+@pytest.mark.parametrize("model", ["GIN", "GIN-VN", "GCN", "GAT", "PNA", "DGN"])
+def test_invalid_inputs_are_reported_on_every_path(model):
+    """An edge endpoint outside its graph, an edge attribute or a node feature outside its table: the reference indexes out of bounds
+    (it never validates); here the run fails with the validation code -- on the default path (one-pass GIN, resident kernels, DGN's
+    index pass from the edge list), on the per-layer kernels, and through the drop-in symbol (whatever range of the pipeline the bad
+    graph lands in) -- and the engine works again with the next good batch."""
+    from flowgnn_amd import FlowGNNError, compute_graphs
+    base = model.replace("-VN", "").lower()
+    w = getattr(weights, f"synth_{base}_weights")(seed=7)
+    hep = model in ("PNA", "DGN")
+    good = (gp.synth_hep10k_batch if hep else gp.synth_molhiv_batch)(300, seed=5)
+    if model == "GIN-VN":
+        good = gp.add_virtual_nodes(good)
+
+    def broken(kind):
+        el, ea, nf = good.edge_list.copy(), good.edge_attr.copy(), good.node_feature.copy()
+        e_mid = int(good.edge_offsets()[150]) + 1
+        if kind == "edge":
+            el[e_mid, 0] = int(good.nums_of_nodes[150]) + 3  # source beyond its graph
+        elif kind == "attr":
+            ea[e_mid, 1] = 6
+        else:
+            nf[int(good.node_offsets()[150]) + 1, 2] = 12
+        return gp.GraphBatch(good.nums_of_nodes, good.nums_of_edges, nf, el, ea, good.node_eigen)
+    # (GAT takes the nine node features as NUMBERS, not as table rows: any integer is a valid input there)
+    kinds = ["edge"] + (["feat"] if base != "gat" else []) + (["attr"] if base in ("gin", "gcn") else [])
+    switch = {"GIN": {"gin_resident": 0}, "GIN-VN": {"gin_resident": 0}, "GCN": {"gcn_resident": 0}, "GAT": {"gat_resident": 0},
+              "PNA": {"pna_fused": 0}, "DGN": {"dgn_rowinfo_direct": 0}}[model]
+    for opts in ({}, switch):
+        e = Engine(model, device=0, options=opts)
+        e.set_weights(w)
+        want = e.forward(good).copy()
+        for kind in kinds:
+            with pytest.raises(FlowGNNError) as ei:
+                e.forward(broken(kind))
+            assert ei.value.code in (2, 3, 4), (kind, ei.value.code)  # FLOWGNN_ERR_EDGE_RANGE / _EDGE_ATTR / _NODE_FEAT
+            assert np.array_equal(e.forward(good), want)
+        e.close()
+    for kind in kinds:
+        with pytest.raises(FlowGNNError) as ei:
+            compute_graphs(model, broken(kind), [w])
+        assert ei.value.code in (2, 3, 4)
+    assert np.allclose(compute_graphs(model, good, [w]), want, rtol=1e-4, atol=1e-4 * max(1.0, float(np.abs(want).max())))
