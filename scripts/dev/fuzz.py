@@ -115,7 +115,12 @@ while time.time() < t_end:
             it += 1  # the reference arithmetic itself overflowed on this batch: nothing to compare
             continue
         scale = max(1.0, float(np.abs(hd).max()), float(np.abs(want).max()))  # (scaled head weights: the logits can be larger than any activation)
-        ok = np.isfinite(got).all() and np.allclose(got, want, rtol=2e-4, atol=2e-3 * scale if model in ("PNA", "DGN", "GAT") else 2e-4 * scale)
+        # The fuzzer's own bounds sit a decade above the worst error ever seen per model (a wrong-head bug in a GAT experiment stayed
+        # inside the tests' documented tolerance at 600x the usual error); scaled weights fall back to the documented ones.
+        tight = {"GIN": 2e-5, "GIN-VN": 2e-5, "GCN": 2e-5, "GAT": 2e-6, "PNA": 1e-3, "DGN": 1e-5}[model]
+        if wscale != 1.0:
+            tight = 2e-3 if model in ("PNA", "DGN", "GAT") else 2e-4
+        ok = np.isfinite(got).all() and np.allclose(got, want, rtol=tight, atol=tight * scale)
         cut = int(rng.integers(0, b.num_graphs + 1))
         parts = [e.forward(b.slice(a, c)) for a, c in ((0, cut), (cut, b.num_graphs)) if c > a]
         split = np.concatenate(parts) if parts else got[:0]
