@@ -338,14 +338,17 @@ class ShardedResults:
     Two buffer pairs alternate from step to step and the gather is asynchronous: step i + 1 computes into the other pair
     while step i's logits travel, and a pair is only reused once its gather has been waited for."""
 
-    def __init__(self, ranges, rank, device, dist_mod):
+    def __init__(self, ranges, rank, device, dist_mod, collectives=None):
         import torch
         self.ranges, self.rank, self.dist = ranges, rank, dist_mod
         self.world = len(ranges)
+        # collectives: whether the per-step gather is issued at all (default: only with more than one rank; the one-GPU RCCL check
+        # of tests/test_rccl_gpu.py forces it with a group of one)
+        self.collectives = self.world > 1 if collectives is None else bool(collectives)
         self.width = max(1, max(b - a for a, b in ranges))
-        nbuf = 2 if self.world > 1 else 1
+        nbuf = 2 if self.collectives else 1
         self.pads = [torch.zeros(self.width, dtype=torch.float32, device=device) for _ in range(nbuf)]
-        self.alls = [torch.empty(self.world * self.width, dtype=torch.float32, device=device) for _ in range(nbuf)] if self.world > 1 else self.pads
+        self.alls = [torch.empty(self.world * self.width, dtype=torch.float32, device=device) for _ in range(nbuf)] if self.collectives else self.pads
         self.work = [None] * nbuf
         self.cur = 0    # the pair the coming step writes
         self.last = 0   # the pair the last finished step wrote
@@ -364,7 +367,7 @@ class ShardedResults:
 
     def gather(self):
         self.last = self.cur
-        if self.world > 1:
+        if self.collectives:
             self.work[self.cur] = self.dist.all_gather_into_tensor(self.alls[self.cur], self.pads[self.cur], async_op=True)
             self.cur ^= 1
 
@@ -443,6 +446,12 @@ def main():
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: what RCCL needs on this driver (already exported on the pool)
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         launch_ranks(args.gpus, sys.argv[1:])  # does not return
+    # stdout carries ONE line, the JSON record.  Libraries write there too (RCCL prints "Librccl path : ..." on stdout when its
+    # group comes up or goes down), so file descriptor 1 is pointed at stderr for the life of the process and the record is written
+    # to a private duplicate of the original stdout.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     import torch
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -455,9 +464,13 @@ def main():
         raise SystemExit(f"rank {rank}: LOCAL_RANK={local_rank} but {torch.cuda.device_count()} GPU(s) visible")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    # FLOWGNN_BENCH_FORCE_COLLECTIVES=1: run the N > 1 code path (RCCL group, barriers, per-step all-gather, max over ranks) with a
+    # group of ONE rank -- the only way to execute it on a one-GPU box (RCCL refuses two ranks on one device)
+    collectives = world > 1 or os.environ.get("FLOWGNN_BENCH_FORCE_COLLECTIVES") == "1"
+    if collectives:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     from flowgnn_amd import Engine, weights
@@ -478,7 +491,7 @@ def main():
     # gather (flowgnn_set_stream).
     side = torch.cuda.Stream()
     with torch.cuda.stream(side):  # the pads are zero-filled on the stream that later writes them
-        res = ShardedResults(ranges, rank, "cuda", dist)
+        res = ShardedResults(ranges, rank, "cuda", dist, collectives)
     torch.cuda.synchronize()
     eng.set_stream(side.cuda_stream)
     bound = [0]
@@ -496,7 +509,7 @@ def main():
             step()
         eng.sync()
         eng.profile_enable(True)  # HIP events around every kernel launch, on the stream the kernels are launched on
-        if world > 1:
+        if collectives:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -505,11 +518,11 @@ def main():
         eng.sync()  # inside the clock: stream sync + validation / range flags (an exact-fp32 re-run, if any, is timed too)
         res.finish()  # ... and the last gathers
         torch.cuda.synchronize()
-        if world > 1:
+        if collectives:
             dist.barrier()
         t1 = time.perf_counter()
         elapsed = t1 - t0
-        if world > 1:
+        if collectives:
             t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
@@ -521,6 +534,10 @@ def main():
     total_job_graphs = ranges[-1][1]
     if int(logits_all.shape[0]) != total_job_graphs:
         raise SystemExit(f"result concat has {int(logits_all.shape[0])} graphs, the job has {total_job_graphs}")
+    if collectives:  # what travelled is what this rank's readout wrote
+        g0, g1 = ranges[rank]
+        if not np.array_equal(logits_all[g0:g1].detach().cpu().numpy(), out_local):
+            raise SystemExit(f"rank {rank}: its range of the gathered logits differs from what its readout wrote")
 
     exit_code = 0
     if rank == 0:
@@ -538,6 +555,8 @@ def main():
         split = eng.get_option({"GIN-VN": "gin"}.get(args.model, args.model.lower()) + "_mfma") != 32
         roof, agg = rooflines(args.model, M, prof, kern, G, N, E, args.steps, split, qmode)
         par = f"batch-sharded x{world}, RCCL all-gather of logits" if world > 1 else "single GPU"
+        if collectives and world == 1:
+            par = "single GPU, the N > 1 code path forced (RCCL group of one rank: barriers, per-step all-gather, max over ranks)"
         line = {
             "metric": M["metric"],
             "value": value, "unit": "graphs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -599,13 +618,13 @@ def main():
             cfgs["DGN"] = measure_config("DGN", hep, csteps, cwarm, local_rank)
             line["configs"] = cfgs
             parity_ok = parity_ok and all(c["parity_ok"] for c in cfgs.values())
-        print(json.dumps(line), flush=True)
+        os.write(json_fd, (json.dumps(line) + "\n").encode())
         if not parity_ok:
             sys.stderr.write("bench.py: PARITY FAILURE against the oracle -- the throughput above is not a valid measurement\n")
             exit_code = 3
     if eng is not None:
         eng.close()
-    if world > 1:  # (rank 0 leaves through the same barrier as the others even when it is about to report a failure)
+    if collectives:  # (rank 0 leaves through the same barrier as the others even when it is about to report a failure)
         dist.barrier()
         dist.destroy_process_group()
     if exit_code:
