@@ -330,8 +330,8 @@ __global__ __launch_bounds__(512) void gcn_layer_fused_kernel(const float* __res
 //   * x_l never goes to HBM between layers: the gather reads neighbour rows from LDS, the dense layer writes x_{l+1} in place;
 //   * the tile's CSR slice is staged once per tile as 16-bit words (row inside the tile << 6 | edge code); dinv and 1 / (deg + 1)
 //     of the tile's rows are computed once per tile, so the per-edge norm is two LDS reads and a multiply;
-//   * the two weight regions are never needed at the same time: W_{l+1} (45 KiB of split fragments) streams L2 -> LDS while gather l
-//     runs, the next layer's edge-embedding table + epilogue vectors (25 KiB) while dense l + 1 runs;
+//   * the two weight regions are never needed at the same time: W_{l+1} (45 KiB of split fragments) streams L2 -> LDS behind gather l
+//     (requested when a wave's walk is done), the next layer's edge-embedding table + epilogue vectors (25 KiB) while dense l + 1 runs;
 //   * per node the launch reads 400 B (x_0, from gcn_encoder_dense_kernel) + 5 B per in-edge + 8 B of row bounds / degree, and
 //     writes 4 B per GRAPH.
 // LDS: 76 800 (rows) + 46 080 (W) + 25 600 (table + epilogue) + 1 920 (edges) + ~2 700 = 153 KB.
@@ -463,14 +463,6 @@ __global__ __launch_bounds__(GCNR_WAVES * 64, 3) void gcn_resident_kernel(const 
                 if (nne > GCNR_EDGES) nne = GCNR_EDGES;
             }
             if (l == 2 && has_next) fetch_csr(nt0, nrows, ne0, nne);
-            if (l + 1 < GCN_L && !(ablate & 16)) {  // W_{l+1} streams in under this layer's gather (45 pieces; ablate 16: timing without it)
-                const uint8_t* gw = layers + (size_t)(l + 1) * GCNR_LAYER_BYTES;
-#pragma unroll
-                for (int p = 0; p < 4; p++) {
-                    const int piece = wv + GCNR_WAVES * p;
-                    if (piece < GCNR_W_BYTES / 1024) lds_dma16(gw + piece * 1024, (uint32_t)lane * 16u, w_addr + piece * 1024);
-                }
-            }
             // ---- m_l[v] = sum over in-edges of norm relu(x_l[u] + ecomb[code]) (message_passing.cc:158-167), CSR order, all from LDS
             const float* xr = s_x + rr * GCN_D + 4 * g;
             float4 xs[6];
@@ -514,6 +506,18 @@ __global__ __launch_bounds__(GCNR_WAVES * 64, 3) void gcn_resident_kernel(const 
                         mq[2 * q + 1] += n2 * __builtin_elementwise_max(wv4[q].hi + xv[q].hi, (float2_t){0.0f, 0.0f});
                     }
                     mt += norm * relu1(wt + xt);
+                }
+            }
+            // W_{l+1} (45 pieces of 1 KiB) is requested BEHIND the walk and lands under the BatchNorm / split that follows and under the
+            // slower waves' last trips.  Requested at the top of the walk -- where it used to be -- every wave paid four LDS-DMA issues
+            // (100-150 cycles each) in front of its first trip and the 45 KiB landed through the LDS the walk is bound by: 5.18 ms per
+            // launch against 5.04 now (same box, scripts/dev/ab.py); in the middle of the walk 5.05.
+            if (l + 1 < GCN_L && !(ablate & 16)) {  // (ablate 16: timing without it)
+                const uint8_t* gw = layers + (size_t)(l + 1) * GCNR_LAYER_BYTES;
+#pragma unroll
+                for (int p = 0; p < 4; p++) {
+                    const int piece = wv + GCNR_WAVES * p;
+                    if (piece < GCNR_W_BYTES / 1024) lds_dma16(gw + piece * 1024, (uint32_t)lane * 16u, w_addr + piece * 1024);
                 }
             }
             float m[25];
@@ -564,14 +568,15 @@ __global__ __launch_bounds__(GCNR_WAVES * 64, 3) void gcn_resident_kernel(const 
             const float a24 = a[24];
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();  // #1: every gather of this layer is done (rows may be rewritten, the table replaced); W_{l+1} has landed
-            if (!(ablate & 8)) {  // the next layer's table + epilogue vectors stream in under the dense layer (ablate 8: timing without it)
+            auto issue_blob = [&]() {  // the next layer's table + epilogue vectors stream in under the dense layer
                 const uint8_t* gbl = layers + (size_t)(l + 1) * GCNR_LAYER_BYTES + GCNR_W_BYTES;
 #pragma unroll
                 for (int p = 0; p < 3; p++) {
                     const int piece = wv + GCNR_WAVES * p;
                     if (piece < GCNR_BLOB_BYTES / 1024) lds_dma16(gbl + piece * 1024, (uint32_t)lane * 16u, blob_addr + piece * 1024);
                 }
-            }
+            };
+            if (!(ablate & 8)) issue_blob();  // (ablate 8: timing without it; issued after the third or the last column tile instead: no change / +1.3 %)
             // ---- x_{l+1} = b + W a on the f16 matrix pipe (split products, dense_split.h), written over the wave's own rows
             const float oscale = *reinterpret_cast<const float*>(s_w + SCALE_OFF);
 #pragma unroll

@@ -1045,8 +1045,6 @@ __device__ __forceinline__ void gr_layer(unsigned long long (&tacc)[6], char* bx
     // decides and waves 4-7 trail by less: 2 305 against 1 959; launch 8.70 -> 8.60 ms.  Priorities alternating trip by trip even the
     // halves out but cost more than they return: 8.69 ms).
     if (GR_PRIO_BY_PHASE) { if (GR_PRIO_HALF && wave >= 4) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
-    if (fold) grc_issue_chunk_w1<8>(wchunks, by, wave, lane);
-    else grc_issue_chunk<8>(wchunks, by, wave, lane);  // chunk 0: lands under the gather (dealt by all eight waves: nobody multiplies now)
     // ENC (the tile loader computes h_0 itself): the next tile's rows are encoded during this layer's MLP steps, a part per step;
     // the table-row numbers of part 0 are requested here, a whole gather ahead of their use
     GrEncIdx enc_ix{};
@@ -1145,6 +1143,13 @@ __device__ __forceinline__ void gr_layer(unsigned long long (&tacc)[6], char* bx
         GR_FOLD(0, x0, w0, xt0, wt0)
         GR_FOLD(1, x1, w1, xt1, wt1)
     }
+    // Chunk 0 of the weight stream (dealt by all eight waves: nobody multiplies now) is requested HERE, behind the trips that walk both
+    // column tiles, and lands under the tails and the operand split.  At the top of the walk -- where it used to be -- every wave paid
+    // its LDS-DMA issue (100-150 cycles an instruction) in front of its first trip and the pieces landed through the LDS the walk is
+    // bound by: launch 8.33 ms; behind the whole walk 8.31 (the wait in front of the barrier then sees some of the latency); here
+    // 8.27 (same box, scripts/dev/ab.py).  GCN's kernel moved its W_{l+1} the same way for -2.8 %.
+    if (fold) grc_issue_chunk_w1<8>(wchunks, by, wave, lane);
+    else grc_issue_chunk<8>(wchunks, by, wave, lane);
 #pragma unroll 1
     for (int t = tboth; t < trips[0]; t++) {
         float4_t x0[6], w0[6];
