@@ -65,6 +65,22 @@ __device__ __forceinline__ uint32_t lds_addr_of(const void* p) {
     return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)p;
 }
 
+// Sum of n consecutive LDS floats in index order (the association of `for (v) sum += s[v]`), eight reads in flight at a time (sixteen: no faster): the plain
+// loop costs an LDS round trip per element, and the readouts run it on one lane per graph while the rest of the workgroup waits.
+__device__ __forceinline__ float lds_sum_in_order(const float* s, int n) {
+    float sum = 0.0f;
+    int v = 0;
+    for (; v + 8 <= n; v += 8) {
+        float x[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) x[i] = s[v + i];
+#pragma unroll
+        for (int i = 0; i < 8; i++) sum += x[i];
+    }
+    for (; v < n; v++) sum += s[v];
+    return sum;
+}
+
 // Streaming (nontemporal) 16-byte store for rows that the next kernel reads only after gigabytes of other rows have gone by:
 // they need not displace the gather's working set (neighbour rows, weight stream) from the caches.
 __device__ __forceinline__ void stream_store4(float* p, float a, float b, float c, float d) {

@@ -530,7 +530,7 @@ __global__ __launch_bounds__(GATR_WAVES * 64, 4) void gat_resident_kernel(const 
     // groups in order of decreasing in-degree (counting sort per tile; order inside a degree class is whatever the LDS atomics
     // gave -- placement never changes a row's arithmetic: MFMA columns are independent and a row is summed in CSR order by one lane)
     __shared__ uint8_t s_perm[GATR_ROWS];
-    __shared__ int s_cnt[16], s_cur[16];
+    __shared__ __attribute__((aligned(16))) int s_cnt[16], s_cur[16];
     constexpr int NT = GATR_WAVES * 64;
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -539,6 +539,10 @@ __global__ __launch_bounds__(GATR_WAVES * 64, 4) void gat_resident_kernel(const 
     if (threadIdx.x < 2 * GAT_D) s_att[threadIdx.x] = reinterpret_cast<const float4*>(threadIdx.x < GAT_D ? w.a_src : w.a_tgt)[threadIdx.x & (GAT_D - 1)];
     if (threadIdx.x < GAT_D) s_pw[threadIdx.x] = w.pool_w[threadIdx.x];
     if (threadIdx.x < GAT_F) s_u4[threadIdx.x] = w.u4[threadIdx.x];
+    // the layers' three dequantisation scales, staged once: read from global memory where they are used, each cost its wave an
+    // exposed L2 round trip (the load sits directly in front of its first use), two per layer and tile
+    __shared__ float s_scales[3 * GAT_L + 1];
+    if (threadIdx.x < 3 * GAT_L) s_scales[threadIdx.x] = w.scales[threadIdx.x];
     float vmax = 0.0f;
     const uint32_t sw_addr = lds_addr_of(s_w);
     int tile = blockIdx.x;
@@ -627,7 +631,15 @@ __global__ __launch_bounds__(GATR_WAVES * 64, 4) void gat_resident_kernel(const 
             int pos = r;
             if (sort_rows) {
                 pos = atomicAdd(&s_cur[skey], 1);
-                for (int k = 0; k < skey; k++) pos += s_cnt[k];
+                // (the 15 class counts as four 16-byte reads and selects: `for (k < skey) pos += s_cnt[k]` was an LDS round trip per class)
+                int cc[16];
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const int4 c4 = *reinterpret_cast<const int4*>(s_cnt + 4 * q);
+                    cc[4 * q + 0] = c4.x; cc[4 * q + 1] = c4.y; cc[4 * q + 2] = c4.z; cc[4 * q + 3] = c4.w;
+                }
+#pragma unroll
+                for (int k = 0; k < 15; k++) pos += k < skey ? cc[k] : 0;
             }
             s_perm[pos] = (uint8_t)r;
         }
@@ -732,7 +744,7 @@ __global__ __launch_bounds__(GATR_WAVES * 64, 4) void gat_resident_kernel(const 
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();  // #1: every gather of this layer is done (s_proj / s_sc may be rewritten); the fragments have landed
             const char* wb = s_w;
-            const float sk_scale = w.scales[l];
+            const float sk_scale = s_scales[l];
             if (!(ablate & 2)) {
 #pragma unroll
                 for (int t = 0; t < 4; t++) {
@@ -791,7 +803,7 @@ __global__ __launch_bounds__(GATR_WAVES * 64, 4) void gat_resident_kernel(const 
                     }
                 }
             }
-            const float lin_scale = w.scales[GAT_L + l], sc_scale = w.scales[2 * GAT_L + l];
+            const float lin_scale = s_scales[GAT_L + l], sc_scale = s_scales[2 * GAT_L + l];
 #pragma unroll
             for (int t2 = 0; t2 < 4; t2++)
                 s_proj[r * GATR_PS + 4 * t2 + g] = make_float4(pr[t2].x * lin_scale, pr[t2].y * lin_scale, pr[t2].z * lin_scale, pr[t2].w * lin_scale);
@@ -806,8 +818,7 @@ __global__ __launch_bounds__(GATR_WAVES * 64, 4) void gat_resident_kernel(const 
             const int gi = g0 + (int)threadIdx.x;
             if (gi < g1) {
                 const int n0 = node_off[gi], n1 = node_off[gi + 1];
-                float sum = 0.0f;
-                for (int v = n0; v < n1; v++) sum += s_dot[v - t0];
+                const float sum = lds_sum_in_order(s_dot + (n0 - t0), n1 - n0);
                 out[gi] = sum / (float)(n1 - n0) + w.pool_b[0];
             }
         }

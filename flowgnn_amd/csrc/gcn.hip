@@ -365,7 +365,10 @@ __global__ __launch_bounds__(GCNR_WAVES * 64, 3) void gcn_resident_kernel(const 
     // waves in order of decreasing in-degree (counting sort per tile; the order inside a degree class is whatever the LDS atomics
     // gave -- placement never changes a row's arithmetic: MFMA columns are independent and a row is summed in CSR order by one lane)
     __shared__ uint8_t s_perm[GCNR_ROWS];
-    __shared__ int s_cnt[16], s_cur[16];
+    __shared__ __attribute__((aligned(16))) int s_cnt[16], s_cur[16];
+    // the readout's weights, staged once per workgroup: read from global memory in the last layer, hipcc issued the seven loads one
+    // at a time, each behind a vmcnt(0) -- seven serialized L2 round trips per tile
+    __shared__ __attribute__((aligned(16))) float s_pw[GCN_D];
     const bool sort_rows = !(ablate & 4);  // development aid: gcn_ablate, -DFLOWGNN_DEV builds=4 keeps rows in natural order
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -376,6 +379,7 @@ __global__ __launch_bounds__(GCNR_WAVES * 64, 3) void gcn_resident_kernel(const 
     float vmax = 0.0f;
     int tile = blockIdx.x;
     if (tile >= n_tiles) return;
+    if ((int)threadIdx.x < GCN_D) s_pw[threadIdx.x] = pool_w[threadIdx.x];  // (read behind the tile loop's first barriers)
     int t0 = tile_row[tile], rows = tile_row[tile + 1] - t0;
     if (rows > GCNR_ROWS) rows = GCNR_ROWS;
     int g0 = tile_graph[tile], g1 = tile_graph[tile + 1];
@@ -408,8 +412,12 @@ __global__ __launch_bounds__(GCNR_WAVES * 64, 3) void gcn_resident_kernel(const 
         if ((int)threadIdx.x < frows) dpre = out_deg[ft0 + threadIdx.x];
     };
     static_assert(GCNR_EDGES <= 2 * NT, "two CSR words per thread");
-    issue_rows(t0, rows);
+    // (The CSR words are CONSUMED -- an empty asm that names them -- before the rows are requested: hipcc then waits for them there,
+    // where they have long landed, and not at the top of the tile loop, where the same vmcnt(0) would also wait for the 75 KiB of
+    // rows requested after them: the tile's CSR staging and row sort now run under that transfer.  Launch 4.92 -> see DESIGN section 4.)
     fetch_csr(t0, rows, e0, ne);
+    asm volatile("" : "+v"(epre0), "+v"(epre1), "+v"(rpre), "+v"(dpre));
+    issue_rows(t0, rows);
     while (true) {
         const int ntile = tile + gridDim.x;
         const bool has_next = ntile < n_tiles;
@@ -422,7 +430,6 @@ __global__ __launch_bounds__(GCNR_WAVES * 64, 3) void gcn_resident_kernel(const 
             s_idp1[threadIdx.x] = 1.0f / (float)(dpre + 1);
         }
         if (threadIdx.x < 16) { s_cnt[threadIdx.x] = 0; s_cur[threadIdx.x] = 0; }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         int skey = 15;  // in-degree class of row threadIdx.x: 0 = longest (>= 14 in-edges) .. 14 = none, 15 = no such row
         if (threadIdx.x < GCNR_ROWS) {
@@ -437,10 +444,19 @@ __global__ __launch_bounds__(GCNR_WAVES * 64, 3) void gcn_resident_kernel(const 
             int pos = threadIdx.x;
             if (sort_rows) {
                 pos = atomicAdd(&s_cur[skey], 1);
-                for (int k = 0; k < skey; k++) pos += s_cnt[k];
+                // (the 15 class counts as four 16-byte reads and selects: `for (k < skey) pos += s_cnt[k]` was an LDS round trip per class)
+                int cc[16];
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const int4 c4 = *reinterpret_cast<const int4*>(s_cnt + 4 * q);
+                    cc[4 * q + 0] = c4.x; cc[4 * q + 1] = c4.y; cc[4 * q + 2] = c4.z; cc[4 * q + 3] = c4.w;
+                }
+#pragma unroll
+                for (int k = 0; k < 15; k++) pos += k < skey ? cc[k] : 0;
             }
             s_perm[pos] = (uint8_t)threadIdx.x;
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of the tile's rows and of layer 0's table
         __syncthreads();
         const int r = s_perm[wv * 16 + j];
         const bool valid = r < rows;
@@ -543,10 +559,10 @@ __global__ __launch_bounds__(GCNR_WAVES * 64, 3) void gcn_resident_kernel(const 
                 float part = 0.0f;
 #pragma unroll
                 for (int q = 0; q < 6; q++) {
-                    const float4 pw = *reinterpret_cast<const float4*>(pool_w + 16 * q + 4 * g);
+                    const float4 pw = *reinterpret_cast<const float4*>(s_pw + 16 * q + 4 * g);
                     part += a[4 * q + 0] * pw.x; part += a[4 * q + 1] * pw.y; part += a[4 * q + 2] * pw.z; part += a[4 * q + 3] * pw.w;
                 }
-                part += a[24] * pool_w[96 + g];
+                part += a[24] * s_pw[96 + g];
                 part += __shfl_xor(part, 16, 64);
                 part += __shfl_xor(part, 32, 64);
                 if (g == 0) s_dot[r] = part;
@@ -579,39 +595,49 @@ __global__ __launch_bounds__(GCNR_WAVES * 64, 3) void gcn_resident_kernel(const 
             if (!(ablate & 8)) issue_blob();  // (ablate 8: timing without it; issued after the third or the last column tile instead: no change / +1.3 %)
             // ---- x_{l+1} = b + W a on the f16 matrix pipe (split products, dense_split.h), written over the wave's own rows
             const float oscale = *reinterpret_cast<const float*>(s_w + SCALE_OFF);
+            // The six fragments of column tile t + 1 are requested BEFORE the MFMAs of tile t issue (scheduling barriers pin the order):
+            // left to itself hipcc reads one fragment, waits for it and issues one or two MFMAs, so every wave paid an LDS round
+            // trip per fragment -- six per column tile -- with nothing of its own in flight.  Launch 5.06 -> 4.92 ms (same box).
+            ds_uint4_t fr[2][6];
+#pragma unroll
+            for (int i = 0; i < 6; i++) fr[0][i] = *reinterpret_cast<const ds_uint4_t*>(s_w + i * 1024 + lane * 16);
 #pragma unroll
             for (int t = 0; t < OT; t++) {
                 const float4 bv = *reinterpret_cast<const float4*>(s_w + BIAS_OFF + (16 * t + 4 * g) * 4);
-                float4_t acc = {bv.x, bv.y, bv.z, bv.w};
-                if (!(ablate & 2)) {
-#pragma unroll
-                for (int ks = 0; ks < 3; ks++) {
-                    const ds_uint4_t a_hi = *reinterpret_cast<const ds_uint4_t*>(s_w + ((t * 3 + ks) * 2 + 0) * 1024 + lane * 16);
-                    const ds_uint4_t a_lo = *reinterpret_cast<const ds_uint4_t*>(s_w + ((t * 3 + ks) * 2 + 1) * 1024 + lane * 16);
-                    acc = DS_MFMA16(a_hi, b_hi[ks], acc);
-                    acc = DS_MFMA16(a_hi, b_lo[ks], acc);
-                    acc = DS_MFMA16(a_lo, b_hi[ks], acc);
-                }
                 const float at = *reinterpret_cast<const float*>(s_w + TAIL_OFF + t * 256 + lane * 4);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(at, a24, acc, 0, 0, 0);
+                if (t + 1 < OT) {
+#pragma unroll
+                    for (int i = 0; i < 6; i++) fr[(t + 1) & 1][i] = *reinterpret_cast<const ds_uint4_t*>(s_w + ((t + 1) * 6 + i) * 1024 + lane * 16);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                float4_t acc = {bv.x, bv.y, bv.z, bv.w};
+                if (!(ablate & 2)) {  // (ablate 2: development aid, timing without the MFMAs)
+#pragma unroll
+                    for (int ks = 0; ks < 3; ks++) {
+                        acc = DS_MFMA16(fr[t & 1][2 * ks], b_hi[ks], acc);
+                        acc = DS_MFMA16(fr[t & 1][2 * ks], b_lo[ks], acc);
+                        acc = DS_MFMA16(fr[t & 1][2 * ks + 1], b_hi[ks], acc);
+                    }
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(at, a24, acc, 0, 0, 0);
                 }
                 const int col = 16 * t + 4 * g;
                 if (col < GCN_D && valid) {
                     const float4_t o = acc * oscale;
                     *reinterpret_cast<float4*>(s_x + r * GCN_D + col) = make_float4(o.x, o.y, o.z, o.w);
                 }
+                __builtin_amdgcn_sched_barrier(0);
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();  // #2: x_{l+1} is complete, the next table has landed
         }
         __syncthreads();  // the per-node readout terms are in s_dot; the rows and the table are dead
+        asm volatile("" : "+v"(epre0), "+v"(epre1), "+v"(rpre), "+v"(dpre));  // (see the prologue)
         if (has_next) issue_rows(nt0, nrows);
         {
             const int gi = g0 + (int)threadIdx.x;
             if (gi < g1) {
                 const int n0 = node_off[gi], n1 = node_off[gi + 1];
-                float sum = 0.0f;
-                for (int v = n0; v < n1; v++) sum += s_dot[v - t0];
+                const float sum = lds_sum_in_order(s_dot + (n0 - t0), n1 - n0);
                 out[gi] = sum / (float)(n1 - n0) + pool_b[0];
             }
         }

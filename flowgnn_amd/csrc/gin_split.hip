@@ -1474,8 +1474,7 @@ __global__ __launch_bounds__(GR_WAVES * 64, 2) void gin_resident_kernel(const fl
             const int gi = cur.g0 + (int)threadIdx.x;
             if (out != nullptr && gi < cur.g1) {  // out == null: multi-task readout, done by the caller from the hout rows
                 const int n0 = node_off[gi], n1 = node_off[gi + 1];
-                float sum = 0.0f;
-                for (int v = n0; v < n1; v++) sum += s_dot[v - cur.t0];
+                const float sum = lds_sum_in_order(s_dot + (n0 - cur.t0), n1 - n0);
                 out[gi] = sum / (float)(n1 - n0) + pool_b[0] + head_c;
             }
         }
