@@ -543,6 +543,7 @@ __global__ __launch_bounds__(GATR_WAVES * 64, 4) void gat_resident_kernel(const 
     // exposed L2 round trip (the load sits directly in front of its first use), two per layer and tile
     __shared__ float s_scales[3 * GAT_L + 1];
     if (threadIdx.x < 3 * GAT_L) s_scales[threadIdx.x] = w.scales[threadIdx.x];
+    const float pool_bias = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, w.pool_b[0])));  // (an SGPR)
     float vmax = 0.0f;
     const uint32_t sw_addr = lds_addr_of(s_w);
     int tile = blockIdx.x;
@@ -670,6 +671,7 @@ __global__ __launch_bounds__(GATR_WAVES * 64, 4) void gat_resident_kernel(const 
             GATR_ABSMAX(vmax, bq[0], bq[4]);
             GATR_ABSMAX(vmax, bq[8], bq[12]);
         }
+        int ro_n0 = 0, ro_n1 = 1;
 #pragma unroll 1
         for (int l = 0; l < GAT_L; l++) {
             // this layer's fragments stream in under the gather, which does not use them: 36 pieces of 1 KiB (last layer: W_skip only)
@@ -691,6 +693,9 @@ __global__ __launch_bounds__(GATR_WAVES * 64, 4) void gat_resident_kernel(const 
                 if (nne > GATR_EDGES) nne = GATR_EDGES;
             }
             if (l == 3 && has_next) fetch_tile(nt0, nrows, ne0, nne);  // lands during the last two layers
+            // the readout's node range of "this lane's graph", a whole gather ahead of its use (requested at the readout, the L2 round
+            // trip was paid by one wave while the other fifteen waited at the tile's first barrier)
+            if (l == GAT_L - 1 && g0 + (int)threadIdx.x < g1) { ro_n0 = node_off[g0 + threadIdx.x]; ro_n1 = node_off[g0 + threadIdx.x + 1]; }
             // ---- attention gather (pull): self edge first, then the CSR row (ascending source); everything out of LDS
             const float4 ssrc = s_sc[rr * 2 + 0];
             float4 den = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -814,14 +819,7 @@ __global__ __launch_bounds__(GATR_WAVES * 64, 4) void gat_resident_kernel(const 
             __syncthreads();  // #2: the next layer's projections and scores are complete
         }
         __syncthreads();  // the per-node readout terms are in s_dot
-        {
-            const int gi = g0 + (int)threadIdx.x;
-            if (gi < g1) {
-                const int n0 = node_off[gi], n1 = node_off[gi + 1];
-                const float sum = lds_sum_in_order(s_dot + (n0 - t0), n1 - n0);
-                out[gi] = sum / (float)(n1 - n0) + w.pool_b[0];
-            }
-        }
+        if (g0 + (int)threadIdx.x < g1) out[g0 + threadIdx.x] = lds_sum_in_order(s_dot + (ro_n0 - t0), ro_n1 - ro_n0) / (float)(ro_n1 - ro_n0) + pool_bias;
         if (!has_next) break;
         tile = ntile; t0 = nt0; rows = nrows; g0 = ng0; g1 = ng1; e0 = ne0; ne = nne;
     }

@@ -380,6 +380,7 @@ __global__ __launch_bounds__(GCNR_WAVES * 64, 3) void gcn_resident_kernel(const 
     int tile = blockIdx.x;
     if (tile >= n_tiles) return;
     if ((int)threadIdx.x < GCN_D) s_pw[threadIdx.x] = pool_w[threadIdx.x];  // (read behind the tile loop's first barriers)
+    const float pool_bias = pool_b[0];
     int t0 = tile_row[tile], rows = tile_row[tile + 1] - t0;
     if (rows > GCNR_ROWS) rows = GCNR_ROWS;
     int g0 = tile_graph[tile], g1 = tile_graph[tile + 1];
@@ -467,6 +468,8 @@ __global__ __launch_bounds__(GCNR_WAVES * 64, 3) void gcn_resident_kernel(const 
 #pragma unroll
         for (int mk = 1; mk < 64; mk <<= 1) trips = max(trips, __shfl_xor(trips, mk, 64));
         trips = __builtin_amdgcn_readfirstlane(trips);
+        const int ro_gi = g0 + (int)threadIdx.x;
+        int ro_n0 = 0, ro_n1 = 1;
 #pragma unroll 1
         for (int l = 0; l < GCN_L; l++) {
             if (l == 1 && has_next) {  // the next tile's descriptor (two dependent scalar round trips), used from layer 2 on
@@ -554,6 +557,9 @@ __global__ __launch_bounds__(GCNR_WAVES * 64, 3) void gcn_resident_kernel(const 
             }
             a[24] = (m[24] + relu1(xst + s_ep[96 + g]) * idp1) * s_ep[GCN_D + 96 + g] + s_ep[2 * GCN_D + 96 + g];
             if (l == GCN_L - 1) {
+                // the readout's node range of "this lane's graph": requested here, a BatchNorm ahead of its use, and consumed BEFORE the
+                // next tile's rows are requested (below) -- behind them, its vmcnt wait would also wait for that whole transfer
+                if (ro_gi < g1) { ro_n0 = node_off[ro_gi]; ro_n1 = node_off[ro_gi + 1]; }
                 // no ReLU after the last BatchNorm; the readout's linear head per node (mean_v(a[v]) . w = mean_v(a[v] . w),
                 // finalize.cc:79-113): 25 terms in the lane, then the node's 4 lanes
                 float part = 0.0f;
@@ -631,16 +637,9 @@ __global__ __launch_bounds__(GCNR_WAVES * 64, 3) void gcn_resident_kernel(const 
             __syncthreads();  // #2: x_{l+1} is complete, the next table has landed
         }
         __syncthreads();  // the per-node readout terms are in s_dot; the rows and the table are dead
-        asm volatile("" : "+v"(epre0), "+v"(epre1), "+v"(rpre), "+v"(dpre));  // (see the prologue)
+        asm volatile("" : "+v"(epre0), "+v"(epre1), "+v"(rpre), "+v"(dpre), "+v"(ro_n0), "+v"(ro_n1));  // (see the prologue)
         if (has_next) issue_rows(nt0, nrows);
-        {
-            const int gi = g0 + (int)threadIdx.x;
-            if (gi < g1) {
-                const int n0 = node_off[gi], n1 = node_off[gi + 1];
-                const float sum = lds_sum_in_order(s_dot + (n0 - t0), n1 - n0);
-                out[gi] = sum / (float)(n1 - n0) + pool_b[0];
-            }
-        }
+        if (ro_gi < g1) out[ro_gi] = lds_sum_in_order(s_dot + (ro_n0 - t0), ro_n1 - ro_n0) / (float)(ro_n1 - ro_n0) + pool_bias;
         if (!has_next) break;
         tile = ntile; t0 = nt0; rows = nrows; g0 = ng0; g1 = ng1; e0 = ne0; ne = nne;
         __syncthreads();  // the readout has read s_dot and s_rp's neighbours: the small arrays may be rewritten

@@ -1471,11 +1471,14 @@ __global__ __launch_bounds__(GR_WAVES * 64, 2) void gin_resident_kernel(const fl
         // readout (GIN/src/finalize.cc:36-113): out[g] = mean_v(h5[v] . w) + b, node order; the terms stay valid until the next
         // tile's last layer rewrites them, so no barrier is needed before the next tile starts
         {
-            const int gi = cur.g0 + (int)threadIdx.x;
-            if (out != nullptr && gi < cur.g1) {  // out == null: multi-task readout, done by the caller from the hout rows
-                const int n0 = node_off[gi], n1 = node_off[gi + 1];
-                const float sum = lds_sum_in_order(s_dot + (n0 - cur.t0), n1 - n0);
-                out[gi] = sum / (float)(n1 - n0) + pool_b[0] + head_c;
+            // (the readout's lanes are wave 7's: the wave that does it enters the next tile's walk late, and wave 0 -- the natural choice --
+            // owns the tile's longest rows and deals LDS-DMA in the MLP steps: launch -0.4 %)
+            if (out != nullptr && wave == GR_WAVES - 1) {  // out == null: multi-task readout, done by the caller from the hout rows
+                for (int gi = cur.g0 + lane; gi < cur.g1; gi += 64) {  // (a tile of one-node graphs has up to GR_ROWS of them)
+                    const int n0 = node_off[gi], n1 = node_off[gi + 1];
+                    const float sum = lds_sum_in_order(s_dot + (n0 - cur.t0), n1 - n0);
+                    out[gi] = sum / (float)(n1 - n0) + pool_b[0] + head_c;
+                }
             }
         }
         if (!has_next) break;

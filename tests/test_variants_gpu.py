@@ -462,3 +462,24 @@ def test_invalid_inputs_are_reported_on_every_path(model):
             compute_graphs(model, broken(kind), [w])
         assert ei.value.code in (2, 3, 4)
     assert np.allclose(compute_graphs(model, good, [w]), want, rtol=1e-4, atol=1e-4 * max(1.0, float(np.abs(want).max())))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("model", ["GIN", "GCN", "GAT"])
+def test_tiles_full_of_one_node_graphs(oracle, model):
+    """A tile of the graph-resident kernels holds up to 256 (GCN: 192) WHOLE graphs when every graph is a single node without
+    edges; the readout of a tile is done by a few lanes (GIN: the 64 lanes of one wave, looping), one graph each -- every one of
+    700 such graphs, mixed with ordinary molecules, must come out, and equal to the oracle's."""
+    rng = np.random.default_rng(11)
+    nf = np.stack([rng.integers(0, c, 700) for c in (119, 4, 12, 12, 10, 6, 6, 2, 2)], 1).astype(np.int32)
+    ones = gp.GraphBatch(np.ones(700, np.int32), np.zeros(700, np.int32), nf, np.zeros((0, 2), np.int32), np.zeros((0, 3), np.int32))
+    mol = gp.synth_molhiv_batch(40, seed=5)
+    b = gp.concat_batches([mol.slice(0, 20), ones, mol.slice(20, 40)])
+    w = weights.SYNTH[model](seed=7)
+    want = getattr(oracle, model.lower() + "_forward")(b, [w], nthreads=4)
+    e = Engine(model, device=0)
+    e.set_weights(w)
+    got = e.forward(b)
+    e.close()
+    assert got.shape == want.shape
+    assert np.allclose(got, want, rtol=1e-4, atol=1e-4), np.abs(got - want).max()
