@@ -450,19 +450,15 @@ __global__ __launch_bounds__(PNA_FT_WAVES * 64, 4) void pna_layer_fused_kernel(c
 #pragma unroll 1
         for (int ks = 0; ks < ((ablate & 2) ? 0 : PNA_KS); ks += 2) {
             // even K-step from s_a while chunk ks+1 streams into s_b
-            // (a wave requests its pieces of the next chunk BETWEEN its two phases, not at the top of the K-step: the LDS-DMA issue --
-            // 100-150 cycles an instruction -- then falls where the wave would have waited anyway; layer 1.087 -> 1.070 ms, same box)
+            pna_issue_chunk_asm(wpk + (size_t)(ks + 1) * PNA_CHUNK, s_b, wave, lane);
             if (!late) pna_gather_slice(s_h, csrc, srcw, e_base, indeg, 8 * ks + 2 * g, b_hi, b_lo, vmax);
-            if (!late) pna_issue_chunk_asm(wpk + (size_t)(ks + 1) * PNA_CHUNK, s_b, wave, lane);
             pna_stream_mfma(s_a, lane, b_hi, b_lo, y);
-            if (late) pna_issue_chunk_asm(wpk + (size_t)(ks + 1) * PNA_CHUNK, s_b, wave, lane);
             if (late) pna_gather_slice(s_h, csrc, srcw, e_base, indeg, 8 * (ks + 1) + 2 * g, b_hi, b_lo, vmax);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (!(ablate & 4)) __syncthreads();
+            if (ks + 2 < PNA_KS) pna_issue_chunk_asm(wpk + (size_t)(ks + 2) * PNA_CHUNK, s_a, wave, lane);
             if (!late) pna_gather_slice(s_h, csrc, srcw, e_base, indeg, 8 * (ks + 1) + 2 * g, b_hi, b_lo, vmax);
-            if (!late && ks + 2 < PNA_KS) pna_issue_chunk_asm(wpk + (size_t)(ks + 2) * PNA_CHUNK, s_a, wave, lane);
             pna_stream_mfma(s_b, lane, b_hi, b_lo, y);
-            if (late && ks + 2 < PNA_KS) pna_issue_chunk_asm(wpk + (size_t)(ks + 2) * PNA_CHUNK, s_a, wave, lane);
             if (late && ks + 2 < PNA_KS) pna_gather_slice(s_h, csrc, srcw, e_base, indeg, 8 * (ks + 2) + 2 * g, b_hi, b_lo, vmax);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (!(ablate & 4)) __syncthreads();  // ablate 4 (development aid): timing without the K-step barriers (results are then wrong)
