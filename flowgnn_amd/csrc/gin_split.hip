@@ -1188,8 +1188,10 @@ __device__ __forceinline__ void gr_layer(unsigned long long (&tacc)[6], char* bx
                 hm &= hm - 1;
                 const int hb = __builtin_amdgcn_readlane(hub_beg[nt], jh), he = __builtin_amdgcn_readlane(hub_end[nt], jh);
                 float part[25];
+                float2_t pq[12];  // as in the row walk: v_pk_add_f32 for the message and for the accumulation
 #pragma unroll
-                for (int k = 0; k < 25; k++) part[k] = 0.0f;
+                for (int k = 0; k < 12; k++) pq[k] = (float2_t){0.0f, 0.0f};
+                float pt = 0.0f;
                 const int hub_trips = (he - hb + 15) >> 4;  // wave-uniform; lanes past the hub's last in-edge walk the no-edge word
 #pragma unroll 1
                 for (int t = 0; t < hub_trips; t++) {
@@ -1198,26 +1200,34 @@ __device__ __forceinline__ void gr_layer(unsigned long long (&tacc)[6], char* bx
                     const unsigned u = w2 >> 6, code = w2 & 63u;
                     const float* hr = s_h + u * GS_D + 4 * g;
                     const float* er = s_ecomb + code * GS_D + 4 * g;
-                    float4 x[6];
-#pragma unroll
-                    for (int q = 0; q < 6; q++) x[q] = *reinterpret_cast<const float4*>(hr + 16 * q);
-                    const float xt = s_h[u * GS_D + 96 + g];
+                    float4_t x[6], w[6];
 #pragma unroll
                     for (int q = 0; q < 6; q++) {
-                        const float4 w = *reinterpret_cast<const float4*>(er + 16 * q);
-                        part[4 * q + 0] += relu1(w.x + x[q].x);
-                        part[4 * q + 1] += relu1(w.y + x[q].y);
-                        part[4 * q + 2] += relu1(w.z + x[q].z);
-                        part[4 * q + 3] += relu1(w.w + x[q].w);
+                        x[q] = *reinterpret_cast<const float4_t*>(hr + 16 * q);
+                        w[q] = *reinterpret_cast<const float4_t*>(er + 16 * q);
                     }
-                    part[24] += relu1(s_ecomb[code * GS_D + 96 + g] + xt);
+                    const float xt = s_h[u * GS_D + 96 + g];
+                    const float wt = s_ecomb[code * GS_D + 96 + g];
+#pragma unroll
+                    for (int q = 0; q < 6; q++) {
+                        pq[2 * q + 0] += __builtin_elementwise_max(w[q].lo + x[q].lo, (float2_t){0.0f, 0.0f});
+                        pq[2 * q + 1] += __builtin_elementwise_max(w[q].hi + x[q].hi, (float2_t){0.0f, 0.0f});
+                    }
+                    pt += relu1(wt + xt);
                 }
+#pragma unroll
+                for (int k = 0; k < 12; k++) { part[2 * k] = pq[k].x; part[2 * k + 1] = pq[k].y; }
+                part[24] = pt;
                 // all-reduce over the 16 lanes of the column tile with DPP row rotations (8, 4, 2, 1): every lane adds the same pairs
                 // at every level, so all 16 hold the same bits whichever lane owns the hub
-#define GR_ROR_ADD(CTRL)                                                                                                          \
+                // (one v_add_f32_dpp per register and level, spelled out: hipcc leaves `x += update_dpp(x)` as v_mov_b32_dpp + v_add_f32 -- 582
+                // unfused moves in this kernel.  A level's 25 adds are independent and a register is read again 25 instructions after it was
+                // written, beyond the two wait states a DPP read needs; the s_nop covers the first read of each level.)
+#define GR_ROR_ADD(ROR)                                                                                                           \
+    asm volatile("s_nop 1");                                                                                                      \
     _Pragma("unroll") for (int k = 0; k < 25; k++)                                                                                \
-        part[k] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, part[k]), CTRL, 0xF, 0xF, false));
-                GR_ROR_ADD(0x128) GR_ROR_ADD(0x124) GR_ROR_ADD(0x122) GR_ROR_ADD(0x121)
+        asm volatile("v_add_f32_dpp %0, %1, %1 row_ror:" #ROR " row_mask:0xf bank_mask:0xf" : "=v"(part[k]) : "v"(part[k]));  /* volatile: in source order */
+                GR_ROR_ADD(8) GR_ROR_ADD(4) GR_ROR_ADD(2) GR_ROR_ADD(1)
 #undef GR_ROR_ADD
                 if (j == jh) {
 #pragma unroll
