@@ -724,10 +724,13 @@ __global__ __launch_bounds__(512, 2) void dgn_layer_mfma_kernel(const float* __r
 #pragma unroll
                     for (int i = 0; i < 4; i++) sv[4 * t + i] = sum[t][i];
                 }
-#define DGN_ROR_ADD(CTRL)                                                                                                         \
+                // (one v_add_f32_dpp per register and level, spelled out and in source order: hipcc leaves `x += update_dpp(x)` as
+                // v_mov_b32_dpp + v_add_f32; a register is read again 28 instructions after it was written, the s_nop covers a level's first read)
+#define DGN_ROR_ADD(ROR)                                                                                                          \
+    asm volatile("s_nop 1");                                                                                                      \
     _Pragma("unroll") for (int k = 0; k < 4 * DGN_OT; k++)                                                                        \
-        sv[k] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sv[k]), CTRL, 0xF, 0xF, false));
-                DGN_ROR_ADD(0x128) DGN_ROR_ADD(0x124) DGN_ROR_ADD(0x122) DGN_ROR_ADD(0x121)
+        asm volatile("v_add_f32_dpp %0, %1, %1 row_ror:" #ROR " row_mask:0xf bank_mask:0xf" : "=v"(sv[k]) : "v"(sv[k]));
+                DGN_ROR_ADD(8) DGN_ROR_ADD(4) DGN_ROR_ADD(2) DGN_ROR_ADD(1)
 #undef DGN_ROR_ADD
 #pragma unroll
                 for (int t = 0; t < DGN_OT; t++) sum[t] = (float4_t){sv[4 * t], sv[4 * t + 1], sv[4 * t + 2], sv[4 * t + 3]};
