@@ -282,10 +282,25 @@ __global__ __launch_bounds__(NT) void build_csr_graph_kernel(BatchView b, CsrVie
         const int v = s_v[e], u = s_u[e];
         const int beg = s_cnt[v], end = s_cnt[v + 1];
         int rank = 0;
-        for (int t = beg; t < end; t++) {
-            const int e2 = s_slot[t];
-            const int u2 = s_u[e2];
-            rank += (u2 < u) | ((u2 == u) & (e2 < e));
+        // four slots, then their four sources, per trip: the two LDS reads of a comparison depend on each other
+        // (molecule class only: rows of two to four in-edges are done in one trip, build 0.185 -> 0.162 ms at 2^18 molhiv graphs; on
+        // kNN rows of sixteen the same loop measured 11 % slower than the plain one, on GIN-VN's hubs 3 %)
+        if constexpr (DYN) {
+            for (int t = beg; t < end; t += 4) {
+                int e2[4], u2[4];
+#pragma unroll
+                for (int i = 0; i < 4; i++) e2[i] = s_slot[t + i < end ? t + i : end - 1];
+#pragma unroll
+                for (int i = 0; i < 4; i++) u2[i] = s_u[e2[i]];
+#pragma unroll
+                for (int i = 0; i < 4; i++) rank += (t + i < end) & ((u2[i] < u) | ((u2[i] == u) & (e2[i] < e)));
+            }
+        } else {
+            for (int t = beg; t < end; t++) {
+                const int e2 = s_slot[t];
+                const int u2 = s_u[e2];
+                rank += (u2 < u) | ((u2 == u) & (e2 < e));
+            }
         }
         const int pos = e0 + beg + rank;
         c.src[pos] = noff + u;
