@@ -1025,7 +1025,7 @@ __device__ __forceinline__ void gr_layer(unsigned long long (&tacc)[6], char* bx
                                          const float* __restrict__ h0, const uint8_t* __restrict__ desc, const float* __restrict__ ecomb_all,
                                          const uint8_t* __restrict__ wchunks_all, const float* __restrict__ pool_w,
                                          float* __restrict__ hout, float& vmax, int wave, int lane, const float* s_u,
-                                         const uint2* __restrict__ enc_idx, const float4* __restrict__ enc_tab) {
+                                         const uint2* __restrict__ enc_idx, const float4* __restrict__ enc_tab, int (&tile_trips)[2]) {
     constexpr int NT = 2;
     const int j = lane & 15, g = lane >> 4;
     constexpr bool last = LAST;  // compile-time: the first four layers carry none of the last layer's code (and registers)
@@ -1085,14 +1085,20 @@ __device__ __forceinline__ void gr_layer(unsigned long long (&tacc)[6], char* bx
     // BEFORE either is folded: the second tile's 14 reads are in flight while the first one's VALU instructions issue.  (A single
     // `while (any lane active)` loop with per-tile guards costs the same moves again: the accumulators become loop phis that hipcc
     // copies on every path.)  Same sums, same order.
+    // (once per tile, in layer 0, and carried in scalar registers: the rows and their in-degrees are the same in all five layers, and
+    // the two six-step butterflies are twelve dependent cross-lane round trips in front of the walk's first trip)
     int trips[NT];
+    if (l == 0) {
 #pragma unroll
-    for (int nt = 0; nt < NT; nt++) {
-        int d = e_end[nt] - e_cur[nt];
+        for (int nt = 0; nt < NT; nt++) {
+            int d = e_end[nt] - e_cur[nt];
 #pragma unroll
-        for (int m = 1; m < 64; m <<= 1) d = max(d, __shfl_xor(d, m, 64));
-        trips[nt] = __builtin_amdgcn_readfirstlane(d);
+            for (int m = 1; m < 64; m <<= 1) d = max(d, __shfl_xor(d, m, 64));
+            tile_trips[nt] = __builtin_amdgcn_readfirstlane(d);
+        }
     }
+#pragma unroll
+    for (int nt = 0; nt < NT; nt++) trips[nt] = tile_trips[nt];
 #define GR_READ(NTI, X, W, XT, WT)                                                                                                \
     {                                                                                                                             \
         const unsigned u = wd[NTI] >> 6, code = wd[NTI] & 63u;                                                                    \
@@ -1458,6 +1464,7 @@ __global__ __launch_bounds__(GR_WAVES * 64, 2) void gin_resident_kernel(const fl
     __syncthreads();
     float vmax = 0.0f;
     bool flip = false;
+    int tile_trips[2] = {0, 0};
     while (true) {
         const int ntile = tile + gridDim.x;
         const bool has_next = ntile < n_tiles;
@@ -1465,17 +1472,17 @@ __global__ __launch_bounds__(GR_WAVES * 64, 2) void gin_resident_kernel(const fl
 #pragma unroll 1
         for (int l = 0; l < 4; l++) {
             if (!flip)
-                gr_layer<PROF, HUBS, false, FOLD, ENC>(tacc, s_a, s_b, s_h, s_desc, s_dot, cur, nxt, has_next, ntile, l, h0, desc, ecomb_all, wchunks_all, pool_w, hout, vmax, wave, lane, nullptr, enc_idx, enc_tab);
+                gr_layer<PROF, HUBS, false, FOLD, ENC>(tacc, s_a, s_b, s_h, s_desc, s_dot, cur, nxt, has_next, ntile, l, h0, desc, ecomb_all, wchunks_all, pool_w, hout, vmax, wave, lane, nullptr, enc_idx, enc_tab, tile_trips);
             else
-                gr_layer<PROF, HUBS, false, FOLD, ENC>(tacc, s_b, s_a, s_h, s_desc, s_dot, cur, nxt, has_next, ntile, l, h0, desc, ecomb_all, wchunks_all, pool_w, hout, vmax, wave, lane, nullptr, enc_idx, enc_tab);
+                gr_layer<PROF, HUBS, false, FOLD, ENC>(tacc, s_b, s_a, s_h, s_desc, s_dot, cur, nxt, has_next, ntile, l, h0, desc, ecomb_all, wchunks_all, pool_w, hout, vmax, wave, lane, nullptr, enc_idx, enc_tab, tile_trips);
             flip = !flip;
         }
         {
             const float* su = fold_head ? s_u : nullptr;
             if (!flip)
-                gr_layer<PROF, HUBS, true, FOLD, ENC>(tacc, s_a, s_b, s_h, s_desc, s_dot, cur, nxt, has_next, ntile, 4, h0, desc, ecomb_all, wchunks_all, pool_w, hout, vmax, wave, lane, su, enc_idx, enc_tab);
+                gr_layer<PROF, HUBS, true, FOLD, ENC>(tacc, s_a, s_b, s_h, s_desc, s_dot, cur, nxt, has_next, ntile, 4, h0, desc, ecomb_all, wchunks_all, pool_w, hout, vmax, wave, lane, su, enc_idx, enc_tab, tile_trips);
             else
-                gr_layer<PROF, HUBS, true, FOLD, ENC>(tacc, s_b, s_a, s_h, s_desc, s_dot, cur, nxt, has_next, ntile, 4, h0, desc, ecomb_all, wchunks_all, pool_w, hout, vmax, wave, lane, su, enc_idx, enc_tab);
+                gr_layer<PROF, HUBS, true, FOLD, ENC>(tacc, s_b, s_a, s_h, s_desc, s_dot, cur, nxt, has_next, ntile, 4, h0, desc, ecomb_all, wchunks_all, pool_w, hout, vmax, wave, lane, su, enc_idx, enc_tab, tile_trips);
             if (!fold_head) flip = !flip;  // the folded last layer leaves the next table in its own table buffer
         }
         // readout (GIN/src/finalize.cc:36-113): out[g] = mean_v(h5[v] . w) + b, node order; the terms stay valid until the next
