@@ -171,6 +171,25 @@ __global__ __launch_bounds__(256) void segment_mean_bias_kernel(const float* __r
     out[gidx] = s / (float)(n1 - n0) + pb[0];
 }
 
+
+// Sum of the rows v0, v0 + 2, ... < n1 of a graph (one float4 chunk c of each), in that order: four rows are requested before the first
+// is added.  One at a time, every row was its own global round trip on the graph's wavefront (the readout kernels below).
+template <int C>
+__device__ __forceinline__ void pool_rows_in_order(float4& acc, const float* __restrict__ h, int v0, int n1, int c) {
+    int v = v0;
+    for (; v + 6 < n1; v += 8) {
+        float4 x[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) x[i] = reinterpret_cast<const float4*>(h)[(size_t)(v + 2 * i) * C + c];
+#pragma unroll
+        for (int i = 0; i < 4; i++) { acc.x += x[i].x; acc.y += x[i].y; acc.z += x[i].z; acc.w += x[i].w; }
+    }
+    for (; v < n1; v += 2) {
+        const float4 x = reinterpret_cast<const float4*>(h)[(size_t)v * C + c];
+        acc.x += x.x; acc.y += x.y; acc.z += x.z; acc.w += x.w;
+    }
+}
+
 // ---------------------------------------------------------------- readout: mean pool + linear head
 // One wavefront per graph; lanes 0..24 take even rows, lanes 32..56 odd rows (float4 chunks).
 template <int D>
@@ -187,11 +206,7 @@ __global__ __launch_bounds__(256) void mean_pool_linear_kernel(const float* __re
     const int n0 = node_off[g], n1 = node_off[g + 1];
     const int half = lane >> 5, c = lane & 31;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (c < C)
-        for (int v = n0 + half; v < n1; v += 2) {
-            const float4 x = reinterpret_cast<const float4*>(h)[(size_t)v * C + c];
-            acc.x += x.x; acc.y += x.y; acc.z += x.z; acc.w += x.w;
-        }
+    if (c < C) pool_rows_in_order<C>(acc, h, n0 + half, n1, c);
     acc.x += __shfl_down(acc.x, 32, 64); acc.y += __shfl_down(acc.y, 32, 64);
     acc.z += __shfl_down(acc.z, 32, 64); acc.w += __shfl_down(acc.w, 32, 64);
     float part = 0.f;
@@ -233,11 +248,7 @@ __global__ __launch_bounds__(256) void mean_pool_linear_mt_kernel(const float* _
             const int n0 = node_off[g], n1 = node_off[g + 1];
             const int half = lane >> 5, c = lane & 31;
             float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (c < C)
-                for (int v = n0 + half; v < n1; v += 2) {
-                    const float4 x = reinterpret_cast<const float4*>(h)[(size_t)v * C + c];
-                    acc.x += x.x; acc.y += x.y; acc.z += x.z; acc.w += x.w;
-                }
+            if (c < C) pool_rows_in_order<C>(acc, h, n0 + half, n1, c);
             acc.x += __shfl_down(acc.x, 32, 64); acc.y += __shfl_down(acc.y, 32, 64);
             acc.z += __shfl_down(acc.z, 32, 64); acc.w += __shfl_down(acc.w, 32, 64);
             if (half == 0 && c < C) {
@@ -281,11 +292,7 @@ __global__ __launch_bounds__(256) void pool_mlp3_kernel(const float* __restrict_
     const int n0 = node_off[g], n1 = node_off[g + 1];
     const int half = lane >> 5, c = lane & 31;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (c < C)
-        for (int v = n0 + half; v < n1; v += 2) {
-            const float4 x = reinterpret_cast<const float4*>(h)[(size_t)v * C + c];
-            acc.x += x.x; acc.y += x.y; acc.z += x.z; acc.w += x.w;
-        }
+    if (c < C) pool_rows_in_order<C>(acc, h, n0 + half, n1, c);
     acc.x += __shfl_down(acc.x, 32, 64); acc.y += __shfl_down(acc.y, 32, 64);
     acc.z += __shfl_down(acc.z, 32, 64); acc.w += __shfl_down(acc.w, 32, 64);
     if (half == 0 && c < C) {
