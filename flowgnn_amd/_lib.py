@@ -35,6 +35,7 @@ def _declare(lib):
     lib.flowgnn_set_weights.argtypes = [eng, C.c_int, C.POINTER(p_float)]
     lib.flowgnn_load_weights_dir.argtypes = [eng, C.c_char_p]
     lib.flowgnn_set_batch.argtypes = [eng, C.c_int, p_int, p_int, p_int, p_int, p_int, p_float]
+    lib.flowgnn_set_job_totals.argtypes = [eng, C.c_longlong, C.c_longlong]
     lib.flowgnn_run.argtypes = [eng]
     lib.flowgnn_sync.argtypes = [eng]
     lib.flowgnn_get_results.argtypes = [eng, p_float]
@@ -92,7 +93,7 @@ def _declare(lib):
     lib.GAT_compute_graphs.argtypes = [C.c_int, p_int, p_int, p_int, p_float, p_int, p_int] + [p_float] * 6
     lib.GCN_compute_graphs.argtypes = [C.c_int, p_int, p_int, p_int, p_float, p_int, p_int, p_int] + [p_float] * 11
     for name in ("flowgnn_create", "flowgnn_destroy", "flowgnn_set_weights_gin", "flowgnn_set_weights", "flowgnn_load_weights_dir",
-                 "flowgnn_set_batch", "flowgnn_run", "flowgnn_sync", "flowgnn_get_results",
+                 "flowgnn_set_batch", "flowgnn_set_job_totals", "flowgnn_run", "flowgnn_sync", "flowgnn_get_results",
                  "flowgnn_results_device", "flowgnn_set_results_buffer", "flowgnn_stream", "flowgnn_batch_info", "flowgnn_exact_reruns", "flowgnn_set_numeric_mode", "flowgnn_set_num_tasks", "flowgnn_num_tasks", "flowgnn_get_csr",
                  "flowgnn_get_h", "flowgnn_profile_enable", "flowgnn_profile_read",
                  "flowgnn_run_aggregation_only", "flowgnn_get_aggregate", "flowgnn_set_stream",

@@ -139,6 +139,9 @@ struct GraphTiles {
 // Everything a model's forward needs about the resident batch.
 struct DeviceBatch {
     BatchView b;
+    long long job_n, job_e;   // nodes / edges of the JOB this batch is a shard of (= b.n_tot / b.e_tot for a batch that is the whole job;
+                              // flowgnn_set_job_totals).  Kernel CHOICES by batch size read these, so that a job computes on the same
+                              // kernels whether one engine holds all of it or a group of engines a shard each
     CsrView csr;
     const float* node_eigen;  // [N][4] or null
     float* h[2];              // ping/pong node embeddings [N][dim]

@@ -1081,7 +1081,7 @@ public:
         return fused_ && split_ && !exact_ && db.gtiles.ok && db.gtiles.n_tiles > 0 && db.gtiles.fill >= 0.4;
     }
     bool use_mfma_agg(const DeviceBatch& db) const {
-        return mfma_agg_ < 0 ? (double)db.b.e_tot >= 8.0 * (double)db.b.n_tot : mfma_agg_ != 0;
+        return mfma_agg_ < 0 ? (double)db.job_e >= 8.0 * (double)db.job_n : mfma_agg_ != 0;  // the JOB's density: every shard of a job takes the same path
     }
     // the matrix-pipe path takes what it needs of the graph structure from the caller's edge list (dgn_rowinfo_kernel): no index build
     bool needs_csr(const DeviceBatch& db) const override {
@@ -1189,8 +1189,8 @@ public:
     }
 
     void configure(const Options& o) override {
-        if (o.i("tile_nominal") > 0) tile_nominal_ = o.i("tile_nominal");
-        if (o.i("tile_slack") >= 0) tile_slack_ = o.i("tile_slack");
+        tile_nominal_ = o.i("tile_nominal") > 0 ? o.i("tile_nominal") : kTileNominal;  // <= 0 / < 0: back to the model's defaults
+        tile_slack_ = o.i("tile_slack") >= 0 ? o.i("tile_slack") : kTileSlack;
         split_ = o.i("dgn_mfma") != 32;
         fused_ = o.on("dgn_fused");
         mfma_agg_ = o.i("dgn_mfma_agg");
@@ -1233,7 +1233,8 @@ private:
     bool qmode_ = false;  // flowgnn_set_numeric_mode(FLOWGNN_NUMERIC_Q6_10): ap_fixed<16,3> arithmetic
     QPack q_;
     GrowBufI tiles_;  // graph-aligned tile starts of the resident batch (tile_bounds_kernel)
-    int tile_nominal_ = 64, tile_slack_ = 64;  // options tile_nominal / tile_slack (< 0: these defaults)
+    static constexpr int kTileNominal = 64, kTileSlack = 64;  // the model's defaults of the options tile_nominal / tile_slack
+    int tile_nominal_ = kTileNominal, tile_slack_ = kTileSlack;
     // dgn_mfma=32 keeps the dense update on the fp32 matrix pipe (dgn_dense_kernel)
     bool split_ = true;
     // dgn_fused=0 keeps aggregation and dense update as two kernels per layer (A/B measurements, the aggregation roofline probe)

@@ -23,6 +23,7 @@ void set_hip_error(const char* what, hipError_t e, const char* file, int line) {
     snprintf(g_err, sizeof(g_err), "HIP error %d (%s) at %s:%d: %s", (int)e, hipGetErrorString(e), file, line, what);
 }
 const char* last_error_text() { return g_err; }
+void set_last_error(const char* what) { snprintf(g_err, sizeof(g_err), "%s", what); }
 
 int read_floats(const char* dir, const char* file, size_t offset_floats, size_t count, float* dst) {
     std::string path = std::string(dir) + "/" + file;
@@ -122,7 +123,14 @@ static double env_number(const char* text) {
     if (strcmp(text, "f16") == 0) return 16.0;
     return atof(text);
 }
-static void read_environment(std::vector<double>* option_values, std::vector<int>* devices) {
+// stale_num_task: FLOWGNN_NUM_TASK (round 2's way to give the entry points NUM_TASK) is set to something other than 1.  It is no
+// longer read -- NUM_TASK is an argument of the *_compute_graphs_mt symbols -- and a caller that still relies on it would get
+// one task's worth of results for [T][100] weights, silently: the plain GIN / GCN entry points refuse to run instead.
+static void read_environment(std::vector<double>* option_values, std::vector<int>* devices, bool* stale_num_task = nullptr) {
+    if (stale_num_task) {
+        const char* v = getenv("FLOWGNN_NUM_TASK");
+        *stale_num_task = v && *v && atoi(v) != 1;
+    }
     if (option_values) {
         option_values->resize(kNumOptions);
         for (int i = 0; i < kNumOptions; i++) {
@@ -189,6 +197,7 @@ struct flowgnn_engine {
     bool force_exact = false;   // the resident batch tripped the range flag once: run it on the exact kernels
     int exact_reruns = 0;
     long long G = 0, N = 0, E = 0;
+    long long job_n = -1, job_e = -1;  // flowgnn_set_job_totals: the job the next batches are shards of (-1: each batch is its own job)
     int max_nodes = 0, max_edges = 0;
     size_t capG = 0, capN = 0, capE = 0;
     int *d_nn = nullptr, *d_ne = nullptr, *d_noff = nullptr, *d_eoff = nullptr;
@@ -435,6 +444,14 @@ static int alloc_batch(flowgnn_engine* e, size_t G, size_t N, size_t E, bool att
     return 0;
 }
 
+int flowgnn_set_job_totals(flowgnn_engine* e, long long job_nodes, long long job_edges) {
+    if (!e) return FLOWGNN_ERR_ARG;
+    if ((job_nodes < 0) != (job_edges < 0)) { e->err = "flowgnn_set_job_totals: both totals, or -1 for both"; return FLOWGNN_ERR_ARG; }
+    e->job_n = job_nodes < 0 ? -1 : job_nodes;
+    e->job_e = job_edges < 0 ? -1 : job_edges;
+    return FLOWGNN_OK;
+}
+
 int flowgnn_set_batch(flowgnn_engine* e, int num_graphs, const int* nums_of_nodes, const int* nums_of_edges,
                       const int* node_feature, const int* edge_list, const int* edge_attr, const float* node_eigen) {
     if (!e || num_graphs < 0) return FLOWGNN_ERR_ARG;
@@ -537,7 +554,10 @@ int flowgnn_set_batch(flowgnn_engine* e, int num_graphs, const int* nums_of_node
                 GraphTiles& gt = e->db.gtiles;
                 gt.row_start = e->d_trow; gt.graph_start = e->d_tgraph;
                 gt.n_tiles = (int)cnt - 1; gt.rows = t_rows; gt.edges = t_edges; gt.ok = true;
-                gt.fill = (double)N / ((double)gt.n_tiles * t_rows);
+                // how full the tiles are WITHOUT the last one (the tail of the batch, whatever is left over): a shard of a cut job
+                // then sees the fill of its graphs' packing, not of its own tail -- a one-tile batch counts as full (one resident
+                // launch beats the per-layer sequence on it anyway) -- and takes the path the whole job would take
+                gt.fill = gt.n_tiles > 1 ? (double)trow[cnt - 2] / ((double)(gt.n_tiles - 1) * t_rows) : 1.0;
             }
         }
         int s_rows = 0, s_edges = 0;
@@ -591,6 +611,8 @@ int flowgnn_set_batch(flowgnn_engine* e, int num_graphs, const int* nums_of_node
     e->has_attr = attr; e->has_eig = eig;
     DeviceBatch& db = e->db;
     db.b.num_graphs = num_graphs; db.b.n_tot = (int)N; db.b.e_tot = (int)E;
+    db.job_n = e->job_n >= 0 ? std::max(e->job_n, N) : N;
+    db.job_e = e->job_e >= 0 ? std::max(e->job_e, E) : E;
     db.b.nums_of_nodes = e->d_nn; db.b.nums_of_edges = e->d_ne;
     db.b.node_off = e->d_noff; db.b.edge_off = e->d_eoff;
     db.b.node_feature = e->d_nf; db.b.edge_list = e->d_el; db.b.edge_attr = attr ? e->d_ea : nullptr;
@@ -978,6 +1000,8 @@ struct flowgnn_group {
     int model_id = 0;
     std::vector<flowgnn_engine*> eng;
     std::vector<int> cut;  // [n + 1] graph cuts of the resident batch
+    bool batch_valid = false;  // the engines hold the shards `cut` describes (flowgnn_group_set_batch); flowgnn_group_compute and the
+                               // entry points leave each engine on its LAST range and clear this
     std::vector<std::unique_ptr<std::mutex>> copy_mu;  // flowgnn_group_compute: one copier per device ...
     std::vector<int> copy_of;                          // ... engine i uses copy_mu[copy_of[i]] (the first engine on its device)
     int num_tasks = 1;
@@ -1003,6 +1027,12 @@ int group_each(flowgnn_group* g, F fn) {  // fn(i) on every engine, one host thr
             return rc[(size_t)i];
         }
     return FLOWGNN_OK;
+}
+// every flowgnn_group_* call starts with no error text of an earlier call; argument errors leave their own
+int group_fail(flowgnn_group* g, int rc, const char* what) {
+    if (g) g->err = what;
+    fg::set_last_error(what);
+    return rc;
 }
 }  // namespace
 
@@ -1064,34 +1094,43 @@ const char* flowgnn_group_last_error(const flowgnn_group* g) { return (g && !g->
 
 int flowgnn_group_set_weights(flowgnn_group* g, int count, const float* const* tensors) {
     if (!g) return FLOWGNN_ERR_ARG;
+    g->err.clear();
     return group_each(g, [&](int i) { return flowgnn_set_weights(g->eng[(size_t)i], count, tensors); });
 }
 int flowgnn_group_load_weights_dir(flowgnn_group* g, const char* dir) {
     if (!g) return FLOWGNN_ERR_ARG;
+    g->err.clear();
     return group_each(g, [&](int i) { return flowgnn_load_weights_dir(g->eng[(size_t)i], dir); });
 }
 int flowgnn_group_set_option(flowgnn_group* g, const char* key, double value) {
     if (!g) return FLOWGNN_ERR_ARG;
+    g->err.clear();
     return group_each(g, [&](int i) { return flowgnn_set_option(g->eng[(size_t)i], key, value); });
 }
 int flowgnn_group_set_num_tasks(flowgnn_group* g, int num_tasks) {
     if (!g) return FLOWGNN_ERR_ARG;
+    g->err.clear();
     const int rc = group_each(g, [&](int i) { return flowgnn_set_num_tasks(g->eng[(size_t)i], num_tasks); });
     if (!rc) g->num_tasks = num_tasks;
     return rc;
 }
 int flowgnn_group_set_numeric_mode(flowgnn_group* g, int mode) {
     if (!g) return FLOWGNN_ERR_ARG;
+    g->err.clear();
     return group_each(g, [&](int i) { return flowgnn_set_numeric_mode(g->eng[(size_t)i], mode); });
 }
 
 int flowgnn_group_set_batch(flowgnn_group* g, int num_graphs, const int* nums_of_nodes, const int* nums_of_edges,
                             const int* node_feature, const int* edge_list, const int* edge_attr, const float* node_eigen) {
-    if (!g || num_graphs < 0) return FLOWGNN_ERR_ARG;
-    if (num_graphs > 0 && (!nums_of_nodes || !nums_of_edges)) return FLOWGNN_ERR_ARG;
+    if (!g) return FLOWGNN_ERR_ARG;
+    g->err.clear();
+    g->batch_valid = false;
+    if (num_graphs < 0) return group_fail(g, FLOWGNN_ERR_ARG, "flowgnn_group_set_batch: negative graph count");
+    if (num_graphs > 0 && (!nums_of_nodes || !nums_of_edges)) return group_fail(g, FLOWGNN_ERR_ARG, "flowgnn_group_set_batch: null count arrays");
     const int n = (int)g->eng.size();
+    g->cut.assign((size_t)n + 1, 0);
     int rc = flowgnn_shard_ranges(num_graphs, nums_of_nodes, nums_of_edges, n, g->cut.data());
-    if (rc) return rc;
+    if (rc) return group_fail(g, rc, "flowgnn_group_set_batch: flowgnn_shard_ranges refused the counts");
     // node / edge offsets of every cut (the reference's running nodes_offset / edges_offset, GIN/src/GIN_compute.cc:96-97)
     std::vector<long long> noff((size_t)n + 1, 0), eoff((size_t)n + 1, 0);
     {
@@ -1102,33 +1141,48 @@ int flowgnn_group_set_batch(flowgnn_group* g, int num_graphs, const int* nums_of
             if (gi < num_graphs) { N += nums_of_nodes[gi]; E += nums_of_edges[gi]; }
         }
     }
-    return group_each(g, [&](int i) {
+    // every shard chooses its kernels by the JOB's totals (flowgnn_set_job_totals): the same kernels as one engine holding all of it
+    const long long job_n = noff[(size_t)n], job_e = eoff[(size_t)n];
+    rc = group_each(g, [&](int i) {
         const int g0 = g->cut[(size_t)i], g1 = g->cut[(size_t)i + 1];
         const long long n0 = noff[(size_t)i], e0 = eoff[(size_t)i];
-        return flowgnn_set_batch(g->eng[(size_t)i], g1 - g0, nums_of_nodes ? nums_of_nodes + g0 : nullptr,
-                                 nums_of_edges ? nums_of_edges + g0 : nullptr, node_feature ? node_feature + n0 * 9 : nullptr,
-                                 edge_list ? edge_list + e0 * 2 : nullptr, edge_attr ? edge_attr + e0 * 3 : nullptr,
-                                 node_eigen ? node_eigen + n0 * 4 : nullptr);
+        flowgnn_engine* e = g->eng[(size_t)i];
+        const long long keep_n = e->job_n, keep_e = e->job_e;
+        flowgnn_set_job_totals(e, job_n, job_e);
+        const int r = flowgnn_set_batch(e, g1 - g0, nums_of_nodes ? nums_of_nodes + g0 : nullptr,
+                                        nums_of_edges ? nums_of_edges + g0 : nullptr, node_feature ? node_feature + n0 * 9 : nullptr,
+                                        edge_list ? edge_list + e0 * 2 : nullptr, edge_attr ? edge_attr + e0 * 3 : nullptr,
+                                        node_eigen ? node_eigen + n0 * 4 : nullptr);
+        flowgnn_set_job_totals(e, keep_n, keep_e);  // a later flowgnn_set_batch on the member itself is its own job again
+        return r;
     });
+    g->batch_valid = rc == FLOWGNN_OK;
+    return rc;
 }
 
 int flowgnn_group_shards(const flowgnn_group* g, int* cuts) {
     if (!g || !cuts) return FLOWGNN_ERR_ARG;
+    if (!g->batch_valid) { fg::set_last_error("flowgnn_group_shards: no batch set by flowgnn_group_set_batch"); return FLOWGNN_ERR_STATE; }
     for (size_t i = 0; i < g->cut.size(); i++) cuts[i] = g->cut[i];
     return FLOWGNN_OK;
 }
 
 int flowgnn_group_run(flowgnn_group* g) {
     if (!g) return FLOWGNN_ERR_ARG;
+    g->err.clear();
+    if (!g->batch_valid) return group_fail(g, FLOWGNN_ERR_STATE, "flowgnn_group_run: no batch set by flowgnn_group_set_batch (flowgnn_group_compute and the entry points leave none)");
     return group_each(g, [&](int i) { return flowgnn_run(g->eng[(size_t)i]); });
 }
 int flowgnn_group_sync(flowgnn_group* g) {
     if (!g) return FLOWGNN_ERR_ARG;
+    g->err.clear();
     return group_each(g, [&](int i) { return flowgnn_sync(g->eng[(size_t)i]); });
 }
 int flowgnn_group_get_results(flowgnn_group* g, float* out_host) {
     if (!g) return FLOWGNN_ERR_ARG;
-    if (!out_host && g->cut.back() > 0) return FLOWGNN_ERR_ARG;
+    g->err.clear();
+    if (!g->batch_valid) return group_fail(g, FLOWGNN_ERR_STATE, "flowgnn_group_get_results: no batch set by flowgnn_group_set_batch (flowgnn_group_compute and the entry points leave none)");
+    if (!out_host && g->cut.back() > 0) return group_fail(g, FLOWGNN_ERR_ARG, "flowgnn_group_get_results: null output");
     return group_each(g, [&](int i) {
         flowgnn_engine* e = g->eng[(size_t)i];
         if (e->G == 0) return flowgnn_sync(e);
@@ -1144,13 +1198,19 @@ int flowgnn_group_get_results(flowgnn_group* g, float* out_host) {
 int flowgnn_group_compute(flowgnn_group* g, int num_graphs, const int* nums_of_nodes, const int* nums_of_edges,
                           const int* node_feature, const int* edge_list, const int* edge_attr, const float* node_eigen,
                           float* out_host, int chunks_per_engine) {
-    if (!g || num_graphs < 0 || chunks_per_engine < 1) return FLOWGNN_ERR_ARG;
-    if (num_graphs > 0 && (!nums_of_nodes || !nums_of_edges || !out_host)) return FLOWGNN_ERR_ARG;
+    if (!g) return FLOWGNN_ERR_ARG;
+    g->err.clear();
+    if (num_graphs < 0 || chunks_per_engine < 1) return group_fail(g, FLOWGNN_ERR_ARG, "flowgnn_group_compute: negative graph count or chunks_per_engine < 1");
+    if (num_graphs > 0 && (!nums_of_nodes || !nums_of_edges || !out_host)) return group_fail(g, FLOWGNN_ERR_ARG, "flowgnn_group_compute: null count arrays or output");
     const int n = (int)g->eng.size();
     const int S = n * chunks_per_engine;
     std::vector<int> cut((size_t)S + 1, 0);
     int rc = flowgnn_shard_ranges(num_graphs, nums_of_nodes, nums_of_edges, S, cut.data());
-    if (rc) return rc;
+    if (rc) return group_fail(g, rc, "flowgnn_group_compute: flowgnn_shard_ranges refused the counts");
+    // the engines end up holding their LAST range, not the shards of a flowgnn_group_set_batch job: run / get_results / shards
+    // answer FLOWGNN_ERR_STATE until the next flowgnn_group_set_batch
+    g->batch_valid = false;
+    g->cut.assign((size_t)n + 1, 0);
     std::vector<long long> noff((size_t)S + 1, 0), eoff((size_t)S + 1, 0);
     {
         long long N = 0, E = 0;
@@ -1161,8 +1221,12 @@ int flowgnn_group_compute(flowgnn_group* g, int num_graphs, const int* nums_of_n
         }
     }
     const int T = g->num_tasks;
+    const long long job_n = noff[(size_t)S], job_e = eoff[(size_t)S];  // every range chooses its kernels by the job's totals
     return group_each(g, [&](int i) {
         flowgnn_engine* e = g->eng[(size_t)i];
+        const long long keep_n = e->job_n, keep_e = e->job_e;
+        struct Restore { flowgnn_engine* e; long long n, m; ~Restore() { flowgnn_set_job_totals(e, n, m); } } restore{e, keep_n, keep_e};
+        flowgnn_set_job_totals(e, job_n, job_e);
         for (int j = i; j < S; j += n) {
             const int g0 = cut[(size_t)j], g1 = cut[(size_t)j + 1];
             if (g1 == g0) continue;
@@ -1316,6 +1380,8 @@ static int compute_graphs_generic(int model, int num_graphs, const int* nums_of_
         }
         if (whole) {  // everything on engine 0
             flowgnn_engine* e0 = flowgnn_group_engine(grp, 0);
+            grp->err.clear();
+            grp->batch_valid = false;  // engine 0 is about to hold this range, whatever a flowgnn_group_set_batch left
             rc = flowgnn_set_batch(e0, g1 - g, nums_of_nodes + g, nums_of_edges + g, node_feature + noff * 9,
                                    edge_list ? edge_list + eoff * 2 : nullptr, edge_attr ? edge_attr + eoff * 3 : nullptr,
                                    node_eigen ? node_eigen + noff * 4 : nullptr);
@@ -1349,11 +1415,21 @@ int GIN_compute_graphs_mt(int num_graphs, int* nums_of_nodes, int* nums_of_edges
                                   node_feature_in, nullptr, edge_list_in, edge_attr_in, 8, t, sz, T);
 }
 
+static int refuse_stale_num_task(const char* symbol) {
+    static const bool stale = [] { bool b = false; read_environment(nullptr, nullptr, &b); return b; }();
+    if (!stale) return FLOWGNN_OK;
+    char msg[256];
+    snprintf(msg, sizeof(msg), "%s: FLOWGNN_NUM_TASK is set in the environment but no longer read -- call %s_mt(..., num_tasks) (include/flowgnn.h) or unset it", symbol, symbol);
+    fg::set_last_error(msg);
+    return FLOWGNN_ERR_UNSUPPORTED;
+}
+
 int GIN_compute_graphs(int num_graphs, int* nums_of_nodes, int* nums_of_edges, int* reload_weights, float* out,
                        int* node_feature_in, int* edge_list_in, int* edge_attr_in, float* node_embedding_weight_in,
                        float* edge_embedding_weight_in, float* node_mlp_1_weights, float* node_mlp_1_bias,
                        float* node_mlp_2_weights, float* node_mlp_2_bias, float* graph_pred_weights_in,
                        float* graph_pred_bias_in) {
+    if (int rc = refuse_stale_num_task("GIN_compute_graphs")) return rc;
     return GIN_compute_graphs_mt(num_graphs, nums_of_nodes, nums_of_edges, reload_weights, out, node_feature_in, edge_list_in,
                                  edge_attr_in, node_embedding_weight_in, edge_embedding_weight_in, node_mlp_1_weights, node_mlp_1_bias,
                                  node_mlp_2_weights, node_mlp_2_bias, graph_pred_weights_in, graph_pred_bias_in, 1);
@@ -1379,6 +1455,7 @@ int GCN_compute_graphs(int num_graphs, int* nums_of_nodes, int* nums_of_edges, i
                        float* edge_embedding_weight_in, float* convs_weight_in, float* convs_bias_in,
                        float* convs_root_emb_weight_in, float* bn_weight_in, float* bn_bias_in, float* bn_mean_in,
                        float* bn_var_in, float* graph_pred_weights_in, float* graph_pred_bias_in) {
+    if (int rc = refuse_stale_num_task("GCN_compute_graphs")) return rc;
     return GCN_compute_graphs_mt(num_graphs, nums_of_nodes, nums_of_edges, reload_weights, out, node_feature_in, edge_list_in,
                                  edge_attr_in, node_embedding_weight_in, edge_embedding_weight_in, convs_weight_in, convs_bias_in,
                                  convs_root_emb_weight_in, bn_weight_in, bn_bias_in, bn_mean_in, bn_var_in, graph_pred_weights_in,

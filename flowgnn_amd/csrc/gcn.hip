@@ -922,8 +922,8 @@ public:
     }
 
     void configure(const Options& o) override {
-        if (o.i("tile_nominal") > 0) tile_nominal_ = o.i("tile_nominal");
-        if (o.i("tile_slack") >= 0) tile_slack_ = o.i("tile_slack");
+        tile_nominal_ = o.i("tile_nominal") > 0 ? o.i("tile_nominal") : kTileNominal;  // <= 0 / < 0: back to the model's defaults
+        tile_slack_ = o.i("tile_slack") >= 0 ? o.i("tile_slack") : kTileSlack;
         split_ = o.i("gcn_mfma") != 32;
         fused_ = !o.on("gcn_unfused");
         resident_ = o.on("gcn_resident");
@@ -960,7 +960,8 @@ private:
     int num_tasks_ = 1;  // NUM_TASK (GCN/src/dcl.h) as a run-time dimension
     GrowBuf esc_;
     GrowBufI tiles_;  // graph-aligned tile starts of the resident batch (tile_bounds_kernel)
-    int tile_nominal_ = 96, tile_slack_ = 32;  // options tile_nominal / tile_slack (< 0: these defaults)
+    static constexpr int kTileNominal = 96, kTileSlack = 32;  // the model's defaults of the options tile_nominal / tile_slack
+    int tile_nominal_ = kTileNominal, tile_slack_ = kTileSlack;
     // gcn_mfma=32 keeps the dense layers on the fp32 matrix pipe (dense100_kernel); the default runs them as three
     // f16 MFMAs per product (dense_split.h), with the engine falling back to fp32 when the range flag trips
     bool split_ = true;

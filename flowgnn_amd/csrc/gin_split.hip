@@ -517,6 +517,9 @@ __device__ __forceinline__ void grc_issue_chunk_w1(const uint8_t* __restrict__ g
 #ifndef GR_PRIO_HALF
 #define GR_PRIO_HALF true
 #endif
+#ifndef GR_FLIP
+#define GR_FLIP 0
+#endif
 #ifndef GR_PRIO_BY_PHASE
 #define GR_PRIO_BY_PHASE true
 #endif
@@ -535,8 +538,10 @@ __device__ __forceinline__ void grc_issue_chunk_w1(const uint8_t* __restrict__ g
 template <int KIND, bool PEND_IN = false, bool PEND_OUT = false>
 __device__ __forceinline__ void gr_step(const char* wb, int lane, int g, const uint4_t (&in_hi)[2][3], const uint4_t (&in_lo)[2][3],
                                         const uint4_t (&in_tb)[2], uint4_t (&hb_hi)[2], uint4_t (&hb_lo)[2], float4_t (&acc2)[2][GS_T2],
-                                        float& vmax, float4_t (&pend)[2], const float* u_step = nullptr, float* dot = nullptr) {
+                                        float& vmax, float4_t (&pend)[2], const float* u_step = nullptr, float* dot = nullptr, int wave = 0) {
     constexpr bool DO2 = KIND == 1 || KIND == 2, DO1 = KIND != 3, DOT = KIND >= 4;
+    // GR_FLIP: the static priority of waves 4-7 changes hands in the middle of the step's unit chain (and back at its end)
+#define GR_PRIO_FLIP(TO_OLD) if (GR_FLIP) { if ((wave >= 4) != (TO_OLD)) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
     constexpr int NTL = (KIND == 2 || KIND == 5) ? 1 : 2;
     uint4_t f0[2], f1[2];  // fragment double buffer: f0 = even units, f1 = odd units
 #define GR_U2_LOAD(F, T) F[0] = GR_LD(GRC_W2_OFF + (2 * (T)) * 1024); F[1] = GR_LD(GRC_W2_OFF + (2 * (T) + 1) * 1024);
@@ -604,6 +609,7 @@ __device__ __forceinline__ void gr_step(const char* wb, int lane, int g, const u
         GR_SB();
         GR_U2_MFMA(f0, 6)
         GR_SB();
+        GR_PRIO_FLIP(true)
     }
     if constexpr (KIND == 3) {  // packed K-step: one MFMA per output tile and column tile (hb_hi holds the packed operand)
         uint4_t p[GS_T2];
@@ -630,6 +636,7 @@ __device__ __forceinline__ void gr_step(const char* wb, int lane, int g, const u
         acc1[0] = GS_MFMA16(f0[0], in_tb[0], acc1[0]);
         acc1[1] = GS_MFMA16(f0[0], in_tb[1], acc1[1]);
         if constexpr (NTL == 2) {
+            if constexpr (!DO2) { GR_PRIO_FLIP(true) }
             GR_FINISH(0)
             GR_BIAS(1)
             acc1[1] = acc1[0];
@@ -650,6 +657,8 @@ __device__ __forceinline__ void gr_step(const char* wb, int lane, int g, const u
         }
         asm volatile("" : "+v"(vmax));
     }
+    if constexpr (DO2 || NTL == 2) { GR_PRIO_FLIP(false) }
+#undef GR_PRIO_FLIP
 #undef GR_U1_MFMA1
 #undef GR_TAIL_LOAD
 #undef GR_BIAS
@@ -1309,8 +1318,8 @@ __device__ __forceinline__ void gr_layer(unsigned long long (&tacc)[6], char* bx
                 gr_issue_rows(h0, reinterpret_cast<char*>(s_h), nxt, c, wave, lane);
                 if (c == GS_STEPS - 2) gr_issue_rows(h0, reinterpret_cast<char*>(s_h), nxt, c + 1, wave, lane);
             }
-            if (c < GS_STEPS - 2) gr_step<4>(cb, lane, g, in_hi, in_lo, in_tb, h_hi, h_lo, acc2, vmax, pend, s_u + 32 * c, dot);
-            else gr_step<5>(cb, lane, g, in_hi, in_lo, in_tb, h_hi, h_lo, acc2, vmax, pend, s_u + 32 * c, dot);
+            if (c < GS_STEPS - 2) gr_step<4>(cb, lane, g, in_hi, in_lo, in_tb, h_hi, h_lo, acc2, vmax, pend, s_u + 32 * c, dot, wave);
+            else gr_step<5>(cb, lane, g, in_hi, in_lo, in_tb, h_hi, h_lo, acc2, vmax, pend, s_u + 32 * c, dot, wave);
             if (ENC || c + 1 < GS_STEPS - 1) {
                 unsigned long long tw = 0;
                 if constexpr (PROF) tw = wall_clock64();
@@ -1340,9 +1349,9 @@ __device__ __forceinline__ void gr_layer(unsigned long long (&tacc)[6], char* bx
         // even step: compute from by while chunk c+1 streams into bx
         grc_issue_chunk(wchunks + (size_t)(c + 1) * GRC_CHUNK_STRIDE, bx, wave, lane);
         if (last && has_next) gr_issue_rows(h0, reinterpret_cast<char*>(s_h), nxt, c, wave, lane);
-        if (c == 0) gr_step<0, false, GR_DEFER>(by, lane, g, in_hi, in_lo, in_tb, h_hi, h_lo, acc2, vmax, pend);
-        else if (c == 6) gr_step<2, GR_DEFER, GR_DEFER>(by, lane, g, in_hi, in_lo, in_tb, h_hi, h_lo, acc2, vmax, pend);
-        else gr_step<1, GR_DEFER, GR_DEFER>(by, lane, g, in_hi, in_lo, in_tb, h_hi, h_lo, acc2, vmax, pend);
+        if (c == 0) gr_step<0, false, GR_DEFER>(by, lane, g, in_hi, in_lo, in_tb, h_hi, h_lo, acc2, vmax, pend, nullptr, nullptr, wave);
+        else if (c == 6) gr_step<2, GR_DEFER, GR_DEFER>(by, lane, g, in_hi, in_lo, in_tb, h_hi, h_lo, acc2, vmax, pend, nullptr, nullptr, wave);
+        else gr_step<1, GR_DEFER, GR_DEFER>(by, lane, g, in_hi, in_lo, in_tb, h_hi, h_lo, acc2, vmax, pend, nullptr, nullptr, wave);
         unsigned long long tw = 0;
         if constexpr (PROF) tw = wall_clock64();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of chunk c+1 (and of the next tile) have landed
@@ -1353,8 +1362,8 @@ __device__ __forceinline__ void gr_layer(unsigned long long (&tacc)[6], char* bx
         if (c + 2 < GS_STEPS) grc_issue_chunk(wchunks + (size_t)(c + 2) * GRC_CHUNK_STRIDE, by, wave, lane);
         else gr_issue_ecomb(ecomb_all + (size_t)ln * EDGE_COMBOS * GS_D, by, wave, lane);
         if (last && has_next) gr_issue_rows(h0, reinterpret_cast<char*>(s_h), nxt, c + 1, wave, lane);
-        if (c == 6) gr_step<3, GR_DEFER, false>(bx, lane, g, in_hi, in_lo, in_tb, h_hi, h_lo, acc2, vmax, pend);
-        else gr_step<1, GR_DEFER, GR_DEFER>(bx, lane, g, in_hi, in_lo, in_tb, h_hi, h_lo, acc2, vmax, pend);
+        if (c == 6) gr_step<3, GR_DEFER, false>(bx, lane, g, in_hi, in_lo, in_tb, h_hi, h_lo, acc2, vmax, pend, nullptr, nullptr, wave);
+        else gr_step<1, GR_DEFER, GR_DEFER>(bx, lane, g, in_hi, in_lo, in_tb, h_hi, h_lo, acc2, vmax, pend, nullptr, nullptr, wave);
         if (c + 2 < GS_STEPS) {
             if constexpr (PROF) tw = wall_clock64();
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -703,8 +703,8 @@ public:
     }
 
     void configure(const Options& o) override {
-        if (o.i("tile_nominal") > 0) tile_nominal_ = o.i("tile_nominal");
-        if (o.i("tile_slack") >= 0) tile_slack_ = o.i("tile_slack");
+        tile_nominal_ = o.i("tile_nominal") > 0 ? o.i("tile_nominal") : kTileNominal;  // <= 0 / < 0: back to the model's defaults
+        tile_slack_ = o.i("tile_slack") >= 0 ? o.i("tile_slack") : kTileSlack;
         split_ = o.i("pna_mfma") != 32;
         fused_ = o.on("pna_fused");
         ablate_ = FG_ABLATE(o.i("pna_ablate"));
@@ -732,7 +732,8 @@ private:
     bool qmode_ = false;  // flowgnn_set_numeric_mode(FLOWGNN_NUMERIC_Q6_10)
     QPack q_;
     GrowBufI tiles_;  // graph-aligned tile starts of the resident batch (tile_bounds_kernel)
-    int tile_nominal_ = 112, tile_slack_ = 48;  // options tile_nominal / tile_slack (< 0: these defaults)
+    static constexpr int kTileNominal = 112, kTileSlack = 48;  // the model's defaults of the options tile_nominal / tile_slack
+    int tile_nominal_ = kTileNominal, tile_slack_ = kTileSlack;
     // pna_mfma=32 keeps the dense update on the fp32 matrix pipe (pna_dense_kernel)
     bool split_ = true;
     // pna_fused=0 keeps aggregation and dense update as two kernels per layer (A/B measurements, the aggregation roofline probe)

@@ -98,6 +98,10 @@ class Engine:
         self._check(self.lib.flowgnn_load_weights_dir(self._h, directory.encode()), "flowgnn_load_weights_dir")
 
     # ---- batch
+    def set_job_totals(self, job_nodes: int = -1, job_edges: int = -1):
+        """The next batches are shards of a job of this size (flowgnn.h: flowgnn_set_job_totals); (-1, -1): each batch is its own job."""
+        self._check(self.lib.flowgnn_set_job_totals(self._h, int(job_nodes), int(job_edges)), "flowgnn_set_job_totals")
+
     def set_batch(self, batch: GraphBatch):
         nn, ne = _i32(batch.nums_of_nodes), _i32(batch.nums_of_edges)
         nf, el, ea = _i32(batch.node_feature), _i32(batch.edge_list), _i32(batch.edge_attr)
@@ -282,7 +286,8 @@ class EngineGroup:
 
     def compute(self, batch: GraphBatch, chunks_per_engine: int = 1) -> np.ndarray:
         """flowgnn_group_compute: the host batch cut into size x chunks_per_engine ranges, engine i taking ranges i, i + size, ...
-        (set_batch, run, results) so that one engine's host -> device copies overlap the others' kernels."""
+        (set_batch, run, results) so that one engine's host -> device copies overlap the others' kernels.  The engines are left on
+        their last range: run() / results() / shards() raise FLOWGNN_ERR_STATE until the next set_batch."""
         nn, ne = _i32(batch.nums_of_nodes), _i32(batch.nums_of_edges)
         nf, el, ea = _i32(batch.node_feature), _i32(batch.edge_list), _i32(batch.edge_attr)
         eig = None if batch.node_eigen is None else _f32(batch.node_eigen)

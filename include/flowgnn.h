@@ -228,6 +228,14 @@ int flowgnn_set_batch(flowgnn_engine* e, int num_graphs,
                       const int* nums_of_nodes, const int* nums_of_edges,
                       const int* node_feature, const int* edge_list, const int* edge_attr,
                       const float* node_eigen);
+/*
+ * Declare the next flowgnn_set_batch batches to be SHARDS of a job of this many nodes and edges (a multi-process caller that cuts
+ * one job over several GPUs, one engine each; flowgnn_group_* does it by itself).  Choices between kernels that depend on the
+ * batch size -- GIN's front end, DGN's aggregation -- are then made from the job's totals, so every shard computes on the
+ * kernels a single engine would have chosen for the whole job and results do not depend on the device count.  (-1, -1), the
+ * default: each batch is its own job.  Totals smaller than a batch's own are raised to them.
+ */
+int flowgnn_set_job_totals(flowgnn_engine* e, long long job_nodes, long long job_edges);
 
 /*
  * Enqueue one full forward of the resident batch on the engine's stream:
@@ -321,8 +329,11 @@ int flowgnn_set_numeric_mode(flowgnn_engine* e, int mode);
  * separate aggregation and dense kernels, "hipgraph" 1 -- and exist for A/B measurements and parity tests.  Defaults come from the
  * table; the environment is read in exactly one place, when flowgnn_create builds an engine (FLOWGNN_<KEY IN UPPER CASE>, "f32"
  * reads as 32), and flowgnn_set_option overrides it.  Call it before flowgnn_set_batch: it invalidates the resident batch.
- * Unknown key: FLOWGNN_ERR_UNSUPPORTED.  No option changes the shape of any buffer, and the shipped library has no option
- * that changes results (the kernels' ablation hooks are compiled in only with -DFLOWGNN_DEV).
+ * Unknown key: FLOWGNN_ERR_UNSUPPORTED.  No option changes the shape of any buffer.  ONE shipped option changes results, by
+ * design: "gat_reference_quirk" (1 = read the node features without the per-graph offset, as GAT/src/GAT_compute.cc:72
+ * does; 0, the default = with it); every other one selects between kernels that agree to
+ * fp32 rounding (bit for bit where DESIGN.md says so).  The kernels' ablation hooks -- which do give wrong results, for per-phase
+ * timing -- are compiled in only with -DFLOWGNN_DEV.  "gin_pingpong" != 0 implies the three-kernel front end ("gin_tile_build" 0).
  */
 int flowgnn_set_option(flowgnn_engine* e, const char* key, double value);
 int flowgnn_get_option(const flowgnn_engine* e, const char* key, double* value);
@@ -334,8 +345,17 @@ const char* flowgnn_option_name(int i);
  * one compute unit, GIN/config_slr.cfg:1-2).  One engine + one host thread per listed device; flowgnn_group_set_batch cuts the
  * batch into contiguous graph ranges balanced by sum(N + E) (flowgnn_shard_ranges: cuts[0..parts], cuts[r] = the first graph
  * whose cumulative node + edge count reaches r / parts of the total) and flowgnn_group_get_results writes [num_graphs][NUM_TASK]
- * in job order.  Graphs are independent, so the results are bit-identical to a single engine's.  A device may appear more than
- * once in the list.  flowgnn_group_engine(g, i) exposes member i for per-engine calls (profiling, taps).
+ * in job order.  A device may appear more than once in the list.  flowgnn_group_engine(g, i) exposes member i for per-engine
+ * calls (profiling, taps).
+ * What a group's results are relative to ONE engine holding the whole job: graphs are independent and every kernel sums a row's
+ * in-edges in an order that depends on the row alone, so results are BIT-IDENTICAL whenever the same kernels run -- and the
+ * kernels are chosen from the JOB's totals, which the group (and the entry points' ranges) hand down to every member through
+ * flowgnn_set_job_totals.  That covers GIN, GIN-VN, GCN, GAT and PNA with default options at any device count.  Two exceptions:
+ * DGN's matrix-pipe aggregation (default on kNN-dense jobs, option "dgn_mfma_agg") sums in tile order -- equal to 1e-5 relative
+ * under a different cut, bit-identical with "dgn_mfma_agg" 0; and a job of LARGE graphs whose tiles are about as full as the
+ * resident kernels' fill threshold (50 %; 40 % PNA / DGN; a batch's last tile does not count, a one-tile batch is full) can pack
+ * above it as a whole and below it in a shard, which then runs the per-layer kernels: fp32 rounding differences.  flowgnn_group_run / get_results / shards answer FLOWGNN_ERR_STATE unless the engines hold
+ * the shards of a flowgnn_group_set_batch job (flowgnn_group_compute and the entry points leave each engine on its last range).
  */
 typedef struct flowgnn_group flowgnn_group;
 int flowgnn_shard_ranges(int num_graphs, const int* nums_of_nodes, const int* nums_of_edges, int parts, int* cuts);

@@ -46,7 +46,9 @@ def test_shipped_library_has_no_ablation_hooks_and_one_env_reader():
     argument, not an environment variable; every option name is reachable through the API."""
     blob = open(LIB, "rb").read()
     assert b"ABLATE" not in blob and b"_ablate" not in blob
-    assert b"FLOWGNN_NUM_TASK" not in blob
+    # FLOWGNN_NUM_TASK appears once: as the name the plain GIN / GCN entry points REFUSE to run under (a stale setting of round 2's
+    # switch would otherwise give one task's results for [T][100] weights silently)
+    assert blob.count(b"FLOWGNN_NUM_TASK is set in the environment but no longer read") == 1
     lib = ctypes.CDLL(LIB)
     lib.flowgnn_option_name.restype = ctypes.c_char_p
     names = [lib.flowgnn_option_name(i).decode() for i in range(lib.flowgnn_option_count())]
@@ -62,7 +64,7 @@ def test_shipped_library_has_no_ablation_hooks_and_one_env_reader():
                 code = line.split("//")[0]
                 if "getenv(" in code:
                     hits.append((os.path.basename(f), i))
-    assert hits and all(f == "engine.hip" for f, _ in hits) and len(hits) <= 3, hits
+    assert hits and all(f == "engine.hip" for f, _ in hits) and len(hits) <= 4, hits
 
 
 @pytest.mark.skipif(not os.path.exists(LIB), reason="libflowgnn_hip.so not built")

@@ -186,8 +186,8 @@ def test_group_compute_pipelines_ranges_and_matches_the_single_engine(oracle):
         grp.set_weights(w)
         got = grp.compute(b, chunks)
         assert np.array_equal(got, want), (engines, chunks, np.abs(got - want).max())
-        small = b.slice(0, 3)  # fewer graphs than ranges: empty ranges are skipped (one-graph ranges pack below the resident kernel's
-        assert np.allclose(grp.compute(small, chunks), want[:3], rtol=1e-5, atol=1e-5)  # fill threshold: per-layer kernels, last-bit differences)
+        small = b.slice(0, 3)  # fewer graphs than ranges: empty ranges are skipped; a one-graph range is one resident tile (the fill
+        assert np.array_equal(grp.compute(small, chunks), want[:3])  # threshold does not count a batch's last tile): the same bits
         assert np.array_equal(grp.compute(b, chunks), want)  # engines re-used with other sizes
         grp.close()
     try:
@@ -196,3 +196,69 @@ def test_group_compute_pipelines_ranges_and_matches_the_single_engine(oracle):
             assert np.array_equal(compute_graphs("GIN", b, [w]), want), setting
     finally:
         entry_set_pipeline(0)
+
+
+def test_kernel_choice_follows_the_job_not_the_shard():
+    """A job of > 1.52 M nodes takes GIN's three-kernel front end on one engine; each half of it alone would take the one-pass
+    front end, whose encoder sum associates differently (last bits).  The group hands the JOB's totals to its members
+    (flowgnn_set_job_totals), so two engines compute the same bits as one -- and so do the ranges of flowgnn_group_compute and a
+    caller that shards by hand."""
+    from flowgnn_amd.dist import shard_ranges
+    b, w = gp.synth_molhiv_batch(66000, seed=77), weights.synth_gin_weights(seed=7)
+    assert b.total_nodes > 1523712 and b.total_nodes // 2 < 1523712
+    e = Engine("GIN", device=0)
+    try:
+        e.set_weights(w)
+        e.profile_enable(True)
+        want = e.forward(b)
+        assert "gin_tile_build" not in e.profile_read() and "atom_encoder" in e.profile_read()
+        # by hand: one engine, the job's halves one after the other, declared as shards of the job
+        e.set_job_totals(b.total_nodes, b.total_edges)
+        parts = [e.forward(b.slice(a, c)) for a, c in shard_ranges(b, 2)]
+        assert np.array_equal(np.concatenate(parts), want)
+        assert "gin_tile_build" not in e.profile_read()
+        # undeclared, a half is its own job and takes the one-pass front end: same values to fp32 rounding
+        e.set_job_totals(-1, -1)
+        a, c = shard_ranges(b, 2)[0]
+        alone = e.forward(b.slice(a, c))
+        assert "gin_tile_build" in e.profile_read()
+        np.testing.assert_allclose(alone, want[a:c], rtol=1e-5, atol=1e-5)
+    finally:
+        e.close()
+    g = EngineGroup("GIN", [0, 0])
+    try:
+        g.set_weights(w)
+        assert np.array_equal(g.forward(b), want)
+        assert np.array_equal(g.compute(b, 3), want)
+    finally:
+        g.close()
+
+
+def test_group_state_after_compute_and_error_text():
+    """flowgnn_group_compute leaves the engines on their last ranges: run / results / shards answer FLOWGNN_ERR_STATE (6) until the
+    next set_batch instead of writing old shards at stale offsets; a successful call clears the error text of a failed one."""
+    from flowgnn_amd.engine import FlowGNNError
+    b, w = gp.synth_molhiv_batch(40, seed=3), weights.synth_gin_weights(seed=7)
+    want = single("GIN", b, w)
+    g = EngineGroup("GIN", [0, 0])
+    try:
+        g.set_weights(w)
+        assert np.array_equal(g.forward(b), want)
+        small = b.slice(0, 7)
+        assert np.array_equal(g.compute(small, 2), want[:7])
+        for call in (g.run, g.results, g.shards):
+            with pytest.raises(FlowGNNError) as ei:
+                call()
+            assert ei.value.code == 6
+        assert b"flowgnn_group_set_batch" in g.lib.flowgnn_group_last_error(g._h)
+        bad = b.slice(0, 5)
+        bad.edge_list = bad.edge_list.copy()
+        bad.edge_list[0, 0] = 10 ** 6
+        with pytest.raises(FlowGNNError):
+            g.forward(bad)
+        assert b"engine" in g.lib.flowgnn_group_last_error(g._h)
+        assert np.array_equal(g.forward(b), want)  # recovers, and ...
+        g.lib.flowgnn_group_sync(g._h)
+        assert b"engine" not in (g.lib.flowgnn_group_last_error(g._h) or b"")  # ... the old text is gone
+    finally:
+        g.close()
