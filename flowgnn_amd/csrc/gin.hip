@@ -622,8 +622,14 @@ public:
                                     b2 + (size_t)l * GIN_D, rsplit.data() + (size_t)l * gin_resident_layer_bytes());
         // ... re-cut into the ping-pong kernel's pieces, with the edge-embedding tables as half tables
         std::vector<uint8_t> pp_pieces((size_t)GIN_L * gin_pp_layer_bytes());
-        for (int l = 0; l < GIN_L; l++)
-            gin_pp_pack_layer(rsplit.data() + (size_t)l * gin_resident_layer_bytes(), pp_pieces.data() + (size_t)l * gin_pp_layer_bytes());
+        {
+            std::vector<uint8_t> eight(gin_resident_layer_bytes());  // the eight-chunk form of the stream (chunk 7 = the packed K-step)
+            for (int l = 0; l < GIN_L; l++) {
+                gin_resident_pack_layer(w1 + (size_t)l * GIN_H * GIN_D, b1 + (size_t)l * GIN_H, w2 + (size_t)l * GIN_D * GIN_H,
+                                        b2 + (size_t)l * GIN_D, eight.data(), false);
+                gin_pp_pack_layer(eight.data(), pp_pieces.data() + (size_t)l * gin_pp_layer_bytes());
+            }
+        }
         std::vector<float> pp_tables(gin_pp_table_floats());
         gin_pp_pack_tables(ecomb.data(), pp_tables.data());
         int rc;

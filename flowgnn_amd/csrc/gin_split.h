@@ -37,7 +37,7 @@ void launch_gin_layer_split(const float* h, float* hout, const int* row_ptr, con
 // the flowgnn_get_h tap; out [G] receives the logits.
 // weight stream of the resident kernel (its own chunk format: gin_split.hip "GR chunks"); chunks_all = 5 x gin_resident_layer_bytes()
 size_t gin_resident_layer_bytes();
-void gin_resident_pack_layer(const float* w1, const float* b1, const float* w2, const float* b2, uint8_t* out);
+void gin_resident_pack_layer(const float* w1, const float* b1, const float* w2, const float* b2, uint8_t* out, bool merged = true);
 constexpr int GIN_RESIDENT_ROWS = 256;
 constexpr int GIN_RESIDENT_EDGES = 1280;
 constexpr int GIN_RESIDENT_DESC_BYTES = 3584;  // per-tile descriptor built by gin_tile_prep_kernel (CSR slice as 16-bit words, row offsets, column owners)

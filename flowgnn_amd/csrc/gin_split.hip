@@ -454,6 +454,7 @@ __global__ __launch_bounds__(WAVES * 64) void gin_layer_split_kernel(const float
 constexpr int GR_ROWS = 256;
 constexpr int GR_EDGES = 1280;
 constexpr int GR_WAVES = 8;
+constexpr int GR_STEPS = 7;  // MLP steps of a layer of the resident kernel (the eight-step schedule of the per-layer kernel with its last two merged)
 
 // Weight stream of the resident kernel ("GR chunks"; gin_resident_pack_layer builds it).  Same 8 steps as the per-layer kernel's
 // stream, with the padding taken out of the matrix work:
@@ -467,6 +468,8 @@ constexpr int GR_WAVES = 8;
 //           [12288, 13312)   K-tail fragments, 512 B per tile (lanes 0..31: g = 0 [w_hi, w_hi], g = 1 [w_lo, 0])
 //           [13312, 13440)   b1 slices, 2 x 16 floats (pre-scaled)
 //           [13440, 27776)   W2 fragments of K-step s-1: (t2 * 2 + p) * 1024; step 7: packed, t2 * 1024; chunk 0: b2[112] + 1/(s1 s2)
+constexpr int GRC_PK_OFF = 6144;             // chunk 6: packed K-step fragments of output tiles 0..5 (the slot of hidden tile 13, which does not exist)
+constexpr int GRC_PK6_OFF = 12288 + 512;      // chunk 6: ... of output tile 6, rows 96..99 only (16 lanes x 16 B, in the K-tail slot of hidden tile 13)
 constexpr int GRC_TAIL_OFF = 12288;
 constexpr int GRC_B1_OFF = 13312;
 constexpr int GRC_W2_OFF = 13440;
@@ -519,6 +522,13 @@ __device__ __forceinline__ void grc_issue_chunk_w1(const uint8_t* __restrict__ g
 #endif
 #ifndef GR_FLIP
 #define GR_FLIP 0
+#endif
+#ifdef GR_PROF_WALK
+#define GR_TACC_DMA 3  /* folded into "epilogue" (unused in this development build's report) */
+#define GR_TACC_BAR 3
+#else
+#define GR_TACC_DMA 5
+#define GR_TACC_BAR 4
 #endif
 #ifndef GR_PRIO_BY_PHASE
 #define GR_PRIO_BY_PHASE true
@@ -669,6 +679,102 @@ __device__ __forceinline__ void gr_step(const char* wb, int lane, int g, const u
 #undef GR_U2_MFMA
 #undef GR_U1_LOAD
 #undef GR_U1_MFMA
+}
+// The LAST step of a layer that computes its second linear layer (steps 6 and 7 of the eight-step schedule as ONE step; chunk 6 of the
+// stream carries both, GR chunks above).  Hidden tile 12 first (the half tile: hidden units 192..199), then per OUTPUT tile t the unit
+// of K-step 5 and the packed MFMA of K-step 6 back to back -- the same order of accumulation as in two steps, so the same bits -- which
+// makes acc2[.][t] FINAL after unit t: with STORE its ReLU'd rows go back into the tile (in place: nobody reads the old rows during the
+// MLP) one unit later, under the MFMAs of the following output tiles.  Stored after the last step the tile's 102 KB of rows cost
+// 0.28 ms per launch at the ~80 B per clock of ds_write_b128 with the matrix pipe idle (measured by leaving them out), and the
+// eighth step a barrier and a fragment round trip of its own for 14 MFMAs.
+template <bool STORE>
+__device__ __forceinline__ void gr_step_final(const char* wb, int lane, int g, const uint4_t (&in_hi)[2][3], const uint4_t (&in_lo)[2][3],
+                                              const uint4_t (&in_tb)[2], const uint4_t (&hb_hi)[2], const uint4_t (&hb_lo)[2],
+                                              float4_t (&acc2)[2][GS_T2], float& vmax, float oscale, float* rw0, float* rw1) {
+    uint4_t f0[2], f1[2], pa, hp[2];
+    float4_t acc1[2];
+#define GRF_U2_LOAD(F, T) F[0] = GR_LD(GRC_W2_OFF + (2 * (T)) * 1024); F[1] = GR_LD(GRC_W2_OFF + (2 * (T) + 1) * 1024);
+#define GRF_U2_MFMA(F, T)                                         \
+    acc2[0][T] = GS_MFMA16(F[0], hb_hi[0], acc2[0][T]);           \
+    acc2[1][T] = GS_MFMA16(F[0], hb_hi[1], acc2[1][T]);           \
+    acc2[0][T] = GS_MFMA16(F[0], hb_lo[0], acc2[0][T]);           \
+    acc2[1][T] = GS_MFMA16(F[0], hb_lo[1], acc2[1][T]);           \
+    acc2[0][T] = GS_MFMA16(F[1], hb_hi[0], acc2[0][T]);           \
+    acc2[1][T] = GS_MFMA16(F[1], hb_hi[1], acc2[1][T]);
+#define GRF_U1_LOAD(F, KS) F[0] = GR_LD((2 * (KS)) * 1024); F[1] = GR_LD((2 * (KS) + 1) * 1024);
+#define GRF_U1_MFMA(F, KS)                                        \
+    acc1[0] = GS_MFMA16(F[0], in_hi[0][KS], acc1[0]);             \
+    acc1[1] = GS_MFMA16(F[0], in_hi[1][KS], acc1[1]);             \
+    acc1[0] = GS_MFMA16(F[0], in_lo[0][KS], acc1[0]);             \
+    acc1[1] = GS_MFMA16(F[0], in_lo[1][KS], acc1[1]);             \
+    acc1[0] = GS_MFMA16(F[1], in_hi[0][KS], acc1[0]);             \
+    acc1[1] = GS_MFMA16(F[1], in_hi[1][KS], acc1[1]);
+    // packed fragment of output tile T: tiles 0..5 in the slot of the (non-existent) hidden tile 13, tile 6 -- outputs 96..99: four real
+    // rows -- as 16 lanes x 16 B behind the K-tail fragments
+#define GRF_PK_LOAD(P, T)                                                                                                          \
+    if constexpr ((T) < 6) P = GR_LD(GRC_PK_OFF + (T) * 1024);                                                                     \
+    else P = (lane & 15) < 4 ? *reinterpret_cast<const uint4_t*>(wb + GRC_PK6_OFF + ((((lane >> 4) << 2) | (lane & 3)) << 4)) : (uint4_t){0u, 0u, 0u, 0u};
+#define GRF_PK_MFMA(P, T)                                  \
+    acc2[0][T] = GS_MFMA16(P, hp[0], acc2[0][T]);          \
+    acc2[1][T] = GS_MFMA16(P, hp[1], acc2[1][T]);
+#define GRF_STORE(T)                                                                                                  \
+    if constexpr (STORE) {                                                                                            \
+        constexpr int col0_ = 16 * (T);                                                                               \
+        if (col0_ + 4 * g < GS_D) {                                                                                   \
+            float4_t r0_ = acc2[0][T] * oscale, r1_ = acc2[1][T] * oscale;                                            \
+            r0_.x = gs_relu(r0_.x); r0_.y = gs_relu(r0_.y); r0_.z = gs_relu(r0_.z); r0_.w = gs_relu(r0_.w);           \
+            r1_.x = gs_relu(r1_.x); r1_.y = gs_relu(r1_.y); r1_.z = gs_relu(r1_.z); r1_.w = gs_relu(r1_.w);           \
+            *reinterpret_cast<float4_t*>(rw0 + col0_ + 4 * g) = r0_;                                                  \
+            *reinterpret_cast<float4_t*>(rw1 + col0_ + 4 * g) = r1_;                                                  \
+        }                                                                                                             \
+    }
+    // ---- hidden tile 12 = b1 + W1 a (three K-steps + the packed K tail)
+    GRF_U1_LOAD(f1, 0)
+    acc1[0] = *reinterpret_cast<const float4_t*>(wb + GRC_B1_OFF + g * 16);
+    GR_SB();
+    acc1[1] = acc1[0];
+    GRF_U1_LOAD(f0, 1) GR_SB(); GRF_U1_MFMA(f1, 0) GR_SB();
+    GRF_U1_LOAD(f1, 2) GR_SB(); GRF_U1_MFMA(f0, 1) GR_SB();
+    f0[0] = *reinterpret_cast<const uint4_t*>(wb + GRC_TAIL_OFF + (lane & 31) * 16); GR_SB();
+    GRF_U1_MFMA(f1, 2) GR_SB();
+    GRF_U2_LOAD(f1, 0) GR_SB();  // the first unit of the second linear layer, requested under the tail
+    acc1[0] = GS_MFMA16(f0[0], in_tb[0], acc1[0]);
+    acc1[1] = GS_MFMA16(f0[0], in_tb[1], acc1[1]);
+    GR_SB();
+    // ---- K-step 5 unit 0 needs nothing of tile 12: its MFMAs cover the ReLU + split + pack of the tile
+    GRF_U2_LOAD(f0, 1) GRF_PK_LOAD(pa, 0) GR_SB();
+    GRF_U2_MFMA(f1, 0) GR_SB();
+#pragma unroll
+    for (int nt = 0; nt < 2; nt++) {
+        float4_t r = acc1[nt];
+        r.x = gs_relu(r.x); r.y = gs_relu(r.y); r.z = gs_relu(r.z); r.w = gs_relu(r.w);
+        vmax = __builtin_fmaxf(__builtin_fmaxf(vmax, r.x), r.y);
+        vmax = __builtin_fmaxf(__builtin_fmaxf(vmax, r.z), r.w);
+        uint32_t hx, hy, lx, ly;  // lanes g = 0 / 1 hold hidden units 192..195 / 196..199
+        GS_SPLIT2(r.x, r.y, hx, lx);
+        GS_SPLIT2(r.z, r.w, hy, ly);
+        // the packed operand:  g = 0, 1: [hi, lo] (own)   g = 2, 3: [hi of lane - 32, 0]
+        const uint32_t ox = __shfl(hx, lane & 31, 64), oy = __shfl(hy, lane & 31, 64);
+        hp[nt] = g < 2 ? (uint4_t){hx, hy, lx, ly} : (uint4_t){ox, oy, 0u, 0u};
+    }
+    asm volatile("" : "+v"(vmax));
+    GR_SB();
+    GRF_PK_MFMA(pa, 0) GR_SB();
+    // (one packed-fragment register quad: the next tile's is requested behind the MFMAs that read this one's)
+    GRF_U2_LOAD(f1, 2) GRF_PK_LOAD(pa, 1) GR_SB(); GRF_U2_MFMA(f0, 1) GRF_PK_MFMA(pa, 1) GR_SB(); GRF_STORE(0) GR_SB();
+    GRF_U2_LOAD(f0, 3) GRF_PK_LOAD(pa, 2) GR_SB(); GRF_U2_MFMA(f1, 2) GRF_PK_MFMA(pa, 2) GR_SB(); GRF_STORE(1) GR_SB();
+    GRF_U2_LOAD(f1, 4) GRF_PK_LOAD(pa, 3) GR_SB(); GRF_U2_MFMA(f0, 3) GRF_PK_MFMA(pa, 3) GR_SB(); GRF_STORE(2) GR_SB();
+    GRF_U2_LOAD(f0, 5) GRF_PK_LOAD(pa, 4) GR_SB(); GRF_U2_MFMA(f1, 4) GRF_PK_MFMA(pa, 4) GR_SB(); GRF_STORE(3) GR_SB();
+    GRF_U2_LOAD(f1, 6) GRF_PK_LOAD(pa, 5) GR_SB(); GRF_U2_MFMA(f0, 5) GRF_PK_MFMA(pa, 5) GR_SB(); GRF_STORE(4) GR_SB();
+    GRF_PK_LOAD(pa, 6) GR_SB();                    GRF_U2_MFMA(f1, 6) GRF_PK_MFMA(pa, 6) GR_SB(); GRF_STORE(5) GR_SB();
+    GRF_STORE(6)
+#undef GRF_U2_LOAD
+#undef GRF_U2_MFMA
+#undef GRF_U1_LOAD
+#undef GRF_U1_MFMA
+#undef GRF_PK_LOAD
+#undef GRF_PK_MFMA
+#undef GRF_STORE
 }
 #undef GR_LD
 
@@ -1036,6 +1142,10 @@ __device__ __forceinline__ void gr_layer(unsigned long long (&tacc)[6], char* bx
                                          float* __restrict__ hout, float& vmax, int wave, int lane, const float* s_u,
                                          const uint2* __restrict__ enc_idx, const float4* __restrict__ enc_tab, int (&tile_trips)[2]) {
     constexpr int NT = 2;
+    // (opaque per layer: what is computed from the lane id -- LDS and global addresses of the fragment reads and DMA pieces, shuffle
+    // indices -- is otherwise hoisted out of the tile loop, forty values that live across the whole kernel, spill, and are reloaded inside
+    // the MLP steps behind an s_waitcnt vmcnt(0) that also waits for the chunk DMA in flight)
+    asm volatile("" : "+v"(lane));
     const int j = lane & 15, g = lane >> 4;
     constexpr bool last = LAST;  // compile-time: the first four layers carry none of the last layer's code (and registers)
     // last layer with the readout folded through its second linear layer: h_5 . w = hid . (W2^T w) + b2 . w, so only the hidden tiles
@@ -1146,6 +1256,10 @@ __device__ __forceinline__ void gr_layer(unsigned long long (&tacc)[6], char* bx
         for (int k = 0; k < 12; k++) aq[nt][k] = (float2_t){0.0f, 0.0f};
     }
     const int tboth = min(trips[0], trips[1]);
+#ifdef GR_PROF_WALK  // development: tacc[5] = the three walk loops alone, tacc[4] = self term + operand split (instead of DMA wait / step barriers)
+    unsigned long long tw0 = 0;
+    if constexpr (PROF) tw0 = wall_clock64();
+#endif
 #pragma unroll 1
     for (int t = 0; t < tboth; t++) {
         float4_t x0[6], w0[6], x1[6], w1[6];
@@ -1184,6 +1298,9 @@ __device__ __forceinline__ void gr_layer(unsigned long long (&tacc)[6], char* bx
 #undef GR_READ
 #undef GR_NEXT
 #undef GR_FOLD
+#ifdef GR_PROF_WALK
+    if constexpr (PROF) { const unsigned long long t = wall_clock64(); tacc[5] += t - tw0; tw0 = t; }
+#endif
 #pragma unroll
     for (int nt = 0; nt < NT; nt++) {
 #pragma unroll
@@ -1252,17 +1369,33 @@ __device__ __forceinline__ void gr_layer(unsigned long long (&tacc)[6], char* bx
         }
     }
     uint4_t in_hi[NT][3], in_lo[NT][3], in_tb[NT];
+    {   // + (1 + eps) h[v], eps == 0; rows beyond the tile contribute zeros.  All fourteen reads of the wave's own rows are requested
+        // before the first add: left to itself hipcc re-uses ONE register quad and serialises them -- ds_read_b128, s_waitcnt
+        // lgkmcnt(0), two adds, fourteen times per layer (the walk's read registers are dead here: there is room for all of them)
+        float4_t sx[NT][6];
+        float sxt[NT];
 #pragma unroll
-    for (int nt = 0; nt < NT; nt++) {  // + (1 + eps) h[v], eps == 0; rows beyond the tile contribute zeros
-        if (row[nt] < cur.rows) {
-            const float* hr = s_h + row[nt] * GS_D + 4 * g;
+        for (int nt = 0; nt < NT; nt++) {
+            const int rr = row[nt] < cur.rows ? row[nt] : 0;
+            const float* hr = s_h + rr * GS_D + 4 * g;
 #pragma unroll
-            for (int q = 0; q < 6; q++) {
-                const float4 x = *reinterpret_cast<const float4*>(hr + 16 * q);
-                bq[nt][4 * q + 0] += x.x; bq[nt][4 * q + 1] += x.y; bq[nt][4 * q + 2] += x.z; bq[nt][4 * q + 3] += x.w;
-            }
-            bq[nt][24] += s_h[row[nt] * GS_D + 96 + g];
+            for (int q = 0; q < 6; q++) sx[nt][q] = *reinterpret_cast<const float4_t*>(hr + 16 * q);
+            sxt[nt] = s_h[rr * GS_D + 96 + g];
         }
+        GR_SB();
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++) {
+            if (row[nt] < cur.rows) {
+#pragma unroll
+                for (int q = 0; q < 6; q++) {
+                    bq[nt][4 * q + 0] += sx[nt][q].x; bq[nt][4 * q + 1] += sx[nt][q].y; bq[nt][4 * q + 2] += sx[nt][q].z; bq[nt][4 * q + 3] += sx[nt][q].w;
+                }
+                bq[nt][24] += sxt[nt];
+            }
+        }
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT; nt++) {
 #pragma unroll
         for (int ks = 0; ks < 3; ks++) {
             GS_SPLIT2(bq[nt][8 * ks + 0], bq[nt][8 * ks + 1], in_hi[nt][ks].x, in_lo[nt][ks].x);
@@ -1284,6 +1417,9 @@ __device__ __forceinline__ void gr_layer(unsigned long long (&tacc)[6], char* bx
             in_tb[nt] = g == 0 ? (uint4_t){h01, h23, l01, l23} : (g == 1 ? (uint4_t){h01, h23, 0u, 0u} : (uint4_t){0u, 0u, 0u, 0u});
         }
     }
+#ifdef GR_PROF_WALK
+    if constexpr (PROF) { asm volatile("" :: "v"(in_hi[0][0].x), "v"(in_lo[1][2].w), "v"(in_tb[1].x)); const unsigned long long t = wall_clock64(); tacc[4] += t - tw0; }
+#endif
     if constexpr (PROF) { const unsigned long long t = wall_clock64(); tacc[0] += t - tp; tp = t; }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of chunk 0
     __syncthreads();  // chunk 0 resident; every wave is done with the table (bx), with the tile's rows and with its CSR slice
@@ -1324,13 +1460,13 @@ __device__ __forceinline__ void gr_layer(unsigned long long (&tacc)[6], char* bx
                 unsigned long long tw = 0;
                 if constexpr (PROF) tw = wall_clock64();
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                if constexpr (PROF) { const unsigned long long t = wall_clock64(); tacc[5] += t - tw; tw = t; }
+                if constexpr (PROF) { const unsigned long long t = wall_clock64(); tacc[GR_TACC_DMA] += t - tw; tw = t; }
                 if constexpr (ENC) {
                     if (has_next) gre_finish(s_h, enc_v, nxt, c, wave, lane);
                 }
                 if (c + 1 < GS_STEPS - 1) {
                     __syncthreads();
-                    if constexpr (PROF) { const unsigned long long t = wall_clock64(); tacc[4] += t - tw; }
+                    if constexpr (PROF) { const unsigned long long t = wall_clock64(); tacc[GR_TACC_BAR] += t - tw; }
                 }
             }
         }
@@ -1345,51 +1481,44 @@ __device__ __forceinline__ void gr_layer(unsigned long long (&tacc)[6], char* bx
 #pragma unroll
     for (int nt = 0; nt < NT; nt++) { h_hi[nt] = (uint4_t){0, 0, 0, 0}; h_lo[nt] = (uint4_t){0, 0, 0, 0}; }
 #pragma unroll 1
-    for (int c = 0; c < GS_STEPS; c += 2) {
+    for (int c = 0; c < GR_STEPS - 1; c += 2) {
         // even step: compute from by while chunk c+1 streams into bx
         grc_issue_chunk(wchunks + (size_t)(c + 1) * GRC_CHUNK_STRIDE, bx, wave, lane);
         if (last && has_next) gr_issue_rows(h0, reinterpret_cast<char*>(s_h), nxt, c, wave, lane);
         if (c == 0) gr_step<0, false, GR_DEFER>(by, lane, g, in_hi, in_lo, in_tb, h_hi, h_lo, acc2, vmax, pend, nullptr, nullptr, wave);
-        else if (c == 6) gr_step<2, GR_DEFER, GR_DEFER>(by, lane, g, in_hi, in_lo, in_tb, h_hi, h_lo, acc2, vmax, pend, nullptr, nullptr, wave);
         else gr_step<1, GR_DEFER, GR_DEFER>(by, lane, g, in_hi, in_lo, in_tb, h_hi, h_lo, acc2, vmax, pend, nullptr, nullptr, wave);
         unsigned long long tw = 0;
         if constexpr (PROF) tw = wall_clock64();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of chunk c+1 (and of the next tile) have landed
-        if constexpr (PROF) { const unsigned long long t = wall_clock64(); tacc[5] += t - tw; tw = t; }
+        if constexpr (PROF) { const unsigned long long t = wall_clock64(); tacc[GR_TACC_DMA] += t - tw; tw = t; }
         __syncthreads();                                  // everyone's landed; everyone is done with by
-        if constexpr (PROF) { const unsigned long long t = wall_clock64(); tacc[4] += t - tw; }
-        // odd step: compute from bx while chunk c+2 (after step 7: the next layer's table) streams into by
-        if (c + 2 < GS_STEPS) grc_issue_chunk(wchunks + (size_t)(c + 2) * GRC_CHUNK_STRIDE, by, wave, lane);
-        else gr_issue_ecomb(ecomb_all + (size_t)ln * EDGE_COMBOS * GS_D, by, wave, lane);
+        if constexpr (PROF) { const unsigned long long t = wall_clock64(); tacc[GR_TACC_BAR] += t - tw; }
+        // odd step: compute from bx while chunk c+2 streams into by
+        grc_issue_chunk(wchunks + (size_t)(c + 2) * GRC_CHUNK_STRIDE, by, wave, lane);
         if (last && has_next) gr_issue_rows(h0, reinterpret_cast<char*>(s_h), nxt, c + 1, wave, lane);
-        if (c == 6) gr_step<3, GR_DEFER, false>(bx, lane, g, in_hi, in_lo, in_tb, h_hi, h_lo, acc2, vmax, pend, nullptr, nullptr, wave);
+        if (c + 1 == GR_STEPS - 2) gr_step<1, GR_DEFER, false>(bx, lane, g, in_hi, in_lo, in_tb, h_hi, h_lo, acc2, vmax, pend, nullptr, nullptr, wave);
         else gr_step<1, GR_DEFER, GR_DEFER>(bx, lane, g, in_hi, in_lo, in_tb, h_hi, h_lo, acc2, vmax, pend, nullptr, nullptr, wave);
-        if (c + 2 < GS_STEPS) {
-            if constexpr (PROF) tw = wall_clock64();
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if constexpr (PROF) { const unsigned long long t = wall_clock64(); tacc[5] += t - tw; tw = t; }
-            __syncthreads();
-            if constexpr (PROF) { const unsigned long long t = wall_clock64(); tacc[4] += t - tw; }
-        }
+        if constexpr (PROF) tw = wall_clock64();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if constexpr (PROF) { const unsigned long long t = wall_clock64(); tacc[GR_TACC_DMA] += t - tw; tw = t; }
+        __syncthreads();
+        if constexpr (PROF) { const unsigned long long t = wall_clock64(); tacc[GR_TACC_BAR] += t - tw; }
     }
+    // the last step (chunk 6, in by): hidden tile 12, K-step 5 and the packed K-step 6; the next layer's table streams into bx, which
+    // nobody reads any more -- an odd number of steps, so the two buffers keep their roles from layer to layer.  In the layers that
+    // feed another one the finished rows go back into the tile from inside the step (gr_step_final).
+    gr_issue_ecomb(ecomb_all + (size_t)ln * EDGE_COMBOS * GS_D, bx, wave, lane);
+    if (last && has_next) {
+        gr_issue_rows(h0, reinterpret_cast<char*>(s_h), nxt, GR_STEPS - 1, wave, lane);
+        gr_issue_rows(h0, reinterpret_cast<char*>(s_h), nxt, GR_STEPS, wave, lane);
+    }
+    gr_step_final<!last>(by, lane, g, in_hi, in_lo, in_tb, h_hi, h_lo, acc2, vmax, oscale, s_h + row[0] * GS_D, s_h + row[1] * GS_D);
 
     }
     if constexpr (PROF) { const unsigned long long t = wall_clock64(); tacc[2] += t - tp; tp = t; }
     // ---- epilogue: h' back into the tile (in place: nobody reads the old rows any more), or the readout terms
     if (!last) {
-#pragma unroll
-        for (int nt = 0; nt < NT; nt++) {
-            float* rw = s_h + row[nt] * GS_D;
-#pragma unroll
-            for (int t2 = 0; t2 < GS_T2; t2++) {
-                const int col = 16 * t2 + 4 * g;
-                if (col < GS_D) {
-                    float4_t r = acc2[nt][t2] * oscale;
-                    r.x = gs_relu(r.x); r.y = gs_relu(r.y); r.z = gs_relu(r.z); r.w = gs_relu(r.w);
-                    *reinterpret_cast<float4*>(rw + col) = make_float4(r.x, r.y, r.z, r.w);
-                }
-            }
-        }
+        // (the rows went back into the tile from inside the last step)
     } else if (fold) {
 #pragma unroll
         for (int nt = 0; nt < NT; nt++) {  // 13 hidden tiles x 4 units per lane, then the node's 4 lanes: a fixed order per node
@@ -1472,28 +1601,16 @@ __global__ __launch_bounds__(GR_WAVES * 64, 2) void gin_resident_kernel(const fl
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     float vmax = 0.0f;
-    bool flip = false;
     int tile_trips[2] = {0, 0};
     while (true) {
         const int ntile = tile + gridDim.x;
         const bool has_next = ntile < n_tiles;
         const GrTile nxt = gr_load_tile(tile_row, tile_graph, ntile, n_tiles, tstride);  // used five layers from now
 #pragma unroll 1
-        for (int l = 0; l < 4; l++) {
-            if (!flip)
-                gr_layer<PROF, HUBS, false, FOLD, ENC>(tacc, s_a, s_b, s_h, s_desc, s_dot, cur, nxt, has_next, ntile, l, h0, desc, ecomb_all, wchunks_all, pool_w, hout, vmax, wave, lane, nullptr, enc_idx, enc_tab, tile_trips);
-            else
-                gr_layer<PROF, HUBS, false, FOLD, ENC>(tacc, s_b, s_a, s_h, s_desc, s_dot, cur, nxt, has_next, ntile, l, h0, desc, ecomb_all, wchunks_all, pool_w, hout, vmax, wave, lane, nullptr, enc_idx, enc_tab, tile_trips);
-            flip = !flip;
-        }
-        {
-            const float* su = fold_head ? s_u : nullptr;
-            if (!flip)
-                gr_layer<PROF, HUBS, true, FOLD, ENC>(tacc, s_a, s_b, s_h, s_desc, s_dot, cur, nxt, has_next, ntile, 4, h0, desc, ecomb_all, wchunks_all, pool_w, hout, vmax, wave, lane, su, enc_idx, enc_tab, tile_trips);
-            else
-                gr_layer<PROF, HUBS, true, FOLD, ENC>(tacc, s_b, s_a, s_h, s_desc, s_dot, cur, nxt, has_next, ntile, 4, h0, desc, ecomb_all, wchunks_all, pool_w, hout, vmax, wave, lane, su, enc_idx, enc_tab, tile_trips);
-            if (!fold_head) flip = !flip;  // the folded last layer leaves the next table in its own table buffer
-        }
+        for (int l = 0; l < 4; l++)
+            gr_layer<PROF, HUBS, false, FOLD, ENC>(tacc, s_a, s_b, s_h, s_desc, s_dot, cur, nxt, has_next, ntile, l, h0, desc, ecomb_all, wchunks_all, pool_w, hout, vmax, wave, lane, nullptr, enc_idx, enc_tab, tile_trips);
+        // (every layer runs an odd number of MLP steps -- seven -- so the table buffer s_a and the first chunk's buffer s_b keep their roles)
+        gr_layer<PROF, HUBS, true, FOLD, ENC>(tacc, s_a, s_b, s_h, s_desc, s_dot, cur, nxt, has_next, ntile, 4, h0, desc, ecomb_all, wchunks_all, pool_w, hout, vmax, wave, lane, fold_head ? s_u : nullptr, enc_idx, enc_tab, tile_trips);
         // readout (GIN/src/finalize.cc:36-113): out[g] = mean_v(h5[v] . w) + b, node order; the terms stay valid until the next
         // tile's last layer rewrites them, so no barrier is needed before the next tile starts
         {
@@ -2176,7 +2293,10 @@ void gin_resident_head_fold(const float* w1_last, const float* w2_last, const fl
     out[208] = (float)c;
 }
 
-void gin_resident_pack_layer(const float* w1, const float* b1, const float* w2, const float* b2, uint8_t* out) {
+// merged = true (the resident kernel's stream): chunk 6 also carries the packed K-step of hidden units 192..199 -- output tiles 0..5 in
+// the W1 slot of hidden tile 13 (pure padding: 200 hidden units are 12.5 tiles), output tile 6 (rows 96..99) as 16 lanes x 16 B behind
+// the K tails -- and chunk 7 is empty: seven MLP steps (gr_step_final).  merged = false: the eight-chunk form gin_pp_pack_layer re-cuts.
+void gin_resident_pack_layer(const float* w1, const float* b1, const float* w2, const float* b2, uint8_t* out, bool merged) {
     std::memset(out, 0, gin_resident_layer_bytes());
     const float s1 = pow2_scale(w1, (size_t)GS_H * GS_D);
     const float s2 = pow2_scale(w2, (size_t)GS_D * GS_H);
@@ -2190,6 +2310,7 @@ void gin_resident_pack_layer(const float* w1, const float* b1, const float* w2, 
         if (s < GS_STEPS - 1) {
             for (int tl = 0; tl < 2; tl++) {
                 const int t = 2 * s + tl;
+                if (merged && t == 13) continue;  // hidden tile 13 does not exist (zeros): its slots in chunk 6 carry the packed K-step
                 for (int lane = 0; lane < 64; lane++) {
                     const int i = lane & 15, gk = lane >> 4;
                     const int o = 16 * t + i;
@@ -2231,6 +2352,12 @@ void gin_resident_pack_layer(const float* w1, const float* b1, const float* w2, 
                     const int i = lane & 15, gk = lane >> 4;
                     const int d = 16 * t2 + i;
                     uint8_t* fp = ck + GRC_W2_OFF + (size_t)t2 * 1024 + lane * 16;
+                    if (merged) {  // into chunk 6 (one chunk back)
+                        uint8_t* c6 = out + (size_t)6 * GRC_CHUNK_STRIDE;
+                        if (t2 < 6) fp = c6 + GRC_PK_OFF + (size_t)t2 * 1024 + lane * 16;
+                        else if (i < 4) fp = c6 + GRC_PK6_OFF + ((gk << 2) | i) * 16;
+                        else continue;  // rows 100..111 of the last output tile: zeros, not stored
+                    }
                     const int k0 = 192 + 4 * (gk & 1);
                     for (int e = 0; e < 4; e++) {
                         const float v = w2s(d, k0 + e);
@@ -2320,6 +2447,18 @@ void launch_gin_resident(const float* h0, float* hout, const int* row_ptr, const
             double kmin = 1e300, kmax = 0.0;  // workgroup lifetimes (wave 0's): how long the launch waits for its last workgroup
             for (size_t i = 0; i < cnt; i += 7 * GR_WAVES) { const double k = (double)hbuf[i + 6]; kmin = k < kmin ? k : kmin; kmax = k > kmax ? k : kmax; }
             fprintf(stderr, " | workgroup lifetime min %.0f max %.0f\n", kmin / 100.0, kmax / 100.0);
+            double mw[GR_WAVES] = {0}, bw[GR_WAVES] = {0}, ew[GR_WAVES] = {0};  // MLP without its barriers, the MLP's step barriers, epilogue + barrier
+            for (size_t i = 0; i < cnt; i += 7) {
+                const int wi = (int)((i / 7) % GR_WAVES);
+                mw[wi] += (double)hbuf[i + 2] - (double)hbuf[i + 4]; bw[wi] += (double)hbuf[i + 4]; ew[wi] += (double)hbuf[i + 3];
+            }
+            fprintf(stderr, "[gin_resident prof] by wave index, us: mlp compute");
+            for (int wi = 0; wi < GR_WAVES; wi++) fprintf(stderr, " %.0f", mw[wi] / grid / 100.0);
+            fprintf(stderr, " | mlp step barriers");
+            for (int wi = 0; wi < GR_WAVES; wi++) fprintf(stderr, " %.0f", bw[wi] / grid / 100.0);
+            fprintf(stderr, " | epilogue+barrier");
+            for (int wi = 0; wi < GR_WAVES; wi++) fprintf(stderr, " %.0f", ew[wi] / grid / 100.0);
+            fprintf(stderr, "\n");
         }
     }
 }

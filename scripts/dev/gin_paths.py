@@ -2,6 +2,9 @@
 usage: gin_paths.py [graphs] [prof]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import flowgnn_amd._lib as _L
+if os.environ.get("FLOWGNN_LIB"):  # a variant build (scripts/dev/variant.sh)
+    _L.LIB_PATH = os.path.abspath(os.environ["FLOWGNN_LIB"])
 from flowgnn_amd import Engine, graphpack as gp, weights
 g = int(sys.argv[1]) if len(sys.argv) > 1 else 1 << 18
 prof = "prof" in sys.argv[2:]
