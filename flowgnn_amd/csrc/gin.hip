@@ -751,15 +751,12 @@ public:
     // computes h_0 itself -- no CSR, no h_0 rows and no separate encoder / index-build launches in HBM.  Needs the folded
     // single-task readout (the loader rides on the folded last layer's steps); gin_tile_build = 0 restores the three-kernel front end.
     bool one_pass(const DeviceBatch& db) const {
-        // measured (2^18 molhiv graphs): the tile build costs what index build + tile prep cost (0.27 ms) and the encoder
-        // inside the last layer's steps costs the resident kernel 0.57 ms (VALU issue at two waves per SIMD) where the separate,
-        // store-bound encoder launch costs 0.51 -- so on large batches the one-pass form does not pay (9.61 vs 9.47 ms per step);
-        // on dataset-sized batches it does (two launches instead of four: 0.229 vs 0.246 ms at 4 113 graphs).  -1 = choose by size.
-        // By the JOB's node count (6 144 tiles of 256 rows at molhiv's 97 % fill), not by this engine's own tile count: a job cut over a
-        // group of engines computes on the kernels one engine would have chosen for all of it -- the two front ends associate the
-        // nine-term encoder sum differently (last-bit differences), and results must not depend on the device count.  An explicit
-        // gin_pingpong keeps the three-kernel front end (the ping-pong kernel has no encoder in its loader).
-        const bool want = tile_build_ < 0 ? (db.job_n <= 1523712 && !pingpong_) : tile_build_ != 0;  // (measured: ahead up to ~50 k molhiv graphs, level at 65 k, behind at 262 k)
+        // Measured: the tile build costs what index build + tile prep cost (0.27 ms at 2^18 molhiv graphs) and the
+        // encoder inside the folded last layer's steps costs the resident kernel 0.32 ms (0.57 ms before the kernel lost its scratch
+        // reloads, which made this form the slower one on large batches in round 3) where the separate, store-bound encoder launch costs
+        // 0.51: ahead at every size now -- 8.49 vs 8.73 ms per step at 2^18 graphs, 1.23 vs 1.24 at 32 768, 0.206 vs 0.222 at 4 113.
+        // -1 = default = on; an explicit gin_pingpong keeps the three-kernel front end (the ping-pong kernel has no encoder in its loader).
+        const bool want = tile_build_ < 0 ? !pingpong_ : tile_build_ != 0;
         return want && use_resident(db) && !qmode_ && !keep_h_ && num_tasks_ == 1 && fold_readout_ && head_fold_ && db.b.edge_attr != nullptr;
     }
     bool needs_csr(const DeviceBatch& db) const override { return !one_pass(db); }

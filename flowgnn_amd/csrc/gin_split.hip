@@ -483,9 +483,20 @@ constexpr int GRC_CHUNK_STRIDE = 28672;  // 28 pieces of 1 KiB in global memory 
 #ifndef GR_DEALERS
 #define GR_DEALERS 4
 #endif
+// which dealer (0 .. DEAL - 1) a wave is, or -1: waves GR_DEAL_BASE .. GR_DEAL_BASE + DEAL - 1 deal (all eight when DEAL == 8)
+#ifndef GR_DEAL_BASE
+#define GR_DEAL_BASE 0
+#endif
+template <int DEAL>
+__device__ __forceinline__ int gr_dealer(int wave) {
+    if (DEAL >= GR_WAVES) return wave;
+    const int d = wave - GR_DEAL_BASE;
+    return (d >= 0 && d < DEAL) ? d : -1;
+}
 template <int DEAL = GR_DEALERS>
 __device__ __forceinline__ void grc_issue_chunk(const uint8_t* __restrict__ gchunk, char* lds_buf, int wave, int lane) {
-    if (wave >= DEAL) return;
+    wave = gr_dealer<DEAL>(wave);
+    if (wave < 0) return;
     const uint32_t lb = lds_addr_of(lds_buf);
 #pragma unroll
     for (int p = 0; p < (28 + DEAL - 1) / DEAL; p++) {
@@ -497,7 +508,8 @@ __device__ __forceinline__ void grc_issue_chunk(const uint8_t* __restrict__ gchu
 // first-layer part of a chunk only (W1 fragments, K-tail, b1: 13 440 B = 13 pieces + 128 B): all the folded last layer reads
 template <int DEAL = GR_DEALERS>
 __device__ __forceinline__ void grc_issue_chunk_w1(const uint8_t* __restrict__ gchunk, char* lds_buf, int wave, int lane) {
-    if (wave >= DEAL) return;
+    wave = gr_dealer<DEAL>(wave);
+    if (wave < 0) return;
     const uint32_t lb = lds_addr_of(lds_buf);
 #pragma unroll
     for (int p = 0; p < (14 + DEAL - 1) / DEAL; p++) {
@@ -781,7 +793,8 @@ __device__ __forceinline__ void gr_step_final(const char* wb, int lane, int g, c
 struct GrTile { int t0, rows, g0, g1; };
 
 __device__ __forceinline__ void gr_issue_ecomb(const float* __restrict__ ecomb, char* lds_buf, int wave, int lane) {
-    if (wave >= GR_DEALERS) return;
+    wave = gr_dealer<GR_DEALERS>(wave);
+    if (wave < 0) return;
 #pragma unroll
     for (int r = 0; r < (24 + GR_DEALERS - 1) / GR_DEALERS; r++) {
         const int piece = wave + GR_DEALERS * r;
@@ -791,7 +804,8 @@ __device__ __forceinline__ void gr_issue_ecomb(const float* __restrict__ ecomb, 
 // pieces [13 part, 13 part + 13) of the tile's rows (<= 100 pieces of 1 KiB; a piece may run past the tile's last row: the
 // rows array has 4 KiB of slack and the surplus lands in unused rows of the buffer)
 __device__ __forceinline__ void gr_issue_rows(const float* __restrict__ h0, char* s_rows, const GrTile& t, int part, int wave, int lane) {
-    if (wave >= GR_DEALERS) return;
+    wave = gr_dealer<GR_DEALERS>(wave);
+    if (wave < 0) return;
     const int np = (t.rows * (GS_D * 4) + 1023) >> 10;
 #pragma unroll
     for (int r = 0; r < (13 + GR_DEALERS - 1) / GR_DEALERS; r++) {

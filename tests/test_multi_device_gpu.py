@@ -199,39 +199,88 @@ def test_group_compute_pipelines_ranges_and_matches_the_single_engine(oracle):
 
 
 def test_kernel_choice_follows_the_job_not_the_shard():
-    """A job of > 1.52 M nodes takes GIN's three-kernel front end on one engine; each half of it alone would take the one-pass
-    front end, whose encoder sum associates differently (last bits).  The group hands the JOB's totals to its members
-    (flowgnn_set_job_totals), so two engines compute the same bits as one -- and so do the ranges of flowgnn_group_compute and a
-    caller that shards by hand."""
+    """Choices the library makes by batch statistics are made from the JOB's totals (flowgnn_set_job_totals; groups and the ranges of
+    flowgnn_group_compute hand them down), so a job runs on the same kernels at any device count.  DGN chooses its aggregation by
+    density (matrix pipe for E >= 8 N): a job of 900 kNN-dense graphs followed by 300 sparse ones is dense as a whole, and
+    its sparse shard must still take the matrix-pipe kernel -- alone, it takes the in-edge walk.  (The two agree to fp32 rounding; the
+    point is that the CHOICE does not depend on the cut.)  GIN has no size-dependent choice left (the one-pass front end is the
+    default at every size): a 66 000-graph job is bit-identical on one engine, on two, and through flowgnn_group_compute."""
     from flowgnn_amd.dist import shard_ranges
-    b, w = gp.synth_molhiv_batch(66000, seed=77), weights.synth_gin_weights(seed=7)
-    assert b.total_nodes > 1523712 and b.total_nodes // 2 < 1523712
+    dense = gp.synth_hep10k_batch(900, seed=5, k=16)
+    sparse = gp.synth_hep10k_batch(300, seed=6, k=3)
+    job = gp.concat_batches([dense, sparse])
+    assert job.total_edges >= 8 * job.total_nodes and sparse.total_edges < 8 * sparse.total_nodes
+    w = weights.SYNTH["DGN"](seed=7)
+
+    def kernels_of(batch, totals):
+        e = Engine("DGN", device=0)
+        try:
+            e.set_weights(w)
+            if totals:
+                e.set_job_totals(*totals)
+            e.profile_enable(True)
+            out = e.forward(batch)
+            return out, set(e.profile_read())
+        finally:
+            e.close()
+
+    want, whole = kernels_of(job, None)
+    assert "dgn_rowinfo" in whole  # the matrix-pipe path's in-edge pass (dgn_rowinfo_kernel)
+    alone, k_alone = kernels_of(sparse, None)
+    assert "dgn_rowinfo" not in k_alone  # its own job: sparse, the in-edge walk
+    shard, k_shard = kernels_of(sparse, (job.total_nodes, job.total_edges))
+    assert "dgn_rowinfo" in k_shard
+    np.testing.assert_allclose(shard, want[900:], rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(alone, want[900:], rtol=2e-4, atol=2e-4)
+    g = EngineGroup("DGN", [0, 0])
+    try:
+        g.set_weights(w)
+        for i in range(2):
+            g.lib.flowgnn_profile_enable(g_member(g, i), 1)
+        got = g.forward(job)
+        np.testing.assert_allclose(got, want, rtol=2e-5, atol=2e-5)
+        for i in range(2):
+            assert "dgn_rowinfo" in g_profile_names(g, i)
+    finally:
+        g.close()
+    b, wg = gp.synth_molhiv_batch(66000, seed=77), weights.synth_gin_weights(seed=7)
     e = Engine("GIN", device=0)
     try:
-        e.set_weights(w)
+        e.set_weights(wg)
         e.profile_enable(True)
         want = e.forward(b)
-        assert "gin_tile_build" not in e.profile_read() and "atom_encoder" in e.profile_read()
-        # by hand: one engine, the job's halves one after the other, declared as shards of the job
-        e.set_job_totals(b.total_nodes, b.total_edges)
-        parts = [e.forward(b.slice(a, c)) for a, c in shard_ranges(b, 2)]
-        assert np.array_equal(np.concatenate(parts), want)
-        assert "gin_tile_build" not in e.profile_read()
-        # undeclared, a half is its own job and takes the one-pass front end: same values to fp32 rounding
-        e.set_job_totals(-1, -1)
-        a, c = shard_ranges(b, 2)[0]
-        alone = e.forward(b.slice(a, c))
         assert "gin_tile_build" in e.profile_read()
-        np.testing.assert_allclose(alone, want[a:c], rtol=1e-5, atol=1e-5)
     finally:
         e.close()
     g = EngineGroup("GIN", [0, 0])
     try:
-        g.set_weights(w)
+        g.set_weights(wg)
         assert np.array_equal(g.forward(b), want)
         assert np.array_equal(g.compute(b, 3), want)
     finally:
         g.close()
+
+
+def g_member(group, i):
+    import ctypes as C
+    group.lib.flowgnn_group_engine.restype = C.c_void_p
+    group.lib.flowgnn_group_engine.argtypes = [C.c_void_p, C.c_int]
+    group.lib.flowgnn_profile_enable.argtypes = [C.c_void_p, C.c_int]
+    return C.c_void_p(group.lib.flowgnn_group_engine(group._h, i))
+
+
+def g_profile_names(group, i):
+    """Kernel names member i of a group has launched since profiling was switched on for it (per-engine call on a group member)."""
+    import ctypes as C
+    lib = group.lib
+    h = g_member(group, i)
+    n = C.c_int(32)
+    names = (C.c_char_p * 32)()
+    ms = (C.c_double * 32)()
+    cnt = (C.c_longlong * 32)()
+    lib.flowgnn_profile_read.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_char_p), C.POINTER(C.c_double), C.POINTER(C.c_longlong)]
+    assert lib.flowgnn_profile_read(h, C.byref(n), names, ms, cnt) == 0
+    return {names[k].decode() for k in range(n.value) if cnt[k] > 0}
 
 
 def test_group_state_after_compute_and_error_text():
