@@ -535,6 +535,9 @@ __device__ __forceinline__ void grc_issue_chunk_w1(const uint8_t* __restrict__ g
 #ifndef GR_FLIP
 #define GR_FLIP 0
 #endif
+#ifndef GR_PRIO_QUARTERS
+#define GR_PRIO_QUARTERS 3  // waves 4-7 hold the priority for this many quarters of the trips that walk both column tiles (1: +0.7 %, 2: level, 3: -0.3 %, 4: +0.8 % of the launch)
+#endif
 #ifdef GR_PROF_WALK
 #define GR_TACC_DMA 3  /* folded into "epilogue" (unused in this development build's report) */
 #define GR_TACC_BAR 3
@@ -1278,7 +1281,7 @@ __device__ __forceinline__ void gr_layer(unsigned long long (&tacc)[6], char* bx
     for (int t = 0; t < tboth; t++) {
         float4_t x0[6], w0[6], x1[6], w1[6];
         float xt0, wt0, xt1, wt1;
-        if (GR_PRIO_HALF && wave >= 4 && t == (tboth >> 1)) __builtin_amdgcn_s_setprio(0);
+        if (GR_PRIO_HALF && wave >= 4 && t == ((tboth * GR_PRIO_QUARTERS) >> 2)) __builtin_amdgcn_s_setprio(0);
         GR_READ(0, x0, w0, xt0, wt0)
         GR_READ(1, x1, w1, xt1, wt1)
         GR_NEXT(0)
