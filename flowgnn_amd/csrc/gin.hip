@@ -767,7 +767,7 @@ public:
         if (qmode_) return ginq_forward(qw_, db, prof, s);
         if (one_pass(db)) {
             if (int rc = perm_.reserve((size_t)db.gtiles.n_tiles * (GIN_RESIDENT_DESC_BYTES / 4))) return rc;
-            if (int rc = enc_idx_.reserve((size_t)n * 2)) return rc;
+            if (int rc = enc_idx_.reserve((size_t)n)) return rc;
             GinTileBuild tb{db.b, enc_idx_.p, d_enc_tab_, db.csr.err};
             {
                 ProfScope p(prof, "gin_tile_build", s);
@@ -967,7 +967,7 @@ private:
     int num_tasks_ = 1;   // NUM_TASK (GIN/src/dcl.h:25) as a run-time dimension
     GinQWeights qw_;
     GrowBufI perm_;  // graph-resident path: per-tile descriptors (gin_tile_prep_kernel / gin_tile_build_kernel)
-    GrowBufI enc_idx_;  // one-pass path: four table-row numbers per node (8 B), written by gin_tile_build_kernel
+    GrowBufI enc_idx_;  // one-pass path: three table-row numbers per node in one word, written by gin_tile_build_kernel
     float* d_enc_tab_ = nullptr;  // ... and the pre-combined encoder table they index
     bool h0_in_hbm_ = false;      // db.h[0] holds h_0 of the resident batch (false after a one-pass run)
     int pingpong_waves_ = 8;

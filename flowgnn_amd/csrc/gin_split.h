@@ -58,7 +58,7 @@ void launch_gin_pp(const float* h0, const int* row_ptr, const int* src, const ui
 // (8 B per node) and the pre-combined encoder table (gin_resident_pack_enc_table); err = the engine's validation flag
 struct GinTileBuild {
     BatchView batch;
-    void* enc_idx;         // device, [n_tot] x 8 B, written by gin_tile_build_kernel
+    void* enc_idx;         // device, [n_tot] x 4 B, written by gin_tile_build_kernel
     const float* enc_tab;  // device, gin_resident_enc_table_floats() floats
     int* err;
 };

@@ -560,10 +560,15 @@ __device__ __forceinline__ void grc_issue_chunk_w1(const uint8_t* __restrict__ g
 // PEND_OUT: the step's LAST hidden tile is left un-finished in `pend` (its accumulators); PEND_IN: the previous step did that, and this
 // step finishes it AFTER requesting its own first fragments -- the ReLU + split VALU work then covers the LDS round trip every step
 // otherwise starts with (both waves of a SIMD sit behind the step barrier waiting ~200 clocks for their first fragment).
-template <int KIND, bool PEND_IN = false, bool PEND_OUT = false>
+struct GrNoHook { __device__ __forceinline__ void operator()() const {} };
+// HOOK: work of the caller's run in the MIDDLE of the step -- between its two hidden tiles (KIND 4), behind the first unit of its only one
+// (KIND 5) -- where the SIMD's two waves arrive at different times: one wave's VALU / memory instructions then issue beside its partner's
+// MFMAs.  At the step's ends, where both waves stand at the barrier together, the same instructions stop the matrix pipe.
+template <int KIND, bool PEND_IN = false, bool PEND_OUT = false, class HOOK = GrNoHook>
 __device__ __forceinline__ void gr_step(const char* wb, int lane, int g, const uint4_t (&in_hi)[2][3], const uint4_t (&in_lo)[2][3],
                                         const uint4_t (&in_tb)[2], uint4_t (&hb_hi)[2], uint4_t (&hb_lo)[2], float4_t (&acc2)[2][GS_T2],
-                                        float& vmax, float4_t (&pend)[2], const float* u_step = nullptr, float* dot = nullptr, int wave = 0) {
+                                        float& vmax, float4_t (&pend)[2], const float* u_step = nullptr, float* dot = nullptr, int wave = 0,
+                                        HOOK hook = HOOK()) {
     constexpr bool DO2 = KIND == 1 || KIND == 2, DO1 = KIND != 3, DOT = KIND >= 4;
     // GR_FLIP: the static priority of waves 4-7 changes hands in the middle of the step's unit chain (and back at its end)
 #define GR_PRIO_FLIP(TO_OLD) if (GR_FLIP) { if ((wave >= 4) != (TO_OLD)) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
@@ -664,6 +669,7 @@ __device__ __forceinline__ void gr_step(const char* wb, int lane, int g, const u
             if constexpr (!DO2) { GR_PRIO_FLIP(true) }
             GR_FINISH(0)
             GR_BIAS(1)
+            if constexpr (DOT) { GR_SB(); hook(); GR_SB(); }
             acc1[1] = acc1[0];
             GR_U1_LOAD(f0, 1, 1) GR_SB(); GR_U1_MFMA1(f1, 0) GR_SB();
             GR_U1_LOAD(f1, 1, 2) GR_SB(); GR_U1_MFMA1(f0, 1) GR_SB();
@@ -673,6 +679,7 @@ __device__ __forceinline__ void gr_step(const char* wb, int lane, int g, const u
             if constexpr (PEND_OUT) { pend[0] = acc1[0]; pend[1] = acc1[1]; }
             else { GR_FINISH(1) }
         } else if constexpr (DOT) {
+            GR_SB(); hook(); GR_SB();  // (KIND 5: one hidden tile; behind its MFMAs, in front of its ReLU + dot)
             GR_FINISH(0)
         } else {
             // step 6: lanes g = 0 / 1 hold hidden units 192..195 / 196..199 (hi in hb_hi.xy, lo in hb_lo.xy); the packed operand of
@@ -974,13 +981,16 @@ __global__ __launch_bounds__(256) void gin_tile_prep_kernel(const int* __restric
 //     into (source row, destination row, edge code) and counting-sorted by destination in LDS; inside a row they are rank-sorted by
 //     (source row, input index) -- unique keys, so the order is the CSR's (graph_build.hip) whatever order the LDS atomics landed in;
 //   * the descriptor is written in gin_tile_prep_kernel's format (edge words, row offsets, column owner table);
-//   * every node's nine features are validated and turned into four row numbers of the pre-combined encoder table (below), 8 B per
+//   * every node's nine features are validated and turned into three row numbers of the pre-combined encoder table (below), 4 B per
 //     node: what the resident kernel's tile loader reads instead of a 400 B row of h_0.
-// Pre-combined encoder table (GinModel::set_weights; rows of 100 floats; GRB_* = first row of each part):
-//   T01[f0][f1] = E0[f0] + E1[f1]   E2[f2]   T34[f3][f4] = E3[f3] + E4[f4]   T5678[f5][f6][f7][f8] = ((E5 + E6) + E7) + E8
-//   h_0 = ((T01 + E2) + T34) + T5678: the reference's nine-term sum (load_inputs.cc:207-214) re-associated -- it differs from the
+// Pre-combined encoder table (GinModel::set_weights; rows of 100 floats; GRB_* = first row of each part; 2 060 rows = 824 KB, L2-resident):
+//   T01[f0][f1] = E0[f0] + E1[f1]   T234[f2][f3][f4] = E2[f2] + (E3[f3] + E4[f4])   T5678[f5][f6][f7][f8] = ((E5 + E6) + E7) + E8
+//   h_0 = (T01 + T234) + T5678: the reference's nine-term sum (load_inputs.cc:207-214) re-associated -- it differs from the
 //   sequential order by fp32 rounding only (<= 4 ulp of a sum of magnitude ~1; the stated parity tolerance is 1e-4).
-constexpr int GRB_T01 = 0, GRB_E2 = 476, GRB_T34 = 488, GRB_T5678 = 608, GRB_ROWS = 752;
+//   Three rows per node, not four or nine: what limits the loader is the bytes it pulls through the CU's vector-memory return path
+//   (64 B per clock: four 400-B rows per node were 59 KB per MLP step of the folded layer, beside the step's own weight DMA).
+// A node's row numbers, local to their parts, in one word: T01 row | T234 row << 9 | T5678 row << 20.
+constexpr int GRB_T01 = 0, GRB_T234 = 476, GRB_T5678 = 1916, GRB_ROWS = 2060;
 
 __device__ __forceinline__ int gr_wave_inclusive_scan(int x, int lane) {
 #pragma unroll
@@ -992,7 +1002,7 @@ __device__ __forceinline__ int gr_wave_inclusive_scan(int x, int lane) {
 }
 
 __global__ __launch_bounds__(256) void gin_tile_build_kernel(BatchView b, const int* __restrict__ tile_row, const int* __restrict__ tile_graph,
-                                                             uint8_t* __restrict__ desc, uint2* __restrict__ enc_idx, int n_tiles, int order,
+                                                             uint8_t* __restrict__ desc, uint32_t* __restrict__ enc_idx, int n_tiles, int order,
                                                              int* __restrict__ err) {
     constexpr int EPT = GR_EDGES / 256;  // edges per thread
     __shared__ int s_eoff[GR_ROWS + 1], s_noff[GR_ROWS + 1];  // edge / row offsets of the tile's graphs, relative to the tile
@@ -1095,54 +1105,55 @@ __global__ __launch_bounds__(256) void gin_tile_build_kernel(BatchView b, const 
                 f[k] = 0;
             }
         }
-        const unsigned i0 = GRB_T01 + f[0] * 4 + f[1], i1 = GRB_E2 + f[2], i2 = GRB_T34 + f[3] * 10 + f[4],
-                       i3 = GRB_T5678 + ((f[5] * 6 + f[6]) * 2 + f[7]) * 2 + f[8];
-        enc_idx[(size_t)t0 + r] = make_uint2(i0 | (i1 << 16), i2 | (i3 << 16));
+        const unsigned i0 = f[0] * 4 + f[1], i1 = (f[2] * 12 + f[3]) * 10 + f[4], i2 = ((f[5] * 6 + f[6]) * 2 + f[7]) * 2 + f[8];
+        enc_idx[(size_t)t0 + r] = i0 | (i1 << 9) | (i2 << 20);
     }
     gr_write_column_order(d, r, rows, r < rows ? (deg < ne ? deg : ne) : 0, order);
 }
 
 // ---- the tile loader's atom encoder (resident kernel, ENC form): rows of h_0 computed straight into the tile's LDS rows
 // A tile's rows are encoded in GRE_PARTS parts of GRE_PART rows, one part per MLP step of the folded last layer (the rows of the
-// CURRENT tile are dead by then).  In a part, wave w owns row slots 5w .. 5w + 4 as three groups of two rows: lanes 0..31 the even
-// slot, lanes 32..63 the odd one, lane & 31 = float4 chunk (25 of 32 lanes active: one contiguous 400 B row per half wave).
+// CURRENT tile are dead by then).  A part is 37 rows = 925 float4 -- contiguous in the tile's LDS rows -- dealt to the eight waves
+// 128 at a time: lane L of wave w takes float4 n = 128 w + 64 k + L (k = 0, 1) of the part, i.e. chunk n mod 25 of row n / 25: every
+// lane of every load carries data (one 400-B row per 25 lanes), and a wave's stores are 1 KiB of consecutive LDS.
 constexpr int GRE_PART = 37, GRE_PARTS = 7;  // 7 x 37 = 259 >= GR_ROWS
-struct GrEncIdx { uint2 k0, k1, k2; };
-struct GrEncVal { float4 a0, a1, a2, a3, b0, b1, b2, b3, c0, c1, c2, c3; };
+struct GrEncIdx { uint32_t k0, k1; };
+struct GrEncVal { float4 a0, a1, a2, b0, b1, b2; };
 
-__device__ __forceinline__ int gre_row(int part, int wave, int lane, int k, int rows) {
-    const int q = 2 * k + (lane >> 5), slot = 5 * wave + q;
-    const int row = GRE_PART * part + slot;
-    return (q < 5 && slot < GRE_PART && row < rows && (lane & 31) < 25) ? row : -1;
+// float4 index of (wave, lane, k) inside its part, or -1 beyond the part / the tile
+__device__ __forceinline__ int gre_slot(int part, int wave, int lane, int k, int rows) {
+    const int n = 128 * wave + 64 * k + lane;
+    const int r = (n * 1311) >> 15;  // n / 25 for n < 1 024
+    return (n < GRE_PART * 25 && GRE_PART * part + r < rows) ? n : -1;
 }
-__device__ __forceinline__ GrEncIdx gre_issue_idx(const uint2* __restrict__ enc_idx, const GrTile& t, int part, int wave, int lane) {
+__device__ __forceinline__ GrEncIdx gre_issue_idx(const uint32_t* __restrict__ enc_idx, const GrTile& t, int part, int wave, int lane) {
     GrEncIdx x;
-    const int r0 = gre_row(part, wave, lane, 0, t.rows), r1 = gre_row(part, wave, lane, 1, t.rows), r2 = gre_row(part, wave, lane, 2, t.rows);
-    x.k0 = r0 >= 0 ? enc_idx[(size_t)t.t0 + r0] : make_uint2(0u, 0u);
-    x.k1 = r1 >= 0 ? enc_idx[(size_t)t.t0 + r1] : make_uint2(0u, 0u);
-    x.k2 = r2 >= 0 ? enc_idx[(size_t)t.t0 + r2] : make_uint2(0u, 0u);
+    const int n0 = gre_slot(part, wave, lane, 0, t.rows), n1 = gre_slot(part, wave, lane, 1, t.rows);
+    // (unconditional, from a clamped row: ALWAYS two loads -- the s_waitcnt vmcnt(..) of gr_layer count on that -- and any row's
+    // numbers are valid table rows; gre_finish writes only the real rows)
+    x.k0 = enc_idx[(size_t)t.t0 + (n0 >= 0 ? GRE_PART * part + ((n0 * 1311) >> 15) : 0)];
+    x.k1 = enc_idx[(size_t)t.t0 + (n1 >= 0 ? GRE_PART * part + ((n1 * 1311) >> 15) : 0)];
     return x;
 }
-#define GRE_LD4(V0, V1, V2, V3, K)                                          \
-    V0 = tab[((K).x & 0xFFFFu) * 25u + c]; V1 = tab[((K).x >> 16) * 25u + c]; \
-    V2 = tab[((K).y & 0xFFFFu) * 25u + c]; V3 = tab[((K).y >> 16) * 25u + c];
-__device__ __forceinline__ GrEncVal gre_issue_tab(const float4* __restrict__ tab, const GrEncIdx& x, int lane) {
+#define GRE_LD3(V0, V1, V2, K, C)                                                  \
+    V0 = tab[((unsigned)GRB_T01 + ((K) & 511u)) * 25u + (C)];                      \
+    V1 = tab[((unsigned)GRB_T234 + (((K) >> 9) & 2047u)) * 25u + (C)];             \
+    V2 = tab[((unsigned)GRB_T5678 + ((K) >> 20)) * 25u + (C)];
+__device__ __forceinline__ GrEncVal gre_issue_tab(const float4* __restrict__ tab, const GrEncIdx& x, int wave, int lane) {
     GrEncVal v;
-    const unsigned c = (unsigned)(lane & 31) < 25u ? (unsigned)(lane & 31) : 0u;  // idle lanes re-read chunk 0 of row 0 (in range)
-    GRE_LD4(v.a0, v.a1, v.a2, v.a3, x.k0)
-    GRE_LD4(v.b0, v.b1, v.b2, v.b3, x.k1)
-    GRE_LD4(v.c0, v.c1, v.c2, v.c3, x.k2)
+    const unsigned n0 = 128u * (unsigned)wave + (unsigned)lane, n1 = n0 + 64u;  // (< 1 024: chunk n - 25 (n / 25) is in range for every lane)
+    const unsigned c0 = n0 - 25u * ((n0 * 1311u) >> 15), c1 = n1 - 25u * ((n1 * 1311u) >> 15);
+    GRE_LD3(v.a0, v.a1, v.a2, x.k0, c0)
+    GRE_LD3(v.b0, v.b1, v.b2, x.k1, c1)
     return v;
 }
-#undef GRE_LD4
-#define GRE_SUM(V0, V1, V2, V3) \
-    make_float4(((V0.x + V1.x) + V2.x) + V3.x, ((V0.y + V1.y) + V2.y) + V3.y, ((V0.z + V1.z) + V2.z) + V3.z, ((V0.w + V1.w) + V2.w) + V3.w)
+#undef GRE_LD3
+#define GRE_SUM(V0, V1, V2) make_float4((V0.x + V1.x) + V2.x, (V0.y + V1.y) + V2.y, (V0.z + V1.z) + V2.z, (V0.w + V1.w) + V2.w)
 __device__ __forceinline__ void gre_finish(float* s_h, const GrEncVal& v, const GrTile& t, int part, int wave, int lane) {
-    const int r0 = gre_row(part, wave, lane, 0, t.rows), r1 = gre_row(part, wave, lane, 1, t.rows), r2 = gre_row(part, wave, lane, 2, t.rows);
-    const int c = lane & 31;
-    if (r0 >= 0) *reinterpret_cast<float4*>(s_h + r0 * GS_D + 4 * c) = GRE_SUM(v.a0, v.a1, v.a2, v.a3);
-    if (r1 >= 0) *reinterpret_cast<float4*>(s_h + r1 * GS_D + 4 * c) = GRE_SUM(v.b0, v.b1, v.b2, v.b3);
-    if (r2 >= 0) *reinterpret_cast<float4*>(s_h + r2 * GS_D + 4 * c) = GRE_SUM(v.c0, v.c1, v.c2, v.c3);
+    const int n0 = gre_slot(part, wave, lane, 0, t.rows), n1 = gre_slot(part, wave, lane, 1, t.rows);
+    float4* dst = reinterpret_cast<float4*>(s_h) + GRE_PART * 25 * part;
+    if (n0 >= 0) dst[n0] = GRE_SUM(v.a0, v.a1, v.a2);
+    if (n1 >= 0) dst[n1] = GRE_SUM(v.b0, v.b1, v.b2);
 }
 #undef GRE_SUM
 
@@ -1157,7 +1168,7 @@ __device__ __forceinline__ void gr_layer(unsigned long long (&tacc)[6], char* bx
                                          const float* __restrict__ h0, const uint8_t* __restrict__ desc, const float* __restrict__ ecomb_all,
                                          const uint8_t* __restrict__ wchunks_all, const float* __restrict__ pool_w,
                                          float* __restrict__ hout, float& vmax, int wave, int lane, const float* s_u,
-                                         const uint2* __restrict__ enc_idx, const float4* __restrict__ enc_tab, int (&tile_trips)[2]) {
+                                         const uint32_t* __restrict__ enc_idx, const float4* __restrict__ enc_tab, int (&tile_trips)[2]) {
     constexpr int NT = 2;
     // (opaque per layer: what is computed from the lane id -- LDS and global addresses of the fragment reads and DMA pieces, shuffle
     // indices -- is otherwise hoisted out of the tile loop, forty values that live across the whole kernel, spill, and are reloaded inside
@@ -1184,6 +1195,7 @@ __device__ __forceinline__ void gr_layer(unsigned long long (&tacc)[6], char* bx
     // ENC (the tile loader computes h_0 itself): the next tile's rows are encoded during this layer's MLP steps, a part per step;
     // the table-row numbers of part 0 are requested here, a whole gather ahead of their use
     GrEncIdx enc_ix{};
+    GrEncVal enc_v{};
     if constexpr (ENC && LAST) {
         if (has_next) enc_ix = gre_issue_idx(enc_idx, nxt, 0, wave, lane);
     }
@@ -1438,7 +1450,19 @@ __device__ __forceinline__ void gr_layer(unsigned long long (&tacc)[6], char* bx
     if constexpr (PROF) { asm volatile("" :: "v"(in_hi[0][0].x), "v"(in_lo[1][2].w), "v"(in_tb[1].x)); const unsigned long long t = wall_clock64(); tacc[4] += t - tw0; }
 #endif
     if constexpr (PROF) { const unsigned long long t = wall_clock64(); tacc[0] += t - tp; tp = t; }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of chunk 0
+    if constexpr (ENC && LAST) {
+        // part 0's table rows (its row numbers were requested at the top of the layer) and part 1's row numbers: eight loads that stay
+        // in flight across the barrier -- step 0's hook sums part 0 (the chunk-0 DMA pieces are older: vmcnt retires in order)
+        if (has_next) {
+            enc_v = gre_issue_tab(enc_tab, enc_ix, wave, lane);
+            enc_ix = gre_issue_idx(enc_idx, nxt, 1, wave, lane);
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of chunk 0
+    }
     __syncthreads();  // chunk 0 resident; every wave is done with the table (bx), with the tile's rows and with its CSR slice
     if (GR_PRIO_BY_PHASE && wave >= 4) __builtin_amdgcn_s_setprio(1);
     if constexpr (PROF) { const unsigned long long t = wall_clock64(); tacc[1] += t - tp; tp = t; }
@@ -1461,26 +1485,37 @@ __device__ __forceinline__ void gr_layer(unsigned long long (&tacc)[6], char* bx
             char* nb = (c & 1) ? by : bx;
             if (c + 1 < GS_STEPS - 1) grc_issue_chunk_w1(wchunks + (size_t)(c + 1) * GRC_CHUNK_STRIDE, nb, wave, lane);
             else gr_issue_ecomb(ecomb_all + (size_t)ln * EDGE_COMBOS * GS_D, nb, wave, lane);
-            GrEncVal enc_v{};
-            if constexpr (ENC) {
-                if (has_next) {  // part c of the next tile: its table rows are requested now and summed at the end of the step
-                    enc_v = gre_issue_tab(enc_tab, enc_ix, lane);
-                    if (c + 1 < GRE_PARTS) enc_ix = gre_issue_idx(enc_idx, nxt, c + 1, wave, lane);
+            if constexpr (!ENC) {
+                if (has_next) {
+                    gr_issue_rows(h0, reinterpret_cast<char*>(s_h), nxt, c, wave, lane);
+                    if (c == GS_STEPS - 2) gr_issue_rows(h0, reinterpret_cast<char*>(s_h), nxt, c + 1, wave, lane);
                 }
-            } else if (has_next) {
-                gr_issue_rows(h0, reinterpret_cast<char*>(s_h), nxt, c, wave, lane);
-                if (c == GS_STEPS - 2) gr_issue_rows(h0, reinterpret_cast<char*>(s_h), nxt, c + 1, wave, lane);
             }
-            if (c < GS_STEPS - 2) gr_step<4>(cb, lane, g, in_hi, in_lo, in_tb, h_hi, h_lo, acc2, vmax, pend, s_u + 32 * c, dot, wave);
-            else gr_step<5>(cb, lane, g, in_hi, in_lo, in_tb, h_hi, h_lo, acc2, vmax, pend, s_u + 32 * c, dot, wave);
-            if (ENC || c + 1 < GS_STEPS - 1) {
+            // ENC (the tile loader computes h_0 itself), in the MIDDLE of the step (gr_step, HOOK): part c of the next tile -- its table rows
+            // were requested a step ago -- is summed into the tile's rows, then part c + 1's table rows and part c + 2's row numbers are
+            // requested.  At the step's ends, where this used to sit, the ~120 VALU / memory instructions per wave issued with both waves
+            // of every SIMD off the matrix pipe: 0.3 ms per launch.
+            auto enc_hook = [&]() {
+                if constexpr (ENC) {
+                    if (has_next) {
+                        gre_finish(s_h, enc_v, nxt, c, wave, lane);
+                        if (c + 1 < GRE_PARTS) enc_v = gre_issue_tab(enc_tab, enc_ix, wave, lane);
+                        if (c + 2 < GRE_PARTS) enc_ix = gre_issue_idx(enc_idx, nxt, c + 2, wave, lane);
+                    }
+                }
+            };
+            if (c < GS_STEPS - 2) gr_step<4>(cb, lane, g, in_hi, in_lo, in_tb, h_hi, h_lo, acc2, vmax, pend, s_u + 32 * c, dot, wave, enc_hook);
+            else gr_step<5>(cb, lane, g, in_hi, in_lo, in_tb, h_hi, h_lo, acc2, vmax, pend, s_u + 32 * c, dot, wave, enc_hook);
+            if (c + 1 < GS_STEPS - 1) {
                 unsigned long long tw = 0;
                 if constexpr (PROF) tw = wall_clock64();
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                // this wave's DMA pieces have landed.  (ENC) the eight loads the hook requested BEHIND them -- six of table rows, two of row
+                // numbers; always exactly that many (gre_issue_*) -- stay in flight: vmcnt retires in order, so "all but the newest
+                // eight" covers every DMA piece.  Waiting for them here would put an L2 / HBM round trip at the end of every step.
+                if (ENC && has_next && c + 2 < GRE_PARTS) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                else if (ENC && has_next && c + 1 < GRE_PARTS) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 if constexpr (PROF) { const unsigned long long t = wall_clock64(); tacc[GR_TACC_DMA] += t - tw; tw = t; }
-                if constexpr (ENC) {
-                    if (has_next) gre_finish(s_h, enc_v, nxt, c, wave, lane);
-                }
                 if (c + 1 < GS_STEPS - 1) {
                     __syncthreads();
                     if constexpr (PROF) { const unsigned long long t = wall_clock64(); tacc[GR_TACC_BAR] += t - tw; }
@@ -1579,7 +1614,7 @@ __global__ __launch_bounds__(GR_WAVES * 64, 2) void gin_resident_kernel(const fl
                                                                        const uint8_t* __restrict__ desc,
                                                                        const int* __restrict__ node_off, float* __restrict__ out, int n_tiles,
                                                                        int* __restrict__ range_flag, unsigned long long* __restrict__ prof_out,
-                                                                       const float* __restrict__ head_u, const uint2* __restrict__ enc_idx,
+                                                                       const float* __restrict__ head_u, const uint32_t* __restrict__ enc_idx,
                                                                        const float4* __restrict__ enc_tab, int tstride) {
     static_assert(!ENC || FOLD, "the in-kernel encoder rides on the folded last layer's steps");
     __shared__ __attribute__((aligned(16))) char s_a[GRC_CHUNK_BYTES];
@@ -1608,7 +1643,7 @@ __global__ __launch_bounds__(GR_WAVES * 64, 2) void gin_resident_kernel(const fl
 #pragma unroll 1
         for (int part = 0; part < GRE_PARTS; part++) {
             const GrEncIdx ix = gre_issue_idx(enc_idx, cur, part, wave, lane);
-            const GrEncVal v = gre_issue_tab(enc_tab, ix, lane);
+            const GrEncVal v = gre_issue_tab(enc_tab, ix, wave, lane);
             gre_finish(s_h, v, cur, part, wave, lane);
         }
     } else {
@@ -2426,7 +2461,7 @@ void launch_gin_resident(const float* h0, float* hout, const int* row_ptr, const
         if (hipMalloc((void**)&d, cnt * 8) != hipSuccess) return;
         (void)hipMemsetAsync(d, 0, cnt * 8, s);
     }
-    const uint2* eidx = enc ? reinterpret_cast<const uint2*>(tb->enc_idx) : nullptr;
+    const uint32_t* eidx = enc ? reinterpret_cast<const uint32_t*>(tb->enc_idx) : nullptr;
     const float4* etab = enc ? reinterpret_cast<const float4*>(tb->enc_tab) : nullptr;
 #define GR_LAUNCH(P, H, F, E)                                                                                                        \
     gin_resident_kernel<P, H, F, E><<<grid, GR_WAVES * 64, 0, s>>>(h0, hout, ecomb_all, chunks_all, pool_w, pool_b, tile_row, tile_graph, \
@@ -2540,7 +2575,7 @@ void launch_gin_pp(const float* h0, const int* row_ptr, const int* src, const ui
 void launch_gin_tile_build(const GinTileBuild& tb, const int* tile_row, const int* tile_graph, uint8_t* tile_desc, int n_tiles, bool hubs,
                            int col_order, hipStream_t s) {
     if (n_tiles <= 0) return;
-    gin_tile_build_kernel<<<n_tiles, 256, 0, s>>>(tb.batch, tile_row, tile_graph, tile_desc, reinterpret_cast<uint2*>(tb.enc_idx), n_tiles,
+    gin_tile_build_kernel<<<n_tiles, 256, 0, s>>>(tb.batch, tile_row, tile_graph, tile_desc, reinterpret_cast<uint32_t*>(tb.enc_idx), n_tiles,
                                                   hubs ? 3 : col_order, tb.err);
 }
 
@@ -2554,10 +2589,12 @@ void gin_resident_pack_enc_table(const float* nemb /* [173][100] */, float* out)
         for (int f1 = 0; f1 < card[1]; f1++)
             for (int d = 0; d < GS_D; d++) { float s = 0.0f; s += E(0, f0, d); s += E(1, f1, d); out[(size_t)(GRB_T01 + f0 * 4 + f1) * GS_D + d] = s; }
     for (int f2 = 0; f2 < card[2]; f2++)
-        for (int d = 0; d < GS_D; d++) out[(size_t)(GRB_E2 + f2) * GS_D + d] = E(2, f2, d);
-    for (int f3 = 0; f3 < card[3]; f3++)
-        for (int f4 = 0; f4 < card[4]; f4++)
-            for (int d = 0; d < GS_D; d++) out[(size_t)(GRB_T34 + f3 * 10 + f4) * GS_D + d] = E(3, f3, d) + E(4, f4, d);
+        for (int f3 = 0; f3 < card[3]; f3++)
+            for (int f4 = 0; f4 < card[4]; f4++)
+                for (int d = 0; d < GS_D; d++) {
+                    const float t34 = E(3, f3, d) + E(4, f4, d);
+                    out[(size_t)(GRB_T234 + (f2 * 12 + f3) * 10 + f4) * GS_D + d] = E(2, f2, d) + t34;
+                }
     for (int f5 = 0; f5 < card[5]; f5++)
         for (int f6 = 0; f6 < card[6]; f6++)
             for (int f7 = 0; f7 < card[7]; f7++)
