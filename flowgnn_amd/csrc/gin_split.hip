@@ -854,6 +854,25 @@ constexpr int GR_HUB_DEG = 8;        // HUBS kernels: rows with more in-edges th
 // row's in-edges are summed in CSR order whoever owns it): results are identical for any permutation.  Rows beyond the tile's
 // last sort last.   slot = wave * 32 + nt * 16 + j  ->  row inside the tile (0..255)
 // Column owner table of a tile (desc + GR_DESC_PERM) from every row's in-degree; thread r = row r of a 256-thread workgroup.
+// column tile kt (0 = the longest rows) -> the wave that owns it and which of the wave's two it is.  Waves w and w + 4 share a SIMD
+// (and with it VALU / LDS issue): GR_SIMD_DEAL deals the sixteen tiles so that every SIMD gets the same share of long and short ones --
+// SIMD w: {w, 7 - w, 8 + w, 15 - w}, wave w the outer two, wave w + 4 the inner two; 0 = (kt, 15 - kt) per wave, which gives the
+// SIMD of waves 0 and 4 the tiles {0, 4, 11, 15} and a fifth more trips than the SIMD of waves 3 and 7.
+#ifndef GR_SIMD_DEAL
+#define GR_SIMD_DEAL 1
+#endif
+__device__ __forceinline__ void gr_tile_owner(int kt, int& wave, int& nt) {
+    if (GR_SIMD_DEAL) {
+        nt = kt >> 3;
+        if (kt < 4) wave = kt;
+        else if (kt < 8) wave = 11 - kt;   // 4..7 -> waves 7..4
+        else if (kt < 12) wave = kt - 4;   // 8..11 -> waves 4..7
+        else wave = 15 - kt;               // 12..15 -> waves 3..0
+    } else {
+        wave = kt < 8 ? kt : 15 - kt;
+        nt = kt < 8 ? 0 : 1;
+    }
+}
 __device__ __forceinline__ void gr_write_column_order(uint8_t* d, int r, int rows, int deg, int order) {
     constexpr int NKEY = 18;
     __shared__ int s_cnt[4][NKEY];
@@ -919,7 +938,7 @@ __device__ __forceinline__ void gr_write_column_order(uint8_t* d, int r, int row
                 p -= cap;
             }
         }
-        const int wave3 = kt < 8 ? kt : 15 - kt, nt3 = kt < 8 ? 0 : 1;
+        const int wave3 = kt < 8 ? kt : 15 - kt, nt3 = kt < 8 ? 0 : 1;  // (the hubs are dealt round-robin: every tile as long as every other; gr_tile_owner's deal measured +0.3 % here)
         d[GR_DESC_PERM + wave3 * 32 + nt3 * 16 + jj] = (uint8_t)r;
         return;
     }
@@ -937,7 +956,8 @@ __device__ __forceinline__ void gr_write_column_order(uint8_t* d, int r, int row
         }
     const int pos = below + mine;          // rank in (key, row) order, 0..255
     const int kt = pos >> 4, j = pos & 15;  // column tile kt (0 = longest rows), lane j
-    const int wave = kt < 8 ? kt : 15 - kt, nt = kt < 8 ? 0 : 1;
+    int wave, nt;
+    gr_tile_owner(kt, wave, nt);
     d[GR_DESC_PERM + wave * 32 + nt * 16 + j] = (uint8_t)r;
 }
 
