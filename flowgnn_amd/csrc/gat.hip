@@ -532,9 +532,8 @@ __global__ __launch_bounds__(GATR_WAVES * 64, 4) void gat_resident_kernel(const 
     __shared__ uint8_t s_perm[GATR_ROWS];
     __shared__ __attribute__((aligned(16))) int s_cnt[16], s_cur[16];
     constexpr int NT = GATR_WAVES * 64;
-    const int lane = threadIdx.x & 63;
+    int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int j = lane & 15, g = lane >> 4;
     for (int i = threadIdx.x; i < GAT_D * ND_FEATURE; i += NT) s_lin0[i] = reinterpret_cast<const float4*>(w.lin0)[i];
     if (threadIdx.x < 2 * GAT_D) s_att[threadIdx.x] = reinterpret_cast<const float4*>(threadIdx.x < GAT_D ? w.a_src : w.a_tgt)[threadIdx.x & (GAT_D - 1)];
     if (threadIdx.x < GAT_D) s_pw[threadIdx.x] = w.pool_w[threadIdx.x];
@@ -571,15 +570,14 @@ __global__ __launch_bounds__(GATR_WAVES * 64, 4) void gat_resident_kernel(const 
 #pragma unroll
         for (int k = 0; k < 2; k++) {
             const int i = threadIdx.x + NT * k;
-            if (i < fne) spre[k] = src[fe0 + i] - ft0;
-        }
-        if ((int)threadIdx.x <= frows) {
-            const int o = row_ptr[ft0 + threadIdx.x] - fe0;
-            rpre = o < 0 ? 0 : (o > fne ? fne : o);
-        }
+            if (i < fne) spre[k] = src[fe0 + i];  // RAW: (source - tile start, offset - first edge, clamps) are applied where the words are
+        }                                          // stored to LDS -- arithmetic on a value here puts its whole global round trip in front of it
+        if ((int)threadIdx.x <= frows) rpre = row_ptr[ft0 + threadIdx.x];
     };
     fetch_tile(t0, rows, e0, ne);
     while (true) {
+        asm volatile("" : "+v"(lane));  // (per tile: nothing computed from the lane id is hoisted out of the tile loop and spilled: -0.6 %)
+        const int j = lane & 15, g = lane >> 4;
         const int ntile = tile + gridDim.x;
         const bool has_next = ntile < n_tiles;
         int nt0 = 0, nrows = 0, ng0 = 0, ng1 = 0, ne0 = 0, nne = 0;
@@ -590,8 +588,11 @@ __global__ __launch_bounds__(GATR_WAVES * 64, 4) void gat_resident_kernel(const 
             if (threadIdx.x + NT * k < GATR_ROWS * ND_FEATURE) s_feat[threadIdx.x + NT * k] = fpre[k];
 #pragma unroll
         for (int k = 0; k < 2; k++)
-            if ((int)threadIdx.x + NT * k < ne) s_src[threadIdx.x + NT * k] = (uint8_t)(spre[k] & 255);
-        if ((int)threadIdx.x <= rows) s_rp[threadIdx.x] = (uint16_t)rpre;
+            if ((int)threadIdx.x + NT * k < ne) s_src[threadIdx.x + NT * k] = (uint8_t)((spre[k] - t0) & 255);
+        if ((int)threadIdx.x <= rows) {
+            const int o = rpre - e0;
+            s_rp[threadIdx.x] = (uint16_t)(o < 0 ? 0 : (o > ne ? ne : o));
+        }
         __syncthreads();
         int skey = 15;  // in-degree class of row threadIdx.x: 0 = longest (>= 14 in-edges) .. 14 = none, 15 = no such row
         if (threadIdx.x < GATR_ROWS) {
