@@ -501,7 +501,9 @@ __global__ __launch_bounds__(512, 2) void dgn_layer_mfma_kernel(const float* __r
         const int indeg = (STAGE_CSR && valid && !(ablate & 8)) ? (int)s_rp[r + 1] - e_base : 0;
         const float eig_v = s_eig[valid ? r : 0];
         const long long node = (long long)t0 + (valid ? r : 0);
-        const int odeg = out_deg[node];
+        int odeg;
+        if constexpr (INFO == 2) odeg = (int)cur_info.w;  // (a row past the tile's end carries row 0's record, as out_deg[node] read row 0's)
+        else odeg = out_deg[node];
         int2 gi = make_int2(0, 0);
         if constexpr (POOL) gi = ginfo[node];  // requested here, used in the epilogue
         // one pass over the row's in-edges: wsum, abssum (DGN/src/load_inputs.cc:105-110), this lane's slice of the adjacency row as a
@@ -549,7 +551,7 @@ __global__ __launch_bounds__(512, 2) void dgn_layer_mfma_kernel(const float* __r
                 if (valid) {
                     rowinfo[(size_t)node * 8 + g] = bits;
                     if (g == 0) *reinterpret_cast<uint4*>(rowinfo + (size_t)node * 8 + 4) =
-                        make_uint4(__builtin_bit_cast(uint32_t, wsum), __builtin_bit_cast(uint32_t, abssum), (uint32_t)ndup, 0u);
+                        make_uint4(__builtin_bit_cast(uint32_t, wsum), __builtin_bit_cast(uint32_t, abssum), (uint32_t)ndup, (uint32_t)odeg);
                 }
             }
         }
@@ -858,7 +860,9 @@ __global__ __launch_bounds__(256) void dgn_rowinfo_kernel(BatchView b, const int
             for (int sb = 0; sb < 4; sb++) wg |= ((s_adj[v][sb] >> (8 * gq)) & 0xFFu) << (8 * sb);
             ri[gq] = wg;
         }
-        *reinterpret_cast<uint4*>(ri + 4) = make_uint4(__builtin_bit_cast(uint32_t, wsum), __builtin_bit_cast(uint32_t, abssum), (uint32_t)nd, 0u);
+        // (the out-degree rides in the record's fourth word: the layers read it a tile ahead with the rest instead of loading out_deg[node]
+        // at the top of the tile, where its round trip stood in front of the row's 1 / deg)
+        *reinterpret_cast<uint4*>(ri + 4) = make_uint4(__builtin_bit_cast(uint32_t, wsum), __builtin_bit_cast(uint32_t, abssum), (uint32_t)nd, (uint32_t)s_odeg[v]);
         out_deg[t0 + v] = s_odeg[v];
         if (nd > 0) atomicOr(dup_flag, 1);
     }

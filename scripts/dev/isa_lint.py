@@ -49,3 +49,30 @@ for si in starts:
     print(f"{short}: vgpr {meta.get('next_free_vgpr')} lds {meta.get('group_segment_fixed_size')} scratch {meta.get('private_segment_fixed_size')} B | "
           f"scratch ops by (kind, loop depth) {dict(sorted(sc.items()))} | ds_read->wait0 {ser_lds} | gload->wait0 {ser_glb} | "
           f"barriers {sum(t.startswith('s_barrier') for _, t in ins)} mfma {sum('v_mfma' in t for _, t in ins)} instr {len(ins)}")
+
+# (second pass, with a kernel name given: global loads whose wait follows within three instructions, by loop depth)
+if want:
+    for si in starts:
+        name = lines[si].split(":")[0]
+        if want not in name:
+            continue
+        try:
+            end = next(i for i in range(si, len(lines)) if ".end_amdhsa_kernel" in lines[i])
+        except StopIteration:
+            continue
+        body = lines[si:end]
+        ins, depth = [], 0
+        for l in body:
+            m = re.search(r"Depth=(\d+)", l)
+            if l.startswith(".LBB"):
+                depth = int(m.group(1)) if m else 0
+            t = l.strip()
+            if l.startswith("\t") and t and not t.startswith((".", ";")):
+                ins.append((depth, t))
+        for n in range(len(ins) - 4):
+            d, a = ins[n]
+            if a.startswith(("global_load", "buffer_load")) and "lds" not in a:
+                for m in range(1, 4):
+                    if ins[n + m][1].startswith("s_waitcnt") and "vmcnt" in ins[n + m][1]:
+                        print(f"   depth {d}: {a[:48]} -> {ins[n + m][1]}")
+                        break
