@@ -553,8 +553,8 @@ __device__ __forceinline__ void grc_issue_chunk_w1(const uint8_t* __restrict__ g
 // 16-row weight tile and one K-step) feeding six MFMAs (w_hi x_hi, w_hi x_lo, w_lo x_hi for both column tiles) -- and the
 // fragments of unit k+1 are requested before the MFMAs of unit k issue (scheduling barriers pin that order): one LDS round trip
 // is always covered by ~120 cycles of matrix pipe, with 16 fragment registers in all.
-// KIND 0: step 0 (first layer's hidden tiles 0,1 only) | 1: steps 1..5 | 2: step 6 (K-step 5 + hidden tile 12, then the packed
-// operand of step 7 is built) | 3: step 7 (packed K-step).
+// KIND 0: step 0 (first layer's hidden tiles 0,1 only) | 1: steps 1..5 (K-step s - 1 of the second layer, then hidden tiles 2s, 2s + 1).
+// The layer's last step (hidden tile 12, K-step 5 and the packed K-step of hidden units 192..199) is gr_step_final.
 // KIND 4 / 5: the LAST layer with the readout folded through its second linear layer (head_u, below): hidden tiles only (two / one),
 // each ReLU'd tile is dotted with its slice of u instead of being split for a second layer that is never computed.
 // PEND_OUT: the step's LAST hidden tile is left un-finished in `pend` (its accumulators); PEND_IN: the previous step did that, and this
@@ -569,10 +569,11 @@ __device__ __forceinline__ void gr_step(const char* wb, int lane, int g, const u
                                         const uint4_t (&in_tb)[2], uint4_t (&hb_hi)[2], uint4_t (&hb_lo)[2], float4_t (&acc2)[2][GS_T2],
                                         float& vmax, float4_t (&pend)[2], const float* u_step = nullptr, float* dot = nullptr, int wave = 0,
                                         HOOK hook = HOOK()) {
-    constexpr bool DO2 = KIND == 1 || KIND == 2, DO1 = KIND != 3, DOT = KIND >= 4;
+    static_assert(KIND == 0 || KIND == 1 || KIND == 4 || KIND == 5, "step kinds");
+    constexpr bool DO2 = KIND == 1, DO1 = true, DOT = KIND >= 4;
     // GR_FLIP: the static priority of waves 4-7 changes hands in the middle of the step's unit chain (and back at its end)
 #define GR_PRIO_FLIP(TO_OLD) if (GR_FLIP) { if ((wave >= 4) != (TO_OLD)) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
-    constexpr int NTL = (KIND == 2 || KIND == 5) ? 1 : 2;
+    constexpr int NTL = KIND == 5 ? 1 : 2;
     uint4_t f0[2], f1[2];  // fragment double buffer: f0 = even units, f1 = odd units
 #define GR_U2_LOAD(F, T) F[0] = GR_LD(GRC_W2_OFF + (2 * (T)) * 1024); F[1] = GR_LD(GRC_W2_OFF + (2 * (T) + 1) * 1024);
 #define GR_U2_MFMA(F, T)                                          \
@@ -601,12 +602,6 @@ __device__ __forceinline__ void gr_step(const char* wb, int lane, int g, const u
 #define GR_TAIL_LOAD(F, TL) F[0] = *reinterpret_cast<const uint4_t*>(wb + GRC_TAIL_OFF + (TL) * 512 + (lane & 31) * 16);
 #define GR_BIAS(TL) acc1[0] = *reinterpret_cast<const float4_t*>(wb + GRC_B1_OFF + (TL) * 64 + g * 16);
     // ReLU, range watch, split of hidden tile TL into its half (.xy / .zw) of the next step's B operands
-#define GR_PACK_STEP7()                                                                                                   \
-    _Pragma("unroll") for (int nt = 0; nt < 2; nt++) {                                                                    \
-        const uint32_t ox = __shfl(hb_hi[nt].x, lane & 31, 64), oy = __shfl(hb_hi[nt].y, lane & 31, 64);                  \
-        const bool own = g < 2;                                                                                          \
-        hb_hi[nt] = own ? (uint4_t){hb_hi[nt].x, hb_hi[nt].y, hb_lo[nt].x, hb_lo[nt].y} : (uint4_t){ox, oy, 0u, 0u};      \
-    }
 #define GR_FINISH(TL) GR_FINISH_FROM(acc1, TL)
 #define GR_FINISH_FROM(SRC, TL)                                                                           \
     _Pragma("unroll") for (int nt = 0; nt < 2; nt++) {                                                    \
@@ -641,17 +636,6 @@ __device__ __forceinline__ void gr_step(const char* wb, int lane, int g, const u
         GR_SB();
         GR_PRIO_FLIP(true)
     }
-    if constexpr (KIND == 3) {  // packed K-step: one MFMA per output tile and column tile (hb_hi holds the packed operand)
-        uint4_t p[GS_T2];
-#pragma unroll
-        for (int t = 0; t < GS_T2; t++) p[t] = GR_LD(GRC_W2_OFF + t * 1024);
-        if constexpr (PEND_IN) { GR_SB(); GR_FINISH_FROM(pend, 0) GR_PACK_STEP7() GR_SB(); }  // hidden tile 12 of step 6, under the seven requests
-#pragma unroll
-        for (int t = 0; t < GS_T2; t++) {
-            acc2[0][t] = GS_MFMA16(p[t], hb_hi[0], acc2[0][t]);
-            acc2[1][t] = GS_MFMA16(p[t], hb_hi[1], acc2[1][t]);
-        }
-    }
     if constexpr (DO1) {  // first linear layer: hidden tiles 2s (, 2s+1) = b1 + W1 a, K = 96 as three K-steps + the packed tail
         if constexpr (!DO2) {
             GR_U1_LOAD(f1, 0, 0)
@@ -678,14 +662,10 @@ __device__ __forceinline__ void gr_step(const char* wb, int lane, int g, const u
             acc1[1] = GS_MFMA16(f0[0], in_tb[1], acc1[1]);
             if constexpr (PEND_OUT) { pend[0] = acc1[0]; pend[1] = acc1[1]; }
             else { GR_FINISH(1) }
-        } else if constexpr (DOT) {
+        } else {
+            static_assert(DOT, "a one-tile step is the folded layer's last (KIND 5)");
             GR_SB(); hook(); GR_SB();  // (KIND 5: one hidden tile; behind its MFMAs, in front of its ReLU + dot)
             GR_FINISH(0)
-        } else {
-            // step 6: lanes g = 0 / 1 hold hidden units 192..195 / 196..199 (hi in hb_hi.xy, lo in hb_lo.xy); the packed operand of
-            // step 7 is  g = 0, 1: [hi, lo] (own)   g = 2, 3: [hi of lane - 32, 0]
-            if constexpr (PEND_OUT) { pend[0] = acc1[0]; pend[1] = acc1[1]; }
-            else { GR_FINISH(0) GR_PACK_STEP7() }
         }
         asm volatile("" : "+v"(vmax));
     }
@@ -696,7 +676,6 @@ __device__ __forceinline__ void gr_step(const char* wb, int lane, int g, const u
 #undef GR_BIAS
 #undef GR_FINISH
 #undef GR_FINISH_FROM
-#undef GR_PACK_STEP7
 #undef GR_U2_LOAD
 #undef GR_U2_MFMA
 #undef GR_U1_LOAD
