@@ -269,6 +269,44 @@ constexpr int PNA_FT_EDGES = 4608;
 constexpr int PNA_FT_STRIDE = 84;
 constexpr int PNA_FT_WAVES = 16;
 
+// Per-tile descriptor (pna_tile_desc_kernel, once per batch pass: the four layers share it): the tile's CSR slice as the layer kernel
+// wants it in LDS -- [0, 4608) source rows inside the tile, one byte each; [4608, 5632) u16 row offsets into them (rows + 1 used) --
+// 5.5 pieces of 1 KiB that come by LDS-DMA with the tile's rows.  (Staged from the batch CSR by the layer kernel itself -- load,
+// subtract the tile's first row, store a byte -- hipcc waited for every word in turn: up to six serialized global round trips per tile
+// and layer behind the row DMA, and two dependent scalar loads for the slice's bounds at the top of every tile.)
+constexpr int PNA_DESC_RP = PNA_FT_EDGES;
+constexpr int PNA_DESC_BYTES = PNA_FT_EDGES + 1024;
+__global__ __launch_bounds__(256) void pna_tile_desc_kernel(const int* __restrict__ row_ptr, const int* __restrict__ src,
+                                                            const int* __restrict__ tile_row, uint8_t* __restrict__ desc, int n_tiles) {
+    const int tile = blockIdx.x;
+    if (tile >= n_tiles) return;
+    const int t0 = tile_row[tile];
+    int rows = tile_row[tile + 1] - t0;
+    if (rows > PNA_FT_ROWS) rows = PNA_FT_ROWS;
+    const int e0 = row_ptr[t0];
+    int ne = row_ptr[t0 + rows] - e0;
+    if (ne > PNA_FT_EDGES) ne = PNA_FT_EDGES;  // cannot happen for a validated batch (the host packed by edge count)
+    uint8_t* d = desc + (size_t)tile * PNA_DESC_BYTES;
+    for (int i = threadIdx.x * 4; i < PNA_FT_EDGES; i += 1024) {  // four source bytes per store
+        uint32_t w = 0;
+#pragma unroll
+        for (int b = 0; b < 4; b++)
+            if (i + b < ne) w |= (uint32_t)((src[e0 + i + b] - t0) & 255) << (8 * b);
+        *reinterpret_cast<uint32_t*>(d + i) = w;
+    }
+    uint16_t* rp = reinterpret_cast<uint16_t*>(d + PNA_DESC_RP);
+    for (int i = threadIdx.x; i < 512; i += 256) {
+        int o = i <= rows ? row_ptr[t0 + i] - e0 : ne;
+        rp[i] = (uint16_t)(o < 0 ? 0 : (o > ne ? ne : o));
+    }
+}
+// a tile's descriptor -> LDS: six pieces (the last one half), dealt to the waves that issue one row piece fewer
+__device__ __forceinline__ void pna_issue_desc(const uint8_t* __restrict__ desc, int tile, char* lds_buf, int wave, int lane) {
+    const int piece = PNA_FT_WAVES - 1 - wave;  // waves 15, 14, ..., 10
+    if (piece < 5 || (piece == 5 && lane < 32))
+        lds_dma16(desc + (size_t)tile * PNA_DESC_BYTES + piece * 1024, (uint32_t)lane * 16u, lds_addr_of(lds_buf) + piece * 1024);
+}
+
 __device__ __forceinline__ void pna_issue_chunk_asm(const uint8_t* __restrict__ gchunk, char* lds_buf, int wave, int lane) {
     const uint32_t lb = lds_addr_of(lds_buf);
 #pragma unroll
@@ -376,7 +414,7 @@ __device__ __forceinline__ void pna_gather_slice(const float* __restrict__ s_h, 
 }
 
 __global__ __launch_bounds__(PNA_FT_WAVES * 64, 4) void pna_layer_fused_kernel(const float* __restrict__ h, float* __restrict__ hout,
-                                                                  const int* __restrict__ row_ptr, const int* __restrict__ src,
+                                                                  const uint8_t* __restrict__ desc,
                                                                   const int* __restrict__ out_deg, const uint8_t* __restrict__ wpk,
                                                                   const float* __restrict__ bias, float avg_deg, float oscale,
                                                                   const int* __restrict__ tile_row, int n_tiles, int* __restrict__ range_flag,
@@ -386,8 +424,7 @@ __global__ __launch_bounds__(PNA_FT_WAVES * 64, 4) void pna_layer_fused_kernel(c
     __shared__ __attribute__((aligned(16))) char s_a[PNA_CHUNK];  // even K-steps
     __shared__ __attribute__((aligned(16))) char s_b[PNA_CHUNK];  // odd K-steps
     __shared__ __attribute__((aligned(16))) float s_h[PNA_FT_ROWS * PNA_FT_STRIDE];
-    __shared__ __attribute__((aligned(4))) uint8_t s_src[2][PNA_FT_EDGES];
-    __shared__ uint16_t s_rp[2][PNA_FT_ROWS + 4];
+    __shared__ __attribute__((aligned(16))) char s_desc[2][PNA_DESC_BYTES];  // the tile's CSR slice (pna_tile_desc_kernel), double buffered
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int j = lane & 15, g = lane >> 4;
@@ -401,35 +438,27 @@ __global__ __launch_bounds__(PNA_FT_WAVES * 64, 4) void pna_layer_fused_kernel(c
     // tile descriptor of the first tile; later ones are fetched one tile ahead
     int t0 = tile_row[tile], rows = tile_row[tile + 1] - t0;
     if (rows > PNA_FT_ROWS) rows = PNA_FT_ROWS;
-    int e0 = row_ptr[t0], ne = row_ptr[t0 + rows] - e0;
-    if (ne > PNA_FT_EDGES) ne = PNA_FT_EDGES;  // cannot happen for a validated batch (the host packed by edge count)
     int buf = 0;
-    for (int i = threadIdx.x; i < ne; i += PNA_FT_WAVES * 64) s_src[0][i] = (uint8_t)((src[e0 + i] - t0) & 255);
-    if ((int)threadIdx.x <= rows) {
-        int o = row_ptr[t0 + threadIdx.x] - e0;
-        s_rp[0][threadIdx.x] = (uint16_t)(o < 0 ? 0 : (o > ne ? ne : o));
-    }
+    pna_issue_desc(desc, tile, s_desc[0], wave, lane);
     pna_issue_rows(h, t0, rows, s_h, wave, lane);
     while (true) {
         const int ntile = tile + gridDim.x;
         const bool has_next = ntile < n_tiles;
-        int nt0 = 0, nrows = 0, ne0 = 0, nne = 0;
+        int nt0 = 0, nrows = 0;
         if (has_next) {
             nt0 = tile_row[ntile];
             nrows = tile_row[ntile + 1] - nt0;
             if (nrows > PNA_FT_ROWS) nrows = PNA_FT_ROWS;
-            ne0 = row_ptr[nt0];
-            nne = row_ptr[nt0 + nrows] - ne0;
-            if (nne > PNA_FT_EDGES) nne = PNA_FT_EDGES;
         }
         pna_issue_chunk_asm(wpk, s_a, wave, lane);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this tile's rows and CSR slice, chunk 0
         __syncthreads();
         const int r = wave * 16 + j;
         const bool valid = r < rows;
-        const uint8_t* csrc = s_src[buf];
-        const int e_base = valid ? (int)s_rp[buf][r] : 0;
-        int indeg = valid ? (int)s_rp[buf][r + 1] - e_base : 0;
+        const uint8_t* csrc = reinterpret_cast<const uint8_t*>(s_desc[buf]);
+        const uint16_t* crp = reinterpret_cast<const uint16_t*>(s_desc[buf] + PNA_DESC_RP);
+        const int e_base = valid ? (int)crp[r] : 0;
+        int indeg = valid ? (int)crp[r + 1] - e_base : 0;
         if (ablate & 1) indeg = 0;  // development aid (pna_ablate, -DFLOWGNN_DEV builds): timing without the gather
         uint32_t srcw[4];  // the first 16 in-edges, one byte each (re-walked by every K-step)
 #pragma unroll
@@ -470,13 +499,8 @@ __global__ __launch_bounds__(PNA_FT_WAVES * 64, 4) void pna_layer_fused_kernel(c
         for (int t = 0; t < PNA_OT; t++) hv[t] = *reinterpret_cast<const float4*>(s_h + (valid ? r : 0) * PNA_FT_STRIDE + 16 * t + 4 * g);
         __syncthreads();  // every wave has its residual rows (and is done gathering): s_h may be overwritten
         if (has_next) {
+            pna_issue_desc(desc, ntile, s_desc[buf ^ 1], wave, lane);  // ... and its CSR slice, into the other small buffer
             pna_issue_rows(h, nt0, nrows, s_h, wave, lane);
-            // ... and its CSR slice into the other small buffer (the loads return under the stores of this tile's rows)
-            for (int i = threadIdx.x; i < nne; i += PNA_FT_WAVES * 64) s_src[buf ^ 1][i] = (uint8_t)((src[ne0 + i] - nt0) & 255);
-            if ((int)threadIdx.x <= nrows) {
-                const int o = row_ptr[nt0 + threadIdx.x] - ne0;
-                s_rp[buf ^ 1][threadIdx.x] = (uint16_t)(o < 0 ? 0 : (o > nne ? nne : o));
-            }
         }
         if (valid) {
             const float logd = logf((float)(odeg + 1));
@@ -499,7 +523,7 @@ __global__ __launch_bounds__(PNA_FT_WAVES * 64, 4) void pna_layer_fused_kernel(c
             }
         }
         if (!has_next) break;
-        tile = ntile; t0 = nt0; rows = nrows; e0 = ne0; ne = nne;
+        tile = ntile; t0 = nt0; rows = nrows;
         buf ^= 1;
     }
     if (__any(!(vmax < 6.0e4f))) {
@@ -667,7 +691,12 @@ public:
             if (fused) {
                 ProfScope p(prof, "pna_layer_fused", s);
                 const int grid = db.gtiles.n_tiles < 256 ? db.gtiles.n_tiles : 256;  // persistent: one 16-wave workgroup per CU (151 KB of LDS)
-                pna_layer_fused_kernel<<<grid, PNA_FT_WAVES * 64, 0, s>>>(db.h[cur], db.h[cur ^ 1], db.csr.row_ptr, db.csr.src, db.csr.out_deg,
+                if (l == 0) {  // the tiles' CSR slices as the layer kernel stages them, once for the four layers
+                    if (int rc = desc_.reserve(((size_t)db.gtiles.n_tiles * PNA_DESC_BYTES + 3) / 4)) return rc;
+                    pna_tile_desc_kernel<<<db.gtiles.n_tiles, 256, 0, s>>>(db.csr.row_ptr, db.csr.src, db.gtiles.row_start,
+                                                                          reinterpret_cast<uint8_t*>(desc_.p), db.gtiles.n_tiles);
+                }
+                pna_layer_fused_kernel<<<grid, PNA_FT_WAVES * 64, 0, s>>>(db.h[cur], db.h[cur ^ 1], reinterpret_cast<const uint8_t*>(desc_.p), db.csr.out_deg,
                                                             d_stream_ + (size_t)l * PNA_SPLIT_LAYER_BYTES, d_cb_ + (size_t)l * PNA_D, avg_deg_,
                                                             oscale_[l], db.gtiles.row_start, db.gtiles.n_tiles, db.range_flag,
                                                             ablate_);
@@ -726,12 +755,14 @@ private:
         if (d_split_) { (void)hipFree(d_split_); d_split_ = nullptr; }
         if (d_stream_) { (void)hipFree(d_stream_); d_stream_ = nullptr; }
         tiles_.release();
+        desc_.release();
         q_.release();
     }
     bool ready_ = false;
     bool qmode_ = false;  // flowgnn_set_numeric_mode(FLOWGNN_NUMERIC_Q6_10)
     QPack q_;
     GrowBufI tiles_;  // graph-aligned tile starts of the resident batch (tile_bounds_kernel)
+    GrowBufI desc_;   // pna_tile_desc_kernel: 5.5 KiB per graph tile
     static constexpr int kTileNominal = 112, kTileSlack = 48;  // the model's defaults of the options tile_nominal / tile_slack
     int tile_nominal_ = kTileNominal, tile_slack_ = kTileSlack;
     // pna_mfma=32 keeps the dense update on the fp32 matrix pipe (pna_dense_kernel)
