@@ -1292,7 +1292,7 @@ __device__ __forceinline__ void gr_layer(unsigned long long (&tacc)[6], char* bx
     for (int t = 0; t < tboth; t++) {
         float4_t x0[6], w0[6], x1[6], w1[6];
         float xt0, wt0, xt1, wt1;
-        if (GR_PRIO_HALF && wave >= 4 && t == ((tboth * GR_PRIO_QUARTERS) >> 2)) __builtin_amdgcn_s_setprio(0);
+        if (GR_PRIO_HALF && wave >= 4 && t == ((tboth * (HUBS ? 4 : GR_PRIO_QUARTERS)) >> 2)) __builtin_amdgcn_s_setprio(0);  // (GIN-VN: through all of them, -0.2 %)
         GR_READ(0, x0, w0, xt0, wt0)
         GR_READ(1, x1, w1, xt1, wt1)
         GR_NEXT(0)
