@@ -38,6 +38,9 @@ def test_bad_arguments_are_rejected_without_a_gpu():
     assert lib.flowgnn_destroy(None) == 1
     assert lib.GIN_compute_graphs(-1, *([None] * 15)) == 1
     assert lib.GIN_compute_graphs(0, *([None] * 15)) == 0  # empty batch is a no-op
+    lib.flowgnn_set_job_totals.argtypes = [ctypes.c_void_p, ctypes.c_longlong, ctypes.c_longlong]
+    assert lib.flowgnn_set_job_totals(None, 10, 20) == 1
+    assert lib.flowgnn_group_run(None) == 1 and lib.flowgnn_group_get_results(None, None) == 1
 
 
 @pytest.mark.skipif(not os.path.exists(LIB), reason="libflowgnn_hip.so not built")
