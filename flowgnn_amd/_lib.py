@@ -67,6 +67,8 @@ def _declare(lib):
     lib.flowgnn_entry_set_option.argtypes = [C.c_int, C.c_char_p, C.c_double]
     lib.flowgnn_entry_set_pipeline.argtypes = [C.c_int]
     lib.flowgnn_shard_ranges.argtypes = [C.c_int, p_int, p_int, C.c_int, p_int]
+    lib.flowgnn_graph_tile_fill.argtypes = [eng, C.c_int, p_int, p_int, C.POINTER(C.c_double)]
+    lib.flowgnn_set_job_tile_fill.argtypes = [eng, C.c_double]
     lib.flowgnn_create_multi.argtypes = [C.c_int, C.c_int, p_int, C.POINTER(grp)]
     lib.flowgnn_group_destroy.argtypes = [grp]
     lib.flowgnn_group_size.argtypes = [grp]
@@ -93,7 +95,7 @@ def _declare(lib):
     lib.GAT_compute_graphs.argtypes = [C.c_int, p_int, p_int, p_int, p_float, p_int, p_int] + [p_float] * 6
     lib.GCN_compute_graphs.argtypes = [C.c_int, p_int, p_int, p_int, p_float, p_int, p_int, p_int] + [p_float] * 11
     for name in ("flowgnn_create", "flowgnn_destroy", "flowgnn_set_weights_gin", "flowgnn_set_weights", "flowgnn_load_weights_dir",
-                 "flowgnn_set_batch", "flowgnn_set_job_totals", "flowgnn_run", "flowgnn_sync", "flowgnn_get_results",
+                 "flowgnn_set_batch", "flowgnn_set_job_totals", "flowgnn_graph_tile_fill", "flowgnn_set_job_tile_fill", "flowgnn_run", "flowgnn_sync", "flowgnn_get_results",
                  "flowgnn_results_device", "flowgnn_set_results_buffer", "flowgnn_stream", "flowgnn_batch_info", "flowgnn_exact_reruns", "flowgnn_set_numeric_mode", "flowgnn_set_num_tasks", "flowgnn_num_tasks", "flowgnn_get_csr",
                  "flowgnn_get_h", "flowgnn_profile_enable", "flowgnn_profile_read",
                  "flowgnn_run_aggregation_only", "flowgnn_get_aggregate", "flowgnn_set_stream",

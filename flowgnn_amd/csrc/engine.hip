@@ -13,6 +13,10 @@
 #include <cctype>
 #include <mutex>
 #include <thread>
+#include <atomic>
+#include <limits>
+#include <condition_variable>
+#include <functional>
 #include <memory>
 
 namespace fg {
@@ -197,6 +201,7 @@ struct flowgnn_engine {
     bool force_exact = false;   // the resident batch tripped the range flag once: run it on the exact kernels
     int exact_reruns = 0;
     long long G = 0, N = 0, E = 0;
+    double job_fill = -1.0;            // flowgnn_set_job_tile_fill: the graph-tile fill of the JOB (-1: the batch's own packing decides)
     long long job_n = -1, job_e = -1;  // flowgnn_set_job_totals: the job the next batches are shards of (-1: each batch is its own job)
     int max_nodes = 0, max_edges = 0;
     size_t capG = 0, capN = 0, capE = 0;
@@ -446,9 +451,42 @@ static int alloc_batch(flowgnn_engine* e, size_t G, size_t N, size_t E, bool att
 
 int flowgnn_set_job_totals(flowgnn_engine* e, long long job_nodes, long long job_edges) {
     if (!e) return FLOWGNN_ERR_ARG;
-    if ((job_nodes < 0) != (job_edges < 0)) { e->err = "flowgnn_set_job_totals: both totals, or -1 for both"; return FLOWGNN_ERR_ARG; }
+    if ((job_nodes < 0) != (job_edges < 0)) {
+        e->err = "flowgnn_set_job_totals: both totals, or -1 for both";
+        fg::set_last_error(e->err.c_str());
+        return FLOWGNN_ERR_ARG;
+    }
     e->job_n = job_nodes < 0 ? -1 : job_nodes;
     e->job_e = job_edges < 0 ? -1 : job_edges;
+    return FLOWGNN_OK;
+}
+
+// fill of the model's graph tiles when `num_graphs` graphs are packed greedily in order (the packing flowgnn_set_batch does), without
+// the last tile; 1 for a one-tile batch, 0 when a graph exceeds the tile limits (no resident path), -1 when the model has no tiles
+static double graph_tile_fill(fg::Model* model, int num_graphs, const int* nums_of_nodes, const int* nums_of_edges) {
+    int t_rows = 0, t_edges = 0;
+    model->graph_tile_limits(t_rows, t_edges);
+    if (t_rows <= 0 || num_graphs <= 0) return -1.0;
+    long long rows_before_last = 0, rows = 0, tiles = 1;
+    int cr = 0, ce = 0;
+    for (int g = 0; g < num_graphs; g++) {
+        const int n = nums_of_nodes[g], m = nums_of_edges[g];
+        if (n > t_rows || m > t_edges) return 0.0;
+        if (cr + n > t_rows || ce + m > t_edges) { tiles++; rows_before_last = rows; cr = 0; ce = 0; }
+        cr += n; ce += m; rows += n;
+    }
+    return tiles > 1 ? (double)rows_before_last / ((double)(tiles - 1) * t_rows) : 1.0;
+}
+
+int flowgnn_set_job_tile_fill(flowgnn_engine* e, double fill) {
+    if (!e) return FLOWGNN_ERR_ARG;
+    e->job_fill = fill < 0.0 ? -1.0 : fill;
+    return FLOWGNN_OK;
+}
+
+int flowgnn_graph_tile_fill(flowgnn_engine* e, int num_graphs, const int* nums_of_nodes, const int* nums_of_edges, double* fill) {
+    if (!e || !fill || num_graphs < 0 || (num_graphs > 0 && (!nums_of_nodes || !nums_of_edges))) return FLOWGNN_ERR_ARG;
+    *fill = graph_tile_fill(e->model, num_graphs, nums_of_nodes, nums_of_edges);
     return FLOWGNN_OK;
 }
 
@@ -558,6 +596,9 @@ int flowgnn_set_batch(flowgnn_engine* e, int num_graphs, const int* nums_of_node
                 // then sees the fill of its graphs' packing, not of its own tail -- a one-tile batch counts as full (one resident
                 // launch beats the per-layer sequence on it anyway) -- and takes the path the whole job would take
                 gt.fill = gt.n_tiles > 1 ? (double)trow[cnt - 2] / ((double)(gt.n_tiles - 1) * t_rows) : 1.0;
+                // ... and a shard that was told the fill of its JOB (flowgnn_set_job_tile_fill; the group and the entry points do)
+                // takes the job's side of the models' thresholds whatever its own graphs pack to
+                if (e->job_fill >= 0.0) gt.fill = e->job_fill;
             }
         }
         int s_rows = 0, s_edges = 0;
@@ -996,8 +1037,97 @@ int flowgnn_get_aggregate(flowgnn_engine* e, int layer, float* h_in_host, int* i
 // one GPU: what the 1-GPU tests do) -- graphs are independent, so results are bit-identical to the single-engine run.
 }  // extern "C"
 
+// One persistent host thread per engine (engine 0 runs on the caller's thread): a call that touches the devices hands every worker the
+// same function and waits for all of them.  (Creating and joining a std::thread per engine and call -- what this replaced -- costs
+// 60-100 us per call with eight engines; a dataset-sized step is 190 us of GPU time.)  Workers spin briefly for the next job before
+// they sleep on the condition variable, so the timed loop of `host --devices` (flowgnn_group_run back to back) never pays a wake-up.
+class GroupWorkers {
+public:
+    ~GroupWorkers() { stop(); }
+    void start(int n_engines) {
+        n_ = n_engines;
+        rc_.assign((size_t)n_engines, 0);
+        for (int i = 1; i < n_engines; i++) th_.emplace_back([this, i] { loop(i); });
+    }
+    void stop() {
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            quit_ = true;
+            gen_.fetch_add(1, std::memory_order_release);
+        }
+        cv_go_.notify_all();
+        for (auto& t : th_) t.join();
+        th_.clear();
+    }
+    // fn(i) for every engine i; returns the per-engine status codes
+    const std::vector<int>& each(const std::function<int(int)>& fn) {
+        if (n_ > 1) {
+            {
+                std::lock_guard<std::mutex> lk(mu_);
+                fn_ = &fn;
+                pending_.store(n_ - 1, std::memory_order_relaxed);
+                gen_.fetch_add(1, std::memory_order_release);
+            }
+            cv_go_.notify_all();
+        }
+        rc_[0] = fn(0);
+        if (n_ > 1) {
+            for (int spin = 0; spin < 20000 && pending_.load(std::memory_order_acquire) > 0; spin++) cpu_relax();
+            if (pending_.load(std::memory_order_acquire) > 0) {
+                std::unique_lock<std::mutex> lk(mu_);
+                cv_done_.wait(lk, [this] { return pending_.load(std::memory_order_acquire) == 0; });
+            }
+            fn_ = nullptr;
+        }
+        return rc_;
+    }
+
+private:
+    static void cpu_relax() {
+#if defined(__x86_64__) || defined(__i386__)
+        __builtin_ia32_pause();
+#else
+        std::this_thread::yield();
+#endif
+    }
+    void loop(int i) {
+        unsigned long long seen = 0;
+        while (true) {
+            // a short spin (a back-to-back caller is here again within microseconds), then sleep
+            for (int spin = 0; spin < 4000 && gen_.load(std::memory_order_acquire) == seen; spin++) cpu_relax();
+            if (gen_.load(std::memory_order_acquire) == seen) {
+                std::unique_lock<std::mutex> lk(mu_);
+                cv_go_.wait(lk, [&] { return gen_.load(std::memory_order_acquire) != seen; });
+            }
+            const std::function<int(int)>* fn;
+            {
+                std::lock_guard<std::mutex> lk(mu_);  // pairs with each(): fn_ and gen_ are published together
+                seen = gen_.load(std::memory_order_acquire);
+                if (quit_) return;
+                fn = fn_;
+            }
+            rc_[(size_t)i] = (*fn)(i);
+            if (pending_.fetch_sub(1, std::memory_order_acq_rel) == 1) {
+                std::lock_guard<std::mutex> lk(mu_);
+                cv_done_.notify_one();
+            }
+        }
+    }
+    int n_ = 0;
+    std::vector<std::thread> th_;
+    std::vector<int> rc_;
+    std::mutex mu_;
+    std::condition_variable cv_go_, cv_done_;
+    const std::function<int(int)>* fn_ = nullptr;
+    std::atomic<unsigned long long> gen_{0};
+    std::atomic<int> pending_{0};
+    bool quit_ = false;
+};
+
 struct flowgnn_group {
     int model_id = 0;
+    GroupWorkers workers;
+    std::mutex call_mu;  // one group call at a time (the workers hold one function)
     std::vector<flowgnn_engine*> eng;
     std::vector<int> cut;  // [n + 1] graph cuts of the resident batch
     bool batch_valid = false;  // the engines hold the shards `cut` describes (flowgnn_group_set_batch); flowgnn_group_compute and the
@@ -1009,18 +1139,10 @@ struct flowgnn_group {
 };
 
 namespace {
-template <typename F>
-int group_each(flowgnn_group* g, F fn) {  // fn(i) on every engine, one host thread per engine; first failure wins
+int group_each(flowgnn_group* g, const std::function<int(int)>& fn) {  // fn(i) on every engine, each on its own (persistent) host thread; first failure wins
     const int n = (int)g->eng.size();
-    std::vector<int> rc((size_t)n, 0);
-    if (n == 1) {
-        rc[0] = fn(0);
-    } else {
-        std::vector<std::thread> th;
-        th.reserve((size_t)n);
-        for (int i = 0; i < n; i++) th.emplace_back([&, i] { rc[(size_t)i] = fn(i); });
-        for (auto& t : th) t.join();
-    }
+    std::lock_guard<std::mutex> call(g->call_mu);
+    const std::vector<int>& rc = g->workers.each(fn);
     for (int i = 0; i < n; i++)
         if (rc[(size_t)i]) {
             g->err = "engine " + std::to_string(i) + " (device " + std::to_string(g->eng[(size_t)i]->device) + "): " + flowgnn_last_error(g->eng[(size_t)i]);
@@ -1070,6 +1192,7 @@ int flowgnn_create_multi(int model, int n_devices, const int* device_ids, flowgn
         g->eng.push_back(e);
     }
     g->cut.assign((size_t)n_devices + 1, 0);
+    g->workers.start(n_devices);
     for (int i = 0; i < n_devices; i++) {
         int first = i;
         for (int k = 0; k < i; k++)
@@ -1083,6 +1206,7 @@ int flowgnn_create_multi(int model, int n_devices, const int* device_ids, flowgn
 
 int flowgnn_group_destroy(flowgnn_group* g) {
     if (!g) return FLOWGNN_ERR_ARG;
+    g->workers.stop();
     for (auto* e : g->eng) flowgnn_destroy(e);
     delete g;
     return FLOWGNN_OK;
@@ -1143,12 +1267,16 @@ int flowgnn_group_set_batch(flowgnn_group* g, int num_graphs, const int* nums_of
     }
     // every shard chooses its kernels by the JOB's totals (flowgnn_set_job_totals): the same kernels as one engine holding all of it
     const long long job_n = noff[(size_t)n], job_e = eoff[(size_t)n];
+    const double job_fill = graph_tile_fill(g->eng[0]->model, num_graphs, nums_of_nodes, nums_of_edges);  // (the members are one model with one option set)
     rc = group_each(g, [&](int i) {
         const int g0 = g->cut[(size_t)i], g1 = g->cut[(size_t)i + 1];
         const long long n0 = noff[(size_t)i], e0 = eoff[(size_t)i];
         flowgnn_engine* e = g->eng[(size_t)i];
         const long long keep_n = e->job_n, keep_e = e->job_e;
         flowgnn_set_job_totals(e, job_n, job_e);
+        const double keep_fill = e->job_fill;
+        flowgnn_set_job_tile_fill(e, job_fill);
+        struct RestoreFill { flowgnn_engine* e; double f; ~RestoreFill() { e->job_fill = f; } } restore_fill{e, keep_fill};
         const int r = flowgnn_set_batch(e, g1 - g0, nums_of_nodes ? nums_of_nodes + g0 : nullptr,
                                         nums_of_edges ? nums_of_edges + g0 : nullptr, node_feature ? node_feature + n0 * 9 : nullptr,
                                         edge_list ? edge_list + e0 * 2 : nullptr, edge_attr ? edge_attr + e0 * 3 : nullptr,
@@ -1158,6 +1286,18 @@ int flowgnn_group_set_batch(flowgnn_group* g, int num_graphs, const int* nums_of
     });
     g->batch_valid = rc == FLOWGNN_OK;
     return rc;
+}
+
+// the members still hold the shards flowgnn_group_set_batch gave them?  (flowgnn_group_engine hands the members out for per-engine
+// calls: a flowgnn_set_batch on one of them would otherwise have its rows copied to the old cut's offset)
+static int group_shards_intact(flowgnn_group* g, const char* who) {
+    for (size_t i = 0; i < g->eng.size(); i++)
+        if (g->eng[i]->G != g->cut[i + 1] - g->cut[i]) {
+            g->batch_valid = false;
+            const std::string msg = std::string(who) + ": engine " + std::to_string(i) + " no longer holds its shard of the group's batch (a per-engine flowgnn_set_batch?); call flowgnn_group_set_batch again";
+            return group_fail(g, FLOWGNN_ERR_STATE, msg.c_str());
+        }
+    return FLOWGNN_OK;
 }
 
 int flowgnn_group_shards(const flowgnn_group* g, int* cuts) {
@@ -1171,6 +1311,7 @@ int flowgnn_group_run(flowgnn_group* g) {
     if (!g) return FLOWGNN_ERR_ARG;
     g->err.clear();
     if (!g->batch_valid) return group_fail(g, FLOWGNN_ERR_STATE, "flowgnn_group_run: no batch set by flowgnn_group_set_batch (flowgnn_group_compute and the entry points leave none)");
+    if (int rc = group_shards_intact(g, "flowgnn_group_run")) return rc;
     return group_each(g, [&](int i) { return flowgnn_run(g->eng[(size_t)i]); });
 }
 int flowgnn_group_sync(flowgnn_group* g) {
@@ -1182,6 +1323,7 @@ int flowgnn_group_get_results(flowgnn_group* g, float* out_host) {
     if (!g) return FLOWGNN_ERR_ARG;
     g->err.clear();
     if (!g->batch_valid) return group_fail(g, FLOWGNN_ERR_STATE, "flowgnn_group_get_results: no batch set by flowgnn_group_set_batch (flowgnn_group_compute and the entry points leave none)");
+    if (int rc = group_shards_intact(g, "flowgnn_group_get_results")) return rc;
     if (!out_host && g->cut.back() > 0) return group_fail(g, FLOWGNN_ERR_ARG, "flowgnn_group_get_results: null output");
     return group_each(g, [&](int i) {
         flowgnn_engine* e = g->eng[(size_t)i];
@@ -1221,12 +1363,14 @@ int flowgnn_group_compute(flowgnn_group* g, int num_graphs, const int* nums_of_n
         }
     }
     const int T = g->num_tasks;
-    const long long job_n = noff[(size_t)S], job_e = eoff[(size_t)S];  // every range chooses its kernels by the job's totals
+    const long long job_n = noff[(size_t)S], job_e = eoff[(size_t)S];  // every range chooses its kernels by the job's totals ...
+    const double job_fill = graph_tile_fill(g->eng[0]->model, num_graphs, nums_of_nodes, nums_of_edges);  // ... and the job's tile fill
     return group_each(g, [&](int i) {
         flowgnn_engine* e = g->eng[(size_t)i];
         const long long keep_n = e->job_n, keep_e = e->job_e;
-        struct Restore { flowgnn_engine* e; long long n, m; ~Restore() { flowgnn_set_job_totals(e, n, m); } } restore{e, keep_n, keep_e};
+        struct Restore { flowgnn_engine* e; long long n, m; double f; ~Restore() { flowgnn_set_job_totals(e, n, m); e->job_fill = f; } } restore{e, keep_n, keep_e, e->job_fill};
         flowgnn_set_job_totals(e, job_n, job_e);
+        flowgnn_set_job_tile_fill(e, job_fill);
         for (int j = i; j < S; j += n) {
             const int g0 = cut[(size_t)j], g1 = cut[(size_t)j + 1];
             if (g1 == g0) continue;
@@ -1415,12 +1559,20 @@ int GIN_compute_graphs_mt(int num_graphs, int* nums_of_nodes, int* nums_of_edges
                                   node_feature_in, nullptr, edge_list_in, edge_attr_in, 8, t, sz, T);
 }
 
-static int refuse_stale_num_task(const char* symbol) {
-    static const bool stale = [] { bool b = false; read_environment(nullptr, nullptr, &b); return b; }();
+// The reference's symbol is `void`: a caller that ignores the status must not read an untouched buffer as results, so a refusal also
+// fills `out` with NaN and says why on stderr (once per process).  The environment is asked on every call (getenv is cheap), so
+// unsetting the variable in the same process clears the refusal.
+static int refuse_stale_num_task(const char* symbol, float* out, int num_graphs) {
+    bool stale = false;
+    read_environment(nullptr, nullptr, &stale);
     if (!stale) return FLOWGNN_OK;
     char msg[256];
     snprintf(msg, sizeof(msg), "%s: FLOWGNN_NUM_TASK is set in the environment but no longer read -- call %s_mt(..., num_tasks) (include/flowgnn.h) or unset it", symbol, symbol);
     fg::set_last_error(msg);
+    static std::atomic<bool> said{false};
+    if (!said.exchange(true)) fprintf(stderr, "flowgnn: %s; the output buffer is filled with NaN\n", msg);
+    if (out)
+        for (int g = 0; g < num_graphs; g++) out[g] = std::numeric_limits<float>::quiet_NaN();
     return FLOWGNN_ERR_UNSUPPORTED;
 }
 
@@ -1429,7 +1581,7 @@ int GIN_compute_graphs(int num_graphs, int* nums_of_nodes, int* nums_of_edges, i
                        float* edge_embedding_weight_in, float* node_mlp_1_weights, float* node_mlp_1_bias,
                        float* node_mlp_2_weights, float* node_mlp_2_bias, float* graph_pred_weights_in,
                        float* graph_pred_bias_in) {
-    if (int rc = refuse_stale_num_task("GIN_compute_graphs")) return rc;
+    if (int rc = refuse_stale_num_task("GIN_compute_graphs", out, num_graphs)) return rc;
     return GIN_compute_graphs_mt(num_graphs, nums_of_nodes, nums_of_edges, reload_weights, out, node_feature_in, edge_list_in,
                                  edge_attr_in, node_embedding_weight_in, edge_embedding_weight_in, node_mlp_1_weights, node_mlp_1_bias,
                                  node_mlp_2_weights, node_mlp_2_bias, graph_pred_weights_in, graph_pred_bias_in, 1);
@@ -1455,7 +1607,7 @@ int GCN_compute_graphs(int num_graphs, int* nums_of_nodes, int* nums_of_edges, i
                        float* edge_embedding_weight_in, float* convs_weight_in, float* convs_bias_in,
                        float* convs_root_emb_weight_in, float* bn_weight_in, float* bn_bias_in, float* bn_mean_in,
                        float* bn_var_in, float* graph_pred_weights_in, float* graph_pred_bias_in) {
-    if (int rc = refuse_stale_num_task("GCN_compute_graphs")) return rc;
+    if (int rc = refuse_stale_num_task("GCN_compute_graphs", out, num_graphs)) return rc;
     return GCN_compute_graphs_mt(num_graphs, nums_of_nodes, nums_of_edges, reload_weights, out, node_feature_in, edge_list_in,
                                  edge_attr_in, node_embedding_weight_in, edge_embedding_weight_in, convs_weight_in, convs_bias_in,
                                  convs_root_emb_weight_in, bn_weight_in, bn_bias_in, bn_mean_in, bn_var_in, graph_pred_weights_in,

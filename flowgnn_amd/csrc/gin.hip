@@ -756,7 +756,7 @@ public:
         // reloads, which made this form the slower one on large batches in round 3) where the separate, store-bound encoder launch costs
         // 0.51: ahead at every size now -- 8.49 vs 8.73 ms per step at 2^18 graphs, 1.23 vs 1.24 at 32 768, 0.206 vs 0.222 at 4 113.
         // -1 = default = on; an explicit gin_pingpong keeps the three-kernel front end (the ping-pong kernel has no encoder in its loader).
-        const bool want = tile_build_ < 0 ? !pingpong_ : tile_build_ != 0;
+        const bool want = tile_build_ < 0 ? !(pingpong_ && !virtual_node_) : tile_build_ != 0;  // (the ping-pong kernel is never used with a virtual node)
         return want && use_resident(db) && !qmode_ && !keep_h_ && num_tasks_ == 1 && fold_readout_ && head_fold_ && db.b.edge_attr != nullptr;
     }
     bool needs_csr(const DeviceBatch& db) const override { return !one_pass(db); }
@@ -974,7 +974,7 @@ private:
     bool pingpong_ = false;       // gin_pingpong = 1: gin_pp_kernel (two half-tiles per CU half a layer out of phase; measured slower)
     uint8_t* d_pp_pieces_ = nullptr;  // weight pieces of gin_pp_kernel
     float* d_pp_tables_ = nullptr;    // ... and its half tables
-    int tile_build_ = -1;         // gin_tile_build: 1 = one-pass front end, 0 = CSR build + atom encoder + tile prep as separate launches, -1 = by batch size
+    int tile_build_ = -1;         // gin_tile_build: 1 = one-pass front end, 0 = CSR build + atom encoder + tile prep as separate launches, -1 = default = one-pass unless gin_pingpong selects the ping-pong kernel (no size rule)
     // gin_fold_readout=0 keeps the separate mean-pool + linear kernel (and the last layer's 2.7 GB of rows)
     bool fold_readout_ = true;
     // gin_resident=0 keeps one launch per layer (gin_layer_split_kernel).  GIN-VN runs the HUBS form of the resident kernel:

@@ -261,6 +261,9 @@ __global__ __launch_bounds__(512) void pna_dense_split_kernel(const float* __res
 // tile's rows of h come into LDS by DMA (padded stride, below), its CSR slice as bytes (the first 16 in-edges of a row are kept
 // packed in four registers and re-walked per K-step); the weight chunks (30 KiB per K-step, pna_pack_stream_layer) stream
 // through two LDS buffers as in pna_dense_split_kernel.  In-edges are summed in CSR order as everywhere else.
+#ifndef PNA_DMA_MID
+#define PNA_DMA_MID 0  // -DPNA_DMA_MID=1 (scripts/dev/variant.sh): the chunk request between a wave's phases, compiled in without the DEV hooks
+#endif
 constexpr int PNA_FT_ROWS = 256;
 constexpr int PNA_FT_EDGES = 4608;
 // LDS row stride: 84 floats = 21 slots of 16 B.  A gather instruction reads 16 different rows at one column; with the rows'
@@ -476,21 +479,42 @@ __global__ __launch_bounds__(PNA_FT_WAVES * 64, 4) void pna_layer_fused_kernel(c
         for (int i = 0; i < PNA_NS * PNA_OT; i++) y[i] = (float4_t){0.f, 0.f, 0.f, 0.f};
         ds_uint4_t b_hi = {0, 0, 0, 0}, b_lo = {0, 0, 0, 0};
         if (late) pna_gather_slice(s_h, csrc, srcw, e_base, indeg, 2 * g, b_hi, b_lo, vmax);  // K-step 0's slice, ahead of the first interval
+        // Development variants of WHERE a K-step's chunk request sits (round-3 finding: requested between a wave's two phases the
+        // kernel was 1.6 % faster and two-engine runs stopped being bit-identical; scripts/dev/pna_dma_race.py bisects it):
+        //   ablate 8: the request between the wave's phases (early waves: gather, REQUEST, multiply; late: multiply, REQUEST, gather)
+        //   + 16: s_waitcnt lgkmcnt(0) in front of the request   + 32: a workgroup barrier in front of it
+        //   + 64: a second barrier (and a short sleep) behind the closing vmcnt(0) + barrier
+        const bool mid = PNA_DMA_MID || (ablate & 8) != 0;
+        auto issue_mid = [&](const uint8_t* gchunk, char* buf) {
+            if (ablate & 16) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (ablate & 32) __syncthreads();
+            pna_issue_chunk_asm(gchunk, buf, wave, lane);
+        };
+        auto close_step = [&]() {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (!(ablate & 4)) __syncthreads();  // ablate 4 (development aid): timing without the K-step barriers (results are then wrong)
+            if (ablate & 64) {
+                asm volatile("s_sleep 2" ::: "memory");
+                __syncthreads();
+            }
+        };
 #pragma unroll 1
         for (int ks = 0; ks < ((ablate & 2) ? 0 : PNA_KS); ks += 2) {
             // even K-step from s_a while chunk ks+1 streams into s_b
-            pna_issue_chunk_asm(wpk + (size_t)(ks + 1) * PNA_CHUNK, s_b, wave, lane);
+            if (!mid) pna_issue_chunk_asm(wpk + (size_t)(ks + 1) * PNA_CHUNK, s_b, wave, lane);
             if (!late) pna_gather_slice(s_h, csrc, srcw, e_base, indeg, 8 * ks + 2 * g, b_hi, b_lo, vmax);
+            if (mid && !late) issue_mid(wpk + (size_t)(ks + 1) * PNA_CHUNK, s_b);
             pna_stream_mfma(s_a, lane, b_hi, b_lo, y);
+            if (mid && late) issue_mid(wpk + (size_t)(ks + 1) * PNA_CHUNK, s_b);
             if (late) pna_gather_slice(s_h, csrc, srcw, e_base, indeg, 8 * (ks + 1) + 2 * g, b_hi, b_lo, vmax);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (!(ablate & 4)) __syncthreads();
-            if (ks + 2 < PNA_KS) pna_issue_chunk_asm(wpk + (size_t)(ks + 2) * PNA_CHUNK, s_a, wave, lane);
+            close_step();
+            if (!mid && ks + 2 < PNA_KS) pna_issue_chunk_asm(wpk + (size_t)(ks + 2) * PNA_CHUNK, s_a, wave, lane);
             if (!late) pna_gather_slice(s_h, csrc, srcw, e_base, indeg, 8 * (ks + 1) + 2 * g, b_hi, b_lo, vmax);
+            if (mid && !late && ks + 2 < PNA_KS) issue_mid(wpk + (size_t)(ks + 2) * PNA_CHUNK, s_a);
             pna_stream_mfma(s_b, lane, b_hi, b_lo, y);
+            if (mid && late && ks + 2 < PNA_KS) issue_mid(wpk + (size_t)(ks + 2) * PNA_CHUNK, s_a);
             if (late && ks + 2 < PNA_KS) pna_gather_slice(s_h, csrc, srcw, e_base, indeg, 8 * (ks + 2) + 2 * g, b_hi, b_lo, vmax);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (!(ablate & 4)) __syncthreads();  // ablate 4 (development aid): timing without the K-step barriers (results are then wrong)
+            close_step();
         }
         // ---- epilogue: h' = h + relu(b + Y_0 + t Y_1 + scale Y_2)   (node_embedding.cc:148-150,205-213); the residual rows come
         // out of the LDS tile, after which the tile is dead and the next one's rows can stream in

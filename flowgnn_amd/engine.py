@@ -102,6 +102,17 @@ class Engine:
         """The next batches are shards of a job of this size (flowgnn.h: flowgnn_set_job_totals); (-1, -1): each batch is its own job."""
         self._check(self.lib.flowgnn_set_job_totals(self._h, int(job_nodes), int(job_edges)), "flowgnn_set_job_totals")
 
+    def graph_tile_fill(self, nums_of_nodes, nums_of_edges) -> float:
+        """Fill of this model's graph tiles for a graph list (flowgnn.h: flowgnn_graph_tile_fill); host code only."""
+        nn, ne = _i32(nums_of_nodes), _i32(nums_of_edges)
+        f = C.c_double()
+        self._check(self.lib.flowgnn_graph_tile_fill(self._h, len(nn), _pi(nn), _pi(ne), C.byref(f)), "flowgnn_graph_tile_fill")
+        return float(f.value)
+
+    def set_job_tile_fill(self, fill: float = -1.0):
+        """The next batches take the JOB's side of the resident kernels' fill threshold (flowgnn.h: flowgnn_set_job_tile_fill)."""
+        self._check(self.lib.flowgnn_set_job_tile_fill(self._h, float(fill)), "flowgnn_set_job_tile_fill")
+
     def set_batch(self, batch: GraphBatch):
         nn, ne = _i32(batch.nums_of_nodes), _i32(batch.nums_of_edges)
         nf, el, ea = _i32(batch.node_feature), _i32(batch.edge_list), _i32(batch.edge_attr)

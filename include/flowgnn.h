@@ -230,12 +230,22 @@ int flowgnn_set_batch(flowgnn_engine* e, int num_graphs,
                       const float* node_eigen);
 /*
  * Declare the next flowgnn_set_batch batches to be SHARDS of a job of this many nodes and edges (a multi-process caller that cuts
- * one job over several GPUs, one engine each; flowgnn_group_* does it by itself).  Choices between kernels that depend on the
- * batch size -- GIN's front end, DGN's aggregation -- are then made from the job's totals, so every shard computes on the
- * kernels a single engine would have chosen for the whole job and results do not depend on the device count.  (-1, -1), the
+ * one job over several GPUs, one engine each; flowgnn_group_* does it by itself).  The one choice between kernels that depends on the
+ * batch size -- DGN's aggregation, by the density E / N (GIN's front end has had no size rule since round 4) -- is then made from
+ * the job's totals, so every shard computes on the kernels a single engine would have chosen for the whole job and results do not
+ * depend on the device count.  (-1, -1), the
  * default: each batch is its own job.  Totals smaller than a batch's own are raised to them.
  */
 int flowgnn_set_job_totals(flowgnn_engine* e, long long job_nodes, long long job_edges);
+/*
+ * The other size-dependent choice: the graph-resident / fused kernels are used when the batch's graph tiles pack at least 50 % full
+ * (40 % PNA / DGN; the last tile does not count).  flowgnn_graph_tile_fill computes that fill for any graph list under this engine's
+ * model and options (host code, no device work; -1: the model has no graph tiles, 0: a graph exceeds the tile limits);
+ * flowgnn_set_job_tile_fill makes the next flowgnn_set_batch batches take the side of the threshold the JOB's fill is on, whatever
+ * their own graphs pack to (< 0: back to each batch's own packing).  flowgnn_group_* and the entry points hand both down by themselves.
+ */
+int flowgnn_graph_tile_fill(flowgnn_engine* e, int num_graphs, const int* nums_of_nodes, const int* nums_of_edges, double* fill);
+int flowgnn_set_job_tile_fill(flowgnn_engine* e, double fill);
 
 /*
  * Enqueue one full forward of the resident batch on the engine's stream:
@@ -352,9 +362,10 @@ const char* flowgnn_option_name(int i);
  * kernels are chosen from the JOB's totals, which the group (and the entry points' ranges) hand down to every member through
  * flowgnn_set_job_totals.  That covers GIN, GIN-VN, GCN, GAT and PNA with default options at any device count.  Two exceptions:
  * DGN's matrix-pipe aggregation (default on kNN-dense jobs, option "dgn_mfma_agg") sums in tile order -- equal to 1e-5 relative
- * under a different cut, bit-identical with "dgn_mfma_agg" 0; and a job of LARGE graphs whose tiles are about as full as the
- * resident kernels' fill threshold (50 %; 40 % PNA / DGN; a batch's last tile does not count, a one-tile batch is full) can pack
- * above it as a whole and below it in a shard, which then runs the per-layer kernels: fp32 rounding differences.  flowgnn_group_run / get_results / shards answer FLOWGNN_ERR_STATE unless the engines hold
+ * under a different cut, bit-identical with "dgn_mfma_agg" 0; and a multi-PROCESS caller
+ * that cuts a job of LARGE graphs whose tiles are about as full as the resident kernels' fill threshold must hand the job's fill down
+ * itself (flowgnn_graph_tile_fill + flowgnn_set_job_tile_fill, as the group does), or a shard can pack to the other side of the
+ * threshold and run the per-layer kernels: fp32 rounding differences.  flowgnn_group_run / get_results / shards answer FLOWGNN_ERR_STATE unless the engines hold
  * the shards of a flowgnn_group_set_batch job (flowgnn_group_compute and the entry points leave each engine on its last range).
  */
 typedef struct flowgnn_group flowgnn_group;

@@ -83,3 +83,28 @@ def test_shard_ranges_c_equals_python():
         for parts in (1, 2, 3, 8, 17, 256):
             assert shard_ranges_c(b.nums_of_nodes, b.nums_of_edges, parts) == shard_ranges(b, parts), (trial, parts)
     assert shard_ranges_c(np.zeros(0, np.int32), np.zeros(0, np.int32), 4) == [(0, 0)] * 4
+
+
+@pytest.mark.skipif(not os.path.exists(LIB), reason="libflowgnn_hip.so not built")
+def test_stale_num_task_refusal_fills_the_output_and_clears_when_unset():
+    """The plain GIN / GCN symbols are `void` in the reference (GIN/src/dcl.h:75-94): a caller that ignores the status must not read an
+    untouched buffer as results.  A refusal fills `out` with NaN, and unsetting the variable in the same process clears it."""
+    import numpy as np
+    lib = ctypes.CDLL(LIB)
+    out = np.ones(4, np.float32)
+    args = [None] * 15
+    args[3] = out.ctypes.data_as(ctypes.POINTER(ctypes.c_float))
+    os.environ["FLOWGNN_NUM_TASK"] = "3"
+    try:
+        for sym in ("GIN_compute_graphs", "GCN_compute_graphs"):
+            out[:] = 1.0
+            assert getattr(lib, sym)(4, *args) == 8  # FLOWGNN_ERR_UNSUPPORTED
+            assert np.isnan(out).all()
+    finally:
+        del os.environ["FLOWGNN_NUM_TASK"]
+    assert lib.GIN_compute_graphs(0, *([None] * 15)) == 0  # the same process, variable unset: no refusal (empty batch: no device needed)
+    os.environ["FLOWGNN_NUM_TASK"] = "1"  # the default value is not stale
+    try:
+        assert lib.GCN_compute_graphs(0, *([None] * 15)) == 0
+    finally:
+        del os.environ["FLOWGNN_NUM_TASK"]

@@ -311,3 +311,65 @@ def test_group_state_after_compute_and_error_text():
         assert b"engine" not in (g.lib.flowgnn_group_last_error(g._h) or b"")  # ... the old text is gone
     finally:
         g.close()
+
+
+def test_shards_take_the_jobs_side_of_the_fill_threshold():
+    """The graph-resident kernels are used when the batch's graph tiles pack >= 50 % full (flowgnn.h).  A job of LARGE graphs packs
+    about that full, and a shard of it can pack to the other side: the group (and flowgnn_set_job_tile_fill for a multi-process
+    caller) hands the JOB's fill down, so the shard runs the kernels the whole job would run -- the same bits (round-4 advisor)."""
+    rng = np.random.default_rng(3)
+    w = weights.synth_gin_weights(seed=7)
+    found = None
+    e = Engine("GIN", device=0)
+    try:
+        e.set_weights(w)
+        for trial in range(200):
+            # graphs of 100..183 nodes: one or two per 256-row tile, fill around the threshold
+            b = gp.synth_molecule_batch(24, seed=1000 + trial, mean_nodes=float(rng.uniform(118, 135)), min_nodes=100, max_nodes=183)
+            f_job = e.graph_tile_fill(b.nums_of_nodes, b.nums_of_edges)
+            cuts = shard_ranges_c(b.nums_of_nodes, b.nums_of_edges, 2)
+            for (a, c) in cuts:
+                f_sh = e.graph_tile_fill(b.nums_of_nodes[a:c], b.nums_of_edges[a:c])
+                if min(f_job, f_sh) < 0.5 <= max(f_job, f_sh) and abs(f_job - f_sh) > 0.01:
+                    found = (b, a, c, f_job, f_sh)
+                    break
+            if found:
+                break
+        assert found, "no job / shard pair on opposite sides of the threshold in 200 trials"
+        b, a, c, f_job, f_sh = found
+        e.profile_enable(True)
+        want = e.forward(b)
+        job_kernels = set(e.profile_read())
+        assert ("gin_resident" in job_kernels) == (f_job >= 0.5)
+    finally:
+        e.close()
+    sh = b.slice(a, c)
+    # the shard as its own job: the other side of the threshold, other kernels (same values to fp32 rounding)
+    e = Engine("GIN", device=0)
+    try:
+        e.set_weights(w)
+        e.profile_enable(True)
+        alone = e.forward(sh)
+        assert ("gin_resident" in set(e.profile_read())) == (f_sh >= 0.5) != (f_job >= 0.5)
+        np.testing.assert_allclose(alone, want[a:c], rtol=2e-4, atol=2e-4)
+    finally:
+        e.close()
+    # told the job's fill (and totals): the job's kernels, the job's bits
+    e = Engine("GIN", device=0)
+    try:
+        e.set_weights(w)
+        e.set_job_totals(b.total_nodes, b.total_edges)
+        e.set_job_tile_fill(f_job)
+        e.profile_enable(True)
+        told = e.forward(sh)
+        assert ("gin_resident" in set(e.profile_read())) == (f_job >= 0.5)
+        assert np.array_equal(told, want[a:c])
+    finally:
+        e.close()
+    g = EngineGroup("GIN", [0, 0])
+    try:
+        g.set_weights(w)
+        assert np.array_equal(g.forward(b), want)
+        assert np.array_equal(g.compute(b, 2), want)
+    finally:
+        g.close()
