@@ -38,7 +38,8 @@ def sharded_forward(compute: Callable[[GraphBatch], np.ndarray], batch: GraphBat
 
     ranges = shard_ranges(batch, world_size)
     g0, g1 = ranges[rank]
-    local = np.asarray(compute(batch.slice(g0, g1)), dtype=np.float32)
+    # (an empty range -- more ranks than graphs -- computes nothing and still takes part in the collective)
+    local = np.asarray(compute(batch.slice(g0, g1)), dtype=np.float32) if g1 > g0 else np.zeros(0, np.float32)
     if world_size == 1:
         return local
     width = max(b - a for a, b in ranges)

@@ -29,7 +29,8 @@ def _worker(rank, world, port, scaling, graphs, q):
     res = b.ShardedResults(ranges, rank, "cpu", dist)
     assert res.local_count() == batch.num_graphs
     for _ in range(3):  # three "steps": both buffer pairs are used and one is reused (asynchronous gathers)
-        res.pad[: batch.num_graphs] = torch.from_numpy(oracle.gin_forward(batch, [w]))
+        if batch.num_graphs:  # (a rank with an empty shard computes nothing and still gathers)
+            res.pad[: batch.num_graphs] = torch.from_numpy(oracle.gin_forward(batch, [w]))
         res.gather()
     q.put((rank, res.assemble().numpy(), ranges, balance))
     dist.barrier()
@@ -44,19 +45,19 @@ def _make(dataset, graphs, seed):
     return bench.make_batch(dataset, graphs, seed)
 
 
-def _run(scaling, graphs):
+def _run(scaling, graphs, world=2):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 31000 + (os.getpid() % 2000) + (7 if scaling == "strong" else 0)
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, scaling, graphs, q)) for r in range(2)]
+    port = 31000 + (os.getpid() % 2000) + (7 if scaling == "strong" else 0) + 13 * world
+    procs = [ctx.Process(target=_worker, args=(r, world, port, scaling, graphs, q)) for r in range(world)]
     for p in procs:
         p.start()
     res = {}
-    for _ in range(2):
-        r, out, ranges, balance = q.get(timeout=180)
+    for _ in range(world):
+        r, out, ranges, balance = q.get(timeout=300)
         res[r] = (out, ranges, balance)
     for p in procs:
-        p.join(timeout=60)
+        p.join(timeout=120)
         assert p.exitcode == 0
     return res
 
@@ -73,6 +74,23 @@ def test_strong_scaling_shards_and_concat_world2(oracle, gin_weights):
         assert ranges[0][1] - ranges[0][0] != ranges[1][1] - ranges[1][0]  # really ragged: cut by work, not by count
         assert balance["imbalance_max_over_mean"] < 1.2
         assert sum(balance["graphs_per_rank"]) == graphs
+
+
+def test_strong_scaling_world8_with_fewer_graphs_than_ranks(oracle, gin_weights):
+    """bench.py --gpus 8 --scaling strong on a job of SIX graphs: plan_job hands two ranks an empty shard and the others one graph
+    each; ShardedResults pads to the widest shard, gathers, trims -- every rank assembles the job in job order."""
+    graphs, world = 6, 8
+    res = _run("strong", graphs, world)
+    job = _make("hep10k-noeig", graphs, 1234)
+    want = oracle.gin_forward(job, [gin_weights])
+    sizes = None
+    for r in range(world):
+        out, ranges, balance = res[r]
+        assert np.array_equal(out, want)
+        assert len(ranges) == world and ranges[0][0] == 0 and ranges[-1][1] == graphs
+        sizes = [c - a for a, c in ranges]
+        assert sum(balance["graphs_per_rank"]) == graphs
+    assert 0 in sizes and 1 in sizes
 
 
 def test_weak_scaling_each_rank_its_own_shard_world2(oracle, gin_weights):
