@@ -37,6 +37,10 @@ F16_MFMA_PEAK_TF = 2500.0   # MI355X_MICROARCH.md: dense f16/bf16 MFMA peak (mea
 FPGA_U50_GRAPHS_PER_S = 20214.0  # GIN molhiv on Alveo U50 (other hardware; informational)
 
 
+def GIN_RESIDENT_BYTES(n, e):  # what gin_resident_kernel reads from HBM per launch (see the GIN entry below)
+    return n * 4 + (n // 256 + 1) * 3584
+
+
 # Per-model bench table.  Algorithmic work per launch of the two kernel classes (DESIGN.md "Kernels"):
 #   aggregation bytes (unpadded): read h once + write the aggregates + edge index (8 B) + edge payload
 #   transform flops: 2 x MACs of the dense update per node per layer
@@ -44,9 +48,11 @@ MODELS = {
     "GIN": dict(metric="graphs/sec on ogbg-molhiv (GIN, dim=100)", dataset="molhiv", graphs=1 << 18,
                 agg_bytes=lambda n, e: n * 400 * 2 + e * 20, flops=lambda n, e: n * 80000,
                 # fused layer: read h once + write h' + CSR (row_ptr 4 B/node, src 4 B + edge code 1 B per edge)
-                # graph-resident kernel (all five layers in one launch): reads the encoder rows once + the CSR, writes 4 B per graph;
+                # graph-resident kernel (all five layers in one launch) behind the one-pass front end (the default since round 4): per node
+                # it reads the 4-byte encoder row numbers gin_tile_build wrote, per 256-row tile the 3 584-byte descriptor (CSR slice as
+                # 16-bit words, row offsets); the encoder / edge tables and the weight stream are L2-resident; it writes 4 B per graph;
                 # its bound is the f16 matrix pipe (5 layers x 3 x 80 000 flop per node)
-                fused_bytes={"gin_layer_fused": lambda n, e: n * 400 * 2 + n * 4 + e * 5, "gin_resident": lambda n, e: n * 400 + n * 4 + e * 5},
+                fused_bytes={"gin_layer_fused": lambda n, e: n * 400 * 2 + n * 4 + e * 5, "gin_resident": GIN_RESIDENT_BYTES},
                 layers_per_launch={"gin_resident": 5}, mfma_bound_kernels=("gin_resident",),
                 # dense layers' worth of products one launch EXECUTES: the single-task readout is folded through the last layer's
                 # second linear layer (never computed), so 4.5 of the 5 layers count
@@ -55,7 +61,7 @@ MODELS = {
                 workload="GIN dim=100, batched ogbg-molhiv-shaped graphs on MI355X (BASELINE configs[1])"),
     "GIN-VN": dict(metric="graphs/sec on ogbg-molhiv (GIN-VN, dim=100)", dataset="molhiv-vn", graphs=1 << 18,
                    agg_bytes=lambda n, e: n * 400 * 2 + e * 20, flops=lambda n, e: n * 80000,
-                   fused_bytes={"gin_layer_fused": lambda n, e: n * 400 * 2 + n * 4 + e * 5, "gin_resident": lambda n, e: n * 400 + n * 4 + e * 5},
+                   fused_bytes={"gin_layer_fused": lambda n, e: n * 400 * 2 + n * 4 + e * 5, "gin_resident": GIN_RESIDENT_BYTES},
                    layers_per_launch={"gin_resident": 5}, mfma_bound_kernels=("gin_resident",), dense_layers_per_launch={"gin_resident": 4.5},
                    hbm_kernels=("gin_aggregate",), mfma_kernels=("gin_resident", "gin_layer_fused", "gin_mlp"),
                    workload="GIN-VN dim=100 (virtual node per graph), ogbg-molhiv-shaped graphs"),
@@ -214,6 +220,9 @@ def rooflines(model, M, prof, kern, G, N, E, steps, split, qmode):
                "frac": ach / HBM_PEAK_GBS, "traffic": traffic_of(name), "avg_ms": kern[name], "bytes_per_launch": nbytes}
         if name in M.get("moved_bytes", {}):
             obj["hbm_bytes_moved"] = M["moved_bytes"][name](N, E)
+        lim = issue_limits(model, name)
+        if lim is not None:
+            obj["issue_limit"] = lim
         return tag(obj)
 
     roof = None
@@ -230,7 +239,10 @@ def rooflines(model, M, prof, kern, G, N, E, steps, split, qmode):
             ach, peak = 3 * work_flops / t_s / 1e12, F16_MFMA_PEAK_TF
             mfma = {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
                     "pipe": "f16 (3 products per fp32 product, fp32 accumulate)", "flops_per_launch": 3 * work_flops,
-                    "fp32_equivalent_tflops": work_flops / t_s / 1e12}
+                    "fp32_equivalent_tflops": work_flops / t_s / 1e12,
+                    # the USEFUL share of the f16 pipe: algorithmic fp32 flops / f16 peak (the other two thirds of `frac` are the
+                    # price of carrying fp32 accuracy through an f16 pipe)
+                    "useful_frac": work_flops / t_s / 1e12 / peak}
         else:
             ach = work_flops / t_s / 1e12
             mfma = {"bound": "mfma", "achieved": ach, "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s",
@@ -272,40 +284,72 @@ def issue_limits(model, kernel):
 
 
 def measure_config(model, batch, steps, warmup, device, sample_graphs=512):
-    """One of the non-headline configurations in the same process: a few timed steps of the resident batch, the HIP-event
-    profile, the dominant kernel's roofline fraction and a parity check of the first `sample_graphs` graphs against the oracle.
-    Compact on purpose (one JSON line carries all of them)."""
+    """One of the non-headline configurations in the same process.  `value` / `ms_per_step` come from `steps` runs of the resident
+    batch bracketed by stream syncs with NO profiling (what a caller gets: dataset-sized batches replay a hipGraph, which HIP events
+    around every launch would switch off -- 167 vs 193 us per step at 4 113 graphs); the kernel times behind `frac` come from a
+    second, HIP-event-profiled pass of the same number of steps (`ms_per_step_profiled`).  Then the stand-alone aggregation probe
+    (`aggregation`), what the committed counter passes say limits the kernel (`limit`, `wait_share`, `hbm_bytes_moved`), and a parity
+    check of the first `sample_graphs` graphs against the oracle.  Compact on purpose (one JSON line carries all of them)."""
     from flowgnn_amd import Engine, weights
     M = MODELS[model]
     w = weights.SYNTH[model](seed=7)
     eng = Engine(model, device=device)
+    agg_ms = None
     try:
         eng.set_weights(w)
         eng.set_batch(batch)
         for _ in range(warmup):
             eng.run()
         eng.sync()
-        eng.profile_enable(True)
         t0 = time.perf_counter()
         for _ in range(steps):
             eng.run()
         eng.sync()
         dt = time.perf_counter() - t0
+        eng.profile_enable(True)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            eng.run()
+        eng.sync()
+        dt_prof = time.perf_counter() - t0
         prof = eng.profile_read()
         eng.profile_enable(False)
         out = eng.results()
         reruns = eng.exact_reruns()
+        try:
+            agg_ms = eng.aggregation_only_ms(layer=0, iters=5)
+        except Exception:  # a model without a stand-alone aggregation kernel (GAT: the layer IS the aggregation)
+            agg_ms = None
     finally:
         eng.close()
     G, N, E = batch.num_graphs, batch.total_nodes, batch.total_edges
     kern = {k: (v["total_ms"] / max(v["launches"], 1)) for k, v in prof.items()}
-    roof, _ = rooflines(model, M, prof, kern, G, N, E, steps, True, False)
+    agg_name = next((k for k in M["hbm_kernels"] if k in kern), M["hbm_kernels"][0])
+    if agg_ms is not None and agg_name not in kern:
+        kern[agg_name] = agg_ms
+    roof, agg = rooflines(model, M, prof, kern, G, N, E, steps, True, False)
     n = min(G, sample_graphs)
     want = np.asarray(oracle_forward(model, batch.slice(0, n), w, effective_cpus()), np.float32)
     par = parity_record(model, out[:n], want)
-    rec = {"value": G * steps / dt, "ms_per_step": dt / steps * 1e3, "graphs": G, "kernel": roof["kernel"] if roof else None,
+    rec = {"value": G * steps / dt, "ms_per_step": dt / steps * 1e3, "ms_per_step_profiled": dt_prof / steps * 1e3, "graphs": G,
+           "kernel": roof["kernel"] if roof else None,
            "avg_ms": roof["avg_ms"] if roof else None, "bound": roof["bound"] if roof else None, "frac": roof["frac"] if roof else None,
            "parity_ok": par["ok"], "max_abs_err": par["max_abs_err"], "exact_reruns": reruns}
+    if roof:
+        lim = roof.get("issue_limit") or {}
+        if lim:  # committed SQ counter pass of this kernel (profiles/limits.json): what binds, and how long its waves are parked
+            rec["limit"] = {"what": lim.get("limit"), "busy": lim.get(lim.get("limit")), "wait_share": lim.get("wait_share"),
+                            "mfma_busy": lim.get("mfma_busy"), "lds_busy": lim.get("lds_busy"), "valu_issue": lim.get("valu_issue")}
+        moved = roof.get("traffic") if roof.get("traffic") is not None else roof.get("hbm_bytes_moved")
+        if moved is not None:
+            rec["hbm_bytes_moved"] = moved
+            rec["hbm_bytes_moved_source"] = "pmc (profiles/traffic.json)" if roof.get("traffic") is not None else "formula"
+        if roof.get("bound") == "hbm":
+            rec["bytes_priced"] = roof.get("bytes_per_launch")
+        if "useful_frac" in roof:
+            rec["useful_frac"] = roof["useful_frac"]
+    if agg and agg.get("kernel") != (roof or {}).get("kernel"):  # the message-passing unit alone (north_star's aggregation roofline)
+        rec["aggregation"] = {"kernel": agg["kernel"], "avg_ms": agg["avg_ms"], "frac": agg["frac"], "bytes": agg["bytes_per_launch"]}
     return {k: (round(v, 4) if isinstance(v, float) and k not in ("value", "max_abs_err") else v) for k, v in rec.items()}
 
 
