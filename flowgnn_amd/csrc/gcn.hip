@@ -16,6 +16,7 @@
 #include "device_common.h"
 #include "modelq.h"
 #include "dense_split.h"
+#include "gin_split.h"  // gin_resident_pack_enc_table: the pre-combined (three rows per node) form of a 173-row table
 #include <cmath>
 #include <cstring>
 
@@ -344,13 +345,163 @@ constexpr int GCNR_LAYER_BYTES = GCNR_W_BYTES + GCNR_BLOB_BYTES;
 static_assert(dense100_split_bytes(GCN_OT) <= (size_t)GCNR_W_BYTES, "weight region");
 static_assert((EDGE_COMBOS + 3) * GCN_D * 4 <= GCNR_BLOB_BYTES, "table region");
 
+// ---------------------------------------------------------------- one-pass front end (round 5): the tile's descriptor straight from the caller's arrays
+// gcn_tile_build_kernel = load_graph (GCN/src/load_inputs.cc:120-166: in-edge tables, out-degree table) + the index part of the atom
+// encoder (:168-215) for ONE tile of whole graphs, as gin_tile_build_kernel is for GIN (gin_split.hip): no global CSR, no x_0 rows in
+// HBM, no separate encoder / index-build launches (0.57 + 0.17 ms of a 5.6 ms step at 2^18 molpcba graphs; the FPGA keeps all of it on
+// chip, GCN/src/GCN_compute.cc:65-98).  One 256-thread workgroup per tile:
+//   * the tile's raw edges (a contiguous slice of edge_list / edge_attr) are validated, turned into (source row, destination row, edge
+//     code) and counting-sorted by destination in LDS; inside a row they are rank-sorted by (source row, input index) -- the CSR's
+//     order (graph_build.hip), whatever order the LDS atomics landed in; out-degrees are counted on the way;
+//   * every node's nine features are validated and turned into three row numbers of the pre-combined PROJECTED table
+//     (gin_resident_pack_enc_table applied to W_0 NodeEmb + b_0: T01 | T234 | T5678, 2 060 rows of 100 floats, L2-resident), so the
+//     resident kernel's tile loader computes x_0 = (T01 + T234) + T5678 itself: the nine-term sum of the projected encoder
+//     re-associated (fp32 rounding only; parity tolerance 1e-4).
+// Descriptor (GCND_BYTES per tile, every byte written on every pass):
+//   [0, 1920) in-edge words u16 x 960: source row << 6 | edge code, CSR order, 0 beyond the tile's edges
+//   [1920, 2308) row offsets u16 x 194 (rows + 1 used; = edge count beyond)   [2320, 2704) out-degrees u16 x 192
+//   [2704, 3472) encoder row numbers u32 x 192: T01 row | T234 row << 9 | T5678 row << 20
+constexpr int GCND_RP = 1920, GCND_ODEG = 2320, GCND_ENC = 2704, GCND_BYTES = 3584;
+constexpr int GCNB_T01 = 0, GCNB_T234 = 476, GCNB_T5678 = 1916;  // first rows of the table's parts (gin_resident_pack_enc_table)
+
+__device__ __forceinline__ int gcnb_wave_inclusive_scan(int x, int lane) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int y = __shfl_up(x, d, 64);
+        if (lane >= d) x += y;
+    }
+    return x;
+}
+
+__global__ __launch_bounds__(256) void gcn_tile_build_kernel(BatchView b, const int* __restrict__ tile_row, const int* __restrict__ tile_graph,
+                                                             uint8_t* __restrict__ desc, int n_tiles, int* __restrict__ err) {
+    constexpr int EPT = (GCNR_EDGES + 255) / 256;  // edges per thread
+    __shared__ int s_eoff[GCNR_ROWS + 1], s_noff[GCNR_ROWS + 1];  // edge / row offsets of the tile's graphs, relative to the tile
+    __shared__ int s_cnt[257], s_cur[256], s_odeg[256];
+    __shared__ unsigned s_bucket[GCNR_EDGES];
+    __shared__ int s_feat[GCNR_ROWS * ND_FEATURE];
+    __shared__ int s_wtot[4];
+    const int tile = blockIdx.x;
+    if (tile >= n_tiles) return;
+    const int r = threadIdx.x, lane = r & 63, wv = r >> 6;
+    const int t0 = tile_row[tile];
+    int rows = tile_row[tile + 1] - t0;
+    if (rows > GCNR_ROWS) rows = GCNR_ROWS;
+    const int g0 = tile_graph[tile];
+    int ng = tile_graph[tile + 1] - g0;
+    if (ng > GCNR_ROWS) ng = GCNR_ROWS;  // every graph has at least one node: a validated tile never has more graphs than rows
+    const int e0 = b.edge_off[g0];
+    int ne = b.edge_off[g0 + ng] - e0;
+    if (ne > GCNR_EDGES) ne = GCNR_EDGES;  // cannot happen for a batch packed by flowgnn_set_batch; never overrun LDS
+    for (int i = r; i <= ng; i += 256) {
+        s_eoff[i] = b.edge_off[g0 + i] - e0;
+        s_noff[i] = b.node_off[g0 + i] - t0;
+    }
+    s_cnt[r] = 0;
+    s_cur[r] = 0;
+    s_odeg[r] = 0;
+    if (r == 0) s_cnt[256] = 0;
+    for (int i = r; i < GCNR_ROWS * ND_FEATURE; i += 256)  // the tile's node features, coalesced
+        s_feat[i] = i < rows * ND_FEATURE ? b.node_feature[(size_t)t0 * ND_FEATURE + i] : 0;
+    __syncthreads();
+    unsigned ekey[EPT];  // (source row << 17) | (edge index inside the tile << 6) | edge code
+    int edst[EPT];       // destination row, -1 = no edge
+#pragma unroll
+    for (int k = 0; k < EPT; k++) {
+        const int i = r + 256 * k;
+        edst[k] = -1;
+        ekey[k] = 0;
+        if (i < ne) {
+            const int2 uv = reinterpret_cast<const int2*>(b.edge_list)[e0 + i];
+            const int a0 = b.edge_attr[3 * (size_t)(e0 + i)], a1 = b.edge_attr[3 * (size_t)(e0 + i) + 1], a2 = b.edge_attr[3 * (size_t)(e0 + i) + 2];
+            int lo = 0, hi = ng - 1;  // the graph of edge i: the last one whose first edge is <= i
+            while (lo < hi) {
+                const int mid = (lo + hi + 1) >> 1;
+                if (s_eoff[mid] <= i) lo = mid; else hi = mid - 1;
+            }
+            const int base = s_noff[lo], n = s_noff[lo + 1] - base;
+            int u = uv.x, v = uv.y;
+            if (!((u >= 0) & (u < n) & (v >= 0) & (v < n))) {  // flag it, then treat as a self-loop on node 0 (as build_csr does)
+                atomicMax(err, ERR_EDGE_RANGE);
+                u = 0;
+                v = 0;
+            }
+            const bool aok = (a0 >= 0) & (a0 < 5) & (a1 >= 0) & (a1 < 6) & (a2 >= 0) & (a2 < 2);  // cardinalities {5,6,2}: GCN/src/host_load.cc
+            if (!aok) atomicMax(err, ERR_EDGE_ATTR);
+            const unsigned code = aok ? (unsigned)((a0 * 6 + a1) * 2 + a2) : 0u;
+            edst[k] = base + v;
+            ekey[k] = ((unsigned)(base + u) << 17) | ((unsigned)i << 6) | code;
+            atomicAdd(&s_cnt[base + v], 1);
+            atomicAdd(&s_odeg[base + u], 1);  // degree_table: out-degree (load_inputs.cc:120)
+        }
+    }
+    __syncthreads();
+    const int deg = s_cnt[r];  // rows beyond the tile's last have none
+    {
+        const int incl = gcnb_wave_inclusive_scan(deg, lane);
+        if (lane == 63) s_wtot[wv] = incl;
+        __syncthreads();
+        int start = incl - deg;
+        for (int w = 0; w < wv; w++) start += s_wtot[w];
+        s_cnt[r] = start;
+        if (r == 255) s_cnt[256] = start + deg;  // = ne
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < EPT; k++)
+        if (edst[k] >= 0) s_bucket[s_cnt[edst[k]] + atomicAdd(&s_cur[edst[k]], 1)] = ekey[k];
+    __syncthreads();
+    uint8_t* d = desc + (size_t)tile * GCND_BYTES;
+    uint16_t* d_edge = reinterpret_cast<uint16_t*>(d);
+    uint16_t* d_rp = reinterpret_cast<uint16_t*>(d + GCND_RP);
+    uint16_t* d_od = reinterpret_cast<uint16_t*>(d + GCND_ODEG);
+    uint32_t* d_enc = reinterpret_cast<uint32_t*>(d + GCND_ENC);
+#pragma unroll
+    for (int k = 0; k < EPT; k++) {
+        const int i = r + 256 * k;
+        if (edst[k] >= 0) {
+            const int beg = s_cnt[edst[k]], end = s_cnt[edst[k] + 1];
+            const unsigned mine = ekey[k] >> 6;
+            int rank = 0;
+            for (int t = beg; t < end; t++) rank += (s_bucket[t] >> 6) < mine;
+            d_edge[beg + rank] = (uint16_t)(((ekey[k] >> 17) << 6) | (ekey[k] & 63u));
+        } else if (i < GCNR_EDGES) {
+            d_edge[i] = 0;  // slots [ne, 960): every valid edge lands in [0, ne), so these are exactly the unused ones
+        }
+    }
+    if (r < GCNR_ROWS + 2) d_rp[r] = (uint16_t)s_cnt[r < 256 ? r : 256];
+    if (r < GCNR_ROWS) {
+        d_od[r] = (uint16_t)s_odeg[r];
+        unsigned word = 0;
+        if (r < rows) {  // the node's rows of the pre-combined projected table (validated: table cardinalities, GCN/src/host_load.cc)
+            int f[ND_FEATURE];
+#pragma unroll
+            for (int k = 0; k < ND_FEATURE; k++) {
+                f[k] = s_feat[r * ND_FEATURE + k];
+                if (f[k] < 0 || f[k] >= c_nd_card[k]) {
+                    atomicMax(err, ERR_NODE_FEAT);
+                    f[k] = 0;
+                }
+            }
+            const unsigned i0 = f[0] * 4 + f[1], i1 = (f[2] * 12 + f[3]) * 10 + f[4], i2 = ((f[5] * 6 + f[6]) * 2 + f[7]) * 2 + f[8];
+            word = i0 | (i1 << 9) | (i2 << 20);
+        }
+        d_enc[r] = word;
+    }
+}
+
+template <bool ONEPASS>
 __global__ __launch_bounds__(GCNR_WAVES * 64, 3) void gcn_resident_kernel(const float* __restrict__ x0, const int* __restrict__ row_ptr,
                                                                          const int* __restrict__ src, const uint8_t* __restrict__ ecode,
                                                                          const int* __restrict__ out_deg, const uint8_t* __restrict__ layers,
                                                                          const float* __restrict__ pool_w, const float* __restrict__ pool_b,
                                                                          const int* __restrict__ tile_row, const int* __restrict__ tile_graph,
                                                                          const int* __restrict__ node_off, float* __restrict__ out, int n_tiles,
-                                                                         int* __restrict__ range_flag, int ablate_arg) {
+                                                                         int* __restrict__ range_flag, int ablate_arg,
+                                                                         const uint8_t* __restrict__ desc, const float4* __restrict__ enc_tab) {
+    // ONEPASS (the default front end since round 5): no x0 / row_ptr / src / ecode / out_deg -- the tile's CSR slice, out-degrees and
+    // encoder row numbers come from gcn_tile_build_kernel's descriptor, and the loader computes the tile's x_0 rows itself from the
+    // pre-combined projected table (three 400-B rows per node out of L2 instead of one out of HBM that another launch wrote).
     const int ablate = FG_ABLATE(ablate_arg);  // 0 in the shipped build: the branches below fold away (common.h)
     (void)ablate_arg;
     constexpr int OT = GCN_OT, NT = GCNR_WAVES * 64;
@@ -369,14 +520,18 @@ __global__ __launch_bounds__(GCNR_WAVES * 64, 3) void gcn_resident_kernel(const 
     // the readout's weights, staged once per workgroup: read from global memory in the last layer, hipcc issued the seven loads one
     // at a time, each behind a vmcnt(0) -- seven serialized L2 round trips per tile
     __shared__ __attribute__((aligned(16))) float s_pw[GCN_D];
+    __shared__ __attribute__((aligned(16))) uint32_t s_nidx[ONEPASS ? GCNR_ROWS : 4];  // ONEPASS: encoder row numbers of the NEXT tile's rows
     const bool sort_rows = !(ablate & 4);  // development aid: gcn_ablate, -DFLOWGNN_DEV builds=4 keeps rows in natural order
-    const int lane = threadIdx.x & 63;
+    const int lane0 = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int j = lane & 15, g = lane >> 4;
     const float* s_ecomb = reinterpret_cast<const float*>(s_blob);
     const float* s_ep = s_ecomb + EDGE_COMBOS * GCN_D;
     const uint32_t x_addr = lds_addr_of(s_x), w_addr = lds_addr_of(s_w), blob_addr = lds_addr_of(s_blob);
     float vmax = 0.0f;
+    // ONEPASS: the lane index is re-derived (opaque) at the top of every tile.  Left visible, hipcc computes every lane-dependent
+    // address of the kernel once, in front of the tile loop, and holds ~60 of them in registers for the whole launch: nothing is
+    // free at the tile boundary, where the loader wants 48 registers of table segments in flight (it spilled 568 B).
+    int lane = lane0;
     int tile = blockIdx.x;
     if (tile >= n_tiles) return;
     if ((int)threadIdx.x < GCN_D) s_pw[threadIdx.x] = pool_w[threadIdx.x];  // (read behind the tile loop's first barriers)
@@ -384,17 +539,23 @@ __global__ __launch_bounds__(GCNR_WAVES * 64, 3) void gcn_resident_kernel(const 
     int t0 = tile_row[tile], rows = tile_row[tile + 1] - t0;
     if (rows > GCNR_ROWS) rows = GCNR_ROWS;
     int g0 = tile_graph[tile], g1 = tile_graph[tile + 1];
-    int e0 = row_ptr[t0], ne = row_ptr[t0 + rows] - e0;
-    if (ne > GCNR_EDGES) ne = GCNR_EDGES;  // cannot happen for a validated batch (the host packed by edge count)
+    int e0 = 0, ne = GCNR_EDGES;  // ONEPASS: the descriptor's 960 edge words are all valid to copy (zeros beyond the tile's edges)
+    if (!ONEPASS) {
+        e0 = row_ptr[t0];
+        ne = row_ptr[t0 + rows] - e0;
+        if (ne > GCNR_EDGES) ne = GCNR_EDGES;  // cannot happen for a validated batch (the host packed by edge count)
+    }
     // a tile's rows of x_0 and layer 0's table come by LDS-DMA (requested as soon as the previous tile's last gather is done); its CSR
     // slice and degrees travel through registers: requested during the previous tile's middle layers, stored to LDS when that tile is done
     auto issue_rows = [&](int ft0, int frows) {
-        const int np = (frows * (GCN_D * 4) + 1023) >> 10;  // <= 75 pieces of 1 KiB
-        const char* gb = reinterpret_cast<const char*>(x0) + (size_t)ft0 * (GCN_D * 4);
+        if (!ONEPASS) {
+            const int np = (frows * (GCN_D * 4) + 1023) >> 10;  // <= 75 pieces of 1 KiB
+            const char* gb = reinterpret_cast<const char*>(x0) + (size_t)ft0 * (GCN_D * 4);
 #pragma unroll
-        for (int p = 0; p < 7; p++) {
-            const int piece = wv + GCNR_WAVES * p;
-            if (piece < np) lds_dma16(gb + (size_t)piece * 1024, (uint32_t)lane * 16u, x_addr + piece * 1024);
+            for (int p = 0; p < 7; p++) {
+                const int piece = wv + GCNR_WAVES * p;
+                if (piece < np) lds_dma16(gb + (size_t)piece * 1024, (uint32_t)lane * 16u, x_addr + piece * 1024);
+            }
         }
 #pragma unroll
         for (int p = 0; p < 3; p++) {
@@ -403,7 +564,20 @@ __global__ __launch_bounds__(GCNR_WAVES * 64, 3) void gcn_resident_kernel(const 
         }
     };
     int epre0 = 0, epre1 = 0, rpre = 0, dpre = 0;
-    auto fetch_csr = [&](int ft0, int frows, int fe0, int fne) {
+    // ONEPASS: the encoder row numbers of this thread's seven float4 slots of the next tile's rows (slot n = thread + 768 k: chunk
+    // n mod 25 of row n / 25), and the 21 table segments they select
+    constexpr int XK = (GCNR_ROWS * GCN_C + NT - 1) / NT;  // 7
+    float4 xa[XK], xb[XK], xc[XK];
+    auto fetch_csr = [&](int ft0, int frows, int fe0, int fne, int ftile) {
+        if (ONEPASS) {
+            const uint8_t* d = desc + (size_t)ftile * GCND_BYTES;
+            const uint16_t* de = reinterpret_cast<const uint16_t*>(d);
+            epre0 = de[threadIdx.x];
+            if ((int)threadIdx.x + NT < GCNR_EDGES) epre1 = de[threadIdx.x + NT];
+            if ((int)threadIdx.x < GCNR_ROWS + 2) rpre = reinterpret_cast<const uint16_t*>(d + GCND_RP)[threadIdx.x];
+            if ((int)threadIdx.x < GCNR_ROWS) dpre = reinterpret_cast<const uint16_t*>(d + GCND_ODEG)[threadIdx.x];
+            return;
+        }
         if ((int)threadIdx.x < fne) epre0 = (((src[fe0 + threadIdx.x] - ft0) & 255) << 6) | (ecode[fe0 + threadIdx.x] & 63);
         if ((int)threadIdx.x + NT < fne) epre1 = (((src[fe0 + threadIdx.x + NT] - ft0) & 255) << 6) | (ecode[fe0 + threadIdx.x + NT] & 63);
         if ((int)threadIdx.x <= frows) {
@@ -412,37 +586,94 @@ __global__ __launch_bounds__(GCNR_WAVES * 64, 3) void gcn_resident_kernel(const 
         }
         if ((int)threadIdx.x < frows) dpre = out_deg[ft0 + threadIdx.x];
     };
+    // The row numbers come by LDS-DMA (768 B = 48 lanes of one piece) into s_nidx at the top of the tile BEFORE the one they belong to:
+    // no register carries them through the layers (seven more live registers through the dense phases spilled), and everything the
+    // loader defines it defines unconditionally (a conditional definition inside the tile loop is a phi with the previous tile's
+    // value: 84 registers "live" around the whole loop).
+    auto opaque_tid = [&]() {
+        unsigned t = threadIdx.x;
+        asm volatile("" : "+v"(t));
+        return t;
+    };
+    auto issue_idx = [&](int ftile) {
+        if (wv == GCNR_WAVES - 1 && lane < 48)
+            lds_dma16(desc + (size_t)ftile * GCND_BYTES + GCND_ENC, (uint32_t)lane * 16u, lds_addr_of(s_nidx));
+    };
+    // ONEPASS x_0: request the table segments of this thread's slots (L2 hits), then -- once the tile's rows are dead -- add and store.
+    // In two halves (slots 0-3, then 4-6): all 21 segments at once are 84 registers across the tile's last barrier, which spilled.
+    constexpr int XH = 4;
+    auto x0_request = [&](int k0, int k1) {
+        const unsigned tid = opaque_tid();
+#pragma unroll
+        for (int k = 0; k < XK; k++) {
+            if (k < k0 || k >= k1) continue;
+            const unsigned n = tid + NT * k;
+            const unsigned row = (n * 5243u) >> 17, c = n - 25u * row;
+            const uint32_t w = s_nidx[row < (unsigned)GCNR_ROWS ? row : 0u];
+            xa[k] = enc_tab[((unsigned)GCNB_T01 + (w & 511u)) * 25u + c];
+            xb[k] = enc_tab[((unsigned)GCNB_T234 + ((w >> 9) & 2047u)) * 25u + c];
+            xc[k] = enc_tab[((unsigned)GCNB_T5678 + (w >> 20)) * 25u + c];
+        }
+    };
+    auto x0_store = [&](int frows, int k0, int k1) {
+        const int tid = (int)opaque_tid();
+#pragma unroll
+        for (int k = 0; k < XK; k++) {
+            if (k < k0 || k >= k1) continue;
+            const int n = tid + NT * k;
+            if (n < frows * GCN_C)
+                reinterpret_cast<float4*>(s_x)[n] = make_float4((xa[k].x + xb[k].x) + xc[k].x, (xa[k].y + xb[k].y) + xc[k].y,
+                                                                (xa[k].z + xb[k].z) + xc[k].z, (xa[k].w + xb[k].w) + xc[k].w);
+        }
+    };
     static_assert(GCNR_EDGES <= 2 * NT, "two CSR words per thread");
+    static_assert(GCNR_ROWS * GCN_C <= 5376 && XK * NT <= 5376 + NT, "n / 25 by multiply-shift");
     // (The CSR words are CONSUMED -- an empty asm that names them -- before the rows are requested: hipcc then waits for them there,
     // where they have long landed, and not at the top of the tile loop, where the same vmcnt(0) would also wait for the 75 KiB of
     // rows requested after them: the tile's CSR staging and row sort now run under that transfer.  Launch 4.92 -> see DESIGN section 4.)
-    fetch_csr(t0, rows, e0, ne);
+    fetch_csr(t0, rows, e0, ne, tile);
     asm volatile("" : "+v"(epre0), "+v"(epre1), "+v"(rpre), "+v"(dpre));
     issue_rows(t0, rows);
+    if (ONEPASS) {
+        issue_idx(tile);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        x0_request(0, XH);
+        x0_store(rows, 0, XH);
+        x0_request(XH, XK);  // (stored at the top of the tile loop, as for every later tile)
+        __syncthreads();     // every wave has read its row numbers: the loop's first act is to request the NEXT tile's into s_nidx
+    }
     while (true) {
+        if (ONEPASS) {
+            lane = lane0;
+            asm volatile("" : "+v"(lane));
+        }
+        const int j = lane & 15, g = lane >> 4;
+        const int tid = ONEPASS ? wv * 64 + lane : (int)threadIdx.x;
         const int ntile = tile + gridDim.x;
         const bool has_next = ntile < n_tiles;
         int nt0 = 0, nrows = 0, ng0 = 0, ng1 = 0, ne0 = 0, nne = 0;
-        if ((int)threadIdx.x < ne) s_edge[threadIdx.x] = (uint16_t)epre0;
-        if ((int)threadIdx.x + NT < ne) s_edge[threadIdx.x + NT] = (uint16_t)epre1;
-        if ((int)threadIdx.x <= rows) s_rp[threadIdx.x] = (uint16_t)rpre;
-        if ((int)threadIdx.x < rows) {
-            s_dinv[threadIdx.x] = dpre > 0 ? 1.0f / sqrtf((float)(dpre + 1)) : 0.0f;  // load_inputs.cc:122
-            s_idp1[threadIdx.x] = 1.0f / (float)(dpre + 1);
+        if (tid < ne) s_edge[tid] = (uint16_t)epre0;  // (ONEPASS: ne = 960, the descriptor has zeros beyond the tile's edges)
+        if (tid + NT < ne) s_edge[tid + NT] = (uint16_t)epre1;
+        if (tid <= rows) s_rp[tid] = (uint16_t)rpre;
+        if (tid < rows) {
+            s_dinv[tid] = dpre > 0 ? 1.0f / sqrtf((float)(dpre + 1)) : 0.0f;  // load_inputs.cc:122
+            s_idp1[tid] = 1.0f / (float)(dpre + 1);
         }
-        if (threadIdx.x < 16) { s_cnt[threadIdx.x] = 0; s_cur[threadIdx.x] = 0; }
+        if (tid < 16) { s_cnt[tid] = 0; s_cur[tid] = 0; }
+        if (ONEPASS) issue_idx(has_next ? ntile : tile);  // (its last readers were the previous tile's closing requests, a barrier ago)
         __syncthreads();
-        int skey = 15;  // in-degree class of row threadIdx.x: 0 = longest (>= 14 in-edges) .. 14 = none, 15 = no such row
-        if (threadIdx.x < GCNR_ROWS) {
-            if ((int)threadIdx.x < rows) {
-                const int deg = (int)s_rp[threadIdx.x + 1] - (int)s_rp[threadIdx.x];
+        int skey = 15;  // in-degree class of row tid: 0 = longest (>= 14 in-edges) .. 14 = none, 15 = no such row
+        if (tid < GCNR_ROWS) {
+            if (tid < rows) {
+                const int deg = (int)s_rp[tid + 1] - (int)s_rp[tid];
                 skey = 14 - (deg < 14 ? deg : 14);
             }
             if (sort_rows) atomicAdd(&s_cnt[skey], 1);
         }
         __syncthreads();
-        if (threadIdx.x < GCNR_ROWS) {
-            int pos = threadIdx.x;
+        if (tid < GCNR_ROWS) {
+            int pos = tid;
             if (sort_rows) {
                 pos = atomicAdd(&s_cur[skey], 1);
                 // (the 15 class counts as four 16-byte reads and selects: `for (k < skey) pos += s_cnt[k]` was an LDS round trip per class)
@@ -455,8 +686,9 @@ __global__ __launch_bounds__(GCNR_WAVES * 64, 3) void gcn_resident_kernel(const 
 #pragma unroll
                 for (int k = 0; k < 15; k++) pos += k < skey ? cc[k] : 0;
             }
-            s_perm[pos] = (uint8_t)threadIdx.x;
+            s_perm[pos] = (uint8_t)tid;
         }
+        if (ONEPASS) x0_store(rows, XH, XK);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of the tile's rows and of layer 0's table
         __syncthreads();
         const int r = s_perm[wv * 16 + j];
@@ -468,7 +700,7 @@ __global__ __launch_bounds__(GCNR_WAVES * 64, 3) void gcn_resident_kernel(const 
 #pragma unroll
         for (int mk = 1; mk < 64; mk <<= 1) trips = max(trips, __shfl_xor(trips, mk, 64));
         trips = __builtin_amdgcn_readfirstlane(trips);
-        const int ro_gi = g0 + (int)threadIdx.x;
+        const int ro_gi = g0 + tid;
         int ro_n0 = 0, ro_n1 = 1;
 #pragma unroll 1
         for (int l = 0; l < GCN_L; l++) {
@@ -477,11 +709,15 @@ __global__ __launch_bounds__(GCNR_WAVES * 64, 3) void gcn_resident_kernel(const 
                 nrows = tile_row[ntile + 1] - nt0;
                 if (nrows > GCNR_ROWS) nrows = GCNR_ROWS;
                 ng0 = tile_graph[ntile]; ng1 = tile_graph[ntile + 1];
-                ne0 = row_ptr[nt0];
-                nne = row_ptr[nt0 + nrows] - ne0;
-                if (nne > GCNR_EDGES) nne = GCNR_EDGES;
+                if (!ONEPASS) {
+                    ne0 = row_ptr[nt0];
+                    nne = row_ptr[nt0 + nrows] - ne0;
+                    if (nne > GCNR_EDGES) nne = GCNR_EDGES;
+                } else {
+                    nne = GCNR_EDGES;
+                }
             }
-            if (l == 2 && has_next) fetch_csr(nt0, nrows, ne0, nne);
+            if (l == 2 && has_next) fetch_csr(nt0, nrows, ne0, nne, ntile);
             // ---- m_l[v] = sum over in-edges of norm relu(x_l[u] + ecomb[code]) (message_passing.cc:158-167), CSR order, all from LDS
             const float* xr = s_x + rr * GCN_D + 4 * g;
             float4 xs[6];
@@ -636,9 +872,16 @@ __global__ __launch_bounds__(GCNR_WAVES * 64, 3) void gcn_resident_kernel(const 
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();  // #2: x_{l+1} is complete, the next table has landed
         }
+        // ONEPASS: this wave is done with the tile's rows; the next tile's table segments travel while the slower waves finish their
+        // walks (the registers of the walk and the BatchNorm are free now), and are stored behind the barrier
+        if (ONEPASS) x0_request(0, XH);  // (unconditional: behind the last tile the numbers are that tile's own again -- valid rows, never stored)
         __syncthreads();  // the per-node readout terms are in s_dot; the rows and the table are dead
         asm volatile("" : "+v"(epre0), "+v"(epre1), "+v"(rpre), "+v"(dpre), "+v"(ro_n0), "+v"(ro_n1));  // (see the prologue)
         if (has_next) issue_rows(nt0, nrows);
+        if (ONEPASS) {
+            x0_store(nrows, 0, XH);  // (nrows = 0 behind the last tile)
+            x0_request(XH, XK);  // the second half travels under the readout, the CSR staging and the row sort of the next tile
+        }
         if (ro_gi < g1) out[ro_gi] = lds_sum_in_order(s_dot + (ro_n0 - t0), ro_n1 - ro_n0) / (float)(ro_n1 - ro_n0) + pool_bias;
         if (!has_next) break;
         tile = ntile; t0 = nt0; rows = nrows; g0 = ng0; g1 = ng1; e0 = ne0; ne = nne;
@@ -725,6 +968,10 @@ public:
                     proj[(size_t)r * GCN_D + o] = (float)a;
                 }
             if ((rc = upload(&d_nemb_proj_, proj))) return rc;
+            // ... and its pre-combined form for the one-pass front end (x_0 = (T01 + T234) + T5678: gcn_tile_build_kernel)
+            std::vector<float> comb(gin_resident_enc_table_floats());
+            gin_resident_pack_enc_table(proj.data(), comb.data());
+            if ((rc = upload(&d_enc_tab_, comb))) return rc;
         }
         {   // the graph-resident kernel's per-layer stream: [W_l split fragments, 45 KiB][ecomb_l | root_l | BN scale_l | BN shift_l, 25 KiB]
             std::vector<uint8_t> res((size_t)GCN_L * GCNR_LAYER_BYTES + 4096, 0);
@@ -819,25 +1066,48 @@ public:
     }
     void set_keep_h(bool on) override { keep_h_ = on; }
 
+    // x_0 by the encoder, then everything else in one launch when the batch packs into graph tiles (tiles under half full waste MFMA
+    // columns: the per-layer kernels take those; so do per-node taps and the multi-task readout)
+    bool use_resident(const DeviceBatch& db) const {
+        return resident_ && !qmode_ && !keep_h_ && split_ && !exact_ && fused_ && num_tasks_ == 1 && db.gtiles.ok && db.gtiles.n_tiles > 0 &&
+               db.gtiles.fill >= 0.5;
+    }
+    // the one-pass front end (gcn_tile_build_kernel + the resident kernel's own encoder): the default; gcn_tile_build = 0 restores the
+    // three-launch front end (index build, projected encoder, resident kernel)
+    bool one_pass(const DeviceBatch& db) const { return tile_build_ && use_resident(db) && db.b.edge_attr != nullptr; }
+    bool needs_csr(const DeviceBatch& db) const override { return !one_pass(db); }
+
     int forward(DeviceBatch& db, Profiler& prof, hipStream_t s) override {
         const int n = db.b.n_tot;
         if (n <= 0) return 0;
         agg_ready_ = false;  // tiles_ / esc_ are rebuilt by whichever float path runs below; a fixed-point pass leaves none
+        x0_in_hbm_ = !qmode_ && !(use_resident(db) && one_pass(db));
         if (qmode_) return gcnq_forward(q_, db, prof, s);
-        // x_0 by the encoder + dense kernel, then everything else in one launch when the batch packs into graph tiles (tiles under
-        // half full waste MFMA columns: the per-layer kernels take those; so do per-node taps and the multi-task readout)
-        if (resident_ && !keep_h_ && split_ && !exact_ && fused_ && num_tasks_ == 1 && db.gtiles.ok && db.gtiles.n_tiles > 0 &&
-            db.gtiles.fill >= 0.5) {
-            {
-                ProfScope p(prof, "gcn_encoder_projected", s);  // x_0 from the projected table (set_weights)
-                atom_encoder_kernel<GCN_D><<<atom_encoder_grid(n, GCN_C), 512, 0, s>>>(db.b.node_feature, d_nemb_proj_, db.h[0], n, db.csr.err);
-            }
-            ProfScope p(prof, "gcn_resident", s);
+        if (use_resident(db)) {
             const int grid = db.gtiles.n_tiles < 256 ? db.gtiles.n_tiles : 256;  // persistent: one 12-wave workgroup per CU (153 KB of LDS)
-            gcn_resident_kernel<<<grid, GCNR_WAVES * 64, 0, s>>>(db.h[0], db.csr.row_ptr, db.csr.src, db.csr.ecode, db.csr.out_deg, d_res_, d_pw_,
-                                                               d_pb_, db.gtiles.row_start, db.gtiles.graph_start, db.b.node_off, db.out,
-                                                               db.gtiles.n_tiles, db.range_flag,
-                                                               ablate_);
+            if (one_pass(db)) {  // two launches: descriptors from the caller's arrays, then everything else (no CSR, no x_0 in HBM)
+                if (int rc = desc_.reserve(((size_t)db.gtiles.n_tiles * GCND_BYTES + 3) / 4)) return rc;
+                {
+                    ProfScope p(prof, "gcn_tile_build", s);
+                    gcn_tile_build_kernel<<<db.gtiles.n_tiles, 256, 0, s>>>(db.b, db.gtiles.row_start, db.gtiles.graph_start,
+                                                                            reinterpret_cast<uint8_t*>(desc_.p), db.gtiles.n_tiles, db.csr.err);
+                }
+                ProfScope p(prof, "gcn_resident", s);
+                gcn_resident_kernel<true><<<grid, GCNR_WAVES * 64, 0, s>>>(nullptr, nullptr, nullptr, nullptr, nullptr, d_res_, d_pw_, d_pb_,
+                                                                          db.gtiles.row_start, db.gtiles.graph_start, db.b.node_off, db.out,
+                                                                          db.gtiles.n_tiles, db.range_flag, ablate_,
+                                                                          reinterpret_cast<const uint8_t*>(desc_.p),
+                                                                          reinterpret_cast<const float4*>(d_enc_tab_));
+            } else {
+                {
+                    ProfScope p(prof, "gcn_encoder_projected", s);  // x_0 from the projected table (set_weights)
+                    atom_encoder_kernel<GCN_D><<<atom_encoder_grid(n, GCN_C), 512, 0, s>>>(db.b.node_feature, d_nemb_proj_, db.h[0], n, db.csr.err);
+                }
+                ProfScope p(prof, "gcn_resident", s);
+                gcn_resident_kernel<false><<<grid, GCNR_WAVES * 64, 0, s>>>(db.h[0], db.csr.row_ptr, db.csr.src, db.csr.ecode, db.csr.out_deg, d_res_, d_pw_,
+                                                                           d_pb_, db.gtiles.row_start, db.gtiles.graph_start, db.b.node_off, db.out,
+                                                                           db.gtiles.n_tiles, db.range_flag, ablate_, nullptr, nullptr);
+            }
             agg_ready_ = false;
             db.final_h = 0;
             db.h_valid = false;  // h[0] holds x_0, not x_4: flowgnn_get_h repeats the pass on the per-layer kernels
@@ -927,6 +1197,7 @@ public:
         split_ = o.i("gcn_mfma") != 32;
         fused_ = !o.on("gcn_unfused");
         resident_ = o.on("gcn_resident");
+        tile_build_ = o.i("gcn_tile_build") != 0;
         ablate_ = FG_ABLATE(o.i("gcn_ablate"));
         agg_ready_ = false;
     }
@@ -939,24 +1210,34 @@ public:
             Profiler none;
             if (int rc = prepare_aggregate(db, none, s)) return rc;
         }
+        if (!x0_in_hbm_) {  // ... behind the one-pass front end: no rows in HBM at all -- the probe reads x_0
+            atom_encoder_kernel<GCN_D><<<atom_encoder_grid(db.b.n_tot, GCN_C), 512, 0, s>>>(db.b.node_feature, d_nemb_proj_, db.h[0], db.b.n_tot, db.csr.err);
+            db.final_h = 0;
+            x0_in_hbm_ = true;
+        }
         launch_aggregate<true>(db, layer, db.h[db.final_h], db.scratch, s);
         return 0;
     }
 
 private:
     void free_all() {
-        float** ptrs[] = {&d_nemb_, &d_nemb_proj_, &d_pw_, &d_pb_, &d_ecomb_, &d_ep_, &d_wf_, &d_wt_, &d_bp_};
+        float** ptrs[] = {&d_nemb_, &d_nemb_proj_, &d_enc_tab_, &d_pw_, &d_pb_, &d_ecomb_, &d_ep_, &d_wf_, &d_wt_, &d_bp_};
         for (auto p : ptrs)
             if (*p) { (void)hipFree(*p); *p = nullptr; }
         if (d_split_) { (void)hipFree(d_split_); d_split_ = nullptr; }
         if (d_res_) { (void)hipFree(d_res_); d_res_ = nullptr; }
         esc_.release();
         tiles_.release();
+        desc_.release();
         q_.release();
     }
     bool ready_ = false;
     bool qmode_ = false;  // flowgnn_set_numeric_mode(FLOWGNN_NUMERIC_Q6_10)
     QPack q_;
+    GrowBufI desc_;               // gcn_tile_build_kernel: GCND_BYTES per graph tile
+    float* d_enc_tab_ = nullptr;  // the projected table pre-combined into three rows per node (gin_resident_pack_enc_table)
+    bool x0_in_hbm_ = false;      // db.h[..] holds rows of the resident batch (false behind the one-pass front end and the fixed-point pass)
+    bool tile_build_ = true;      // gcn_tile_build = 0: index build + projected encoder as separate launches in front of the resident kernel
     int num_tasks_ = 1;  // NUM_TASK (GCN/src/dcl.h) as a run-time dimension
     GrowBuf esc_;
     GrowBufI tiles_;  // graph-aligned tile starts of the resident batch (tile_bounds_kernel)

@@ -6,7 +6,7 @@ end: `vmcnt(8)` / `vmcnt(6)`, gin_split.hip) the wait covers the transfer only w
 This test compiles the kernels' files to gfx950 assembly (no GPU needed), follows every request along every control-flow path to
 the wait that covers it, and compares with the committed snapshot: a compiler upgrade or an edit that moves a load across a request
 changes the (M, K) list or turns a cover into a carry, and the snapshot must then be regenerated AND re-read:
-    python scripts/dev/dma_lint.py --json /tmp/dma_lint/*.s > tests/golden/dma_lint.json"""
+    KEEP_DMA_LINT_ASM=1 python -m pytest tests/test_dma_lint.py; python scripts/dev/dma_lint.py --json /tmp/dma_lint/*.s > tests/golden/dma_lint.json"""
 import json
 import os
 import shutil
@@ -35,6 +35,8 @@ def test_every_lds_dma_request_is_covered_as_in_the_snapshot(tmp_path):
 
     with ThreadPoolExecutor(len(FILES)) as ex:
         paths = list(ex.map(asm, FILES))
+    if os.environ.get("KEEP_DMA_LINT_ASM"):  # for regenerating the snapshot (docstring)
+        shutil.copytree(tmp_path, "/tmp/dma_lint", dirs_exist_ok=True)
     got = {os.path.basename(p): json.loads(json.dumps(dma_lint.snapshot(p))) for p in paths}
     want = json.load(open(os.path.join(ROOT, "tests", "golden", "dma_lint.json")))
     # the rule itself, whatever the snapshot says: every request meets a covering wait on every path that does not end the wave
@@ -43,5 +45,3 @@ def test_every_lds_dma_request_is_covered_as_in_the_snapshot(tmp_path):
             assert r["covers_vmcnt0"] + len(r["counted"]) > 0, (f, k)
             assert all(K >= M for M, K in r["counted"]), (f, k, r["counted"])
     assert got == want, "LDS-DMA coverage moved: re-read the kernels' waits, then regenerate tests/golden/dma_lint.json (docstring)"
-    if os.environ.get("KEEP_DMA_LINT_ASM"):
-        shutil.copytree(tmp_path, "/tmp/dma_lint", dirs_exist_ok=True)
