@@ -369,9 +369,32 @@ __device__ __forceinline__ void pna_slice_add(PnaSlice& a, const float2& x) {
 __device__ __forceinline__ void pna_slice_edge(PnaSlice& a, const float* __restrict__ s_h, int u, int col) {
     pna_slice_add(a, *reinterpret_cast<const float2*>(s_h + u * PNA_FT_STRIDE + col));
 }
+// a finished slice -> the K-step's B operand: mean = S / indeg (0 -> 1), std = sqrt(relu(Q / indeg - mean^2)) (node_embedding.cc:123,143-145)
+__device__ __forceinline__ void pna_slice_finish(const PnaSlice& a, int indeg, ds_uint4_t& b_hi, ds_uint4_t& b_lo, float& vmax) {
+    // mean = S / indeg (0 -> 1), std = sqrt(relu(Q / indeg - mean^2))   (node_embedding.cc:123,143-145)
+    // 1 / indeg and the square root as single instructions (v_rcp_f32, v_sqrt_f32: 1 ulp): four IEEE divisions and two IEEE square
+    // roots per slice are ~60 dependent VALU instructions, and at two waves per SIMD nothing hides their latency
+    const float rdeg = __builtin_amdgcn_rcpf((float)(indeg == 0 ? 1 : indeg));
+    const float m0 = a.S0 * rdeg, m1 = a.S1 * rdeg;
+    const float sd0 = __builtin_amdgcn_sqrtf(relu1(__builtin_fmaf(-m0, m0, a.Q0 * rdeg))), sd1 = __builtin_amdgcn_sqrtf(relu1(__builtin_fmaf(-m1, m1, a.Q1 * rdeg)));
+    // K-slots e = 0..7: (feature f0: mean, min, max, std), (feature f0 + 1: the same)
+    DS_SPLIT2(m0, a.mn0, b_hi.x, b_lo.x);
+    DS_SPLIT2(a.mx0, sd0, b_hi.y, b_lo.y);
+    DS_SPLIT2(m1, a.mn1, b_hi.z, b_lo.z);
+    DS_SPLIT2(a.mx1, sd1, b_hi.w, b_lo.w);
+    asm("v_max3_f32 %0, |%1|, |%2|, %0" : "+v"(vmax) : "v"(m0), "v"(m1));
+    asm("v_max3_f32 %0, |%1|, |%2|, %0" : "+v"(vmax) : "v"(sd0), "v"(sd1));
+    asm("v_max3_f32 %0, |%1|, |%2|, %0" : "+v"(vmax) : "v"(a.mn0), "v"(a.mn1));
+    asm("v_max3_f32 %0, |%1|, |%2|, %0" : "+v"(vmax) : "v"(a.mx0), "v"(a.mx1));
+    asm volatile("" : "+v"(vmax));
+}
+
 __device__ __forceinline__ void pna_gather_slice(const float* __restrict__ s_h, const uint8_t* __restrict__ s_src, const uint32_t (&srcw)[4],
                                                  int e_base, int indeg, int col, ds_uint4_t& b_hi, ds_uint4_t& b_lo, float& vmax) {
     PnaSlice a{0.f, 0.f, 0.f, 0.f, PNA_SENT_MAX, PNA_SENT_MAX, PNA_SENT_MIN, PNA_SENT_MIN};
+#ifdef PNA_GATHER_PRIO
+    __builtin_amdgcn_s_setprio(PNA_GATHER_PRIO);
+#endif
 #pragma unroll
     for (int w = 0; w < 4; w++) {
         if (__all(indeg >= 4 * w + 4)) {  // every row of the wave has these four in-edges (kNN graphs): four reads in flight, no masks
@@ -398,22 +421,10 @@ __device__ __forceinline__ void pna_gather_slice(const float* __restrict__ s_h, 
     }
     for (int e = 16; __any(e < indeg); e++)  // rows with more than 16 in-edges: the rest comes from the LDS copy of the CSR slice
         if (e < indeg) pna_slice_edge(a, s_h, (int)s_src[e_base + e], col);
-    // mean = S / indeg (0 -> 1), std = sqrt(relu(Q / indeg - mean^2))   (node_embedding.cc:123,143-145)
-    // 1 / indeg and the square root as single instructions (v_rcp_f32, v_sqrt_f32: 1 ulp): four IEEE divisions and two IEEE square
-    // roots per slice are ~60 dependent VALU instructions, and at two waves per SIMD nothing hides their latency
-    const float rdeg = __builtin_amdgcn_rcpf((float)(indeg == 0 ? 1 : indeg));
-    const float m0 = a.S0 * rdeg, m1 = a.S1 * rdeg;
-    const float sd0 = __builtin_amdgcn_sqrtf(relu1(__builtin_fmaf(-m0, m0, a.Q0 * rdeg))), sd1 = __builtin_amdgcn_sqrtf(relu1(__builtin_fmaf(-m1, m1, a.Q1 * rdeg)));
-    // K-slots e = 0..7: (feature f0: mean, min, max, std), (feature f0 + 1: the same)
-    DS_SPLIT2(m0, a.mn0, b_hi.x, b_lo.x);
-    DS_SPLIT2(a.mx0, sd0, b_hi.y, b_lo.y);
-    DS_SPLIT2(m1, a.mn1, b_hi.z, b_lo.z);
-    DS_SPLIT2(a.mx1, sd1, b_hi.w, b_lo.w);
-    asm("v_max3_f32 %0, |%1|, |%2|, %0" : "+v"(vmax) : "v"(m0), "v"(m1));
-    asm("v_max3_f32 %0, |%1|, |%2|, %0" : "+v"(vmax) : "v"(sd0), "v"(sd1));
-    asm("v_max3_f32 %0, |%1|, |%2|, %0" : "+v"(vmax) : "v"(a.mn0), "v"(a.mn1));
-    asm("v_max3_f32 %0, |%1|, |%2|, %0" : "+v"(vmax) : "v"(a.mx0), "v"(a.mx1));
-    asm volatile("" : "+v"(vmax));
+    pna_slice_finish(a, indeg, b_hi, b_lo, vmax);
+#ifdef PNA_GATHER_PRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
 }
 
 __global__ __launch_bounds__(PNA_FT_WAVES * 64, 4) void pna_layer_fused_kernel(const float* __restrict__ h, float* __restrict__ hout,
@@ -421,9 +432,21 @@ __global__ __launch_bounds__(PNA_FT_WAVES * 64, 4) void pna_layer_fused_kernel(c
                                                                   const int* __restrict__ out_deg, const uint8_t* __restrict__ wpk,
                                                                   const float* __restrict__ bias, float avg_deg, float oscale,
                                                                   const int* __restrict__ tile_row, int n_tiles, int* __restrict__ range_flag,
-                                                                  int ablate_arg) {
+                                                                  int ablate_arg, unsigned long long* __restrict__ prof_out) {
     const int ablate = FG_ABLATE(ablate_arg);  // 0 in the shipped build: the branches below fold away (common.h)
     (void)ablate_arg;
+    (void)prof_out;
+    // development aid (-DFLOWGNN_DEV, pna_ablate bit 128): per-wave phase times in 10 ns ticks -> prof_out[(workgroup, wave)][8]:
+    // 0 wait for the tile's rows / chunk 0, 1 tile set-up, 2 gathers, 3 MFMA phases, 4 closing wait + barrier of the K-steps,
+    // 5 epilogue, 6 whole kernel, 7 tiles
+#ifdef FLOWGNN_DEV
+    const bool prof = (ablate & 128) && prof_out;
+    unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0}, tp = 0, tk0 = 0, ntl = 0;
+    if (prof) tk0 = tp = wall_clock64();
+#define PNA_STAMP(i) do { if (prof) { const unsigned long long t_ = wall_clock64(); tacc[i] += t_ - tp; tp = t_; } } while (0)
+#else
+#define PNA_STAMP(i) do { } while (0)
+#endif
     __shared__ __attribute__((aligned(16))) char s_a[PNA_CHUNK];  // even K-steps
     __shared__ __attribute__((aligned(16))) char s_b[PNA_CHUNK];  // odd K-steps
     __shared__ __attribute__((aligned(16))) float s_h[PNA_FT_ROWS * PNA_FT_STRIDE];
@@ -434,7 +457,9 @@ __global__ __launch_bounds__(PNA_FT_WAVES * 64, 4) void pna_layer_fused_kernel(c
     // Waves 0..7 gather a K-step's slice and then multiply; waves 8..15 multiply first (with the slice they gathered one interval
     // earlier) and then gather the next one: between two barriers half of the waves of every SIMD are in the matrix pipe while
     // the other half is in the VALU / LDS gather.
-    const bool late = wave >= PNA_FT_WAVES / 2;
+    // (development: pna_ablate bit 256 = no half-step offset, every wave gathers then multiplies; bit 512 = the offset by SIMD pairs --
+    //  waves 2, 3, 6, 7, ... late -- instead of by workgroup halves)
+    const bool late = (ablate & 256) ? false : (ablate & 512) ? ((wave >> 1) & 1) != 0 : wave >= PNA_FT_WAVES / 2;
     float vmax = 0.0f;
     int tile = blockIdx.x;
     if (tile >= n_tiles) return;
@@ -456,6 +481,7 @@ __global__ __launch_bounds__(PNA_FT_WAVES * 64, 4) void pna_layer_fused_kernel(c
         pna_issue_chunk_asm(wpk, s_a, wave, lane);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this tile's rows and CSR slice, chunk 0
         __syncthreads();
+        PNA_STAMP(0);
         const int r = wave * 16 + j;
         const bool valid = r < rows;
         const uint8_t* csrc = reinterpret_cast<const uint8_t*>(s_desc[buf]);
@@ -478,7 +504,9 @@ __global__ __launch_bounds__(PNA_FT_WAVES * 64, 4) void pna_layer_fused_kernel(c
 #pragma unroll
         for (int i = 0; i < PNA_NS * PNA_OT; i++) y[i] = (float4_t){0.f, 0.f, 0.f, 0.f};
         ds_uint4_t b_hi = {0, 0, 0, 0}, b_lo = {0, 0, 0, 0};
+        PNA_STAMP(1);
         if (late) pna_gather_slice(s_h, csrc, srcw, e_base, indeg, 2 * g, b_hi, b_lo, vmax);  // K-step 0's slice, ahead of the first interval
+        PNA_STAMP(2);
         // Development variants of WHERE a K-step's chunk request sits (round-3 finding: requested between a wave's two phases the
         // kernel was 1.6 % faster and two-engine runs stopped being bit-identical; scripts/dev/pna_dma_race.py bisects it):
         //   ablate 8: the request between the wave's phases (early waves: gather, REQUEST, multiply; late: multiply, REQUEST, gather)
@@ -491,12 +519,14 @@ __global__ __launch_bounds__(PNA_FT_WAVES * 64, 4) void pna_layer_fused_kernel(c
             pna_issue_chunk_asm(gchunk, buf, wave, lane);
         };
         auto close_step = [&]() {
+            PNA_STAMP(2);  // (a late wave's gather sits in front of the closing wait; an early wave's MFMA phase was stamped already)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (!(ablate & 4)) __syncthreads();  // ablate 4 (development aid): timing without the K-step barriers (results are then wrong)
             if (ablate & 64) {
                 asm volatile("s_sleep 2" ::: "memory");
                 __syncthreads();
             }
+            PNA_STAMP(4);
         };
 #pragma unroll 1
         for (int ks = 0; ks < ((ablate & 2) ? 0 : PNA_KS); ks += 2) {
@@ -504,14 +534,28 @@ __global__ __launch_bounds__(PNA_FT_WAVES * 64, 4) void pna_layer_fused_kernel(c
             if (!mid) pna_issue_chunk_asm(wpk + (size_t)(ks + 1) * PNA_CHUNK, s_b, wave, lane);
             if (!late) pna_gather_slice(s_h, csrc, srcw, e_base, indeg, 8 * ks + 2 * g, b_hi, b_lo, vmax);
             if (mid && !late) issue_mid(wpk + (size_t)(ks + 1) * PNA_CHUNK, s_b);
+            PNA_STAMP(2);
+            if (ablate & 1024) __builtin_amdgcn_s_setprio(2);
             pna_stream_mfma(s_a, lane, b_hi, b_lo, y);
+            if (ablate & 1024) __builtin_amdgcn_s_setprio(0);
+#ifdef FLOWGNN_DEV
+            if (prof) asm volatile("" :: "v"(y[14].x), "v"(y[13].x));  // the stamp behind the MFMAs' results, not behind their issue
+#endif
+            PNA_STAMP(3);
             if (mid && late) issue_mid(wpk + (size_t)(ks + 1) * PNA_CHUNK, s_b);
             if (late) pna_gather_slice(s_h, csrc, srcw, e_base, indeg, 8 * (ks + 1) + 2 * g, b_hi, b_lo, vmax);
             close_step();
             if (!mid && ks + 2 < PNA_KS) pna_issue_chunk_asm(wpk + (size_t)(ks + 2) * PNA_CHUNK, s_a, wave, lane);
             if (!late) pna_gather_slice(s_h, csrc, srcw, e_base, indeg, 8 * (ks + 1) + 2 * g, b_hi, b_lo, vmax);
             if (mid && !late && ks + 2 < PNA_KS) issue_mid(wpk + (size_t)(ks + 2) * PNA_CHUNK, s_a);
+            PNA_STAMP(2);
+            if (ablate & 1024) __builtin_amdgcn_s_setprio(2);
             pna_stream_mfma(s_b, lane, b_hi, b_lo, y);
+            if (ablate & 1024) __builtin_amdgcn_s_setprio(0);
+#ifdef FLOWGNN_DEV
+            if (prof) asm volatile("" :: "v"(y[14].x), "v"(y[13].x));
+#endif
+            PNA_STAMP(3);
             if (mid && late && ks + 2 < PNA_KS) issue_mid(wpk + (size_t)(ks + 2) * PNA_CHUNK, s_a);
             if (late && ks + 2 < PNA_KS) pna_gather_slice(s_h, csrc, srcw, e_base, indeg, 8 * (ks + 2) + 2 * g, b_hi, b_lo, vmax);
             close_step();
@@ -546,10 +590,23 @@ __global__ __launch_bounds__(PNA_FT_WAVES * 64, 4) void pna_layer_fused_kernel(c
                     make_float4(hv[t].x + relu1(fin.x), hv[t].y + relu1(fin.y), hv[t].z + relu1(fin.z), hv[t].w + relu1(fin.w));
             }
         }
+        PNA_STAMP(5);
+#ifdef FLOWGNN_DEV
+        ntl++;
+#endif
         if (!has_next) break;
         tile = ntile; t0 = nt0; rows = nrows;
         buf ^= 1;
     }
+#ifdef FLOWGNN_DEV
+    if (prof && lane == 0) {
+        unsigned long long* o = prof_out + ((size_t)blockIdx.x * PNA_FT_WAVES + wave) * 8;
+        for (int i = 0; i < 6; i++) o[i] = tacc[i];
+        o[6] = wall_clock64() - tk0;
+        o[7] = ntl;
+    }
+#endif
+#undef PNA_STAMP
     if (__any(!(vmax < 6.0e4f))) {
         if (lane == 0) atomicOr(range_flag, 1);
     }
@@ -723,7 +780,7 @@ public:
                 pna_layer_fused_kernel<<<grid, PNA_FT_WAVES * 64, 0, s>>>(db.h[cur], db.h[cur ^ 1], reinterpret_cast<const uint8_t*>(desc_.p), db.csr.out_deg,
                                                             d_stream_ + (size_t)l * PNA_SPLIT_LAYER_BYTES, d_cb_ + (size_t)l * PNA_D, avg_deg_,
                                                             oscale_[l], db.gtiles.row_start, db.gtiles.n_tiles, db.range_flag,
-                                                            ablate_);
+                                                            ablate_, prof_buf(grid, l));
                 cur ^= 1;
                 continue;
             }
@@ -771,8 +828,44 @@ public:
         return 0;
     }
 
+    // development aid (-DFLOWGNN_DEV, pna_ablate bit 128): phase times of the LAST layer launch of a pass, printed by the next one
+    unsigned long long* prof_buf(int grid, int layer) {
+#ifdef FLOWGNN_DEV
+        if (!(ablate_ & 128)) return nullptr;
+        const size_t n = (size_t)256 * PNA_FT_WAVES * 8;
+        if (!d_prof_) { if (hipMalloc((void**)&d_prof_, n * 8) != hipSuccess) return nullptr; (void)hipMemset(d_prof_, 0, n * 8); }
+        if (layer == 1) {  // layer 0's record is complete by stream order once we synchronise: read it, print the per-phase means
+            std::vector<unsigned long long> h(n);
+            (void)hipDeviceSynchronize();
+            (void)hipMemcpy(h.data(), d_prof_, n * 8, hipMemcpyDeviceToHost);
+            double acc[8] = {0}, early[8] = {0}, late[8] = {0};
+            int cnt = 0;
+            for (int wg = 0; wg < grid; wg++)
+                for (int w = 0; w < PNA_FT_WAVES; w++) {
+                    const unsigned long long* o = &h[((size_t)wg * PNA_FT_WAVES + w) * 8];
+                    if (!o[7]) continue;
+                    for (int i = 0; i < 8; i++) { acc[i] += (double)o[i]; (w < 8 ? early : late)[i] += (double)o[i]; }
+                    cnt++;
+                }
+            if (cnt) {
+                static const char* nm[8] = {"rows_wait", "setup", "gather", "mfma", "close_wait", "epilogue", "kernel", "tiles"};
+                fprintf(stderr, "pna phase stamps (us per wave, mean over %d waves; early waves | late waves):", cnt);
+                for (int i = 0; i < 8; i++) fprintf(stderr, " %s %.1f (%.1f | %.1f)", nm[i], acc[i] / cnt * (i < 7 ? 0.01 : 1.0), early[i] / (cnt / 2) * (i < 7 ? 0.01 : 1.0), late[i] / (cnt / 2) * (i < 7 ? 0.01 : 1.0));
+                fprintf(stderr, "\n");
+            }
+        }
+        return layer == 0 ? d_prof_ : nullptr;
+#else
+        (void)grid; (void)layer;
+        return nullptr;
+#endif
+    }
+
 private:
+    unsigned long long* d_prof_ = nullptr;
     void free_all() {
+        if (d_prof_) { (void)hipFree(d_prof_); d_prof_ = nullptr; }
+
         float** ptrs[] = {&d_nemb_, &d_wf_, &d_cb_, &d_w1_, &d_b1_, &d_w2_, &d_b2_, &d_w3_, &d_b3_};
         for (auto p : ptrs)
             if (*p) { (void)hipFree(*p); *p = nullptr; }
