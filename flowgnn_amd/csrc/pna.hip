@@ -755,6 +755,10 @@ public:
         edges = fused_ ? PNA_FT_EDGES : 0;
     }
 
+    // tiles that are mostly empty (graphs of 65..128 nodes) waste MFMA columns: below 40 % full the two-kernel layer is used
+    bool use_fused(const DeviceBatch& db) const {
+        return fused_ && !qmode_ && split_ && !exact_ && db.gtiles.ok && db.gtiles.n_tiles > 0 && db.gtiles.fill >= 0.4;
+    }
     int forward(DeviceBatch& db, Profiler& prof, hipStream_t s) override {
         const int n = db.b.n_tot;
         if (n <= 0) return 0;
@@ -766,8 +770,7 @@ public:
         }
         if (int rc = make_tile_bounds(tiles_, db.b.node_off, db.b.num_graphs, n, tile_nominal_, tile_slack_, s)) return rc;
         int cur = 0;
-        // tiles that are mostly empty (graphs of 65..128 nodes) waste MFMA columns: below 40 % full the two-kernel layer is used
-        const bool fused = fused_ && split_ && !exact_ && db.gtiles.ok && db.gtiles.n_tiles > 0 && db.gtiles.fill >= 0.4;
+        const bool fused = use_fused(db);
         for (int l = 0; l < PNA_L; l++) {
             if (fused) {
                 ProfScope p(prof, "pna_layer_fused", s);
