@@ -70,10 +70,12 @@ MODELS = {
                 # fused layer (aggregate + BN/root/degree epilogue + dense): rows in and out, CSR entry + norm + code per
                 # edge, row bounds + out-degree per node; unfused dense layer: read a row, write a row
                 # graph-resident kernel (five aggregations + four dense layers in one launch): priced on 5 aggregations' + 4 dense
-                # layers' per-layer figures; it really moves the x_0 rows once + the CSR (roofline.hbm_bytes_moved)
+                # layers' per-layer figures; behind the one-pass front end (round 5) it really moves one 3 584-byte descriptor per
+                # 192-row tile (CSR slice, out-degrees, encoder row numbers; roofline.hbm_bytes_moved) -- the projected encoder table
+                # and the weight stream are L2-resident
                 fused_bytes={"gcn_layer_fused": lambda n, e: n * 400 * 2 + n * 8 + e * 9, "gcn_dense": lambda n, e: n * 400 * 2,
                              "gcn_resident": lambda n, e: 4 * (n * 400 * 2 + n * 8 + e * 9) + (n * 400 + n * 8 + e * 9)},
-                moved_bytes={"gcn_resident": lambda n, e: n * (400 + 8) + e * 5},
+                moved_bytes={"gcn_resident": lambda n, e: (n // 192 + 1) * 3584},
                 layers_per_launch={"gcn_resident": 4},
                 hbm_kernels=("gcn_aggregate",), mfma_kernels=("gcn_resident", "gcn_layer_fused", "gcn_dense"),
                 workload="GCN dim=100, batched ogbg-molpcba-shaped graphs on MI355X (BASELINE configs[2])"),
