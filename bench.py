@@ -192,7 +192,7 @@ def parity_record(model, got, want, numeric="f32"):
 
 def rooflines(model, M, prof, kern, G, N, E, steps, split, qmode):
     """(roofline of the dominant kernel, roofline of the stand-alone aggregation kernel) from the HIP-event profile of the timed
-    region: algorithmic bytes / flops per launch (DESIGN.md section 4, SURVEY 8d) over the kernel's average launch duration."""
+    region: algorithmic bytes / flops per launch (DESIGN.md section 4-5, SURVEY 8d) over the kernel's average launch duration."""
     agg_bytes, mlp_flops = M["agg_bytes"](N, E), M["flops"](N, E)
     layer = {k: v for k, v in prof.items() if k in M["hbm_kernels"] + M["mfma_kernels"]}
     dominant = max(layer.items(), key=lambda kv: kv[1]["total_ms"])[0] if layer else None

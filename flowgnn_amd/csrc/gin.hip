@@ -751,7 +751,7 @@ public:
     // computes h_0 itself -- no CSR, no h_0 rows and no separate encoder / index-build launches in HBM.  Needs the folded
     // single-task readout (the loader rides on the folded last layer's steps); gin_tile_build = 0 restores the three-kernel front end.
     bool one_pass(const DeviceBatch& db) const {
-        // Measured: the tile build costs what index build + tile prep cost (0.27 ms at 2^18 molhiv graphs) and the
+        // Measured (NOTEBOOK.md section 4): the tile build costs what index build + tile prep cost (0.27 ms at 2^18 molhiv graphs) and the
         // encoder inside the folded last layer's steps costs the resident kernel 0.32 ms (0.57 ms before the kernel lost its scratch
         // reloads, which made this form the slower one on large batches in round 3) where the separate, store-bound encoder launch costs
         // 0.51: ahead at every size now -- 8.49 vs 8.73 ms per step at 2^18 graphs, 1.23 vs 1.24 at 32 768, 0.206 vs 0.222 at 4 113.

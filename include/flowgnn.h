@@ -299,7 +299,7 @@ int flowgnn_exact_reruns(const flowgnn_engine* e);
  * flowgnn_run then records its launch sequence (index build + forward pass) into a hipGraph on the second run of a
  * batch and replays it afterwards; any call that changes what the kernels read or write (weights, batch, result
  * buffer, numeric mode, an exact-fp32 re-run) drops the recording, and runs with the profiler enabled are never
- * replays.  Off by default: on the measured runtime plain asynchronous launches are as fast.
+ * replays.  Off by default: on the measured runtime plain asynchronous launches are as fast (NOTEBOOK.md section 5).
  * Returns how many runs of this engine were replays (-1 for a null handle).
  */
 long long flowgnn_graph_replays(const flowgnn_engine* e);
@@ -356,7 +356,8 @@ const char* flowgnn_option_name(int i);
  * batch into contiguous graph ranges balanced by sum(N + E) (flowgnn_shard_ranges: cuts[0..parts], cuts[r] = the first graph
  * whose cumulative node + edge count reaches r / parts of the total) and flowgnn_group_get_results writes [num_graphs][NUM_TASK]
  * in job order.  A device may appear more than once in the list.  flowgnn_group_engine(g, i) exposes member i for per-engine
- * calls (profiling, taps).
+ * calls (profiling, taps; a flowgnn_set_batch on a member makes flowgnn_group_run / get_results refuse until the next
+ * flowgnn_group_set_batch).  Every engine has a persistent host thread: a group call costs microseconds of host time.
  * What a group's results are relative to ONE engine holding the whole job: graphs are independent and every kernel sums a row's
  * in-edges in an order that depends on the row alone, so results are BIT-IDENTICAL whenever the same kernels run -- and the
  * kernels are chosen from the JOB's totals, which the group (and the entry points' ranges) hand down to every member through
