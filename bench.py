@@ -341,7 +341,9 @@ def measure_config(model, batch, steps, warmup, device, sample_graphs=512):
         lim = roof.get("issue_limit") or {}
         if lim:  # committed SQ counter pass of this kernel (profiles/limits.json): what binds, and how long its waves are parked
             rec["limit"] = {"what": lim.get("limit"), "busy": lim.get(lim.get("limit")), "wait_share": lim.get("wait_share"),
-                            "mfma_busy": lim.get("mfma_busy"), "lds_busy": lim.get("lds_busy"), "valu_issue": lim.get("valu_issue")}
+                            "mfma_busy": lim.get("mfma_busy"), "lds_busy": lim.get("lds_busy"), "valu_issue": lim.get("valu_issue"),
+                            # matrix pipe + VALU of a SIMD share its issue (tools/coissue4.hip): their shares add up to <= ~1.2
+                            "simd_issue": lim.get("simd_issue"), "simd_issue_ceiling": lim.get("simd_issue_ceiling")}
         moved = roof.get("traffic") if roof.get("traffic") is not None else roof.get("hbm_bytes_moved")
         if moved is not None:
             rec["hbm_bytes_moved"] = moved

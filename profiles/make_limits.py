@@ -12,6 +12,11 @@ shares of what the hardware offers over the kernel's duration (GRBM_GUI_ACTIVE /
 and, as shares of the waves' own cycles (SQ_WAVE_CYCLES): wait_share (SQ_WAIT_ANY: parked on s_waitcnt / barriers) and
 issue_stall_share (SQ_WAIT_INST_ANY).  `limit` names the largest of the four resource shares -- what the kernel would hit first if
 its waves never waited; `wait_share` says how far the waves are from hitting anything.
+`simd_issue` = mfma_busy + valu_issue: the matrix pipe and the VALU of a SIMD do NOT run side by side -- tools/coissue4.hip
+(profiles/r05_coissue4.txt): four waves per SIMD, 17.5 clocks per MFMA alone, 3.8-4.4 per VALU instruction alone, and the two
+streams together take 0.76-0.87 of the SUM of their times whichever waves carry them (1.04 for v_pk_fma_f32), so the two shares
+can add up to 1.15-1.3 at the very most (`simd_issue_ceiling` 1.2).  A kernel at 0.86 is within 30 % of that roof whatever its
+distance from the f16 peak says.
 bench.py attaches the entry of the kernel it reports as roofline.issue_limit.
 """
 import json
@@ -69,6 +74,9 @@ def main():
                 rec["lds_issue"] = 4.0 * kb["SQ_ACTIVE_INST_LDS"] / (clk2 * 256 * 4)
                 rec["issue_stall_share"] = kb["SQ_WAIT_INST_ANY"] / max(kb["SQ_WAVE_CYCLES"], 1.0)
                 rec["valu_insts_per_launch"] = kb["SQ_INSTS_VALU"]
+            if "valu_issue" in rec:
+                rec["simd_issue"] = rec["mfma_busy"] + rec["valu_issue"]
+                rec["simd_issue_ceiling"] = 1.2
             res_keys = [k for k in ("mfma_busy", "lds_busy", "valu_issue", "lds_issue") if k in rec]
             rec["limit"] = max(res_keys, key=lambda k: rec[k])
             rec = {k: (round(v, 4) if isinstance(v, float) else v) for k, v in rec.items()}
