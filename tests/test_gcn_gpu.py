@@ -106,3 +106,42 @@ def test_split_range_fallback(oracle, w):
     assert e.exact_reruns() == 1 and np.isfinite(got).all()
     assert np.allclose(got, want, rtol=1e-4, atol=1e-4 * np.abs(want).max()), np.abs(got - want).max()
     e.close()
+
+
+def test_one_pass_front_end(oracle, w):
+    """The default front end (gcn_tile_build_kernel + the resident kernel's own encoder: two launches, no index build, no x_0 rows in
+    HBM) against the three-launch front end (index build, projected encoder, resident kernel): the same in-edge order (the
+    descriptor's words are the CSR's, bit for bit), x_0 re-associated as (T01 + T234) + T5678 -- fp32 rounding only; bit-identical
+    under a batch split; the CSR and the aggregation probe are still there on demand."""
+    rng = np.random.default_rng(4)
+    b = gp.concat_batches([gp.synth_molpcba_batch(700, seed=41), directed_variant(gp.synth_molpcba_batch(60, seed=42)),
+                           gp.synth_molecule_batch(30, seed=43, mean_nodes=150.0, min_nodes=120, max_nodes=190)])
+    el = b.edge_list.copy()
+    eo = b.edge_offsets()
+    for g in rng.integers(0, b.num_graphs, 40):  # duplicate edges and self loops
+        if eo[g + 1] - eo[g] >= 2:
+            el[eo[g]] = el[eo[g] + 1]
+            el[eo[g + 1] - 1, 1] = el[eo[g + 1] - 1, 0]
+    b = gp.GraphBatch(b.nums_of_nodes, b.nums_of_edges, b.node_feature, el, b.edge_attr)
+    want = oracle.gcn_forward(b, [w], nthreads=8)
+    res = {}
+    for tb in (1, 0):
+        e = Engine("GCN", device=0, options={"gcn_tile_build": tb})
+        try:
+            e.set_weights(w)
+            e.profile_enable(True)
+            res[tb] = e.forward(b).copy()
+            names = set(e.profile_read())
+            assert ("gcn_tile_build" in names) == (tb == 1) and ("build_csr" in names) == (tb == 0), names
+            assert "gcn_resident" in names
+            if tb == 1:
+                assert np.array_equal(e.forward(b.slice(100, 600)), res[1][100:600])  # a different tiling: the same bits
+                one = e.forward(b)
+                row_ptr, src, eid, out_deg = e.csr()  # built on demand behind the one-pass run
+                assert row_ptr[-1] == b.total_edges and out_deg.sum() == b.total_edges
+                assert e.aggregation_only_ms(layer=0, iters=1) > 0.0
+                assert np.array_equal(e.forward(b), one)
+        finally:
+            e.close()
+    assert close(res[1], want) and close(res[0], want)
+    assert np.allclose(res[1], res[0], rtol=2e-6, atol=2e-6), np.abs(res[1] - res[0]).max()
