@@ -378,7 +378,8 @@ def plan_job(dataset: str, graphs: int, world: int, rank: int, scaling: str, mak
     g0, g1 = ranges[rank]
     return job.slice(g0, g1), ranges, {"graphs_per_rank": [b - a for a, b in ranges], "node_plus_edge_load_per_rank": loads,
                                        "imbalance_max_over_mean": max(loads) / mean if mean else 1.0,
-                                       "job_nodes": int(job.total_nodes), "job_edges": int(job.total_edges)}
+                                       "job_nodes": int(job.total_nodes), "job_edges": int(job.total_edges),
+                                       "_job_counts": (job.nums_of_nodes, job.nums_of_edges)}  # (popped before the record is printed)
 
 
 class ShardedResults:
@@ -534,6 +535,7 @@ def main():
         eng.set_numeric_mode(args.numeric)
     if balance:  # strong scaling: this rank holds a shard of ONE job -- kernels are chosen as one engine would for all of it
         eng.set_job_totals(balance["job_nodes"], balance["job_edges"])
+        eng.set_job_tile_fill(eng.graph_tile_fill(*balance.pop("_job_counts")))  # ... and takes the job's side of the tile-fill threshold
     eng.set_batch(batch)
     G, N, E = batch.num_graphs, batch.total_nodes, batch.total_edges
 

@@ -104,7 +104,7 @@ static const OptionDef kOptionTable[] = {
     {"gin_agg_untiled", 0}, {"gin_agg_tile", 128},
     {"gcn_resident", 1}, {"gcn_tile_build", 1}, {"gcn_unfused", 0}, {"gcn_mfma", 16},
     {"gat_resident", 1}, {"gat_mfma", 16}, {"gat_fold_readout", 1}, {"gat_reference_quirk", 0},
-    {"pna_fused", 1}, {"pna_mfma", 16}, {"pna_mfma_agg", -1},
+    {"pna_fused", 1}, {"pna_mfma", 16},
     {"dgn_fused", 1}, {"dgn_mfma", 16}, {"dgn_mfma_agg", -1}, {"dgn_fold_readout", 1}, {"dgn_rowinfo_direct", 1},
 #ifdef FLOWGNN_DEV
     {"gcn_ablate", 0}, {"gat_ablate", 0}, {"pna_ablate", 0}, {"dgn_ablate", 0},
