@@ -654,6 +654,15 @@ public:
         if ((rc = upload(&d_pw_, v_pw))) return rc;
         if ((rc = upload(&d_pb_, v_pb))) return rc;
         if ((rc = upload(&d_ecomb_, ecomb))) return rc;
+        {   // the resident kernel's copy of the edge-embedding combos, scaled by 2^-16: its walk forms relu(x + e) in that scaled domain
+            // with one clamped packed FMA per two values (gin_split.hip, GR_MSG2).  Exact while |e| < 4 096 (x + e < 2^16 needs
+            // x < 6e4, the range every operand is checked against anyway); tables beyond that take the per-layer kernels.
+            float emax = 0.0f;
+            std::vector<float> sc(ecomb.size());
+            for (size_t i = 0; i < ecomb.size(); i++) { sc[i] = ecomb[i] * (1.0f / 65536.0f); emax = std::fmax(emax, std::fabs(ecomb[i])); }
+            table_ok_ = emax < 4096.0f;  // (NaN: false)
+            if ((rc = upload(&d_ecomb_res_, sc))) return rc;
+        }
         if ((rc = upload(&d_w1f_, w1f))) return rc;
         if ((rc = upload(&d_w1tail_, w1tail))) return rc;
         if ((rc = upload(&d_b1p_, b1p))) return rc;
@@ -743,7 +752,7 @@ public:
     bool use_resident(const DeviceBatch& db) const {
         // tiles that are mostly empty (graphs of 130..256 nodes, or dense graphs that hit the edge limit first) waste the
         // MFMA columns of the absent rows: below half full the per-layer kernels are the better choice
-        return resident_ && fused_ && split_ && !exact_ && db.gtiles.ok && db.gtiles.n_tiles > 0 && db.gtiles.fill >= resident_min_fill_;
+        return resident_ && table_ok_ && fused_ && split_ && !exact_ && db.gtiles.ok && db.gtiles.n_tiles > 0 && db.gtiles.fill >= resident_min_fill_;
     }
 
     // One-pass form of the graph-resident path (default): gin_tile_build_kernel turns the caller's edge list / attributes / node
@@ -775,7 +784,7 @@ public:
                                       virtual_node_, resident_order_, s);
             }
             ProfScope p(prof, "gin_resident", s);  // the whole model
-            launch_gin_resident(nullptr, nullptr, nullptr, nullptr, nullptr, d_ecomb_, d_rsplit_, d_pw_, d_pb_, db.gtiles.row_start,
+            launch_gin_resident(nullptr, nullptr, nullptr, nullptr, nullptr, d_ecomb_res_, d_rsplit_, d_pw_, d_pb_, db.gtiles.row_start,
                                 db.gtiles.graph_start, reinterpret_cast<uint8_t*>(perm_.p), db.b.node_off, db.out, db.gtiles.n_tiles,
                                 db.range_flag, s, virtual_node_, d_head_, resident_order_, resident_prof_, &tb);
             db.final_h = 0;
@@ -801,7 +810,7 @@ public:
             }
             if (gt.n_big > 0) {  // graphs of 129..256 nodes (or 641..1280 edges): one full tile each on the eight-wave resident kernel
                 ProfScope p(prof, "gin_resident_big", s);
-                launch_gin_resident(db.h[0], nullptr, db.csr.row_ptr, db.csr.src, db.csr.ecode, d_ecomb_, d_rsplit_, d_pw_, d_pb_, gt.big_row,
+                launch_gin_resident(db.h[0], nullptr, db.csr.row_ptr, db.csr.src, db.csr.ecode, d_ecomb_res_, d_rsplit_, d_pw_, d_pb_, gt.big_row,
                                     gt.big_graph, reinterpret_cast<uint8_t*>(perm_.p + sub_words), db.b.node_off, db.out, gt.n_big,
                                     db.range_flag, s, false, d_head_, resident_order_, false, nullptr, 2);
             }
@@ -815,7 +824,7 @@ public:
             const bool rows = keep_h_ || multi;
             {
                 ProfScope p(prof, "gin_resident", s);
-                launch_gin_resident(db.h[0], rows ? db.h[1] : nullptr, db.csr.row_ptr, db.csr.src, db.csr.ecode, d_ecomb_, d_rsplit_, d_pw_, d_pb_,
+                launch_gin_resident(db.h[0], rows ? db.h[1] : nullptr, db.csr.row_ptr, db.csr.src, db.csr.ecode, d_ecomb_res_, d_rsplit_, d_pw_, d_pb_,
                                     db.gtiles.row_start, db.gtiles.graph_start, reinterpret_cast<uint8_t*>(perm_.p), db.b.node_off,
                                     multi ? nullptr : db.out, db.gtiles.n_tiles, db.range_flag, s, virtual_node_,
                                     (!rows && fold_readout_ && head_fold_) ? d_head_ : nullptr, resident_order_, resident_prof_);
@@ -935,7 +944,7 @@ public:
 
 private:
     void free_all() {
-        float** ptrs[] = {&d_chunks_, &d_nemb_, &d_pw_, &d_pb_, &d_ecomb_, &d_w1f_, &d_w1tail_, &d_b1p_, &d_w2f_, &d_b2p_};
+        float** ptrs[] = {&d_chunks_, &d_nemb_, &d_pw_, &d_pb_, &d_ecomb_, &d_ecomb_res_, &d_w1f_, &d_w1tail_, &d_b1p_, &d_w2f_, &d_b2p_};
         for (auto p : ptrs)
             if (*p) { (void)hipFree(*p); *p = nullptr; }
         if (d_split_) { (void)hipFree(d_split_); d_split_ = nullptr; }
@@ -986,6 +995,8 @@ private:
     float* d_head_ = nullptr;      // gin_resident_head_fold
     bool head_fold_ = true;  // gin_head_fold=0: the last layer's second linear layer is computed (readout not folded through it)
     float* d_chunks_ = nullptr;
+    float* d_ecomb_res_ = nullptr;  // ecomb * 2^-16: the resident kernel's walk (GR_MSG2, gin_split.hip)
+    bool table_ok_ = true;          // |ecomb| < 4 096: the scaled walk is exact (set_weights)
     float *d_nemb_ = nullptr, *d_pw_ = nullptr, *d_pb_ = nullptr, *d_ecomb_ = nullptr, *d_w1f_ = nullptr,
           *d_w1tail_ = nullptr, *d_b1p_ = nullptr, *d_w2f_ = nullptr, *d_b2p_ = nullptr;
 };

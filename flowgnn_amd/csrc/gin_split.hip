@@ -453,6 +453,7 @@ __global__ __launch_bounds__(WAVES * 64) void gin_layer_split_kernel(const float
 // LDS: 2 x 27 264 (chunks) + 102 400 (rows) + 2 560 (edges) + 520 (row offsets) + 1 024 (per-node readout terms) = 161 032 B.
 constexpr int GR_ROWS = 256;
 constexpr int GR_EDGES = 1280;
+constexpr float GR_MSG_SCALE = 1.0f / 65536.0f, GR_MSG_UNSCALE = 65536.0f;  // the walk's scaled domain (gr_layer: GR_MSG2)
 constexpr int GR_WAVES = 8;
 constexpr int GR_STEPS = 7;  // MLP steps of a layer of the resident kernel (the eight-step schedule of the per-layer kernel with its last two merged)
 
@@ -1265,17 +1266,28 @@ __device__ __forceinline__ void gr_layer(unsigned long long (&tacc)[6], char* bx
         const unsigned nw = s_edge[more ? e_cur[NTI] : 0];                                                                        \
         wd[NTI] = more ? nw : GR_NO_EDGE;                                                                                         \
     }
+    // The message relu(x + e) as ONE packed instruction (round 5).  The SIMD issues MFMAs and VALU instructions through one port
+    // (tools/coissue4.hip), so the walk's instruction count is kernel time: add + two v_max + add per two values were 51 VALU
+    // instructions per in-edge and lane.  The VOP3P clamp bit clamps a float result to [0, 1]; with the table stored as e * 2^-16
+    // (gin.hip: the resident kernel's own copy) v_pk_fma_f32(x, 2^-16, e * 2^-16) clamp = relu(x + e) * 2^-16 EXACTLY -- scaling
+    // by a power of two commutes with every rounding -- as long as x + e < 2^16.  The sums run in the scaled domain and come back with
+    // the self term (a = fma(m', 2^16, h[v]) below): the same bits as before.  x + e >= 2^16 needs h[u] > 6e4 (|e| < 4 096 is checked
+    // when the weights are set), and then a[u] = h[u] + m[u] >= h[u] raises the range flag in this very layer: the pass is repeated on
+    // the exact kernels, as for any operand beyond the f16 range.  26 VALU instructions per in-edge and lane.
+    const float2_t gr_c2 = {GR_MSG_SCALE, GR_MSG_SCALE};
+#define GR_MSG2(D, XX, WW) asm("v_pk_fma_f32 %0, %1, %2, %3 clamp" : "=v"(D) : "v"(XX), "s"(gr_c2), "v"(WW))  /* (the constant in a scalar pair: two more live vector registers spilled) */
+#define GR_MSG1(D, XX, WW) asm("v_fma_f32 %0, %1, %2, %3 clamp" : "=v"(D) : "v"(XX), "s"(GR_MSG_SCALE), "v"(WW))
 #define GR_FOLD(NTI, X, W, XT, WT)                                                                                                \
     {                                                                                                                             \
         _Pragma("unroll") for (int q = 0; q < 6; q++) {                                                                           \
-            const float2_t a = __builtin_elementwise_max(W[q].lo + X[q].lo, (float2_t){0.0f, 0.0f});                              \
-            const float2_t b = __builtin_elementwise_max(W[q].hi + X[q].hi, (float2_t){0.0f, 0.0f});                              \
+            float2_t a, b;                                                                                                        \
+            { const float2_t xl = X[q].lo, wl = W[q].lo, xh = X[q].hi, wh = W[q].hi; GR_MSG2(a, xl, wl); GR_MSG2(b, xh, wh); }      \
             aq[NTI][2 * q + 0] += a;                                                                                              \
             aq[NTI][2 * q + 1] += b;                                                                                              \
         }                                                                                                                         \
-        at[NTI] += relu1(WT + XT);                                                                                                \
+        { float m1; GR_MSG1(m1, XT, WT); at[NTI] += m1; }                                                                         \
     }
-    // the 24 + 1 sums of a row as 12 register PAIRS: v_pk_add_f32 for the message and for the accumulation (two v_max between)
+    // the 24 + 1 sums of a row as 12 register PAIRS: one v_pk_fma_f32 (clamp) for the message, one v_pk_add_f32 for the accumulation
     float2_t aq[NT][12];
     float at[NT] = {0.0f, 0.0f};
 #pragma unroll
@@ -1325,7 +1337,7 @@ __device__ __forceinline__ void gr_layer(unsigned long long (&tacc)[6], char* bx
     }
 #undef GR_READ
 #undef GR_NEXT
-#undef GR_FOLD
+#undef GR_FOLD  // (GR_MSG2 / GR_MSG1 serve the hub walk below as well)
 #ifdef GR_PROF_WALK
     if constexpr (PROF) { const unsigned long long t = wall_clock64(); tacc[5] += t - tw0; tw0 = t; }
 #endif
@@ -1370,10 +1382,12 @@ __device__ __forceinline__ void gr_layer(unsigned long long (&tacc)[6], char* bx
                     const float wt = s_ecomb[code * GS_D + 96 + g];
 #pragma unroll
                     for (int q = 0; q < 6; q++) {
-                        pq[2 * q + 0] += __builtin_elementwise_max(w[q].lo + x[q].lo, (float2_t){0.0f, 0.0f});
-                        pq[2 * q + 1] += __builtin_elementwise_max(w[q].hi + x[q].hi, (float2_t){0.0f, 0.0f});
+                        float2_t a, b;
+                        { const float2_t xl = x[q].lo, wl = w[q].lo, xh = x[q].hi, wh = w[q].hi; GR_MSG2(a, xl, wl); GR_MSG2(b, xh, wh); }
+                        pq[2 * q + 0] += a;
+                        pq[2 * q + 1] += b;
                     }
-                    pt += relu1(wt + xt);
+                    { float m1; GR_MSG1(m1, xt, wt); pt += m1; }
                 }
 #pragma unroll
                 for (int k = 0; k < 12; k++) { part[2 * k] = pq[k].x; part[2 * k + 1] = pq[k].y; }
@@ -1396,6 +1410,8 @@ __device__ __forceinline__ void gr_layer(unsigned long long (&tacc)[6], char* bx
             }
         }
     }
+#undef GR_MSG2
+#undef GR_MSG1
     uint4_t in_hi[NT][3], in_lo[NT][3], in_tb[NT];
     {   // + (1 + eps) h[v], eps == 0; rows beyond the tile contribute zeros.  All fourteen reads of the wave's own rows are requested
         // before the first add: left to itself hipcc re-uses ONE register quad and serialises them -- ds_read_b128, s_waitcnt
@@ -1413,12 +1429,14 @@ __device__ __forceinline__ void gr_layer(unsigned long long (&tacc)[6], char* bx
         GR_SB();
 #pragma unroll
         for (int nt = 0; nt < NT; nt++) {
+            // a = h[v] + m = fma(m * 2^-16, 2^16, h[v]): the scaled sums come back exactly (rows beyond the tile: m = +0 stays +0)
             if (row[nt] < cur.rows) {
 #pragma unroll
                 for (int q = 0; q < 6; q++) {
-                    bq[nt][4 * q + 0] += sx[nt][q].x; bq[nt][4 * q + 1] += sx[nt][q].y; bq[nt][4 * q + 2] += sx[nt][q].z; bq[nt][4 * q + 3] += sx[nt][q].w;
+                    bq[nt][4 * q + 0] = __builtin_fmaf(bq[nt][4 * q + 0], GR_MSG_UNSCALE, sx[nt][q].x); bq[nt][4 * q + 1] = __builtin_fmaf(bq[nt][4 * q + 1], GR_MSG_UNSCALE, sx[nt][q].y);
+                    bq[nt][4 * q + 2] = __builtin_fmaf(bq[nt][4 * q + 2], GR_MSG_UNSCALE, sx[nt][q].z); bq[nt][4 * q + 3] = __builtin_fmaf(bq[nt][4 * q + 3], GR_MSG_UNSCALE, sx[nt][q].w);
                 }
-                bq[nt][24] += sxt[nt];
+                bq[nt][24] = __builtin_fmaf(bq[nt][24], GR_MSG_UNSCALE, sxt[nt]);
             }
         }
     }
