@@ -731,6 +731,7 @@ __global__ __launch_bounds__(GCNR_WAVES * 64, 3) void gcn_resident_kernel(const 
             // instead of 100 -- changes nothing, 5.14 ms: the walk is bound by its LDS reads, not by VALU issue.)
             float2_t mq[12];
             float mt = 0.0f;
+            const float2_t msg_c2 = {1.0f / 65536.0f, 1.0f / 65536.0f};
 #pragma unroll
             for (int k = 0; k < 12; k++) mq[k] = (float2_t){0.0f, 0.0f};
             {
@@ -754,13 +755,22 @@ __global__ __launch_bounds__(GCNR_WAVES * 64, 3) void gcn_resident_kernel(const 
                     }
                     const float xt = s_x[u * GCN_D + 96 + g];
                     const float wt = s_ecomb[code * GCN_D + 96 + g];
-                    const float2_t n2 = {norm, norm};
+                    // relu(x + e) as ONE clamped packed FMA per two values (as gin_resident_kernel's walk, gin_split.hip GR_MSG2): the table is
+                    // stored as e * 2^-16, v_pk_fma_f32(x, 2^-16, e') clamp = relu(x + e) * 2^-16 exactly while x + e < 2^16, and the norm
+                    // carries the 2^16 back (exact): the same bits with two VALU instructions per two values instead of four.  x + e >= 2^16
+                    // needs |x| > 6e4 (|e| < 4 096: set_weights), and every x this kernel writes is tracked by the range flag below.
+                    const float ns = norm * 65536.0f;
+                    const float2_t n2 = {ns, ns};
 #pragma unroll
                     for (int q = 0; q < 6; q++) {
-                        mq[2 * q + 0] += n2 * __builtin_elementwise_max(wv4[q].lo + xv[q].lo, (float2_t){0.0f, 0.0f});
-                        mq[2 * q + 1] += n2 * __builtin_elementwise_max(wv4[q].hi + xv[q].hi, (float2_t){0.0f, 0.0f});
+                        float2_t ta, tb;
+                        { const float2_t xl = xv[q].lo, wl = wv4[q].lo, xh = xv[q].hi, wh = wv4[q].hi;
+                          asm("v_pk_fma_f32 %0, %1, %2, %3 clamp" : "=v"(ta) : "v"(xl), "s"(msg_c2), "v"(wl));
+                          asm("v_pk_fma_f32 %0, %1, %2, %3 clamp" : "=v"(tb) : "v"(xh), "s"(msg_c2), "v"(wh)); }
+                        mq[2 * q + 0] += n2 * ta;
+                        mq[2 * q + 1] += n2 * tb;
                     }
-                    mt += norm * relu1(wt + xt);
+                    { float t1; asm("v_fma_f32 %0, %1, %2, %3 clamp" : "=v"(t1) : "v"(xt), "s"(1.0f / 65536.0f), "v"(wt)); mt += ns * t1; }
                 }
             }
             // W_{l+1} (45 pieces of 1 KiB) is requested BEHIND the walk and lands under the BatchNorm / split that follows and under the
@@ -866,6 +876,9 @@ __global__ __launch_bounds__(GCNR_WAVES * 64, 3) void gcn_resident_kernel(const 
                 if (col < GCN_D && valid) {
                     const float4_t o = acc * oscale;
                     *reinterpret_cast<float4*>(s_x + r * GCN_D + col) = make_float4(o.x, o.y, o.z, o.w);
+                    // (the next walk's clamped messages need |x| < 6e4: beyond it the pass is repeated on the exact kernels)
+                    asm("v_max3_f32 %0, |%1|, |%2|, %0" : "+v"(vmax) : "v"(o.x), "v"(o.y));
+                    asm("v_max3_f32 %0, |%1|, |%2|, %0" : "+v"(vmax) : "v"(o.z), "v"(o.w));
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -967,6 +980,7 @@ public:
                     for (int i = 0; i < GCN_D; i++) a += (double)cw[(size_t)o * GCN_D + i] * (double)nemb[(size_t)r * GCN_D + i];
                     proj[(size_t)r * GCN_D + o] = (float)a;
                 }
+            proj_max_src_ = proj;
             if ((rc = upload(&d_nemb_proj_, proj))) return rc;
             // ... and its pre-combined form for the one-pass front end (x_0 = (T01 + T234) + T5678: gcn_tile_build_kernel)
             std::vector<float> comb(gin_resident_enc_table_floats());
@@ -975,13 +989,25 @@ public:
         }
         {   // the graph-resident kernel's per-layer stream: [W_l split fragments, 45 KiB][ecomb_l | root_l | BN scale_l | BN shift_l, 25 KiB]
             std::vector<uint8_t> res((size_t)GCN_L * GCNR_LAYER_BYTES + 4096, 0);
+            float emax = 0.0f;
             for (int l = 0; l < GCN_L; l++) {
                 uint8_t* base = res.data() + (size_t)l * GCNR_LAYER_BYTES;
                 std::memcpy(base, split_all.data() + (size_t)l * dense100_split_bytes(GCN_OT), dense100_split_bytes(GCN_OT));
-                std::memcpy(base + GCNR_W_BYTES, &ecomb[(size_t)l * EDGE_COMBOS * GCN_D], sizeof(float) * EDGE_COMBOS * GCN_D);
+                {   // the edge-embedding combos scaled by 2^-16: the resident walk's clamped messages (gcn_resident_kernel)
+                    float* dst = reinterpret_cast<float*>(base + GCNR_W_BYTES);
+                    for (int i = 0; i < EDGE_COMBOS * GCN_D; i++) {
+                        const float e = ecomb[(size_t)l * EDGE_COMBOS * GCN_D + i];
+                        dst[i] = e * (1.0f / 65536.0f);
+                        emax = std::fmax(emax, std::fabs(e));
+                    }
+                }
                 std::memcpy(base + GCNR_W_BYTES + sizeof(float) * EDGE_COMBOS * GCN_D, &ep[(size_t)l * 3 * GCN_D], sizeof(float) * 3 * GCN_D);
             }
             if ((rc = upload(&d_res_, res))) return rc;
+            // the scaled walk is exact while x + e < 2^16: |e| < 4 096 here, |x| < 6e4 by the range flag (x_0: nine projected-table rows)
+            float pmax = 0.0f;
+            for (int r = 0; r < ND_FEATURE_TOTAL * GCN_D; r++) pmax = std::fmax(pmax, std::fabs(proj_max_src_[r]));
+            table_ok_ = emax < 4096.0f && 9.0f * pmax < 6.0e4f;
         }
         if ((rc = upload(&d_split_, split_all))) return rc;
         if ((rc = upload(&d_nemb_, v_nemb))) return rc;
@@ -1069,7 +1095,7 @@ public:
     // x_0 by the encoder, then everything else in one launch when the batch packs into graph tiles (tiles under half full waste MFMA
     // columns: the per-layer kernels take those; so do per-node taps and the multi-task readout)
     bool use_resident(const DeviceBatch& db) const {
-        return resident_ && !qmode_ && !keep_h_ && split_ && !exact_ && fused_ && num_tasks_ == 1 && db.gtiles.ok && db.gtiles.n_tiles > 0 &&
+        return resident_ && table_ok_ && !qmode_ && !keep_h_ && split_ && !exact_ && fused_ && num_tasks_ == 1 && db.gtiles.ok && db.gtiles.n_tiles > 0 &&
                db.gtiles.fill >= 0.5;
     }
     // the one-pass front end (gcn_tile_build_kernel + the resident kernel's own encoder): the default; gcn_tile_build = 0 restores the
@@ -1236,6 +1262,8 @@ private:
     QPack q_;
     GrowBufI desc_;               // gcn_tile_build_kernel: GCND_BYTES per graph tile
     float* d_enc_tab_ = nullptr;  // the projected table pre-combined into three rows per node (gin_resident_pack_enc_table)
+    bool table_ok_ = true;             // the resident walk's scaled messages are exact for these weights (set_weights)
+    std::vector<float> proj_max_src_;  // the projected table (host copy, for that check)
     bool x0_in_hbm_ = false;      // db.h[..] holds rows of the resident batch (false behind the one-pass front end and the fixed-point pass)
     bool tile_build_ = true;      // gcn_tile_build = 0: index build + projected encoder as separate launches in front of the resident kernel
     int num_tasks_ = 1;  // NUM_TASK (GCN/src/dcl.h) as a run-time dimension
