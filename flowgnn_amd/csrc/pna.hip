@@ -389,15 +389,28 @@ __device__ __forceinline__ void pna_slice_finish(const PnaSlice& a, int indeg, d
     asm volatile("" : "+v"(vmax));
 }
 
+// wmask (wave-uniform, once per tile: pna_walk_mask): bit w = every row of the wave has the four in-edges of word w, bit 4 + w = some row
+// has one of them, bit 8 = some row has more than sixteen.  (Evaluated inside the walk, each __all / __any was a v_cndmask + v_cmp +
+// scalar compare per word and K-step: 20 of a gather's ~150 VALU instructions -- and VALU issue is kernel time, tools/coissue4.hip.)
+__device__ __forceinline__ int pna_walk_mask(int indeg) {
+    int m = 0;
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+        if (__all(indeg >= 4 * w + 4)) m |= 1 << w;
+        if (__any(indeg > 4 * w)) m |= 16 << w;
+    }
+    if (__any(indeg > 16)) m |= 256;
+    return __builtin_amdgcn_readfirstlane(m);
+}
 __device__ __forceinline__ void pna_gather_slice(const float* __restrict__ s_h, const uint8_t* __restrict__ s_src, const uint32_t (&srcw)[4],
-                                                 int e_base, int indeg, int col, ds_uint4_t& b_hi, ds_uint4_t& b_lo, float& vmax) {
+                                                 int e_base, int indeg, int wmask, int col, ds_uint4_t& b_hi, ds_uint4_t& b_lo, float& vmax) {
     PnaSlice a{0.f, 0.f, 0.f, 0.f, PNA_SENT_MAX, PNA_SENT_MAX, PNA_SENT_MIN, PNA_SENT_MIN};
 #ifdef PNA_GATHER_PRIO
     __builtin_amdgcn_s_setprio(PNA_GATHER_PRIO);
 #endif
 #pragma unroll
     for (int w = 0; w < 4; w++) {
-        if (__all(indeg >= 4 * w + 4)) {  // every row of the wave has these four in-edges (kNN graphs): four reads in flight, no masks
+        if (wmask & (1 << w)) {  // every row of the wave has these four in-edges (kNN graphs): four reads in flight, no masks
             float2 x[4];
 #pragma unroll
             for (int b = 0; b < 4; b++) x[b] = *reinterpret_cast<const float2*>(s_h + (int)((srcw[w] >> (8 * b)) & 0xFFu) * PNA_FT_STRIDE + col);
@@ -413,14 +426,15 @@ __device__ __forceinline__ void pna_gather_slice(const float* __restrict__ s_h, 
                 asm("v_max3_f32 %0, %1, %2, %0" : "+v"(a.mx0) : "v"(x[b].x), "v"(x[b + 1].x));
                 asm("v_max3_f32 %0, %1, %2, %0" : "+v"(a.mx1) : "v"(x[b].y), "v"(x[b + 1].y));
             }
-        } else if (__any(indeg > 4 * w)) {  // ragged: whole words are skipped when no row of the wave has them
+        } else if (wmask & (16 << w)) {  // ragged: whole words are skipped when no row of the wave has them
 #pragma unroll
             for (int b = 0; b < 4; b++)
                 if (indeg > 4 * w + b) pna_slice_edge(a, s_h, (int)((srcw[w] >> (8 * b)) & 0xFFu), col);
         }
     }
-    for (int e = 16; __any(e < indeg); e++)  // rows with more than 16 in-edges: the rest comes from the LDS copy of the CSR slice
-        if (e < indeg) pna_slice_edge(a, s_h, (int)s_src[e_base + e], col);
+    if (wmask & 256)
+        for (int e = 16; __any(e < indeg); e++)  // rows with more than 16 in-edges: the rest comes from the LDS copy of the CSR slice
+            if (e < indeg) pna_slice_edge(a, s_h, (int)s_src[e_base + e], col);
     pna_slice_finish(a, indeg, b_hi, b_lo, vmax);
 #ifdef PNA_GATHER_PRIO
     __builtin_amdgcn_s_setprio(0);
@@ -489,6 +503,7 @@ __global__ __launch_bounds__(PNA_FT_WAVES * 64, 4) void pna_layer_fused_kernel(c
         const int e_base = valid ? (int)crp[r] : 0;
         int indeg = valid ? (int)crp[r + 1] - e_base : 0;
         if (ablate & 1) indeg = 0;  // development aid (pna_ablate, -DFLOWGNN_DEV builds): timing without the gather
+        const int wmask = pna_walk_mask(indeg);
         uint32_t srcw[4];  // the first 16 in-edges, one byte each (re-walked by every K-step)
 #pragma unroll
         for (int w = 0; w < 4; w++) {
@@ -505,7 +520,7 @@ __global__ __launch_bounds__(PNA_FT_WAVES * 64, 4) void pna_layer_fused_kernel(c
         for (int i = 0; i < PNA_NS * PNA_OT; i++) y[i] = (float4_t){0.f, 0.f, 0.f, 0.f};
         ds_uint4_t b_hi = {0, 0, 0, 0}, b_lo = {0, 0, 0, 0};
         PNA_STAMP(1);
-        if (late) pna_gather_slice(s_h, csrc, srcw, e_base, indeg, 2 * g, b_hi, b_lo, vmax);  // K-step 0's slice, ahead of the first interval
+        if (late) pna_gather_slice(s_h, csrc, srcw, e_base, indeg, wmask, 2 * g, b_hi, b_lo, vmax);  // K-step 0's slice, ahead of the first interval
         PNA_STAMP(2);
         // Development variants of WHERE a K-step's chunk request sits (round-3 finding: requested between a wave's two phases the
         // kernel was 1.6 % faster and two-engine runs stopped being bit-identical; scripts/dev/pna_dma_race.py bisects it):
@@ -532,7 +547,7 @@ __global__ __launch_bounds__(PNA_FT_WAVES * 64, 4) void pna_layer_fused_kernel(c
         for (int ks = 0; ks < ((ablate & 2) ? 0 : PNA_KS); ks += 2) {
             // even K-step from s_a while chunk ks+1 streams into s_b
             if (!mid) pna_issue_chunk_asm(wpk + (size_t)(ks + 1) * PNA_CHUNK, s_b, wave, lane);
-            if (!late) pna_gather_slice(s_h, csrc, srcw, e_base, indeg, 8 * ks + 2 * g, b_hi, b_lo, vmax);
+            if (!late) pna_gather_slice(s_h, csrc, srcw, e_base, indeg, wmask, 8 * ks + 2 * g, b_hi, b_lo, vmax);
             if (mid && !late) issue_mid(wpk + (size_t)(ks + 1) * PNA_CHUNK, s_b);
             PNA_STAMP(2);
             if (ablate & 1024) __builtin_amdgcn_s_setprio(2);
@@ -543,10 +558,10 @@ __global__ __launch_bounds__(PNA_FT_WAVES * 64, 4) void pna_layer_fused_kernel(c
 #endif
             PNA_STAMP(3);
             if (mid && late) issue_mid(wpk + (size_t)(ks + 1) * PNA_CHUNK, s_b);
-            if (late) pna_gather_slice(s_h, csrc, srcw, e_base, indeg, 8 * (ks + 1) + 2 * g, b_hi, b_lo, vmax);
+            if (late) pna_gather_slice(s_h, csrc, srcw, e_base, indeg, wmask, 8 * (ks + 1) + 2 * g, b_hi, b_lo, vmax);
             close_step();
             if (!mid && ks + 2 < PNA_KS) pna_issue_chunk_asm(wpk + (size_t)(ks + 2) * PNA_CHUNK, s_a, wave, lane);
-            if (!late) pna_gather_slice(s_h, csrc, srcw, e_base, indeg, 8 * (ks + 1) + 2 * g, b_hi, b_lo, vmax);
+            if (!late) pna_gather_slice(s_h, csrc, srcw, e_base, indeg, wmask, 8 * (ks + 1) + 2 * g, b_hi, b_lo, vmax);
             if (mid && !late && ks + 2 < PNA_KS) issue_mid(wpk + (size_t)(ks + 2) * PNA_CHUNK, s_a);
             PNA_STAMP(2);
             if (ablate & 1024) __builtin_amdgcn_s_setprio(2);
@@ -557,7 +572,7 @@ __global__ __launch_bounds__(PNA_FT_WAVES * 64, 4) void pna_layer_fused_kernel(c
 #endif
             PNA_STAMP(3);
             if (mid && late && ks + 2 < PNA_KS) issue_mid(wpk + (size_t)(ks + 2) * PNA_CHUNK, s_a);
-            if (late && ks + 2 < PNA_KS) pna_gather_slice(s_h, csrc, srcw, e_base, indeg, 8 * (ks + 2) + 2 * g, b_hi, b_lo, vmax);
+            if (late && ks + 2 < PNA_KS) pna_gather_slice(s_h, csrc, srcw, e_base, indeg, wmask, 8 * (ks + 2) + 2 * g, b_hi, b_lo, vmax);
             close_step();
         }
         // ---- epilogue: h' = h + relu(b + Y_0 + t Y_1 + scale Y_2)   (node_embedding.cc:148-150,205-213); the residual rows come
