@@ -1247,9 +1247,16 @@ __device__ __forceinline__ void gr_layer(unsigned long long (&tacc)[6], char* bx
     }
 #pragma unroll
     for (int nt = 0; nt < NT; nt++) trips[nt] = tile_trips[nt];
+// (development, -DGR_CONFLICT_FREE_WALK: every lane of a column tile reads a row of its own bank class -- WRONG results, the walk's time
+//  without LDS bank conflicts; scripts/dev/variant.sh)
+#ifdef GR_CONFLICT_FREE_WALK
+#define GR_WALK_ROW(U) ((((U) & ~15u) | (unsigned)j) < (unsigned)GR_ROWS ? (((U) & ~15u) | (unsigned)j) : (unsigned)j)
+#else
+#define GR_WALK_ROW(U) (U)
+#endif
 #define GR_READ(NTI, X, W, XT, WT)                                                                                                \
     {                                                                                                                             \
-        const unsigned u = wd[NTI] >> 6, code = wd[NTI] & 63u;                                                                    \
+        const unsigned u = GR_WALK_ROW(wd[NTI] >> 6), code = wd[NTI] & 63u;                                                       \
         const float* hr = s_h + u * GS_D + 4 * g;                                                                                 \
         const float* er = s_ecomb + code * GS_D + 4 * g;                                                                          \
         _Pragma("unroll") for (int q = 0; q < 6; q++) {                                                                           \
