@@ -1254,9 +1254,14 @@ __device__ __forceinline__ void gr_layer(unsigned long long (&tacc)[6], char* bx
 #else
 #define GR_WALK_ROW(U) (U)
 #endif
+#ifdef GR_ONE_CODE_WALK  // every lane reads the table row of code 0 (one broadcast); cf_zero is an opaque 0, so the reads stay in the loop
+#define GR_WALK_CODE(C) ((C) & cf_zero)
+#else
+#define GR_WALK_CODE(C) (C)
+#endif
 #define GR_READ(NTI, X, W, XT, WT)                                                                                                \
     {                                                                                                                             \
-        const unsigned u = GR_WALK_ROW(wd[NTI] >> 6), code = wd[NTI] & 63u;                                                       \
+        const unsigned u = GR_WALK_ROW(wd[NTI] >> 6), code = GR_WALK_CODE(wd[NTI] & 63u);                                                    \
         const float* hr = s_h + u * GS_D + 4 * g;                                                                                 \
         const float* er = s_ecomb + code * GS_D + 4 * g;                                                                          \
         _Pragma("unroll") for (int q = 0; q < 6; q++) {                                                                           \
@@ -1303,6 +1308,10 @@ __device__ __forceinline__ void gr_layer(unsigned long long (&tacc)[6], char* bx
         for (int k = 0; k < 12; k++) aq[nt][k] = (float2_t){0.0f, 0.0f};
     }
     const int tboth = min(trips[0], trips[1]);
+#ifdef GR_ONE_CODE_WALK
+    unsigned cf_zero = 0;
+    asm volatile("" : "+v"(cf_zero));
+#endif
 #ifdef GR_PROF_WALK  // development: tacc[5] = the three walk loops alone, tacc[4] = self term + operand split (instead of DMA wait / step barriers)
     unsigned long long tw0 = 0;
     if constexpr (PROF) tw0 = wall_clock64();
