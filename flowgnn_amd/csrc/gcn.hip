@@ -342,6 +342,10 @@ constexpr int GCNR_WAVES = 12;
 constexpr int GCNR_W_BYTES = 45 * 1024;     // dense100_split_bytes(GCN_OT) = 45 264, padded to whole 1 KiB DMA pieces
 constexpr int GCNR_BLOB_BYTES = 25 * 1024;  // ecomb [60][100] | root | BN scale | BN shift (25 200 B)
 constexpr int GCNR_LAYER_BYTES = GCNR_W_BYTES + GCNR_BLOB_BYTES;
+// The edge-embedding table a second time, for the walk's reads through the vector-memory path: planes [quad q of 6][quarter g][code, padded
+// to 64] of 16 B -- the sixteen lanes of a quarter wave (one q, one g, sixteen codes) fall into one plane of 1 KiB = 8 cache lines.
+constexpr int GCNR_PLANES_OFF = GCN_L * GCNR_LAYER_BYTES + 4096, GCNR_PLANES_BYTES = 6 * 4 * 64 * 16;
+constexpr int GCNR_EQ_VMEM = 4;  // quads of a table row the walk reads through L1 (the other two and the tail from LDS)
 static_assert(dense100_split_bytes(GCN_OT) <= (size_t)GCNR_W_BYTES, "weight region");
 static_assert((EDGE_COMBOS + 3) * GCN_D * 4 <= GCNR_BLOB_BYTES, "table region");
 
@@ -756,6 +760,17 @@ __global__ __launch_bounds__(GCNR_WAVES * 64, 3) void gcn_resident_kernel(const 
             {
                 int e = e_begin;
                 int w_nx = e < e_end ? (int)s_edge[e] : 0;
+                // Two memories feed the walk.  Per in-edge a lane group reads 400 B of x[u] and 400 B of the edge table, and the LDS array --
+                // half of its cycles bank conflicts of sixteen unrelated rows per pass -- is what the walk waits for, while the CU's
+                // vector-memory path (64 B per clock from L1) has nothing to do between the weight streams.  So GCNR_EQ_VMEM of the table
+                // row's six quads come from the table's second copy in global memory (set_weights: planes [quad][quarter][code] of 16 B, so
+                // that a quarter wave's sixteen codes fall into 8 cache lines; 24 KB per layer, L1 / L2 resident), requested one trip ahead.
+                // Same values, same instructions on them: bit-identical.  Launch at 2^18 molhiv graphs, one box: 4.61 ms (all LDS),
+                // 4.40 / 4.34 / 4.49 / 4.69 with 3 / 4 / 5 / 6 quads through L1 (row-major copy: best at 3 quads, 4.39).
+                const float* etab_g = reinterpret_cast<const float*>(layers + GCNR_PLANES_OFF + (size_t)l * GCNR_PLANES_BYTES) + 256 * g;
+                float4_t wg[GCNR_EQ_VMEM];
+#pragma unroll
+                for (int q = 0; q < GCNR_EQ_VMEM; q++) wg[q] = *reinterpret_cast<const float4_t*>(etab_g + (w_nx & 63) * 4 + 1024 * q);
 #pragma unroll 1
                 for (int t = 0; t < trips; t++) {
                     GCN_WALK_WORD(w_nx);
@@ -769,9 +784,16 @@ __global__ __launch_bounds__(GCNR_WAVES * 64, 3) void gcn_resident_kernel(const 
                     const float* er = s_ecomb + code * GCN_D + 4 * g;
                     float4_t xv[6], wv4[6];
 #pragma unroll
+                    for (int q = 0; q < GCNR_EQ_VMEM; q++) wv4[q] = wg[q];
+                    {
+                        const float* ergn = etab_g + (w_nx & 63) * 4;  // the next trip's row (code 0 behind the last edge)
+#pragma unroll
+                        for (int q = 0; q < GCNR_EQ_VMEM; q++) wg[q] = *reinterpret_cast<const float4_t*>(ergn + 1024 * q);
+                    }
+#pragma unroll
                     for (int q = 0; q < 6; q++) {
                         xv[q] = *reinterpret_cast<const float4_t*>(hr + 16 * q);
-                        wv4[q] = *reinterpret_cast<const float4_t*>(er + 16 * q);
+                        if (q >= GCNR_EQ_VMEM) wv4[q] = *reinterpret_cast<const float4_t*>(er + 16 * q);
                     }
                     const float xt = s_x[u * GCN_D + 96 + g];
                     const float wt = s_ecomb[code * GCN_D + 96 + g];
@@ -1008,7 +1030,7 @@ public:
             if ((rc = upload(&d_enc_tab_, comb))) return rc;
         }
         {   // the graph-resident kernel's per-layer stream: [W_l split fragments, 45 KiB][ecomb_l | root_l | BN scale_l | BN shift_l, 25 KiB]
-            std::vector<uint8_t> res((size_t)GCN_L * GCNR_LAYER_BYTES + 4096, 0);
+            std::vector<uint8_t> res((size_t)GCNR_PLANES_OFF + (size_t)GCN_L * GCNR_PLANES_BYTES, 0);
             float emax = 0.0f;
             for (int l = 0; l < GCN_L; l++) {
                 uint8_t* base = res.data() + (size_t)l * GCNR_LAYER_BYTES;
@@ -1020,6 +1042,11 @@ public:
                         dst[i] = e * (1.0f / 65536.0f);
                         emax = std::fmax(emax, std::fabs(e));
                     }
+                    float* pl = reinterpret_cast<float*>(res.data() + GCNR_PLANES_OFF + (size_t)l * GCNR_PLANES_BYTES);
+                    for (int q = 0; q < 6; q++)
+                        for (int gq = 0; gq < 4; gq++)
+                            for (int c = 0; c < EDGE_COMBOS; c++)
+                                for (int k = 0; k < 4; k++) pl[(((size_t)q * 4 + gq) * 64 + c) * 4 + k] = dst[c * GCN_D + 16 * q + 4 * gq + k];
                 }
                 std::memcpy(base + GCNR_W_BYTES + sizeof(float) * EDGE_COMBOS * GCN_D, &ep[(size_t)l * 3 * GCN_D], sizeof(float) * 3 * GCN_D);
             }
