@@ -658,8 +658,15 @@ public:
             // with one clamped packed FMA per two values (gin_split.hip, GR_MSG2).  Exact while |e| < 4 096 (x + e < 2^16 needs
             // x < 6e4, the range every operand is checked against anyway); tables beyond that take the per-layer kernels.
             float emax = 0.0f;
-            std::vector<float> sc(ecomb.size());
+            std::vector<float> sc(ecomb.size() + (size_t)GIN_L * 6 * 4 * 64 * 4, 0.0f);
             for (size_t i = 0; i < ecomb.size(); i++) { sc[i] = ecomb[i] * (1.0f / 65536.0f); emax = std::fmax(emax, std::fabs(ecomb[i])); }
+            // ... and once more in plane order [layer][quad q][quarter g][code, padded to 64] of 16 B, for the walk's reads through L1
+            for (int l = 0; l < GIN_L; l++)
+                for (int q = 0; q < 6; q++)
+                    for (int gq = 0; gq < 4; gq++)
+                        for (int c = 0; c < EDGE_COMBOS; c++)
+                            for (int k = 0; k < 4; k++)
+                                sc[ecomb.size() + ((((size_t)l * 6 + q) * 4 + gq) * 64 + c) * 4 + k] = sc[((size_t)l * EDGE_COMBOS + c) * GIN_D + 16 * q + 4 * gq + k];
             table_ok_ = emax < 4096.0f;  // (NaN: false)
             if ((rc = upload(&d_ecomb_res_, sc))) return rc;
         }

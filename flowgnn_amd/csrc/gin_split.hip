@@ -824,6 +824,7 @@ __device__ __forceinline__ GrTile gr_load_tile(const int* __restrict__ tile_row,
 constexpr int GR_DESC_RP = GR_EDGES * 2;
 constexpr int GR_DESC_PERM = GR_DESC_RP + 528;
 constexpr int GR_DESC_BYTES = 3584;  // 3.5 pieces of 1 KiB
+constexpr int GR_PLANES_FLOATS = 6 * 4 * 64 * 4, GR_PLANES_OFF = 5 * EDGE_COMBOS * GS_D;  // behind the five layers' row-major tables
 constexpr unsigned GR_NO_EDGE = (unsigned)GR_ROWS << 6;  // edge word of "no in-edge left": source row GR_ROWS (all -1e30), code 0
 constexpr int GR_HUB_DEG = 8;        // HUBS kernels: rows with more in-edges than this are walked by their whole 16-lane group
 
@@ -1224,6 +1225,15 @@ __device__ __forceinline__ void gr_layer(unsigned long long (&tacc)[6], char* bx
 #pragma unroll
     for (int nt = 0; nt < NT; nt++) wd[nt] = e_cur[nt] < e_end[nt] ? (unsigned)s_edge[e_cur[nt]] : GR_NO_EDGE;
     const float* s_ecomb = reinterpret_cast<const float*>(bx);
+    // GIN-VN: three of a table row's six quads come through the vector-memory path, from the table's plane-ordered copy in global memory
+    // (gin.hip set_weights; [quad][quarter][code] of 16 B: a quarter wave's sixteen codes fall into 8 cache lines) -- the HUBS kernel
+    // waits for its LDS array (limits.json), and the CU's L1 path is idle between weight chunks: gin_resident 9.02 -> 8.87 ms (2 / 3 / 4
+    // quads: -1.0 / -1.7 / -1.4 %; requested a trip ahead: +0.4 %; in the hub walk as well: +-0).  Plain GIN's walk does not wait for
+    // LDS bandwidth (+-0.3 % with 2, 3 or 4 quads) and keeps all six reads in LDS.  As in gcn_resident_kernel's walk, where the same
+    // split returns 6 %; same values, same arithmetic: bit-identical.
+    constexpr int EQ_VMEM = HUBS ? 3 : 0;
+    const float* epl = ecomb_all + GR_PLANES_OFF + (size_t)l * GR_PLANES_FLOATS + 256 * g;
+    (void)epl;
     // A lane whose row has no in-edge left walks the NO-EDGE word: source row GR_ROWS of the tile (-1e30 in every feature, written
     // once per workgroup), so its message is relu(-1e30 + e) = +0 and the accumulation needs no per-lane guard.  (With the guard,
     // `if (lane active) bq += ...`, hipcc keeps two copies of the 25 accumulators and moves them back and forth: 54 v_mov per trip
@@ -1264,9 +1274,10 @@ __device__ __forceinline__ void gr_layer(unsigned long long (&tacc)[6], char* bx
         const unsigned u = GR_WALK_ROW(wd[NTI] >> 6), code = GR_WALK_CODE(wd[NTI] & 63u);                                                    \
         const float* hr = s_h + u * GS_D + 4 * g;                                                                                 \
         const float* er = s_ecomb + code * GS_D + 4 * g;                                                                          \
+        _Pragma("unroll") for (int q = 0; q < EQ_VMEM; q++) W[q] = *reinterpret_cast<const float4_t*>(epl + code * 4 + 1024 * q);   \
         _Pragma("unroll") for (int q = 0; q < 6; q++) {                                                                           \
             X[q] = *reinterpret_cast<const float4_t*>(hr + 16 * q);                                                               \
-            W[q] = *reinterpret_cast<const float4_t*>(er + 16 * q);                                                               \
+            if (q >= EQ_VMEM) W[q] = *reinterpret_cast<const float4_t*>(er + 16 * q);                                             \
         }                                                                                                                         \
         XT = s_h[u * GS_D + 96 + g];                                                                                              \
         WT = s_ecomb[code * GS_D + 96 + g];                                                                                       \
