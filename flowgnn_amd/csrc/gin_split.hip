@@ -1225,13 +1225,16 @@ __device__ __forceinline__ void gr_layer(unsigned long long (&tacc)[6], char* bx
 #pragma unroll
     for (int nt = 0; nt < NT; nt++) wd[nt] = e_cur[nt] < e_end[nt] ? (unsigned)s_edge[e_cur[nt]] : GR_NO_EDGE;
     const float* s_ecomb = reinterpret_cast<const float*>(bx);
-    // GIN-VN: three of a table row's six quads come through the vector-memory path, from the table's plane-ordered copy in global memory
-    // (gin.hip set_weights; [quad][quarter][code] of 16 B: a quarter wave's sixteen codes fall into 8 cache lines) -- the HUBS kernel
-    // waits for its LDS array (limits.json), and the CU's L1 path is idle between weight chunks: gin_resident 9.02 -> 8.87 ms (2 / 3 / 4
-    // quads: -1.0 / -1.7 / -1.4 %; requested a trip ahead: +0.4 %; in the hub walk as well: +-0).  Plain GIN's walk does not wait for
-    // LDS bandwidth (+-0.3 % with 2, 3 or 4 quads) and keeps all six reads in LDS.  As in gcn_resident_kernel's walk, where the same
-    // split returns 6 %; same values, same arithmetic: bit-identical.
-    constexpr int EQ_VMEM = HUBS ? 3 : 0;
+    // Two memories feed the walk: three of a table row's six quads come through the vector-memory path, from the table's plane-ordered
+    // copy in global memory (gin.hip set_weights; [quad][quarter][code] of 16 B: a quarter wave's sixteen codes fall into 8 cache
+    // lines) -- the CU's L1 path is idle between weight chunks, and the walk waits for the LDS array (HUBS: `lds_busy` is the kernel's
+    // limit, limits.json) or at least for its latency under bank conflicts.  As in gcn_resident_kernel's walk, where the split returns
+    // 6 %; same values, same arithmetic: bit-identical.  Measured (2^18 graphs, A/B on one box, gin_resident):
+    //   GIN-VN  quads 0..2: 9.02 -> 8.87 ms (2 / 3 / 4 quads: -1.0 / -1.7 / -1.4 %; quads 3..5: +0.3 % on that; requested a trip ahead:
+    //           +0.4 %, 24 more live registers in a loop at 250; in the hub walk as well: +-0)
+    //   GIN     quads 3..5 -- the ones the fold consumes LAST, so the loads' longer latency hides behind the LDS-fed quads: 7.70 -> 7.61
+    //           (3 / 4 / 5 quads: -1.2 / -0.9 / +0.2 %); quads 0..2, consumed first: +-0.3 %
+    constexpr int EQ_VMEM = 3, EQ_LO = HUBS ? 0 : 3;
     const float* epl = ecomb_all + GR_PLANES_OFF + (size_t)l * GR_PLANES_FLOATS + 256 * g;
     (void)epl;
     // A lane whose row has no in-edge left walks the NO-EDGE word: source row GR_ROWS of the tile (-1e30 in every feature, written
@@ -1274,10 +1277,10 @@ __device__ __forceinline__ void gr_layer(unsigned long long (&tacc)[6], char* bx
         const unsigned u = GR_WALK_ROW(wd[NTI] >> 6), code = GR_WALK_CODE(wd[NTI] & 63u);                                                    \
         const float* hr = s_h + u * GS_D + 4 * g;                                                                                 \
         const float* er = s_ecomb + code * GS_D + 4 * g;                                                                          \
-        _Pragma("unroll") for (int q = 0; q < EQ_VMEM; q++) W[q] = *reinterpret_cast<const float4_t*>(epl + code * 4 + 1024 * q);   \
+        _Pragma("unroll") for (int q = EQ_LO; q < EQ_LO + EQ_VMEM; q++) W[q] = *reinterpret_cast<const float4_t*>(epl + code * 4 + 1024 * q); \
         _Pragma("unroll") for (int q = 0; q < 6; q++) {                                                                           \
             X[q] = *reinterpret_cast<const float4_t*>(hr + 16 * q);                                                               \
-            if (q >= EQ_VMEM) W[q] = *reinterpret_cast<const float4_t*>(er + 16 * q);                                             \
+            if (q < EQ_LO || q >= EQ_LO + EQ_VMEM) W[q] = *reinterpret_cast<const float4_t*>(er + 16 * q);                        \
         }                                                                                                                         \
         XT = s_h[u * GS_D + 96 + g];                                                                                              \
         WT = s_ecomb[code * GS_D + 96 + g];                                                                                       \
