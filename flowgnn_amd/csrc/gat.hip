@@ -516,8 +516,8 @@ __global__ __launch_bounds__(GATR_WAVES * 64, 4) void gat_resident_kernel(const 
     // projections: 16 float4 (dims, heads in the float4) per row at a stride of GATR_PS = 17 float4 -- row u starts in bank group
     // u mod 16, so the sixteen rows a gather instruction reads spread over the groups as the former per-row rotation did, but the
     // dim index is a compile-time offset (the rotation cost ~10 VALU instructions per edge and lane in a VALU-issue-bound kernel)
-    __shared__ __attribute__((aligned(16))) float4 s_proj[GATR_ROWS * GATR_PS];
-    __shared__ __attribute__((aligned(16))) float4 s_sc[GATR_ROWS * 2];
+    __shared__ __attribute__((aligned(16))) float4 s_proj[(GATR_ROWS + 1) * GATR_PS];  // + the no-edge row (zeros; below)
+    __shared__ __attribute__((aligned(16))) float4 s_sc[(GATR_ROWS + 1) * 2];         // + the no-edge row (score -inf)
     __shared__ __attribute__((aligned(16))) float4 s_lin0[GAT_D * ND_FEATURE];
     __shared__ int s_feat[GATR_ROWS * ND_FEATURE];
     __shared__ __attribute__((aligned(4))) uint8_t s_src[GATR_EDGES];
@@ -538,6 +538,10 @@ __global__ __launch_bounds__(GATR_WAVES * 64, 4) void gat_resident_kernel(const 
     if (threadIdx.x < 2 * GAT_D) s_att[threadIdx.x] = reinterpret_cast<const float4*>(threadIdx.x < GAT_D ? w.a_src : w.a_tgt)[threadIdx.x & (GAT_D - 1)];
     if (threadIdx.x < GAT_D) s_pw[threadIdx.x] = w.pool_w[threadIdx.x];
     if (threadIdx.x < GAT_F) s_u4[threadIdx.x] = w.u4[threadIdx.x];
+    // The no-edge row GATR_ROWS: a lane whose row has no in-edge left keeps walking it -- score -inf, so exp2(leaky(s_v + -inf)) = +0
+    // is added to the denominator and 0 * 0 to the numerators, which leaves every sum's bits as they were (written once per workgroup)
+    if (threadIdx.x < GATR_PS) s_proj[GATR_ROWS * GATR_PS + threadIdx.x] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (threadIdx.x < 2) s_sc[GATR_ROWS * 2 + threadIdx.x] = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
     // the layers' three dequantisation scales, staged once: read from global memory where they are used, each cost its wave an
     // exposed L2 round trip (the load sits directly in front of its first use), two per layer and tile
     __shared__ float s_scales[3 * GAT_L + 1];
@@ -673,6 +677,11 @@ __global__ __launch_bounds__(GATR_WAVES * 64, 4) void gat_resident_kernel(const 
             GATR_ABSMAX(vmax, bq[8], bq[12]);
         }
         int ro_n0 = 0, ro_n1 = 1;
+        // trips of the walk: the self edge + the wave's longest row, wave-uniform, once per tile (the rows are the same in every layer)
+        int trips = e_end - e_begin;
+#pragma unroll
+        for (int mk = 1; mk < 64; mk <<= 1) trips = max(trips, __shfl_xor(trips, mk, 64));
+        trips = __builtin_amdgcn_readfirstlane(trips) + 1;
 #pragma unroll 1
         for (int l = 0; l < GAT_L; l++) {
             // this layer's fragments stream in under the gather, which does not use them: 36 pieces of 1 KiB (last layer: W_skip only)
@@ -704,31 +713,43 @@ __global__ __launch_bounds__(GATR_WAVES * 64, 4) void gat_resident_kernel(const 
 #pragma unroll
             for (int t = 0; t < 4; t++) num[t] = make_float4(0.f, 0.f, 0.f, 0.f);
             {
+                // Branch-free trips over a wave-uniform count (as gcn_resident_kernel's and gin_resident_kernel's walks).  The former
+                // `while (any lane has an edge) if (this lane has one) ...` cost, per trip, ten 64-bit moves of the accumulators (hipcc
+                // keeps a copy of every loop-carried value for the lanes that sit a trip out), four branches and a dozen exec-mask
+                // instructions beside the 26 VALU instructions that are the work -- in a kernel bound by VALU issue.
                 int e = e_begin;
-                int u = rr;
-                int u_nx = e < e_end ? (int)s_src[e] : 0;
-                bool more = true;
-                while (__any(more)) {
-                    if (more) {
-                        const float4 st = s_sc[u * 2 + 1];
-                        float4 p[4];
+                int u = rr;  // trip 0: the self edge
+                int u_nx = e < e_end ? (int)s_src[e] : GATR_ROWS;
+                // accumulators as register PAIRS (heads 0,1 | 2,3): one v_pk_fma_f32 per pair, no operand shuffles
+                float2_t dn[2] = {{0.f, 0.f}, {0.f, 0.f}}, nm[4][2];
 #pragma unroll
-                        for (int t = 0; t < 4; t++) p[t] = s_proj[u * GATR_PS + 4 * t + g];
-                        more = e < e_end;
-                        u = u_nx;
-                        e++;
-                        if (e < e_end) u_nx = (int)s_src[e];
-                        float4 sv = make_float4(ssrc.x + st.x, ssrc.y + st.y, ssrc.z + st.z, ssrc.w + st.w);
-                        // leaky_0.2(x) = max(x, 0.2 x)
-                        sv.x = __builtin_amdgcn_exp2f(__builtin_fmaxf(sv.x, sv.x * 0.2f)); sv.y = __builtin_amdgcn_exp2f(__builtin_fmaxf(sv.y, sv.y * 0.2f));
-                        sv.z = __builtin_amdgcn_exp2f(__builtin_fmaxf(sv.z, sv.z * 0.2f)); sv.w = __builtin_amdgcn_exp2f(__builtin_fmaxf(sv.w, sv.w * 0.2f));
-                        den.x += sv.x; den.y += sv.y; den.z += sv.z; den.w += sv.w;
+                for (int q = 0; q < 4; q++) { nm[q][0] = (float2_t){0.f, 0.f}; nm[q][1] = (float2_t){0.f, 0.f}; }
+#pragma unroll 1
+                for (int t = 0; t < trips; t++) {
+                    const float4_t st = *reinterpret_cast<const float4_t*>(&s_sc[u * 2 + 1]);
+                    float4_t p[4];
 #pragma unroll
-                        for (int t = 0; t < 4; t++) {
-                            num[t].x += sv.x * p[t].x; num[t].y += sv.y * p[t].y; num[t].z += sv.z * p[t].z; num[t].w += sv.w * p[t].w;
-                        }
+                    for (int q = 0; q < 4; q++) p[q] = *reinterpret_cast<const float4_t*>(&s_proj[u * GATR_PS + 4 * q + g]);
+                    u = u_nx;
+                    e++;
+                    const bool more = e < e_end;
+                    const int nx = (int)s_src[more ? e : 0];
+                    u_nx = more ? nx : GATR_ROWS;
+                    __builtin_amdgcn_sched_barrier(0);  // the trip's six reads are in flight before the first of them is waited for
+                    float4_t sv = {ssrc.x + st.x, ssrc.y + st.y, ssrc.z + st.z, ssrc.w + st.w};
+                    // leaky_0.2(x) = max(x, 0.2 x)
+                    sv.x = __builtin_amdgcn_exp2f(__builtin_fmaxf(sv.x, sv.x * 0.2f)); sv.y = __builtin_amdgcn_exp2f(__builtin_fmaxf(sv.y, sv.y * 0.2f));
+                    sv.z = __builtin_amdgcn_exp2f(__builtin_fmaxf(sv.z, sv.z * 0.2f)); sv.w = __builtin_amdgcn_exp2f(__builtin_fmaxf(sv.w, sv.w * 0.2f));
+                    dn[0] += sv.lo; dn[1] += sv.hi;
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        nm[q][0] = __builtin_elementwise_fma(sv.lo, p[q].lo, nm[q][0]);
+                        nm[q][1] = __builtin_elementwise_fma(sv.hi, p[q].hi, nm[q][1]);
                     }
                 }
+                den = make_float4(dn[0].x, dn[0].y, dn[1].x, dn[1].y);
+#pragma unroll
+                for (int q = 0; q < 4; q++) num[q] = make_float4(nm[q][0].x, nm[q][0].y, nm[q][1].x, nm[q][1].y);
             }
             float4_t acc[4];  // rows 16 t + 4 g + r' = (dim 4 t + g, head r') of this lane's node
             {   // msg = num / den: one v_rcp_f32 per head (1 ulp; sixteen IEEE divisions are ~160 dependent instructions per lane and layer)
