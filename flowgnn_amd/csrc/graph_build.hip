@@ -209,10 +209,8 @@ __global__ __launch_bounds__(NT) void build_csr_graph_kernel(BatchView b, CsrVie
     IdxT* s_v = DYN ? s_u + emax : st_v;
     IdxT* s_slot = DYN ? s_v + emax : st_slot;
     uint8_t* s_code = DYN ? reinterpret_cast<uint8_t*>(s_slot + emax) : st_code;
+    const int g = blockIdx.x;
     const int tid = threadIdx.x;
-    // one graph per workgroup (gridDim.x = num_graphs); a build behind `only_if` is launched with a small grid that strides over the
-    // graphs instead: when the flag says "not needed" -- the usual case -- 2^15 workgroups of 18 KB of LDS each took 20 us to start and return
-    for (int g = blockIdx.x; g < b.num_graphs; g += gridDim.x) {
     const int n = b.nums_of_nodes[g];
     const int noff = b.node_off[g];
     const int e0 = b.edge_off[g];
@@ -309,33 +307,30 @@ __global__ __launch_bounds__(NT) void build_csr_graph_kernel(BatchView b, CsrVie
         c.eid[pos] = e0 + e;
         if (has_attr) c.ecode[pos] = s_code[e];
     }
-    if (g + (int)gridDim.x < b.num_graphs) __syncthreads();  // the LDS tables are re-initialised for the next graph
-    }
 }
 
 // only_if (device int, or null): per-graph classes only -- every workgroup returns at once when *only_if == 0 (DGN's matrix-pipe path
 // needs the CSR only for batches with duplicate edges, which its own index pass finds on the device)
 void launch_build_csr(const BatchView& b, const CsrView& c, bool has_edge_attr, int max_nodes, int max_edges, hipStream_t s, const int* only_if) {
-    const int grid = only_if != nullptr && b.num_graphs > 1024 ? 1024 : b.num_graphs;
     if (b.num_graphs > 0 && max_nodes <= 256 && max_edges <= 1024) {
         // dynamic LDS of one graph: 3 nmax + 1 + NT / 64 ints, 3 emax indices, emax codes
         const int nmax = (max_nodes + 1) & ~1, emax = (max_edges + 3) & ~3;
         const size_t lds = (size_t)(3 * nmax + 1 + 1 + 1) * 4 + (size_t)emax * (3 * sizeof(uint16_t) + 1);
-        build_csr_graph_kernel<64, 256, 1024, uint16_t, true><<<grid, 64, lds, s>>>(b, c, has_edge_attr, nmax, emax, only_if);
+        build_csr_graph_kernel<64, 256, 1024, uint16_t, true><<<b.num_graphs, 64, lds, s>>>(b, c, has_edge_attr, nmax, emax, only_if);
         return;
     }
     // kNN graphs of the hep10k shape (<= ~100 nodes x 16 in-edges): 18 KB of LDS per graph, so nine workgroups share a CU;
     // in the class below one graph claims 139 KB and a CU holds a single 4-wave workgroup (0.93 -> 0.22 ms for 2^15 graphs)
     if (b.num_graphs > 0 && max_nodes <= 256 && max_edges <= 2048) {
-        build_csr_graph_kernel<128, 256, 2048, uint16_t, false><<<grid, 128, 0, s>>>(b, c, has_edge_attr, 256, 2048, only_if);
+        build_csr_graph_kernel<128, 256, 2048, uint16_t, false><<<b.num_graphs, 128, 0, s>>>(b, c, has_edge_attr, 256, 2048, only_if);
         return;
     }
     if (b.num_graphs > 0 && max_nodes <= 512 && max_edges <= 6144) {  // the reference's own caps: 500 nodes / 5500 edges
-        build_csr_graph_kernel<256, 512, 6144, uint16_t, false><<<grid, 256, 0, s>>>(b, c, has_edge_attr, 512, 6144, only_if);
+        build_csr_graph_kernel<256, 512, 6144, uint16_t, false><<<b.num_graphs, 256, 0, s>>>(b, c, has_edge_attr, 512, 6144, only_if);
         return;
     }
     if (b.num_graphs > 0 && max_nodes <= 2048 && max_edges <= 16384) {
-        build_csr_graph_kernel<256, 2048, 16384, uint16_t, false><<<grid, 256, 0, s>>>(b, c, has_edge_attr, 2048, 16384, only_if);
+        build_csr_graph_kernel<256, 2048, 16384, uint16_t, false><<<b.num_graphs, 256, 0, s>>>(b, c, has_edge_attr, 2048, 16384, only_if);
         return;
     }
     // flat global path: any graph size
