@@ -681,7 +681,7 @@ __global__ __launch_bounds__(GCNR_WAVES * 64, 3) void gcn_resident_kernel(const 
         if (tid <= rows) s_rp[tid] = (uint16_t)rpre;
         if (tid < rows) {
             s_dinv[tid] = dpre > 0 ? 1.0f / sqrtf((float)(dpre + 1)) : 0.0f;  // load_inputs.cc:122
-            s_idp1[tid] = 1.0f / (float)(dpre + 1);
+            s_idp1[tid] = 65536.0f / (float)(dpre + 1);  // 2^16 / (deg + 1): the self term arrives scaled by 2^-16 (epilogue below)
         }
         if (tid < 16) { s_cnt[tid] = 0; s_cur[tid] = 0; }
         if (ONEPASS) issue_idx(has_next ? ntile : tile);  // (its last readers were the previous tile's closing requests, a barrier ago)
@@ -838,12 +838,20 @@ __global__ __launch_bounds__(GCNR_WAVES * 64, 3) void gcn_resident_kernel(const 
                 const float4 rt = *reinterpret_cast<const float4*>(s_ep + 16 * q + 4 * g);
                 const float4 sc = *reinterpret_cast<const float4*>(s_ep + GCN_D + 16 * q + 4 * g);
                 const float4 sh = *reinterpret_cast<const float4*>(s_ep + 2 * GCN_D + 16 * q + 4 * g);
-                a[4 * q + 0] = (m[4 * q + 0] + relu1(xs[q].x + rt.x) * idp1) * sc.x + sh.x;
-                a[4 * q + 1] = (m[4 * q + 1] + relu1(xs[q].y + rt.y) * idp1) * sc.y + sh.y;
-                a[4 * q + 2] = (m[4 * q + 2] + relu1(xs[q].z + rt.z) * idp1) * sc.z + sh.z;
-                a[4 * q + 3] = (m[4 * q + 3] + relu1(xs[q].w + rt.w) * idp1) * sc.w + sh.w;
+                // relu(x + root) as ONE clamped packed FMA per two values, as the walk's messages: the blob holds root * 2^-16, the clamp
+                // gives relu(x + root) * 2^-16 exactly (x + root < 2^16: range flag and set_weights' table check), and idp1 carries
+                // the 2^16 back inside the next FMA -- the same bits for 13 instructions instead of 50
+                float2_t r01, r23;
+                { const float2_t x01 = {xs[q].x, xs[q].y}, x23 = {xs[q].z, xs[q].w}, t01 = {rt.x, rt.y}, t23 = {rt.z, rt.w};
+                  asm("v_pk_fma_f32 %0, %1, %2, %3 clamp" : "=v"(r01) : "v"(x01), "s"(msg_c2), "v"(t01));
+                  asm("v_pk_fma_f32 %0, %1, %2, %3 clamp" : "=v"(r23) : "v"(x23), "s"(msg_c2), "v"(t23)); }
+                a[4 * q + 0] = __builtin_fmaf(__builtin_fmaf(r01.x, idp1, m[4 * q + 0]), sc.x, sh.x);
+                a[4 * q + 1] = __builtin_fmaf(__builtin_fmaf(r01.y, idp1, m[4 * q + 1]), sc.y, sh.y);
+                a[4 * q + 2] = __builtin_fmaf(__builtin_fmaf(r23.x, idp1, m[4 * q + 2]), sc.z, sh.z);
+                a[4 * q + 3] = __builtin_fmaf(__builtin_fmaf(r23.y, idp1, m[4 * q + 3]), sc.w, sh.w);
             }
-            a[24] = (m[24] + relu1(xst + s_ep[96 + g]) * idp1) * s_ep[GCN_D + 96 + g] + s_ep[2 * GCN_D + 96 + g];
+            { float r24; asm("v_fma_f32 %0, %1, %2, %3 clamp" : "=v"(r24) : "v"(xst), "s"(1.0f / 65536.0f), "v"(s_ep[96 + g]));
+              a[24] = __builtin_fmaf(__builtin_fmaf(r24, idp1, m[24]), s_ep[GCN_D + 96 + g], s_ep[2 * GCN_D + 96 + g]); }
             if (l == GCN_L - 1) {
                 // the readout's node range of "this lane's graph": requested here, a BatchNorm ahead of its use, and consumed BEFORE the
                 // next tile's rows are requested (below) -- behind them, its vmcnt wait would also wait for that whole transfer
@@ -873,7 +881,7 @@ __global__ __launch_bounds__(GCNR_WAVES * 64, 3) void gcn_resident_kernel(const 
                 DS_SPLIT2(a[8 * ks + 6], a[8 * ks + 7], b_hi[ks].w, b_lo[ks].w);
             }
 #pragma unroll
-            for (int k = 0; k < 24; k += 2) vmax = __builtin_fmaxf(__builtin_fmaxf(vmax, a[k]), a[k + 1]);  // a >= 0 (ReLU)
+            for (int k = 0; k < 24; k += 2) asm("v_max3_f32 %0, %1, %2, %0" : "+v"(vmax) : "v"(a[k]), "v"(a[k + 1]));  // a >= 0 (ReLU)
             asm volatile("" : "+v"(vmax));
             const float a24 = a[24];
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1049,6 +1057,13 @@ public:
                                 for (int k = 0; k < 4; k++) pl[(((size_t)q * 4 + gq) * 64 + c) * 4 + k] = dst[c * GCN_D + 16 * q + 4 * gq + k];
                 }
                 std::memcpy(base + GCNR_W_BYTES + sizeof(float) * EDGE_COMBOS * GCN_D, &ep[(size_t)l * 3 * GCN_D], sizeof(float) * 3 * GCN_D);
+                {   // ... and the root embedding scaled likewise: the epilogue's relu(x + root) is one clamped FMA too
+                    float* rt = reinterpret_cast<float*>(base + GCNR_W_BYTES + sizeof(float) * EDGE_COMBOS * GCN_D);
+                    for (int d = 0; d < GCN_D; d++) {
+                        emax = std::fmax(emax, std::fabs(rt[d]));
+                        rt[d] *= 1.0f / 65536.0f;
+                    }
+                }
             }
             if ((rc = upload(&d_res_, res))) return rc;
             // the scaled walk is exact while x + e < 2^16: |e| < 4 096 here, |x| < 6e4 by the range flag (x_0: nine projected-table rows)
