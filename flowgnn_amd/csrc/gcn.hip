@@ -551,6 +551,12 @@ __global__ __launch_bounds__(GCNR_WAVES * 64, 3) void gcn_resident_kernel(const 
     const float* s_ep = s_ecomb + EDGE_COMBOS * GCN_D;
     const uint32_t x_addr = lds_addr_of(s_x), w_addr = lds_addr_of(s_w), blob_addr = lds_addr_of(s_blob);
     float vmax = 0.0f;
+#ifdef FLOWGNN_DEV  // gcn_ablate 64: per-phase clocks of workgroup 0's waves, printed at the end (scripts/dev: ab.py ... gcn_ablate=64)
+    unsigned long long tph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = wall_clock64();
+#define GCN_STAMP(i) do { if (ablate & 64) { const unsigned long long t_ = wall_clock64(); tph[i] += t_ - tlast; tlast = t_; } } while (0)
+#else
+#define GCN_STAMP(i) do { } while (0)
+#endif
     // ONEPASS: the lane index is re-derived (opaque) at the top of every tile.  Left visible, hipcc computes every lane-dependent
     // address of the kernel once, in front of the tile loop, and holds ~60 of them in registers for the whole launch: nothing is
     // free at the tile boundary, where the loader wants 48 registers of table segments in flight (it spilled 568 B).
@@ -726,6 +732,7 @@ __global__ __launch_bounds__(GCNR_WAVES * 64, 3) void gcn_resident_kernel(const 
         const int ro_gi = g0 + tid;
         int ro_n0 = 0, ro_n1 = 1;
 #pragma unroll 1
+        GCN_STAMP(0);  // tile set-up
         for (int l = 0; l < GCN_L; l++) {
             if (l == 1 && has_next) {  // the next tile's descriptor (two dependent scalar round trips), used from layer 2 on
                 nt0 = tile_row[ntile];
@@ -815,6 +822,7 @@ __global__ __launch_bounds__(GCNR_WAVES * 64, 3) void gcn_resident_kernel(const 
                     { float t1; asm("v_fma_f32 %0, %1, %2, %3 clamp" : "=v"(t1) : "v"(xt), "s"(1.0f / 65536.0f), "v"(wt)); mt += ns * t1; }
                 }
             }
+            GCN_STAMP(1);  // self row + walk
             // W_{l+1} (45 pieces of 1 KiB) is requested BEHIND the walk and lands under the BatchNorm / split that follows and under the
             // slower waves' last trips.  Requested at the top of the walk -- where it used to be -- every wave paid four LDS-DMA issues
             // (100-150 cycles each) in front of its first trip and the 45 KiB landed through the LDS the walk is bound by: 5.18 ms per
@@ -884,6 +892,7 @@ __global__ __launch_bounds__(GCNR_WAVES * 64, 3) void gcn_resident_kernel(const 
             for (int k = 0; k < 24; k += 2) asm("v_max3_f32 %0, %1, %2, %0" : "+v"(vmax) : "v"(a[k]), "v"(a[k + 1]));  // a >= 0 (ReLU)
             asm volatile("" : "+v"(vmax));
             const float a24 = a[24];
+            GCN_STAMP(2);  // W request, BatchNorm, split
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();  // #1: every gather of this layer is done (rows may be rewritten, the table replaced); W_{l+1} has landed
             auto issue_blob = [&]() {  // the next layer's table + epilogue vectors stream in under the dense layer
@@ -894,6 +903,7 @@ __global__ __launch_bounds__(GCNR_WAVES * 64, 3) void gcn_resident_kernel(const 
                     if (piece < GCNR_BLOB_BYTES / 1024) lds_dma16(gbl + piece * 1024, (uint32_t)lane * 16u, blob_addr + piece * 1024);
                 }
             };
+            GCN_STAMP(3);  // wait + barrier #1
             if (!(ablate & 8)) issue_blob();  // (ablate 8: timing without it; issued after the third or the last column tile instead: no change / +1.3 %)
             // ---- x_{l+1} = b + W a on the f16 matrix pipe (split products, dense_split.h), written over the wave's own rows
             const float oscale = *reinterpret_cast<const float*>(s_w + SCALE_OFF);
@@ -901,6 +911,17 @@ __global__ __launch_bounds__(GCNR_WAVES * 64, 3) void gcn_resident_kernel(const 
             // left to itself hipcc reads one fragment, waits for it and issues one or two MFMAs, so every wave paid an LDS round
             // trip per fragment -- six per column tile -- with nothing of its own in flight.  Launch 5.06 -> 4.92 ms (same box).
             ds_uint4_t fr[2][6];
+            float4_t accp = {0.f, 0.f, 0.f, 0.f};
+            auto store_tile = [&](const float4_t& acc, int t) {
+                const int col = 16 * t + 4 * g;
+                if (col < GCN_D && valid) {
+                    const float4_t o = acc * oscale;
+                    *reinterpret_cast<float4*>(s_x + r * GCN_D + col) = make_float4(o.x, o.y, o.z, o.w);
+                    // (the next walk's clamped messages need |x| < 6e4: beyond it the pass is repeated on the exact kernels)
+                    asm("v_max3_f32 %0, |%1|, |%2|, %0" : "+v"(vmax) : "v"(o.x), "v"(o.y));
+                    asm("v_max3_f32 %0, |%1|, |%2|, %0" : "+v"(vmax) : "v"(o.z), "v"(o.w));
+                }
+            };
 #pragma unroll
             for (int i = 0; i < 6; i++) fr[0][i] = *reinterpret_cast<const ds_uint4_t*>(s_w + i * 1024 + lane * 16);
 #pragma unroll
@@ -922,18 +943,18 @@ __global__ __launch_bounds__(GCNR_WAVES * 64, 3) void gcn_resident_kernel(const 
                     }
                     acc = __builtin_amdgcn_mfma_f32_16x16x4f32(at, a24, acc, 0, 0, 0);
                 }
-                const int col = 16 * t + 4 * g;
-                if (col < GCN_D && valid) {
-                    const float4_t o = acc * oscale;
-                    *reinterpret_cast<float4*>(s_x + r * GCN_D + col) = make_float4(o.x, o.y, o.z, o.w);
-                    // (the next walk's clamped messages need |x| < 6e4: beyond it the pass is repeated on the exact kernels)
-                    asm("v_max3_f32 %0, |%1|, |%2|, %0" : "+v"(vmax) : "v"(o.x), "v"(o.y));
-                    asm("v_max3_f32 %0, |%1|, |%2|, %0" : "+v"(vmax) : "v"(o.z), "v"(o.w));
-                }
+                // a column tile's results are stored one tile LATER, behind the next tile's MFMAs: stored at once, the wave stood
+                // through the latency of its ten-MFMA chain (each waits for its predecessor's accumulator) seven times per layer
+                __builtin_amdgcn_sched_barrier(0);
+                if (t > 0) store_tile(accp, t - 1);
+                accp = acc;
                 __builtin_amdgcn_sched_barrier(0);
             }
+            store_tile(accp, OT - 1);
+            GCN_STAMP(4);  // dense layer
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();  // #2: x_{l+1} is complete, the next table has landed
+            GCN_STAMP(5);  // wait + barrier #2
         }
         // ONEPASS: this wave is done with the tile's rows; the next tile's table segments travel while the slower waves finish their
         // walks (the registers of the walk and the BatchNorm are free now), and are stored behind the barrier
@@ -948,8 +969,15 @@ __global__ __launch_bounds__(GCNR_WAVES * 64, 3) void gcn_resident_kernel(const 
         if (ro_gi < g1) out[ro_gi] = lds_sum_in_order(s_dot + (ro_n0 - t0), ro_n1 - ro_n0) / (float)(ro_n1 - ro_n0) + pool_bias;
         if (!has_next) break;
         tile = ntile; t0 = nt0; rows = nrows; g0 = ng0; g1 = ng1; e0 = ne0; ne = nne;
+        GCN_STAMP(6);  // last layer's tail, readout, next tile's requests
         __syncthreads();  // the readout has read s_dot and s_rp's neighbours: the small arrays may be rewritten
     }
+#ifdef FLOWGNN_DEV
+    if ((ablate & 64) && blockIdx.x == 0 && (threadIdx.x & 63) == 0)
+        printf("gcn wave %d clocks(100MHz): setup %llu walk %llu bn %llu bar1 %llu dense %llu bar2 %llu tail %llu\n", (int)(threadIdx.x >> 6), tph[0], tph[1], tph[2],
+               tph[3], tph[4], tph[5], tph[6]);
+#endif
+#undef GCN_STAMP
     if (__any(!(vmax < 6.0e4f))) {
         if (lane == 0) atomicOr(range_flag, 1);
     }
