@@ -668,18 +668,26 @@ __global__ __launch_bounds__(512, 2) void dgn_layer_mfma_kernel(const float* __r
             asm volatile("" : "+v"(vmax));
             const char* wb = s_w + (size_t)k * (DGN_OT * 2 * 1024);
             if (!(ablate & 2)) {
+            ds_uint4_t ff[2][4];  // the fragments of the NEXT pair of output tiles are requested before this pair's MFMAs issue
+#pragma unroll
+            for (int i = 0; i < 4; i++) ff[0][i] = *reinterpret_cast<const ds_uint4_t*>(wb + i * 1024 + lane * 16);
 #pragma unroll
             for (int t0_ = 0; t0_ < DGN_OT; t0_ += 2) {
                 const int n = t0_ + 1 < DGN_OT ? 2 : 1;
-                ds_uint4_t f[4];
+                const int n2 = t0_ + 3 < DGN_OT ? 2 : 1;
+                if (t0_ + 2 < DGN_OT) {
 #pragma unroll
-                for (int i = 0; i < 2 * n; i++) f[i] = *reinterpret_cast<const ds_uint4_t*>(wb + ((t0_ * 2) + i) * 1024 + lane * 16);
+                    for (int i = 0; i < 2 * n2; i++) ff[((t0_ >> 1) + 1) & 1][i] = *reinterpret_cast<const ds_uint4_t*>(wb + (((t0_ + 2) * 2) + i) * 1024 + lane * 16);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                const ds_uint4_t (&f)[4] = ff[(t0_ >> 1) & 1];
 #pragma unroll
                 for (int i = 0; i < n; i++) acc[t0_ + i] = DS_MFMA16(f[2 * i], b_hi, acc[t0_ + i]);
 #pragma unroll
                 for (int i = 0; i < n; i++) acc[t0_ + i] = DS_MFMA16(f[2 * i], b_lo, acc[t0_ + i]);
 #pragma unroll
                 for (int i = 0; i < n; i++) acc[t0_ + i] = DS_MFMA16(f[2 * i + 1], b_hi, acc[t0_ + i]);
+                __builtin_amdgcn_sched_barrier(0);
             }
             } else { acc[0].x += b_hi.x + b_lo.y; }
         }
