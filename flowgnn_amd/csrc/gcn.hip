@@ -841,11 +841,20 @@ __global__ __launch_bounds__(GCNR_WAVES * 64, 3) void gcn_resident_kernel(const 
             m[24] = mt;
             // ---- a_{l+1} = BN_l(m_l + relu(x_l + root_l) / (deg + 1))   (node_embedding.cc:123-138); folded BatchNorm
             float a[25];
+            // (the three epilogue vectors of quad q + 1 are requested before quad q is computed: read where they are used, hipcc waited
+            // for them in a dozen small batches -- an LDS round trip each, with two other waves on the SIMD to cover it)
+            float4 epv[2][3];
+#pragma unroll
+            for (int i = 0; i < 3; i++) epv[0][i] = *reinterpret_cast<const float4*>(s_ep + i * GCN_D + 4 * g);
+            const float ept0 = s_ep[96 + g], ept1 = s_ep[GCN_D + 96 + g], ept2 = s_ep[2 * GCN_D + 96 + g];
 #pragma unroll
             for (int q = 0; q < 6; q++) {
-                const float4 rt = *reinterpret_cast<const float4*>(s_ep + 16 * q + 4 * g);
-                const float4 sc = *reinterpret_cast<const float4*>(s_ep + GCN_D + 16 * q + 4 * g);
-                const float4 sh = *reinterpret_cast<const float4*>(s_ep + 2 * GCN_D + 16 * q + 4 * g);
+                if (q + 1 < 6) {
+#pragma unroll
+                    for (int i = 0; i < 3; i++) epv[(q + 1) & 1][i] = *reinterpret_cast<const float4*>(s_ep + i * GCN_D + 16 * (q + 1) + 4 * g);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                const float4 rt = epv[q & 1][0], sc = epv[q & 1][1], sh = epv[q & 1][2];
                 // relu(x + root) as ONE clamped packed FMA per two values, as the walk's messages: the blob holds root * 2^-16, the clamp
                 // gives relu(x + root) * 2^-16 exactly (x + root < 2^16: range flag and set_weights' table check), and idp1 carries
                 // the 2^16 back inside the next FMA -- the same bits for 13 instructions instead of 50
@@ -857,9 +866,10 @@ __global__ __launch_bounds__(GCNR_WAVES * 64, 3) void gcn_resident_kernel(const 
                 a[4 * q + 1] = __builtin_fmaf(__builtin_fmaf(r01.y, idp1, m[4 * q + 1]), sc.y, sh.y);
                 a[4 * q + 2] = __builtin_fmaf(__builtin_fmaf(r23.x, idp1, m[4 * q + 2]), sc.z, sh.z);
                 a[4 * q + 3] = __builtin_fmaf(__builtin_fmaf(r23.y, idp1, m[4 * q + 3]), sc.w, sh.w);
+                __builtin_amdgcn_sched_barrier(0);
             }
-            { float r24; asm("v_fma_f32 %0, %1, %2, %3 clamp" : "=v"(r24) : "v"(xst), "s"(1.0f / 65536.0f), "v"(s_ep[96 + g]));
-              a[24] = __builtin_fmaf(__builtin_fmaf(r24, idp1, m[24]), s_ep[GCN_D + 96 + g], s_ep[2 * GCN_D + 96 + g]); }
+            { float r24; asm("v_fma_f32 %0, %1, %2, %3 clamp" : "=v"(r24) : "v"(xst), "s"(1.0f / 65536.0f), "v"(ept0));
+              a[24] = __builtin_fmaf(__builtin_fmaf(r24, idp1, m[24]), ept1, ept2); }
             if (l == GCN_L - 1) {
                 // the readout's node range of "this lane's graph": requested here, a BatchNorm ahead of its use, and consumed BEFORE the
                 // next tile's rows are requested (below) -- behind them, its vmcnt wait would also wait for that whole transfer
