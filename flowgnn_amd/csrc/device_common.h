@@ -77,7 +77,13 @@ __device__ __forceinline__ float lds_sum_in_order(const float* s, int n) {
 #pragma unroll
         for (int i = 0; i < 8; i++) sum += x[i];
     }
-    for (; v < n; v++) sum += s[v];
+    if (v < n) {  // the last one to seven elements in one batch as well: absent ones read as +0, which leaves the sum's bits alone
+        float x[8];
+#pragma unroll
+        for (int i = 0; i < 7; i++) x[i] = v + i < n ? s[v + i] : 0.0f;
+#pragma unroll
+        for (int i = 0; i < 7; i++) sum += x[i];
+    }
     return sum;
 }
 
