@@ -650,7 +650,11 @@ __global__ __launch_bounds__(GATR_WAVES * 64, 4) void gat_resident_kernel(const 
             s_perm[pos] = (uint8_t)r;
         }
         __syncthreads();
-        const int r = s_perm[wv * 16 + j];
+        // Which wave walks which 16 rows of the degree order: waves w, w + 4, w + 8, w + 12 share a SIMD, and dealt in order SIMD 0 walked
+        // groups 0, 4, 8, 12 and SIMD 3 groups 3, 7, 11, 15.  Snake order over the SIMDs (groups 0 7 8 15 | 1 6 9 14 | 2 5 10 13 | 3 4 11 12)
+        // gives every SIMD the same share of long and short walks: gat_resident -1.2 % (a Latin square: -0.8 %; scripts/dev/ab.py)
+        const int grp = (wv >> 2) * 4 + (((wv >> 2) & 1) ? 3 - (wv & 3) : (wv & 3));
+        const int r = s_perm[grp * 16 + j];
         const bool valid = r < rows;
         const int rr = valid ? r : 0;  // rows past the tile's end repeat row 0's self edge (finite values, never used)
         const int e_begin = valid ? (int)s_rp[r] : 0, e_end = valid && !(ablate & 1) ? (int)s_rp[r + 1] : e_begin;  // ablate: development aid (gat_ablate, -DFLOWGNN_DEV builds)

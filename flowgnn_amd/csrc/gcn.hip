@@ -720,7 +720,13 @@ __global__ __launch_bounds__(GCNR_WAVES * 64, 3) void gcn_resident_kernel(const 
         if (ONEPASS) x0_store(rows, XH, XK);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of the tile's rows and of layer 0's table
         __syncthreads();
-        const int r = s_perm[wv * 16 + j];
+        // Which wave walks which 16 rows of the degree order.  Waves w, w + 4, w + 8 share a SIMD; dealt in order (wave w = group w) SIMD 0
+        // walked groups 0, 4, 8 and SIMD 3 groups 3, 7, 11 -- the longest rows together.  Waves 0..2 now take groups 0, 4, 8, waves 3..5
+        // groups 1, 5, 9, ...: every SIMD gets a long, a middle and a short walk (ranks 0+5+10, 4+9+3, 8+2+7, 1+6+11), and the waves that
+        // carry the tile's set-up (threads 0..191) one of each: gcn_resident -1.0 %.  (The reverse order, long rows on the last
+        // waves: +5 %; snake order over the SIMDs: +0.5 %; scripts/dev/ab.py, one box.)
+        const int grp = (wv % 3) * 4 + wv / 3;
+        const int r = s_perm[grp * 16 + j];
         const bool valid = r < rows;
         const int rr = valid ? r : 0;  // rows past the tile's end repeat row 0 without in-edges (finite values, never stored)
         const int e_begin = valid ? (int)s_rp[r] : 0, e_end = valid && !(ablate & 1) ? (int)s_rp[r + 1] : e_begin;  // ablate: development aid (gcn_ablate, -DFLOWGNN_DEV builds)
