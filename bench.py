@@ -89,9 +89,14 @@ MODELS = {
     "PNA": dict(metric="graphs/sec on hep10k (PNA, dim=80)", dataset="hep10k", graphs=1 << 15,
                 agg_bytes=lambda n, e: n * 320 + n * 320 * 4 + e * 8, flops=lambda n, e: n * 153600,
                 # unfused split dense: read 4 aggregates + h, write h'; fused layer: read h (tile rows) + CSR, write h'
-                fused_bytes={"pna_dense": lambda n, e: n * (1280 + 320 + 320), "pna_layer_fused": lambda n, e: n * (320 + 320 + 4) + e * 4},
-                mfma_bound_kernels=("pna_layer_fused",),
-                hbm_kernels=("pna_aggregate",), mfma_kernels=("pna_layer_fused", "pna_dense"),
+                # graph-resident kernel (encoder + four layers + readout in one launch): four layers of products; what it moves is 36 B of
+                # node features + 4 B of out-degree per node and one 5 632-byte CSR descriptor per 256-row tile
+                fused_bytes={"pna_dense": lambda n, e: n * (1280 + 320 + 320), "pna_layer_fused": lambda n, e: n * (320 + 320 + 4) + e * 4,
+                             "pna_resident": lambda n, e: 4 * (n * (320 + 320 + 4) + e * 4)},
+                moved_bytes={"pna_resident": lambda n, e: n * 40 + (n // 245 + 1) * 5632},
+                layers_per_launch={"pna_resident": 4},
+                mfma_bound_kernels=("pna_layer_fused", "pna_resident"),
+                hbm_kernels=("pna_aggregate",), mfma_kernels=("pna_resident", "pna_layer_fused", "pna_dense"),
                 workload="PNA dim=80, hep10k-shaped kNN graphs on MI355X (BASELINE configs[4])"),
     "DGN": dict(metric="graphs/sec on hep10k (DGN, dim=100)", dataset="hep10k", graphs=1 << 15,
                 agg_bytes=lambda n, e: n * 400 * 3 + e * 12, flops=lambda n, e: n * 40000,

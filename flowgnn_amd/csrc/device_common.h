@@ -309,14 +309,14 @@ __global__ __launch_bounds__(256) void pool_mlp3_kernel(const float* __restrict_
     __builtin_amdgcn_wave_barrier();
     if (lane < H1) {
         float s = b1[lane];
-        for (int i = 0; i < D; i++) s += s_hg[wv][i] * w1[lane * D + i];
+        for (int i = 0; i < D; i++) s = __builtin_fmaf(s_hg[wv][i], w1[lane * D + i], s);  // (spelled out: the resident kernels' heads round alike)
         s_o1[wv][lane] = relu1(s);
     }
     __builtin_amdgcn_wave_barrier();
     float part = 0.f;
     if (lane < H2) {
         float s = b2[lane];
-        for (int i = 0; i < H1; i++) s += s_o1[wv][i] * w2[lane * H1 + i];
+        for (int i = 0; i < H1; i++) s = __builtin_fmaf(s_o1[wv][i], w2[lane * H1 + i], s);
         part = relu1(s) * w3[lane];
     }
 #pragma unroll

@@ -99,15 +99,15 @@ static const OptionDef kOptionTable[] = {
     {"csr_flat", 0},              // 1: global-memory index build for every graph (A/B)
     {"tile_nominal", -1},         // rows per tile of the tiled aggregation kernels (< 0: the model's default)
     {"tile_slack", -1},
-    {"gin_resident", 1}, {"gin_tile_build", -1}, {"gin_pingpong", 0}, {"gin_resident_min_fill", 0.5}, {"gin_resident_nosort", 0}, {"gin_resident_prof", 0},
+    {"gin_resident", 1}, {"gin_tile_build", -1}, {"gin_resident_min_fill", 0.5}, {"gin_resident_nosort", 0}, {"gin_resident_prof", 0},
     {"gin_unfused", 0}, {"gin_mfma", 16}, {"gin_split_nt", 4}, {"gin_fold_readout", 1}, {"gin_head_fold", 1},
     {"gin_agg_untiled", 0}, {"gin_agg_tile", 128},
     {"gcn_resident", 1}, {"gcn_tile_build", 1}, {"gcn_unfused", 0}, {"gcn_mfma", 16},
     {"gat_resident", 1}, {"gat_mfma", 16}, {"gat_fold_readout", 1}, {"gat_reference_quirk", 0},
-    {"pna_fused", 1}, {"pna_mfma", 16},
+    {"pna_resident", 1}, {"pna_tile_build", 1}, {"pna_fused", 1}, {"pna_mfma", 16},
     {"dgn_fused", 1}, {"dgn_mfma", 16}, {"dgn_mfma_agg", -1}, {"dgn_fold_readout", 1}, {"dgn_rowinfo_direct", 1},
 #ifdef FLOWGNN_DEV
-    {"gcn_ablate", 0}, {"gat_ablate", 0}, {"pna_ablate", 0}, {"dgn_ablate", 0},
+    {"gcn_ablate", 0}, {"gat_ablate", 0}, {"pna_ablate", 0}, {"dgn_ablate", 0}, {"gin_pingpong", 0},
 #endif
 };
 constexpr int kNumOptions = (int)(sizeof(kOptionTable) / sizeof(kOptionTable[0]));

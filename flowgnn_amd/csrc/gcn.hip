@@ -494,22 +494,10 @@ __global__ __launch_bounds__(256) void gcn_tile_build_kernel(BatchView b, const 
     }
 }
 
-// Timing variants of the walk (development, scripts/dev/variant.sh): -DGCN_CF_ROWS reads the source row out of the lane group's own
-// 16 aligned rows (stride 100 dwords: 16 distinct bank quads), -DGCN_CF_CODES reads edge code 0 on every lane (one broadcast) --
-// wrong sums, the shipped kernel's instruction stream: what the walk's LDS bank conflicts cost (NOTEBOOK round 5).
-#if defined(GCN_CF_ROWS) || defined(GCN_CF_CODES)
-#ifdef GCN_CF_ROWS
-#define GCN_CF_U(U) (((((U) & ~15) | (lane & 15)) < GCNR_ROWS) ? (((U) & ~15) | (lane & 15)) : (lane & 15))
-#else
-#define GCN_CF_U(U) (U)
+#ifdef FLOWGNN_DEV
+#include "dev/walk_timing_variants.h"  // development: timing variants of the walk (wrong sums on purpose), selected by extra -D flags
 #endif
-#ifdef GCN_CF_CODES
-#define GCN_CF_C(C) ((C) & cf_zero_)  // (a literal 0 would let hipcc hoist the table reads out of the walk: that variant times the walk WITHOUT them)
-#else
-#define GCN_CF_C(C) (C)
-#endif
-#define GCN_WALK_WORD(W) { int cf_zero_ = 0; asm volatile("" : "+v"(cf_zero_)); (void)cf_zero_; W = (GCN_CF_U((W) >> 6) << 6) | GCN_CF_C((W) & 63); }
-#else
+#ifndef GCN_WALK_WORD
 #define GCN_WALK_WORD(W)
 #endif
 

@@ -620,7 +620,8 @@ public:
         for (int l = 0; l < GIN_L; l++)
             gin_resident_pack_layer(w1 + (size_t)l * GIN_H * GIN_D, b1 + (size_t)l * GIN_H, w2 + (size_t)l * GIN_D * GIN_H,
                                     b2 + (size_t)l * GIN_D, rsplit.data() + (size_t)l * gin_resident_layer_bytes());
-        // ... re-cut into the ping-pong kernel's pieces, with the edge-embedding tables as half tables
+#ifdef FLOWGNN_DEV
+        // ... re-cut into the ping-pong kernel's pieces, with the edge-embedding tables as half tables (development builds only)
         std::vector<uint8_t> pp_pieces((size_t)GIN_L * gin_pp_layer_bytes());
         {
             std::vector<uint8_t> eight(gin_resident_layer_bytes());  // the eight-chunk form of the stream (chunk 7 = the packed K-step)
@@ -632,9 +633,10 @@ public:
         }
         std::vector<float> pp_tables(gin_pp_table_floats());
         gin_pp_pack_tables(ecomb.data(), pp_tables.data());
+        if (int rc0 = upload(&d_pp_pieces_, pp_pieces)) return rc0;
+        if (int rc0 = upload(&d_pp_tables_, pp_tables)) return rc0;
+#endif
         int rc;
-        if ((rc = upload(&d_pp_pieces_, pp_pieces))) return rc;
-        if ((rc = upload(&d_pp_tables_, pp_tables))) return rc;
         if ((rc = ginq_upload(qw_, nemb, eemb, w1, b1, w2, b2, pw, pb))) return rc;  // Q6.10 copies (numeric mode 1)
         if ((rc = upload(&d_split_, split))) return rc;
         if ((rc = upload(&d_rsplit_, rsplit))) return rc;
@@ -746,16 +748,19 @@ public:
         rows = resident_ ? GIN_RESIDENT_ROWS : 0;
         edges = resident_ ? GIN_RESIDENT_EDGES : 0;
     }
+#ifdef FLOWGNN_DEV  // the ping-pong form (dev/gin_pp_device.inc: bit-identical, measured slower) exists in development builds only
     void sub_tile_limits(int& rows, int& edges) const override {
         const bool on = resident_ && pingpong_ && !virtual_node_;
         rows = on ? GIN_PP_ROWS : 0;
         edges = on ? GIN_PP_EDGES : 0;
     }
-    // ping-pong form (gin_pp_kernel): the batch's half-tiles on it, the few graphs beyond the half-tile limits on gin_resident_kernel
+    // the batch's half-tiles on gin_pp_kernel, the few graphs beyond the half-tile limits on gin_resident_kernel.  (Decided from the
+    // SHARD's own half-tile fill: unlike the shipped kernels' choices this one does not follow the job -- development only.)
     bool use_pingpong(const DeviceBatch& db) const {
         return pingpong_ && !virtual_node_ && use_resident(db) && !keep_h_ && num_tasks_ == 1 && fold_readout_ && head_fold_ && db.gtiles.sub_ok &&
                db.gtiles.n_sub > 0 && db.gtiles.sub_fill >= resident_min_fill_;
     }
+#endif
     bool use_resident(const DeviceBatch& db) const {
         // tiles that are mostly empty (graphs of 130..256 nodes, or dense graphs that hit the edge limit first) waste the
         // MFMA columns of the absent rows: below half full the per-layer kernels are the better choice
@@ -771,8 +776,9 @@ public:
         // encoder inside the folded last layer's steps costs the resident kernel 0.32 ms (0.57 ms before the kernel lost its scratch
         // reloads, which made this form the slower one on large batches in round 3) where the separate, store-bound encoder launch costs
         // 0.51: ahead at every size now -- 8.49 vs 8.73 ms per step at 2^18 graphs, 1.23 vs 1.24 at 32 768, 0.206 vs 0.222 at 4 113.
-        // -1 = default = on; an explicit gin_pingpong keeps the three-kernel front end (the ping-pong kernel has no encoder in its loader).
-        const bool want = tile_build_ < 0 ? !(pingpong_ && !virtual_node_) : tile_build_ != 0;  // (the ping-pong kernel is never used with a virtual node)
+        // -1 = default = on (development builds: an explicit gin_pingpong keeps the three-kernel front end -- the ping-pong kernel has no
+        // encoder in its loader and is never used with a virtual node).
+        const bool want = tile_build_ < 0 ? !(pingpong_ && !virtual_node_) : tile_build_ != 0;
         return want && use_resident(db) && !qmode_ && !keep_h_ && num_tasks_ == 1 && fold_readout_ && head_fold_ && db.b.edge_attr != nullptr;
     }
     bool needs_csr(const DeviceBatch& db) const override { return !one_pass(db); }
@@ -805,6 +811,7 @@ public:
             atom_encoder_kernel<GIN_D><<<atom_encoder_grid(n, GIN_C), 512, 0, s>>>(db.b.node_feature, d_nemb_, db.h[0], n, db.csr.err);
         }
         const bool multi = num_tasks_ > 1;  // NUM_TASK > 1: the layers leave h_5 in HBM and a multi-task readout kernel follows
+#ifdef FLOWGNN_DEV
         if (use_pingpong(db)) {
             const GraphTiles& gt = db.gtiles;
             const size_t sub_words = ((size_t)gt.n_sub * gin_pp_desc_bytes() + 3) / 4, big_words = (size_t)gt.n_big * (GIN_RESIDENT_DESC_BYTES / 4);
@@ -825,6 +832,7 @@ public:
             db.h_valid = false;
             return 0;
         }
+#endif
         if (use_resident(db)) {
             // all five layers and the readout in one launch; h_5 rows are written (to h[1]) only for the flowgnn_get_h tap
             if (int rc = perm_.reserve((size_t)db.gtiles.n_tiles * (GIN_RESIDENT_DESC_BYTES / 4))) return rc;
@@ -919,8 +927,10 @@ public:
         resident_ = o.on("gin_resident");
         resident_min_fill_ = o.num("gin_resident_min_fill");
         tile_build_ = o.i("gin_tile_build");
+#ifdef FLOWGNN_DEV
         pingpong_ = o.on("gin_pingpong");
         pingpong_waves_ = o.i("gin_pingpong") == 2 ? 16 : 8;  // 2: the sixteen-wave form (eight waves per half, one column tile each)
+#endif
         head_fold_ = o.on("gin_head_fold");
     }
     void set_exact(bool on) override { exact_ = on; }
@@ -987,7 +997,7 @@ private:
     float* d_enc_tab_ = nullptr;  // ... and the pre-combined encoder table they index
     bool h0_in_hbm_ = false;      // db.h[0] holds h_0 of the resident batch (false after a one-pass run)
     int pingpong_waves_ = 8;
-    bool pingpong_ = false;       // gin_pingpong = 1: gin_pp_kernel (two half-tiles per CU half a layer out of phase; measured slower)
+    bool pingpong_ = false;       // development builds, gin_pingpong = 1: gin_pp_kernel (two half-tiles per CU half a layer out of phase; measured slower)
     uint8_t* d_pp_pieces_ = nullptr;  // weight pieces of gin_pp_kernel
     float* d_pp_tables_ = nullptr;    // ... and its half tables
     int tile_build_ = -1;         // gin_tile_build: 1 = one-pass front end, 0 = CSR build + atom encoder + tile prep as separate launches, -1 = default = one-pass unless gin_pingpong selects the ping-pong kernel (no size rule)

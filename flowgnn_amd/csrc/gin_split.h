@@ -41,7 +41,8 @@ void gin_resident_pack_layer(const float* w1, const float* b1, const float* w2, 
 constexpr int GIN_RESIDENT_ROWS = 256;
 constexpr int GIN_RESIDENT_EDGES = 1280;
 constexpr int GIN_RESIDENT_DESC_BYTES = 3584;  // per-tile descriptor built by gin_tile_prep_kernel (CSR slice as 16-bit words, row offsets, column owners)
-// ping-pong form of the graph-resident kernel (gin_pp_kernel): two half-tiles of <= 128 rows / 640 in-edges per CU, half a layer out
+#ifdef FLOWGNN_DEV
+// development builds only (dev/gin_pp_*.inc) -- ping-pong form of the graph-resident kernel (gin_pp_kernel): two half-tiles of <= 128 rows / 640 in-edges per CU, half a layer out
 // of phase -- one half multiplies while the other gathers and loads.  Single-task folded readout only; graphs beyond the half-tile
 // limits go to launch_gin_resident with the (start, end) pair lists (tstride 2).
 constexpr int GIN_PP_ROWS = 128, GIN_PP_EDGES = 640;
@@ -53,6 +54,7 @@ void gin_pp_pack_tables(const float* ecomb_all /* [5][60][100] */, float* out);
 void launch_gin_pp(const float* h0, const int* row_ptr, const int* src, const uint8_t* ecode, const float* tables, const uint8_t* pieces,
                    const float* pool_b, const int* sub_tiles /* [n_sub][4] */, uint8_t* sub_desc, const int* node_off, float* out, int n_sub,
                    int* range_flag, const float* head_u, hipStream_t s, bool prof = false, int waves = 8);
+#endif
 
 // what the one-pass tile loader needs (launch_gin_resident, tb != null): the caller's arrays, the per-node table-row numbers it writes
 // (8 B per node) and the pre-combined encoder table (gin_resident_pack_enc_table); err = the engine's validation flag

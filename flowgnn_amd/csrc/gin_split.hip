@@ -1260,17 +1260,15 @@ __device__ __forceinline__ void gr_layer(unsigned long long (&tacc)[6], char* bx
     }
 #pragma unroll
     for (int nt = 0; nt < NT; nt++) trips[nt] = tile_trips[nt];
-// (development, -DGR_CONFLICT_FREE_WALK: every lane of a column tile reads a row of its own bank class -- WRONG results, the walk's time
-//  without LDS bank conflicts; scripts/dev/variant.sh)
-#ifdef GR_CONFLICT_FREE_WALK
-#define GR_WALK_ROW(U) ((((U) & ~15u) | (unsigned)j) < (unsigned)GR_ROWS ? (((U) & ~15u) | (unsigned)j) : (unsigned)j)
-#else
+#ifdef FLOWGNN_DEV
+#include "dev/walk_timing_variants.h"  // development: timing variants of the walk (wrong sums on purpose), selected by extra -D flags
+#endif
+#ifndef GR_WALK_ROW
 #define GR_WALK_ROW(U) (U)
 #endif
-#ifdef GR_ONE_CODE_WALK  // every lane reads the table row of code 0 (one broadcast); cf_zero is an opaque 0, so the reads stay in the loop
-#define GR_WALK_CODE(C) ((C) & cf_zero)
-#else
+#ifndef GR_WALK_CODE
 #define GR_WALK_CODE(C) (C)
+#define GR_WALK_TIMING_SETUP()
 #endif
 #define GR_READ(NTI, X, W, XT, WT)                                                                                                \
     {                                                                                                                             \
@@ -1322,10 +1320,7 @@ __device__ __forceinline__ void gr_layer(unsigned long long (&tacc)[6], char* bx
         for (int k = 0; k < 12; k++) aq[nt][k] = (float2_t){0.0f, 0.0f};
     }
     const int tboth = min(trips[0], trips[1]);
-#ifdef GR_ONE_CODE_WALK
-    unsigned cf_zero = 0;
-    asm volatile("" : "+v"(cf_zero));
-#endif
+    GR_WALK_TIMING_SETUP()
 #ifdef GR_PROF_WALK  // development: tacc[5] = the three walk loops alone, tacc[4] = self term + operand split (instead of DMA wait / step barriers)
     unsigned long long tw0 = 0;
     if constexpr (PROF) tw0 = wall_clock64();
@@ -1739,577 +1734,9 @@ __global__ __launch_bounds__(GR_WAVES * 64, 2) void gin_resident_kernel(const fl
 }
 
 
-// ================================================================ ping-pong graph-resident GIN
-// gin_resident_kernel marches its eight waves through barrier-delimited phases TOGETHER: all gather (VALU + LDS issue, matrix pipe
-// idle), then all multiply (matrix pipe + LDS fragment reads, the two waves of a SIMD taking MFMA slots from each other).  Here the
-// workgroup is two HALVES of four waves (one wave per SIMD each); a half owns its own half-tile of whole graphs (<= 128 rows / 640
-// in-edges, rows resident in LDS across the five layers as before) and the halves run the same program HALF A LAYER OUT OF PHASE:
-// while one half multiplies (its wave has the SIMD's matrix pipe to itself), the other gathers its next layer's operands and acts
-// as the LOADER -- it issues the LDS-DMA of the multiplying half's weight pieces and of the edge-embedding tables.  Matrix work
-// beside memory work on every SIMD, at all times (MI355X_MICROARCH.md, "Two waves per SIMD": the complementary pairing).
-//   * a phase = 14 sub-steps, each closed by one workgroup barrier.  Multiply: the layer's weight stream cut into 14 PIECES of
-//     <= 14 336 B -- W1 of hidden tiles 2s, 2s+1 (even pieces) and the W2 K-step that consumes them (odd pieces) -- through two piece
-//     buffers: piece i+1 lands (loader) while piece i is multiplied.  Gather: two passes over the half-tile's in-edges, features
-//     0..47 then 48..99, seven sub-steps each, so that the 60-row edge-embedding table is needed one HALF at a time (two half-table
-//     buffers of 12 480 B; a half table is reloaded while the other one is in use) -- that is what makes everything fit 160 KB.
-//   * phase p: half A (waves 0-3) gathers in even phases and multiplies in odd ones, half B (waves 4-7) the other way round, one
-//     phase behind: half h in phase p is at q = p - h, tile q / 10, layer (q % 10) / 2, role q & 1.
-//   * arithmetic per row is exactly gin_resident_kernel's (same MFMA sequence per column tile, in-edges in CSR order): bit-identical.
-// LDS: 2 x 14 336 (pieces) + 2 x 12 480 (half tables) + 2 x 51 200 (rows) + 2 x 1 792 (descriptors) + 1 024 + 832 = 161 472 B.
-constexpr int PP_ROWS = 128, PP_EDGES = 640;
-constexpr int PP_PIECE = 14336, PP_PIECES = 14;
-constexpr int PP_HDR_OFF = 13440;             // piece 0: b2[112] + 1 / (s1 s2) behind the W1 part
-constexpr int PP_TBL_STRIDE = 52;             // floats per row of a half table (13 bank groups: odd, conflict-free over 16 rows)
-constexpr int PP_TBL_BYTES = EDGE_COMBOS * PP_TBL_STRIDE * 4;  // 12 480
-constexpr int PP_DESC_RP = PP_EDGES * 2;      // u16 row offsets (129 used) behind the u16 edge words
-constexpr int PP_DESC_PERM = PP_DESC_RP + 272;
-constexpr int PP_DESC_BYTES = 1792;
-constexpr int PP_SUB = 7;                     // sub-steps per gather pass (2 passes = 14 = PP_PIECES)
-
-// descriptor of a half-tile (as gin_tile_prep_kernel's, for 128 rows / 8 column tiles over the 4 waves of a half): thread r = row r
-__global__ __launch_bounds__(128) void gin_pp_prep_kernel(const int* __restrict__ row_ptr, const int* __restrict__ src,
-                                                          const uint8_t* __restrict__ ecode, const int4* __restrict__ tiles,
-                                                          uint8_t* __restrict__ desc, int n_tiles, int ntc) {
-    constexpr int NKEY = 18;
-    __shared__ int s_cnt[2][NKEY];
-    const int tile = blockIdx.x;
-    if (tile >= n_tiles) return;
-    const int4 t = tiles[tile];
-    const int t0 = t.x;
-    int rows = t.y;
-    if (rows > PP_ROWS) rows = PP_ROWS;
-    const int e0 = row_ptr[t0];
-    int ne = row_ptr[t0 + rows] - e0;
-    if (ne > PP_EDGES) ne = PP_EDGES;
-    uint8_t* d = desc + (size_t)tile * PP_DESC_BYTES;
-    uint16_t* d_edge = reinterpret_cast<uint16_t*>(d);
-    uint16_t* d_rp = reinterpret_cast<uint16_t*>(d + PP_DESC_RP);
-    const int r = threadIdx.x, lane = r & 63, wv = r >> 6;
-    for (int i = r; i < ne; i += 128)
-        d_edge[i] = (uint16_t)((((unsigned)(src[e0 + i] - t0) & 0x7Fu) << 6) | ((unsigned)ecode[e0 + i] & 63u));
-    int key = NKEY - 1, deg = 0;
-    {
-        const int lo = r <= rows ? row_ptr[t0 + r] - e0 : ne;
-        const int lo_c = lo < 0 ? 0 : (lo > ne ? ne : lo);
-        d_rp[r] = (uint16_t)lo_c;
-        if (r == 127) d_rp[128] = (uint16_t)ne;
-        if (r < rows) {
-            const int hi = row_ptr[t0 + r + 1] - e0;
-            deg = (hi > ne ? ne : hi) - lo_c;
-            if (deg < 0) deg = 0;
-            key = 16 - (deg < 16 ? deg : 16);
-        }
-    }
-    int below = 0, mine = 0;
-    for (int k = 0; k < NKEY; k++) {
-        const unsigned long long m = __ballot(key == k);
-        if (lane == 0) s_cnt[wv][k] = __popcll(m);
-        if (key == k) mine = __popcll(m & ((1ull << lane) - 1ull));
-    }
-    __syncthreads();
-    for (int k = 0; k < NKEY; k++)
-        for (int w = 0; w < 2; w++) {
-            const int c = s_cnt[w][k];
-            if (k < key || (k == key && w < wv)) below += c;
-        }
-    const int pos = below + mine;           // rank in (decreasing in-degree, row) order, 0..127
-    const int kt = pos >> 4, j = pos & 15;  // column tile kt (0 = longest rows)
-    if (ntc == 1) {  // eight waves per half, one column tile each: wave kt owns column tile kt
-        d[PP_DESC_PERM + pos] = (uint8_t)r;
-        return;
-    }
-    const int w4 = kt < 4 ? kt : 7 - kt, nt = kt < 4 ? 0 : 1;  // snake over the half's four waves
-    d[PP_DESC_PERM + w4 * 32 + nt * 16 + j] = (uint8_t)r;
-}
-
-#define PP_LD(off) (*reinterpret_cast<const uint4_t*>(wb + (off) + lane * 16))
-// one W2 piece: acc2[nt][t] += W2 frag(t) x relu(hidden) of the W1 piece before it (7 units of 6 MFMAs, fragments one unit ahead)
-// NTC = column tiles (of 16 rows) per wave: 2 in the eight-wave workgroup (four waves per half), 1 in the sixteen-wave one (eight per half)
-template <bool PACKED, int NTC>
-__device__ __forceinline__ void pp_w2(const char* wb, int lane, const uint4_t (&hb_hi)[NTC], const uint4_t (&hb_lo)[NTC], float4_t (&acc2)[NTC][GS_T2]) {
-    if constexpr (PACKED) {  // hidden units 192..199: one MFMA per output tile and column tile (hb_hi holds the packed operand)
-        uint4_t p[GS_T2];
-#pragma unroll
-        for (int t = 0; t < GS_T2; t++) p[t] = PP_LD(t * 1024);
-#pragma unroll
-        for (int t = 0; t < GS_T2; t++) {
-            acc2[0][t] = GS_MFMA16(p[t], hb_hi[0], acc2[0][t]);
-            if constexpr (NTC == 2) acc2[NTC - 1][t] = GS_MFMA16(p[t], hb_hi[NTC - 1], acc2[NTC - 1][t]);
-        }
-    } else {
-        uint4_t f0[2], f1[2];
-#define PP_U2_LOAD(F, T) F[0] = PP_LD((2 * (T)) * 1024); F[1] = PP_LD((2 * (T) + 1) * 1024);
-#define PP_U2_MFMA(F, T)                                                                                    \
-    acc2[0][T] = GS_MFMA16(F[0], hb_hi[0], acc2[0][T]);                                                     \
-    if constexpr (NTC == 2) acc2[NTC - 1][T] = GS_MFMA16(F[0], hb_hi[NTC - 1], acc2[NTC - 1][T]);           \
-    acc2[0][T] = GS_MFMA16(F[0], hb_lo[0], acc2[0][T]);                                                     \
-    if constexpr (NTC == 2) acc2[NTC - 1][T] = GS_MFMA16(F[0], hb_lo[NTC - 1], acc2[NTC - 1][T]);           \
-    acc2[0][T] = GS_MFMA16(F[1], hb_hi[0], acc2[0][T]);                                                     \
-    if constexpr (NTC == 2) acc2[NTC - 1][T] = GS_MFMA16(F[1], hb_hi[NTC - 1], acc2[NTC - 1][T]);
-        PP_U2_LOAD(f0, 0) GR_SB();
-        PP_U2_LOAD(f1, 1) GR_SB(); PP_U2_MFMA(f0, 0) GR_SB();
-        PP_U2_LOAD(f0, 2) GR_SB(); PP_U2_MFMA(f1, 1) GR_SB();
-        PP_U2_LOAD(f1, 3) GR_SB(); PP_U2_MFMA(f0, 2) GR_SB();
-        PP_U2_LOAD(f0, 4) GR_SB(); PP_U2_MFMA(f1, 3) GR_SB();
-        PP_U2_LOAD(f1, 5) GR_SB(); PP_U2_MFMA(f0, 4) GR_SB();
-        PP_U2_LOAD(f0, 6) GR_SB(); PP_U2_MFMA(f1, 5) GR_SB();
-        PP_U2_MFMA(f0, 6) GR_SB();
-#undef PP_U2_LOAD
-#undef PP_U2_MFMA
-    }
-}
-
-// one W1 piece: hidden tiles 2s (, 2s+1) = b1 + W1 a (K = 96 as three K-steps + the packed tail), then ReLU + split into the next W2
-// piece's B operands -- or (DOT: the folded last layer) dotted with their slice of u.  NTL 1, !DOT = the last W1 piece (hidden tile
-// 12): the packed operand of the packed W2 piece is built.
-template <int NTL, bool DOT, int NTC>
-__device__ __forceinline__ void pp_w1(const char* wb, int lane, int g, const uint4_t (&in_hi)[NTC][3], const uint4_t (&in_lo)[NTC][3],
-                                      const uint4_t (&in_tb)[NTC], uint4_t (&hb_hi)[NTC], uint4_t (&hb_lo)[NTC], float& vmax,
-                                      const float* u_step, float (&dot)[NTC]) {
-    uint4_t f0[2], f1[2];
-    float4_t acc1[NTC];
-#define PP_U1_LOAD(F, TL, KS) F[0] = PP_LD((TL) * 6144 + (2 * (KS)) * 1024); F[1] = PP_LD((TL) * 6144 + (2 * (KS) + 1) * 1024);
-#define PP_U1_MFMA1(F, KS)                                                                                  \
-    acc1[0] = GS_MFMA16(F[0], in_hi[0][KS], acc1[0]);                                                       \
-    if constexpr (NTC == 2) acc1[NTC - 1] = GS_MFMA16(F[0], in_hi[NTC - 1][KS], acc1[NTC - 1]);             \
-    acc1[0] = GS_MFMA16(F[0], in_lo[0][KS], acc1[0]);                                                       \
-    if constexpr (NTC == 2) acc1[NTC - 1] = GS_MFMA16(F[0], in_lo[NTC - 1][KS], acc1[NTC - 1]);             \
-    acc1[0] = GS_MFMA16(F[1], in_hi[0][KS], acc1[0]);                                                       \
-    if constexpr (NTC == 2) acc1[NTC - 1] = GS_MFMA16(F[1], in_hi[NTC - 1][KS], acc1[NTC - 1]);
-#define PP_TAIL_LOAD(F, TL) F[0] = *reinterpret_cast<const uint4_t*>(wb + GRC_TAIL_OFF + (TL) * 512 + (lane & 31) * 16);
-#define PP_BIAS(TL) acc1[0] = *reinterpret_cast<const float4_t*>(wb + GRC_B1_OFF + (TL) * 64 + g * 16);
-#define PP_FINISH(TL)                                                                                     \
-    _Pragma("unroll") for (int nt = 0; nt < NTC; nt++) {                                                    \
-        float4_t r = acc1[nt];                                                                            \
-        r.x = gs_relu(r.x); r.y = gs_relu(r.y); r.z = gs_relu(r.z); r.w = gs_relu(r.w);                   \
-        if constexpr (DOT) {                                                                              \
-            const float4 uu = *reinterpret_cast<const float4*>(u_step + 16 * (TL) + 4 * g);              \
-            dot[nt] += r.x * uu.x; dot[nt] += r.y * uu.y; dot[nt] += r.z * uu.z; dot[nt] += r.w * uu.w;   \
-            continue;                                                                                     \
-        }                                                                                                 \
-        vmax = __builtin_fmaxf(__builtin_fmaxf(vmax, r.x), r.y);                                          \
-        vmax = __builtin_fmaxf(__builtin_fmaxf(vmax, r.z), r.w);                                          \
-        if ((TL) == 0) { GS_SPLIT2(r.x, r.y, hb_hi[nt].x, hb_lo[nt].x); GS_SPLIT2(r.z, r.w, hb_hi[nt].y, hb_lo[nt].y); } \
-        else { GS_SPLIT2(r.x, r.y, hb_hi[nt].z, hb_lo[nt].z); GS_SPLIT2(r.z, r.w, hb_hi[nt].w, hb_lo[nt].w); }           \
-    }
-    PP_U1_LOAD(f1, 0, 0)
-    PP_BIAS(0)
-    GR_SB();
-    if constexpr (NTC == 2) acc1[NTC - 1] = acc1[0];
-    PP_U1_LOAD(f0, 0, 1) GR_SB(); PP_U1_MFMA1(f1, 0) GR_SB();
-    PP_U1_LOAD(f1, 0, 2) GR_SB(); PP_U1_MFMA1(f0, 1) GR_SB();
-    PP_TAIL_LOAD(f0, 0) GR_SB(); PP_U1_MFMA1(f1, 2) GR_SB();
-    if constexpr (NTL == 2) { PP_U1_LOAD(f1, 1, 0) GR_SB(); }
-    acc1[0] = GS_MFMA16(f0[0], in_tb[0], acc1[0]);
-    if constexpr (NTC == 2) acc1[NTC - 1] = GS_MFMA16(f0[0], in_tb[NTC - 1], acc1[NTC - 1]);
-    if constexpr (NTL == 2) {
-        PP_FINISH(0)
-        PP_BIAS(1)
-        if constexpr (NTC == 2) acc1[NTC - 1] = acc1[0];
-        PP_U1_LOAD(f0, 1, 1) GR_SB(); PP_U1_MFMA1(f1, 0) GR_SB();
-        PP_U1_LOAD(f1, 1, 2) GR_SB(); PP_U1_MFMA1(f0, 1) GR_SB();
-        PP_TAIL_LOAD(f0, 1) GR_SB(); PP_U1_MFMA1(f1, 2) GR_SB();
-        acc1[0] = GS_MFMA16(f0[0], in_tb[0], acc1[0]);
-        if constexpr (NTC == 2) acc1[NTC - 1] = GS_MFMA16(f0[0], in_tb[NTC - 1], acc1[NTC - 1]);
-        PP_FINISH(1)
-    } else if constexpr (DOT) {
-        PP_FINISH(0)
-    } else {
-        PP_FINISH(0)
-        // lanes g = 0 / 1 hold hidden units 192..195 / 196..199 (hi in hb_hi.xy, lo in hb_lo.xy); the packed operand of the packed
-        // W2 piece is  g = 0, 1: [hi, lo] (own)   g = 2, 3: [hi of lane - 32, 0]
-#pragma unroll
-        for (int nt = 0; nt < NTC; nt++) {
-            const uint32_t ox = __shfl(hb_hi[nt].x, lane & 31, 64), oy = __shfl(hb_hi[nt].y, lane & 31, 64);
-            const bool own = g < 2;
-            hb_hi[nt] = own ? (uint4_t){hb_hi[nt].x, hb_hi[nt].y, hb_lo[nt].x, hb_lo[nt].y} : (uint4_t){ox, oy, 0u, 0u};
-        }
-    }
-    asm volatile("" : "+v"(vmax));
-#undef PP_U1_LOAD
-#undef PP_U1_MFMA1
-#undef PP_TAIL_LOAD
-#undef PP_BIAS
-#undef PP_FINISH
-}
-#undef PP_LD
-
-// `bytes` (a multiple of 16) from global memory to LDS, dealt over `nw` waves (this wave = wi): 1 KiB pieces by LDS-DMA
-__device__ __forceinline__ void pp_dma(const void* gsrc, void* ldst, int bytes, int wi, int nw, int lane) {
-    const int pieces = (bytes + 1023) >> 10;
-    const uint32_t lb = lds_addr_of(ldst);
-    for (int pc = wi; pc < pieces; pc += nw) {
-        const int left = bytes - pc * 1024;
-        if (left >= 1024 || lane * 16 < left) lds_dma16(reinterpret_cast<const char*>(gsrc) + (size_t)pc * 1024, (uint32_t)lane * 16u, lb + pc * 1024);
-    }
-}
-// pieces [first, first + count) of such a transfer, one per wave of the `nw` (this wave = wi): a slice of a long transfer per sub-step
-__device__ __forceinline__ void pp_dma_slice(const void* gsrc, void* ldst, int bytes, int first, int count, int wi, int nw, int lane) {
-    const int pieces = (bytes + 1023) >> 10;
-    const uint32_t lb = lds_addr_of(ldst);
-    for (int pc = first + wi; pc < first + count && pc < pieces; pc += nw) {
-        const int left = bytes - pc * 1024;
-        if (left >= 1024 || lane * 16 < left) lds_dma16(reinterpret_cast<const char*>(gsrc) + (size_t)pc * 1024, (uint32_t)lane * 16u, lb + pc * 1024);
-    }
-}
-
-
-// One pass (features 0..47 or 48..99) of the gather slot: PP_SUB sub-steps, each = loader duties, then up to `tps` in-edges of each of
-// this wave's 2 x 16 rows (CSR order), then the sub-step's barrier.
-#define PP_STAMP(K) if constexpr (PROF) { const unsigned long long t_ = clock64(); tacc[K] += t_ - tp; tp = t_; }
-template <int PASS, bool PROF, int NTC>
-__device__ __forceinline__ void pp_gather_pass(float (&bq)[NTC][25], const int (&e_beg)[NTC], const int (&e_end)[NTC], const uint16_t* s_edge,
-                                               const float* s_h, const float* s_tab, int tps, int p, int lm, const uint8_t* pieces_m,
-                                               const uint8_t* pieces_n, const float* tbl_h2, const float* tbl_h1n, char* s_cb0, char* s_cb1,
-                                               char* s_tb0, char* s_tb1, int w4, int lane, int g, unsigned long long (&tacc)[8], unsigned long long& tp) {
-    constexpr int NWH = 8 / NTC;  // waves per half: the loader's pieces are dealt over them
-    int e_cur[NTC];
-#pragma unroll
-    for (int nt = 0; nt < NTC; nt++) e_cur[nt] = e_beg[nt];
-#pragma unroll 1
-    for (int ss = 0; ss < PP_SUB; ss++) {
-        const int i = PASS * PP_SUB + ss;
-        PP_STAMP(7)
-        // loader: the multiplying half's next piece (the folded last layer reads its W1 pieces only: the even ones) ...
-        if (i + 1 < PP_PIECES) {
-            if (p > 0 && (lm != 4 || ((i + 1) & 1) == 0))
-                pp_dma(pieces_m + (size_t)(i + 1) * PP_PIECE, ((i + 1) & 1) ? s_cb1 : s_cb0, ((i + 1) & 1) ? PP_PIECE : PP_HDR_OFF + 512, w4, NWH, lane);
-        } else {
-            pp_dma(pieces_n, s_cb0, PP_HDR_OFF + 512, w4, NWH, lane);  // piece 0 of the next phase's layer
-        }
-        // ... and the half tables: even phases bring in the second half of this layer's table during pass 0 (needed in pass 1 of this
-        // phase and of the next), odd phases the first half of the NEXT layer's table during pass 1
-        if (PASS == 0 && (p & 1) == 0) pp_dma_slice(tbl_h2, s_tb1, PP_TBL_BYTES, 2 * ss, 2, w4, NWH, lane);
-        if (PASS == 1 && (p & 1) == 1) pp_dma_slice(tbl_h1n, s_tb0, PP_TBL_BYTES, 2 * ss, 2, w4, NWH, lane);
-        PP_STAMP(0)
-        for (int t = 0; t < tps; t++) {
-#pragma unroll
-            for (int nt = 0; nt < NTC; nt++) {
-                if (e_cur[nt] < e_end[nt]) {
-                    const unsigned wd = s_edge[e_cur[nt]];
-                    const unsigned u = wd >> 6, code = wd & 63u;
-                    e_cur[nt]++;
-                    const float* hr = s_h + u * GS_D + 4 * g + 48 * PASS;
-                    const float* er = s_tab + code * PP_TBL_STRIDE + 4 * g;
-                    float4 x[3], w[3];
-#pragma unroll
-                    for (int qq = 0; qq < 3; qq++) x[qq] = *reinterpret_cast<const float4*>(hr + 16 * qq);
-#pragma unroll
-                    for (int qq = 0; qq < 3; qq++) w[qq] = *reinterpret_cast<const float4*>(er + 16 * qq);
-#pragma unroll
-                    for (int qq = 0; qq < 3; qq++) {
-                        bq[nt][12 * PASS + 4 * qq + 0] += relu1(w[qq].x + x[qq].x);
-                        bq[nt][12 * PASS + 4 * qq + 1] += relu1(w[qq].y + x[qq].y);
-                        bq[nt][12 * PASS + 4 * qq + 2] += relu1(w[qq].z + x[qq].z);
-                        bq[nt][12 * PASS + 4 * qq + 3] += relu1(w[qq].w + x[qq].w);
-                    }
-                    if (PASS == 1) bq[nt][24] += relu1(s_tab[code * PP_TBL_STRIDE + 48 + g] + s_h[u * GS_D + 96 + g]);
-                }
-            }
-        }
-        PP_STAMP(1)
-        if (PASS == 1 && ss == PP_SUB - 1) break;  // the caller finishes the operands (it reads this half's rows) BEFORE the phase's last barrier
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        PP_STAMP(2)
-        __syncthreads();
-        PP_STAMP(3)
-    }
-}
-
-#define PP_SUBSTEP_END() PP_STAMP(4) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); PP_STAMP(5) __syncthreads(); PP_STAMP(6)
-// multiply slot of layers 0..3: 14 pieces through the two piece buffers (even pieces s_cb0, odd s_cb1), then h' in place
-template <bool PROF, int NTC>
-__device__ __forceinline__ void pp_multiply(const char* s_cb0, const char* s_cb1, float* s_h, const int (&row)[NTC], const uint4_t (&in_hi)[NTC][3],
-                                            const uint4_t (&in_lo)[NTC][3], const uint4_t (&in_tb)[NTC], float& vmax, int lane, int g,
-                                            unsigned long long (&tacc)[8], unsigned long long& tp) {
-    float4_t acc2[NTC][GS_T2];
-    uint4_t hb_hi[NTC], hb_lo[NTC];
-    float dot[NTC];
-#pragma unroll
-    for (int nt = 0; nt < NTC; nt++) dot[nt] = 0.0f;
-#pragma unroll
-    for (int t2 = 0; t2 < GS_T2; t2++) {
-        const float4 b = *reinterpret_cast<const float4*>(s_cb0 + PP_HDR_OFF + (16 * t2 + 4 * g) * 4);
-#pragma unroll
-        for (int nt = 0; nt < NTC; nt++) acc2[nt][t2] = (float4_t){b.x, b.y, b.z, b.w};
-    }
-    const float oscale = *reinterpret_cast<const float*>(s_cb0 + PP_HDR_OFF + 112 * 4);
-#pragma unroll
-    for (int nt = 0; nt < NTC; nt++) { hb_hi[nt] = (uint4_t){0, 0, 0, 0}; hb_lo[nt] = (uint4_t){0, 0, 0, 0}; }
-#pragma unroll
-    for (int st = 0; st < 6; st++) {
-        pp_w1<2, false, NTC>(s_cb0, lane, g, in_hi, in_lo, in_tb, hb_hi, hb_lo, vmax, nullptr, dot);
-        PP_SUBSTEP_END()
-        pp_w2<false, NTC>(s_cb1, lane, hb_hi, hb_lo, acc2);
-        PP_SUBSTEP_END()
-    }
-    pp_w1<1, false, NTC>(s_cb0, lane, g, in_hi, in_lo, in_tb, hb_hi, hb_lo, vmax, nullptr, dot);
-    PP_SUBSTEP_END()
-    pp_w2<true, NTC>(s_cb1, lane, hb_hi, hb_lo, acc2);
-    // h' back into the half-tile, in place (this half's next gather reads it after the barrier)
-#pragma unroll
-    for (int nt = 0; nt < NTC; nt++) {
-        float* rw = s_h + row[nt] * GS_D;
-#pragma unroll
-        for (int t2 = 0; t2 < GS_T2; t2++) {
-            const int col = 16 * t2 + 4 * g;
-            if (col < GS_D) {
-                float4_t r = acc2[nt][t2] * oscale;
-                r.x = gs_relu(r.x); r.y = gs_relu(r.y); r.z = gs_relu(r.z); r.w = gs_relu(r.w);
-                *reinterpret_cast<float4*>(rw + col) = make_float4(r.x, r.y, r.z, r.w);
-            }
-        }
-    }
-    PP_SUBSTEP_END()
-}
-
-// multiply slot of the last layer, readout folded through its second linear layer: the seven W1 pieces only (hidden tiles dotted with
-// u = W2^T w), every other sub-step empty; the next half-tile's rows and descriptor come in, a slice per sub-step
-template <bool PROF, int NTC>
-__device__ __forceinline__ void pp_multiply_last(const char* s_cb0, const char* s_cb1, float* s_dot, const float* s_u, const int (&row)[NTC],
-                                                 const uint4_t (&in_hi)[NTC][3], const uint4_t (&in_lo)[NTC][3], const uint4_t (&in_tb)[NTC], float& vmax,
-                                                 int lane, int g, bool has_next, const float* next_rows, float* s_h, int next_bytes,
-                                                 const uint8_t* next_desc, char* s_desc, int w4, unsigned long long (&tacc)[8], unsigned long long& tp) {
-    (void)s_cb1;
-    constexpr int NWH = 8 / NTC;
-    uint4_t hb_hi[NTC], hb_lo[NTC];
-    float dot[NTC];
-#pragma unroll
-    for (int nt = 0; nt < NTC; nt++) { dot[nt] = 0.0f; hb_hi[nt] = (uint4_t){0, 0, 0, 0}; hb_lo[nt] = (uint4_t){0, 0, 0, 0}; }
-#pragma unroll
-    for (int st = 0; st < 7; st++) {
-        // the rows and the descriptor of this half-tile are dead: the next one's come in (the descriptor not in the very first sub-step:
-        // a wave of this half that is a few cycles behind may still be reading its column owners from it)
-        if (has_next) pp_dma_slice(next_rows, s_h, next_bytes, 8 * st, 4, w4, NWH, lane);
-        if (st < 6) pp_w1<2, true, NTC>(s_cb0, lane, g, in_hi, in_lo, in_tb, hb_hi, hb_lo, vmax, s_u + 32 * st, dot);
-        else pp_w1<1, true, NTC>(s_cb0, lane, g, in_hi, in_lo, in_tb, hb_hi, hb_lo, vmax, s_u + 32 * st, dot);
-        if (st == 6) {
-#pragma unroll
-            for (int nt = 0; nt < NTC; nt++) {
-                float part = dot[nt];
-                part += __shfl_xor(part, 16, 64);
-                part += __shfl_xor(part, 32, 64);
-                if (g == 0) s_dot[row[nt]] = part;
-            }
-        }
-        PP_SUBSTEP_END()
-        if (has_next) {
-            pp_dma_slice(next_rows, s_h, next_bytes, 8 * st + 4, 4, w4, NWH, lane);
-            if (st == 0) pp_dma(next_desc, s_desc, PP_DESC_BYTES, w4, NWH, lane);
-        }
-        PP_SUBSTEP_END()
-    }
-}
-#undef PP_SUBSTEP_END
-
-struct PpTile { int t0, rows, g0, g1; };
-__device__ __forceinline__ PpTile pp_load_tile(const int4* __restrict__ tiles, int idx, int n_tiles) {
-    PpTile t{0, 0, 0, 0};
-    if (idx >= 0 && idx < n_tiles) {
-        const int4 v = tiles[idx];
-        t.t0 = v.x; t.rows = v.y < PP_ROWS ? v.y : PP_ROWS; t.g0 = v.z; t.g1 = v.w;
-    }
-    return t;
-}
-
-template <bool PROF, int NTC>
-__global__ __launch_bounds__(1024 / NTC) void gin_pp_kernel(const float* __restrict__ h0, const float* __restrict__ tbl_all /* [5][2][60][52] */,
-                                                        const uint8_t* __restrict__ pieces_all /* [5][14][14336] */,
-                                                        const float* __restrict__ pool_b, const int4* __restrict__ tiles,
-                                                        const uint8_t* __restrict__ desc, const int* __restrict__ node_off,
-                                                        float* __restrict__ out, int n_tiles, int* __restrict__ range_flag,
-                                                        const float* __restrict__ head_u, unsigned long long* __restrict__ prof_out) {
-    unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    unsigned long long tp = 0, tk0 = 0;
-    if constexpr (PROF) { tk0 = clock64(); tp = tk0; }
-    __shared__ __attribute__((aligned(16))) char s_cb0[PP_PIECE];
-    __shared__ __attribute__((aligned(16))) char s_cb1[PP_PIECE];
-    __shared__ __attribute__((aligned(16))) char s_tb0[PP_TBL_BYTES];
-    __shared__ __attribute__((aligned(16))) char s_tb1[PP_TBL_BYTES];
-    __shared__ __attribute__((aligned(16))) float s_hA[PP_ROWS * GS_D];
-    __shared__ __attribute__((aligned(16))) float s_hB[PP_ROWS * GS_D];
-    __shared__ __attribute__((aligned(16))) char s_descA[PP_DESC_BYTES];
-    __shared__ __attribute__((aligned(16))) char s_descB[PP_DESC_BYTES];
-    __shared__ float s_dotA[PP_ROWS];
-    __shared__ float s_dotB[PP_ROWS];
-    __shared__ __attribute__((aligned(16))) float s_u[208];
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    constexpr int NWH = 8 / NTC;  // waves per half; w4 = this wave's index inside its half
-    const int half = wave / NWH, w4 = wave % NWH;
-    const int j = lane & 15, g = lane >> 4;
-    float* s_h = half ? s_hB : s_hA;
-    char* s_desc = half ? s_descB : s_descA;
-    float* s_dot = half ? s_dotB : s_dotA;
-    // this workgroup's half-tiles: list entries b, b + grid, ...; half A takes the even ones, half B the odd ones
-    const int first = blockIdx.x, stride = gridDim.x;
-    if (first >= n_tiles) return;
-    const int cnt = (n_tiles - first + stride - 1) / stride;
-    const int TA = (cnt + 1) >> 1, TB = cnt >> 1;
-    const int T_mine = half ? TB : TA;
-    const int P = (10 * TA > 10 * TB + 1) ? 10 * TA : 10 * TB + 1;
-    if ((int)threadIdx.x < 208) s_u[threadIdx.x] = head_u[threadIdx.x];
-    const float head_c = head_u[208];
-    auto tile_of = [&](int ordinal) { return first + (2 * ordinal + half) * stride; };  // list index of this half's ordinal-th half-tile
-    PpTile cur = pp_load_tile(tiles, T_mine > 0 ? tile_of(0) : -1, n_tiles);
-    // prologue: every half brings in its first half-tile (rows + descriptor); half A the first half table of layer 0
-    if (T_mine > 0) {
-        pp_dma(h0 + (size_t)cur.t0 * GS_D, s_h, ((cur.rows * GS_D * 4 + 15) >> 4) << 4, w4, NWH, lane);
-        pp_dma(desc + (size_t)tile_of(0) * PP_DESC_BYTES, s_desc, PP_DESC_BYTES, w4, NWH, lane);
-    }
-    if (half == 0) pp_dma(tbl_all, s_tb0, PP_TBL_BYTES, w4, NWH, lane);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-
-    float vmax = 0.0f;
-    uint4_t in_hi[NTC][3], in_lo[NTC][3], in_tb[NTC];
-#pragma unroll
-    for (int nt = 0; nt < NTC; nt++) {
-        in_tb[nt] = (uint4_t){0, 0, 0, 0};
-#pragma unroll
-        for (int ks = 0; ks < 3; ks++) { in_hi[nt][ks] = (uint4_t){0, 0, 0, 0}; in_lo[nt][ks] = (uint4_t){0, 0, 0, 0}; }
-    }
-    bool readout_due = false;
-    PpTile done_tile{0, 0, 0, 0};
-
-#pragma unroll 1
-    for (int p = 0; p < P; p++) {
-        const int q = p - half;
-        const bool active = q >= 0 && q / 10 < T_mine;
-        const int l = (q >= 0 ? (q % 10) : 0) >> 1;
-        const bool g_slot = (half == (p & 1));          // this half's slot in phase p: gather / loader, or multiply
-        const int lg = ((p - (p & 1)) % 10) >> 1;       // the layer the gather slot works on = the layer multiplied in phase p + 1
-        const int lm = p > 0 ? ((p - 1 + (p & 1)) % 10) >> 1 : 0;  // the layer multiplied in this phase (by half 1 - (p & 1)); p = 0: nobody multiplies
-        if (readout_due) {
-            // readout of the half-tile finished in the previous phase (GIN/src/finalize.cc:36-113): out[g] = mean_v(h5[v] . w) + b, node order
-            const int ti = (int)threadIdx.x - half * (NWH * 64);  // thread inside the half
-            const int gi = done_tile.g0 + ti;
-            if (ti < PP_ROWS && gi < done_tile.g1) {
-                const int n0 = node_off[gi], n1 = node_off[gi + 1];
-                float sum = 0.0f;
-                for (int v = n0; v < n1; v++) sum += s_dot[v - done_tile.t0];
-                out[gi] = sum / (float)(n1 - n0) + pool_b[0] + head_c;
-            }
-            readout_due = false;
-        }
-        if (g_slot) {
-            // ------------------------------------------------------------ gather slot (+ loader duties)
-            const uint16_t* s_edge = reinterpret_cast<const uint16_t*>(s_desc);
-            const uint16_t* s_rp = reinterpret_cast<const uint16_t*>(s_desc + PP_DESC_RP);
-            const uint8_t* s_perm = reinterpret_cast<const uint8_t*>(s_desc + PP_DESC_PERM);
-            const int rows_here = active ? cur.rows : 0;  // an idle half walks no edges and produces zero operands
-            float bq[NTC][25];
-            int e_beg[NTC], e_end[NTC], row[NTC];
-            int dmax = 0;
-#pragma unroll
-            for (int nt = 0; nt < NTC; nt++) {
-                row[nt] = s_perm[w4 * (16 * NTC) + nt * 16 + j];
-                const bool valid = row[nt] < rows_here;
-                const int rr = valid ? row[nt] : 0;
-                e_beg[nt] = s_rp[rr];
-                e_end[nt] = valid ? (int)s_rp[rr + 1] : e_beg[nt];
-                dmax = max(dmax, e_end[nt] - e_beg[nt]);
-#pragma unroll
-                for (int k = 0; k < 25; k++) bq[nt][k] = 0.0f;
-            }
-#pragma unroll
-            for (int d = 32; d >= 1; d >>= 1) dmax = max(dmax, __shfl_xor(dmax, d, 64));
-            const int tps = (__builtin_amdgcn_readfirstlane(dmax) + PP_SUB - 1) / PP_SUB;  // trips per sub-step (wave-uniform)
-            const uint8_t* pieces_m = pieces_all + (size_t)lm * PP_PIECES * PP_PIECE;
-            const uint8_t* pieces_n = pieces_all + (size_t)lg * PP_PIECES * PP_PIECE;
-            const float* tbl_h2 = tbl_all + ((size_t)lg * 2 + 1) * (PP_TBL_BYTES / 4);
-            const float* tbl_h1n = tbl_all + ((size_t)((lg + 1) % 5) * 2) * (PP_TBL_BYTES / 4);
-            PP_STAMP(7)
-            pp_gather_pass<0, PROF, NTC>(bq, e_beg, e_end, s_edge, s_h, reinterpret_cast<const float*>(s_tb0), tps, p, lm, pieces_m, pieces_n, tbl_h2, tbl_h1n,
-                                    s_cb0, s_cb1, s_tb0, s_tb1, w4, lane, g, tacc, tp);
-            pp_gather_pass<1, PROF, NTC>(bq, e_beg, e_end, s_edge, s_h, reinterpret_cast<const float*>(s_tb1), tps, p, lm, pieces_m, pieces_n, tbl_h2, tbl_h1n,
-                                    s_cb0, s_cb1, s_tb0, s_tb1, w4, lane, g, tacc, tp);
-            // + (1 + eps) h[v], eps == 0, then the B operands of the first linear layer (as gr_layer) -- inside the phase's last sub-step:
-            // after its barrier this half's other waves may already be overwriting the rows (next half-tile's DMA, h' in place)
-#pragma unroll
-            for (int nt = 0; nt < NTC; nt++) {
-                if (row[nt] < rows_here) {
-                    const float* hr = s_h + row[nt] * GS_D + 4 * g;
-#pragma unroll
-                    for (int qq = 0; qq < 6; qq++) {
-                        const float4 x = *reinterpret_cast<const float4*>(hr + 16 * qq);
-                        bq[nt][4 * qq + 0] += x.x; bq[nt][4 * qq + 1] += x.y; bq[nt][4 * qq + 2] += x.z; bq[nt][4 * qq + 3] += x.w;
-                    }
-                    bq[nt][24] += s_h[row[nt] * GS_D + 96 + g];
-                }
-#pragma unroll
-                for (int ks = 0; ks < 3; ks++) {
-                    GS_SPLIT2(bq[nt][8 * ks + 0], bq[nt][8 * ks + 1], in_hi[nt][ks].x, in_lo[nt][ks].x);
-                    GS_SPLIT2(bq[nt][8 * ks + 2], bq[nt][8 * ks + 3], in_hi[nt][ks].y, in_lo[nt][ks].y);
-                    GS_SPLIT2(bq[nt][8 * ks + 4], bq[nt][8 * ks + 5], in_hi[nt][ks].z, in_lo[nt][ks].z);
-                    GS_SPLIT2(bq[nt][8 * ks + 6], bq[nt][8 * ks + 7], in_hi[nt][ks].w, in_lo[nt][ks].w);
-                }
-#pragma unroll
-                for (int k = 0; k < 24; k += 2)
-                    vmax = __builtin_fmaxf(__builtin_fmaxf(vmax, __builtin_fabsf(bq[nt][k])), __builtin_fabsf(bq[nt][k + 1]));
-                vmax = __builtin_fmaxf(vmax, __builtin_fabsf(bq[nt][24]));
-                const float t0 = __shfl(bq[nt][24], j, 64), t1 = __shfl(bq[nt][24], j + 16, 64);
-                const float t2 = __shfl(bq[nt][24], j + 32, 64), t3 = __shfl(bq[nt][24], j + 48, 64);
-                uint32_t h01, h23, l01, l23;
-                GS_SPLIT2(t0, t1, h01, l01);
-                GS_SPLIT2(t2, t3, h23, l23);
-                in_tb[nt] = g == 0 ? (uint4_t){h01, h23, l01, l23} : (g == 1 ? (uint4_t){h01, h23, 0u, 0u} : (uint4_t){0u, 0u, 0u, 0u});
-            }
-            PP_STAMP(1)
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            PP_STAMP(2)
-            __syncthreads();
-            PP_STAMP(3)
-        } else {
-            // ------------------------------------------------------------ multiply slot
-            const bool last = l == 4;
-            const int next_ord = q / 10 + 1;
-            const bool has_next = active && last && next_ord < T_mine;
-            const PpTile nxt = pp_load_tile(tiles, has_next ? tile_of(next_ord) : -1, n_tiles);
-            int row[NTC];
-            {
-                const uint8_t* s_perm = reinterpret_cast<const uint8_t*>(s_desc + PP_DESC_PERM);
-#pragma unroll
-                for (int nt = 0; nt < NTC; nt++) row[nt] = s_perm[w4 * (16 * NTC) + nt * 16 + j];
-            }
-            PP_STAMP(7)
-            if (!active) {
-#pragma unroll 1
-                for (int i = 0; i < PP_PIECES; i++) __syncthreads();
-                PP_STAMP(6)
-            } else if (!last) {
-                pp_multiply<PROF, NTC>(s_cb0, s_cb1, s_h, row, in_hi, in_lo, in_tb, vmax, lane, g, tacc, tp);
-            } else {
-                const int nb = ((nxt.rows * GS_D * 4 + 15) >> 4) << 4;
-                pp_multiply_last<PROF, NTC>(s_cb0, s_cb1, s_dot, s_u, row, in_hi, in_lo, in_tb, vmax, lane, g, has_next, h0 + (size_t)nxt.t0 * GS_D, s_h, nb,
-                                       desc + (size_t)(has_next ? tile_of(next_ord) : 0) * PP_DESC_BYTES, s_desc, w4, tacc, tp);
-                readout_due = true;
-                done_tile = cur;
-                cur = nxt;
-            }
-        }
-    }
-    if (readout_due) {  // (the barrier that closed the last phase made the terms visible)
-        const int ti = (int)threadIdx.x - half * (NWH * 64);
-        const int gi = done_tile.g0 + ti;
-        if (ti < PP_ROWS && gi < done_tile.g1) {
-            const int n0 = node_off[gi], n1 = node_off[gi + 1];
-            float sum = 0.0f;
-            for (int v = n0; v < n1; v++) sum += s_dot[v - done_tile.t0];
-            out[gi] = sum / (float)(n1 - n0) + pool_b[0] + head_c;
-        }
-    }
-    if (__any(!(vmax < 6.0e4f))) {
-        if (lane == 0) atomicOr(range_flag, 1);
-    }
-    if constexpr (PROF) {  // per-wave totals in shader cycles (s_memtime)
-        if (lane == 0) {
-            for (int i = 0; i < 8; i++) prof_out[((size_t)blockIdx.x * (2 * NWH) + wave) * 9 + i] = tacc[i];
-            prof_out[((size_t)blockIdx.x * (2 * NWH) + wave) * 9 + 8] = clock64() - tk0;
-        }
-    }
-}
-#undef PP_STAMP
+#ifdef FLOWGNN_DEV
+#include "dev/gin_pp_device.inc"  // gin_pp_kernel: the ping-pong form, measured slower -- development builds only
+#endif
 
 inline float pow2_scale(const float* w, size_t n) {
     float m = 0.0f;
@@ -2562,62 +1989,9 @@ void launch_gin_resident(const float* h0, float* hout, const int* row_ptr, const
     }
 }
 
-// ---- ping-pong kernel, host side
-size_t gin_pp_layer_bytes() { return (size_t)PP_PIECES * PP_PIECE; }
-size_t gin_pp_table_floats() { return (size_t)5 * 2 * EDGE_COMBOS * PP_TBL_STRIDE; }
-// the resident kernel's chunk stream of one layer (gin_resident_pack_layer) re-cut into the 14 pieces of gin_pp_kernel
-void gin_pp_pack_layer(const uint8_t* grc_layer, uint8_t* out) {
-    std::memset(out, 0, gin_pp_layer_bytes());
-    for (int st = 0; st < GS_STEPS; st++) {
-        const uint8_t* ck = grc_layer + (size_t)st * GRC_CHUNK_STRIDE;
-        if (st < GS_STEPS - 1) std::memcpy(out + (size_t)(2 * st) * PP_PIECE, ck, GRC_W2_OFF);  // W1 fragments, K tail, b1: piece 2 st
-        if (st == 0) std::memcpy(out + PP_HDR_OFF, ck + GRC_W2_OFF, 512);                         // b2 + output scale behind piece 0
-        else std::memcpy(out + (size_t)(2 * st - 1) * PP_PIECE, ck + GRC_W2_OFF, GRC_CHUNK_BYTES - GRC_W2_OFF);  // W2 K-step st - 1: piece 2 st - 1
-    }
-}
-// the 60-row edge-embedding tables [5][60][100] as two half tables per layer (features 0..47 | 48..99), rows padded to 52 floats
-void gin_pp_pack_tables(const float* ecomb_all, float* out) {
-    std::memset(out, 0, gin_pp_table_floats() * sizeof(float));
-    for (int l = 0; l < 5; l++)
-        for (int c = 0; c < EDGE_COMBOS; c++)
-            for (int d = 0; d < GS_D; d++) {
-                const int hf = d < 48 ? 0 : 1, col = d < 48 ? d : d - 48;
-                out[(((size_t)l * 2 + hf) * EDGE_COMBOS + c) * PP_TBL_STRIDE + col] = ecomb_all[((size_t)l * EDGE_COMBOS + c) * GS_D + d];
-            }
-}
-int gin_pp_desc_bytes() { return PP_DESC_BYTES; }
-void launch_gin_pp(const float* h0, const int* row_ptr, const int* src, const uint8_t* ecode, const float* tables, const uint8_t* pieces,
-                   const float* pool_b, const int* sub_tiles, uint8_t* sub_desc, const int* node_off, float* out, int n_sub, int* range_flag,
-                   const float* head_u, hipStream_t s, bool prof, int waves) {
-    if (n_sub <= 0) return;
-    const int4* tiles = reinterpret_cast<const int4*>(sub_tiles);
-    const int ntc = waves == 16 ? 1 : 2;  // sixteen waves: eight per half, one column tile each; eight: four per half, two each
-    gin_pp_prep_kernel<<<n_sub, 128, 0, s>>>(row_ptr, src, ecode, tiles, sub_desc, n_sub, ntc);
-    const int grid = n_sub < 256 ? n_sub : 256;  // persistent: one workgroup (two halves) per CU
-    if (!prof) {
-        if (ntc == 1) gin_pp_kernel<false, 1><<<grid, 1024, 0, s>>>(h0, tables, pieces, pool_b, tiles, sub_desc, node_off, out, n_sub, range_flag, head_u, nullptr);
-        else gin_pp_kernel<false, 2><<<grid, 512, 0, s>>>(h0, tables, pieces, pool_b, tiles, sub_desc, node_off, out, n_sub, range_flag, head_u, nullptr);
-        return;
-    }
-    // development aid (option gin_resident_prof): where the waves' cycles go, printed per launch (synchronises!)
-    unsigned long long* d = nullptr;
-    const int nwv = ntc == 1 ? 16 : 8;
-    const size_t cnt = (size_t)grid * nwv * 9;
-    if (hipMalloc((void**)&d, cnt * 8) != hipSuccess) return;
-    (void)hipMemsetAsync(d, 0, cnt * 8, s);
-    if (ntc == 1) gin_pp_kernel<true, 1><<<grid, 1024, 0, s>>>(h0, tables, pieces, pool_b, tiles, sub_desc, node_off, out, n_sub, range_flag, head_u, d);
-    else gin_pp_kernel<true, 2><<<grid, 512, 0, s>>>(h0, tables, pieces, pool_b, tiles, sub_desc, node_off, out, n_sub, range_flag, head_u, d);
-    std::vector<unsigned long long> hbuf(cnt);
-    (void)hipStreamSynchronize(s);
-    (void)hipMemcpy(hbuf.data(), d, cnt * 8, hipMemcpyDeviceToHost);
-    (void)hipFree(d);
-    double tot[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-    for (size_t i = 0; i < cnt; i++) tot[i % 9] += (double)hbuf[i];
-    const double nw = (double)grid * nwv;
-    fprintf(stderr, "[gin_pp prof] half-tiles %d grid %d waves %d | per wave, kcycles: gather slot: loader %.0f  walk+finish %.0f  dma wait %.0f  barrier %.0f | multiply slot: compute %.0f  dma wait %.0f  barrier %.0f | other %.0f | kernel %.0f\n",
-            n_sub, grid, nwv, tot[0] / nw / 1e3, tot[1] / nw / 1e3, tot[2] / nw / 1e3, tot[3] / nw / 1e3, tot[4] / nw / 1e3, tot[5] / nw / 1e3, tot[6] / nw / 1e3,
-            tot[7] / nw / 1e3, tot[8] / nw / 1e3);
-}
+#ifdef FLOWGNN_DEV
+#include "dev/gin_pp_host.inc"
+#endif
 
 void launch_gin_tile_build(const GinTileBuild& tb, const int* tile_row, const int* tile_graph, uint8_t* tile_desc, int n_tiles, bool hubs,
                            int col_order, hipStream_t s) {

@@ -272,14 +272,16 @@ constexpr int PNA_FT_EDGES = 4608;
 constexpr int PNA_FT_STRIDE = 84;
 constexpr int PNA_FT_WAVES = 16;
 
-// Per-tile descriptor (pna_tile_desc_kernel, once per batch pass: the four layers share it): the tile's CSR slice as the layer kernel
-// wants it in LDS -- [0, 4608) source rows inside the tile, one byte each; [4608, 5632) u16 row offsets into them (rows + 1 used) --
-// 5.5 pieces of 1 KiB that come by LDS-DMA with the tile's rows.  (Staged from the batch CSR by the layer kernel itself -- load,
+// Per-tile descriptor (pna_tile_build_kernel from the caller's edge list, or pna_tile_desc_kernel from the batch CSR; once per batch
+// pass: the four layers share it): the tile's CSR slice as the layer kernels want it in LDS -- [0, 4608) source rows inside the tile,
+// one byte each; [4608, 5632) u16 row offsets into them (rows + 1 used); [5632, 6144) u16 out-degrees of the tile's rows (the
+// resident kernel's degree scalers) -- 6 pieces of 1 KiB that come by LDS-DMA.  (Staged from the batch CSR by the layer kernel itself -- load,
 // subtract the tile's first row, store a byte -- hipcc waited for every word in turn: up to six serialized global round trips per tile
 // and layer behind the row DMA, and two dependent scalar loads for the slice's bounds at the top of every tile.)
 constexpr int PNA_DESC_RP = PNA_FT_EDGES;
-constexpr int PNA_DESC_BYTES = PNA_FT_EDGES + 1024;
-__global__ __launch_bounds__(256) void pna_tile_desc_kernel(const int* __restrict__ row_ptr, const int* __restrict__ src,
+constexpr int PNA_DESC_OD = PNA_FT_EDGES + 1024;
+constexpr int PNA_DESC_BYTES = PNA_FT_EDGES + 1536;
+__global__ __launch_bounds__(256) void pna_tile_desc_kernel(const int* __restrict__ row_ptr, const int* __restrict__ src, const int* __restrict__ out_deg,
                                                             const int* __restrict__ tile_row, uint8_t* __restrict__ desc, int n_tiles) {
     const int tile = blockIdx.x;
     if (tile >= n_tiles) return;
@@ -302,11 +304,107 @@ __global__ __launch_bounds__(256) void pna_tile_desc_kernel(const int* __restric
         int o = i <= rows ? row_ptr[t0 + i] - e0 : ne;
         rp[i] = (uint16_t)(o < 0 ? 0 : (o > ne ? ne : o));
     }
+    uint16_t* od = reinterpret_cast<uint16_t*>(d + PNA_DESC_OD);
+    od[threadIdx.x] = (uint16_t)((int)threadIdx.x < rows ? out_deg[t0 + threadIdx.x] : 0);
 }
-// a tile's descriptor -> LDS: six pieces (the last one half), dealt to the waves that issue one row piece fewer
+
+// The same descriptor straight from the caller's edge list: what the resident kernel needs of load_graph (PNA/src/load_inputs.cc:87-131)
+// WITHOUT the batch CSR.  One 256-thread workgroup per tile of whole graphs: the tile's edges are a contiguous slice of edge_list;
+// each is validated as the index build validates it, turned into (source row, destination row) of the tile and ORed into a 256 x 256
+// bit matrix in LDS.  Thread v then walks the set bits of row v in ascending order -- the CSR's order (sources ascending; copies of a
+// duplicate edge are equal terms, so their order among themselves is immaterial) -- and emits the row's source bytes: no sort at all.
+// An atomicOr that finds its bit set has found a duplicate edge: the copy goes to a list, and a row that has copies counts, per source,
+// how many (rare; a short scan).  Bit-identical to launch_build_csr + pna_tile_desc_kernel.
+__global__ __launch_bounds__(256) void pna_tile_build_kernel(BatchView b, const int* __restrict__ tile_row, const int* __restrict__ tile_graph,
+                                                             int n_tiles, uint8_t* __restrict__ desc, int* __restrict__ err) {
+    __shared__ uint32_t s_adj[PNA_FT_ROWS][8];
+    __shared__ int s_cnt[PNA_FT_ROWS], s_odeg[PNA_FT_ROWS], s_wsum[4], s_next;
+    __shared__ uint16_t s_ext[PNA_FT_EDGES];  // copies of duplicate edges: destination << 8 | source
+    __shared__ __attribute__((aligned(16))) uint8_t s_out[PNA_DESC_BYTES];
+    const int tile = blockIdx.x, tid = threadIdx.x;
+    if (tile >= n_tiles) return;
+    const int t0 = tile_row[tile];
+    int rows = tile_row[tile + 1] - t0;
+    if (rows > PNA_FT_ROWS) rows = PNA_FT_ROWS;
+    const int g0 = tile_graph[tile], g1 = tile_graph[tile + 1];
+#pragma unroll
+    for (int i = 0; i < 8; i++) s_adj[tid][i] = 0u;
+    s_cnt[tid] = 0;
+    s_odeg[tid] = 0;
+    if (tid == 0) s_next = 0;
+    for (int i = tid; i < PNA_DESC_BYTES / 4; i += 256) reinterpret_cast<uint32_t*>(s_out)[i] = 0u;
+    __syncthreads();
+    for (int gph = g0; gph < g1; gph++) {  // (a handful of graphs per tile; their headers are wave-uniform scalar loads)
+        const int n = b.nums_of_nodes[gph], base = b.node_off[gph] - t0, e0 = b.edge_off[gph], ne = b.edge_off[gph + 1] - e0;
+        for (int e = tid; e < ne; e += 256) {
+            const int2 uv = reinterpret_cast<const int2*>(b.edge_list)[e0 + e];
+            int u = uv.x, v = uv.y;
+            if (!((u >= 0) & (u < n) & (v >= 0) & (v < n))) {  // as the index build: flag it, then a self-loop on the graph's node 0
+                atomicMax(err, ERR_EDGE_RANGE);
+                u = 0;
+                v = 0;
+            }
+            u += base; v += base;
+            if (u >= PNA_FT_ROWS || v >= PNA_FT_ROWS) continue;  // (cannot happen: the host packed whole graphs into <= 256 rows)
+            const uint32_t bit = 1u << (u & 31);
+            const uint32_t old = atomicOr(&s_adj[v][u >> 5], bit);
+            if (old & bit) {
+                const int k = atomicAdd(&s_next, 1);
+                if (k < PNA_FT_EDGES) s_ext[k] = (uint16_t)((v << 8) | u);
+            }
+            atomicAdd(&s_cnt[v], 1);
+            atomicAdd(&s_odeg[u], 1);
+        }
+    }
+    __syncthreads();
+    // row offsets: exclusive scan of the in-degrees over the 256 rows (thread = row)
+    const int lane = tid & 63, wv = tid >> 6;
+    const int c = tid < rows ? s_cnt[tid] : 0;
+    int incl = c;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int o = __shfl_up(incl, d, 64);
+        if (lane >= d) incl += o;
+    }
+    if (lane == 63) s_wsum[wv] = incl;
+    __syncthreads();
+    int off = incl - c;
+    for (int w = 0; w < wv; w++) off += s_wsum[w];
+    int total = s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3];
+    if (total > PNA_FT_EDGES) total = PNA_FT_EDGES;  // cannot happen for a validated batch (the host packed by edge count)
+    uint16_t* rp = reinterpret_cast<uint16_t*>(s_out + PNA_DESC_RP);
+    rp[tid] = (uint16_t)(tid <= rows ? (off < total ? off : total) : total);
+    rp[256 + tid] = (uint16_t)total;
+    reinterpret_cast<uint16_t*>(s_out + PNA_DESC_OD)[tid] = (uint16_t)(tid < rows ? s_odeg[tid] : 0);
+    if (tid < rows) {
+        const int v = tid;
+        int nd = c;  // copies beyond the first of any (u -> v): in-degree - distinct sources
+#pragma unroll
+        for (int i = 0; i < 8; i++) nd -= __popc(s_adj[v][i]);
+        const int next = nd > 0 ? (s_next < PNA_FT_EDGES ? s_next : PNA_FT_EDGES) : 0;
+        int pos = off;
+        for (int sb = 0; sb < 8; sb++) {
+            uint32_t w = s_adj[v][sb];
+            while (w) {
+                const int u = 32 * sb + __ffs((int)w) - 1;
+                w &= w - 1;
+                int mult = 1;
+                for (int k = 0; k < next; k++) mult += s_ext[k] == (uint16_t)((v << 8) | u);
+                for (int m = 0; m < mult; m++) {
+                    if (pos < PNA_FT_EDGES) s_out[pos] = (uint8_t)u;
+                    pos++;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    uint4* dst = reinterpret_cast<uint4*>(desc + (size_t)tile * PNA_DESC_BYTES);
+    for (int i = tid; i < PNA_DESC_BYTES / 16; i += 256) dst[i] = reinterpret_cast<const uint4*>(s_out)[i];
+}
+// a tile's descriptor -> LDS: six pieces, dealt to the waves that issue one row piece fewer
 __device__ __forceinline__ void pna_issue_desc(const uint8_t* __restrict__ desc, int tile, char* lds_buf, int wave, int lane) {
     const int piece = PNA_FT_WAVES - 1 - wave;  // waves 15, 14, ..., 10
-    if (piece < 5 || (piece == 5 && lane < 32))
+    if (piece < PNA_DESC_BYTES / 1024)
         lds_dma16(desc + (size_t)tile * PNA_DESC_BYTES + piece * 1024, (uint32_t)lane * 16u, lds_addr_of(lds_buf) + piece * 1024);
 }
 
@@ -352,6 +450,23 @@ __device__ __forceinline__ void pna_stream_mfma(const char* wb, int lane, const 
 #pragma unroll
         for (int i = 0; i < n; i++) y[G * 2 + i] = DS_MFMA16(f[2 * i + 1], b_hi, y[G * 2 + i]);
     }
+}
+
+// h'[v] = h[v] + relu(b + Y_0 + t Y_1 + scale Y_2) for one float4 of outputs (node_embedding.cc:148-150,205-213), the accumulators still
+// carrying the weights' power-of-two scale.  Every fusion is spelled out: the per-layer and the graph-resident kernel then round alike
+// (left to -ffp-contract the same expression contracted differently in the two kernels: 1 ulp per layer, 10 ulp on a logit).
+__device__ __forceinline__ float4 pna_update(const float4& hv, const float4& b, const float4_t& y0, const float4_t& y1, const float4_t& y2,
+                                             float oscale, float sf_t, float sf_scale) {
+    float o[4];
+    const float hh[4] = {hv.x, hv.y, hv.z, hv.w}, bb[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        float f = __builtin_fmaf(y0[c], oscale, bb[c]);
+        f = __builtin_fmaf(sf_t, y1[c] * oscale, f);
+        f = __builtin_fmaf(sf_scale, y2[c] * oscale, f);
+        o[c] = hh[c] + relu1(f);
+    }
+    return make_float4(o[0], o[1], o[2], o[3]);
 }
 
 // one K-step's B operand: the aggregates of features f0 = 8k + 2g, f0 + 1 of this lane's node, gathered out of the LDS tile
@@ -595,15 +710,9 @@ __global__ __launch_bounds__(PNA_FT_WAVES * 64, 4) void pna_layer_fused_kernel(c
 #pragma unroll
             for (int t = 0; t < PNA_OT; t++) bb[t] = *reinterpret_cast<const float4*>(bias + 16 * t + 4 * g);
 #pragma unroll
-            for (int t = 0; t < PNA_OT; t++) {
-                const float4 b = bb[t];
-                float4_t fin = {b.x, b.y, b.z, b.w};
-                fin += y[0 * PNA_OT + t] * oscale;
-                fin += sf_t * (y[1 * PNA_OT + t] * oscale);
-                fin += sf_scale * (y[2 * PNA_OT + t] * oscale);
+            for (int t = 0; t < PNA_OT; t++)
                 *reinterpret_cast<float4*>(hout + (size_t)node * PNA_D + 16 * t + 4 * g) =
-                    make_float4(hv[t].x + relu1(fin.x), hv[t].y + relu1(fin.y), hv[t].z + relu1(fin.z), hv[t].w + relu1(fin.w));
-            }
+                    pna_update(hv[t], bb[t], y[0 * PNA_OT + t], y[1 * PNA_OT + t], y[2 * PNA_OT + t], oscale, sf_t, sf_scale);
         }
         PNA_STAMP(5);
 #ifdef FLOWGNN_DEV
@@ -624,6 +733,198 @@ __global__ __launch_bounds__(PNA_FT_WAVES * 64, 4) void pna_layer_fused_kernel(c
 #undef PNA_STAMP
     if (__any(!(vmax < 6.0e4f))) {
         if (lane == 0) atomicOr(range_flag, 1);
+    }
+}
+
+// ---------------------------------------------------------------- graph-resident kernel: encoder + four layers + readout in one launch
+// The FPGA holds one graph on chip from load_graph to the logit (PNA/src/PNA_compute.cc:46-100).  Here a persistent 16-wave
+// workgroup holds a tile of WHOLE graphs (GraphTiles: <= 256 rows / 4 608 in-edges) in LDS across all four layers:
+//   loader    h_0 = the nine-term encoder sum (load_inputs.cc:133-179), in the order of atom_encoder_kernel, straight into the
+//             tile's LDS rows (the 55 KB table stays L2-resident);
+//   layers    the K-step schedule of pna_layer_fused_kernel, the weight stream running on across the layers (40 chunks);
+//             h' = h + relu(...) is written IN PLACE (a wave owns its sixteen rows, and every gather of the layer is behind a
+//             barrier by then), so no row of h ever goes to HBM;
+//   readout   mean pool + 80 -> 40 -> 20 -> 1 head (finalize.cc:34-52), one wave per graph of the tile, the association of
+//             pool_mlp3_kernel (even rows | odd rows, then the two halves).
+// HBM traffic per tile: 36 B of node features per row, the 6 KiB descriptor (CSR slice + out-degrees), one logit per graph.
+// Same bits as the per-layer path (atom_encoder + 4 x pna_layer_fused + pool_mlp3): same operations in the same order.
+struct PnaResidentArgs {
+    const int* node_feature;   // [N][9]
+    const float* nemb;         // [173][80]
+    const uint8_t* desc;       // pna_tile_build_kernel / pna_tile_desc_kernel
+    const uint8_t* wpk;        // feature-major weight stream, 4 layers x 10 chunks
+    const float* bias;         // [4][80]
+    const int* tile_row;       // GraphTiles::row_start
+    const int* tile_graph;     // GraphTiles::graph_start
+    const int* node_off;       // [G + 1]
+    const float *w1t, *b1, *w2t, *b2, *w3, *b3;  // head, w1 / w2 transposed ([in][out]: coalesced over the output lanes)
+    float* out;                // [G]
+    int* range_flag;
+    int* err;
+    float avg_deg;
+    float oscale[PNA_L];
+    int n_tiles;
+};
+
+__global__ __launch_bounds__(PNA_FT_WAVES * 64, 4) void pna_resident_kernel(const PnaResidentArgs a) {
+    __shared__ __attribute__((aligned(16))) char s_a[PNA_CHUNK];  // even K-steps
+    __shared__ __attribute__((aligned(16))) char s_b[PNA_CHUNK];  // odd K-steps; the readout's scratch between two tiles
+    __shared__ __attribute__((aligned(16))) float s_h[PNA_FT_ROWS * PNA_FT_STRIDE];
+    __shared__ __attribute__((aligned(16))) char s_desc[2][PNA_DESC_BYTES];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int j = lane & 15, g = lane >> 4;
+    const bool late = wave >= PNA_FT_WAVES / 2;  // the half-step offset of pna_layer_fused_kernel
+    float vmax = 0.0f;
+    int tile = blockIdx.x;
+    if (tile >= a.n_tiles) return;
+    int buf = 0;
+    pna_issue_desc(a.desc, tile, s_desc[0], wave, lane);
+    while (true) {
+        const int t0 = a.tile_row[tile];
+        int rows = a.tile_row[tile + 1] - t0;
+        if (rows > PNA_FT_ROWS) rows = PNA_FT_ROWS;
+        const int ntile = tile + gridDim.x;
+        const bool has_next = ntile < a.n_tiles;
+        pna_issue_chunk_asm(a.wpk, s_a, wave, lane);
+        if (has_next) pna_issue_desc(a.desc, ntile, s_desc[buf ^ 1], wave, lane);  // lands under this tile's first K-step at the latest
+        {   // ---- loader: h_0 rows of the tile (atom_encoder_kernel's sum, k = 0..8)
+            constexpr int off[ND_FEATURE] = {0, 119, 123, 135, 147, 157, 163, 169, 171};  // load_inputs.cc:5
+            constexpr int card[ND_FEATURE] = {119, 4, 12, 12, 10, 6, 6, 2, 2};            // host_load.cc:5
+            const float4* tab = reinterpret_cast<const float4*>(a.nemb);
+#pragma unroll 1
+            for (int it = 0; it < (PNA_FT_ROWS * PNA_C) / (PNA_FT_WAVES * 64); it++) {
+                const int item = (int)threadIdx.x + PNA_FT_WAVES * 64 * it;
+                const int row = item / PNA_C, c = item - row * PNA_C;
+                if (row < rows) {
+                    const int* nf = a.node_feature + (size_t)(t0 + row) * ND_FEATURE;
+                    int f[ND_FEATURE];
+#pragma unroll
+                    for (int k = 0; k < ND_FEATURE; k++) f[k] = nf[k];
+                    float4 w[ND_FEATURE];
+#pragma unroll
+                    for (int k = 0; k < ND_FEATURE; k++) {
+                        int fk = f[k];
+                        if (fk < 0 || fk >= card[k]) {
+                            atomicMax(a.err, ERR_NODE_FEAT);
+                            fk = 0;
+                        }
+                        w[k] = tab[(off[k] + fk) * PNA_C + c];
+                    }
+                    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                    for (int k = 0; k < ND_FEATURE; k++) { s.x += w[k].x; s.y += w[k].y; s.z += w[k].z; s.w += w[k].w; }
+                    *reinterpret_cast<float4*>(s_h + row * PNA_FT_STRIDE + 4 * c) = s;
+                }
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this tile's CSR slice, chunk 0 of layer 0
+        __syncthreads();                                  // ... and every row of h_0
+        const int r = wave * 16 + j;
+        const bool valid = r < rows;
+        const uint8_t* csrc = reinterpret_cast<const uint8_t*>(s_desc[buf]);
+        const uint16_t* crp = reinterpret_cast<const uint16_t*>(s_desc[buf] + PNA_DESC_RP);
+        const int e_base = valid ? (int)crp[r] : 0;
+        const int indeg = valid ? (int)crp[r + 1] - e_base : 0;
+        const int wmask = pna_walk_mask(indeg);
+        uint32_t srcw[4];  // the first 16 in-edges, one byte each (re-walked by every K-step of every layer)
+#pragma unroll
+        for (int w = 0; w < 4; w++) {
+            uint32_t v = 0;
+#pragma unroll
+            for (int b = 0; b < 4; b++) v |= (4 * w + b < indeg ? (uint32_t)csrc[e_base + 4 * w + b] : 0u) << (8 * b);
+            srcw[w] = v;
+        }
+        const int odeg = (int)reinterpret_cast<const uint16_t*>(s_desc[buf] + PNA_DESC_OD)[valid ? r : 0];
+        float* own = s_h + (valid ? r : 0) * PNA_FT_STRIDE + 4 * g;
+#pragma unroll 1
+        for (int l = 0; l < PNA_L; l++) {
+            const uint8_t* wl = a.wpk + (size_t)l * PNA_SPLIT_LAYER_BYTES;
+            float4_t y[PNA_NS * PNA_OT];
+#pragma unroll
+            for (int i = 0; i < PNA_NS * PNA_OT; i++) y[i] = (float4_t){0.f, 0.f, 0.f, 0.f};
+            ds_uint4_t b_hi = {0, 0, 0, 0}, b_lo = {0, 0, 0, 0};
+            if (late) pna_gather_slice(s_h, csrc, srcw, e_base, indeg, wmask, 2 * g, b_hi, b_lo, vmax);
+#pragma unroll 1
+            for (int ks = 0; ks < PNA_KS; ks += 2) {
+                pna_issue_chunk_asm(wl + (size_t)(ks + 1) * PNA_CHUNK, s_b, wave, lane);
+                if (!late) pna_gather_slice(s_h, csrc, srcw, e_base, indeg, wmask, 8 * ks + 2 * g, b_hi, b_lo, vmax);
+                pna_stream_mfma(s_a, lane, b_hi, b_lo, y);
+                if (late) pna_gather_slice(s_h, csrc, srcw, e_base, indeg, wmask, 8 * (ks + 1) + 2 * g, b_hi, b_lo, vmax);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                // chunk ks + 2 of this layer, or chunk 0 of the next one: the stream runs on across the layers
+                if (ks + 2 < PNA_KS || l + 1 < PNA_L) pna_issue_chunk_asm(wl + (size_t)(ks + 2) * PNA_CHUNK, s_a, wave, lane);
+                if (!late) pna_gather_slice(s_h, csrc, srcw, e_base, indeg, wmask, 8 * (ks + 1) + 2 * g, b_hi, b_lo, vmax);
+                pna_stream_mfma(s_b, lane, b_hi, b_lo, y);
+                if (late && ks + 2 < PNA_KS) pna_gather_slice(s_h, csrc, srcw, e_base, indeg, wmask, 8 * (ks + 2) + 2 * g, b_hi, b_lo, vmax);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+            }
+            // ---- epilogue: h' = h + relu(b + Y_0 + t Y_1 + scale Y_2) in place (node_embedding.cc:148-150,205-213).  No wave gathers
+            // any more (the layer's last barrier is behind us) and a wave writes its own sixteen rows only.
+            const float logd = logf((float)(odeg + 1));
+            const float sf_t = logd / a.avg_deg;
+            const float sf_scale = (logd == 0.0f) ? 1.0f : a.avg_deg / logd;
+            const float oscale = a.oscale[l];
+            const float* bl = a.bias + l * PNA_D + 4 * g;
+            float4 bb[PNA_OT];
+#pragma unroll
+            for (int t = 0; t < PNA_OT; t++) bb[t] = *reinterpret_cast<const float4*>(bl + 16 * t);
+#pragma unroll
+            for (int t = 0; t < PNA_OT; t++) {
+                const float4 hv = *reinterpret_cast<const float4*>(own + 16 * t);
+                const float4 hn = pna_update(hv, bb[t], y[0 * PNA_OT + t], y[1 * PNA_OT + t], y[2 * PNA_OT + t], oscale, sf_t, sf_scale);
+                if (valid) *reinterpret_cast<float4*>(own + 16 * t) = hn;
+            }
+            __syncthreads();  // h' of every row is in place
+        }
+        {   // ---- readout: one wave per graph of the tile (pool_mlp3_kernel's association)
+            const int g0 = a.tile_graph[tile], g1 = a.tile_graph[tile + 1];
+            float* s_hg = reinterpret_cast<float*>(s_b) + wave * 128;  // [0, 80) pooled row, [80, 120) first hidden layer
+            float* s_o1 = s_hg + PNA_D;
+            const int half = lane >> 5, c = lane & 31;
+            for (int gi = g0 + wave; gi < g1; gi += PNA_FT_WAVES) {
+                const int n0 = a.node_off[gi] - t0, n1 = a.node_off[gi + 1] - t0;
+                float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (c < PNA_C)
+                    for (int v = n0 + half; v < n1; v += 2) {
+                        const float4 x = *reinterpret_cast<const float4*>(s_h + v * PNA_FT_STRIDE + 4 * c);
+                        acc.x += x.x; acc.y += x.y; acc.z += x.z; acc.w += x.w;
+                    }
+                acc.x += __shfl_down(acc.x, 32, 64); acc.y += __shfl_down(acc.y, 32, 64);
+                acc.z += __shfl_down(acc.z, 32, 64); acc.w += __shfl_down(acc.w, 32, 64);
+                if (half == 0 && c < PNA_C) {
+                    const float n = (float)(n1 - n0);
+                    s_hg[4 * c + 0] = acc.x / n; s_hg[4 * c + 1] = acc.y / n;
+                    s_hg[4 * c + 2] = acc.z / n; s_hg[4 * c + 3] = acc.w / n;
+                }
+                __builtin_amdgcn_wave_barrier();
+                if (lane < 40) {
+                    float s = a.b1[lane];
+                    for (int i = 0; i < PNA_D; i++) s = __builtin_fmaf(s_hg[i], a.w1t[i * 40 + lane], s);
+                    s_o1[lane] = relu1(s);
+                }
+                __builtin_amdgcn_wave_barrier();
+                float part = 0.f;
+                if (lane < 20) {
+                    float s = a.b2[lane];
+                    for (int i = 0; i < 40; i++) s = __builtin_fmaf(s_o1[i], a.w2t[i * 20 + lane], s);
+                    part = relu1(s) * a.w3[lane];
+                }
+#pragma unroll
+                for (int d = 32; d >= 1; d >>= 1) part += __shfl_down(part, d, 64);
+                if (lane == 0) a.out[gi] = a.b3[0] + part;
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        if (!has_next) break;
+        __syncthreads();  // the readout is done with the rows and with s_b: the next tile may load
+        tile = ntile;
+        buf ^= 1;
+    }
+    if (__any(!(vmax < 6.0e4f))) {
+        if (lane == 0) atomicOr(a.range_flag, 1);
     }
 }
 
@@ -733,6 +1034,15 @@ public:
         if ((rc = upload(&d_b2_, v_b2))) return rc;
         if ((rc = upload(&d_w3_, v_w3))) return rc;
         if ((rc = upload(&d_b3_, v_b3))) return rc;
+        {   // the resident kernel's head reads w1 / w2 transposed (lane = output unit)
+            std::vector<float> w1t(80 * 40), w2t(40 * 20);
+            for (int o = 0; o < 40; o++)
+                for (int i = 0; i < 80; i++) w1t[i * 40 + o] = v_w1[o * 80 + i];
+            for (int o = 0; o < 20; o++)
+                for (int i = 0; i < 40; i++) w2t[i * 20 + o] = v_w2[o * 40 + i];
+            if ((rc = upload(&d_w1t_, w1t))) return rc;
+            if ((rc = upload(&d_w2t_, w2t))) return rc;
+        }
         ready_ = true;
         return 0;
     }
@@ -774,10 +1084,48 @@ public:
     bool use_fused(const DeviceBatch& db) const {
         return fused_ && !qmode_ && split_ && !exact_ && db.gtiles.ok && db.gtiles.n_tiles > 0 && db.gtiles.fill >= 0.4;
     }
+    // the graph-resident kernel: every layer's h stays in LDS, nothing per node is written (flowgnn_get_h repeats the pass per layer)
+    bool use_resident(const DeviceBatch& db) const { return resident_ && !keep_h_ && use_fused(db); }
+    // pna_tile_build=0 keeps the index build + pna_tile_desc_kernel in front of the resident kernel
+    bool needs_csr(const DeviceBatch& db) const override { return !(tile_build_ && use_resident(db)); }
+    void set_keep_h(bool on) override { keep_h_ = on; }
+
+    int forward_resident(DeviceBatch& db, Profiler& prof, hipStream_t s) {
+        if (int rc = desc_.reserve(((size_t)db.gtiles.n_tiles * PNA_DESC_BYTES + 3) / 4)) return rc;
+        if (tile_build_) {  // two launches per step: descriptors from the caller's arrays, then everything else (no CSR in HBM)
+            ProfScope p(prof, "pna_tile_build", s);
+            pna_tile_build_kernel<<<db.gtiles.n_tiles, 256, 0, s>>>(db.b, db.gtiles.row_start, db.gtiles.graph_start, db.gtiles.n_tiles,
+                                                                   reinterpret_cast<uint8_t*>(desc_.p), db.csr.err);
+        } else {
+            ProfScope p(prof, "pna_tile_desc", s);
+            pna_tile_desc_kernel<<<db.gtiles.n_tiles, 256, 0, s>>>(db.csr.row_ptr, db.csr.src, db.csr.out_deg, db.gtiles.row_start,
+                                                                  reinterpret_cast<uint8_t*>(desc_.p), db.gtiles.n_tiles);
+        }
+        PnaResidentArgs a;
+        a.node_feature = db.b.node_feature; a.nemb = d_nemb_; a.desc = reinterpret_cast<const uint8_t*>(desc_.p);
+        a.wpk = d_stream_; a.bias = d_cb_;
+        a.tile_row = db.gtiles.row_start; a.tile_graph = db.gtiles.graph_start; a.node_off = db.b.node_off;
+        a.w1t = d_w1t_; a.b1 = d_b1_; a.w2t = d_w2t_; a.b2 = d_b2_; a.w3 = d_w3_; a.b3 = d_b3_;
+        a.out = db.out; a.range_flag = db.range_flag; a.err = db.csr.err;
+        a.avg_deg = avg_deg_;
+        for (int l = 0; l < PNA_L; l++) a.oscale[l] = oscale_[l];
+        a.n_tiles = db.gtiles.n_tiles;
+        const int grid = db.gtiles.n_tiles < 256 ? db.gtiles.n_tiles : 256;  // persistent: one 16-wave workgroup per CU
+        {
+            ProfScope p(prof, "pna_resident", s);
+            pna_resident_kernel<<<grid, PNA_FT_WAVES * 64, 0, s>>>(a);
+        }
+        db.final_h = 0;
+        db.h_valid = false;  // no per-node tensor leaves the kernel: flowgnn_get_h repeats the pass on the per-layer kernels
+        return 0;
+    }
+
     int forward(DeviceBatch& db, Profiler& prof, hipStream_t s) override {
         const int n = db.b.n_tot;
         if (n <= 0) return 0;
         if (qmode_) return pnaq_forward(q_, db, prof, s);
+        db.h_valid = true;
+        if (use_resident(db)) return forward_resident(db, prof, s);
         {
             ProfScope p(prof, "atom_encoder", s);
             atom_encoder_kernel<PNA_D><<<atom_encoder_grid(n, PNA_C), 512, 0, s>>>(db.b.node_feature, d_nemb_,
@@ -792,7 +1140,7 @@ public:
                 const int grid = db.gtiles.n_tiles < 256 ? db.gtiles.n_tiles : 256;  // persistent: one 16-wave workgroup per CU (151 KB of LDS)
                 if (l == 0) {  // the tiles' CSR slices as the layer kernel stages them, once for the four layers
                     if (int rc = desc_.reserve(((size_t)db.gtiles.n_tiles * PNA_DESC_BYTES + 3) / 4)) return rc;
-                    pna_tile_desc_kernel<<<db.gtiles.n_tiles, 256, 0, s>>>(db.csr.row_ptr, db.csr.src, db.gtiles.row_start,
+                    pna_tile_desc_kernel<<<db.gtiles.n_tiles, 256, 0, s>>>(db.csr.row_ptr, db.csr.src, db.csr.out_deg, db.gtiles.row_start,
                                                                           reinterpret_cast<uint8_t*>(desc_.p), db.gtiles.n_tiles);
                 }
                 pna_layer_fused_kernel<<<grid, PNA_FT_WAVES * 64, 0, s>>>(db.h[cur], db.h[cur ^ 1], reinterpret_cast<const uint8_t*>(desc_.p), db.csr.out_deg,
@@ -835,6 +1183,8 @@ public:
         tile_slack_ = o.i("tile_slack") >= 0 ? o.i("tile_slack") : kTileSlack;
         split_ = o.i("pna_mfma") != 32;
         fused_ = o.on("pna_fused");
+        resident_ = o.on("pna_resident");
+        tile_build_ = o.on("pna_tile_build");
         ablate_ = FG_ABLATE(o.i("pna_ablate"));
     }
     void set_exact(bool on) override { exact_ = on; }
@@ -884,7 +1234,7 @@ private:
     void free_all() {
         if (d_prof_) { (void)hipFree(d_prof_); d_prof_ = nullptr; }
 
-        float** ptrs[] = {&d_nemb_, &d_wf_, &d_cb_, &d_w1_, &d_b1_, &d_w2_, &d_b2_, &d_w3_, &d_b3_};
+        float** ptrs[] = {&d_nemb_, &d_wf_, &d_cb_, &d_w1_, &d_b1_, &d_w2_, &d_b2_, &d_w3_, &d_b3_, &d_w1t_, &d_w2t_};
         for (auto p : ptrs)
             if (*p) { (void)hipFree(*p); *p = nullptr; }
         if (d_split_) { (void)hipFree(d_split_); d_split_ = nullptr; }
@@ -905,13 +1255,15 @@ private:
     // pna_fused=0 keeps aggregation and dense update as two kernels per layer (A/B measurements, the aggregation roofline probe)
     int ablate_ = 0;  // development aid (-DFLOWGNN_DEV builds only, option pna_ablate): per-phase timing (scripts/dev/pna_ablate.sh)
     bool fused_ = true;
+    // pna_resident=0 keeps one launch per layer (encoder, four fused layers, readout) with h through HBM
+    bool resident_ = true, tile_build_ = true, keep_h_ = false;
     bool exact_ = false;
     uint8_t* d_split_ = nullptr;
     uint8_t* d_stream_ = nullptr;  // feature-major weight stream of the fused layer kernel
     float oscale_[PNA_L] = {1.f, 1.f, 1.f, 1.f};
     float avg_deg_ = 1.0f;
     float *d_nemb_ = nullptr, *d_wf_ = nullptr, *d_cb_ = nullptr, *d_w1_ = nullptr, *d_b1_ = nullptr, *d_w2_ = nullptr,
-          *d_b2_ = nullptr, *d_w3_ = nullptr, *d_b3_ = nullptr;
+          *d_b2_ = nullptr, *d_w3_ = nullptr, *d_b3_ = nullptr, *d_w1t_ = nullptr, *d_w2t_ = nullptr;
 };
 
 Model* make_pna_model() { return new PnaModel(); }

@@ -1,5 +1,7 @@
 """A/B of two builds of the library on ONE box (boxes differ by 1-2 %, so two gpurun calls cannot separate small changes).
-usage: ab.py MODEL graphs libA.so libB.so [rounds] [key=value ...]   (each measurement in its own process, A and B alternating)
+usage: ab.py MODEL graphs libA.so libB.so [rounds] [key=value | A:key=value | B:key=value ...]
+       (each measurement in its own process, A and B alternating; an A: / B: prefix gives the option to that side only, so the same
+       library can be compared with itself under two option sets: ab.py PNA 32768 lib.so lib.so 3 B:pna_resident=0)
 Make the B build with:  make -C flowgnn_amd/csrc LIB=../../scripts/dev/_b.so HOST=  (after `rm *.o`), *.so is git-ignored."""
 import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -33,5 +35,6 @@ rest = sys.argv[5:]
 rounds = int(rest.pop(0)) if rest and rest[0].isdigit() else 3
 for r in range(rounds):
     for name, lib in (("A", la), ("B", lb)):
-        out = subprocess.run([sys.executable, "-c", CHILD, model, g, os.path.abspath(lib)] + rest, capture_output=True, text=True)
+        mine = [a[2:] if a[:2] == name + ":" else a for a in rest if a[:2] in (name + ":",) or a[1:2] != ":"]
+        out = subprocess.run([sys.executable, "-c", CHILD, model, g, os.path.abspath(lib)] + mine, capture_output=True, text=True)
         print(name, out.stdout.strip() or out.stderr.strip()[-400:], flush=True)

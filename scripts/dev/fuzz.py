@@ -48,12 +48,12 @@ def rand_graph(rng):
 
 
 VARIANTS = {
-    "GIN": [{"gin_tile_build": 1}, {"gin_tile_build": 0}, {"gin_pingpong": 1, "gin_tile_build": 0}, {"gin_pingpong": 2, "gin_tile_build": 0}, {"gin_resident": 0},
+    "GIN": [{"gin_tile_build": 1}, {"gin_tile_build": 0}, {"gin_resident": 0},
             {"gin_resident": 0, "gin_unfused": 1}, {"gin_fold_readout": 0}, {"gin_head_fold": 0}, {"gin_resident_min_fill": 0}, {"hipgraph": 0}],
     "GIN-VN": [{"gin_tile_build": 1}, {"gin_tile_build": 0}, {"gin_resident": 0}, {"gin_resident": 0, "gin_unfused": 1}, {"gin_resident_min_fill": 0}],
     "GCN": [{"gcn_resident": 0}, {"gcn_resident": 0, "gcn_unfused": 1}, {"hipgraph": 0}, {"gcn_tile_build": 0}],
     "GAT": [{"gat_resident": 0}, {"gat_fold_readout": 0}, {"hipgraph": 0}],
-    "PNA": [{"pna_fused": 0}, {"hipgraph": 0}],
+    "PNA": [{"pna_fused": 0}, {"pna_resident": 0}, {"pna_tile_build": 0}, {"hipgraph": 0}],
     "DGN": [{"dgn_fused": 0}, {"dgn_mfma_agg": 0}, {"dgn_mfma_agg": 1}, {"dgn_mfma_agg": 1, "dgn_rowinfo_direct": 0}, {"dgn_mfma_agg": 1, "dgn_fold_readout": 0}],
 }[model]
 

@@ -1,6 +1,8 @@
 #!/bin/bash
 # variant.sh NAME FILE.hip "-DFLAG=1 ..."  -> scripts/dev/_NAME.so: the shipped objects with FILE.hip recompiled under the extra flags
 # (for scripts/dev/ab.py; *.so is git-ignored).  Run from the repo root after `make -C flowgnn_amd/csrc`.
+# The walks' timing variants (csrc/dev/walk_timing_variants.h: GR_CONFLICT_FREE_WALK, GR_ONE_CODE_WALK, GCN_CF_ROWS, GCN_CF_CODES) and the
+# ping-pong kernel live behind -DFLOWGNN_DEV: pass it with them, e.g. variant.sh cf gcn.hip "-DFLOWGNN_DEV -DGCN_CF_ROWS".
 set -e
 name=$1; file=$2; flags=$3
 src=flowgnn_amd/csrc

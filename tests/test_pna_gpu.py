@@ -77,6 +77,60 @@ def test_hep10k_size_properties(eng, oracle, w):
     assert_close(out, want, oracle_scale(hd), what="all 10 000 graphs")
 
 
+def test_resident_kernel_is_the_per_layer_path_bit_for_bit(eng, w):
+    """pna_resident_kernel (encoder + four layers + readout of a tile of whole graphs in one launch, h in LDS throughout) performs the
+    operations of atom_encoder + 4 x pna_layer_fused + pool_mlp3 in the same order: the same bits, on full kNN tiles, on ragged
+    molecule tiles (rows with 0..4 in-edges, the sentinel min / max) and on a batch that ends inside a tile."""
+    per_layer = Engine("PNA", device=0, options={"pna_resident": 0})
+    per_layer.set_weights(w)
+    try:
+        for b in (gp.synth_hep10k_batch(700, seed=77, with_eigen=False), gp.synth_molhiv_batch(3000, seed=78),
+                  gp.synth_hep10k_batch(3, seed=79, with_eigen=False)):
+            got, want = eng.forward(b), per_layer.forward(b)
+            assert np.isfinite(got).all()
+            assert np.array_equal(got, want), np.abs(got - want).max()
+            # flowgnn_get_h after a resident run repeats the pass per layer and returns the same rows
+            assert np.array_equal(eng.final_h(), per_layer.final_h())
+    finally:
+        per_layer.close()
+
+
+def test_tile_build_from_the_edge_list_is_the_csr_path_bit_for_bit(eng, oracle, w):
+    """pna_tile_build_kernel (descriptors straight from the caller's edge list: adjacency bit matrix per tile, no sort, no CSR in HBM)
+    against launch_build_csr + pna_tile_desc_kernel: the same logits bit for bit -- with duplicate edges (up to 40 copies of one edge),
+    self loops, rows of in-degree 0 and > 16, graphs of one node, and a tile that ends the batch."""
+    rng = np.random.default_rng(5)
+    hep = gp.synth_hep10k_batch(300, seed=81, with_eigen=False)
+    eo = hep.edge_offsets()
+    for g in range(0, 300, 7):  # duplicates and self loops inside every seventh graph
+        e0, ne = int(eo[g]), int(eo[g + 1] - eo[g])
+        for _ in range(12):
+            i, k = rng.integers(0, ne, 2)
+            hep.edge_list[e0 + i] = hep.edge_list[e0 + k]
+        v = int(rng.integers(0, hep.nums_of_nodes[g]))
+        hep.edge_list[e0 + int(rng.integers(0, ne))] = [v, v]
+    g = 5  # forty copies of one edge: a row with 40+ in-edges, most of them the same source
+    hep.edge_list[int(eo[g]):int(eo[g]) + 40] = hep.edge_list[int(eo[g])]
+    mol = gp.synth_molhiv_batch(500, seed=82)
+    one = gp.GraphBatch(np.array([1, 1, 2], np.int32), np.array([0, 1, 3], np.int32), np.zeros((4, 9), np.int32),
+                        np.array([[0, 0], [0, 1], [0, 1], [1, 1]], np.int32), np.zeros((4, 3), np.int32))
+    from_csr = Engine("PNA", device=0, options={"pna_tile_build": 0})
+    from_csr.set_weights(w)
+    try:
+        for b in (hep, mol, one, gp.concat_batches([one, hep.slice(0, 9), one])):
+            got, want = eng.forward(b), from_csr.forward(b)
+            assert np.isfinite(got).all()
+            assert np.array_equal(got, want), np.abs(got - want).max()
+        assert_close(eng.forward(hep), oracle.pna_forward(hep, [w], nthreads=8), oracle_scale(oracle.pna_forward(hep, [w], dump_h=True, nthreads=8)[1]))
+    finally:
+        from_csr.close()
+    bad = gp.synth_hep10k_batch(4, seed=83, with_eigen=False)
+    bad.edge_list[3] = [0, 1000]  # out of range: refused as by the index build
+    from flowgnn_amd import FlowGNNError
+    with pytest.raises(FlowGNNError):
+        eng.forward(bad)
+
+
 def test_split_range_fallback(oracle, w):
     """Same contract as GCN/GIN: pna_dense_split_kernel raises the range flag when an aggregate leaves the f16 range
     and the engine repeats the pass on pna_dense_kernel (fp32 MFMA)."""
