@@ -37,8 +37,13 @@ F16_MFMA_PEAK_TF = 2500.0   # MI355X_MICROARCH.md: dense f16/bf16 MFMA peak (mea
 FPGA_U50_GRAPHS_PER_S = 20214.0  # GIN molhiv on Alveo U50 (other hardware; informational)
 
 
-def GIN_RESIDENT_BYTES(n, e):  # what gin_resident_kernel reads from HBM per launch (see the GIN entry below)
-    return n * 4 + (n // 256 + 1) * 3584
+def GIN_RESIDENT_BYTES(n, e, tiles=None):  # what gin_resident_kernel reads from HBM per launch (see the GIN entry below)
+    return n * 4 + (tiles if tiles else n // 256 + 1) * 3584
+
+
+# rows of a graph tile of each model's resident kernel: with the engine's tile fill of the batch (flowgnn_graph_tile_fill) that gives the
+# number of tiles the batch really packs to -- what the per-tile descriptors in the `moved_bytes` formulas are counted by
+TILE_ROWS = {"GIN": 256, "GIN-VN": 256, "GCN": 192, "PNA": 256, "DGN": 128}
 
 
 # Per-model bench table.  Algorithmic work per launch of the two kernel classes (DESIGN.md "Kernels"):
@@ -53,6 +58,7 @@ MODELS = {
                 # 16-bit words, row offsets); the encoder / edge tables and the weight stream are L2-resident; it writes 4 B per graph;
                 # its bound is the f16 matrix pipe (5 layers x 3 x 80 000 flop per node)
                 fused_bytes={"gin_layer_fused": lambda n, e: n * 400 * 2 + n * 4 + e * 5, "gin_resident": GIN_RESIDENT_BYTES},
+                moved_bytes={"gin_resident": lambda n, e, t: GIN_RESIDENT_BYTES(n, e, t)},
                 layers_per_launch={"gin_resident": 5}, mfma_bound_kernels=("gin_resident",),
                 # dense layers' worth of products one launch EXECUTES: the single-task readout is folded through the last layer's
                 # second linear layer (never computed), so 4.5 of the 5 layers count
@@ -62,6 +68,7 @@ MODELS = {
     "GIN-VN": dict(metric="graphs/sec on ogbg-molhiv (GIN-VN, dim=100)", dataset="molhiv-vn", graphs=1 << 18,
                    agg_bytes=lambda n, e: n * 400 * 2 + e * 20, flops=lambda n, e: n * 80000,
                    fused_bytes={"gin_layer_fused": lambda n, e: n * 400 * 2 + n * 4 + e * 5, "gin_resident": GIN_RESIDENT_BYTES},
+                   moved_bytes={"gin_resident": lambda n, e, t: GIN_RESIDENT_BYTES(n, e, t)},
                    layers_per_launch={"gin_resident": 5}, mfma_bound_kernels=("gin_resident",), dense_layers_per_launch={"gin_resident": 4.5},
                    hbm_kernels=("gin_aggregate",), mfma_kernels=("gin_resident", "gin_layer_fused", "gin_mlp"),
                    workload="GIN-VN dim=100 (virtual node per graph), ogbg-molhiv-shaped graphs"),
@@ -75,7 +82,7 @@ MODELS = {
                 # and the weight stream are L2-resident
                 fused_bytes={"gcn_layer_fused": lambda n, e: n * 400 * 2 + n * 8 + e * 9, "gcn_dense": lambda n, e: n * 400 * 2,
                              "gcn_resident": lambda n, e: 4 * (n * 400 * 2 + n * 8 + e * 9) + (n * 400 + n * 8 + e * 9)},
-                moved_bytes={"gcn_resident": lambda n, e: (n // 192 + 1) * 3584},
+                moved_bytes={"gcn_resident": lambda n, e, t: t * 3584},
                 layers_per_launch={"gcn_resident": 4},
                 hbm_kernels=("gcn_aggregate",), mfma_kernels=("gcn_resident", "gcn_layer_fused", "gcn_dense"),
                 workload="GCN dim=100, batched ogbg-molpcba-shaped graphs on MI355X (BASELINE configs[2])"),
@@ -84,25 +91,31 @@ MODELS = {
                 # the graph-resident kernel runs all five layers in one launch: priced on five times the per-layer figure (what it
                 # really moves is 36 B of features per node + the CSR: roofline.hbm_bytes_moved)
                 hbm_kernels=("gat_resident", "gat_layer"), mfma_kernels=(), layers_per_launch={"gat_resident": 5},
-                moved_bytes={"gat_resident": lambda n, e: n * (36 + 4) + e * 4},
+                moved_bytes={"gat_resident": lambda n, e, t: n * (36 + 4) + e * 4},
                 workload="GAT 5-layer, 4 heads x 16, ogbg-molhiv-shaped graphs on MI355X (BASELINE configs[3])"),
-    "PNA": dict(metric="graphs/sec on hep10k (PNA, dim=80)", dataset="hep10k", graphs=1 << 15,
+    "PNA": dict(metric="graphs/sec on hep10k (PNA, dim=80)", dataset="hep10k", graphs=1 << 16,
                 agg_bytes=lambda n, e: n * 320 + n * 320 * 4 + e * 8, flops=lambda n, e: n * 153600,
                 # unfused split dense: read 4 aggregates + h, write h'; fused layer: read h (tile rows) + CSR, write h'
                 # graph-resident kernel (encoder + four layers + readout in one launch): four layers of products; what it moves is 36 B of
                 # node features + 4 B of out-degree per node and one 5 632-byte CSR descriptor per 256-row tile
                 fused_bytes={"pna_dense": lambda n, e: n * (1280 + 320 + 320), "pna_layer_fused": lambda n, e: n * (320 + 320 + 4) + e * 4,
                              "pna_resident": lambda n, e: 4 * (n * (320 + 320 + 4) + e * 4)},
-                moved_bytes={"pna_resident": lambda n, e: n * 40 + (n // 245 + 1) * 5632},
+                moved_bytes={"pna_resident": lambda n, e, t: n * 36 + t * 6144},
                 layers_per_launch={"pna_resident": 4},
                 mfma_bound_kernels=("pna_layer_fused", "pna_resident"),
                 hbm_kernels=("pna_aggregate",), mfma_kernels=("pna_resident", "pna_layer_fused", "pna_dense"),
                 workload="PNA dim=80, hep10k-shaped kNN graphs on MI355X (BASELINE configs[4])"),
-    "DGN": dict(metric="graphs/sec on hep10k (DGN, dim=100)", dataset="hep10k", graphs=1 << 15,
+    "DGN": dict(metric="graphs/sec on hep10k (DGN, dim=100)", dataset="hep10k", graphs=1 << 16,
                 agg_bytes=lambda n, e: n * 400 * 3 + e * 12, flops=lambda n, e: n * 40000,
                 # unfused split dense: read both aggregates + h, write h'; fused layer: read h (tile rows) + CSR + eigenvector, write h'
-                fused_bytes={"dgn_dense": lambda n, e: n * (800 + 400 + 400), "dgn_layer_fused": lambda n, e: n * (400 + 300 + 44)},  # rows in, rows out (average of 4 launches: the last one writes none, dgn_fold_readout), 32 B of stored in-edge pass + eigenvector entry + out-degree per row
-                hbm_kernels=("dgn_aggregate",), mfma_kernels=("dgn_layer_fused", "dgn_dense"),
+                # graph-resident kernel (encoder + four layers + readout in one launch): four layers of products; what it moves is the
+                # 48-byte record per row that dgn_tile_build writes (adjacency mask, wsum, abssum, degrees, eig1, encoder rows)
+                fused_bytes={"dgn_dense": lambda n, e: n * (800 + 400 + 400), "dgn_layer_fused": lambda n, e: n * (400 + 300 + 44),  # rows in, rows out (average of 4 launches: the last one writes none, dgn_fold_readout), 32 B of stored in-edge pass + eigenvector entry + out-degree per row
+                             "dgn_resident": lambda n, e: 4 * n * (400 + 400 + 44)},
+                moved_bytes={"dgn_resident": lambda n, e, t: t * 6144},
+                layers_per_launch={"dgn_resident": 4},
+                mfma_bound_kernels=("dgn_resident",),
+                hbm_kernels=("dgn_aggregate",), mfma_kernels=("dgn_resident", "dgn_layer_fused", "dgn_dense"),
                 workload="DGN dim=100, hep10k-shaped kNN graphs on MI355X (BASELINE configs[4])"),
 }
 
@@ -195,7 +208,7 @@ def parity_record(model, got, want, numeric="f32"):
             "ok": bool((err <= bound).all() and np.isfinite(got).all())}
 
 
-def rooflines(model, M, prof, kern, G, N, E, steps, split, qmode):
+def rooflines(model, M, prof, kern, G, N, E, steps, split, qmode, tiles=None):
     """(roofline of the dominant kernel, roofline of the stand-alone aggregation kernel) from the HIP-event profile of the timed
     region: algorithmic bytes / flops per launch over the kernel's average launch duration."""
     agg_bytes, mlp_flops = M["agg_bytes"](N, E), M["flops"](N, E)
@@ -226,7 +239,7 @@ def rooflines(model, M, prof, kern, G, N, E, steps, split, qmode):
         obj = {"kernel": name, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                "frac": ach / HBM_PEAK_GBS, "traffic": traffic_of(name), "avg_ms": kern[name], "bytes_per_launch": nbytes}
         if name in M.get("moved_bytes", {}):
-            obj["hbm_bytes_moved"] = M["moved_bytes"][name](N, E)
+            obj["hbm_bytes_moved"] = M["moved_bytes"][name](N, E, tiles or N // TILE_ROWS.get(model, 256) + 1)
         lim = issue_limits(model, name)
         if lim is not None:
             obj["issue_limit"] = lim
@@ -263,12 +276,14 @@ def rooflines(model, M, prof, kern, G, N, E, steps, split, qmode):
                     "frac": ach / HBM_PEAK_GBS, "traffic": traffic_of(dominant), "avg_ms": kern[dominant],
                     "bytes_per_launch": fb, "mfma": mfma}
             if dominant in M.get("moved_bytes", {}):
-                roof["hbm_bytes_moved"] = M["moved_bytes"][dominant](N, E)
+                roof["hbm_bytes_moved"] = M["moved_bytes"][dominant](N, E, tiles or N // TILE_ROWS.get(model, 256) + 1)
         else:
             roof = dict({"kernel": dominant, "traffic": traffic_of(dominant), "avg_ms": kern[dominant],
                          "launches_per_step": launches_per_step}, **mfma)
             if fbf is not None:
                 roof["hbm_bytes_per_launch"] = fbf(N, E)
+            if dominant in M.get("moved_bytes", {}):
+                roof["hbm_bytes_moved"] = M["moved_bytes"][dominant](N, E, tiles or N // TILE_ROWS.get(model, 256) + 1)
         tag(roof)
         lim = issue_limits(model, dominant)
         if lim is not None:
@@ -290,6 +305,18 @@ def issue_limits(model, kernel):
         return None
 
 
+def tile_count(eng, model, batch):
+    """Graph tiles the engine packs this batch into (from its own fill figure; None for a model without resident tiles)."""
+    rows = TILE_ROWS.get(model)
+    if not rows or batch.num_graphs == 0:
+        return None
+    try:
+        fill = eng.graph_tile_fill(batch.nums_of_nodes, batch.nums_of_edges)
+    except Exception:
+        return None
+    return int(np.ceil(batch.total_nodes / (fill * rows))) + 1 if fill > 0 else None
+
+
 def measure_config(model, batch, steps, warmup, device, sample_graphs=512):
     """One of the non-headline configurations in the same process.  `value` / `ms_per_step` come from `steps` runs of the resident
     batch bracketed by stream syncs with NO profiling (what a caller gets: dataset-sized batches replay a hipGraph, which HIP events
@@ -305,6 +332,7 @@ def measure_config(model, batch, steps, warmup, device, sample_graphs=512):
     try:
         eng.set_weights(w)
         eng.set_batch(batch)
+        tiles = tile_count(eng, model, batch)
         for _ in range(warmup):
             eng.run()
         eng.sync()
@@ -324,7 +352,7 @@ def measure_config(model, batch, steps, warmup, device, sample_graphs=512):
         out = eng.results()
         reruns = eng.exact_reruns()
         try:
-            agg_ms = eng.aggregation_only_ms(layer=0, iters=5)
+            agg_ms = eng.aggregation_only_ms(layer=0, iters=10)
         except Exception:  # a model without a stand-alone aggregation kernel (GAT: the layer IS the aggregation)
             agg_ms = None
     finally:
@@ -334,7 +362,7 @@ def measure_config(model, batch, steps, warmup, device, sample_graphs=512):
     agg_name = next((k for k in M["hbm_kernels"] if k in kern), M["hbm_kernels"][0])
     if agg_ms is not None and agg_name not in kern:
         kern[agg_name] = agg_ms
-    roof, agg = rooflines(model, M, prof, kern, G, N, E, steps, True, False)
+    roof, agg = rooflines(model, M, prof, kern, G, N, E, steps, True, False, tiles)
     n = min(G, sample_graphs)
     want = np.asarray(oracle_forward(model, batch.slice(0, n), w, effective_cpus()), np.float32)
     par = parity_record(model, out[:n], want)
@@ -611,7 +639,7 @@ def main():
 
         # the dense updates of every model run as three f16 MFMAs per fp32 product unless option <m>_mfma = 32 ("f32")
         split = eng.get_option({"GIN-VN": "gin"}.get(args.model, args.model.lower()) + "_mfma") != 32
-        roof, agg = rooflines(args.model, M, prof, kern, G, N, E, args.steps, split, qmode)
+        roof, agg = rooflines(args.model, M, prof, kern, G, N, E, args.steps, split, qmode, tile_count(eng, args.model, batch))
         par = f"batch-sharded x{world}, RCCL all-gather of logits" if world > 1 else "single GPU"
         if collectives and world == 1:
             par = "single GPU, the N > 1 code path forced (RCCL group of one rank: barriers, per-step all-gather, max over ranks)"
@@ -674,9 +702,13 @@ def main():
             cfgs["GIN-VN"] = measure_config("GIN-VN", gp.add_virtual_nodes(mol), csteps, cwarm, local_rank)
             del mol
             cfgs["GCN"] = measure_config("GCN", make_batch("molpcba", MODELS["GCN"]["graphs"], 1234), csteps, cwarm, local_rank)
-            hep = make_batch("hep10k", MODELS["PNA"]["graphs"], 1234)
+            hep = make_batch("hep10k", MODELS["PNA"]["graphs"], 1234)  # SURVEY 8(d)'s 2^16: every [N][D] fp32 tensor >= 1 GB
             cfgs["PNA"] = measure_config("PNA", hep, csteps, cwarm, local_rank)
             cfgs["DGN"] = measure_config("DGN", hep, csteps, cwarm, local_rank)
+            half = hep.slice(0, 1 << 15)  # ... and half of it once, beside: how much of the stand-alone aggregation probe's rate is the
+            del hep                       # 256 MiB Infinity Cache (the resident kernels keep h on chip: their rate should not move)
+            cfgs["PNA@32768"] = measure_config("PNA", half, csteps, cwarm, local_rank)
+            cfgs["DGN@32768"] = measure_config("DGN", half, csteps, cwarm, local_rank)
             line["configs"] = cfgs
             parity_ok = parity_ok and all(c["parity_ok"] for c in cfgs.values())
         os.write(json_fd, (json.dumps(line) + "\n").encode())

@@ -380,6 +380,7 @@ __global__ __launch_bounds__(512, 2) void dgn_layer_fused_kernel(const float* __
 // the fp32 rows are not kept on chip.
 constexpr int DGN_HT_STRIDE = 136;                           // f16 per feature row of s_ht (128 sources + 8: 68 banks, conflict-free)
 constexpr int DGN_HT_BYTES = DGN_D * DGN_HT_STRIDE * 2;      // 27 200 per half (hi | lo)
+constexpr int DGN_REC_DW = 12;  // words of a row's record for dgn_resident_kernel: [0..3] mask per lane group, wsum, abssum, ndup, outdeg, eig1, 9 table rows as bytes
 
 // INFO: what a row's in-edge pass produces -- this lane's adjacency mask, wsum, abssum, the duplicate count -- depends on the graph and
 // the eigenvector only, not on the layer: the first layer's launch (INFO 1) stores it, 32 B per row, the later ones (INFO 2) load it
@@ -794,6 +795,10 @@ __global__ __launch_bounds__(512, 2) void dgn_layer_mfma_kernel(const float* __r
 // rowinfo is bit-identical to what INFO = 1 stores.  Rows with duplicate in-edges (multiplicity is not in the mask) count the
 // copies by a scan over the tile's edges -- rare -- and raise *dup_flag: the launching model then also builds the CSR (on the
 // device's say-so: launch_build_csr(..., only_if)), because the layer kernels' correction walk for duplicates reads it.
+// REC (the graph-resident kernel's tile build): the row's record is 12 words -- the eight above, eig1[v], and the nine encoder
+// table rows offset_k + feature_k (validated as atom_encoder_kernel validates them) as bytes: everything dgn_resident_kernel reads
+// per row.  Duplicate edges need no CSR there (that kernel re-sums such rows from the caller's edge list): dup_flag is not raised.
+template <bool REC>
 __global__ __launch_bounds__(256) void dgn_rowinfo_kernel(BatchView b, const int* __restrict__ tile_row, const int* __restrict__ tile_graph,
                                                           int n_tiles, const float* __restrict__ eig4, uint32_t* __restrict__ rowinfo,
                                                           int* __restrict__ out_deg, int* __restrict__ err, int* __restrict__ dup_flag) {
@@ -860,7 +865,7 @@ __global__ __launch_bounds__(256) void dgn_rowinfo_kernel(BatchView b, const int
             }
         }
         // this lane group's byte of every 32-source block: bit 8 s + e <-> source 32 s + 8 g + e (dgn_layer_mfma_kernel)
-        uint32_t* ri = rowinfo + (size_t)(t0 + v) * 8;
+        uint32_t* ri = rowinfo + (size_t)(t0 + v) * (REC ? DGN_REC_DW : 8);
 #pragma unroll
         for (int gq = 0; gq < 4; gq++) {
             uint32_t wg = 0;
@@ -871,8 +876,23 @@ __global__ __launch_bounds__(256) void dgn_rowinfo_kernel(BatchView b, const int
         // (the out-degree rides in the record's fourth word: the layers read it a tile ahead with the rest instead of loading out_deg[node]
         // at the top of the tile, where its round trip stood in front of the row's 1 / deg)
         *reinterpret_cast<uint4*>(ri + 4) = make_uint4(__builtin_bit_cast(uint32_t, wsum), __builtin_bit_cast(uint32_t, abssum), (uint32_t)nd, (uint32_t)s_odeg[v]);
-        out_deg[t0 + v] = s_odeg[v];
-        if (nd > 0) atomicOr(dup_flag, 1);
+        if constexpr (REC) {
+            uint32_t fw[3] = {0u, 0u, 0u};
+            const int* nf = b.node_feature + (size_t)(t0 + v) * ND_FEATURE;
+#pragma unroll
+            for (int k = 0; k < ND_FEATURE; k++) {
+                int f = nf[k];
+                if (f < 0 || f >= c_nd_card[k]) {
+                    atomicMax(err, ERR_NODE_FEAT);
+                    f = 0;
+                }
+                fw[k >> 2] |= (uint32_t)(c_nd_off[k] + f) << (8 * (k & 3));
+            }
+            *reinterpret_cast<uint4*>(ri + 8) = make_uint4(__builtin_bit_cast(uint32_t, eig_v), fw[0], fw[1], fw[2]);
+        } else {
+            out_deg[t0 + v] = s_odeg[v];
+            if (nd > 0) atomicOr(dup_flag, 1);
+        }
     }
 }
 
@@ -929,6 +949,355 @@ __global__ __launch_bounds__(256) void dgn_pool_part_mlp3_kernel(const float* __
         for (int d = 32; d >= 1; d >>= 1) p += __shfl_down(p, d, 64);
         if (lane == 0) out[gph] = bias3 + p;
         __builtin_amdgcn_wave_barrier();  // s_hg / s_o1 are rewritten for the wave's next graph
+    }
+}
+
+// ---------------------------------------------------------------- graph-resident DGN: load_graph to the logit without leaving the chip
+// The FPGA holds one graph on chip from load_graph to the logit (DGN/src/DGN_compute.cc:44-104).  Here a persistent 8-wave workgroup
+// (one per CU) holds a tile of WHOLE graphs (GraphTiles: <= 128 rows) across the encoder, all four layers and the readout:
+//   tile build   dgn_tile_build_kernel (the launch in front): per row a 48-byte record from the caller's arrays -- adjacency mask,
+//                wsum, abssum, duplicate count, out-degree (as dgn_rowinfo_kernel), eig1 and the nine encoder table rows as bytes;
+//   loader       the tile's records come by LDS-DMA (6 KiB, requested a tile ahead); h_0 = the nine-term encoder sum
+//                (load_inputs.cc:114-172) in atom_encoder_kernel's order out of the LDS-resident table, into REGISTERS: lane (j, g)
+//                of wave w keeps features 16 t + 4 g .. + 3 (t < 7) of row 16 w + j in fp32 for the whole tile -- the accumulator layout
+//                of the dense update, so the self term h[v] of a K-step and the residual never touch memory;
+//   layers       the matrix-pipe aggregation of dgn_layer_mfma_kernel over the transposed f16-split rows s_ht (rebuilt from the
+//                registers between layers, in place) with the adjacency operands built ONCE per tile; the dense update's weights
+//                do not fit beside the encoder table (100 KB per layer), so they stream through two 14 KiB LDS slots, one K-step's
+//                fragments each, across the 28 K-steps of the tile: one barrier per K-step (vmcnt(0) + s_barrier, then the request
+//                for the next chunk).  (Waves 4..7 passing that barrier between their aggregation and their dense half -- the two
+//                waves of a SIMD half a K-step apart, as in pna_layer_fused_kernel -- measured 2.23 ms against 2.17: not kept);
+//   readout      h_4 goes to LDS as fp32 rows, then one wave per graph: pool_mlp3_kernel's sum order and head (finalize.cc:28-52).
+// HBM traffic per row: the 48-byte record; per graph one logit.  Same operations in the same order as atom_encoder_kernel +
+// dgn_rowinfo + 4 x dgn_layer_mfma_kernel<2, false> + pool_mlp3_kernel on the same tiles: the same bits.  (Like that path, the
+// order of a row's in-edge sum depends on where its graph sits in the tile: toleranced under batch splits, tests/test_dgn_gpu.py.)
+// Rows with duplicate in-edges (the mask has no multiplicities) add the extra copies from the caller's edge list: slow and rare.
+constexpr int DGN_REC_TILE_BYTES = DGN_FT_ROWS * DGN_REC_DW * 4;  // 6 144: six DMA pieces
+constexpr int DGN_CHUNK = DGN_OT * 2 * 1024;                      // 14 336: the fragments of one K-step
+
+struct DgnResidentArgs {
+    const uint32_t* rec;      // [n_tot + 128][12] (dgn_tile_build_kernel<true>)
+    const float* table;       // [173][100]
+    const uint8_t* wpk;       // 4 x DGN_FT_LAYER_BYTES (dgn_pack_fused_layer)
+    const int* tile_row;      // GraphTiles::row_start
+    const int* tile_graph;    // GraphTiles::graph_start
+    BatchView b;              // node_off for the readout; the edge list for rows with duplicate in-edges
+    const float *w1t, *b1, *w2t, *b2, *w3, *b3;  // head, w1 / w2 transposed ([in][out]: coalesced over the output lanes)
+    float* out;               // [G]
+    int* range_flag;
+    int n_tiles;
+};
+
+__global__ __launch_bounds__(512, 2) void dgn_resident_kernel(const DgnResidentArgs a) {
+    constexpr int OFF_W = 2 * DGN_HT_BYTES, OFF_TAB = OFF_W + 2 * DGN_CHUNK, OFF_REC = OFF_TAB + ND_FEATURE_TOTAL * DGN_D * 4,
+                  OFF_BIAS = OFF_REC + DGN_REC_TILE_BYTES, OFF_EIG = OFF_BIAS + DGN_L * 512, LDS_TOTAL = OFF_EIG + 4 * DGN_FT_ROWS;
+    static_assert(OFF_W % 16 == 0 && OFF_TAB % 16 == 0 && OFF_REC % 16 == 0 && OFF_BIAS % 16 == 0 && OFF_EIG % 16 == 0, "alignment");
+    static_assert(LDS_TOTAL <= 160 * 1024, "LDS of one CU");
+    static_assert(DGN_FT_ROWS * DGN_D * 4 <= OFF_W, "the readout's fp32 rows take the place of s_ht");
+    __shared__ __attribute__((aligned(16))) char s_all[LDS_TOTAL];
+    uint16_t* s_ht_hi = reinterpret_cast<uint16_t*>(s_all);
+    uint16_t* s_ht_lo = reinterpret_cast<uint16_t*>(s_all + DGN_HT_BYTES);
+    char* s_w = s_all + OFF_W;
+    const float4* s_tab = reinterpret_cast<const float4*>(s_all + OFF_TAB);
+    const uint32_t* s_rec = reinterpret_cast<const uint32_t*>(s_all + OFF_REC);
+    float* s_bias = reinterpret_cast<float*>(s_all + OFF_BIAS);
+    float* s_eig = reinterpret_cast<float*>(s_all + OFF_EIG);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 15, g = lane >> 4;
+    int tile = blockIdx.x;
+    if (tile >= a.n_tiles) return;
+    auto issue_chunk = [&](int l, int k) {  // K-step k of layer l -> slot (l + k) & 1: fourteen 1 KiB pieces over eight waves
+        const uint8_t* gsrc = a.wpk + (size_t)l * DGN_FT_LAYER_BYTES + (size_t)k * DGN_CHUNK;
+        const uint32_t lb = lds_addr_of(s_w) + (uint32_t)(((l + k) & 1) * DGN_CHUNK);
+        lds_dma16(gsrc + wave * 1024, (uint32_t)lane * 16u, lb + wave * 1024);
+        if (wave < 6) lds_dma16(gsrc + (wave + 8) * 1024, (uint32_t)lane * 16u, lb + (wave + 8) * 1024);
+    };
+    auto issue_rec = [&](int t) {  // a tile's records -> s_rec: six pieces, on the waves that carry one chunk piece only and four more
+        if (wave >= 2) {
+            const int piece = 7 - wave;
+            lds_dma16(reinterpret_cast<const char*>(a.rec) + (size_t)a.tile_row[t] * (DGN_REC_DW * 4) + piece * 1024, (uint32_t)lane * 16u,
+                      lds_addr_of(s_rec) + piece * 1024);
+        }
+    };
+    issue_rec(tile);
+    // once per workgroup: the encoder table and the four layers' bias vectors (pre-scaled, 112 floats + 1 / scale each)
+    for (int i = tid; i < ND_FEATURE_TOTAL * DGN_C; i += 512)
+        reinterpret_cast<float4*>(s_all + OFF_TAB)[i] = reinterpret_cast<const float4*>(a.table)[i];
+    if (tid < DGN_L * 128) s_bias[tid] = *reinterpret_cast<const float*>(a.wpk + (size_t)(tid >> 7) * DGN_FT_LAYER_BYTES + DGN_FT_BIAS + (tid & 127) * 4);
+    const int lr = 16 * wave + j;  // this lane's row of the tile (the four lanes g of a row share it)
+    auto put_row_piece = [&](int c, const float4_t& x) {  // features 4 c .. 4 c + 3 of row lr -> the transposed split rows
+        if (c >= DGN_C) return;
+        uint32_t h01, l01, h23, l23;
+        DS_SPLIT2(x.x, x.y, h01, l01);
+        DS_SPLIT2(x.z, x.w, h23, l23);
+        uint16_t* ph = s_ht_hi + (4 * c) * DGN_HT_STRIDE + lr;
+        uint16_t* pl = s_ht_lo + (4 * c) * DGN_HT_STRIDE + lr;
+        ph[0] = (uint16_t)h01; ph[DGN_HT_STRIDE] = (uint16_t)(h01 >> 16); ph[2 * DGN_HT_STRIDE] = (uint16_t)h23; ph[3 * DGN_HT_STRIDE] = (uint16_t)(h23 >> 16);
+        pl[0] = (uint16_t)l01; pl[DGN_HT_STRIDE] = (uint16_t)(l01 >> 16); pl[2 * DGN_HT_STRIDE] = (uint16_t)l23; pl[3 * DGN_HT_STRIDE] = (uint16_t)(l23 >> 16);
+    };
+    float vmax = 0.0f;
+    while (true) {
+        const int t0 = a.tile_row[tile];
+        int rows = a.tile_row[tile + 1] - t0;
+        if (rows > DGN_FT_ROWS) rows = DGN_FT_ROWS;
+        const int ntile = tile + gridDim.x;
+        const bool has_next = ntile < a.n_tiles;
+        issue_chunk(0, 0);  // slot 0: last read in K-step 26 of the previous tile, and every wave is past that step's barrier
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this tile's records (and the chunk)
+        __syncthreads();                                  // ... of every wave; the previous tile's readout is over
+        // ---- this lane's row: the stored in-edge pass, eig1, the encoder
+        const bool valid = lr < rows;
+        const uint32_t* rc = s_rec + lr * DGN_REC_DW;
+        const uint32_t bits = valid ? rc[g] : 0u;
+        const uint4 info = *reinterpret_cast<const uint4*>(rc + 4);
+        const float wsum = valid ? __builtin_bit_cast(float, info.x) : 0.0f;
+        const float abssum = valid ? __builtin_bit_cast(float, info.y) : 0.0f;
+        const int ndup = valid ? (int)info.z : 0;
+        const int odeg = valid ? (int)info.w : 0;
+        const float eig_v = valid ? __builtin_bit_cast(float, rc[8]) : 0.0f;
+        if (g == 0) s_eig[lr] = eig_v;  // rows beyond the tile's last: zeros (never NaN under a zero mask)
+        float4_t hreg[DGN_OT];
+        {
+            const uint32_t f0 = rc[9], f1 = rc[10], f2 = rc[11];
+            int trow[ND_FEATURE];
+#pragma unroll
+            for (int k = 0; k < ND_FEATURE; k++) trow[k] = (int)(((k < 4 ? f0 : (k < 8 ? f1 : f2)) >> (8 * (k & 3))) & 0xFFu) * DGN_C;
+#pragma unroll
+            for (int t = 0; t < DGN_OT; t++) {
+                const int c = 4 * t + g;
+                const int cc = c < DGN_C ? c : 0;
+                float4 w[ND_FEATURE];
+#pragma unroll
+                for (int k = 0; k < ND_FEATURE; k++) w[k] = s_tab[(valid ? trow[k] : 0) + cc];
+                float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int k = 0; k < ND_FEATURE; k++) { s.x += w[k].x; s.y += w[k].y; s.z += w[k].z; s.w += w[k].w; }
+                const bool on = valid && c < DGN_C;
+                hreg[t] = (float4_t){on ? s.x : 0.f, on ? s.y : 0.f, on ? s.z : 0.f, on ? s.w : 0.f};
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < DGN_OT; t++) put_row_piece(4 * t + g, hreg[t]);
+        const float inv_abs = 1.0f / (abssum == 0.0f ? 1.0f / 8192.0f : abssum);  // epsilon of ap_fixed<16,3> (node_embedding.cc:125-128)
+        const float inv_dg = odeg == 0 ? 0.0f : 1.0f / (float)odeg;
+        const int ae = (int)((__builtin_bit_cast(uint32_t, abssum) >> 23) & 0xFFu) - 127;  // abssum in [2^ae, 2^(ae+1))
+        const int aec = ae < -100 ? -100 : ae;
+        const float wscale = __builtin_bit_cast(float, (uint32_t)(127 - aec) << 23);        // 2^-ae: w wscale in (-2, 2)
+        const float inv_abs_s = inv_abs * __builtin_bit_cast(float, (uint32_t)(127 + aec) << 23);  // inv_abs / wscale (exact)
+        const float wsum_s = wsum * wscale;
+        // adjacency operands of the four source blocks (dgn_layer_mfma_kernel): once per TILE here, the four layers share them
+        ds_uint4_t b_one[4], b_eh[4], b_el[4];
+        bool blk[4];
+#pragma unroll
+        for (int sb = 0; sb < 4; sb++) {
+            ds_uint4_t m;
+#pragma unroll
+            for (int pr = 0; pr < 4; pr++) {
+                const uint32_t lo16 = (uint32_t)(-(int)((bits >> (8 * sb + 2 * pr)) & 1u)) & 0xFFFFu;
+                const uint32_t hi16 = (uint32_t)(-(int)((bits >> (8 * sb + 2 * pr + 1)) & 1u)) & 0xFFFF0000u;
+                m[pr] = lo16 | hi16;
+            }
+            blk[sb] = __any(((bits >> (8 * sb)) & 0xFFu) != 0);
+            b_one[sb] = m & (ds_uint4_t){0x3C003C00u, 0x3C003C00u, 0x3C003C00u, 0x3C003C00u};
+            b_eh[sb] = (ds_uint4_t){0u, 0u, 0u, 0u};
+            b_el[sb] = b_eh[sb];
+            if (blk[sb]) {
+                float es[8];  // eig1 of sources 32 sb + 8 g .. + 7 (records of rows beyond the tile's last are never under a set bit)
+#pragma unroll
+                for (int i = 0; i < 8; i++) es[i] = __builtin_bit_cast(float, s_rec[(32 * sb + 8 * g + i) * DGN_REC_DW + 8]);
+                ds_uint4_t eh, el;
+                DS_SPLIT2((es[0] - eig_v) * wscale, (es[1] - eig_v) * wscale, eh.x, el.x);
+                DS_SPLIT2((es[2] - eig_v) * wscale, (es[3] - eig_v) * wscale, eh.y, el.y);
+                DS_SPLIT2((es[4] - eig_v) * wscale, (es[5] - eig_v) * wscale, eh.z, el.z);
+                DS_SPLIT2((es[6] - eig_v) * wscale, (es[7] - eig_v) * wscale, eh.w, el.w);
+                b_eh[sb] = m & eh;
+                b_el[sb] = m & el;
+            }
+        }
+        const bool dups = __any(ndup > 0);
+        const int g0 = a.tile_graph[tile], g1 = a.tile_graph[tile + 1];
+#pragma unroll 1
+        for (int l = 0; l < DGN_L; l++) {
+            const float oscale = s_bias[l * 128 + 112];
+            float4_t acc[DGN_OT];
+            // one K-step's barrier: this wave's pieces of the chunk have landed, then everybody's have -- and every wave is done with
+            // the other slot, which the next chunk may now overwrite.  In K-step 0 it also orders the layer's s_ht stores before its reads.
+            auto sync_step = [&](int k) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                if (k + 1 < DGN_FT_KS) issue_chunk(l, k + 1);
+                else if (l + 1 < DGN_L) issue_chunk(l + 1, 0);
+                if (l == 0 && k == 0 && has_next) issue_rec(ntile);  // every wave is done with this tile's records
+            };
+#pragma unroll
+            for (int k = 0; k < DGN_FT_KS; k++) {
+                sync_step(k);
+                if (k == 0) {
+#pragma unroll
+                    for (int t = 0; t < DGN_OT; t++) {
+                        const float4 bv = *reinterpret_cast<const float4*>(s_bias + l * 128 + 16 * t + 4 * g);
+                        acc[t] = (float4_t){bv.x, bv.y, bv.z, bv.w};
+                    }
+                }
+                // ---- aggregation of features 16 k .. 16 k + 15 on the matrix pipe (dgn_layer_mfma_kernel)
+                const bool real = k < 6 || g == 0;
+                const float4_t hv = hreg[k];
+                const int frow = k < 6 ? 16 * k + j : 96 + (j & 3);
+                const uint16_t* ah = s_ht_hi + frow * DGN_HT_STRIDE + 8 * g;
+                const uint16_t* al = s_ht_lo + frow * DGN_HT_STRIDE + 8 * g;
+                float4_t m1 = (float4_t){0.f, 0.f, 0.f, 0.f}, pp = m1;
+#pragma unroll
+                for (int sb = 0; sb < 4; sb++) {
+                    if (blk[sb]) {
+                        const ds_uint4_t fh = *reinterpret_cast<const ds_uint4_t*>(ah + 32 * sb);
+                        const ds_uint4_t fl = *reinterpret_cast<const ds_uint4_t*>(al + 32 * sb);
+                        m1 = DS_MFMA16(fh, b_one[sb], m1);
+                        pp = DS_MFMA16(fh, b_eh[sb], pp);
+                        m1 = DS_MFMA16(fl, b_one[sb], m1);
+                        pp = DS_MFMA16(fl, b_eh[sb], pp);
+                        pp = DS_MFMA16(fh, b_el[sb], pp);
+                    }
+                }
+                if (dups) {  // multiplicity > 1: the extra copies of a duplicate edge (the mask counted the first), from the caller's edge list --
+                             // every copy after a row's first (u -> v) adds the split row of u (hi + lo) once more, as dgn_layer_mfma_kernel's walk
+                             // over the CSR does (there in ascending u, here in list order: the same bits while a row repeats one source only)
+                    const bool mine = ndup > 0 && real;
+                    uint32_t seen0 = 0u, seen1 = 0u, seen2 = 0u, seen3 = 0u;
+                    for (int gph = g0; gph < g1; gph++) {
+                        const int n = a.b.nums_of_nodes[gph], base = a.b.node_off[gph] - t0, e0 = a.b.edge_off[gph], ne = a.b.edge_off[gph + 1] - e0;
+                        if (!__any(mine && lr >= base && lr < base + n)) continue;
+                        for (int e = 0; e < ne; e++) {
+                            int u = load_i32_rare(a.b.edge_list + 2 * (size_t)(e0 + e)), v = load_i32_rare(a.b.edge_list + 2 * (size_t)(e0 + e) + 1);
+                            if (!((u >= 0) & (u < n) & (v >= 0) & (v < n))) { u = 0; v = 0; }  // as the tile build: a self-loop on the graph's node 0
+                            u += base; v += base;
+                            if (mine && v == lr && u < DGN_FT_ROWS) {
+                                const uint32_t bit = 1u << (u & 31);
+                                const int wi = u >> 5;
+                                const uint32_t cur = wi == 0 ? seen0 : (wi == 1 ? seen1 : (wi == 2 ? seen2 : seen3));
+                                if (cur & bit) {
+                                    const float eu = (s_eig[u] - eig_v) * wscale;  // the copy's (scaled) weight
+#pragma unroll
+                                    for (int c = 0; c < 4; c++) {
+                                        const int f = (k < 6 ? 16 * k : 96) + 4 * g + c;
+                                        const float x = (float)__builtin_bit_cast(_Float16, s_ht_hi[f * DGN_HT_STRIDE + u]) +
+                                                        (float)__builtin_bit_cast(_Float16, s_ht_lo[f * DGN_HT_STRIDE + u]);
+                                        m1[c] += x;
+                                        pp[c] = __builtin_fmaf(x, eu, pp[c]);
+                                    }
+                                }
+                                seen0 |= wi == 0 ? bit : 0u; seen1 |= wi == 1 ? bit : 0u; seen2 |= wi == 2 ? bit : 0u; seen3 |= wi == 3 ? bit : 0u;
+                            }
+                        }
+                    }
+                }
+                // a1 = m1 / outdeg (x / 0 = 0), a2 = |(m2 - wsum h[v]) / abssum|   (node_embedding.cc:143-146); pp = m2 wscale
+                float4 a1, a2;
+                a1.x = m1.x * inv_dg; a1.y = m1.y * inv_dg; a1.z = m1.z * inv_dg; a1.w = m1.w * inv_dg;
+                a2.x = fabsf(__builtin_fmaf(-wsum_s, hv.x, pp.x) * inv_abs_s);
+                a2.y = fabsf(__builtin_fmaf(-wsum_s, hv.y, pp.y) * inv_abs_s);
+                a2.z = fabsf(__builtin_fmaf(-wsum_s, hv.z, pp.z) * inv_abs_s);
+                a2.w = fabsf(__builtin_fmaf(-wsum_s, hv.w, pp.w) * inv_abs_s);
+                if (!real || !valid) { a1 = make_float4(0.f, 0.f, 0.f, 0.f); a2 = a1; }
+                ds_uint4_t b_hi, b_lo;
+                DS_SPLIT2(a1.x, a1.y, b_hi.x, b_lo.x);
+                DS_SPLIT2(a1.z, a1.w, b_hi.y, b_lo.y);
+                DS_SPLIT2(a2.x, a2.y, b_hi.z, b_lo.z);
+                DS_SPLIT2(a2.z, a2.w, b_hi.w, b_lo.w);
+                asm("v_max3_f32 %0, |%1|, |%2|, %0" : "+v"(vmax) : "v"(a1.x), "v"(a1.y));
+                asm("v_max3_f32 %0, |%1|, |%2|, %0" : "+v"(vmax) : "v"(a1.z), "v"(a1.w));
+                asm("v_max3_f32 %0, |%1|, |%2|, %0" : "+v"(vmax) : "v"(a2.x), "v"(a2.y));
+                asm("v_max3_f32 %0, |%1|, |%2|, %0" : "+v"(vmax) : "v"(a2.z), "v"(a2.w));
+                asm volatile("" : "+v"(vmax));
+                // ---- dense update, K-step k: 21 MFMAs on the chunk in slot (l + k) & 1
+                const char* wb = s_w + ((l + k) & 1) * DGN_CHUNK;
+                ds_uint4_t ff[2][4];  // the fragments of the NEXT pair of output tiles are requested before this pair's MFMAs issue
+#pragma unroll
+                for (int i = 0; i < 4; i++) ff[0][i] = *reinterpret_cast<const ds_uint4_t*>(wb + i * 1024 + lane * 16);
+#pragma unroll
+                for (int t0_ = 0; t0_ < DGN_OT; t0_ += 2) {
+                    const int n = t0_ + 1 < DGN_OT ? 2 : 1;
+                    const int n2 = t0_ + 3 < DGN_OT ? 2 : 1;
+                    if (t0_ + 2 < DGN_OT) {
+#pragma unroll
+                        for (int i = 0; i < 2 * n2; i++) ff[((t0_ >> 1) + 1) & 1][i] = *reinterpret_cast<const ds_uint4_t*>(wb + (((t0_ + 2) * 2) + i) * 1024 + lane * 16);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    const ds_uint4_t (&f)[4] = ff[(t0_ >> 1) & 1];
+#pragma unroll
+                    for (int i = 0; i < n; i++) acc[t0_ + i] = DS_MFMA16(f[2 * i], b_hi, acc[t0_ + i]);
+#pragma unroll
+                    for (int i = 0; i < n; i++) acc[t0_ + i] = DS_MFMA16(f[2 * i], b_lo, acc[t0_ + i]);
+#pragma unroll
+                    for (int i = 0; i < n; i++) acc[t0_ + i] = DS_MFMA16(f[2 * i + 1], b_hi, acc[t0_ + i]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            // ---- epilogue: h' = h + relu(b + W0 a1 + W1 a2) in the registers (node_embedding.cc:176-181)
+#pragma unroll
+            for (int t = 0; t < DGN_OT; t++) {
+                const bool on = valid && 16 * t + 4 * g < DGN_D;
+                const float4_t rr = acc[t] * oscale;
+                hreg[t] = (float4_t){on ? hreg[t].x + relu1(rr.x) : 0.f, on ? hreg[t].y + relu1(rr.y) : 0.f,
+                                     on ? hreg[t].z + relu1(rr.z) : 0.f, on ? hreg[t].w + relu1(rr.w) : 0.f};
+            }
+            __syncthreads();  // every wave is done with the layer's s_ht
+            if (l + 1 < DGN_L) {
+#pragma unroll
+                for (int t = 0; t < DGN_OT; t++) put_row_piece(4 * t + g, hreg[t]);  // (ordered before the next layer's reads by its K-step 0 barrier)
+            }
+        }
+        {   // ---- readout: h_4 as fp32 rows where s_ht was, then one wave per graph of the tile (pool_mlp3_kernel's association)
+            float* s_rows = reinterpret_cast<float*>(s_all);
+            if (valid) {
+#pragma unroll
+                for (int t = 0; t < DGN_OT; t++)
+                    if (16 * t + 4 * g < DGN_D)
+                        *reinterpret_cast<float4*>(s_rows + lr * DGN_D + 16 * t + 4 * g) = make_float4(hreg[t].x, hreg[t].y, hreg[t].z, hreg[t].w);
+            }
+            __syncthreads();
+            float* s_hg = reinterpret_cast<float*>(s_w + DGN_CHUNK) + wave * 160;  // slot 1 (free until K-step 0's barrier of the next tile): [0, 100) pooled row, [100, 150) first hidden layer
+            float* s_o1 = s_hg + DGN_D;
+            const int half = lane >> 5, c = lane & 31;
+            for (int gi = g0 + wave; gi < g1; gi += 8) {
+                const int n0 = a.b.node_off[gi] - t0, n1 = a.b.node_off[gi + 1] - t0;
+                float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (c < DGN_C)
+                    for (int v = n0 + half; v < n1; v += 2) {
+                        const float4 x = *reinterpret_cast<const float4*>(s_rows + v * DGN_D + 4 * c);
+                        sum.x += x.x; sum.y += x.y; sum.z += x.z; sum.w += x.w;
+                    }
+                sum.x += __shfl_down(sum.x, 32, 64); sum.y += __shfl_down(sum.y, 32, 64);
+                sum.z += __shfl_down(sum.z, 32, 64); sum.w += __shfl_down(sum.w, 32, 64);
+                if (half == 0 && c < DGN_C) {
+                    const float n = (float)(n1 - n0);
+                    s_hg[4 * c + 0] = sum.x / n; s_hg[4 * c + 1] = sum.y / n;
+                    s_hg[4 * c + 2] = sum.z / n; s_hg[4 * c + 3] = sum.w / n;
+                }
+                __builtin_amdgcn_wave_barrier();
+                if (lane < 50) {
+                    float s = a.b1[lane];
+                    for (int i = 0; i < DGN_D; i++) s = __builtin_fmaf(s_hg[i], a.w1t[i * 50 + lane], s);
+                    s_o1[lane] = relu1(s);
+                }
+                __builtin_amdgcn_wave_barrier();
+                float part = 0.f;
+                if (lane < 25) {
+                    float s = a.b2[lane];
+                    for (int i = 0; i < 50; i++) s = __builtin_fmaf(s_o1[i], a.w2t[i * 25 + lane], s);
+                    part = relu1(s) * a.w3[lane];
+                }
+#pragma unroll
+                for (int d = 32; d >= 1; d >>= 1) part += __shfl_down(part, d, 64);
+                if (lane == 0) a.out[gi] = a.b3[0] + part;
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        if (!has_next) break;
+        tile = ntile;
+    }
+    if (__any(!(vmax < 6.0e4f))) {
+        if (lane == 0) atomicOr(a.range_flag, 1);
     }
 }
 
@@ -1033,6 +1402,15 @@ public:
         if ((rc = upload(&d_b1_, v_b1))) return rc;
         if ((rc = upload(&d_w2_, v_w2))) return rc;
         if ((rc = upload(&d_b2_, v_b2))) return rc;
+        {   // the resident kernel's head reads w1 / w2 transposed (lane = output unit)
+            std::vector<float> w1t(100 * 50), w2t(50 * 25);
+            for (int o = 0; o < 50; o++)
+                for (int i = 0; i < 100; i++) w1t[i * 50 + o] = v_w0[o * 100 + i];
+            for (int o = 0; o < 25; o++)
+                for (int i = 0; i < 50; i++) w2t[i * 25 + o] = v_w1[o * 50 + i];
+            if ((rc = upload(&d_w0t_, w1t))) return rc;
+            if ((rc = upload(&d_w1t_, w2t))) return rc;
+        }
         ready_ = true;
         return 0;
     }
@@ -1095,9 +1473,43 @@ public:
     bool use_mfma_agg(const DeviceBatch& db) const {
         return mfma_agg_ < 0 ? (double)db.job_e >= 8.0 * (double)db.job_n : mfma_agg_ != 0;  // the JOB's density: every shard of a job takes the same path
     }
-    // the matrix-pipe path takes what it needs of the graph structure from the caller's edge list (dgn_rowinfo_kernel): no index build
+    // the graph-resident kernel: every layer's h stays on chip, nothing per node is written (flowgnn_get_h repeats the pass per layer).
+    // dgn_resident = 1: where the per-layer path would aggregate on the matrix pipe (dense tiles); 2: for every batch that tiles
+    bool use_resident(const DeviceBatch& db) const {
+        return resident_ != 0 && !keep_h_ && !qmode_ && db.node_eigen && use_fused(db) && (resident_ == 2 || use_mfma_agg(db));
+    }
+    // the matrix-pipe paths take what they need of the graph structure from the caller's edge list (dgn_rowinfo_kernel): no index build
     bool needs_csr(const DeviceBatch& db) const override {
+        if (db.b.n_tot > 0 && use_resident(db)) return false;
         return !(rowinfo_direct_ && !qmode_ && db.b.n_tot > 0 && db.node_eigen && use_fused(db) && use_mfma_agg(db));
+    }
+
+    // two launches per step: per-row records from the caller's arrays, then everything else
+    int forward_resident(DeviceBatch& db, Profiler& prof, hipStream_t s) {
+        const int n = db.b.n_tot;
+        if (int rc = rec_.reserve(((size_t)n + DGN_FT_ROWS) * DGN_REC_DW)) return rc;  // (a tile's DMA reads 128 records whatever its rows)
+        {
+            ProfScope p(prof, "dgn_tile_build", s);
+            dgn_rowinfo_kernel<true><<<db.gtiles.n_tiles, 256, 0, s>>>(db.b, db.gtiles.row_start, db.gtiles.graph_start, db.gtiles.n_tiles, db.node_eigen,
+                                                                       reinterpret_cast<uint32_t*>(rec_.p), nullptr, db.csr.err, nullptr);
+        }
+        DgnResidentArgs a;
+        a.rec = reinterpret_cast<const uint32_t*>(rec_.p);
+        a.table = d_emb_;
+        a.wpk = d_fused_;
+        a.tile_row = db.gtiles.row_start; a.tile_graph = db.gtiles.graph_start;
+        a.b = db.b;
+        a.w1t = d_w0t_; a.b1 = d_b0_; a.w2t = d_w1t_; a.b2 = d_b1_; a.w3 = d_w2_; a.b3 = d_b2_;
+        a.out = db.out; a.range_flag = db.range_flag;
+        a.n_tiles = db.gtiles.n_tiles;
+        const int grid = db.gtiles.n_tiles < 256 ? db.gtiles.n_tiles : 256;  // persistent: one 8-wave workgroup per CU (157 KB of LDS)
+        {
+            ProfScope p(prof, "dgn_resident", s);
+            dgn_resident_kernel<<<grid, 512, 0, s>>>(a);
+        }
+        db.final_h = 0;
+        db.h_valid = false;  // no per-node tensor leaves the kernel: flowgnn_get_h repeats the pass on the per-layer kernels
+        return 0;
     }
 
     int forward(DeviceBatch& db, Profiler& prof, hipStream_t s) override {
@@ -1106,6 +1518,8 @@ public:
         if (!db.node_eigen) return 1;
         agg_ready_ = false;  // tiles_ / esc_ are rebuilt by whichever float path runs below; a fixed-point pass leaves none
         if (qmode_) return dgnq_forward(q_, db, prof, s);
+        db.h_valid = true;
+        if (use_resident(db)) return forward_resident(db, prof, s);
         {
             ProfScope p(prof, "atom_encoder", s);
             atom_encoder_kernel<DGN_D><<<atom_encoder_grid(n, DGN_C), 512, 0, s>>>(db.b.node_feature, d_emb_, db.h[0], n, db.csr.err);
@@ -1124,8 +1538,8 @@ public:
             if (int rc = dupflag_.reserve(1)) return rc;
             ProfScope p(prof, "dgn_rowinfo", s);
             FG_HIP_TRY(hipMemsetAsync(dupflag_.p, 0, sizeof(int), s));
-            dgn_rowinfo_kernel<<<db.gtiles.n_tiles, 256, 0, s>>>(db.b, db.gtiles.row_start, db.gtiles.graph_start, db.gtiles.n_tiles, db.node_eigen,
-                                                                 reinterpret_cast<uint32_t*>(rowinfo_.p), db.csr.out_deg, db.csr.err, dupflag_.p);
+            dgn_rowinfo_kernel<false><<<db.gtiles.n_tiles, 256, 0, s>>>(db.b, db.gtiles.row_start, db.gtiles.graph_start, db.gtiles.n_tiles, db.node_eigen,
+                                                                        reinterpret_cast<uint32_t*>(rowinfo_.p), db.csr.out_deg, db.csr.err, dupflag_.p);
             // the layer kernels' correction walk for duplicate edges reads the CSR: built only if the pass found one (device-side test)
             launch_build_csr(db.b, db.csr, false, db.max_nodes, db.max_edges, s, dupflag_.p);
         }
@@ -1208,6 +1622,7 @@ public:
         mfma_agg_ = o.i("dgn_mfma_agg");
         fold_readout_ = o.on("dgn_fold_readout");
         rowinfo_direct_ = o.on("dgn_rowinfo_direct");
+        resident_ = o.i("dgn_resident");
         ablate_ = FG_ABLATE(o.i("dgn_ablate"));
         agg_ready_ = false;
     }
@@ -1227,12 +1642,13 @@ public:
 
 private:
     void free_all() {
-        float** ptrs[] = {&d_emb_, &d_wf_, &d_wt_, &d_bp_, &d_w0_, &d_b0_, &d_w1_, &d_b1_, &d_w2_, &d_b2_};
+        float** ptrs[] = {&d_emb_, &d_wf_, &d_wt_, &d_bp_, &d_w0_, &d_b0_, &d_w1_, &d_b1_, &d_w2_, &d_b2_, &d_w0t_, &d_w1t_};
         for (auto p : ptrs)
             if (*p) { (void)hipFree(*p); *p = nullptr; }
         esc_.release();
         tiles_.release();
         rowinfo_.release();
+        rec_.release();
         ginfo_.release();
         dupflag_.release();
         pool_cnt_.release();
@@ -1254,6 +1670,9 @@ private:
     GrowBufI rowinfo_;   // dgn_layer_mfma_kernel: 32 B per row of layer-independent in-edge pass results
     GrowBufI dupflag_;           // dgn_rowinfo_kernel: set on the device when the batch has duplicate edges
     bool rowinfo_direct_ = true;
+    GrowBufI rec_;       // dgn_resident_kernel: 48 B per row (dgn_rowinfo_kernel<true>)
+    int resident_ = 1;   // dgn_resident
+    float *d_w0t_ = nullptr, *d_w1t_ = nullptr;  // head weights transposed for the resident kernel's readout
     GrowBufI ginfo_, pool_cnt_;  // POOL form of the last layer: (graph, position) per node; partial rows per graph
     GrowBuf pool_part_;          //   [G][8][100] per-wave partial sums of h_4
     bool fold_readout_ = true, keep_h_ = false;

@@ -105,7 +105,7 @@ static const OptionDef kOptionTable[] = {
     {"gcn_resident", 1}, {"gcn_tile_build", 1}, {"gcn_unfused", 0}, {"gcn_mfma", 16},
     {"gat_resident", 1}, {"gat_mfma", 16}, {"gat_fold_readout", 1}, {"gat_reference_quirk", 0},
     {"pna_resident", 1}, {"pna_tile_build", 1}, {"pna_fused", 1}, {"pna_mfma", 16},
-    {"dgn_fused", 1}, {"dgn_mfma", 16}, {"dgn_mfma_agg", -1}, {"dgn_fold_readout", 1}, {"dgn_rowinfo_direct", 1},
+    {"dgn_fused", 1}, {"dgn_mfma", 16}, {"dgn_mfma_agg", -1}, {"dgn_fold_readout", 1}, {"dgn_rowinfo_direct", 1}, {"dgn_resident", 1},
 #ifdef FLOWGNN_DEV
     {"gcn_ablate", 0}, {"gat_ablate", 0}, {"pna_ablate", 0}, {"dgn_ablate", 0}, {"gin_pingpong", 0},
 #endif
@@ -925,23 +925,29 @@ int flowgnn_get_csr(flowgnn_engine* e, int* row_ptr, int* src, int* eid, int* ou
     return FLOWGNN_OK;
 }
 
+// The last run kept no per-node rows (a graph-resident kernel, or a readout folded into the last layer): repeat the pass with the
+// tap on, on the per-layer kernels -- which also leaves the model's per-batch state of that path (row tiles of the stand-alone
+// aggregation kernels) describing THIS batch.  What flowgnn_get_h, flowgnn_get_aggregate and flowgnn_run_aggregation_only read.
+static int ensure_rows(flowgnn_engine* e) {
+    int rc = flowgnn_sync(e);
+    if (rc) return rc;
+    if (e->db.h_valid || e->db.tap) return FLOWGNN_OK;
+    e->model->set_keep_h(true);
+    e->model->set_exact(e->force_exact);
+    rc = engine_forward(e);
+    e->model->set_keep_h(false);
+    if (rc) { e->err = fg::last_error_text(); return rc; }
+    return flowgnn_sync(e);
+}
+
 int flowgnn_get_h(flowgnn_engine* e, float* h_host, int* dim) {
     if (!e) return FLOWGNN_ERR_ARG;
     if (!e->ran) return FLOWGNN_ERR_STATE;
-    int rc = flowgnn_sync(e);
+    int rc = ensure_rows(e);
     if (rc) return rc;
-    if (!e->db.h_valid && !e->db.tap) {  // the readout was folded into the last layer: repeat the pass with the tap on
-        e->model->set_keep_h(true);
-        e->model->set_exact(e->force_exact);
-        rc = engine_forward(e);
-        e->model->set_keep_h(false);
-        if (rc) { e->err = fg::last_error_text(); return rc; }
-        rc = flowgnn_sync(e);
-        if (rc) return rc;
-        if (!e->db.h_valid && !e->db.tap) {
-            e->err = "flowgnn_get_h: node embeddings are not available as float rows in this numeric mode";
-            return FLOWGNN_ERR_UNSUPPORTED;
-        }
+    if (!e->db.h_valid && !e->db.tap) {
+        e->err = "flowgnn_get_h: node embeddings are not available as float rows in this numeric mode";
+        return FLOWGNN_ERR_UNSUPPORTED;
     }
     const int D = e->db.tap ? e->db.tap_dim : e->model->emb_dim();
     const float* srcp = e->db.tap ? e->db.tap : e->db.h[e->db.final_h];
@@ -980,8 +986,10 @@ int flowgnn_run_aggregation_only(flowgnn_engine* e, int layer, int iters, float*
     if (!e->ran) { e->err = "flowgnn_run_aggregation_only needs a prior flowgnn_run"; return FLOWGNN_ERR_STATE; }
     ENGINE_TRY(e, use_device(e));
     e->drop_graph();
+    int rc = e->model->aggregate_dim() > 0 ? ensure_rows(e) : FLOWGNN_OK;  // the kernel's input rows (a resident run left none)
+    if (rc) return rc;
     ensure_csr(e);
-    int rc = e->model->aggregation_only(e->db, layer, e->stream);  // warm-up; also the model's verdict on `layer`
+    rc = e->model->aggregation_only(e->db, layer, e->stream);  // warm-up; also the model's verdict on `layer`
     if (rc) {
         e->err = rc == FLOWGNN_ERR_UNSUPPORTED ? "no standalone aggregation kernel for this model / numeric mode (the fixed-point modes have none)" : "flowgnn_run_aggregation_only: bad layer";
         return rc;
@@ -1018,6 +1026,8 @@ int flowgnn_get_aggregate(flowgnn_engine* e, int layer, float* h_in_host, int* i
     if (agg_dim) *agg_dim = AD;
     if (AD <= 0) { e->err = "no standalone aggregation kernel for this model / numeric mode (the fixed-point modes have none)"; return FLOWGNN_ERR_UNSUPPORTED; }
     if (e->N == 0 || (!h_in_host && !agg_host)) return FLOWGNN_OK;
+    rc = ensure_rows(e);
+    if (rc) return rc;
     ensure_csr(e);
     rc = e->model->aggregation_only(e->db, layer, e->stream);
     if (rc) { e->err = rc == FLOWGNN_ERR_UNSUPPORTED ? "flowgnn_get_aggregate: not available in this numeric mode" : "flowgnn_get_aggregate: bad layer"; return rc; }

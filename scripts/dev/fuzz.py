@@ -54,7 +54,7 @@ VARIANTS = {
     "GCN": [{"gcn_resident": 0}, {"gcn_resident": 0, "gcn_unfused": 1}, {"hipgraph": 0}, {"gcn_tile_build": 0}],
     "GAT": [{"gat_resident": 0}, {"gat_fold_readout": 0}, {"hipgraph": 0}],
     "PNA": [{"pna_fused": 0}, {"pna_resident": 0}, {"pna_tile_build": 0}, {"hipgraph": 0}],
-    "DGN": [{"dgn_fused": 0}, {"dgn_mfma_agg": 0}, {"dgn_mfma_agg": 1}, {"dgn_mfma_agg": 1, "dgn_rowinfo_direct": 0}, {"dgn_mfma_agg": 1, "dgn_fold_readout": 0}],
+    "DGN": [{"dgn_fused": 0}, {"dgn_mfma_agg": 0}, {"dgn_resident": 2}, {"dgn_mfma_agg": 1, "dgn_resident": 0}, {"dgn_mfma_agg": 1, "dgn_resident": 0, "dgn_rowinfo_direct": 0}, {"dgn_mfma_agg": 1, "dgn_resident": 0, "dgn_fold_readout": 0}],
 }[model]
 
 e = Engine(model, 0)

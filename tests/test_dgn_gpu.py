@@ -89,6 +89,97 @@ def test_hep10k_size_properties(eng, oracle, w):
     assert_close(walk, want, oracle_scale(hd), what="all 10 000 graphs, in-edge walk")
 
 
+def _with_duplicates(hep, seed):
+    """Duplicate edges and self loops inside every seventh graph; forty copies of one edge in graph 5."""
+    rng = np.random.default_rng(seed)
+    eo = hep.edge_offsets()
+    for g in range(0, hep.num_graphs, 7):
+        e0, ne = int(eo[g]), int(eo[g + 1] - eo[g])
+        for _ in range(12):
+            i, k = rng.integers(0, ne, 2)
+            hep.edge_list[e0 + i] = hep.edge_list[e0 + k]
+        v = int(rng.integers(0, hep.nums_of_nodes[g]))
+        hep.edge_list[e0 + int(rng.integers(0, ne))] = [v, v]
+    if hep.num_graphs > 5:
+        hep.edge_list[int(eo[5]):int(eo[5]) + 40] = hep.edge_list[int(eo[5])]
+    return hep
+
+
+def _without_duplicates(b):
+    """The batch with every repeated (u, v) of a graph dropped (first copy kept)."""
+    eo = b.edge_offsets()
+    keep = np.ones(b.total_edges, bool)
+    ne = b.nums_of_edges.copy()
+    for g in range(b.num_graphs):
+        e = b.edge_list[eo[g]:eo[g + 1]].astype(np.int64)
+        _, first = np.unique(e[:, 0] * 65536 + e[:, 1], return_index=True)
+        k = np.zeros(len(e), bool)
+        k[first] = True
+        keep[eo[g]:eo[g + 1]] = k
+        ne[g] = int(k.sum())
+    return gp.GraphBatch(b.nums_of_nodes.copy(), ne, b.node_feature.copy(), b.edge_list[keep].copy(), b.edge_attr[keep].copy(),
+                         None if b.node_eigen is None else b.node_eigen.copy())
+
+
+def test_resident_kernel_is_the_per_layer_path_bit_for_bit(eng, w):
+    """dgn_resident_kernel (records from the caller's arrays, then encoder + four layers + readout of a tile of whole graphs in ONE
+    launch: h in registers and as split rows in LDS throughout, the weights streamed) performs the operations of atom_encoder +
+    dgn_rowinfo + 4 x dgn_layer_mfma_kernel + pool_mlp3 in the same order on the same tiles: the same bits -- on full kNN tiles, on
+    ragged molecule tiles (forced onto the matrix pipe), on a batch that ends inside a tile; flowgnn_get_h after a resident run repeats
+    the pass per layer."""
+    per_layer = Engine("DGN", device=0, options={"dgn_resident": 0, "dgn_fold_readout": 0, "dgn_mfma_agg": 1})
+    forced = Engine("DGN", device=0, options={"dgn_resident": 2, "dgn_mfma_agg": 1})
+    for e in (per_layer, forced):
+        e.set_weights(w)
+    try:
+        mol = with_eigen(gp.synth_molhiv_batch(3000, seed=78), 1)  # (its repeated bonds: rows that repeat ONE source add the copy alike in both
+        for b in (gp.synth_hep10k_batch(700, seed=77), _without_duplicates(mol), gp.synth_hep10k_batch(3, seed=79)):  # kernels; the rest is toleranced, below)
+            want = per_layer.forward(b)
+            assert np.isfinite(want).all()
+            for e in (forced,) + ((eng,) if b.total_edges >= 8 * b.total_nodes else ()):
+                got = e.forward(b)
+                assert np.array_equal(got, want), np.abs(got - want).max()
+            assert np.array_equal(forced.final_h(), per_layer.final_h())
+        forced.profile_enable(True)
+        forced.forward(gp.synth_hep10k_batch(64, seed=80))
+        prof_names = set(forced.profile_read())
+        assert prof_names == {"dgn_tile_build", "dgn_resident"}, prof_names  # two launches per step
+    finally:
+        for e in (per_layer, forced):
+            e.close()
+
+
+def test_resident_kernel_duplicate_edges_and_edge_cases(eng, oracle, w):
+    """Rows with duplicate in-edges (the adjacency mask carries no multiplicities) re-sum their in-edges from the caller's edge list:
+    against the oracle and against the in-edge walk, with up to 40 copies of one edge, self loops, graphs of one node, rows without
+    in-edges, and out-of-range edges / node features refused as by the index build."""
+    hep = _with_duplicates(gp.synth_hep10k_batch(300, seed=81), 5)
+    one = gp.GraphBatch(np.array([1, 1, 2], np.int32), np.array([0, 1, 3], np.int32), np.zeros((4, 9), np.int32),
+                        np.array([[0, 0], [0, 1], [0, 1], [1, 1]], np.int32), np.zeros((4, 3), np.int32),
+                        np.array([[0, .1, 0, 0], [0, -.2, 0, 0], [0, .3, 0, 0], [0, .05, 0, 0]], np.float32))
+    forced = Engine("DGN", device=0, options={"dgn_resident": 2})
+    walk = Engine("DGN", device=0, options={"dgn_resident": 0, "dgn_mfma_agg": 0})
+    forced.set_weights(w)
+    walk.set_weights(w)
+    try:
+        for b in (hep, one, gp.concat_batches([one, hep.slice(0, 9), one]), with_eigen(gp.synth_molhiv_batch(3000, seed=78), 1)):
+            got = forced.forward(b)
+            want, hd = oracle.dgn_forward(b, [w], dump_h=True, nthreads=8)
+            assert_close(got, want, oracle_scale(hd), what="resident vs oracle")
+            assert_close(got, walk.forward(b), oracle_scale(hd), what="resident vs in-edge walk")
+        bad = gp.synth_hep10k_batch(4, seed=83)
+        bad.edge_list[3] = [0, 1000]
+        with pytest.raises(FlowGNNError):
+            forced.forward(bad)
+        bad = gp.synth_hep10k_batch(4, seed=84)
+        bad.node_feature[5, 0] = 119
+        with pytest.raises(FlowGNNError):
+            forced.forward(bad)
+    finally:
+        forced.close()
+        walk.close()
+
+
 def test_split_range_fallback(oracle, w):
     """Same contract as GCN/GIN: dense200_res_relu_split_kernel raises the range flag beyond the f16 range and the engine
     repeats the pass on dgn_dense_kernel (fp32 MFMA)."""

@@ -43,7 +43,7 @@ def test_dgn_rows_whose_in_edges_all_have_zero_weight(oracle):
     w = weights.SYNTH["DGN"](seed=7)
     want, hd = oracle.dgn_forward(b, [w], dump_h=True, nthreads=4)
     scale = max(1.0, float(np.abs(hd).max()))
-    for opts in ({"dgn_mfma_agg": 1}, {"dgn_mfma_agg": 1, "dgn_rowinfo_direct": 0}, {"dgn_mfma_agg": 0}):
+    for opts in ({"dgn_mfma_agg": 1}, {"dgn_mfma_agg": 1, "dgn_resident": 0}, {"dgn_mfma_agg": 1, "dgn_resident": 0, "dgn_rowinfo_direct": 0}, {"dgn_mfma_agg": 0}):
         e = Engine("DGN", device=0, options=opts)
         e.set_weights(w)
         got = e.forward(b)

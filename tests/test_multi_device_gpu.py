@@ -225,11 +225,11 @@ def test_kernel_choice_follows_the_job_not_the_shard():
             e.close()
 
     want, whole = kernels_of(job, None)
-    assert "dgn_rowinfo" in whole  # the matrix-pipe path's in-edge pass (dgn_rowinfo_kernel)
+    assert "dgn_resident" in whole  # the matrix-pipe path (graph-resident kernel behind dgn_tile_build)
     alone, k_alone = kernels_of(sparse, None)
-    assert "dgn_rowinfo" not in k_alone  # its own job: sparse, the in-edge walk
+    assert "dgn_resident" not in k_alone  # its own job: sparse, the in-edge walk
     shard, k_shard = kernels_of(sparse, (job.total_nodes, job.total_edges))
-    assert "dgn_rowinfo" in k_shard
+    assert "dgn_resident" in k_shard
     np.testing.assert_allclose(shard, want[900:], rtol=2e-5, atol=2e-5)
     np.testing.assert_allclose(alone, want[900:], rtol=2e-4, atol=2e-4)
     g = EngineGroup("DGN", [0, 0])
@@ -240,7 +240,7 @@ def test_kernel_choice_follows_the_job_not_the_shard():
         got = g.forward(job)
         np.testing.assert_allclose(got, want, rtol=2e-5, atol=2e-5)
         for i in range(2):
-            assert "dgn_rowinfo" in g_profile_names(g, i)
+            assert "dgn_resident" in g_profile_names(g, i)
     finally:
         g.close()
     b, wg = gp.synth_molhiv_batch(66000, seed=77), weights.synth_gin_weights(seed=7)

@@ -416,7 +416,7 @@ def test_dgn_in_edge_pass_from_the_edge_list_is_the_csr_one():
     for b in (gp.synth_hep10k_batch(257, seed=3), dup, gp.concat_batches([dup, with_eig(random_graph(128, 2560, seed=5), 2), with_eig(gp.synth_molhiv_batch(60, seed=8), 1)])):
         outs = {}
         for direct in (1, 0):
-            e = Engine("DGN", device=0, options={"dgn_mfma_agg": 1, "dgn_rowinfo_direct": direct})
+            e = Engine("DGN", device=0, options={"dgn_mfma_agg": 1, "dgn_rowinfo_direct": direct, "dgn_resident": 0})  # (the per-layer path: the resident kernel has its own tile build)
             e.set_weights(w)
             outs[direct] = e.forward(b)
             assert np.array_equal(e.forward(b), outs[direct])
@@ -455,7 +455,7 @@ def test_invalid_inputs_are_reported_on_every_path(model):
     # (GAT takes the nine node features as NUMBERS, not as table rows: any integer is a valid input there)
     kinds = ["edge"] + (["feat"] if base != "gat" else []) + (["attr"] if base in ("gin", "gcn") else [])
     switch = {"GIN": {"gin_resident": 0}, "GIN-VN": {"gin_resident": 0}, "GCN": {"gcn_resident": 0}, "GAT": {"gat_resident": 0},
-              "PNA": {"pna_fused": 0}, "DGN": {"dgn_rowinfo_direct": 0}}[model]
+              "PNA": {"pna_fused": 0}, "DGN": {"dgn_resident": 0}}[model]
     for opts in ({}, switch):
         e = Engine(model, device=0, options=opts)
         e.set_weights(w)
