@@ -503,6 +503,54 @@ def launch_ranks(n: int, argv):
     raise SystemExit(rc)
 
 
+def dry_run(args):
+    """`--dry-run`: the N-rank job of `--gpus N` planned and its result concat exercised in ONE process on CPU tensors -- plan_job for
+    every rank, a ShardedResults per rank over a stand-in for the process group whose all-gather copies the ranks' pads (what RCCL
+    does over xGMI) -- and the per-rank shard balance printed as one JSON line.  No GPU, no kernels: what can go wrong in planning
+    (ragged ranges, pad width, job order of the concatenated logits) fails here, before the first multi-GPU run."""
+    import torch
+    M = MODELS[args.model]
+    graphs, world = args.graphs or M["graphs"], args.gpus
+    plans = [plan_job(M["dataset"], graphs, world, r, args.scaling) for r in range(world)]
+    ranges = plans[0][1]
+    assert all(p[1] == ranges for p in plans), "ranks disagree about the job's ranges"
+
+    class Done:
+        def wait(self):
+            return True
+
+    class OneProcessGroup:
+        def __init__(self):
+            self.members = []
+
+        def all_gather_into_tensor(self, out, pad, async_op=True):
+            out.copy_(torch.cat([m.pads[m.cur] for m in self.members]))
+            return Done()
+
+    group = OneProcessGroup()
+    group.members = [ShardedResults(ranges, r, "cpu", group, collectives=True) for r in range(world)]
+    for r, m in enumerate(group.members):  # every rank's readout "writes" the job-wide ids of its graphs
+        a, b = ranges[r]
+        assert plans[r][0].num_graphs == b - a == m.local_count(), (r, plans[r][0].num_graphs, a, b)
+        m.pad[: b - a] = torch.arange(a, b, dtype=torch.float32)
+    for m in list(group.members):
+        # (gather() flips `cur`: every member gathers from the pads the others hold NOW, so flip them together afterwards)
+        m.last = m.cur
+        m.work[m.cur] = group.all_gather_into_tensor(m.alls[m.cur], m.pads[m.cur])
+    total = ranges[-1][1]
+    ok = all(torch.equal(m.assemble(), torch.arange(total, dtype=torch.float32)) for m in group.members)
+    loads = [int(p[0].total_nodes + p[0].total_edges) for p in plans]
+    mean = sum(loads) / world
+    line = {"dry_run": True, "metric": M["metric"], "n_gpus": world, "scaling": args.scaling if world > 1 else "weak",
+            "graphs_per_step_job": total, "pad_width": group.members[0].width,
+            "ranks": [{"rank": r, "range": list(ranges[r]), "graphs": p[0].num_graphs, "nodes": p[0].total_nodes, "edges": p[0].total_edges,
+                       "node_plus_edge_load": loads[r]} for r, p in enumerate(plans)],
+            "imbalance_max_over_mean": max(loads) / mean if mean else 1.0, "result_concat_in_job_order": bool(ok)}
+    print(json.dumps(line))
+    if not ok:
+        sys.exit(3)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -522,9 +570,13 @@ def main():
                     help="test hook: perturb the GPU logits before they are compared with the oracle (the run must then exit with code 3)")
     ap.add_argument("--numeric", default="f32", choices=["f32", "q6.10"],
                     help="q6.10: the reference's ap_fixed<16,6> bit-faithful mode (a fidelity mode, ~10x slower)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="plan the --gpus N job and exercise its result concat for all N ranks in this one process on CPU tensors; print the per-rank shard balance (no GPU needed)")
     args = ap.parse_args()
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
+    if args.dry_run:
+        return dry_run(args)
 
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: what RCCL needs on this driver (already exported on the pool)
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:

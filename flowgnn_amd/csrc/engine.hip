@@ -99,12 +99,14 @@ static const OptionDef kOptionTable[] = {
     {"csr_flat", 0},              // 1: global-memory index build for every graph (A/B)
     {"tile_nominal", -1},         // rows per tile of the tiled aggregation kernels (< 0: the model's default)
     {"tile_slack", -1},
+    {"tile_balance", 1},          // graph tiles of a batch of <= 8 rounds over the CUs: fewer rows per tile, whole rounds of tiles (flowgnn_set_batch)
     {"gin_resident", 1}, {"gin_tile_build", -1}, {"gin_resident_min_fill", 0.5}, {"gin_resident_nosort", 0}, {"gin_resident_prof", 0},
     {"gin_unfused", 0}, {"gin_mfma", 16}, {"gin_split_nt", 4}, {"gin_fold_readout", 1}, {"gin_head_fold", 1},
     {"gin_agg_untiled", 0}, {"gin_agg_tile", 128},
     {"gcn_resident", 1}, {"gcn_tile_build", 1}, {"gcn_unfused", 0}, {"gcn_mfma", 16},
     {"gat_resident", 1}, {"gat_mfma", 16}, {"gat_fold_readout", 1}, {"gat_reference_quirk", 0},
     {"pna_resident", 1}, {"pna_tile_build", 1}, {"pna_fused", 1}, {"pna_mfma", 16},
+    {"pna_mfma_agg", 0},          // deprecated (removed in round 5, the kernel it selected is gone): accepted and ignored, so that callers' scripts keep working
     {"dgn_fused", 1}, {"dgn_mfma", 16}, {"dgn_mfma_agg", -1}, {"dgn_fold_readout", 1}, {"dgn_rowinfo_direct", 1}, {"dgn_resident", 1},
 #ifdef FLOWGNN_DEV
     {"gcn_ablate", 0}, {"gat_ablate", 0}, {"pna_ablate", 0}, {"dgn_ablate", 0}, {"gin_pingpong", 0},
@@ -560,19 +562,45 @@ int flowgnn_set_batch(flowgnn_engine* e, int num_graphs, const int* nums_of_node
         e->model->graph_tile_limits(t_rows, t_edges);
         if (t_rows > 0 && num_graphs > 0) {
             std::vector<int> trow, tgraph;
-            trow.push_back(0);
-            tgraph.push_back(0);
-            int cr = 0, ce = 0;
             bool fits = true;
-            for (int g = 0; g < num_graphs && fits; g++) {
-                const int n = nums_of_nodes[g], m = nums_of_edges[g];
-                if (n > t_rows || m > t_edges) { fits = false; break; }
-                if (cr + n > t_rows || ce + m > t_edges) {
-                    trow.push_back(noff[g]);
-                    tgraph.push_back(g);
-                    cr = 0; ce = 0;
+            // whole graphs, in batch order, into tiles of at most `cap` rows / t_edges in-edges
+            auto pack = [&](int cap, std::vector<int>& tr, std::vector<int>& tg) {
+                tr.clear(); tg.clear();
+                tr.push_back(0);
+                tg.push_back(0);
+                int cr = 0, ce = 0;
+                for (int g = 0; g < num_graphs; g++) {
+                    const int n = nums_of_nodes[g], m = nums_of_edges[g];
+                    if (n > cap || m > t_edges) return false;
+                    if (cr + n > cap || ce + m > t_edges) {
+                        tr.push_back(noff[g]);
+                        tg.push_back(g);
+                        cr = 0; ce = 0;
+                    }
+                    cr += n; ce += m;
                 }
-                cr += n; ce += m;
+                return true;
+            };
+            fits = pack(t_rows, trow, tgraph);
+            const int std_tiles = (int)trow.size();  // (the closing entry is appended below)
+            int std_last_row = fits ? trow.back() : 0;
+            // A batch of a few ROUNDS of tiles over the CUs (dataset-sized batches: 4 113 molhiv graphs pack to 410 GIN tiles of 256
+            // rows -- two rounds over 256 CUs, the second 60 % full, at the price of two): the same graphs in tiles of fewer rows, as
+            // many tiles as fill whole rounds (512 of ~203 rows), cost each CU two SHORTER tiles.  The smallest row cap whose greedy
+            // packing needs no more than rounds x 256 tiles, by bisection; the fill the models' thresholds see stays that of the
+            // full-size packing (it describes the graphs, not this choice).  Option tile_balance = 0: off.
+            constexpr int kCUs = 256, kMaxRounds = 8;
+            if (fits && e->opts.on("tile_balance") && std_tiles > 1) {
+                const int rounds = (std_tiles + kCUs - 1) / kCUs, target = rounds * kCUs;
+                if (rounds <= kMaxRounds && std_tiles < target) {
+                    int lo = mx_n, hi = t_rows;  // pack(hi) <= target tiles holds; find the smallest cap that still does
+                    std::vector<int> tr2, tg2;
+                    while (lo < hi) {
+                        const int mid = (lo + hi) / 2;
+                        if (pack(mid, tr2, tg2) && (int)tr2.size() <= target) hi = mid; else lo = mid + 1;
+                    }
+                    if (hi < t_rows && pack(hi, tr2, tg2) && (int)tr2.size() <= target) { trow.swap(tr2); tgraph.swap(tg2); }
+                }
             }
             if (fits) {
                 trow.push_back((int)N);
@@ -595,7 +623,7 @@ int flowgnn_set_batch(flowgnn_engine* e, int num_graphs, const int* nums_of_node
                 // how full the tiles are WITHOUT the last one (the tail of the batch, whatever is left over): a shard of a cut job
                 // then sees the fill of its graphs' packing, not of its own tail -- a one-tile batch counts as full (one resident
                 // launch beats the per-layer sequence on it anyway) -- and takes the path the whole job would take
-                gt.fill = gt.n_tiles > 1 ? (double)trow[cnt - 2] / ((double)(gt.n_tiles - 1) * t_rows) : 1.0;
+                gt.fill = std_tiles > 1 ? (double)std_last_row / ((double)(std_tiles - 1) * t_rows) : 1.0;
                 // ... and a shard that was told the fill of its JOB (flowgnn_set_job_tile_fill; the group and the entry points do)
                 // takes the job's side of the models' thresholds whatever its own graphs pack to
                 if (e->job_fill >= 0.0) gt.fill = e->job_fill;
@@ -1080,7 +1108,16 @@ public:
             }
             cv_go_.notify_all();
         }
-        rc_[0] = fn(0);
+        // engine 0 runs here, on the caller's thread: its hipSetDevice must not outlive the call (the caller's current device is the
+        // caller's business), and whatever fn(0) throws (std::bad_alloc from a staging vector) the workers still hold &fn and write
+        // rc_ -- so the wait below runs before anything leaves this frame, and the exception becomes a status code (this is a C ABI)
+        int caller_dev = -1;
+        const bool have_dev = hipGetDevice(&caller_dev) == hipSuccess;
+        try {
+            rc_[0] = fn(0);
+        } catch (...) {
+            rc_[0] = FLOWGNN_ERR_HIP;
+        }
         if (n_ > 1) {
             for (int spin = 0; spin < 20000 && pending_.load(std::memory_order_acquire) > 0; spin++) cpu_relax();
             if (pending_.load(std::memory_order_acquire) > 0) {
@@ -1089,6 +1126,7 @@ public:
             }
             fn_ = nullptr;
         }
+        if (have_dev) (void)hipSetDevice(caller_dev);
         return rc_;
     }
 
@@ -1116,7 +1154,11 @@ private:
                 if (quit_) return;
                 fn = fn_;
             }
-            rc_[(size_t)i] = (*fn)(i);
+            try {
+                rc_[(size_t)i] = (*fn)(i);
+            } catch (...) {
+                rc_[(size_t)i] = FLOWGNN_ERR_HIP;  // (an exception must not end the worker with the caller still waiting for it)
+            }
             if (pending_.fetch_sub(1, std::memory_order_acq_rel) == 1) {
                 std::lock_guard<std::mutex> lk(mu_);
                 cv_done_.notify_one();

@@ -1080,7 +1080,7 @@ public:
                     for (int i = 0; i < EDGE_COMBOS * GCN_D; i++) {
                         const float e = ecomb[(size_t)l * EDGE_COMBOS * GCN_D + i];
                         dst[i] = e * (1.0f / 65536.0f);
-                        emax = std::fmax(emax, std::fabs(e));
+                        { const float ae = std::fabs(e); emax = (ae > emax || ae != ae) ? ae : emax; }  // (not fmax: it would drop a NaN)
                     }
                     float* pl = reinterpret_cast<float*>(res.data() + GCNR_PLANES_OFF + (size_t)l * GCNR_PLANES_BYTES);
                     for (int q = 0; q < 6; q++)
@@ -1092,7 +1092,7 @@ public:
                 {   // ... and the root embedding scaled likewise: the epilogue's relu(x + root) is one clamped FMA too
                     float* rt = reinterpret_cast<float*>(base + GCNR_W_BYTES + sizeof(float) * EDGE_COMBOS * GCN_D);
                     for (int d = 0; d < GCN_D; d++) {
-                        emax = std::fmax(emax, std::fabs(rt[d]));
+                        { const float ar = std::fabs(rt[d]); emax = (ar > emax || ar != ar) ? ar : emax; }
                         rt[d] *= 1.0f / 65536.0f;
                     }
                 }
@@ -1100,7 +1100,7 @@ public:
             if ((rc = upload(&d_res_, res))) return rc;
             // the scaled walk is exact while x + e < 2^16: |e| < 4 096 here, |x| < 6e4 by the range flag (x_0: nine projected-table rows)
             float pmax = 0.0f;
-            for (int r = 0; r < ND_FEATURE_TOTAL * GCN_D; r++) pmax = std::fmax(pmax, std::fabs(proj_max_src_[r]));
+            for (int r = 0; r < ND_FEATURE_TOTAL * GCN_D; r++) { const float ap = std::fabs(proj_max_src_[r]); pmax = (ap > pmax || ap != ap) ? ap : pmax; }
             table_ok_ = emax < 4096.0f && 9.0f * pmax < 6.0e4f;
         }
         if ((rc = upload(&d_split_, split_all))) return rc;

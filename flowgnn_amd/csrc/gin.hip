@@ -661,7 +661,7 @@ public:
             // x < 6e4, the range every operand is checked against anyway); tables beyond that take the per-layer kernels.
             float emax = 0.0f;
             std::vector<float> sc(ecomb.size() + (size_t)GIN_L * 6 * 4 * 64 * 4, 0.0f);
-            for (size_t i = 0; i < ecomb.size(); i++) { sc[i] = ecomb[i] * (1.0f / 65536.0f); emax = std::fmax(emax, std::fabs(ecomb[i])); }
+            for (size_t i = 0; i < ecomb.size(); i++) { sc[i] = ecomb[i] * (1.0f / 65536.0f); const float ae = std::fabs(ecomb[i]); emax = (ae > emax || ae != ae) ? ae : emax; }  // (not fmax: it would drop a NaN)
             // ... and once more in plane order [layer][quad q][quarter g][code, padded to 64] of 16 B, for the walk's reads through L1
             for (int l = 0; l < GIN_L; l++)
                 for (int q = 0; q < 6; q++)
@@ -669,7 +669,7 @@ public:
                         for (int c = 0; c < EDGE_COMBOS; c++)
                             for (int k = 0; k < 4; k++)
                                 sc[ecomb.size() + ((((size_t)l * 6 + q) * 4 + gq) * 64 + c) * 4 + k] = sc[((size_t)l * EDGE_COMBOS + c) * GIN_D + 16 * q + 4 * gq + k];
-            table_ok_ = emax < 4096.0f;  // (NaN: false)
+            table_ok_ = emax < 4096.0f;  // (a NaN / Inf entry: emax is then NaN / Inf and the comparison false -> the per-layer kernels)
             if ((rc = upload(&d_ecomb_res_, sc))) return rc;
         }
         if ((rc = upload(&d_w1f_, w1f))) return rc;

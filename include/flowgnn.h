@@ -238,11 +238,14 @@ int flowgnn_set_batch(flowgnn_engine* e, int num_graphs,
  */
 int flowgnn_set_job_totals(flowgnn_engine* e, long long job_nodes, long long job_edges);
 /*
- * The other size-dependent choice: the graph-resident / fused kernels are used when the batch's graph tiles pack at least 50 % full
- * (40 % PNA / DGN; the last tile does not count).  flowgnn_graph_tile_fill computes that fill for any graph list under this engine's
+ * The other size-dependent choice: the graph-resident / fused kernels are used when the batch's graph tiles pack at least as full as
+ * the model's threshold (GIN / GIN-VN: option "gin_resident_min_fill", default 50 %; GCN / GAT 50 %; PNA / DGN 40 %; the last tile does
+ * not count).  flowgnn_graph_tile_fill computes that fill for any graph list under this engine's
  * model and options (host code, no device work; -1: the model has no graph tiles, 0: a graph exceeds the tile limits);
  * flowgnn_set_job_tile_fill makes the next flowgnn_set_batch batches take the side of the threshold the JOB's fill is on, whatever
  * their own graphs pack to (< 0: back to each batch's own packing).  flowgnn_group_* and the entry points hand both down by themselves.
+ * (Development builds only -- make DEV=1, option "gin_pingpong": that kernel decides by the SHARD's own half-tile fill, which is not
+ * handed down; the shipped library has no such path.)
  */
 int flowgnn_graph_tile_fill(flowgnn_engine* e, int num_graphs, const int* nums_of_nodes, const int* nums_of_edges, double* fill);
 int flowgnn_set_job_tile_fill(flowgnn_engine* e, double fill);

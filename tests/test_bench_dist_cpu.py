@@ -125,3 +125,21 @@ def test_parity_record():
     assert not bench.parity_record("GIN", np.array([1.0, np.nan, 3.0], np.float32), want)["ok"]
     q = bench.parity_record("GIN", want, want, numeric="q6.10")
     assert q["ok"] and not bench.parity_record("GIN", want + np.float32(2 ** -10), want, numeric="q6.10")["ok"]
+
+
+def test_dry_run_plans_every_rank_in_one_process():
+    """`bench.py --gpus N --dry-run` (no GPU): the N-rank job planned and its result concat exercised in one process -- weak and strong
+    scaling at 1 / 2 / 8 ranks, ragged strong-scaling shards included -- prints the per-rank shard balance."""
+    import json
+    for args in (["--gpus", "8", "--scaling", "strong", "--graphs", "3001"], ["--gpus", "2", "--graphs", "500", "--model", "DGN"],
+                 ["--gpus", "1", "--graphs", "64"], ["--gpus", "8", "--scaling", "strong", "--graphs", "5"]):
+        p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--dry-run"] + args, capture_output=True, text=True, timeout=300)
+        assert p.returncode == 0, p.stderr[-2000:]
+        d = json.loads(p.stdout.strip().splitlines()[-1])
+        n = int(args[1])
+        assert d["dry_run"] and d["n_gpus"] == n and d["result_concat_in_job_order"] and len(d["ranks"]) == n
+        total = int(args[args.index("--graphs") + 1]) * (n if "strong" not in args else 1)
+        assert d["graphs_per_step_job"] == total == sum(r["graphs"] for r in d["ranks"])
+        assert [r["range"][0] for r in d["ranks"]] == [0] + [r["range"][1] for r in d["ranks"]][:-1]
+        if "strong" in args and total >= 1000:
+            assert d["imbalance_max_over_mean"] < 1.05

@@ -124,7 +124,8 @@ def _without_duplicates(b):
 def test_resident_kernel_is_the_per_layer_path_bit_for_bit(eng, w):
     """dgn_resident_kernel (records from the caller's arrays, then encoder + four layers + readout of a tile of whole graphs in ONE
     launch: h in registers and as split rows in LDS throughout, the weights streamed) performs the operations of atom_encoder +
-    dgn_rowinfo + 4 x dgn_layer_mfma_kernel + pool_mlp3 in the same order on the same tiles: the same bits -- on full kNN tiles, on
+    dgn_rowinfo + 4 x dgn_layer_mfma_kernel + dgn_pool_part_mlp3<false> (rows pooled in row order) in the same order on the same tiles:
+    the same bits -- on full kNN tiles, on
     ragged molecule tiles (forced onto the matrix pipe), on a batch that ends inside a tile; flowgnn_get_h after a resident run repeats
     the pass per layer."""
     per_layer = Engine("DGN", device=0, options={"dgn_resident": 0, "dgn_fold_readout": 0, "dgn_mfma_agg": 1})

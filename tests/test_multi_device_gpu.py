@@ -12,6 +12,14 @@ import pytest
 from flowgnn_amd import Engine, EngineGroup, compute_graphs, entry_set_devices, graphpack as gp, shard_ranges_c, weights
 
 pytestmark = pytest.mark.gpu
+
+
+def devs(n):
+    """n device ordinals for an engine group: device 0 listed n times on a one-GPU box (the default), or the devices of
+    FLOWGNN_TEST_DEVICES=0,1,... taken round robin -- the same tests then run on several physical GPUs."""
+    ids = [int(x) for x in os.environ.get("FLOWGNN_TEST_DEVICES", "0").split(",") if x.strip() != ""] or [0]
+    return [ids[i % len(ids)] for i in range(n)]
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HOST = os.path.join(ROOT, "flowgnn_amd", "host")
 MODELS = ["GIN", "GIN-VN", "GCN", "GAT", "PNA", "DGN"]
@@ -42,7 +50,7 @@ def single(model, b, w):
         e.close()
 
 
-@pytest.mark.parametrize("devices", [[0, 0], [0, 0, 0]], ids=["2x", "3x"])
+@pytest.mark.parametrize("devices", [devs(2), devs(3)], ids=["2x", "3x"])
 @pytest.mark.parametrize("model", MODELS)
 def test_group_is_bit_identical_to_one_engine(model, devices):
     b, w = batch_for(model), weights.SYNTH[model](seed=7)
@@ -69,7 +77,7 @@ def test_group_is_bit_identical_to_one_engine(model, devices):
 def test_more_engines_than_graphs_and_empty_batch():
     b, w = gp.synth_molhiv_batch(2, seed=5), weights.synth_gin_weights(seed=7)
     want = single("GIN", b, w)
-    g = EngineGroup("GIN", [0, 0, 0, 0])
+    g = EngineGroup("GIN", devs(4))
     try:
         g.set_weights(w)
         assert np.array_equal(g.forward(b), want)  # two shards are empty
@@ -82,7 +90,7 @@ def test_more_engines_than_graphs_and_empty_batch():
 def test_group_options_num_tasks_and_fixed_point(oracle):
     b = gp.synth_molpcba_batch(40, seed=8)
     w = weights.synth_gin_weights(seed=7, num_tasks=6)
-    g = EngineGroup("GIN", [0, 0], options={"gin_resident": 0})
+    g = EngineGroup("GIN", devs(2), options={"gin_resident": 0})
     try:
         g.set_num_tasks(6)
         g.set_weights(w)
@@ -117,7 +125,7 @@ def test_entry_points_on_two_engines_with_reloads_spanning_a_cut(model, oracle):
     try:
         entry_set_devices([0])
         one = compute_graphs(model, b, sets, rw)
-        entry_set_devices([0, 0])
+        entry_set_devices(devs(2))
         two = compute_graphs(model, b, sets, rw)
     finally:
         entry_set_devices([0])
@@ -157,7 +165,7 @@ def test_dgn_default_kernel_on_two_engines_is_toleranced(oracle):
     e.set_weights(w)
     one = e.forward(b)
     e.close()
-    g = EngineGroup("DGN", [0, 0])
+    g = EngineGroup("DGN", devs(2))
     try:
         g.set_weights(w)
         two = g.forward(b)
@@ -182,7 +190,7 @@ def test_group_compute_pipelines_ranges_and_matches_the_single_engine(oracle):
     want = ref.forward(b).copy()
     ref.close()
     for engines, chunks in ((1, 3), (2, 1), (2, 4), (3, 2)):
-        grp = EngineGroup("GIN", [0] * engines)
+        grp = EngineGroup("GIN", devs(engines))
         grp.set_weights(w)
         got = grp.compute(b, chunks)
         assert np.array_equal(got, want), (engines, chunks, np.abs(got - want).max())
@@ -232,7 +240,7 @@ def test_kernel_choice_follows_the_job_not_the_shard():
     assert "dgn_resident" in k_shard
     np.testing.assert_allclose(shard, want[900:], rtol=2e-5, atol=2e-5)
     np.testing.assert_allclose(alone, want[900:], rtol=2e-4, atol=2e-4)
-    g = EngineGroup("DGN", [0, 0])
+    g = EngineGroup("DGN", devs(2))
     try:
         g.set_weights(w)
         for i in range(2):
@@ -252,7 +260,7 @@ def test_kernel_choice_follows_the_job_not_the_shard():
         assert "gin_tile_build" in e.profile_read()
     finally:
         e.close()
-    g = EngineGroup("GIN", [0, 0])
+    g = EngineGroup("GIN", devs(2))
     try:
         g.set_weights(wg)
         assert np.array_equal(g.forward(b), want)
@@ -289,7 +297,7 @@ def test_group_state_after_compute_and_error_text():
     from flowgnn_amd.engine import FlowGNNError
     b, w = gp.synth_molhiv_batch(40, seed=3), weights.synth_gin_weights(seed=7)
     want = single("GIN", b, w)
-    g = EngineGroup("GIN", [0, 0])
+    g = EngineGroup("GIN", devs(2))
     try:
         g.set_weights(w)
         assert np.array_equal(g.forward(b), want)
@@ -366,7 +374,7 @@ def test_shards_take_the_jobs_side_of_the_fill_threshold():
         assert np.array_equal(told, want[a:c])
     finally:
         e.close()
-    g = EngineGroup("GIN", [0, 0])
+    g = EngineGroup("GIN", devs(2))
     try:
         g.set_weights(w)
         assert np.array_equal(g.forward(b), want)
