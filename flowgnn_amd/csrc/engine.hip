@@ -99,6 +99,7 @@ static const OptionDef kOptionTable[] = {
     {"csr_flat", 0},              // 1: global-memory index build for every graph (A/B)
     {"tile_nominal", -1},         // rows per tile of the tiled aggregation kernels (< 0: the model's default)
     {"tile_slack", -1},
+    {"h2d_pack", 16},             // flowgnn_set_batch: host threads that narrow a large batch's int32 arrays for the transfer (h2d_pack.cpp); 0: plain copies
     {"tile_balance", 1},          // graph tiles of a batch of <= 8 rounds over the CUs: fewer rows per tile, whole rounds of tiles (flowgnn_set_batch)
     {"gin_resident", 1}, {"gin_tile_build", -1}, {"gin_resident_min_fill", 0.5}, {"gin_resident_nosort", 0}, {"gin_resident_prof", 0},
     {"gin_unfused", 0}, {"gin_mfma", 16}, {"gin_split_nt", 4}, {"gin_fold_readout", 1}, {"gin_head_fold", 1},
@@ -184,6 +185,68 @@ double Options::num(const char* key) const {
 
 using namespace fg;
 
+namespace fg {
+// h2d_pack.cpp
+size_t h2d_pack_bytes(size_t n_nodes, size_t n_edges, bool attr, size_t* off_edges, size_t* off_attr);
+void h2d_pack(const int* node_feature, const int* edge_list, const int* edge_attr, size_t n_nodes, size_t n_edges, uint8_t* dst, int threads);
+
+// the packed arrays back into the reference's int32 layout (what every kernel reads): 255 / 65 535 = "did not fit" -> -1, which the
+// validation on the device refuses as it would have refused the original value
+__global__ __launch_bounds__(256) void unpack_batch_kernel(const uint8_t* __restrict__ nf8, const uint16_t* __restrict__ el16, const uint8_t* __restrict__ ea8,
+                                                           int* __restrict__ nf, int* __restrict__ el, int* __restrict__ ea, long long n9, long long e2,
+                                                           long long ne) {
+    const long long stride = (long long)gridDim.x * 256 * 4;
+    for (long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4; i < n9; i += stride) {  // four values per thread: n9 and e2 are padded to 16 B
+        const uint32_t w = *reinterpret_cast<const uint32_t*>(nf8 + i);
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            if (i + k < n9) { const int v = (int)((w >> (8 * k)) & 0xFFu); nf[i + k] = v == 255 ? -1 : v; }
+    }
+    for (long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4; i < e2; i += stride) {
+        const uint2 w = *reinterpret_cast<const uint2*>(el16 + i);
+        const int v[4] = {(int)(w.x & 0xFFFFu), (int)(w.x >> 16), (int)(w.y & 0xFFFFu), (int)(w.y >> 16)};
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            if (i + k < e2) el[i + k] = v[k] == 65535 ? -1 : v[k];
+    }
+    if (ea8)
+        for (long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4; i < ne; i += stride) {
+            const uint32_t w = *reinterpret_cast<const uint32_t*>(ea8 + i);
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                if (i + k < ne) {
+                    const int c = (int)((w >> (8 * k)) & 0xFFu);
+                    int* o = ea + 3 * (i + k);
+                    if (c == 255) { o[0] = -1; o[1] = 0; o[2] = 0; }
+                    else { o[0] = c / 12; o[1] = (c >> 1) % 6; o[2] = c & 1; }
+                }
+        }
+}
+static void launch_unpack_batch(const uint8_t* nf8, const uint8_t* el16, const uint8_t* ea8, int* nf, int* el, int* ea, long long n, long long e, hipStream_t s) {
+    const long long work = n * 9 > e * 2 ? n * 9 : e * 2;
+    long long blocks = (work / 4 + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    if (blocks < 1) blocks = 1;
+    unpack_batch_kernel<<<(int)blocks, 256, 0, s>>>(nf8, reinterpret_cast<const uint16_t*>(el16), ea8, nf, el, ea, n * 9, e * 2, e);
+}
+
+// host threads a call may use: the option's count, capped by what this process may run on (affinity mask, cgroup CPU quota)
+static int host_threads(int want) {
+    int n = (int)std::thread::hardware_concurrency();
+    if (n < 1) n = 1;
+    if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {  // cgroup v2: "<quota> <period>" or "max <period>"
+        char q[32];
+        long long period = 0;
+        if (fscanf(f, "%31s %lld", q, &period) == 2 && strcmp(q, "max") != 0 && period > 0) {
+            const long long cpus = (atoll(q) + period - 1) / period;
+            if (cpus >= 1 && cpus < n) n = (int)cpus;
+        }
+        fclose(f);
+    }
+    return want < n ? (want < 1 ? 1 : want) : n;
+}
+}  // namespace fg
+
 // ------------------------------------------------------------------ engine object
 struct flowgnn_engine {
     int model_id = 0;
@@ -218,6 +281,8 @@ struct flowgnn_engine {
     size_t cap_tiles = 0;
     int* d_sub = nullptr;                        // GraphTiles::sub | big_row | big_graph in one allocation
     size_t cap_sub = 0;
+    uint8_t *h_pack = nullptr, *d_pack = nullptr;  // packed host -> device transfer (h2d_pack.cpp): pinned staging + its device copy
+    size_t cap_pack = 0;
     bool has_attr = false, has_eig = false;
     DeviceBatch db{};
 
@@ -258,6 +323,10 @@ struct flowgnn_engine {
         if (d_sub) (void)hipFree(d_sub);
         d_sub = nullptr;
         cap_sub = 0;
+        if (h_pack) (void)hipHostFree(h_pack);
+        if (d_pack) (void)hipFree(d_pack);
+        h_pack = d_pack = nullptr;
+        cap_pack = 0;
         capG = capN = capE = 0;
     }
 };
@@ -492,8 +561,10 @@ int flowgnn_graph_tile_fill(flowgnn_engine* e, int num_graphs, const int* nums_o
     return FLOWGNN_OK;
 }
 
-int flowgnn_set_batch(flowgnn_engine* e, int num_graphs, const int* nums_of_nodes, const int* nums_of_edges,
-                      const int* node_feature, const int* edge_list, const int* edge_attr, const float* node_eigen) {
+// copy_mu (flowgnn_group_compute): held around the large host -> device copies only -- one copier per DEVICE at a time, while another
+// engine of the same device packs its next range on the host or packs its tiles
+static int set_batch_impl(flowgnn_engine* e, int num_graphs, const int* nums_of_nodes, const int* nums_of_edges,
+                          const int* node_feature, const int* edge_list, const int* edge_attr, const float* node_eigen, std::mutex* copy_mu) {
     if (!e || num_graphs < 0) return FLOWGNN_ERR_ARG;
     if (num_graphs > 0 && (!nums_of_nodes || !nums_of_edges)) return FLOWGNN_ERR_ARG;
     const bool attr = e->model->has_edge_attr();
@@ -550,10 +621,41 @@ int flowgnn_set_batch(flowgnn_engine* e, int num_graphs, const int* nums_of_node
         e->d_ne = e->d_nn + G; e->d_noff = e->d_nn + 2 * G; e->d_eoff = e->d_nn + 3 * G + 1;
         ENGINE_TRY(e, h2d(e->d_nn, meta.data(), sizeof(int) * meta.size()));
     }
-    ENGINE_TRY(e, h2d(e->d_nf, node_feature, sizeof(int) * (size_t)N * ND_FEATURE));
-    ENGINE_TRY(e, h2d(e->d_el, edge_list, sizeof(int) * (size_t)E * 2));
-    if (attr) ENGINE_TRY(e, h2d(e->d_ea, edge_attr, sizeof(int) * (size_t)E * EDGE_ATTR));
-    if (eig) ENGINE_TRY(e, h2d(e->d_eig, node_eigen, sizeof(float) * (size_t)N * 4));
+    // The three int32 arrays narrowed on the host (9 B per node, 5 B per edge: a quarter of the bytes), copied from pinned memory and
+    // widened again on the GPU (h2d_pack.cpp; option h2d_pack, 0 = off).  Large batches only: below a few megabytes the plain copies
+    // are latency, not bytes.  Not for GAT (its nine node features are NUMBERS, any integer is valid input) nor for graphs whose
+    // node ids do not fit 16 bits.
+    const size_t plain_bytes = sizeof(int) * ((size_t)N * ND_FEATURE + (size_t)E * 2 + (attr ? (size_t)E * EDGE_ATTR : 0));
+    const int pack_threads = e->opts.i("h2d_pack") > 0 ? host_threads(e->opts.i("h2d_pack")) : 0;
+    if (pack_threads > 0 && e->copy_stream && plain_bytes >= ((size_t)8 << 20) && mx_n <= 65535 && e->model_id != FLOWGNN_MODEL_GAT) {
+        size_t off_e = 0, off_a = 0;
+        const size_t pb = fg::h2d_pack_bytes((size_t)N, (size_t)E, attr, &off_e, &off_a);
+        if (pb > e->cap_pack) {
+            if (e->h_pack) (void)hipHostFree(e->h_pack);
+            if (e->d_pack) (void)hipFree(e->d_pack);
+            e->h_pack = e->d_pack = nullptr;
+            e->cap_pack = 0;
+            const size_t cap = pb + pb / 8;
+            EHIP_TRY(e, hipHostMalloc((void**)&e->h_pack, cap, hipHostMallocDefault));
+            EHIP_TRY(e, hipMalloc((void**)&e->d_pack, cap));
+            e->cap_pack = cap;
+        }
+        fg::h2d_pack(node_feature, edge_list, attr ? edge_attr : nullptr, (size_t)N, (size_t)E, e->h_pack, pack_threads);
+        std::unique_lock<std::mutex> lk;
+        if (copy_mu) lk = std::unique_lock<std::mutex>(*copy_mu);
+        EHIP_TRY(e, hipMemcpyAsync(e->d_pack, e->h_pack, pb, hipMemcpyHostToDevice, e->copy_stream));
+        launch_unpack_batch(e->d_pack, e->d_pack + off_e, attr ? e->d_pack + off_a : nullptr, e->d_nf, e->d_el, attr ? e->d_ea : nullptr,
+                            (long long)N, (long long)E, e->copy_stream);
+        if (eig) EHIP_TRY(e, hipMemcpyAsync(e->d_eig, node_eigen, sizeof(float) * (size_t)N * 4, hipMemcpyHostToDevice, e->copy_stream));
+        EHIP_TRY(e, hipStreamSynchronize(e->copy_stream));
+    } else {
+        std::unique_lock<std::mutex> lk;
+        if (copy_mu) lk = std::unique_lock<std::mutex>(*copy_mu);
+        ENGINE_TRY(e, h2d(e->d_nf, node_feature, sizeof(int) * (size_t)N * ND_FEATURE));
+        ENGINE_TRY(e, h2d(e->d_el, edge_list, sizeof(int) * (size_t)E * 2));
+        if (attr) ENGINE_TRY(e, h2d(e->d_ea, edge_attr, sizeof(int) * (size_t)E * EDGE_ATTR));
+        if (eig) ENGINE_TRY(e, h2d(e->d_eig, node_eigen, sizeof(float) * (size_t)N * 4));
+    }
 
     // graph-aligned tiles for kernels that keep whole graphs on chip across layers (GraphTiles, common.h)
     e->db.gtiles = GraphTiles{};
@@ -702,6 +804,11 @@ int flowgnn_set_batch(flowgnn_engine* e, int num_graphs, const int* nums_of_node
     e->force_exact = false;
     e->batch_ready = true;
     return FLOWGNN_OK;
+}
+
+int flowgnn_set_batch(flowgnn_engine* e, int num_graphs, const int* nums_of_nodes, const int* nums_of_edges,
+                      const int* node_feature, const int* edge_list, const int* edge_attr, const float* node_eigen) {
+    return set_batch_impl(e, num_graphs, nums_of_nodes, nums_of_edges, node_feature, edge_list, edge_attr, node_eigen, nullptr);
 }
 
 int flowgnn_run(flowgnn_engine* e) {
@@ -1428,14 +1535,13 @@ int flowgnn_group_compute(flowgnn_group* g, int num_graphs, const int* nums_of_n
             if (g1 == g0) continue;
             const long long n0 = noff[(size_t)j], e0 = eoff[(size_t)j];
             int r;
-            {   // one host -> device copy per DEVICE at a time: two threads copying from pageable memory to the same GPU get a
-                // quarter of the rate each (6.0 ms against 1.4 for a 67 MB range), and the ranges would then march in lockstep
-                // instead of alternating copy / kernels
-                std::lock_guard<std::mutex> lk(*g->copy_mu[(size_t)g->copy_of[(size_t)i]]);
-                r = flowgnn_set_batch(e, g1 - g0, nums_of_nodes + g0, nums_of_edges + g0, node_feature ? node_feature + n0 * 9 : nullptr,
-                                      edge_list ? edge_list + e0 * 2 : nullptr, edge_attr ? edge_attr + e0 * 3 : nullptr,
-                                      node_eigen ? node_eigen + n0 * 4 : nullptr);
-            }
+            // one host -> device copy per DEVICE at a time (the mutex is taken inside, around the copies only: the host-side packing of
+            // this range runs under the other engine's copy): two threads copying from pageable memory to the same GPU get a quarter
+            // of the rate each (6.0 ms against 1.4 for a 67 MB range), and the ranges would then march in lockstep instead of
+            // alternating copy / kernels
+            r = set_batch_impl(e, g1 - g0, nums_of_nodes + g0, nums_of_edges + g0, node_feature ? node_feature + n0 * 9 : nullptr,
+                               edge_list ? edge_list + e0 * 2 : nullptr, edge_attr ? edge_attr + e0 * 3 : nullptr,
+                               node_eigen ? node_eigen + n0 * 4 : nullptr, g->copy_mu[(size_t)g->copy_of[(size_t)i]].get());
             if (!r) r = flowgnn_run(e);
             if (!r) r = flowgnn_get_results(e, out_host + (size_t)g0 * T);
             if (r) return r;

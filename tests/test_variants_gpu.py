@@ -492,3 +492,52 @@ def test_tiles_full_of_one_node_graphs(oracle, model):
     e.close()
     assert got.shape == want.shape
     assert np.allclose(got, want, rtol=1e-4, atol=1e-4), np.abs(got - want).max()
+
+
+@pytest.mark.parametrize("model", ["GIN", "GCN", "PNA", "DGN"])
+def test_packed_host_to_device_transfer_is_the_plain_one(model):
+    """Option h2d_pack (default on for batches of >= 8 MB): flowgnn_set_batch narrows node_feature / edge_list / edge_attr on host
+    threads (9 B per node, 5 B per edge), copies a quarter of the bytes from pinned memory and widens them on the GPU into the
+    reference's int32 layout.  Same logits bit for bit as the plain copies -- through the engine and through the drop-in symbol --
+    and values that do not fit the narrow types (a feature of 300 or -7, a node id of 70 000, an attribute of 9) are refused with
+    the code the plain path gives."""
+    from flowgnn_amd import FlowGNNError, compute_graphs, entry_set_option
+    hep = model in ("PNA", "DGN")
+    b = (gp.synth_hep10k_batch(2500, seed=11) if hep else gp.synth_molhiv_batch(9000, seed=11) if model == "GIN" else gp.synth_molpcba_batch(9000, seed=11))
+    assert 4 * (b.node_feature.size + b.edge_list.size + (0 if hep else b.edge_attr.size)) >= 8 << 20
+    w = weights.SYNTH[model](seed=7)
+    outs = {}
+    for pack in (16, 0):
+        e = Engine(model, device=0, options={"h2d_pack": pack})
+        e.set_weights(w)
+        outs[pack] = e.forward(b)
+        codes = []
+        for kind in ("feat_big", "feat_neg", "node_big") + (() if hep else ("attr",)):
+            nf, el, ea = b.node_feature.copy(), b.edge_list.copy(), b.edge_attr.copy()
+            if kind == "feat_big":
+                nf[1234, 3] = 300
+            elif kind == "feat_neg":
+                nf[77, 0] = -7
+            elif kind == "node_big":
+                el[4321, 1] = 70000
+            else:
+                ea[999, 1] = 9
+            bad = gp.GraphBatch(b.nums_of_nodes, b.nums_of_edges, nf, el, ea, b.node_eigen)
+            with pytest.raises(FlowGNNError) as ei:
+                e.forward(bad)
+            codes.append(ei.value.code)
+        outs[("codes", pack)] = codes
+        assert np.array_equal(e.forward(b), outs[pack])  # the engine works again with the next good batch
+        e.close()
+    assert np.array_equal(outs[16], outs[0])
+    assert outs[("codes", 16)] == outs[("codes", 0)], (outs[("codes", 16)], outs[("codes", 0)])
+    try:
+        entry_set_option(model, "h2d_pack", 16)
+        packed = compute_graphs(model, b, [w])
+        entry_set_option(model, "h2d_pack", 0)
+        plain = compute_graphs(model, b, [w])
+    finally:
+        entry_set_option(model, "h2d_pack", 16)
+    assert np.array_equal(packed, plain)
+    if model != "DGN":  # (DGN's matrix-pipe sums depend on the tile a graph lands in: the entry point cuts ranges)
+        assert np.array_equal(packed, outs[16])
