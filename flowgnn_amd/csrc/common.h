@@ -134,6 +134,16 @@ struct GraphTiles {
     int n_big = 0;
     bool sub_ok = false;
     double sub_fill = 0.0;             // rows of the sub-tiles' graphs / (n_sub * sub_rows)
+    // Third packing (Model::wants_packed_tile_lists): the same graphs BIN-PACKED into tiles (best fit, largest first, inside windows
+    // of 1 024 consecutive graphs) instead of cut in batch order -- tiles of graphs that are a large part of a tile (49-node graphs
+    // in 128-row tiles) go from 80 % to 95 % full, and a resident kernel's time is per TILE.  A tile is then a LIST of graphs, not a
+    // range: bp_list holds graph ids in tile order, bp_graph[t] .. bp_graph[t + 1] index it, bp_row[t] is the tile's first row in the
+    // tile-ordered row space its own tile-build kernel writes (what the resident kernel reads is all tile-ordered).
+    const int* bp_list = nullptr;      // device [num_graphs]
+    const int* bp_lrow = nullptr;      // device [num_graphs]: the first row, inside its tile, of the graph at this list position
+    const int* bp_graph = nullptr;     // device [bp_tiles + 1]
+    const int* bp_row = nullptr;       // device [bp_tiles + 1]
+    int bp_tiles = 0;                  // 0: not built
 };
 
 // Everything a model's forward needs about the resident batch.
@@ -202,6 +212,8 @@ public:
     virtual void graph_tile_limits(int& rows, int& edges) const { rows = 0; edges = 0; }
     // rows > 0: flowgnn_set_batch also packs the half-tile lists of GraphTiles (sub / big_*)
     virtual void sub_tile_limits(int& rows, int& edges) const { rows = 0; edges = 0; }
+    // true: flowgnn_set_batch also bin-packs the graphs into tile LISTS (GraphTiles::bp_*)
+    virtual bool wants_packed_tile_lists() const { return false; }
     virtual int emb_dim() const = 0;
     virtual int scratch_dim() const = 0;          // floats per node of scratch the forward needs
     virtual bool has_edge_attr() const = 0;

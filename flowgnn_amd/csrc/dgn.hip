@@ -798,13 +798,18 @@ __global__ __launch_bounds__(512, 2) void dgn_layer_mfma_kernel(const float* __r
 // REC (the graph-resident kernel's tile build): the row's record is 12 words -- the eight above, eig1[v], and the nine encoder
 // table rows offset_k + feature_k (validated as atom_encoder_kernel validates them) as bytes: everything dgn_resident_kernel reads
 // per row.  Duplicate edges need no CSR there (that kernel re-sums such rows from the caller's edge list): dup_flag is not raised.
+// `list` (REC only, GraphTiles::bp_list; null: tile t holds the graphs tile_graph[t] .. tile_graph[t + 1] - 1 and its rows are the batch's
+// rows tile_row[t] ..): tile t holds the graphs list[tile_graph[t]] .. list[tile_graph[t + 1] - 1], one behind the other, and
+// tile_row[t] is its first row in the tile-ordered record space -- a row's inputs (features, eig1) are then found through its graph.
 template <bool REC>
 __global__ __launch_bounds__(256) void dgn_rowinfo_kernel(BatchView b, const int* __restrict__ tile_row, const int* __restrict__ tile_graph,
                                                           int n_tiles, const float* __restrict__ eig4, uint32_t* __restrict__ rowinfo,
-                                                          int* __restrict__ out_deg, int* __restrict__ err, int* __restrict__ dup_flag) {
+                                                          int* __restrict__ out_deg, int* __restrict__ err, int* __restrict__ dup_flag,
+                                                          const int* __restrict__ list = nullptr) {
     __shared__ uint32_t s_adj[DGN_FT_ROWS][4];
     __shared__ int s_odeg[DGN_FT_ROWS], s_ndup[DGN_FT_ROWS];
     __shared__ float s_eig[DGN_FT_ROWS];
+    __shared__ int s_node[DGN_FT_ROWS];  // the batch's node behind every row of the tile
     const int tile = blockIdx.x, tid = threadIdx.x;
     if (tile >= n_tiles) return;
     const int t0 = tile_row[tile];
@@ -814,25 +819,42 @@ __global__ __launch_bounds__(256) void dgn_rowinfo_kernel(BatchView b, const int
     if (tid < DGN_FT_ROWS) {
         s_adj[tid][0] = 0u; s_adj[tid][1] = 0u; s_adj[tid][2] = 0u; s_adj[tid][3] = 0u;
         s_odeg[tid] = 0; s_ndup[tid] = 0;
-        s_eig[tid] = tid < rows ? eig4[(size_t)(t0 + tid) * 4 + 1] : 0.0f;
+        s_node[tid] = 0;
     }
     __syncthreads();
-    for (int gph = g0; gph < g1; gph++) {  // (a handful of graphs per tile; their headers are wave-uniform scalar loads)
-        const int n = b.nums_of_nodes[gph], base = b.node_off[gph] - t0, e0 = b.edge_off[gph], ne = b.edge_off[gph + 1] - e0;
-        for (int e = tid; e < ne; e += 256) {
-            const int2 uv = reinterpret_cast<const int2*>(b.edge_list)[e0 + e];
-            int u = uv.x, v = uv.y;
-            if (!((u >= 0) & (u < n) & (v >= 0) & (v < n))) {  // as the index build: flag it, then a self-loop on the graph's node 0
-                atomicMax(err, ERR_EDGE_RANGE);
-                u = 0;
-                v = 0;
+    {
+        int run = 0;
+        for (int i = g0; i < g1; i++) {
+            const int gph = list ? list[i] : i;
+            const int n = b.nums_of_nodes[gph], first = b.node_off[gph], base = list ? run : first - t0;
+            for (int k = tid; k < n; k += 256)
+                if (base + k < DGN_FT_ROWS) s_node[base + k] = first + k;
+            run += n;
+        }
+    }
+    __syncthreads();
+    if (tid < DGN_FT_ROWS) s_eig[tid] = tid < rows ? eig4[(size_t)s_node[tid] * 4 + 1] : 0.0f;
+    {
+        int run = 0;
+        for (int i = g0; i < g1; i++) {
+            const int gph = list ? list[i] : i;
+            const int n = b.nums_of_nodes[gph], base = list ? run : b.node_off[gph] - t0, e0 = b.edge_off[gph], ne = b.edge_off[gph + 1] - e0;
+            run += n;
+            for (int e = tid; e < ne; e += 256) {
+                const int2 uv = reinterpret_cast<const int2*>(b.edge_list)[e0 + e];
+                int u = uv.x, v = uv.y;
+                if (!((u >= 0) & (u < n) & (v >= 0) & (v < n))) {  // as the index build: flag it, then a self-loop on the graph's node 0
+                    atomicMax(err, ERR_EDGE_RANGE);
+                    u = 0;
+                    v = 0;
+                }
+                u += base; v += base;
+                if (u >= DGN_FT_ROWS || v >= DGN_FT_ROWS) continue;  // (cannot happen: the host packed whole graphs into <= 128 rows)
+                const uint32_t bit = 1u << (u & 31);
+                const uint32_t old = atomicOr(&s_adj[v][u >> 5], bit);
+                if (old & bit) atomicAdd(&s_ndup[v], 1);
+                atomicAdd(&s_odeg[u], 1);
             }
-            u += base; v += base;
-            if (u >= DGN_FT_ROWS || v >= DGN_FT_ROWS) continue;  // (cannot happen: the host packed whole graphs into <= 128 rows)
-            const uint32_t bit = 1u << (u & 31);
-            const uint32_t old = atomicOr(&s_adj[v][u >> 5], bit);
-            if (old & bit) atomicAdd(&s_ndup[v], 1);
-            atomicAdd(&s_odeg[u], 1);
         }
     }
     __syncthreads();
@@ -849,8 +871,11 @@ __global__ __launch_bounds__(256) void dgn_rowinfo_kernel(BatchView b, const int
                 int mult = 1;
                 if (nd > 0) {  // how many copies of (u -> v) the caller listed: a scan over the tile's edges (rows with duplicates only)
                     mult = 0;
-                    for (int gph = g0; gph < g1; gph++) {
-                        const int n = b.nums_of_nodes[gph], base = b.node_off[gph] - t0, e0 = b.edge_off[gph], ne = b.edge_off[gph + 1] - e0;
+                    int run = 0;
+                    for (int i = g0; i < g1; i++) {
+                        const int gph = list ? list[i] : i;
+                        const int n = b.nums_of_nodes[gph], base = list ? run : b.node_off[gph] - t0, e0 = b.edge_off[gph], ne = b.edge_off[gph + 1] - e0;
+                        run += n;
                         if (v < base || v >= base + n) continue;
                         for (int e = 0; e < ne; e++) {
                             const int2 uv = reinterpret_cast<const int2*>(b.edge_list)[e0 + e];
@@ -878,7 +903,7 @@ __global__ __launch_bounds__(256) void dgn_rowinfo_kernel(BatchView b, const int
         *reinterpret_cast<uint4*>(ri + 4) = make_uint4(__builtin_bit_cast(uint32_t, wsum), __builtin_bit_cast(uint32_t, abssum), (uint32_t)nd, (uint32_t)s_odeg[v]);
         if constexpr (REC) {
             uint32_t fw[3] = {0u, 0u, 0u};
-            const int* nf = b.node_feature + (size_t)(t0 + v) * ND_FEATURE;
+            const int* nf = b.node_feature + (size_t)s_node[v] * ND_FEATURE;
 #pragma unroll
             for (int k = 0; k < ND_FEATURE; k++) {
                 int f = nf[k];
@@ -1039,9 +1064,10 @@ struct DgnResidentArgs {
     const uint32_t* rec;      // [n_tot + 128][12] (dgn_tile_build_kernel<true>)
     const float* table;       // [173][100]
     const uint8_t* wpk;       // 4 x DGN_FT_LAYER_BYTES (dgn_pack_fused_layer)
-    const int* tile_row;      // GraphTiles::row_start
-    const int* tile_graph;    // GraphTiles::graph_start
-    BatchView b;              // node_off for the readout; the edge list for rows with duplicate in-edges
+    const int* tile_row;      // GraphTiles::row_start, or bp_row (the tile's first row in the record space)
+    const int* tile_graph;    // GraphTiles::graph_start, or bp_graph
+    const int* list;          // GraphTiles::bp_list (tile t = the graphs list[tile_graph[t]] ..), or null (tile t = graphs tile_graph[t] ..)
+    BatchView b;              // node counts for the readout; the edge list for rows with duplicate in-edges
     const float* head;        // DGN_HEAD_BYTES: w1 [100][50] and w2 [50][25] transposed ([in][out]: unit along the lanes), b1, b2, w3, b3
     float* out;               // [G]
     int* range_flag;
@@ -1185,7 +1211,37 @@ __global__ __launch_bounds__(512, 2) void dgn_resident_kernel(const DgnResidentA
         }
         const bool dups = __any(ndup > 0);
         const int g0 = a.tile_graph[tile], g1 = a.tile_graph[tile + 1];
-        const int my_noff = a.b.node_off[g0 + lane < g1 ? g0 + lane : g1];  // for the readout, 28 K-steps from here
+        // the first row (inside the tile) of each of the tile's first 63 graphs, one per lane; lane = graph count: the tile's rows.  For the
+        // readout, 28 K-steps from here, and the rare rows with duplicate in-edges
+        int my_noff;
+        if (a.list) {  // a list of graphs: running sum of their node counts (inclusive scan over the lanes, shifted by one)
+            const int cnt = g0 + lane < g1 ? a.b.nums_of_nodes[a.list[g0 + lane]] : 0;
+            int incl = cnt;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const int o = __shfl_up(incl, d, 64);
+                if (lane >= d) incl += o;
+            }
+            my_noff = incl - cnt;
+        } else {
+            my_noff = a.b.node_off[g0 + lane < g1 ? g0 + lane : g1] - t0;
+        }
+        // graph gl of the tile (wave-uniform): its id and its rows [n0, n1) inside the tile
+        auto tile_graph_at = [&](int gl, int& n0, int& n1) {
+            const int gph = a.list ? a.list[g0 + gl] : g0 + gl;
+            if (gl < 63) {
+                n0 = __builtin_amdgcn_readlane(my_noff, gl);
+                n1 = gl + 1 < g1 - g0 ? __builtin_amdgcn_readlane(my_noff, gl + 1) : rows;
+            } else if (!a.list) {
+                n0 = a.b.node_off[gph] - t0;
+                n1 = a.b.node_off[gph + 1] - t0;
+            } else {  // beyond the lanes' reach (a tile of more than 63 graphs of one or two nodes): count again
+                n0 = 0;
+                for (int i = 0; i < gl; i++) n0 += a.b.nums_of_nodes[a.list[g0 + i]];
+                n1 = n0 + a.b.nums_of_nodes[gph];
+            }
+            return gph;
+        };
 #pragma unroll 1
         for (int l = 0; l < DGN_L; l++) {
             const float oscale = s_bias[l * 128 + 112];
@@ -1234,8 +1290,10 @@ __global__ __launch_bounds__(512, 2) void dgn_resident_kernel(const DgnResidentA
                              // over the CSR does (there in ascending u, here in list order: the same bits while a row repeats one source only)
                     const bool mine = ndup > 0 && real;
                     uint32_t seen0 = 0u, seen1 = 0u, seen2 = 0u, seen3 = 0u;
-                    for (int gph = g0; gph < g1; gph++) {
-                        const int n = a.b.nums_of_nodes[gph], base = a.b.node_off[gph] - t0, e0 = a.b.edge_off[gph], ne = a.b.edge_off[gph + 1] - e0;
+                    for (int gl = 0; gl < g1 - g0; gl++) {
+                        int base, gend;
+                        const int gph = tile_graph_at(gl, base, gend);
+                        const int n = gend - base, e0 = a.b.edge_off[gph], ne = a.b.edge_off[gph + 1] - e0;
                         if (!__any(mine && lr >= base && lr < base + n)) continue;
                         for (int e = 0; e < ne; e++) {
                             int u = load_i32_rare(a.b.edge_list + 2 * (size_t)(e0 + e)), v = load_i32_rare(a.b.edge_list + 2 * (size_t)(e0 + e) + 1);
@@ -1341,10 +1399,9 @@ __global__ __launch_bounds__(512, 2) void dgn_resident_kernel(const DgnResidentA
             float* s_o1 = s_hg + DGN_D;
             static_assert((DGN_FT_ROWS * DGN_D + RW * 160) * 4 <= 2 * DGN_HT_BYTES, "readout scratch behind the rows");
             const int half = lane >> 5, c = lane & 31;
-            auto pool = [&](int gi) {  // mean over the graph's rows -> s_hg (even rows | odd rows, then the two halves)
-                const int gl = gi - g0;  // node offsets of the tile's first 63 graphs: requested at the top of the tile, one per lane
-                const int n0 = (gl < 63 ? __builtin_amdgcn_readlane(my_noff, gl) : a.b.node_off[gi]) - t0;
-                const int n1 = (gl + 1 < 64 ? __builtin_amdgcn_readlane(my_noff, gl + 1) : a.b.node_off[gi + 1]) - t0;
+            auto pool = [&](int gl) {  // mean over the rows of the tile's graph gl -> s_hg (even rows | odd rows, then the two halves); -> its id
+                int n0, n1;
+                const int gph = tile_graph_at(gl, n0, n1);
                 float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (c < DGN_C) {
                     int v = n0 + half;
@@ -1368,6 +1425,7 @@ __global__ __launch_bounds__(512, 2) void dgn_resident_kernel(const DgnResidentA
                     s_hg[4 * c + 2] = sum.z / n; s_hg[4 * c + 3] = sum.w / n;
                 }
                 __builtin_amdgcn_wave_barrier();
+                return gph;
             };
             auto head = [&](int gi) {
                 const float p = dgn_head_wave(s_hg, s_o1, s_head, 50, s_head + DGN_HEAD_W2, 25, lane < 50 ? s_head[DGN_HEAD_B1 + lane] : 0.0f,
@@ -1375,14 +1433,14 @@ __global__ __launch_bounds__(512, 2) void dgn_resident_kernel(const DgnResidentA
                 if (lane == 0) a.out[gi] = s_head[DGN_HEAD_B3] + p;
                 __builtin_amdgcn_wave_barrier();
             };
-            int gi = g0 + wave;
-            const bool have = wave < RW && gi < g1;
-            if (have) pool(gi);  // the wave's first graph is pooled while the head block travels
+            int gl = wave, gi = 0;
+            const bool have = wave < RW && gl < g1 - g0;
+            if (have) gi = pool(gl);  // the wave's first graph is pooled while the head block travels
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();  // every wave's pieces of the head have landed
             if (have) {
                 head(gi);
-                for (gi += RW; gi < g1; gi += RW) { pool(gi); head(gi); }
+                for (gl += RW; gl < g1 - g0; gl += RW) { gi = pool(gl); head(gi); }
             }
             __syncthreads();  // the slots are the next tile's again (its first chunk request is its first statement)
         }
@@ -1564,6 +1622,7 @@ public:
         rows = fused_ ? DGN_FT_ROWS : 0;
         edges = fused_ ? DGN_FT_EDGES : 0;
     }
+    bool wants_packed_tile_lists() const override { return fused_ && resident_ != 0 && binpack_ && !qmode_; }
 
     bool use_fused(const DeviceBatch& db) const {
         // tiles that are mostly empty (graphs of 65..128 nodes) waste MFMA columns: below 40 % full the two-kernel layer is used
@@ -1587,21 +1646,27 @@ public:
     int forward_resident(DeviceBatch& db, Profiler& prof, hipStream_t s) {
         const int n = db.b.n_tot;
         if (int rc = rec_.reserve(((size_t)n + DGN_FT_ROWS) * DGN_REC_DW)) return rc;  // (a tile's DMA reads 128 records whatever its rows)
+        // bin-packed tile lists when flowgnn_set_batch made them (option dgn_binpack): fewer, fuller tiles of the same graphs
+        const bool bp = binpack_ && db.gtiles.bp_tiles > 0;
+        const int* t_row = bp ? db.gtiles.bp_row : db.gtiles.row_start;
+        const int* t_graph = bp ? db.gtiles.bp_graph : db.gtiles.graph_start;
+        const int* t_list = bp ? db.gtiles.bp_list : nullptr;
+        const int n_tiles = bp ? db.gtiles.bp_tiles : db.gtiles.n_tiles;
         {
             ProfScope p(prof, "dgn_tile_build", s);
-            dgn_rowinfo_kernel<true><<<db.gtiles.n_tiles, 256, 0, s>>>(db.b, db.gtiles.row_start, db.gtiles.graph_start, db.gtiles.n_tiles, db.node_eigen,
-                                                                       reinterpret_cast<uint32_t*>(rec_.p), nullptr, db.csr.err, nullptr);
+            dgn_rowinfo_kernel<true><<<n_tiles, 256, 0, s>>>(db.b, t_row, t_graph, n_tiles, db.node_eigen, reinterpret_cast<uint32_t*>(rec_.p),
+                                                             nullptr, db.csr.err, nullptr, t_list);
         }
         DgnResidentArgs a;
         a.rec = reinterpret_cast<const uint32_t*>(rec_.p);
         a.table = d_emb_;
         a.wpk = d_fused_;
-        a.tile_row = db.gtiles.row_start; a.tile_graph = db.gtiles.graph_start;
+        a.tile_row = t_row; a.tile_graph = t_graph; a.list = t_list;
         a.b = db.b;
         a.head = d_head_;
         a.out = db.out; a.range_flag = db.range_flag;
-        a.n_tiles = db.gtiles.n_tiles;
-        const int grid = db.gtiles.n_tiles < 256 ? db.gtiles.n_tiles : 256;  // persistent: one 8-wave workgroup per CU (157 KB of LDS)
+        a.n_tiles = n_tiles;
+        const int grid = n_tiles < 256 ? n_tiles : 256;  // persistent: one 8-wave workgroup per CU (157 KB of LDS)
         {
             ProfScope p(prof, "dgn_resident", s);
             dgn_resident_kernel<<<grid, 512, 0, s>>>(a);
@@ -1722,6 +1787,7 @@ public:
         fold_readout_ = o.on("dgn_fold_readout");
         rowinfo_direct_ = o.on("dgn_rowinfo_direct");
         resident_ = o.i("dgn_resident");
+        binpack_ = o.on("dgn_binpack");
         ablate_ = FG_ABLATE(o.i("dgn_ablate"));
         agg_ready_ = false;
     }
@@ -1771,6 +1837,7 @@ private:
     bool rowinfo_direct_ = true;
     GrowBufI rec_;       // dgn_resident_kernel: 48 B per row (dgn_rowinfo_kernel<true>)
     int resident_ = 1;   // dgn_resident
+    bool binpack_ = true;  // dgn_binpack: the resident kernel walks bin-packed tile lists (GraphTiles::bp_*)
     float* d_head_ = nullptr;  // the resident kernel's readout: head weights transposed + biases in one block (DGN_HEAD_BYTES)
     GrowBufI ginfo_, pool_cnt_;  // POOL form of the last layer: (graph, position) per node; partial rows per graph
     GrowBuf pool_part_;          //   [G][8][100] per-wave partial sums of h_4

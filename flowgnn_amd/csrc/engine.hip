@@ -101,14 +101,14 @@ static const OptionDef kOptionTable[] = {
     {"tile_slack", -1},
     {"h2d_pack", 16},             // flowgnn_set_batch: host threads that narrow a large batch's int32 arrays for the transfer (h2d_pack.cpp); 0: plain copies
     {"tile_balance", 1},          // graph tiles of a batch of <= 8 rounds over the CUs: fewer rows per tile, whole rounds of tiles (flowgnn_set_batch)
-    {"gin_resident", 1}, {"gin_tile_build", -1}, {"gin_resident_min_fill", 0.5}, {"gin_resident_nosort", 0}, {"gin_resident_prof", 0},
+    {"gin_resident", 1}, {"gin_binpack", 1}, {"gin_tile_build", -1}, {"gin_resident_min_fill", 0.5}, {"gin_resident_nosort", 0}, {"gin_resident_prof", 0},
     {"gin_unfused", 0}, {"gin_mfma", 16}, {"gin_split_nt", 4}, {"gin_fold_readout", 1}, {"gin_head_fold", 1},
     {"gin_agg_untiled", 0}, {"gin_agg_tile", 128},
     {"gcn_resident", 1}, {"gcn_tile_build", 1}, {"gcn_unfused", 0}, {"gcn_mfma", 16},
     {"gat_resident", 1}, {"gat_mfma", 16}, {"gat_fold_readout", 1}, {"gat_reference_quirk", 0},
     {"pna_resident", 1}, {"pna_tile_build", 1}, {"pna_fused", 1}, {"pna_mfma", 16},
     {"pna_mfma_agg", 0},          // deprecated (removed in round 5, the kernel it selected is gone): accepted and ignored, so that callers' scripts keep working
-    {"dgn_fused", 1}, {"dgn_mfma", 16}, {"dgn_mfma_agg", -1}, {"dgn_fold_readout", 1}, {"dgn_rowinfo_direct", 1}, {"dgn_resident", 1},
+    {"dgn_fused", 1}, {"dgn_mfma", 16}, {"dgn_mfma_agg", -1}, {"dgn_fold_readout", 1}, {"dgn_rowinfo_direct", 1}, {"dgn_resident", 1}, {"dgn_binpack", 1},
 #ifdef FLOWGNN_DEV
     {"gcn_ablate", 0}, {"gat_ablate", 0}, {"pna_ablate", 0}, {"dgn_ablate", 0}, {"gin_pingpong", 0},
 #endif
@@ -281,6 +281,8 @@ struct flowgnn_engine {
     size_t cap_tiles = 0;
     int* d_sub = nullptr;                        // GraphTiles::sub | big_row | big_graph in one allocation
     size_t cap_sub = 0;
+    int* d_bp = nullptr;                         // GraphTiles::bp_list | bp_graph | bp_row in one allocation
+    size_t cap_bp = 0;
     uint8_t *h_pack = nullptr, *d_pack = nullptr;  // packed host -> device transfer (h2d_pack.cpp): pinned staging + its device copy
     size_t cap_pack = 0;
     bool has_attr = false, has_eig = false;
@@ -323,6 +325,9 @@ struct flowgnn_engine {
         if (d_sub) (void)hipFree(d_sub);
         d_sub = nullptr;
         cap_sub = 0;
+        if (d_bp) (void)hipFree(d_bp);
+        d_bp = nullptr;
+        cap_bp = 0;
         if (h_pack) (void)hipHostFree(h_pack);
         if (d_pack) (void)hipFree(d_pack);
         h_pack = d_pack = nullptr;
@@ -730,6 +735,72 @@ static int set_batch_impl(flowgnn_engine* e, int num_graphs, const int* nums_of_
                 // takes the job's side of the models' thresholds whatever its own graphs pack to
                 if (e->job_fill >= 0.0) gt.fill = e->job_fill;
             }
+        }
+        // bin-packed tile lists (GraphTiles::bp_*): best fit, largest graph first, inside windows of 1 024 consecutive graphs.  Bins are
+        // kept in buckets by the rows they have left, so placing a graph is a scan over at most t_rows buckets, not over the bins.
+        if (e->db.gtiles.ok && e->model->wants_packed_tile_lists() && num_graphs > 1) {
+            constexpr int kWindow = 1024;
+            std::vector<int> list, lrow, tstart, trow2;
+            list.reserve((size_t)num_graphs);
+            lrow.reserve((size_t)num_graphs);
+            tstart.push_back(0);
+            trow2.push_back(0);
+            struct Bin { int rows, edges; std::vector<int> graphs; };
+            std::vector<Bin> bins;
+            std::vector<std::vector<int>> bucket((size_t)t_rows + 1);  // bucket[r]: bins with r rows left
+            std::vector<int> order;
+            std::vector<int> count((size_t)t_rows + 2);
+            long long rows_done = 0;
+            for (int w0 = 0; w0 < num_graphs; w0 += kWindow) {
+                const int w1 = w0 + kWindow < num_graphs ? w0 + kWindow : num_graphs;
+                // the window's graphs by node count, largest first (counting sort: n <= t_rows; ties in batch order)
+                std::fill(count.begin(), count.end(), 0);
+                for (int g = w0; g < w1; g++) count[(size_t)(t_rows - nums_of_nodes[g]) + 1]++;
+                for (int r = 0; r <= t_rows; r++) count[(size_t)r + 1] += count[(size_t)r];
+                order.assign((size_t)(w1 - w0), 0);
+                for (int g = w0; g < w1; g++) order[(size_t)count[(size_t)(t_rows - nums_of_nodes[g])]++] = g;
+                bins.clear();
+                for (auto& b : bucket) b.clear();
+                for (int g : order) {
+                    const int n = nums_of_nodes[g], m = nums_of_edges[g];
+                    int chosen = -1;
+                    for (int r = n; r <= t_rows && chosen < 0; r++) {  // the fullest bin that still takes it
+                        std::vector<int>& bk = bucket[(size_t)r];
+                        for (size_t k = bk.size(); k-- > 0;)
+                            if (bins[(size_t)bk[k]].edges + m <= t_edges) { chosen = bk[k]; bk.erase(bk.begin() + (long)k); break; }
+                    }
+                    if (chosen < 0) { chosen = (int)bins.size(); bins.push_back(Bin{0, 0, {}}); }
+                    Bin& b = bins[(size_t)chosen];
+                    b.rows += n; b.edges += m; b.graphs.push_back(g);
+                    bucket[(size_t)(t_rows - b.rows)].push_back(chosen);
+                }
+                for (const Bin& b : bins) {
+                    int local = 0;
+                    for (int g : b.graphs) { list.push_back(g); lrow.push_back(local); local += nums_of_nodes[g]; }
+                    rows_done += b.rows;
+                    tstart.push_back((int)list.size());
+                    trow2.push_back((int)rows_done);
+                }
+            }
+            const size_t T1 = tstart.size(), total = 2 * list.size() + 2 * T1;
+            if (total > e->cap_bp) {
+                if (e->d_bp) (void)hipFree(e->d_bp);
+                e->d_bp = nullptr;
+                e->cap_bp = 0;
+                const size_t cap = total + total / 8;
+                EHIP_TRY(e, hipMalloc((void**)&e->d_bp, sizeof(int) * cap));
+                e->cap_bp = cap;
+            }
+            list.insert(list.end(), lrow.begin(), lrow.end());
+            list.insert(list.end(), tstart.begin(), tstart.end());
+            list.insert(list.end(), trow2.begin(), trow2.end());
+            ENGINE_TRY(e, h2d(e->d_bp, list.data(), sizeof(int) * total));
+            GraphTiles& gt = e->db.gtiles;
+            gt.bp_list = e->d_bp;
+            gt.bp_lrow = e->d_bp + num_graphs;
+            gt.bp_graph = e->d_bp + 2 * (size_t)num_graphs;
+            gt.bp_row = e->d_bp + 2 * (size_t)num_graphs + T1;
+            gt.bp_tiles = (int)T1 - 1;
         }
         int s_rows = 0, s_edges = 0;
         e->model->sub_tile_limits(s_rows, s_edges);

@@ -782,23 +782,32 @@ public:
         return want && use_resident(db) && !qmode_ && !keep_h_ && num_tasks_ == 1 && fold_readout_ && head_fold_ && db.b.edge_attr != nullptr;
     }
     bool needs_csr(const DeviceBatch& db) const override { return !one_pass(db); }
+    // (asked at flowgnn_set_batch, before the batch is known: the lists are built whenever the one-pass path could take them)
+    bool wants_packed_tile_lists() const override {
+        return binpack_ && resident_ && !qmode_ && num_tasks_ == 1 && fold_readout_ && head_fold_ && tile_build_ != 0 && !pingpong_;
+    }
 
     int forward(DeviceBatch& db, Profiler& prof, hipStream_t s) override {
         const int n = db.b.n_tot;
         if (n <= 0) return 0;
         if (qmode_) return ginq_forward(qw_, db, prof, s);
         if (one_pass(db)) {
-            if (int rc = perm_.reserve((size_t)db.gtiles.n_tiles * (GIN_RESIDENT_DESC_BYTES / 4))) return rc;
+            // bin-packed tile lists when flowgnn_set_batch made them (option gin_binpack): fewer, fuller tiles of the same graphs -- everything
+            // the resident kernel reads is written by the tile build in tile order, and a row's sums depend on the row alone: the same bits
+            const bool bp = binpack_ && db.gtiles.bp_tiles > 0;
+            const int* t_row = bp ? db.gtiles.bp_row : db.gtiles.row_start;
+            const int* t_graph = bp ? db.gtiles.bp_graph : db.gtiles.graph_start;
+            const int n_tiles = bp ? db.gtiles.bp_tiles : db.gtiles.n_tiles;
+            if (int rc = perm_.reserve((size_t)n_tiles * (GIN_RESIDENT_DESC_BYTES / 4))) return rc;
             if (int rc = enc_idx_.reserve((size_t)n)) return rc;
-            GinTileBuild tb{db.b, enc_idx_.p, d_enc_tab_, db.csr.err};
+            GinTileBuild tb{db.b, enc_idx_.p, d_enc_tab_, db.csr.err, bp ? db.gtiles.bp_list : nullptr, bp ? db.gtiles.bp_lrow : nullptr};
             {
                 ProfScope p(prof, "gin_tile_build", s);
-                launch_gin_tile_build(tb, db.gtiles.row_start, db.gtiles.graph_start, reinterpret_cast<uint8_t*>(perm_.p), db.gtiles.n_tiles,
-                                      virtual_node_, resident_order_, s);
+                launch_gin_tile_build(tb, t_row, t_graph, reinterpret_cast<uint8_t*>(perm_.p), n_tiles, virtual_node_, resident_order_, s);
             }
             ProfScope p(prof, "gin_resident", s);  // the whole model
-            launch_gin_resident(nullptr, nullptr, nullptr, nullptr, nullptr, d_ecomb_res_, d_rsplit_, d_pw_, d_pb_, db.gtiles.row_start,
-                                db.gtiles.graph_start, reinterpret_cast<uint8_t*>(perm_.p), db.b.node_off, db.out, db.gtiles.n_tiles,
+            launch_gin_resident(nullptr, nullptr, nullptr, nullptr, nullptr, d_ecomb_res_, d_rsplit_, d_pw_, d_pb_, t_row, t_graph,
+                                reinterpret_cast<uint8_t*>(perm_.p), db.b.node_off, db.out, n_tiles,
                                 db.range_flag, s, virtual_node_, d_head_, resident_order_, resident_prof_, &tb);
             db.final_h = 0;
             db.h_valid = false;
@@ -922,6 +931,7 @@ public:
         agg_untiled_ = o.on("gin_agg_untiled");
         agg_tile_ = o.i("gin_agg_tile");
         resident_order_ = o.i("gin_resident_nosort");
+        binpack_ = o.on("gin_binpack");
         resident_prof_ = o.on("gin_resident_prof");
         fold_readout_ = o.on("gin_fold_readout");
         resident_ = o.on("gin_resident");
@@ -985,6 +995,7 @@ private:
     int split_nt_ = 4;
     bool agg_untiled_ = false;  // gin_agg_untiled=1: the first (un-tiled) aggregation kernel, A/B measurements
     int agg_tile_ = 128;        // gin_agg_tile: 64 | 128 | 256 rows per tile of the stand-alone aggregation kernel
+    bool binpack_ = true;       // gin_binpack: the one-pass resident path walks bin-packed tile lists (GraphTiles::bp_*)
     int resident_order_ = 0;    // gin_resident_nosort: column order of the resident kernel's tiles (0 degree-sorted, 1 natural, 2 bank-aware)
     bool resident_prof_ = false;  // gin_resident_prof: phase stamps printed per launch (synchronises)
     bool exact_ = false;

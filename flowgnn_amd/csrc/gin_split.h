@@ -63,6 +63,10 @@ struct GinTileBuild {
     void* enc_idx;         // device, [n_tot] x 4 B, written by gin_tile_build_kernel
     const float* enc_tab;  // device, gin_resident_enc_table_floats() floats
     int* err;
+    // bin-packed tiles (GraphTiles::bp_list / bp_lrow; null: a tile is the range of graphs tile_graph[t] .. and of the batch's rows tile_row[t] ..):
+    // a tile is the graphs list[tile_graph[t]] .. one behind the other, tile_row[t] its first row in the tile-ordered row space
+    const int* list = nullptr;
+    const int* lrow = nullptr;
 };
 size_t gin_resident_enc_table_floats();
 void gin_resident_pack_enc_table(const float* node_embedding /* [173][100] */, float* out);

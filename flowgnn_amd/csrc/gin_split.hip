@@ -1004,9 +1004,10 @@ __device__ __forceinline__ int gr_wave_inclusive_scan(int x, int lane) {
 
 __global__ __launch_bounds__(256) void gin_tile_build_kernel(BatchView b, const int* __restrict__ tile_row, const int* __restrict__ tile_graph,
                                                              uint8_t* __restrict__ desc, uint32_t* __restrict__ enc_idx, int n_tiles, int order,
-                                                             int* __restrict__ err) {
+                                                             int* __restrict__ err, const int* __restrict__ list) {
     constexpr int EPT = GR_EDGES / 256;  // edges per thread
     __shared__ int s_eoff[GR_ROWS + 1], s_noff[GR_ROWS + 1];  // edge / row offsets of the tile's graphs, relative to the tile
+    __shared__ int s_ebase[GR_ROWS + 1], s_nbase[GR_ROWS + 1];  // + these = the batch's edge / node behind a tile-local edge / row of that graph
     __shared__ int s_cnt[GR_ROWS + 1], s_cur[GR_ROWS];
     __shared__ unsigned s_bucket[GR_EDGES];
     __shared__ int s_feat[GR_ROWS * ND_FEATURE];
@@ -1020,22 +1021,55 @@ __global__ __launch_bounds__(256) void gin_tile_build_kernel(BatchView b, const 
     const int g0 = tile_graph[tile];
     int ng = tile_graph[tile + 1] - g0;
     if (ng > GR_ROWS) ng = GR_ROWS;  // every graph has at least one node, so a validated tile never has more graphs than rows
-    const int e0 = b.edge_off[g0];
-    int ne = b.edge_off[g0 + ng] - e0;
-    if (ne > GR_EDGES) ne = GR_EDGES;  // cannot happen for a batch packed by flowgnn_set_batch; never overrun LDS
-    for (int i = r; i <= ng; i += 256) {
-        s_eoff[i] = b.edge_off[g0 + i] - e0;
-        s_noff[i] = b.node_off[g0 + i] - t0;
+    int ne;
+    if (list == nullptr) {
+        const int e0 = b.edge_off[g0];
+        ne = b.edge_off[g0 + ng] - e0;
+        for (int i = r; i <= ng; i += 256) {
+            s_eoff[i] = b.edge_off[g0 + i] - e0;
+            s_noff[i] = b.node_off[g0 + i] - t0;
+            s_ebase[i] = e0;
+            s_nbase[i] = t0;
+        }
+    } else {  // a LIST of graphs (bin-packed tiles): running sums of their counts (thread = graph, ng <= 256)
+        const int gph = r < ng ? list[g0 + r] : 0;
+        const int cn = r < ng ? b.nums_of_nodes[gph] : 0, ce = r < ng ? b.nums_of_edges[gph] : 0;
+        const int in_n = gr_wave_inclusive_scan(cn, lane), in_e = gr_wave_inclusive_scan(ce, lane);
+        __shared__ int s_wn[4], s_we[4];
+        if (lane == 63) { s_wn[wv] = in_n; s_we[wv] = in_e; }
+        __syncthreads();
+        int sn = in_n - cn, se = in_e - ce;
+        for (int w = 0; w < wv; w++) { sn += s_wn[w]; se += s_we[w]; }
+        if (r < ng) {
+            s_noff[r] = sn; s_eoff[r] = se;
+            s_nbase[r] = b.node_off[gph] - sn;
+            s_ebase[r] = b.edge_off[gph] - se;
+        }
+        ne = s_we[0] + s_we[1] + s_we[2] + s_we[3];
+        if (r == 0) { s_noff[ng] = s_wn[0] + s_wn[1] + s_wn[2] + s_wn[3]; s_eoff[ng] = ne; }
     }
+    if (ne > GR_EDGES) ne = GR_EDGES;  // cannot happen for a batch packed by flowgnn_set_batch; never overrun LDS
     s_cnt[r] = 0;
     s_cur[r] = 0;
     if (r == 0) s_cnt[GR_ROWS] = 0;
+    if (list == nullptr) {
 #pragma unroll
-    for (int p = 0; p < ND_FEATURE; p++) {  // the tile's node features, coalesced
-        const int i = r + 256 * p;
-        s_feat[i] = i < rows * ND_FEATURE ? b.node_feature[(size_t)t0 * ND_FEATURE + i] : 0;
+        for (int p = 0; p < ND_FEATURE; p++) {  // the tile's node features, coalesced
+            const int i = r + 256 * p;
+            s_feat[i] = i < rows * ND_FEATURE ? b.node_feature[(size_t)t0 * ND_FEATURE + i] : 0;
+        }
     }
     __syncthreads();
+    if (list != nullptr && r < rows) {  // (a list's rows are scattered over the batch: every row finds its graph, then its node)
+        int lo = 0, hi = ng - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (s_noff[mid] <= r) lo = mid; else hi = mid - 1;
+        }
+        const int* nf = b.node_feature + (size_t)(s_nbase[lo] + r) * ND_FEATURE;
+#pragma unroll
+        for (int k = 0; k < ND_FEATURE; k++) s_feat[r * ND_FEATURE + k] = nf[k];
+    }
     unsigned ekey[EPT];  // (source row << 17) | (edge index inside the tile << 6) | edge code
     int edst[EPT];       // destination row, -1 = no edge
 #pragma unroll
@@ -1044,13 +1078,14 @@ __global__ __launch_bounds__(256) void gin_tile_build_kernel(BatchView b, const 
         edst[k] = -1;
         ekey[k] = 0;
         if (i < ne) {
-            const int2 uv = reinterpret_cast<const int2*>(b.edge_list)[e0 + i];
-            const int a0 = b.edge_attr[3 * (size_t)(e0 + i)], a1 = b.edge_attr[3 * (size_t)(e0 + i) + 1], a2 = b.edge_attr[3 * (size_t)(e0 + i) + 2];
             int lo = 0, hi = ng - 1;  // the graph of edge i: the last one whose first edge is <= i
             while (lo < hi) {
                 const int mid = (lo + hi + 1) >> 1;
                 if (s_eoff[mid] <= i) lo = mid; else hi = mid - 1;
             }
+            const size_t ge = (size_t)(s_ebase[lo] + i);  // the edge's place in the caller's arrays
+            const int2 uv = reinterpret_cast<const int2*>(b.edge_list)[ge];
+            const int a0 = b.edge_attr[3 * ge], a1 = b.edge_attr[3 * ge + 1], a2 = b.edge_attr[3 * ge + 2];
             const int base = s_noff[lo], n = s_noff[lo + 1] - base;
             int u = uv.x, v = uv.y;
             if (!((u >= 0) & (u < n) & (v >= 0) & (v < n))) {  // flag it, then treat as a self-loop on node 0 (as build_csr does)
@@ -1657,7 +1692,8 @@ __global__ __launch_bounds__(GR_WAVES * 64, 2) void gin_resident_kernel(const fl
                                                                        const int* __restrict__ node_off, float* __restrict__ out, int n_tiles,
                                                                        int* __restrict__ range_flag, unsigned long long* __restrict__ prof_out,
                                                                        const float* __restrict__ head_u, const uint32_t* __restrict__ enc_idx,
-                                                                       const float4* __restrict__ enc_tab, int tstride) {
+                                                                       const float4* __restrict__ enc_tab, int tstride,
+                                                                       const int* __restrict__ list, const int* __restrict__ lrow) {
     static_assert(!ENC || FOLD, "the in-kernel encoder rides on the folded last layer's steps");
     __shared__ __attribute__((aligned(16))) char s_a[GRC_CHUNK_BYTES];
     __shared__ __attribute__((aligned(16))) char s_b[GRC_CHUNK_BYTES];
@@ -1712,9 +1748,11 @@ __global__ __launch_bounds__(GR_WAVES * 64, 2) void gin_resident_kernel(const fl
             // owns the tile's longest rows and deals LDS-DMA in the MLP steps: launch -0.4 %)
             if (out != nullptr && wave == GR_WAVES - 1) {  // out == null: multi-task readout, done by the caller from the hout rows
                 for (int gi = cur.g0 + lane; gi < cur.g1; gi += 64) {  // (a tile of one-node graphs has up to GR_ROWS of them)
-                    const int n0 = node_off[gi], n1 = node_off[gi + 1];
-                    const float sum = lds_sum_in_order(s_dot + (n0 - cur.t0), n1 - n0);
-                    out[gi] = sum / (float)(n1 - n0) + pool_b[0] + head_c;
+                    // a range of graphs, or (bin-packed tiles, ENC form only) list positions: the graph's id and its first row inside the tile
+                    const int gph = list ? list[gi] : gi;
+                    const int n0 = node_off[gph], n1 = node_off[gph + 1];
+                    const float sum = lds_sum_in_order(s_dot + (list ? lrow[gi] : n0 - cur.t0), n1 - n0);
+                    out[gph] = sum / (float)(n1 - n0) + pool_b[0] + head_c;
                 }
             }
         }
@@ -1939,7 +1977,8 @@ void launch_gin_resident(const float* h0, float* hout, const int* row_ptr, const
     const float4* etab = enc ? reinterpret_cast<const float4*>(tb->enc_tab) : nullptr;
 #define GR_LAUNCH(P, H, F, E)                                                                                                        \
     gin_resident_kernel<P, H, F, E><<<grid, GR_WAVES * 64, 0, s>>>(h0, hout, ecomb_all, chunks_all, pool_w, pool_b, tile_row, tile_graph, \
-                                                                   tile_desc, node_off, out, n_tiles, range_flag, d, head_u, eidx, etab, tstride)
+                                                                   tile_desc, node_off, out, n_tiles, range_flag, d, head_u, eidx, etab, tstride, \
+                                                                   enc ? tb->list : nullptr, enc ? tb->lrow : nullptr)
 #define GR_LAUNCH_FE(P, H)                                    \
     do {                                                      \
         if (enc) GR_LAUNCH(P, H, true, true);                 \
@@ -1997,7 +2036,7 @@ void launch_gin_tile_build(const GinTileBuild& tb, const int* tile_row, const in
                            int col_order, hipStream_t s) {
     if (n_tiles <= 0) return;
     gin_tile_build_kernel<<<n_tiles, 256, 0, s>>>(tb.batch, tile_row, tile_graph, tile_desc, reinterpret_cast<uint32_t*>(tb.enc_idx), n_tiles,
-                                                  hubs ? 3 : col_order, tb.err);
+                                                  hubs ? 3 : col_order, tb.err, tb.list);
 }
 
 // the pre-combined encoder table of gin_tile_build_kernel / the resident kernel's tile loader (GRB_* layout above)

@@ -129,7 +129,7 @@ def test_resident_kernel_is_the_per_layer_path_bit_for_bit(eng, w):
     ragged molecule tiles (forced onto the matrix pipe), on a batch that ends inside a tile; flowgnn_get_h after a resident run repeats
     the pass per layer."""
     per_layer = Engine("DGN", device=0, options={"dgn_resident": 0, "dgn_fold_readout": 0, "dgn_mfma_agg": 1})
-    forced = Engine("DGN", device=0, options={"dgn_resident": 2, "dgn_mfma_agg": 1})
+    forced = Engine("DGN", device=0, options={"dgn_resident": 2, "dgn_mfma_agg": 1, "dgn_binpack": 0})  # (the per-layer path's tiles: graphs in batch order)
     for e in (per_layer, forced):
         e.set_weights(w)
     try:
@@ -137,9 +137,13 @@ def test_resident_kernel_is_the_per_layer_path_bit_for_bit(eng, w):
         for b in (gp.synth_hep10k_batch(700, seed=77), _without_duplicates(mol), gp.synth_hep10k_batch(3, seed=79)):  # kernels; the rest is toleranced, below)
             want = per_layer.forward(b)
             assert np.isfinite(want).all()
-            for e in (forced,) + ((eng,) if b.total_edges >= 8 * b.total_nodes else ()):
-                got = e.forward(b)
-                assert np.array_equal(got, want), np.abs(got - want).max()
+            got = forced.forward(b)
+            assert np.array_equal(got, want), np.abs(got - want).max()
+            # the default engine bin-packs the graphs into fuller tiles (option dgn_binpack): a graph's place in its tile, and with it the
+            # order of its matrix-pipe sums, changes -- the same values to fp32 rounding (the stated 1e-5 of a batch split)
+            packed = eng.forward(b)
+            assert np.allclose(packed, want, rtol=1e-5, atol=1e-5 * max(1.0, float(np.abs(want).max()))), np.abs(packed - want).max()
+            assert np.array_equal(packed, eng.forward(b))
             assert np.array_equal(forced.final_h(), per_layer.final_h())
         forced.profile_enable(True)
         forced.forward(gp.synth_hep10k_batch(64, seed=80))
