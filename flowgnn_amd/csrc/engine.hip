@@ -104,9 +104,9 @@ static const OptionDef kOptionTable[] = {
     {"gin_resident", 1}, {"gin_binpack", 1}, {"gin_tile_build", -1}, {"gin_resident_min_fill", 0.5}, {"gin_resident_nosort", 0}, {"gin_resident_prof", 0},
     {"gin_unfused", 0}, {"gin_mfma", 16}, {"gin_split_nt", 4}, {"gin_fold_readout", 1}, {"gin_head_fold", 1},
     {"gin_agg_untiled", 0}, {"gin_agg_tile", 128},
-    {"gcn_resident", 1}, {"gcn_tile_build", 1}, {"gcn_unfused", 0}, {"gcn_mfma", 16},
+    {"gcn_resident", 1}, {"gcn_binpack", 1}, {"gcn_tile_build", 1}, {"gcn_unfused", 0}, {"gcn_mfma", 16},
     {"gat_resident", 1}, {"gat_mfma", 16}, {"gat_fold_readout", 1}, {"gat_reference_quirk", 0},
-    {"pna_resident", 1}, {"pna_tile_build", 1}, {"pna_fused", 1}, {"pna_mfma", 16},
+    {"pna_resident", 1}, {"pna_binpack", 1}, {"pna_tile_build", 1}, {"pna_fused", 1}, {"pna_mfma", 16},
     {"pna_mfma_agg", 0},          // deprecated (removed in round 5, the kernel it selected is gone): accepted and ignored, so that callers' scripts keep working
     {"dgn_fused", 1}, {"dgn_mfma", 16}, {"dgn_mfma_agg", -1}, {"dgn_fold_readout", 1}, {"dgn_rowinfo_direct", 1}, {"dgn_resident", 1}, {"dgn_binpack", 1},
 #ifdef FLOWGNN_DEV

@@ -377,10 +377,14 @@ __device__ __forceinline__ int gcnb_wave_inclusive_scan(int x, int lane) {
     return x;
 }
 
+// `list` (GraphTiles::bp_list, bin-packed tiles; null: tile t = the graphs tile_graph[t] .. and the batch's rows tile_row[t] ..): tile t
+// = the graphs list[tile_graph[t]] .., one behind the other; everything the resident kernel reads of a tile is in its descriptor.
 __global__ __launch_bounds__(256) void gcn_tile_build_kernel(BatchView b, const int* __restrict__ tile_row, const int* __restrict__ tile_graph,
-                                                             uint8_t* __restrict__ desc, int n_tiles, int* __restrict__ err) {
+                                                             uint8_t* __restrict__ desc, int n_tiles, int* __restrict__ err,
+                                                             const int* __restrict__ list) {
     constexpr int EPT = (GCNR_EDGES + 255) / 256;  // edges per thread
     __shared__ int s_eoff[GCNR_ROWS + 1], s_noff[GCNR_ROWS + 1];  // edge / row offsets of the tile's graphs, relative to the tile
+    __shared__ int s_ebase[GCNR_ROWS + 1], s_nbase[GCNR_ROWS + 1];  // + these = the batch's edge / node behind a tile-local edge / row of that graph
     __shared__ int s_cnt[257], s_cur[256], s_odeg[256];
     __shared__ unsigned s_bucket[GCNR_EDGES];
     __shared__ int s_feat[GCNR_ROWS * ND_FEATURE];
@@ -394,20 +398,52 @@ __global__ __launch_bounds__(256) void gcn_tile_build_kernel(BatchView b, const 
     const int g0 = tile_graph[tile];
     int ng = tile_graph[tile + 1] - g0;
     if (ng > GCNR_ROWS) ng = GCNR_ROWS;  // every graph has at least one node: a validated tile never has more graphs than rows
-    const int e0 = b.edge_off[g0];
-    int ne = b.edge_off[g0 + ng] - e0;
-    if (ne > GCNR_EDGES) ne = GCNR_EDGES;  // cannot happen for a batch packed by flowgnn_set_batch; never overrun LDS
-    for (int i = r; i <= ng; i += 256) {
-        s_eoff[i] = b.edge_off[g0 + i] - e0;
-        s_noff[i] = b.node_off[g0 + i] - t0;
+    int ne;
+    if (list == nullptr) {
+        const int e0 = b.edge_off[g0];
+        ne = b.edge_off[g0 + ng] - e0;
+        for (int i = r; i <= ng; i += 256) {
+            s_eoff[i] = b.edge_off[g0 + i] - e0;
+            s_noff[i] = b.node_off[g0 + i] - t0;
+            s_ebase[i] = e0;
+            s_nbase[i] = t0;
+        }
+    } else {  // a LIST of graphs (bin-packed tiles): running sums of their counts (thread = graph, ng <= 192)
+        const int gph = r < ng ? list[g0 + r] : 0;
+        const int cn = r < ng ? b.nums_of_nodes[gph] : 0, ce = r < ng ? b.nums_of_edges[gph] : 0;
+        const int in_n = gcnb_wave_inclusive_scan(cn, lane), in_e = gcnb_wave_inclusive_scan(ce, lane);
+        __shared__ int s_wn[4], s_we[4];
+        if (lane == 63) { s_wn[wv] = in_n; s_we[wv] = in_e; }
+        __syncthreads();
+        int sn = in_n - cn, se = in_e - ce;
+        for (int w = 0; w < wv; w++) { sn += s_wn[w]; se += s_we[w]; }
+        if (r < ng) {
+            s_noff[r] = sn; s_eoff[r] = se;
+            s_nbase[r] = b.node_off[gph] - sn;
+            s_ebase[r] = b.edge_off[gph] - se;
+        }
+        ne = s_we[0] + s_we[1] + s_we[2] + s_we[3];
+        if (r == 0) { s_noff[ng] = s_wn[0] + s_wn[1] + s_wn[2] + s_wn[3]; s_eoff[ng] = ne; }
     }
+    if (ne > GCNR_EDGES) ne = GCNR_EDGES;  // cannot happen for a batch packed by flowgnn_set_batch; never overrun LDS
     s_cnt[r] = 0;
     s_cur[r] = 0;
     s_odeg[r] = 0;
     if (r == 0) s_cnt[256] = 0;
-    for (int i = r; i < GCNR_ROWS * ND_FEATURE; i += 256)  // the tile's node features, coalesced
-        s_feat[i] = i < rows * ND_FEATURE ? b.node_feature[(size_t)t0 * ND_FEATURE + i] : 0;
+    if (list == nullptr)
+        for (int i = r; i < GCNR_ROWS * ND_FEATURE; i += 256)  // the tile's node features, coalesced
+            s_feat[i] = i < rows * ND_FEATURE ? b.node_feature[(size_t)t0 * ND_FEATURE + i] : 0;
     __syncthreads();
+    if (list != nullptr && r < GCNR_ROWS) {  // (a list's rows are scattered over the batch: every row finds its graph, then its node)
+        int lo = 0, hi = ng - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (s_noff[mid] <= r) lo = mid; else hi = mid - 1;
+        }
+        const int* nf = b.node_feature + (size_t)(s_nbase[lo] + (r < rows ? r : 0)) * ND_FEATURE;
+#pragma unroll
+        for (int k = 0; k < ND_FEATURE; k++) s_feat[r * ND_FEATURE + k] = r < rows ? nf[k] : 0;
+    }
     unsigned ekey[EPT];  // (source row << 17) | (edge index inside the tile << 6) | edge code
     int edst[EPT];       // destination row, -1 = no edge
 #pragma unroll
@@ -416,13 +452,14 @@ __global__ __launch_bounds__(256) void gcn_tile_build_kernel(BatchView b, const 
         edst[k] = -1;
         ekey[k] = 0;
         if (i < ne) {
-            const int2 uv = reinterpret_cast<const int2*>(b.edge_list)[e0 + i];
-            const int a0 = b.edge_attr[3 * (size_t)(e0 + i)], a1 = b.edge_attr[3 * (size_t)(e0 + i) + 1], a2 = b.edge_attr[3 * (size_t)(e0 + i) + 2];
             int lo = 0, hi = ng - 1;  // the graph of edge i: the last one whose first edge is <= i
             while (lo < hi) {
                 const int mid = (lo + hi + 1) >> 1;
                 if (s_eoff[mid] <= i) lo = mid; else hi = mid - 1;
             }
+            const size_t ge = (size_t)(s_ebase[lo] + i);  // the edge's place in the caller's arrays
+            const int2 uv = reinterpret_cast<const int2*>(b.edge_list)[ge];
+            const int a0 = b.edge_attr[3 * ge], a1 = b.edge_attr[3 * ge + 1], a2 = b.edge_attr[3 * ge + 2];
             const int base = s_noff[lo], n = s_noff[lo + 1] - base;
             int u = uv.x, v = uv.y;
             if (!((u >= 0) & (u < n) & (v >= 0) & (v < n))) {  // flag it, then treat as a self-loop on node 0 (as build_csr does)
@@ -509,7 +546,8 @@ __global__ __launch_bounds__(GCNR_WAVES * 64, 3) void gcn_resident_kernel(const 
                                                                          const int* __restrict__ tile_row, const int* __restrict__ tile_graph,
                                                                          const int* __restrict__ node_off, float* __restrict__ out, int n_tiles,
                                                                          int* __restrict__ range_flag, int ablate_arg,
-                                                                         const uint8_t* __restrict__ desc, const float4* __restrict__ enc_tab) {
+                                                                         const uint8_t* __restrict__ desc, const float4* __restrict__ enc_tab,
+                                                                         const int* __restrict__ list, const int* __restrict__ lrow) {
     // ONEPASS (the default front end since round 5): no x0 / row_ptr / src / ecode / out_deg -- the tile's CSR slice, out-degrees and
     // encoder row numbers come from gcn_tile_build_kernel's descriptor, and the loader computes the tile's x_0 rows itself from the
     // pre-combined projected table (three 400-B rows per node out of L2 instead of one out of HBM that another launch wrote).
@@ -724,7 +762,7 @@ __global__ __launch_bounds__(GCNR_WAVES * 64, 3) void gcn_resident_kernel(const 
         for (int mk = 1; mk < 64; mk <<= 1) trips = max(trips, __shfl_xor(trips, mk, 64));
         trips = __builtin_amdgcn_readfirstlane(trips);
         const int ro_gi = g0 + tid;
-        int ro_n0 = 0, ro_n1 = 1;
+        int ro_n0 = 0, ro_n1 = 1, ro_g = 0;
 #pragma unroll 1
         GCN_STAMP(0);  // tile set-up
         for (int l = 0; l < GCN_L; l++) {
@@ -867,7 +905,12 @@ __global__ __launch_bounds__(GCNR_WAVES * 64, 3) void gcn_resident_kernel(const 
             if (l == GCN_L - 1) {
                 // the readout's node range of "this lane's graph": requested here, a BatchNorm ahead of its use, and consumed BEFORE the
                 // next tile's rows are requested (below) -- behind them, its vmcnt wait would also wait for that whole transfer
-                if (ro_gi < g1) { ro_n0 = node_off[ro_gi]; ro_n1 = node_off[ro_gi + 1]; }
+                // (bin-packed tiles, ONEPASS only: ro_gi is a position in the tile list -- the graph's id and its first row inside the tile)
+                if (ro_gi < g1) {
+                    ro_g = list ? list[ro_gi] : ro_gi;
+                    ro_n0 = node_off[ro_g]; ro_n1 = node_off[ro_g + 1];
+                    if (list) { const int lr0 = lrow[ro_gi]; ro_n1 = lr0 + t0 + (ro_n1 - ro_n0); ro_n0 = lr0 + t0; }
+                }
                 // no ReLU after the last BatchNorm; the readout's linear head per node (mean_v(a[v]) . w = mean_v(a[v] . w),
                 // finalize.cc:79-113): 25 terms in the lane, then the node's 4 lanes
                 float part = 0.0f;
@@ -964,13 +1007,13 @@ __global__ __launch_bounds__(GCNR_WAVES * 64, 3) void gcn_resident_kernel(const 
         // walks (the registers of the walk and the BatchNorm are free now), and are stored behind the barrier
         if (ONEPASS) x0_request(0, XH);  // (unconditional: behind the last tile the numbers are that tile's own again -- valid rows, never stored)
         __syncthreads();  // the per-node readout terms are in s_dot; the rows and the table are dead
-        asm volatile("" : "+v"(epre0), "+v"(epre1), "+v"(rpre), "+v"(dpre), "+v"(ro_n0), "+v"(ro_n1));  // (see the prologue)
+        asm volatile("" : "+v"(epre0), "+v"(epre1), "+v"(rpre), "+v"(dpre), "+v"(ro_n0), "+v"(ro_n1), "+v"(ro_g));  // (see the prologue)
         if (has_next) issue_rows(nt0, nrows);
         if (ONEPASS) {
             x0_store(nrows, 0, XH);  // (nrows = 0 behind the last tile)
             x0_request(XH, XK);  // the second half travels under the readout, the CSR staging and the row sort of the next tile
         }
-        if (ro_gi < g1) out[ro_gi] = lds_sum_in_order(s_dot + (ro_n0 - t0), ro_n1 - ro_n0) / (float)(ro_n1 - ro_n0) + pool_bias;
+        if (ro_gi < g1) out[ro_g] = lds_sum_in_order(s_dot + (ro_n0 - t0), ro_n1 - ro_n0) / (float)(ro_n1 - ro_n0) + pool_bias;
         if (!has_next) break;
         tile = ntile; t0 = nt0; rows = nrows; g0 = ng0; g1 = ng1; e0 = ne0; ne = nne;
         GCN_STAMP(6);  // last layer's tail, readout, next tile's requests
@@ -1196,6 +1239,7 @@ public:
     // three-launch front end (index build, projected encoder, resident kernel)
     bool one_pass(const DeviceBatch& db) const { return tile_build_ && use_resident(db) && db.b.edge_attr != nullptr; }
     bool needs_csr(const DeviceBatch& db) const override { return !one_pass(db); }
+    bool wants_packed_tile_lists() const override { return binpack_ && tile_build_ && resident_ && !qmode_ && num_tasks_ == 1; }
 
     int forward(DeviceBatch& db, Profiler& prof, hipStream_t s) override {
         const int n = db.b.n_tot;
@@ -1206,18 +1250,23 @@ public:
         if (use_resident(db)) {
             const int grid = db.gtiles.n_tiles < 256 ? db.gtiles.n_tiles : 256;  // persistent: one 12-wave workgroup per CU (153 KB of LDS)
             if (one_pass(db)) {  // two launches: descriptors from the caller's arrays, then everything else (no CSR, no x_0 in HBM)
-                if (int rc = desc_.reserve(((size_t)db.gtiles.n_tiles * GCND_BYTES + 3) / 4)) return rc;
+                // bin-packed tile lists when flowgnn_set_batch made them (option gcn_binpack): fewer, fuller tiles of the same graphs; a
+                // row's sums depend on the row alone, so the logits are the same bits
+                const bool bp = binpack_ && db.gtiles.bp_tiles > 0;
+                const int* t_row = bp ? db.gtiles.bp_row : db.gtiles.row_start;
+                const int* t_graph = bp ? db.gtiles.bp_graph : db.gtiles.graph_start;
+                const int n_tiles = bp ? db.gtiles.bp_tiles : db.gtiles.n_tiles;
+                if (int rc = desc_.reserve(((size_t)n_tiles * GCND_BYTES + 3) / 4)) return rc;
                 {
                     ProfScope p(prof, "gcn_tile_build", s);
-                    gcn_tile_build_kernel<<<db.gtiles.n_tiles, 256, 0, s>>>(db.b, db.gtiles.row_start, db.gtiles.graph_start,
-                                                                            reinterpret_cast<uint8_t*>(desc_.p), db.gtiles.n_tiles, db.csr.err);
+                    gcn_tile_build_kernel<<<n_tiles, 256, 0, s>>>(db.b, t_row, t_graph, reinterpret_cast<uint8_t*>(desc_.p), n_tiles, db.csr.err,
+                                                                  bp ? db.gtiles.bp_list : nullptr);
                 }
                 ProfScope p(prof, "gcn_resident", s);
-                gcn_resident_kernel<true><<<grid, GCNR_WAVES * 64, 0, s>>>(nullptr, nullptr, nullptr, nullptr, nullptr, d_res_, d_pw_, d_pb_,
-                                                                          db.gtiles.row_start, db.gtiles.graph_start, db.b.node_off, db.out,
-                                                                          db.gtiles.n_tiles, db.range_flag, ablate_,
-                                                                          reinterpret_cast<const uint8_t*>(desc_.p),
-                                                                          reinterpret_cast<const float4*>(d_enc_tab_));
+                gcn_resident_kernel<true><<<n_tiles < 256 ? n_tiles : 256, GCNR_WAVES * 64, 0, s>>>(
+                    nullptr, nullptr, nullptr, nullptr, nullptr, d_res_, d_pw_, d_pb_, t_row, t_graph, db.b.node_off, db.out, n_tiles, db.range_flag,
+                    ablate_, reinterpret_cast<const uint8_t*>(desc_.p), reinterpret_cast<const float4*>(d_enc_tab_), bp ? db.gtiles.bp_list : nullptr,
+                    bp ? db.gtiles.bp_lrow : nullptr);
             } else {
                 {
                     ProfScope p(prof, "gcn_encoder_projected", s);  // x_0 from the projected table (set_weights)
@@ -1226,7 +1275,7 @@ public:
                 ProfScope p(prof, "gcn_resident", s);
                 gcn_resident_kernel<false><<<grid, GCNR_WAVES * 64, 0, s>>>(db.h[0], db.csr.row_ptr, db.csr.src, db.csr.ecode, db.csr.out_deg, d_res_, d_pw_,
                                                                            d_pb_, db.gtiles.row_start, db.gtiles.graph_start, db.b.node_off, db.out,
-                                                                           db.gtiles.n_tiles, db.range_flag, ablate_, nullptr, nullptr);
+                                                                           db.gtiles.n_tiles, db.range_flag, ablate_, nullptr, nullptr, nullptr, nullptr);
             }
             agg_ready_ = false;
             db.final_h = 0;
@@ -1318,6 +1367,7 @@ public:
         fused_ = !o.on("gcn_unfused");
         resident_ = o.on("gcn_resident");
         tile_build_ = o.i("gcn_tile_build") != 0;
+        binpack_ = o.on("gcn_binpack");
         ablate_ = FG_ABLATE(o.i("gcn_ablate"));
         agg_ready_ = false;
     }
@@ -1359,6 +1409,7 @@ private:
     bool table_ok_ = true;             // the resident walk's scaled messages are exact for these weights (set_weights)
     std::vector<float> proj_max_src_;  // the projected table (host copy, for that check)
     bool x0_in_hbm_ = false;      // db.h[..] holds rows of the resident batch (false behind the one-pass front end and the fixed-point pass)
+    bool binpack_ = true;         // gcn_binpack: the one-pass resident path walks bin-packed tile lists (GraphTiles::bp_*)
     bool tile_build_ = true;      // gcn_tile_build = 0: index build + projected encoder as separate launches in front of the resident kernel
     int num_tasks_ = 1;  // NUM_TASK (GCN/src/dcl.h) as a run-time dimension
     GrowBuf esc_;

@@ -315,18 +315,25 @@ __global__ __launch_bounds__(256) void pna_tile_desc_kernel(const int* __restric
 // duplicate edge are equal terms, so their order among themselves is immaterial) -- and emits the row's source bytes: no sort at all.
 // An atomicOr that finds its bit set has found a duplicate edge: the copy goes to a list, and a row that has copies counts, per source,
 // how many (rare; a short scan).  Bit-identical to launch_build_csr + pna_tile_desc_kernel.
+// `list` (GraphTiles::bp_list, bin-packed tiles; null: tile t = the graphs tile_graph[t] .. and the batch's rows tile_row[t] ..): tile t =
+// the graphs list[tile_graph[t]] .., one behind the other, tile_row[t] its first row in the tile-ordered row space.  fidx (that row
+// space, 3 words per row): the row's nine encoder table rows offset_k + feature_k as bytes, validated here as atom_encoder_kernel
+// validates them -- what the resident kernel's loader reads instead of the caller's 36 B of node features (it cannot find a list's rows).
 __global__ __launch_bounds__(256) void pna_tile_build_kernel(BatchView b, const int* __restrict__ tile_row, const int* __restrict__ tile_graph,
-                                                             int n_tiles, uint8_t* __restrict__ desc, int* __restrict__ err) {
+                                                             int n_tiles, uint8_t* __restrict__ desc, int* __restrict__ err,
+                                                             const int* __restrict__ list, uint32_t* __restrict__ fidx) {
     __shared__ uint32_t s_adj[PNA_FT_ROWS][8];
     __shared__ int s_cnt[PNA_FT_ROWS], s_odeg[PNA_FT_ROWS], s_wsum[4], s_next;
     __shared__ uint16_t s_ext[PNA_FT_EDGES];  // copies of duplicate edges: destination << 8 | source
     __shared__ __attribute__((aligned(16))) uint8_t s_out[PNA_DESC_BYTES];
+    __shared__ int s_node[PNA_FT_ROWS];  // the batch's node behind every row of the tile
     const int tile = blockIdx.x, tid = threadIdx.x;
     if (tile >= n_tiles) return;
     const int t0 = tile_row[tile];
     int rows = tile_row[tile + 1] - t0;
     if (rows > PNA_FT_ROWS) rows = PNA_FT_ROWS;
     const int g0 = tile_graph[tile], g1 = tile_graph[tile + 1];
+    s_node[tid] = 0;
 #pragma unroll
     for (int i = 0; i < 8; i++) s_adj[tid][i] = 0u;
     s_cnt[tid] = 0;
@@ -334,8 +341,13 @@ __global__ __launch_bounds__(256) void pna_tile_build_kernel(BatchView b, const 
     if (tid == 0) s_next = 0;
     for (int i = tid; i < PNA_DESC_BYTES / 4; i += 256) reinterpret_cast<uint32_t*>(s_out)[i] = 0u;
     __syncthreads();
-    for (int gph = g0; gph < g1; gph++) {  // (a handful of graphs per tile; their headers are wave-uniform scalar loads)
-        const int n = b.nums_of_nodes[gph], base = b.node_off[gph] - t0, e0 = b.edge_off[gph], ne = b.edge_off[gph + 1] - e0;
+    int run = 0;
+    for (int gi = g0; gi < g1; gi++) {  // (a handful of graphs per tile; their headers are wave-uniform scalar loads)
+        const int gph = list ? list[gi] : gi;
+        const int n = b.nums_of_nodes[gph], first = b.node_off[gph], base = list ? run : first - t0, e0 = b.edge_off[gph], ne = b.edge_off[gph + 1] - e0;
+        run += n;
+        for (int k = tid; k < n; k += 256)
+            if (base + k < PNA_FT_ROWS) s_node[base + k] = first + k;
         for (int e = tid; e < ne; e += 256) {
             const int2 uv = reinterpret_cast<const int2*>(b.edge_list)[e0 + e];
             int u = uv.x, v = uv.y;
@@ -396,6 +408,23 @@ __global__ __launch_bounds__(256) void pna_tile_build_kernel(BatchView b, const 
                 }
             }
         }
+    }
+    if (fidx && tid < rows) {  // the row's nine encoder table rows (load_inputs.cc:133-179), as bytes
+        constexpr int off[ND_FEATURE] = {0, 119, 123, 135, 147, 157, 163, 169, 171};  // load_inputs.cc:5
+        constexpr int card[ND_FEATURE] = {119, 4, 12, 12, 10, 6, 6, 2, 2};            // host_load.cc:5
+        const int* nf = b.node_feature + (size_t)s_node[tid] * ND_FEATURE;
+        uint32_t fw[3] = {0u, 0u, 0u};
+#pragma unroll
+        for (int k = 0; k < ND_FEATURE; k++) {
+            int f = nf[k];
+            if (f < 0 || f >= card[k]) {
+                atomicMax(err, ERR_NODE_FEAT);
+                f = 0;
+            }
+            fw[k >> 2] |= (uint32_t)(off[k] + f) << (8 * (k & 3));
+        }
+        uint32_t* o = fidx + (size_t)(t0 + tid) * 3;
+        o[0] = fw[0]; o[1] = fw[1]; o[2] = fw[2];
     }
     __syncthreads();
     uint4* dst = reinterpret_cast<uint4*>(desc + (size_t)tile * PNA_DESC_BYTES);
@@ -749,7 +778,10 @@ __global__ __launch_bounds__(PNA_FT_WAVES * 64, 4) void pna_layer_fused_kernel(c
 // HBM traffic per tile: 36 B of node features per row, the 6 KiB descriptor (CSR slice + out-degrees), one logit per graph.
 // Same bits as the per-layer path (atom_encoder + 4 x pna_layer_fused + pool_mlp3): same operations in the same order.
 struct PnaResidentArgs {
-    const int* node_feature;   // [N][9]
+    const uint32_t* fidx;      // [rows][3]: nine encoder table rows per row as bytes, tile order (pna_tile_build_kernel), or null: ...
+    const int* node_feature;   // ... [N][9], the caller's features (batch-order tiles only)
+    const int* list;           // GraphTiles::bp_list / bp_lrow (bin-packed tiles), or null: tile t = the graphs tile_graph[t] ..
+    const int* lrow;
     const float* nemb;         // [173][80]
     const uint8_t* desc;       // pna_tile_build_kernel / pna_tile_desc_kernel
     const uint8_t* wpk;        // feature-major weight stream, 4 layers x 10 chunks
@@ -797,20 +829,30 @@ __global__ __launch_bounds__(PNA_FT_WAVES * 64, 4) void pna_resident_kernel(cons
                 const int item = (int)threadIdx.x + PNA_FT_WAVES * 64 * it;
                 const int row = item / PNA_C, c = item - row * PNA_C;
                 if (row < rows) {
-                    const int* nf = a.node_feature + (size_t)(t0 + row) * ND_FEATURE;
-                    int f[ND_FEATURE];
+                    int trow[ND_FEATURE];  // the nine table rows of this node
+                    if (a.fidx) {
+                        const uint32_t* fi = a.fidx + (size_t)(t0 + row) * 3;
+                        const uint32_t f0 = fi[0], f1 = fi[1], f2 = fi[2];
 #pragma unroll
-                    for (int k = 0; k < ND_FEATURE; k++) f[k] = nf[k];
+                        for (int k = 0; k < ND_FEATURE; k++) trow[k] = (int)(((k < 4 ? f0 : (k < 8 ? f1 : f2)) >> (8 * (k & 3))) & 0xFFu);
+                    } else {
+                        const int* nf = a.node_feature + (size_t)(t0 + row) * ND_FEATURE;
+                        int f[ND_FEATURE];
+#pragma unroll
+                        for (int k = 0; k < ND_FEATURE; k++) f[k] = nf[k];
+#pragma unroll
+                        for (int k = 0; k < ND_FEATURE; k++) {
+                            int fk = f[k];
+                            if (fk < 0 || fk >= card[k]) {
+                                atomicMax(a.err, ERR_NODE_FEAT);
+                                fk = 0;
+                            }
+                            trow[k] = off[k] + fk;
+                        }
+                    }
                     float4 w[ND_FEATURE];
 #pragma unroll
-                    for (int k = 0; k < ND_FEATURE; k++) {
-                        int fk = f[k];
-                        if (fk < 0 || fk >= card[k]) {
-                            atomicMax(a.err, ERR_NODE_FEAT);
-                            fk = 0;
-                        }
-                        w[k] = tab[(off[k] + fk) * PNA_C + c];
-                    }
+                    for (int k = 0; k < ND_FEATURE; k++) w[k] = tab[trow[k] * PNA_C + c];
                     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
                     for (int k = 0; k < ND_FEATURE; k++) { s.x += w[k].x; s.y += w[k].y; s.z += w[k].z; s.w += w[k].w; }
@@ -884,8 +926,10 @@ __global__ __launch_bounds__(PNA_FT_WAVES * 64, 4) void pna_resident_kernel(cons
             float* s_hg = reinterpret_cast<float*>(s_b) + wave * 128;  // [0, 80) pooled row, [80, 120) first hidden layer
             float* s_o1 = s_hg + PNA_D;
             const int half = lane >> 5, c = lane & 31;
-            for (int gi = g0 + wave; gi < g1; gi += PNA_FT_WAVES) {
-                const int n0 = a.node_off[gi] - t0, n1 = a.node_off[gi + 1] - t0;
+            for (int gp = g0 + wave; gp < g1; gp += PNA_FT_WAVES) {
+                // a range of graphs, or (bin-packed tiles) list positions: the graph's id and its first row inside the tile
+                const int gi = a.list ? a.list[gp] : gp;
+                const int n0 = a.list ? a.lrow[gp] : a.node_off[gi] - t0, n1 = n0 + (a.node_off[gi + 1] - a.node_off[gi]);
                 float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (c < PNA_C)
                     for (int v = n0 + half; v < n1; v += 2) {
@@ -1089,28 +1133,38 @@ public:
     // pna_tile_build=0 keeps the index build + pna_tile_desc_kernel in front of the resident kernel
     bool needs_csr(const DeviceBatch& db) const override { return !(tile_build_ && use_resident(db)); }
     void set_keep_h(bool on) override { keep_h_ = on; }
+    bool wants_packed_tile_lists() const override { return binpack_ && tile_build_ && resident_ && fused_ && !qmode_; }
 
     int forward_resident(DeviceBatch& db, Profiler& prof, hipStream_t s) {
-        if (int rc = desc_.reserve(((size_t)db.gtiles.n_tiles * PNA_DESC_BYTES + 3) / 4)) return rc;
+        // bin-packed tile lists when flowgnn_set_batch made them (option pna_binpack; tile-build path only): fewer, fuller tiles of the
+        // same graphs.  A row's aggregates and a graph's pooling depend on the row / the graph alone: the same bits.
+        const bool bp = binpack_ && tile_build_ && db.gtiles.bp_tiles > 0;
+        const int* t_row = bp ? db.gtiles.bp_row : db.gtiles.row_start;
+        const int* t_graph = bp ? db.gtiles.bp_graph : db.gtiles.graph_start;
+        const int n_tiles = bp ? db.gtiles.bp_tiles : db.gtiles.n_tiles;
+        if (int rc = desc_.reserve(((size_t)n_tiles * PNA_DESC_BYTES + 3) / 4)) return rc;
         if (tile_build_) {  // two launches per step: descriptors from the caller's arrays, then everything else (no CSR in HBM)
+            if (int rc = fidx_.reserve((size_t)db.b.n_tot * 3)) return rc;
             ProfScope p(prof, "pna_tile_build", s);
-            pna_tile_build_kernel<<<db.gtiles.n_tiles, 256, 0, s>>>(db.b, db.gtiles.row_start, db.gtiles.graph_start, db.gtiles.n_tiles,
-                                                                   reinterpret_cast<uint8_t*>(desc_.p), db.csr.err);
+            pna_tile_build_kernel<<<n_tiles, 256, 0, s>>>(db.b, t_row, t_graph, n_tiles, reinterpret_cast<uint8_t*>(desc_.p), db.csr.err,
+                                                          bp ? db.gtiles.bp_list : nullptr, reinterpret_cast<uint32_t*>(fidx_.p));
         } else {
             ProfScope p(prof, "pna_tile_desc", s);
-            pna_tile_desc_kernel<<<db.gtiles.n_tiles, 256, 0, s>>>(db.csr.row_ptr, db.csr.src, db.csr.out_deg, db.gtiles.row_start,
-                                                                  reinterpret_cast<uint8_t*>(desc_.p), db.gtiles.n_tiles);
+            pna_tile_desc_kernel<<<n_tiles, 256, 0, s>>>(db.csr.row_ptr, db.csr.src, db.csr.out_deg, t_row, reinterpret_cast<uint8_t*>(desc_.p), n_tiles);
         }
         PnaResidentArgs a;
+        a.fidx = tile_build_ ? reinterpret_cast<const uint32_t*>(fidx_.p) : nullptr;
+        a.list = bp ? db.gtiles.bp_list : nullptr;
+        a.lrow = bp ? db.gtiles.bp_lrow : nullptr;
         a.node_feature = db.b.node_feature; a.nemb = d_nemb_; a.desc = reinterpret_cast<const uint8_t*>(desc_.p);
         a.wpk = d_stream_; a.bias = d_cb_;
-        a.tile_row = db.gtiles.row_start; a.tile_graph = db.gtiles.graph_start; a.node_off = db.b.node_off;
+        a.tile_row = t_row; a.tile_graph = t_graph; a.node_off = db.b.node_off;
         a.w1t = d_w1t_; a.b1 = d_b1_; a.w2t = d_w2t_; a.b2 = d_b2_; a.w3 = d_w3_; a.b3 = d_b3_;
         a.out = db.out; a.range_flag = db.range_flag; a.err = db.csr.err;
         a.avg_deg = avg_deg_;
         for (int l = 0; l < PNA_L; l++) a.oscale[l] = oscale_[l];
-        a.n_tiles = db.gtiles.n_tiles;
-        const int grid = db.gtiles.n_tiles < 256 ? db.gtiles.n_tiles : 256;  // persistent: one 16-wave workgroup per CU
+        a.n_tiles = n_tiles;
+        const int grid = n_tiles < 256 ? n_tiles : 256;  // persistent: one 16-wave workgroup per CU
         {
             ProfScope p(prof, "pna_resident", s);
             pna_resident_kernel<<<grid, PNA_FT_WAVES * 64, 0, s>>>(a);
@@ -1185,6 +1239,7 @@ public:
         fused_ = o.on("pna_fused");
         resident_ = o.on("pna_resident");
         tile_build_ = o.on("pna_tile_build");
+        binpack_ = o.on("pna_binpack");
         ablate_ = FG_ABLATE(o.i("pna_ablate"));
     }
     void set_exact(bool on) override { exact_ = on; }
@@ -1241,6 +1296,7 @@ private:
         if (d_stream_) { (void)hipFree(d_stream_); d_stream_ = nullptr; }
         tiles_.release();
         desc_.release();
+        fidx_.release();
         q_.release();
     }
     bool ready_ = false;
@@ -1248,6 +1304,8 @@ private:
     QPack q_;
     GrowBufI tiles_;  // graph-aligned tile starts of the resident batch (tile_bounds_kernel)
     GrowBufI desc_;   // pna_tile_desc_kernel: 5.5 KiB per graph tile
+    GrowBufI fidx_;   // pna_tile_build_kernel: nine encoder table rows per node as bytes, tile order (12 B per node)
+    bool binpack_ = true;  // pna_binpack: the resident kernel walks bin-packed tile lists (GraphTiles::bp_*)
     static constexpr int kTileNominal = 112, kTileSlack = 48;  // the model's defaults of the options tile_nominal / tile_slack
     int tile_nominal_ = kTileNominal, tile_slack_ = kTileSlack;
     // pna_mfma=32 keeps the dense update on the fp32 matrix pipe (pna_dense_kernel)
