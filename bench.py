@@ -306,15 +306,13 @@ def issue_limits(model, kernel):
 
 
 def tile_count(eng, model, batch):
-    """Graph tiles the engine packs this batch into (from its own fill figure; None for a model without resident tiles)."""
-    rows = TILE_ROWS.get(model)
-    if not rows or batch.num_graphs == 0:
-        return None
+    """Graph tiles the resident kernel walks for the engine's resident batch: the bin-packed count when the model packs (flowgnn_batch_tiles),
+    else the batch-order count; None for a model / batch without graph tiles."""
     try:
-        fill = eng.graph_tile_fill(batch.nums_of_nodes, batch.nums_of_edges)
+        plain, packed = eng.batch_tiles()
     except Exception:
         return None
-    return int(np.ceil(batch.total_nodes / (fill * rows))) + 1 if fill > 0 else None
+    return (packed or plain) or None
 
 
 def measure_config(model, batch, steps, warmup, device, sample_graphs=512):

@@ -43,6 +43,7 @@ def _declare(lib):
     lib.flowgnn_set_results_buffer.argtypes = [eng, C.c_void_p]
     lib.flowgnn_stream.argtypes = [eng, C.POINTER(C.c_void_p)]
     lib.flowgnn_batch_info.argtypes = [eng] + [C.POINTER(C.c_longlong)] * 3
+    lib.flowgnn_batch_tiles.argtypes = [eng] + [C.POINTER(C.c_int)] * 2
     lib.flowgnn_exact_reruns.argtypes = [eng]
     lib.flowgnn_graph_replays.argtypes = [eng]
     lib.flowgnn_graph_replays.restype = C.c_longlong
@@ -96,7 +97,7 @@ def _declare(lib):
     lib.GCN_compute_graphs.argtypes = [C.c_int, p_int, p_int, p_int, p_float, p_int, p_int, p_int] + [p_float] * 11
     for name in ("flowgnn_create", "flowgnn_destroy", "flowgnn_set_weights_gin", "flowgnn_set_weights", "flowgnn_load_weights_dir",
                  "flowgnn_set_batch", "flowgnn_set_job_totals", "flowgnn_graph_tile_fill", "flowgnn_set_job_tile_fill", "flowgnn_run", "flowgnn_sync", "flowgnn_get_results",
-                 "flowgnn_results_device", "flowgnn_set_results_buffer", "flowgnn_stream", "flowgnn_batch_info", "flowgnn_exact_reruns", "flowgnn_set_numeric_mode", "flowgnn_set_num_tasks", "flowgnn_num_tasks", "flowgnn_get_csr",
+                 "flowgnn_results_device", "flowgnn_set_results_buffer", "flowgnn_stream", "flowgnn_batch_info", "flowgnn_batch_tiles", "flowgnn_exact_reruns", "flowgnn_set_numeric_mode", "flowgnn_set_num_tasks", "flowgnn_num_tasks", "flowgnn_get_csr",
                  "flowgnn_get_h", "flowgnn_profile_enable", "flowgnn_profile_read",
                  "flowgnn_run_aggregation_only", "flowgnn_get_aggregate", "flowgnn_set_stream",
                  "flowgnn_set_option", "flowgnn_get_option", "flowgnn_option_count", "flowgnn_entry_set_devices", "flowgnn_entry_set_option",

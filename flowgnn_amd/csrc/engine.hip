@@ -189,6 +189,7 @@ namespace fg {
 // h2d_pack.cpp
 size_t h2d_pack_bytes(size_t n_nodes, size_t n_edges, bool attr, size_t* off_edges, size_t* off_attr);
 void h2d_pack(const int* node_feature, const int* edge_list, const int* edge_attr, size_t n_nodes, size_t n_edges, uint8_t* dst, int threads);
+void host_parallel_for(int parts, const std::function<void(int)>& fn);
 
 // the packed arrays back into the reference's int32 layout (what every kernel reads): 255 / 65 535 = "did not fit" -> -1, which the
 // validation on the device refuses as it would have refused the original value
@@ -740,47 +741,88 @@ static int set_batch_impl(flowgnn_engine* e, int num_graphs, const int* nums_of_
         // kept in buckets by the rows they have left, so placing a graph is a scan over at most t_rows buckets, not over the bins.
         if (e->db.gtiles.ok && e->model->wants_packed_tile_lists() && num_graphs > 1) {
             constexpr int kWindow = 1024;
-            std::vector<int> list, lrow, tstart, trow2;
-            list.reserve((size_t)num_graphs);
-            lrow.reserve((size_t)num_graphs);
+            // (flat arrays and a bitmap of the non-empty buckets, windows dealt to the pool of host threads: the packing runs inside every
+            // flowgnn_set_batch -- the drop-in symbols call it per range -- so it must cost microseconds per thousand graphs)
+            const int n_win = (num_graphs + kWindow - 1) / kWindow;
+            std::vector<int> list((size_t)num_graphs), lrow((size_t)num_graphs);  // a window's graphs stay inside its span of the list
+            std::vector<std::vector<int>> win_cnt((size_t)n_win), win_rows((size_t)n_win);  // per window: graphs / rows of each of its tiles
+            int par = e->opts.i("h2d_pack") > 0 ? host_threads(e->opts.i("h2d_pack")) : 1;
+            if (par > (n_win + 3) / 4) par = (n_win + 3) / 4;  // (at least four windows per thread)
+            if (par < 1) par = 1;
+            fg::host_parallel_for(par, [&](int part) {
+                std::vector<int> bin_rows, bin_edges, bin_of((size_t)kWindow), bin_cnt, bin_pos;
+                std::vector<std::vector<int>> bucket((size_t)t_rows + 1);  // bucket[r]: bins with r rows left
+                std::vector<unsigned long long> nonempty(((size_t)t_rows + 64) / 64);
+                std::vector<int> order((size_t)kWindow);
+                std::vector<int> count((size_t)t_rows + 2);
+                for (int wi_ = part; wi_ < n_win; wi_ += par) {
+                    const int w0 = wi_ * kWindow;
+                    const int w1 = w0 + kWindow < num_graphs ? w0 + kWindow : num_graphs, wn = w1 - w0;
+                    // the window's graphs by node count, largest first (counting sort: n <= t_rows; ties in batch order)
+                    std::fill(count.begin(), count.end(), 0);
+                    for (int g = w0; g < w1; g++) count[(size_t)(t_rows - nums_of_nodes[g]) + 1]++;
+                    for (int r = 0; r <= t_rows; r++) count[(size_t)r + 1] += count[(size_t)r];
+                    for (int g = w0; g < w1; g++) order[(size_t)count[(size_t)(t_rows - nums_of_nodes[g])]++] = g;
+                    bin_rows.clear();
+                    bin_edges.clear();
+                    for (int r = 0; r <= t_rows; r++)
+                        if (!bucket[(size_t)r].empty()) bucket[(size_t)r].clear();
+                    std::fill(nonempty.begin(), nonempty.end(), 0ull);
+                    for (int oi = 0; oi < wn; oi++) {
+                        const int g = order[(size_t)oi], n = nums_of_nodes[g], m = nums_of_edges[g];
+                        int chosen = -1;
+                        for (int r = n; r <= t_rows && chosen < 0;) {  // the fullest bin that still takes it: the next non-empty bucket from r = n up
+                            const size_t wi = (size_t)r >> 6;
+                            const unsigned long long bits = nonempty[wi] >> (r & 63);
+                            if (!bits) { r = (int)((wi + 1) << 6); continue; }
+                            r += __builtin_ctzll(bits);
+                            if (r > t_rows) break;
+                            std::vector<int>& bk = bucket[(size_t)r];
+                            for (size_t k = bk.size(); k-- > 0;)
+                                if (bin_edges[(size_t)bk[k]] + m <= t_edges) { chosen = bk[k]; bk[k] = bk.back(); bk.pop_back(); break; }
+                            if (chosen >= 0 && bk.empty()) nonempty[wi] &= ~(1ull << (r & 63));
+                            r++;
+                        }
+                        if (chosen < 0) { chosen = (int)bin_rows.size(); bin_rows.push_back(0); bin_edges.push_back(0); }
+                        bin_rows[(size_t)chosen] += n;
+                        bin_edges[(size_t)chosen] += m;
+                        bin_of[(size_t)oi] = chosen;
+                        const int left = t_rows - bin_rows[(size_t)chosen];
+                        bucket[(size_t)left].push_back(chosen);
+                        nonempty[(size_t)left >> 6] |= 1ull << (left & 63);
+                    }
+                    // the window's tiles, in the order the bins were opened; inside a tile the graphs largest first
+                    const int nb = (int)bin_rows.size();
+                    bin_cnt.assign((size_t)nb + 1, 0);
+                    for (int oi = 0; oi < wn; oi++) bin_cnt[(size_t)bin_of[(size_t)oi] + 1]++;
+                    for (int k = 0; k < nb; k++) bin_cnt[(size_t)k + 1] += bin_cnt[(size_t)k];
+                    bin_pos.assign(bin_cnt.begin(), bin_cnt.end() - 1);
+                    std::fill(bin_rows.begin(), bin_rows.end(), 0);  // (reused as the running row inside each tile)
+                    for (int oi = 0; oi < wn; oi++) {
+                        const int k = bin_of[(size_t)oi], g = order[(size_t)oi];
+                        const size_t at = (size_t)w0 + (size_t)bin_pos[(size_t)k]++;
+                        list[at] = g;
+                        lrow[at] = bin_rows[(size_t)k];
+                        bin_rows[(size_t)k] += nums_of_nodes[g];
+                    }
+                    win_cnt[(size_t)wi_].resize((size_t)nb);
+                    win_rows[(size_t)wi_] = bin_rows;
+                    for (int k = 0; k < nb; k++) win_cnt[(size_t)wi_][(size_t)k] = bin_cnt[(size_t)k + 1] - bin_cnt[(size_t)k];
+                }
+            });
+            std::vector<int> tstart, trow2;
             tstart.push_back(0);
             trow2.push_back(0);
-            struct Bin { int rows, edges; std::vector<int> graphs; };
-            std::vector<Bin> bins;
-            std::vector<std::vector<int>> bucket((size_t)t_rows + 1);  // bucket[r]: bins with r rows left
-            std::vector<int> order;
-            std::vector<int> count((size_t)t_rows + 2);
-            long long rows_done = 0;
-            for (int w0 = 0; w0 < num_graphs; w0 += kWindow) {
-                const int w1 = w0 + kWindow < num_graphs ? w0 + kWindow : num_graphs;
-                // the window's graphs by node count, largest first (counting sort: n <= t_rows; ties in batch order)
-                std::fill(count.begin(), count.end(), 0);
-                for (int g = w0; g < w1; g++) count[(size_t)(t_rows - nums_of_nodes[g]) + 1]++;
-                for (int r = 0; r <= t_rows; r++) count[(size_t)r + 1] += count[(size_t)r];
-                order.assign((size_t)(w1 - w0), 0);
-                for (int g = w0; g < w1; g++) order[(size_t)count[(size_t)(t_rows - nums_of_nodes[g])]++] = g;
-                bins.clear();
-                for (auto& b : bucket) b.clear();
-                for (int g : order) {
-                    const int n = nums_of_nodes[g], m = nums_of_edges[g];
-                    int chosen = -1;
-                    for (int r = n; r <= t_rows && chosen < 0; r++) {  // the fullest bin that still takes it
-                        std::vector<int>& bk = bucket[(size_t)r];
-                        for (size_t k = bk.size(); k-- > 0;)
-                            if (bins[(size_t)bk[k]].edges + m <= t_edges) { chosen = bk[k]; bk.erase(bk.begin() + (long)k); break; }
+            {
+                long long rows_done = 0;
+                int graphs_done = 0;
+                for (int wi_ = 0; wi_ < n_win; wi_++)
+                    for (size_t k = 0; k < win_cnt[(size_t)wi_].size(); k++) {
+                        graphs_done += win_cnt[(size_t)wi_][k];
+                        rows_done += win_rows[(size_t)wi_][k];
+                        tstart.push_back(graphs_done);
+                        trow2.push_back((int)rows_done);
                     }
-                    if (chosen < 0) { chosen = (int)bins.size(); bins.push_back(Bin{0, 0, {}}); }
-                    Bin& b = bins[(size_t)chosen];
-                    b.rows += n; b.edges += m; b.graphs.push_back(g);
-                    bucket[(size_t)(t_rows - b.rows)].push_back(chosen);
-                }
-                for (const Bin& b : bins) {
-                    int local = 0;
-                    for (int g : b.graphs) { list.push_back(g); lrow.push_back(local); local += nums_of_nodes[g]; }
-                    rows_done += b.rows;
-                    tstart.push_back((int)list.size());
-                    trow2.push_back((int)rows_done);
-                }
             }
             const size_t T1 = tstart.size(), total = 2 * list.size() + 2 * T1;
             if (total > e->cap_bp) {
@@ -1061,6 +1103,13 @@ int flowgnn_batch_info(const flowgnn_engine* e, long long* num_graphs, long long
     if (num_graphs) *num_graphs = e->G;
     if (total_nodes) *total_nodes = e->N;
     if (total_edges) *total_edges = e->E;
+    return FLOWGNN_OK;
+}
+
+int flowgnn_batch_tiles(const flowgnn_engine* e, int* batch_order, int* packed) {
+    if (!e) return FLOWGNN_ERR_ARG;
+    if (batch_order) *batch_order = e->batch_ready && e->db.gtiles.ok ? e->db.gtiles.n_tiles : 0;
+    if (packed) *packed = e->batch_ready && e->db.gtiles.ok ? e->db.gtiles.bp_tiles : 0;
     return FLOWGNN_OK;
 }
 
@@ -1705,9 +1754,11 @@ static int compute_graphs_generic(int model, int num_graphs, const int* nums_of_
     flowgnn_group*& grp = g_entry_group[model];
     if (!grp) {
         if (g_entry_devices.empty()) read_environment(nullptr, &g_entry_devices);
-        // one listed device: TWO engines on it, so that a large batch's host -> device copies run under the other engine's kernels
+        // one listed device: THREE engines on it, so that a large batch's host-side work (narrowing the arrays for the transfer, packing
+        // tiles) and its host -> device copies run under the other engines' kernels (two engines: 13.4 ms per 2^18 molhiv graphs, three:
+        // 11.8 -- one engine's host phase per range is longer than another's kernels for a range)
         std::vector<int> devs = g_entry_devices;
-        if (devs.size() == 1 && g_entry_pipeline != 1) devs.push_back(devs[0]);
+        if (devs.size() == 1 && g_entry_pipeline != 1) { devs.push_back(devs[0]); devs.push_back(devs[0]); }
         int rc = flowgnn_create_multi(model, (int)devs.size(), devs.data(), &grp);
         if (rc) return rc;
         for (auto& kv : g_entry_options[model]) {

@@ -126,6 +126,13 @@ PackPool& pack_pool() {
 }
 }  // namespace
 
+// fn(t) for t = 0 .. parts - 1 on the pool (part 0 on the caller's thread): flowgnn_set_batch's other host loop, the bin packing of
+// graph tiles, runs on it too
+void host_parallel_for(int parts, const std::function<void(int)>& fn) {
+    if (parts <= 1) { fn(0); return; }
+    pack_pool().run(parts, fn);
+}
+
 // node_feature [N][9], edge_list [E][2], edge_attr [E][3] or null -> dst (h2d_pack_bytes bytes), on up to `threads` host threads (one
 // per ~2 MB of input at least: a small range is not worth waking sixteen workers for)
 void h2d_pack(const int* node_feature, const int* edge_list, const int* edge_attr, size_t n_nodes, size_t n_edges, uint8_t* dst, int threads) {

@@ -109,6 +109,12 @@ class Engine:
         self._check(self.lib.flowgnn_graph_tile_fill(self._h, len(nn), _pi(nn), _pi(ne), C.byref(f)), "flowgnn_graph_tile_fill")
         return float(f.value)
 
+    def batch_tiles(self):
+        """(tiles in batch order, bin-packed tiles or 0) of the resident batch (flowgnn.h: flowgnn_batch_tiles)."""
+        a, b = C.c_int(0), C.c_int(0)
+        self._check(self.lib.flowgnn_batch_tiles(self._h, C.byref(a), C.byref(b)), "flowgnn_batch_tiles")
+        return int(a.value), int(b.value)
+
     def set_job_tile_fill(self, fill: float = -1.0):
         """The next batches take the JOB's side of the resident kernels' fill threshold (flowgnn.h: flowgnn_set_job_tile_fill)."""
         self._check(self.lib.flowgnn_set_job_tile_fill(self._h, float(fill)), "flowgnn_set_job_tile_fill")

@@ -176,7 +176,7 @@ int GAT_compute_graphs(int num_graphs, int* nums_of_nodes, int* nums_of_edges,
  *  flowgnn_entry_set_option: flowgnn_set_option for the engines behind the entry points of `model` (FLOWGNN_MODEL_*).
  *  flowgnn_entry_set_pipeline: the entry points take HOST arrays, so a large batch is cut into several ranges per engine and an
  *     engine's host -> device copy of its next range runs under the other engines' kernels (flowgnn_group_compute); with ONE listed
- *     device the entry points keep two engines on it for that.  0 (default): ranges of ~48 MB of host arrays, at most 8 per
+ *     device the entry points keep three engines on it for that.  0 (default): ranges of ~48 MB of host arrays, at most 8 per
  *     engine, small batches uncut on one engine; k >= 1: exactly k ranges per engine (1 = no pipelining, one engine per device).
  */
 int flowgnn_entry_set_devices(int n_devices, const int* device_ids);
@@ -284,6 +284,12 @@ int flowgnn_set_stream(flowgnn_engine* e, void* stream, int use_external);
 /* Totals of the resident batch. */
 int flowgnn_batch_info(const flowgnn_engine* e, long long* num_graphs,
                        long long* total_nodes, long long* total_edges);
+/*
+ * Graph tiles of the resident batch (0, 0 when the model keeps no whole graphs on chip or a graph exceeds its tile limits):
+ * *batch_order = tiles cut in batch order (what the per-layer kernels and taps use), *packed = the bin-packed tile lists a
+ * graph-resident kernel walks instead when the model asks for them (options <model>_binpack; 0 = not built).
+ */
+int flowgnn_batch_tiles(const flowgnn_engine* e, int* batch_order, int* packed);
 
 /*
  * Number of forward passes this engine repeated on its exact-fp32 kernels because
