@@ -30,8 +30,8 @@ KERNELS = {
     "GIN-VN": {"gin_resident": "gin_resident_kernel"},
     "GCN": {"gcn_resident": "gcn_resident_kernel"},
     "GAT": {"gat_resident": "gat_resident_kernel"},
-    "PNA": {"pna_layer_fused": "pna_layer_fused_kernel"},
-    "DGN": {"dgn_layer_fused": "dgn_layer_mfma_kernel"},
+    "PNA": {"pna_resident": "pna_resident_kernel", "pna_layer_fused": "pna_layer_fused_kernel"},
+    "DGN": {"dgn_resident": "dgn_resident_kernel", "dgn_layer_fused": "dgn_layer_mfma_kernel"},
 }
 
 
@@ -49,6 +49,7 @@ def parse(path):
         m = re.match(r"\s+(\S+)\s+dispatches=(\d+)\s+avg=([\d,\.]+)", line)
         if m and cur is not None:
             out[cur][m.group(1)] = float(m.group(3).replace(",", ""))
+            out[cur]["_dispatches"] = max(out[cur].get("_dispatches", 0), int(m.group(2)))
     return out
 
 
@@ -60,8 +61,9 @@ def main():
         b = parse(os.path.join(HERE, f"{tag}_{model}_pmc_SQ2.txt"))
         entry = {}
         for name, pat in kernels.items():
-            ka = next((v for k, v in a.items() if pat in k), None)
-            kb = next((v for k, v in b.items() if pat in k), None)
+            # the instance launched once per step (a kernel's other instances -- the aggregation probe's one-off input pass -- have fewer dispatches)
+            ka = max((v for k, v in a.items() if pat in k), key=lambda v: v.get("_dispatches", 0), default=None)
+            kb = max((v for k, v in b.items() if pat in k), key=lambda v: v.get("_dispatches", 0), default=None)
             if not ka:
                 continue
             clk = ka["GRBM_GUI_ACTIVE"] / 8.0
