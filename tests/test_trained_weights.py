@@ -188,3 +188,30 @@ def test_trained_weights_on_other_graph_shapes(model, shape, per_layer, oracle):
     elif 64.0 * max(hmax) < 6.0e4:
         assert reruns == 0, (model, shape, hmax)
     assert EXPECT_RERUN[(model, shape)] == (reruns > 0), (model, shape, reruns, hmax)
+
+
+def test_q_oracle_is_in_the_range_of_the_three_logits_the_reference_itself_produced(oracle):
+    """The only outputs of the reference's own code on record: SURVEY.md section 8(c) -- its eight GIN sources compiled against a throw-away
+    ap_fixed stand-in (not shipped, not allowed here) with the real GIN/*.bin weights gave -3.95898438 (19 nodes / 40 edges), -3.96875
+    (6 / 12) and -3.90429688 (25 / 52) on synthetic chain + ring molecules, all multiples of 2^-10.  The molecules' features were not
+    recorded, so this pins no bit: it checks that the fixed-point oracle, on chain + ring molecules of those sizes with the shipped
+    weights, produces multiples of 2^-10 in the same narrow band (a wrong weight offset, a transposed matrix or a missing ReLU moves
+    trained GIN logits by whole units)."""
+    from flowgnn_amd import graphpack as gp
+    w = trained("GIN")
+    recorded = {(19, 40): -3.95898438, (6, 12): -3.96875, (25, 52): -3.90429688}
+    got = []
+    for feat in ([0] * 9, [1] * 9, [5, 0, 4, 5, 3, 0, 2, 0, 0]):
+        for attr in ([0, 0, 0], [0, 0, 1]):
+            for (n, e), _ in recorded.items():
+                und = [(i, i + 1) for i in range(n - 1)] + [(0, n - 1)] + ([(0, n // 2)] if e // 2 - (n - 1) == 2 else [])
+                el = np.array([p for a, b in und for p in ((a, b), (b, a))], np.int32)
+                assert el.shape[0] == e
+                b = gp.GraphBatch(np.array([n], np.int32), np.array([e], np.int32), np.tile(np.array(feat, np.int32), (n, 1)), el,
+                                  np.tile(np.array(attr, np.int32), (e, 1)))
+                got.append(float(np.ravel(oracle.gin_forward_q(b, [w]))[0]))
+    got = np.array(got)
+    assert np.array_equal(got * 1024, np.round(got * 1024))  # Q6.10 patterns
+    lo, hi = min(recorded.values()), max(recorded.values())
+    assert got.min() > lo - 0.75 and got.max() < hi + 0.75, (got.min(), got.max())
+    assert abs(np.median(got) - np.median(list(recorded.values()))) < 0.5, np.median(got)
