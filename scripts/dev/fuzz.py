@@ -49,12 +49,12 @@ def rand_graph(rng):
 
 VARIANTS = {
     "GIN": [{"gin_tile_build": 1}, {"gin_tile_build": 0}, {"gin_resident": 0},
-            {"gin_resident": 0, "gin_unfused": 1}, {"gin_fold_readout": 0}, {"gin_head_fold": 0}, {"gin_resident_min_fill": 0}, {"hipgraph": 0}],
-    "GIN-VN": [{"gin_tile_build": 1}, {"gin_tile_build": 0}, {"gin_resident": 0}, {"gin_resident": 0, "gin_unfused": 1}, {"gin_resident_min_fill": 0}],
-    "GCN": [{"gcn_resident": 0}, {"gcn_resident": 0, "gcn_unfused": 1}, {"hipgraph": 0}, {"gcn_tile_build": 0}],
-    "GAT": [{"gat_resident": 0}, {"gat_fold_readout": 0}, {"hipgraph": 0}],
-    "PNA": [{"pna_fused": 0}, {"pna_resident": 0}, {"pna_tile_build": 0}, {"hipgraph": 0}],
-    "DGN": [{"dgn_fused": 0}, {"dgn_mfma_agg": 0}, {"dgn_resident": 2}, {"dgn_mfma_agg": 1, "dgn_resident": 0}, {"dgn_mfma_agg": 1, "dgn_resident": 0, "dgn_rowinfo_direct": 0}, {"dgn_mfma_agg": 1, "dgn_resident": 0, "dgn_fold_readout": 0}],
+            {"gin_resident": 0, "gin_unfused": 1}, {"gin_fold_readout": 0}, {"gin_head_fold": 0}, {"gin_resident_min_fill": 0}, {"hipgraph": 0}, {"gin_binpack": 0}, {"tile_balance": 0}],
+    "GIN-VN": [{"gin_tile_build": 1}, {"gin_tile_build": 0}, {"gin_resident": 0}, {"gin_resident": 0, "gin_unfused": 1}, {"gin_resident_min_fill": 0}, {"gin_binpack": 0}, {"tile_balance": 0}],
+    "GCN": [{"gcn_resident": 0}, {"gcn_resident": 0, "gcn_unfused": 1}, {"hipgraph": 0}, {"gcn_tile_build": 0}, {"gcn_binpack": 0}, {"tile_balance": 0}],
+    "GAT": [{"gat_resident": 0}, {"gat_fold_readout": 0}, {"hipgraph": 0}, {"tile_balance": 0}],
+    "PNA": [{"pna_fused": 0}, {"pna_resident": 0}, {"pna_tile_build": 0}, {"hipgraph": 0}, {"pna_binpack": 0}, {"pna_binpack": 0, "pna_tile_build": 0}, {"tile_balance": 0}],
+    "DGN": [{"dgn_fused": 0}, {"dgn_mfma_agg": 0}, {"dgn_resident": 2}, {"dgn_binpack": 0}, {"tile_balance": 0}, {"dgn_mfma_agg": 1, "dgn_resident": 0}, {"dgn_mfma_agg": 1, "dgn_resident": 0, "dgn_rowinfo_direct": 0}, {"dgn_mfma_agg": 1, "dgn_resident": 0, "dgn_fold_readout": 0}],
 }[model]
 
 e = Engine(model, 0)
