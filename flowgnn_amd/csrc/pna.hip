@@ -798,6 +798,13 @@ struct PnaResidentArgs {
     int n_tiles;
 };
 
+// development only (-DFLOWGNN_DEV -DPNAR_TIMING=<bits>, scripts/dev/variant.sh): TIMING variants that leave a phase out and compute wrong
+// results on purpose -- 1 no encoder (h_0 = 0), 2 no readout, 4 no gathers, 8 no MFMAs.  Never part of the shipped library.
+#if defined(FLOWGNN_DEV) && defined(PNAR_TIMING)
+#define PNAR_SKIP(bit) ((PNAR_TIMING & (bit)) != 0)
+#else
+#define PNAR_SKIP(bit) false
+#endif
 __global__ __launch_bounds__(PNA_FT_WAVES * 64, 4) void pna_resident_kernel(const PnaResidentArgs a) {
     __shared__ __attribute__((aligned(16))) char s_a[PNA_CHUNK];  // even K-steps
     __shared__ __attribute__((aligned(16))) char s_b[PNA_CHUNK];  // odd K-steps; the readout's scratch between two tiles
@@ -828,7 +835,8 @@ __global__ __launch_bounds__(PNA_FT_WAVES * 64, 4) void pna_resident_kernel(cons
             for (int it = 0; it < (PNA_FT_ROWS * PNA_C) / (PNA_FT_WAVES * 64); it++) {
                 const int item = (int)threadIdx.x + PNA_FT_WAVES * 64 * it;
                 const int row = item / PNA_C, c = item - row * PNA_C;
-                if (row < rows) {
+                if (row < rows && PNAR_SKIP(1)) *reinterpret_cast<float4*>(s_h + row * PNA_FT_STRIDE + 4 * c) = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (row < rows && !PNAR_SKIP(1)) {
                     int trow[ND_FEATURE];  // the nine table rows of this node
                     if (a.fidx) {
                         const uint32_t* fi = a.fidx + (size_t)(t0 + row) * 3;
@@ -867,7 +875,7 @@ __global__ __launch_bounds__(PNA_FT_WAVES * 64, 4) void pna_resident_kernel(cons
         const uint8_t* csrc = reinterpret_cast<const uint8_t*>(s_desc[buf]);
         const uint16_t* crp = reinterpret_cast<const uint16_t*>(s_desc[buf] + PNA_DESC_RP);
         const int e_base = valid ? (int)crp[r] : 0;
-        const int indeg = valid ? (int)crp[r + 1] - e_base : 0;
+        const int indeg = (valid && !PNAR_SKIP(4)) ? (int)crp[r + 1] - e_base : 0;
         const int wmask = pna_walk_mask(indeg);
         uint32_t srcw[4];  // the first 16 in-edges, one byte each (re-walked by every K-step of every layer)
 #pragma unroll
@@ -891,14 +899,14 @@ __global__ __launch_bounds__(PNA_FT_WAVES * 64, 4) void pna_resident_kernel(cons
             for (int ks = 0; ks < PNA_KS; ks += 2) {
                 pna_issue_chunk_asm(wl + (size_t)(ks + 1) * PNA_CHUNK, s_b, wave, lane);
                 if (!late) pna_gather_slice(s_h, csrc, srcw, e_base, indeg, wmask, 8 * ks + 2 * g, b_hi, b_lo, vmax);
-                pna_stream_mfma(s_a, lane, b_hi, b_lo, y);
+                if (!PNAR_SKIP(8)) pna_stream_mfma(s_a, lane, b_hi, b_lo, y); else y[0][0] += __builtin_bit_cast(float, b_hi.x ^ b_lo.y);
                 if (late) pna_gather_slice(s_h, csrc, srcw, e_base, indeg, wmask, 8 * (ks + 1) + 2 * g, b_hi, b_lo, vmax);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();
                 // chunk ks + 2 of this layer, or chunk 0 of the next one: the stream runs on across the layers
                 if (ks + 2 < PNA_KS || l + 1 < PNA_L) pna_issue_chunk_asm(wl + (size_t)(ks + 2) * PNA_CHUNK, s_a, wave, lane);
                 if (!late) pna_gather_slice(s_h, csrc, srcw, e_base, indeg, wmask, 8 * (ks + 1) + 2 * g, b_hi, b_lo, vmax);
-                pna_stream_mfma(s_b, lane, b_hi, b_lo, y);
+                if (!PNAR_SKIP(8)) pna_stream_mfma(s_b, lane, b_hi, b_lo, y); else y[0][0] += __builtin_bit_cast(float, b_hi.x ^ b_lo.y);
                 if (late && ks + 2 < PNA_KS) pna_gather_slice(s_h, csrc, srcw, e_base, indeg, wmask, 8 * (ks + 2) + 2 * g, b_hi, b_lo, vmax);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();
@@ -921,7 +929,9 @@ __global__ __launch_bounds__(PNA_FT_WAVES * 64, 4) void pna_resident_kernel(cons
             }
             __syncthreads();  // h' of every row is in place
         }
-        {   // ---- readout: one wave per graph of the tile (pool_mlp3_kernel's association)
+        if (PNAR_SKIP(2)) {
+            if (threadIdx.x == 0) a.out[a.list ? a.list[a.tile_graph[tile]] : a.tile_graph[tile]] = s_h[0];
+        } else {   // ---- readout: one wave per graph of the tile (pool_mlp3_kernel's association)
             const int g0 = a.tile_graph[tile], g1 = a.tile_graph[tile + 1];
             float* s_hg = reinterpret_cast<float*>(s_b) + wave * 128;  // [0, 80) pooled row, [80, 120) first hidden layer
             float* s_o1 = s_hg + PNA_D;
