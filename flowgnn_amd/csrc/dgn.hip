@@ -1326,7 +1326,11 @@ __global__ __launch_bounds__(512, 2) void dgn_resident_kernel(const DgnResidentA
                 a2.y = fabsf(__builtin_fmaf(-wsum_s, hv.y, pp.y) * inv_abs_s);
                 a2.z = fabsf(__builtin_fmaf(-wsum_s, hv.z, pp.z) * inv_abs_s);
                 a2.w = fabsf(__builtin_fmaf(-wsum_s, hv.w, pp.w) * inv_abs_s);
-                if (!real || !valid) { a1 = make_float4(0.f, 0.f, 0.f, 0.f); a2 = a1; }
+                // lanes that hold K-slot padding (K-step 6, g != 0) contribute zeros.  Rows beyond the tile's last need no mask: their
+                // adjacency bits, out-degree and sums are zero, so m1 = pp = 0 and a1 = a2 = +0 come out of the arithmetic above (with the
+                // mask spelled out for every K-step hipcc kept an exec-mask region and eight v_mov per K-step: others-per-MFMA is what
+                // this kernel is bound by, tools/coissue6.hip)
+                if (!real) { a1 = make_float4(0.f, 0.f, 0.f, 0.f); a2 = a1; }
                 ds_uint4_t b_hi, b_lo;
                 DS_SPLIT2(a1.x, a1.y, b_hi.x, b_lo.x);
                 DS_SPLIT2(a1.z, a1.w, b_hi.y, b_lo.y);
@@ -1364,8 +1368,11 @@ __global__ __launch_bounds__(512, 2) void dgn_resident_kernel(const DgnResidentA
             }
             // ---- epilogue: h' = h + relu(b + W0 a1 + W1 a2) in the registers (node_embedding.cc:176-181)
 #pragma unroll
+            // (only the padding columns 100 .. 111 of the last output tile are masked.  Rows beyond the tile's last are left to run: they
+            // are nobody's source -- no adjacency bit names them -- so what they hold only has to stay finite, and relu(bias) does; the
+            // readout pools the graphs' rows.  One v_cndmask per value less in six of seven tiles.)
             for (int t = 0; t < DGN_OT; t++) {
-                const bool on = valid && 16 * t + 4 * g < DGN_D;
+                const bool on = 16 * t + 4 * g < DGN_D;
                 const float4_t rr = acc[t] * oscale;
                 hreg[t] = (float4_t){on ? hreg[t].x + relu1(rr.x) : 0.f, on ? hreg[t].y + relu1(rr.y) : 0.f,
                                      on ? hreg[t].z + relu1(rr.z) : 0.f, on ? hreg[t].w + relu1(rr.w) : 0.f};
