@@ -1378,7 +1378,9 @@ __global__ __launch_bounds__(512, 2) void dgn_resident_kernel(const DgnResidentA
                                      on ? hreg[t].z + relu1(rr.z) : 0.f, on ? hreg[t].w + relu1(rr.w) : 0.f};
             }
             __syncthreads();  // every wave is done with the layer's s_ht
-            if (l + 1 < DGN_L) {
+            // (the graphs' rows only: a row beyond the tile's last keeps the zeros the loader wrote into its s_ht column -- its registers
+            // grow by relu(bias) per layer and are never read by anybody else, its column is read by every MFMA of the tile, beside zeros)
+            if (l + 1 < DGN_L && valid) {
 #pragma unroll
                 for (int t = 0; t < DGN_OT; t++) put_row_piece(4 * t + g, hreg[t]);  // (ordered before the next layer's reads by its K-step 0 barrier)
             }
