@@ -1489,8 +1489,10 @@ __device__ __forceinline__ void gr_layer(unsigned long long (&tacc)[6], char* bx
         GR_SB();
 #pragma unroll
         for (int nt = 0; nt < NT; nt++) {
-            // a = h[v] + m = fma(m * 2^-16, 2^16, h[v]): the scaled sums come back exactly (rows beyond the tile: m = +0 stays +0)
-            if (row[nt] < cur.rows) {
+            // a = h[v] + m = fma(m * 2^-16, 2^16, h[v]): the scaled sums come back exactly.  Rows beyond the tile's last are left to run
+            // (unmasked: no exec-mask region between the walk and the first MFMAs): their sums are +0, their self term is row 0's, what the
+            // layers make of it is stored in LDS rows no graph owns and is read by nobody
+            {
 #pragma unroll
                 for (int q = 0; q < 6; q++) {
                     bq[nt][4 * q + 0] = __builtin_fmaf(bq[nt][4 * q + 0], GR_MSG_UNSCALE, sx[nt][q].x); bq[nt][4 * q + 1] = __builtin_fmaf(bq[nt][4 * q + 1], GR_MSG_UNSCALE, sx[nt][q].y);
